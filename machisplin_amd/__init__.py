@@ -1,0 +1,14 @@
+"""machisplin_amd -- MI355X (gfx950) backend for MACHISPLIN's data-parallel hot path.
+
+The package holds only what the path needs: ``csrc/`` (hand-written HIP kernels and the
+C ABI of include/machisplin_hip.h, built into ``libmachisplin_hip.so``) and the host-side
+mirror of the reference's interface for the path (``Tps``/``interpolate``/``predict`` as
+``machisplin.mltps`` calls them, V73:442-930).  Importing the package needs neither a GPU
+nor the built library; every compute entry point does, and raises without them.
+"""
+from . import _lib
+from ._lib import MhsError, init
+from .raster import Geometry
+from .tps import Tps, interpolate
+
+__all__ = ["MhsError", "init", "Geometry", "Tps", "interpolate", "_lib"]

@@ -1,0 +1,129 @@
+"""ctypes binding of libmachisplin_hip.so (the C ABI declared in include/machisplin_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible when a compute entry point is reached, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmachisplin_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NUMERIC, ERR_ALLOC = range(6)
+F64, F32, I16 = 0, 1, 2
+GCV_FIELDS, GCV_CONVERGED = 0, 1
+
+
+class MhsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[mhs status {code}] {msg}")
+        self.code = code
+
+
+class Grid(C.Structure):
+    """struct mhs_grid"""
+    _fields_ = [("xmin", C.c_double), ("ymax", C.c_double), ("xres", C.c_double),
+                ("yres", C.c_double), ("nrow", C.c_int64), ("ncol", C.c_int64)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol include/machisplin_hip.h declares
+SIGNATURES = {
+    "mhs_last_error": (C.c_char_p, []),
+    "mhs_version": (C.c_char_p, []),
+    "mhs_init": (C.c_int, [C.c_int]),
+    "mhs_shutdown": (C.c_int, []),
+    "mhs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mhs_sync": (C.c_int, [_vp]),
+    "mhs_timer_start": (C.c_int, [_vp]),
+    "mhs_timer_stop": (C.c_int, [_vp, _dp]),
+    "mhs_tps_fit": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "mhs_tps_from_coef": (C.c_int, [_vp, _vp, _vp, _i64, C.c_double, _vp, _vp, C.POINTER(_vp)]),
+    "mhs_tps_size": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "mhs_tps_get": (C.c_int, [_vp, _vp, _vp, _vp, _dp, _vp, _vp, _dp, _dp]),
+    "mhs_tps_free": (C.c_int, [_vp]),
+    "mhs_tps_predict_grid": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp]),
+    "mhs_tps_predict_grid_dev": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "mhs_tps_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+_inited_device = None
+
+
+def _hip_runtimes_mapped():
+    libs = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    libs.add(line.split()[-1])
+    except OSError:
+        pass
+    return libs
+
+
+def load() -> C.CDLL:
+    """dlopen the library (once) and attach the prototypes.  No GPU needed."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C machisplin_amd/csrc`).  machisplin_amd has no CPU fallback.")
+        # torch ships its own libamdhip64 (same SONAME): import it first so this library
+        # binds to the runtime torch's allocator and streams live in.
+        import torch  # noqa: F401
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        mapped = _hip_runtimes_mapped()
+        if len(mapped) > 1:
+            raise ImportError(f"two HIP runtimes are mapped into this process: {sorted(mapped)}")
+        _lib = lib
+        return lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise MhsError(rc, load().mhs_last_error().decode(errors="replace"))
+
+
+def init(device: int | None = None) -> int:
+    """Select the GPU (default: LOCAL_RANK or 0) and bring the library up on it."""
+    global _inited_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _inited_device == device:
+        return device
+    check(lib.mhs_init(int(device)))
+    _inited_device = device
+    return device
+
+
+def lib() -> C.CDLL:
+    """The initialised library; raises MhsError(ERR_NODEVICE) without a gfx950 GPU."""
+    if _inited_device is None:
+        init()
+    return load()
+
+
+def ptr(a) -> int:
+    """Raw address of a numpy array (host) or torch tensor (host or device)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data

@@ -1,0 +1,81 @@
+// Internal declarations shared by the HIP translation units of libmachisplin_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "machisplin_hip.h"
+
+namespace mhs {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define MHS_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return mhs::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define MHS_REQUIRE(cond, msg)                                               \
+    do {                                                                     \
+        if (!(cond)) { mhs::set_error("%s: %s", __func__, msg); return MHS_ERR_INVALID; } \
+    } while (0)
+
+// log(m) table for m in [1,2): 2^LOG_TAB_BITS intervals, entry = {1/c_i, -log(1/c_i)}
+constexpr int LOG_TAB_BITS = 10;
+constexpr int LOG_TAB_N = 1 << LOG_TAB_BITS;
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    double2 *log_tab = nullptr;  // device, LOG_TAB_N entries
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 0;
+};
+Context &ctx();
+int require_ready();
+// _dev entry points launch on exactly the stream they are given; NULL is HIP's default
+// (null) stream, which is also torch's default stream.
+inline hipStream_t pick_stream(void *s) { return (hipStream_t)s; }
+
+// device buffer with RAII for temporaries inside one ABI call
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+    }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
+// one knot as the evaluation kernels read it (scalar loads, 32 B per knot):
+// scaled coordinates and the coefficient with fields' constants folded in,
+// cw = c_j * 0.5/(8 pi)  so that  sum_j cw_j * d2 * log(d2) = sum_j c_j phi(d2).
+struct Knot { double u, v, cw, pad; };
+
+}  // namespace mhs
+
+struct mhs_tps;
+namespace mhs {
+int upload_knots(mhs_tps *t);  // (re)build t->knots_dev from t->c / t->knots_uv
+}
+
+// fitted spline handle (opaque to callers)
+struct mhs_tps {
+    int64_t n = 0;
+    double lambda = 0, eff_df = 0, gcv = 0;
+    double center[2] = {0, 0}, scale[2] = {1, 1};
+    double d[3] = {0, 0, 0};
+    std::vector<double> c;        // n
+    std::vector<double> knots_uv; // n x 2 column-major, scaled
+    mhs::Knot *knots_dev = nullptr;
+};

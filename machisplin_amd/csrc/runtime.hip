@@ -1,0 +1,135 @@
+// Runtime of libmachisplin_hip.so: device selection, the library stream, error
+// reporting, constant tables and HIP-event timers.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "common.h"
+
+namespace mhs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MHS_ERR_NODEVICE
+         : e == hipErrorOutOfMemory ? MHS_ERR_ALLOC : MHS_ERR_HIP;
+}
+
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+int require_ready() {
+    if (!ctx().ready) {
+        set_error("mhs_init() has not been called (or failed): no gfx950 device selected");
+        return MHS_ERR_NODEVICE;
+    }
+    return MHS_OK;
+}
+
+// {1/c_i rounded to double, -log(that double)} with c_i the midpoint of
+// [1 + i/N, 1 + (i+1)/N).  log(m) = logc_i + log1p(m*invc_i - 1), |m*invc_i - 1| <= 2^-11.
+static void build_log_table(std::vector<double2> &tab) {
+    tab.resize(LOG_TAB_N);
+    for (int i = 0; i < LOG_TAB_N; ++i) {
+        long double c = 1.0L + ((long double)i + 0.5L) / (long double)LOG_TAB_N;
+        double invc = (double)(1.0L / c);
+        double logc = (double)(-logl((long double)invc));
+        tab[i] = make_double2(invc, logc);
+    }
+}
+
+}  // namespace mhs
+
+using namespace mhs;
+
+extern "C" {
+
+const char *mhs_last_error(void) { return g_err; }
+const char *mhs_version(void) { return "machisplin_hip 0.1 (gfx950)"; }
+
+int mhs_device_count(int *count) {
+    MHS_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__); }
+    *count = n;
+    return MHS_OK;
+}
+
+int mhs_init(int device) {
+    Context &c = ctx();
+    if (c.ready && c.device == device) return MHS_OK;
+    if (c.ready) mhs_shutdown();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error("mhs_init: no HIP device visible (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return MHS_ERR_NODEVICE;
+    }
+    MHS_REQUIRE(device >= 0 && device < n, "device index out of range");
+    MHS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MHS_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("mhs_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return MHS_ERR_NODEVICE;
+    }
+    c.n_cu = prop.multiProcessorCount;
+    MHS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    MHS_HIP(hipEventCreate(&c.ev0));
+    MHS_HIP(hipEventCreate(&c.ev1));
+    std::vector<double2> tab;
+    build_log_table(tab);
+    MHS_HIP(hipMalloc((void **)&c.log_tab, sizeof(double2) * LOG_TAB_N));
+    MHS_HIP(hipMemcpy(c.log_tab, tab.data(), sizeof(double2) * LOG_TAB_N, hipMemcpyHostToDevice));
+    c.device = device;
+    c.ready = true;
+    return MHS_OK;
+}
+
+int mhs_shutdown(void) {
+    Context &c = ctx();
+    if (!c.ready) return MHS_OK;
+    (void)hipStreamSynchronize(c.stream);
+    if (c.log_tab) (void)hipFree(c.log_tab);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c = Context();
+    return MHS_OK;
+}
+
+int mhs_sync(void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_HIP(hipStreamSynchronize(pick_stream(stream)));
+    return MHS_OK;
+}
+
+int mhs_timer_start(void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_HIP(hipEventRecord(ctx().ev0, pick_stream(stream)));
+    return MHS_OK;
+}
+
+int mhs_timer_stop(void *stream, double *elapsed_ms) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(elapsed_ms != nullptr, "elapsed_ms is NULL");
+    MHS_HIP(hipEventRecord(ctx().ev1, pick_stream(stream)));
+    MHS_HIP(hipEventSynchronize(ctx().ev1));
+    float ms = 0.f;
+    MHS_HIP(hipEventElapsedTime(&ms, ctx().ev0, ctx().ev1));
+    *elapsed_ms = (double)ms;
+    return MHS_OK;
+}
+
+}  // extern "C"

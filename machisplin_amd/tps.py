@@ -1,0 +1,113 @@
+"""Host-side mirror of the reference's TPS interface for the hot path.
+
+``Tps(x, Y)``            <-> ``fields::Tps(x, Y)``                    V73:722, V73:751
+``interpolate(geom, m)`` <-> ``terra::interpolate(terra::rast(rb), m)`` V73:726, V73:753
+``m.predict(xy)``        <-> ``predict(m, xy)`` (predict.Krig)
+
+All arithmetic runs in libmachisplin_hip.so (HIP, gfx950); this module only marshals
+arguments.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .raster import Geometry
+
+
+class Tps:
+    """Fitted thin-plate smoothing spline, the subset of fields' ``Krig`` object that
+    ``predict.Krig`` reads: ``c``, ``d``, ``lambda_``, ``knots`` (range-scaled),
+    ``center``/``scale`` (``$transform$x.center`` / ``$x.scale``), ``eff_df``, ``gcv``."""
+
+    def __init__(self, x, Y, lambda_: float | None = None, gcv_mode: str = "fields"):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("x must be an N x 2 matrix of (LONG, LAT)")
+        y = np.ascontiguousarray(np.asarray(Y, dtype=np.float64).reshape(-1))
+        if y.shape[0] != x.shape[0]:
+            raise ValueError("x and Y have different numbers of rows")
+        xy_cm = np.asfortranarray(x)  # column-major, as R hands it over
+        mode = {"fields": _lib.GCV_FIELDS, "converged": _lib.GCV_CONVERGED}[gcv_mode]
+        lam = math.nan if lambda_ is None else float(lambda_)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mhs_tps_fit(xy_cm.ctypes.data, y.ctypes.data, x.shape[0], lam, mode,
+                                          C.byref(h)))
+        self._h = h
+        self._pull()
+
+    @classmethod
+    def from_coef(cls, knots_uv, c, d, lambda_, center, scale) -> "Tps":
+        """Wrap coefficients captured elsewhere (e.g. a real fields::Tps object)."""
+        self = cls.__new__(cls)
+        kn = np.asfortranarray(np.asarray(knots_uv, dtype=np.float64))
+        c = np.ascontiguousarray(np.asarray(c, dtype=np.float64))
+        d = np.ascontiguousarray(np.asarray(d, dtype=np.float64))
+        ce = np.ascontiguousarray(np.asarray(center, dtype=np.float64))
+        sc = np.ascontiguousarray(np.asarray(scale, dtype=np.float64))
+        if kn.ndim != 2 or kn.shape[1] != 2 or c.shape != (kn.shape[0],) or d.shape != (3,):
+            raise ValueError("knots must be n x 2, c length n, d length 3")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mhs_tps_from_coef(kn.ctypes.data, c.ctypes.data, d.ctypes.data,
+                                                kn.shape[0], float(lambda_), ce.ctypes.data,
+                                                sc.ctypes.data, C.byref(h)))
+        self._h = h
+        self._pull()
+        return self
+
+    def _pull(self):
+        lib = _lib.lib()
+        n = C.c_int64()
+        _lib.check(lib.mhs_tps_size(self._h, C.byref(n)))
+        n = n.value
+        self.c = np.empty(n)
+        self.d = np.empty(3)
+        kn = np.empty((n, 2), order="F")
+        lam, edf, gcv = C.c_double(), C.c_double(), C.c_double()
+        self.center, self.scale = np.empty(2), np.empty(2)
+        _lib.check(lib.mhs_tps_get(self._h, self.c.ctypes.data, self.d.ctypes.data, kn.ctypes.data,
+                                   C.byref(lam), self.center.ctypes.data, self.scale.ctypes.data,
+                                   C.byref(edf), C.byref(gcv)))
+        self.knots = np.ascontiguousarray(kn)
+        self.lambda_, self.eff_df, self.gcv = lam.value, edf.value, gcv.value
+        self.n = n
+
+    def predict(self, xy) -> np.ndarray:
+        """predict(tps, xy) at arbitrary points (n x 2: LONG, LAT)."""
+        xy = np.asfortranarray(np.asarray(xy, dtype=np.float64).reshape(-1, 2))
+        out = np.empty(xy.shape[0])
+        _lib.check(_lib.lib().mhs_tps_predict_points(self._h, xy.ctypes.data, xy.shape[0],
+                                                     out.ctypes.data))
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and _lib._lib is not None:
+            _lib._lib.mhs_tps_free(h)
+            self._h = None
+
+
+def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None):
+    """terra::interpolate(geometry-only raster, tps): evaluate the spline at EVERY cell
+    centre of ``geom`` (or of the window (r0, r1, c0, c1)); no NA mask (V73:726,753).
+
+    Returns a float64 torch tensor on the GPU, shape (r1-r0, c1-c0), row-major from the
+    north-west cell.  ``out`` may be a pre-allocated 2-D device tensor (row stride = ld).
+    """
+    import torch
+    r0, r1, c0, c1 = window if window is not None else (0, geom.nrow, 0, geom.ncol)
+    dev = torch.device("cuda", _lib.init())
+    if out is None:
+        out = torch.empty((r1 - r0, c1 - c0), dtype=torch.float64, device=dev)
+    if out.dtype != torch.float64 or not out.is_cuda or out.dim() != 2 or out.stride(1) != 1:
+        raise ValueError("out must be a 2-D float64 device tensor with unit column stride")
+    if tuple(out.shape) != (r1 - r0, c1 - c0):
+        raise ValueError("out has the wrong shape for the window")
+    g = geom.c_struct()
+    s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().mhs_tps_predict_grid_dev(model._h, C.byref(g), r0, r1, c0, c1,
+                                                   out.data_ptr(), out.stride(0), s))
+    return out

@@ -1,0 +1,82 @@
+"""GPU parity: HIP thin-plate-spline evaluation (through the C ABI) vs the oracle's
+predict.Krig restatement, same coefficients, same cell centres."""
+import numpy as np
+import pytest
+
+from conftest import synth_stations
+from oracle import tps as otps
+
+pytestmark = pytest.mark.gpu
+
+# |sum_j c_j phi_j| suffers cancellation (sum|terms| / |sum| ~ 1e2..1e3), so the bound is
+# stated against the magnitude of the surface: 1e-10 of max|f| (north-star asks 1e-6).
+RTOL = 1e-10
+
+
+def _check(hip, n, nrow, ncol, seed, window=None, lam=None):
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, nrow, ncol)
+    xy, y = synth_stations(n, seed, g if n <= nrow * ncol else None)
+    m = otps.fit(xy, y, lam=lam)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    r0, r1, c0, c1 = window or (0, nrow, 0, ncol)
+    got = hip.interpolate(g, t, window=window).cpu().numpy()
+    want = otps.predict_grid(m, g.xmin, g.ymax, g.xres, g.yres, nrow, ncol, r0, r1, c0, c1)
+    assert got.shape == want.shape
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < RTOL, err
+    return m, t
+
+
+@pytest.mark.parametrize("n,nrow,ncol", [(12, 5, 7), (200, 48, 64), (813, 130, 257), (64, 1, 1)])
+def test_grid_matches_oracle(hip, n, nrow, ncol):
+    _check(hip, n, nrow, ncol, seed=n)
+
+
+def test_window_and_strided_output(hip):
+    import torch
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 300, 400)
+    xy, y = synth_stations(150, 3, g)
+    m = otps.fit(xy, y)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    full = hip.interpolate(g, t)
+    big = torch.full((300, 512), float("nan"), dtype=torch.float64, device=full.device)
+    win = (17, 203, 33, 390)
+    hip.interpolate(g, t, window=win, out=big[17:203, 33:390])
+    torch.cuda.synchronize()
+    assert torch.equal(big[17:203, 33:390], full[17:203, 33:390])  # same cells, same bits
+    assert torch.isnan(big[:, :33]).all() and torch.isnan(big[:17]).all()
+    assert torch.isnan(big[:, 390:]).all() and torch.isnan(big[203:]).all()
+
+
+def test_points_match_oracle_and_knot_coincidence(hip):
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 200, 200)
+    xy, y = synth_stations(300, 11, g)
+    m = otps.fit(xy, y)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    rng = np.random.default_rng(5)
+    pts = np.vstack([xy, np.column_stack([rng.uniform(-78.1, -77.7, 1000), rng.uniform(-5.3, -4.9, 1000)])])
+    got = t.predict(pts)  # first 300 points sit exactly on knots (r2 == 0)
+    want = otps.predict_points(m, pts)
+    assert np.abs(got - want).max() / np.abs(want).max() < RTOL
+
+
+def test_exactly_linear_residual_gives_plane(hip):
+    """G4 analytic KAT: c == 0 => the surface is the plane d0 + d1 u + d2 v."""
+    g = hip.Geometry(0.0, 10.0, 0.01, 0.01, 100, 120)
+    rng = np.random.default_rng(1)
+    kn = rng.uniform(0, 1, (50, 2))
+    t = hip.Tps.from_coef(kn, np.zeros(50), [1.5, -2.0, 0.25], 0.0, [0.0, 9.0], [1.2, 1.0])
+    got = hip.interpolate(g, t).cpu().numpy()
+    u = (g.x_from_col(np.arange(120)) - 0.0) / 1.2
+    v = (g.y_from_row(np.arange(100)) - 9.0) / 1.0
+    want = 1.5 - 2.0 * u[None, :] + 0.25 * v[:, None]
+    assert np.abs(got - want).max() < 1e-13
+
+
+def test_bad_arguments_are_rejected(hip):
+    g = hip.Geometry(0.0, 1.0, 0.1, 0.1, 10, 10)
+    t = hip.Tps.from_coef(np.random.rand(5, 2), np.zeros(5), [0, 0, 0], 0.0, [0, 0], [1, 1])
+    with pytest.raises(hip.MhsError):
+        hip.interpolate(g, t, window=(0, 11, 0, 10))
+    with pytest.raises(hip.MhsError):
+        hip.Tps.from_coef(np.random.rand(5, 2), np.zeros(5), [0, 0, 0], 0.0, [0, 0], [0, 1])
