@@ -96,6 +96,14 @@ MHS_API int mhs_timer_stop(void *stream, double *elapsed_ms);
  * GCV search run on the host.                                                   */
 MHS_API int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda,
                 int gcv_mode, mhs_tps **out);
+/* Host-only helper of the fit (no GPU needed; exported so the host logic is testable on
+ * a CPU box): given the tridiagonal form T = P'(Q2'KQ2)P (diag[m], offdiag[m-1]) and
+ * g = P'Q2'y, evaluate fields' GCV criterion / choose lambda (NaN => search, gcv_mode)
+ * and return q = (T + lambda I)^-1 g.  n_unique = m + 3; n_obs >= n_unique (replicates). */
+MHS_API int mhs_host_gcv_tridiag(const double *diag, const double *offdiag, const double *g,
+                                 int64_t m, int64_t n_unique, int64_t n_obs, double pure_ss,
+                                 double lambda, int gcv_mode, double *lambda_out,
+                                 double *gcv_out, double *eff_df_out, double *q_out);
 /* build a spline object from coefficients captured elsewhere (e.g. from a real
  * fields::Tps object: $c, $d, $knots (scaled), $transform$x.center/$x.scale)   */
 MHS_API int mhs_tps_from_coef(const double *knots_uv /* n x 2 column-major, scaled */,

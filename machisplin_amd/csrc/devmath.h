@@ -1,0 +1,64 @@
+// Device math shared by the TPS kernels: table-driven FP64 log for r^2 log r.
+#pragma once
+#include "common.h"
+
+namespace mhs {
+
+constexpr double LN2_D = 0.6931471805599453094;
+constexpr double LOG_BIAS_D = -1023.0 * 0.6931471805599453094;
+
+// returns log(d2) + 1023 ln2 for finite d2 >= 0 (d2 == 0 gives a finite value, so
+// d2 * log(d2) evaluates to 0 at a knot without a branch; fields floors d2 at 1e-20,
+// where d2 log d2 = -4.6e-19, far below one ulp of any non-trivial sum).
+// tab: LOG_TAB_N x {1/c_i, log c_i} (runtime.hip), normally staged in LDS.
+// r2 = 2^e m, m in [1,2): log m = log c_i + log1p(m/c_i - 1), |m/c_i - 1| <= 2^-11, cubic
+// log1p => absolute error < 2e-14.
+__device__ __forceinline__ double table_log_biased(double d2, const double2 *tab) {
+    const int hi = __double2hiint(d2);
+    const int lo = __double2loint(d2);
+    const unsigned e = (unsigned)hi >> 20;
+    const unsigned off = ((unsigned)hi >> (20 - LOG_TAB_BITS - 4)) & ((LOG_TAB_N - 1) << 4);
+    const double2 t = *(const double2 *)((const char *)tab + off);
+    const int mh = (hi & 0x000FFFFF) | 0x3FF00000;
+    const double m = __hiloint2double(mh, lo);
+    const double r = fma(m, t.x, -1.0);
+    const double q = fma(r, 1.0 / 3.0, -0.5);
+    const double r2 = r * r;
+    const double lp = fma(r2, q, r);
+    const double L = fma((double)(int)e, LN2_D, t.y);
+    return L + lp;
+}
+
+// d2 * log(d2), exactly 0 for d2 == 0
+__device__ __forceinline__ double r2logr2(double d2, const double2 *tab) {
+    return d2 * (table_log_biased(d2, tab) + LOG_BIAS_D);
+}
+
+__device__ __forceinline__ void stage_log_table(double2 *lds_tab, const double2 *gtab) {
+    for (int i = threadIdx.x; i < LOG_TAB_N; i += blockDim.x) lds_tab[i] = gtab[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// sum over a block of up to 1024 threads; result valid in every thread
+__device__ __forceinline__ double block_sum(double x, double *scratch /* >= 17 doubles in LDS */) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nw; ++i) s += scratch[i];
+        scratch[16] = s;
+    }
+    __syncthreads();
+    return scratch[16];
+}
+
+}  // namespace mhs

@@ -16,25 +16,9 @@
 #include <cmath>
 #include <cstring>
 #include "common.h"
+#include "devmath.h"
 
 namespace mhs {
-
-__device__ __forceinline__ double table_log(double d2, const double2 *tab) {
-    const double LN2 = 0.6931471805599453094;
-    const int hi = __double2hiint(d2);
-    const int lo = __double2loint(d2);
-    const int e = hi >> 20;  // biased exponent; the -1023 ln2 is folded into the caller's constant
-    const unsigned off = ((unsigned)hi >> (20 - LOG_TAB_BITS - 4)) & ((LOG_TAB_N - 1) << 4);
-    const double2 t = *(const double2 *)((const char *)tab + off);
-    const int mh = (hi & 0x000FFFFF) | 0x3FF00000;
-    const double m = __hiloint2double(mh, lo);
-    const double r = fma(m, t.x, -1.0);
-    const double q = fma(r, 1.0 / 3.0, -0.5);
-    const double r2 = r * r;
-    const double lp = fma(r2, q, r);
-    const double L = fma((double)e, LN2, t.y);
-    return L + lp;  // = log(d2) + 1023 ln2
-}
 
 constexpr int EVAL_ROWS = 4;       // rows per lane
 constexpr int EVAL_WAVES = 4;      // waves per block, stacked along rows
@@ -53,8 +37,7 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
     const Knot *__restrict__ knots, int n, const double2 *__restrict__ gtab, EvalGeom g,
     double *__restrict__ out) {
     __shared__ double2 tab[LOG_TAB_N];
-    for (int i = threadIdx.x; i < LOG_TAB_N; i += 64 * EVAL_WAVES) tab[i] = gtab[i];
-    __syncthreads();
+    stage_log_table(tab, gtab);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -73,7 +56,6 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
         acc[k] = 0.0;
     }
 
-    const double NEG_BIAS = -1023.0 * 0.6931471805599453094;
 #pragma unroll 2
     for (int j = 0; j < n; ++j) {
         const Knot kn = knots[j];
@@ -83,8 +65,7 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
         for (int k = 0; k < EVAL_ROWS; ++k) {
             const double dy = v[k] - kn.v;
             const double dd = fma(dy, dy, dx2);
-            const double L = table_log(dd, tab) + NEG_BIAS;
-            acc[k] = fma(kn.cw, dd * L, acc[k]);
+            acc[k] = fma(kn.cw, r2logr2(dd, tab), acc[k]);
         }
     }
 
@@ -101,20 +82,17 @@ __global__ __launch_bounds__(256) void tps_eval_points_kernel(
     const double *__restrict__ px, const double *__restrict__ py, int64_t npts,
     double *__restrict__ out) {
     __shared__ double2 tab[LOG_TAB_N];
-    for (int i = threadIdx.x; i < LOG_TAB_N; i += 256) tab[i] = gtab[i];
-    __syncthreads();
+    stage_log_table(tab, gtab);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t ii = i < npts ? i : npts - 1;
     const double u = (px[ii] - g.cx) / g.sx;
     const double v = (py[ii] - g.cy) / g.sy;
-    const double NEG_BIAS = -1023.0 * 0.6931471805599453094;
     double acc = 0.0;
     for (int j = 0; j < n; ++j) {
         const Knot kn = knots[j];
         const double dx = u - kn.u, dy = v - kn.v;
         const double dd = fma(dy, dy, dx * dx);
-        const double L = table_log(dd, tab) + NEG_BIAS;
-        acc = fma(kn.cw, dd * L, acc);
+        acc = fma(kn.cw, r2logr2(dd, tab), acc);
     }
     if (i < npts) out[i] = g.d0 + g.d1 * u + g.d2 * v + acc;
 }

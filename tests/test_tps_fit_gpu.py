@@ -1,0 +1,96 @@
+"""GPU parity: HIP fields::Tps fit (Gram, projection, tridiagonalisation / MFMA Cholesky,
+through the C ABI) vs the oracle's QR + eigen + GCV restatement on the same stations."""
+import numpy as np
+import pytest
+
+from conftest import synth_stations
+from oracle import tps as otps
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("n", [12, 70, 200, 813])
+def test_fixed_lambda_cholesky_path(hip, n):
+    xy, y = synth_stations(n, 100 + n)
+    lam = 3e-3
+    want = otps.fit(xy, y, lam=lam)
+    got = hip.Tps(xy, y, lambda_=lam)
+    assert got.n == n and got.lambda_ == lam
+    assert np.array_equal(got.knots, want["knots"])
+    assert np.array_equal(got.center, want["center"]) and np.array_equal(got.scale, want["scale"])
+    # fp64 tolerance: the SPD system has condition ~ e_max/lambda; 1e-8 on coefficients
+    assert _rel(got.c, want["c"]) < 1e-8
+    assert _rel(got.d, want["d"]) < 1e-8
+    rng = np.random.default_rng(n)
+    pts = np.column_stack([rng.uniform(-78, -76, 500), rng.uniform(-7, -5, 500)])
+    assert _rel(got.predict(pts), otps.predict_points(want, pts)) < 1e-9
+
+
+@pytest.mark.parametrize("n,mode", [(12, "fields"), (200, "fields"), (200, "converged"), (813, "fields")])
+def test_gcv_path(hip, n, mode):
+    xy, y = synth_stations(n, 200 + n)
+    want = otps.fit(xy, y, gcv_mode=mode)
+    got = hip.Tps(xy, y, gcv_mode=mode)
+    # 'fields' mode reproduces the same golden-section trajectory; 'converged' locates a flat
+    # minimum, so lambda itself only agrees to ~sqrt(eps)
+    assert abs(got.lambda_ - want["lambda"]) / want["lambda"] < (1e-8 if mode == "fields" else 1e-6)
+    assert abs(got.eff_df - want["eff_df"]) < 1e-5 * want["eff_df"]
+    assert abs(got.gcv - want["gcv"]) < 1e-9 * want["gcv"]
+    # compare surfaces at the GPU's lambda so the check is on the solve, not on the flat minimum
+    ref = otps.fit(xy, y, lam=got.lambda_)
+    assert _rel(got.c, ref["c"]) < 1e-8
+    assert _rel(got.d, ref["d"]) < 1e-8
+
+
+def test_replicates_are_collapsed(hip):
+    xy, y = synth_stations(150, 7)
+    xy2 = np.vstack([xy, xy[:9], xy[3:5]])
+    y2 = np.concatenate([y, y[:9] + 0.3, y[3:5] - 0.1])
+    want = otps.fit(xy2, y2)
+    got = hip.Tps(xy2, y2)
+    assert got.n == 150
+    assert abs(got.lambda_ - want["lambda"]) / want["lambda"] < 1e-8
+    ref = otps.fit(xy2, y2, lam=got.lambda_)
+    assert _rel(got.c, ref["c"]) < 1e-8 and _rel(got.d, ref["d"]) < 1e-8
+
+
+def test_exactly_linear_residual_gives_zero_c(hip):
+    """G4 KAT: y exactly linear in (x, y) => c = 0 and the surface is that plane."""
+    xy, _ = synth_stations(120, 9)
+    y = 2.0 + 0.5 * xy[:, 0] - 0.25 * xy[:, 1]
+    got = hip.Tps(xy, y, lambda_=1e-3)
+    assert np.abs(got.c).max() < 1e-9
+    assert np.abs(got.predict(xy) - y).max() < 1e-9
+
+
+def test_lambda_to_zero_interpolates(hip):
+    xy, y = synth_stations(90, 10)
+    got = hip.Tps(xy, y, lambda_=1e-10)
+    assert np.abs(got.predict(xy) - y).max() < 1e-5
+
+
+def test_degenerate_inputs_fail_loudly(hip):
+    x = np.linspace(0, 1, 30)
+    with pytest.raises(hip.MhsError):  # collinear
+        hip.Tps(np.column_stack([x, 2 * x + 1]), np.sin(x))
+    with pytest.raises(hip.MhsError):  # <= 3 distinct locations
+        hip.Tps(np.array([[0, 0], [1, 0], [0, 1], [0, 0.0]]), np.arange(4.0))
+    with pytest.raises(hip.MhsError):  # NaN row
+        hip.Tps(np.array([[0, 0], [1, 0], [0, 1], [1, np.nan], [2, 2]]), np.arange(5.0))
+
+
+def test_fit_then_grid_end_to_end(hip):
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 160, 200)
+    xy, y = synth_stations(400, 21, g)
+    want = otps.fit(xy, y)
+    got = hip.Tps(xy, y)
+    surf = hip.interpolate(g, got).cpu().numpy()
+    ref = otps.predict_grid(otps.fit(xy, y, lam=got.lambda_), g.xmin, g.ymax, g.xres, g.yres, 160, 200)
+    assert _rel(surf, ref) < 1e-8
+    # and against the oracle's own lambda: 1e-6 is the north-star bound
+    ref2 = otps.predict_grid(want, g.xmin, g.ymax, g.xres, g.yres, 160, 200)
+    assert _rel(surf, ref2) < 1e-6
