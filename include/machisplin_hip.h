@@ -126,6 +126,87 @@ MHS_API int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_
 /* predict(tps, xy): arbitrary points, xy n x 2 column-major (Step-5 station check) */
 MHS_API int mhs_tps_predict_points(const mhs_tps *t, const double *xy, int64_t n, double *out_host);
 
+/* ------------------------------------------------------- ensemble members --
+ * Loaders take the FLAT parameter arrays of the fitted R objects (the shim extracts
+ * them with REAL()/INTEGER()); the library copies them to the device.  p = number of
+ * predictors = covariate layers + 2 (rast_stack <- c(covar.ras, LONG, LAT), V73:138).  */
+
+/* mgcv::gam(resp ~ a+b+...) has no s() terms (V73:195,600): a linear model.
+ * coef[p+1], intercept first.  replaces terra::predict(rast_stack, gam) V73:604,606 */
+MHS_API int mhs_lm_load(const double *coef, int p, mhs_model **out);
+/* nnet::nnet(size, linout=TRUE) (V73:463): wts in nnet order -- per hidden unit its bias
+ * then p input weights, then output bias and `size` hidden->output weights.  The
+ * response un-scaling pred*max2.resp.f + min.resp.f (V73:469-470) is y_scale/y_shift.
+ * replaces terra::predict(rast_stack, nnet) V73:468,472                              */
+MHS_API int mhs_nnet_load(const double *wts, int p, int size, double y_scale, double y_shift,
+                          mhs_model **out);
+/* earth::earth (V73:539): selected terms only; dirs/cuts are nterms x p ROW-major
+ * (dirs: 0 unused, 1 max(0,x-cut), -1 max(0,cut-x), 2 linear).
+ * replaces terra::predict(rast_stack, earth) V73:543,545                              */
+MHS_API int mhs_earth_load(const double *coef, const int32_t *dirs, const double *cuts, int nterms,
+                           int p, mhs_model **out);
+/* kernlab::ksvm eps-svr, rbfdot, scaled=TRUE (V73:560): alpha[nsv] signed coefficients,
+ * sv nsv x p ROW-major support vectors in scaled coordinates, b, kpar$sigma,
+ * scaling$x.scale (center/scale, p each) and scaling$y.scale.
+ * replaces terra::predict(rast_stack, ksvm, na.rm=TRUE) V73:582,584                   */
+MHS_API int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, double b,
+                         double sigma, const double *x_center, const double *x_scale,
+                         double y_center, double y_scale, mhs_model **out);
+/* gbm object cut at n.trees = best.trees (V73:497): concatenated per-tree node arrays
+ * (SplitVar 0-based / -1 terminal, SplitCodePred, LeftNode, RightNode, MissingNode; child
+ * indices tree-local), tree t owns nodes tree_offsets[t] .. tree_offsets[t+1]-1.
+ * replaces terra::predict(rast_stack, gbm, n.trees=, type="response") V73:497,499     */
+MHS_API int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets,
+                         const int32_t *split_var, const double *split_val, const int32_t *left,
+                         const int32_t *right, const int32_t *missing, int p, mhs_model **out);
+/* randomForest regression $forest (V73:517): per-tree columns concatenated
+ * (leftDaughter/rightDaughter 1-based tree-local, nodestatus -1 terminal, bestvar
+ * 1-based, xbestsplit, nodepred).
+ * replaces terra::predict(rast_stack, randomForest, type="response", ...) V73:521,523 */
+MHS_API int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *left,
+                        const int32_t *right, const int32_t *status, const int32_t *best_var,
+                        const double *split, const double *node_pred, int p, mhs_model **out);
+MHS_API int mhs_model_free(mhs_model *m);
+
+/* the covariate layers of rast_stack, planar; LONG and LAT are generated from the grid */
+typedef struct mhs_stack {
+    const void *data;     /* layer k at data + k*plane_stride elements, row-major            */
+    int32_t n_layers;     /* C = p - 2                                                       */
+    int32_t dtype;        /* MHS_F64 / MHS_F32 / MHS_I16                                     */
+    int64_t plane_stride; /* elements between layers                                         */
+    int64_t ld;           /* elements between rows (>= ncol of the grid)                     */
+    double nodata;        /* value that means NA (e.g. -32768 for INT2S); NaN = none.  NaN   */
+                          /* cells are always NA                                             */
+} mhs_stack;
+
+/* terra::predict(rast_stack, model) over the window [r0,r1) x [c0,c1) of grid g:
+ *   accumulate == 0:  out  = pred * weight       (V73:475,499,523,545,584,606)
+ *   accumulate != 0:  out += pred * weight       (V73:471,498,522,544,583,605)
+ * `covars` describes DEVICE planes covering the whole grid g; out is (r1-r0) x ld.      */
+MHS_API int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_stack *covars,
+                            int64_t r0, int64_t r1, int64_t c0, int64_t c1, double weight,
+                            int accumulate, double *out_dev, int64_t ld, void *stream);
+/* the whole Step-2 raster loop V73:447-619: out = (((p1 w1) + p2 w2) + ...) / wt_total,
+ * models in mods.run order, weights = the rounded kept weights, wt_total = the
+ * unrounded OptX.mfit.wt.tot (V73:337).                                                  */
+MHS_API int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weights,
+                                     int n_models, double wt_total, const mhs_grid *g,
+                                     const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0,
+                                     int64_t c1, double *out_dev, int64_t ld, void *stream);
+/* same, host pointers (covars->data and out on the host) */
+MHS_API int mhs_ensemble_predict(const mhs_model *const *models, const double *weights,
+                                 int n_models, double wt_total, const mhs_grid *g,
+                                 const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0,
+                                 int64_t c1, double *out_host);
+/* predict(model, data.frame): X is n x p COLUMN-major (all p predictors given, LONG and
+ * LAT included), out[n].  Station residuals V73:477-482,501-505,...                     */
+MHS_API int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *out_host);
+
+/* out = a / divisor (b == NULL) or a / divisor + b: pred.elev / wt.tot (V73:619) and the
+ * Step-5 sum pred + TPS (V73:906-907); NaN if either is NaN.  n elements, device. */
+MHS_API int mhs_scale_add_dev(const double *a, double divisor, const double *b, double *out,
+                              int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

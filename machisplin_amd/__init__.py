@@ -8,7 +8,10 @@ nor the built library; every compute entry point does, and raises without them.
 """
 from . import _lib
 from ._lib import MhsError, init
-from .raster import Geometry
+from .raster import Geometry, RasterStack
+from . import models
+from .models import predict, ensemble_predict
 from .tps import Tps, interpolate
 
-__all__ = ["MhsError", "init", "Geometry", "Tps", "interpolate", "_lib"]
+__all__ = ["MhsError", "init", "Geometry", "RasterStack", "Tps", "interpolate", "predict",
+           "ensemble_predict", "models", "_lib"]

@@ -29,6 +29,12 @@ class Grid(C.Structure):
                 ("yres", C.c_double), ("nrow", C.c_int64), ("ncol", C.c_int64)]
 
 
+class Stack(C.Structure):
+    """struct mhs_stack"""
+    _fields_ = [("data", C.c_void_p), ("n_layers", C.c_int32), ("dtype", C.c_int32),
+                ("plane_stride", C.c_int64), ("ld", C.c_int64), ("nodata", C.c_double)]
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -53,6 +59,22 @@ SIGNATURES = {
     "mhs_tps_predict_grid": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp]),
     "mhs_tps_predict_grid_dev": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "mhs_tps_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mhs_lm_load": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "mhs_nnet_load": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(_vp)]),
+    "mhs_earth_load": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "mhs_svr_load": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_double, C.c_double, _vp, _vp, C.c_double,
+                               C.c_double, C.POINTER(_vp)]),
+    "mhs_gbm_load": (C.c_int, [C.c_double, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "mhs_rf_load": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "mhs_model_free": (C.c_int, [_vp]),
+    "mhs_predict_dev": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Stack), _i64, _i64, _i64, _i64,
+                                  C.c_double, C.c_int, _vp, _i64, _vp]),
+    "mhs_ensemble_predict_dev": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),
+                                           C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "mhs_ensemble_predict": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),
+                                       C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp]),
+    "mhs_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mhs_scale_add_dev": (C.c_int, [_vp, C.c_double, _vp, _vp, _i64, _vp]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,743 @@
+// Per-cell evaluation of the six ensemble members on gfx950 and their weighted sum:
+// the terra::predict(rast_stack, model) loop of machisplin.mltps Step 2 (V73:447-619).
+//
+// Every kernel reads the C covariate planes once per cell (coalesced along columns),
+// generates LONG/LAT from the grid affine, and writes  out (+)= pred * weight.
+// Regimes: lm / nnet / earth are HBM-bound (a few dozen flops per cell);
+// ksvm is FP64-VALU bound (nSV exp-pairs per cell, support vectors through the scalar
+// cache, exp from a 64-entry 2^(j/64) table in LDS); gbm / randomForest are LDS-latency
+// bound tree walks (node records staged chunk-wise in LDS, predictors parked in LDS so a
+// lane can index them by the node's split variable).
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "common.h"
+#include "devmath.h"
+
+enum { K_LM = 0, K_NNET = 1, K_EARTH = 2, K_SVR = 3, K_GBM = 4, K_RF = 5 };
+
+namespace mhs {
+
+constexpr int PMAX = 12;  // predictors supported by the register-resident kernels
+
+struct PredGeom {
+    double xmin, ymax, xres, yres;
+    int64_t r0, c0;  // window origin in the grid
+    int nr, nc;      // window size
+    int64_t ld_out;
+};
+
+struct StackDev {
+    const void *data;
+    int C;            // planes
+    int dtype;
+    int64_t plane_stride, ld;
+    double nodata;
+    int has_nodata;
+    int all_from_planes;  // points mode: every predictor (LONG, LAT too) comes from a plane
+};
+
+// 16-byte node record shared by gbm and randomForest walks
+struct __attribute__((aligned(16))) Node {
+    double val;              // split value, or the prediction at a terminal
+    short var;               // 0-based predictor, -1 = terminal
+    unsigned short left, right, missing;  // tree-local child indices
+};
+
+struct TreeChunk { int first_tree, n_trees, node_begin, node_count; };
+
+}  // namespace mhs
+
+struct mhs_model {
+    int kind = -1;
+    int p = 0;
+    // lm / nnet / earth / svr parameters (device)
+    double *dpar = nullptr;
+    int *ipar = nullptr;
+    int n0 = 0, n1 = 0;       // nnet: size ; earth: nterms, nfactors ; svr: nsv, row stride
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // nnet: y_scale,y_shift ; svr: b, sigma, y_center, y_scale
+    // trees
+    mhs::Node *nodes = nullptr;
+    int *tree_off = nullptr;       // n_trees + 1 node offsets
+    mhs::TreeChunk *chunks = nullptr;
+    int n_trees = 0, n_chunks = 0, max_chunk_nodes = 0;
+    int64_t n_nodes = 0;
+    double init_f = 0;
+    bool lds_ok = true;
+};
+
+namespace mhs {
+
+__device__ __forceinline__ double load_plane(const StackDev &s, int k, int64_t row, int64_t col) {
+    const int64_t idx = (int64_t)k * s.plane_stride + row * s.ld + col;
+    double v;
+    if (s.dtype == MHS_F64) v = ((const double *)s.data)[idx];
+    else if (s.dtype == MHS_F32) v = (double)((const float *)s.data)[idx];
+    else v = (double)((const short *)s.data)[idx];
+    if (s.has_nodata && v == s.nodata) v = NAN;
+    return v;
+}
+
+// predictor k of the cell at window position (row, col): rast_stack layer order
+__device__ __forceinline__ double predictor(const StackDev &s, const PredGeom &g, int k, int row, int col) {
+    const int64_t ar = g.r0 + row, ac = g.c0 + col;
+    if (k < s.C || s.all_from_planes) return load_plane(s, k, ar, ac);
+    if (k == s.C) return g.xmin + ((double)ac + 0.5) * g.xres;  // LONG (V73:131-133)
+    return g.ymax - ((double)ar + 0.5) * g.yres;                // LAT  (V73:128-130)
+}
+
+__device__ __forceinline__ void emit(double *out, int64_t idx, double pred, double weight, int accumulate) {
+    double v = pred * weight;
+    if (accumulate) v = out[idx] + v;
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------- lm --
+__global__ __launch_bounds__(256) void lm_kernel(const double *__restrict__ coef, int p, StackDev s,
+                                                 PredGeom g, double weight, int accumulate,
+                                                 double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)g.nr * g.nc) return;
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    double acc = coef[0];
+    for (int j = 0; j < p; ++j) acc = acc + coef[j + 1] * predictor(s, g, j, row, col);
+    emit(out, (int64_t)row * g.ld_out + col, acc, weight, accumulate);
+}
+
+// ----------------------------------------------------------------------- nnet --
+__device__ __forceinline__ double nnet_sigmoid(double z) {  // nnet.c sigmoid()
+    if (z < -15.0) return 0.0;
+    if (z > 15.0) return 1.0;
+    return 1.0 / (1.0 + exp(-z));
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void nnet_kernel(const double *__restrict__ w, int H, double y_scale,
+                                                   double y_shift, StackDev s, PredGeom g,
+                                                   double weight, int accumulate,
+                                                   double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)g.nr * g.nc) return;
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    double x[P];
+    bool na = false;
+#pragma unroll
+    for (int j = 0; j < P; ++j) { x[j] = predictor(s, g, j, row, col); na |= isnan(x[j]); }
+    double acc = w[(P + 1) * H];
+    for (int h = 0; h < H; ++h) {
+        const double *wh = w + h * (P + 1);
+        double z = wh[0];
+#pragma unroll
+        for (int j = 0; j < P; ++j) z = z + wh[1 + j] * x[j];
+        acc = acc + w[(P + 1) * H + 1 + h] * nnet_sigmoid(z);
+    }
+    acc = acc * y_scale + y_shift;
+    emit(out, (int64_t)row * g.ld_out + col, na ? NAN : acc, weight, accumulate);
+}
+
+// ---------------------------------------------------------------------- earth --
+// terms as factor lists: term k owns factors tstart[k] .. tstart[k+1]-1, each (var, dir, cut)
+__global__ __launch_bounds__(256) void earth_kernel(const double *__restrict__ coef,
+                                                    const double *__restrict__ fcut,
+                                                    const int *__restrict__ tstart,
+                                                    const int *__restrict__ fvar,
+                                                    const int *__restrict__ fdir, int nterms, int p,
+                                                    StackDev s, PredGeom g, double weight, int accumulate,
+                                                    double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)g.nr * g.nc) return;
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    bool na = false;
+    for (int j = 0; j < p; ++j) na |= isnan(predictor(s, g, j, row, col));
+    double acc = 0.0;
+    for (int k = 0; k < nterms; ++k) {
+        double term = 1.0;
+        for (int f = tstart[k]; f < tstart[k + 1]; ++f) {
+            const double xv = predictor(s, g, fvar[f], row, col);
+            const int d = fdir[f];
+            const double fac = d == 2 ? xv : (d == 1 ? fmax(0.0, xv - fcut[f]) : fmax(0.0, fcut[f] - xv));
+            term = term * fac;
+        }
+        acc = acc + coef[k] * term;
+    }
+    emit(out, (int64_t)row * g.ld_out + col, na ? NAN : acc, weight, accumulate);
+}
+
+// ------------------------------------------------------------------------ svr --
+// exp(x) for x <= ~0: x = (64 e + j) ln2/64 + r, |r| <= ln2/128; 2^(j/64) from LDS.
+constexpr int EXP_TAB_N = 64;
+__device__ __forceinline__ double table_exp(double x, const double *tab) {
+    x = fmax(x, -700.0);
+    const double kd = rint(x * 0x1.71547652b82fep+6);  // 64/ln2
+    double r = fma(kd, -0x1.62e42fefa0000p-7, x);    // ln2/64, high part (17 trailing zero bits)
+    r = fma(kd, -0x1.cf79abc9e3b3ap-46, r);           // ln2/64, low part
+    const int k = (int)kd;
+    const double sj = tab[k & (EXP_TAB_N - 1)];
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    const double v = fma(sj, q * r, sj);
+    const int hi = __double2hiint(v) + ((k >> 6) << 20);
+    return __hiloint2double(hi, __double2loint(v));
+}
+
+// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = 2 sigma sv_k, a = -sigma |sv|^2
+template <int P, int R>
+__global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp, int nsv, int stride,
+                                                  const double *__restrict__ xcs, double sigma, double b,
+                                                  double y_center, double y_scale, StackDev s, PredGeom g,
+                                                  double weight, int accumulate, double *__restrict__ out) {
+    __shared__ double etab[EXP_TAB_N];
+    if (threadIdx.x < EXP_TAB_N) etab[threadIdx.x] = exp2((double)threadIdx.x / EXP_TAB_N);
+    __syncthreads();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t half = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i0 >= half) return;
+    double x[R][P], q[R], acc[R];
+    bool na[R];
+    int row[R], col[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * half;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; q[c] = 0.0; acc[c] = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double xv = predictor(s, g, j, row[c], col[c]);
+            na[c] |= isnan(xv);
+            x[c][j] = (xv - xcs[j]) / xcs[P + j];
+            q[c] = fma(x[c][j], x[c][j], q[c]);
+        }
+        q[c] = -sigma * q[c];
+    }
+    for (int v = 0; v < nsv; ++v) {
+        const double *sp = svp + (int64_t)v * stride;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            double arg = q[c] + sp[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
+            acc[c] = fma(sp[P + 1], table_exp(arg, etab), acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        const int64_t i = i0 + c * half;
+        if (i < total) {
+            const double pred = (acc[c] - b) * y_scale + y_center;
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : pred, weight, accumulate);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- trees --
+// gbm_pred / predictRegTree walks.  Dynamic LDS: xs[p][R*256] predictors, then one chunk
+// of node records (LDS_NODES) or nothing (nodes read from global, for trees too large).
+template <bool GBM, bool LDS_NODES, int R>
+__global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnodes,
+                                                   const int *__restrict__ tree_off,
+                                                   const TreeChunk *__restrict__ chunks, int n_chunks,
+                                                   int n_trees, double init_f, int p, StackDev s,
+                                                   PredGeom g, double weight, int accumulate,
+                                                   double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;                                  // [p][R*256]
+    Node *lnodes = (Node *)(smem + (size_t)p * R * 256 * sizeof(double));
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t half = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * half;
+        if (i >= total) i = total - 1;
+        if (i < 0) i = 0;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0;
+        for (int j = 0; j < p; ++j) {
+            const double xv = predictor(s, g, j, row[c], col[c]);
+            na[c] |= isnan(xv);
+            xs[(j * R + c) * 256 + threadIdx.x] = xv;
+        }
+    }
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const TreeChunk tc = chunks[ch];
+        if (LDS_NODES) {
+            __syncthreads();
+            const int4 *src = (const int4 *)(gnodes + tc.node_begin);
+            int4 *dst = (int4 *)lnodes;
+            for (int e = threadIdx.x; e < tc.node_count; e += 256) dst[e] = src[e];
+            __syncthreads();
+        }
+        for (int t = tc.first_tree; t < tc.first_tree + tc.n_trees; ++t) {
+            const int tbase = LDS_NODES ? tree_off[t] - tc.node_begin : tree_off[t];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                Node nd;
+                if constexpr (LDS_NODES) nd = lnodes[tbase]; else nd = gnodes[tbase];
+                while (nd.var >= 0) {
+                    const double xv = xs[(nd.var * R + c) * 256 + threadIdx.x];
+                    unsigned nxt;
+                    if (GBM) nxt = isnan(xv) ? nd.missing : (xv < nd.val ? nd.left : nd.right);
+                    else nxt = (xv <= nd.val) ? nd.left : nd.right;
+                    if constexpr (LDS_NODES) nd = lnodes[tbase + nxt]; else nd = gnodes[tbase + nxt];
+                }
+                acc[c] = acc[c] + nd.val;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        const int64_t i = i0 + c * half;
+        if (i0 < half && i < total) {
+            double pred;
+            if (GBM) pred = init_f + acc[c];
+            else pred = na[c] ? NAN : acc[c] / (double)n_trees;
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], pred, weight, accumulate);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(const double *__restrict__ a, double divisor,
+                                                        const double *__restrict__ b,
+                                                        double *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = a[i] / divisor;
+    if (b) v = v + b[i];
+    out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void scale_window_kernel(double *__restrict__ out, int nr, int nc,
+                                                           int64_t ld, double divisor) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)nr * nc) return;
+    const int row = (int)(i / nc), col = (int)(i - (int64_t)row * nc);
+    out[(int64_t)row * ld + col] = out[(int64_t)row * ld + col] / divisor;
+}
+
+// ------------------------------------------------------------------ host side --
+template <typename T>
+static int to_device(const T *h, size_t n, T **d) {
+    MHS_HIP(hipMalloc((void **)d, sizeof(T) * (n ? n : 1)));
+    if (n) MHS_HIP(hipMemcpy(*d, h, sizeof(T) * n, hipMemcpyHostToDevice));
+    return MHS_OK;
+}
+
+constexpr int TREE_R = 2;
+constexpr size_t LDS_LIMIT = 150 * 1024;     // of the 160 KiB per CU
+constexpr int GBM_CHUNK_NODES = 1024;        // 16 KiB of node records per chunk
+
+static int finish_trees(mhs_model *m, const std::vector<Node> &nodes, const std::vector<int> &off) {
+    const int nt = m->n_trees;
+    const size_t xs_bytes = (size_t)m->p * TREE_R * 256 * sizeof(double);
+    int biggest = 0;
+    for (int t = 0; t < nt; ++t) biggest = std::max(biggest, off[t + 1] - off[t]);
+    int cap = (m->kind == K_GBM) ? std::max(GBM_CHUNK_NODES, biggest) : biggest;
+    m->lds_ok = xs_bytes + (size_t)cap * sizeof(Node) <= LDS_LIMIT;
+    std::vector<TreeChunk> chunks;
+    if (m->lds_ok) {
+        int t = 0;
+        while (t < nt) {
+            TreeChunk c{t, 0, off[t], 0};
+            while (t < nt && off[t + 1] - c.node_begin <= cap) { ++t; }
+            c.n_trees = t - c.first_tree;
+            c.node_count = off[t] - c.node_begin;
+            chunks.push_back(c);
+        }
+        m->max_chunk_nodes = cap;
+    } else {
+        chunks.push_back(TreeChunk{0, nt, 0, off[nt]});
+        m->max_chunk_nodes = 0;
+    }
+    m->n_chunks = (int)chunks.size();
+    m->n_nodes = (int64_t)nodes.size();
+    if (int rc = to_device(nodes.data(), nodes.size(), &m->nodes)) return rc;
+    if (int rc = to_device(off.data(), off.size(), &m->tree_off)) return rc;
+    return to_device(chunks.data(), chunks.size(), &m->chunks);
+}
+
+static int check_common(int p, mhs_model **out) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(out != nullptr, "out is NULL");
+    MHS_REQUIRE(p >= 2 && p <= 64, "p (covariates + LONG + LAT) out of range");
+    return MHS_OK;
+}
+
+template <int P>
+static void launch_nnet(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
+                        double *out, hipStream_t st, unsigned blocks) {
+    hipLaunchKernelGGL((nnet_kernel<P>), dim3(blocks), dim3(256), 0, st, m->dpar, m->n0, m->s0, m->s1, s, g, w, acc, out);
+}
+template <int P>
+static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
+                       double *out, hipStream_t st, int64_t total) {
+    constexpr int R = 2;
+    const int64_t half = (total + R - 1) / R;
+    hipLaunchKernelGGL((svr_kernel<P, R>), dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st,
+                       m->dpar, m->n0, m->n1, m->dpar + (size_t)m->n0 * m->n1, m->s1, m->s0, m->s2, m->s3,
+                       s, g, w, acc, out);
+}
+
+#define MHS_DISPATCH_P(P_, CALL)                                                     \
+    switch (P_) {                                                                    \
+        case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;      \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;      \
+        case 8: CALL(8); break; case 9: CALL(9); break; case 10: CALL(10); break;    \
+        case 11: CALL(11); break; case 12: CALL(12); break;                          \
+        default: set_error("predict: p = %d exceeds the %d predictors this build supports for nnet/ksvm", P_, PMAX); \
+                 return MHS_ERR_INVALID;                                             \
+    }
+
+template <bool GBM>
+static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
+                        double *out, hipStream_t st, int64_t total) {
+    const int64_t half = (total + TREE_R - 1) / TREE_R;
+    const unsigned blocks = (unsigned)((half + 255) / 256);
+    const size_t xs_bytes = (size_t)m->p * TREE_R * 256 * sizeof(double);
+    if (m->lds_ok) {
+        const size_t bytes = xs_bytes + (size_t)m->max_chunk_nodes * sizeof(Node);
+        auto kern = tree_kernel<GBM, true, TREE_R>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks,
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
+    } else {
+        auto kern = tree_kernel<GBM, false, TREE_R>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), xs_bytes, st, m->nodes, m->tree_off, m->chunks,
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
+    }
+    return MHS_OK;
+}
+
+static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g, double weight,
+                        int accumulate, double *out, hipStream_t st) {
+    const int64_t total = (int64_t)g.nr * g.nc;
+    if (total == 0) return MHS_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    switch (m->kind) {
+        case K_LM:
+            hipLaunchKernelGGL(lm_kernel, dim3(blocks), dim3(256), 0, st, m->dpar, m->p, s, g, weight, accumulate, out);
+            break;
+        case K_NNET: {
+#define CALL_NNET(P) launch_nnet<P>(m, s, g, weight, accumulate, out, st, blocks)
+            MHS_DISPATCH_P(m->p, CALL_NNET)
+#undef CALL_NNET
+            break;
+        }
+        case K_EARTH:
+            hipLaunchKernelGGL(earth_kernel, dim3(blocks), dim3(256), 0, st, m->dpar, m->dpar + m->n0,
+                               m->ipar, m->ipar + m->n0 + 1, m->ipar + m->n0 + 1 + m->n1, m->n0, m->p, s, g,
+                               weight, accumulate, out);
+            break;
+        case K_SVR: {
+#define CALL_SVR(P) launch_svr<P>(m, s, g, weight, accumulate, out, st, total)
+            MHS_DISPATCH_P(m->p, CALL_SVR)
+#undef CALL_SVR
+            break;
+        }
+        case K_GBM:
+            if (int rc = launch_trees<true>(m, s, g, weight, accumulate, out, st, total)) return rc;
+            break;
+        case K_RF:
+            if (int rc = launch_trees<false>(m, s, g, weight, accumulate, out, st, total)) return rc;
+            break;
+        default:
+            set_error("predict: unknown model kind %d", m->kind);
+            return MHS_ERR_INVALID;
+    }
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
+static int make_stack(const mhs_model *m, const mhs_grid *g, const mhs_stack *c, StackDev *s) {
+    MHS_REQUIRE(c && c->data, "covariate stack is NULL");
+    MHS_REQUIRE(c->n_layers == m->p - 2, "stack has the wrong number of layers for this model (p = layers + 2)");
+    MHS_REQUIRE(c->dtype == MHS_F64 || c->dtype == MHS_F32 || c->dtype == MHS_I16, "bad stack dtype");
+    MHS_REQUIRE(c->ld >= g->ncol && c->plane_stride >= c->ld * g->nrow, "stack strides smaller than the grid");
+    s->data = c->data; s->C = c->n_layers; s->dtype = c->dtype; s->plane_stride = c->plane_stride;
+    s->ld = c->ld; s->nodata = c->nodata; s->has_nodata = !std::isnan(c->nodata); s->all_from_planes = 0;
+    return MHS_OK;
+}
+
+static int make_geom(const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int64_t c1, int64_t ld, PredGeom *pg) {
+    MHS_REQUIRE(g && g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
+    MHS_REQUIRE(0 <= r0 && r0 <= r1 && r1 <= g->nrow && 0 <= c0 && c0 <= c1 && c1 <= g->ncol, "window outside the grid");
+    MHS_REQUIRE(ld >= c1 - c0, "ld smaller than the window width");
+    MHS_REQUIRE((r1 - r0) * (c1 - c0) < (1LL << 40) && r1 - r0 < (1LL << 31) && c1 - c0 < (1LL << 31), "window too large");
+    pg->xmin = g->xmin; pg->ymax = g->ymax; pg->xres = g->xres; pg->yres = g->yres;
+    pg->r0 = r0; pg->c0 = c0; pg->nr = (int)(r1 - r0); pg->nc = (int)(c1 - c0); pg->ld_out = ld;
+    return MHS_OK;
+}
+
+}  // namespace mhs
+
+using namespace mhs;
+
+extern "C" {
+
+int mhs_model_free(mhs_model *m) {
+    if (!m) return MHS_OK;
+    if (m->dpar) (void)hipFree(m->dpar);
+    if (m->ipar) (void)hipFree(m->ipar);
+    if (m->nodes) (void)hipFree(m->nodes);
+    if (m->tree_off) (void)hipFree(m->tree_off);
+    if (m->chunks) (void)hipFree(m->chunks);
+    delete m;
+    return MHS_OK;
+}
+
+int mhs_lm_load(const double *coef, int p, mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(coef != nullptr, "coef is NULL");
+    mhs_model *m = new mhs_model();
+    m->kind = K_LM; m->p = p;
+    if (int rc = to_device(coef, (size_t)p + 1, &m->dpar)) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_nnet_load(const double *wts, int p, int size, double y_scale, double y_shift, mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(wts != nullptr && size >= 1 && size <= 4096, "bad nnet arguments");
+    MHS_REQUIRE(p <= PMAX, "p exceeds the predictors supported for nnet");
+    mhs_model *m = new mhs_model();
+    m->kind = K_NNET; m->p = p; m->n0 = size; m->s0 = y_scale; m->s1 = y_shift;
+    if (int rc = to_device(wts, (size_t)(p + 1) * size + size + 1, &m->dpar)) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_earth_load(const double *coef, const int32_t *dirs, const double *cuts, int nterms, int p,
+                   mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(coef && dirs && cuts && nterms >= 1, "bad earth arguments");
+    std::vector<int> tstart(1, 0), fvar, fdir;
+    std::vector<double> fcut;
+    for (int k = 0; k < nterms; ++k) {
+        for (int v = 0; v < p; ++v) {
+            const int d = dirs[(size_t)k * p + v];
+            MHS_REQUIRE(d == 0 || d == 1 || d == -1 || d == 2, "earth dirs must be 0, 1, -1 or 2");
+            if (d != 0) { fvar.push_back(v); fdir.push_back(d); fcut.push_back(cuts[(size_t)k * p + v]); }
+        }
+        tstart.push_back((int)fvar.size());
+    }
+    mhs_model *m = new mhs_model();
+    m->kind = K_EARTH; m->p = p; m->n0 = nterms; m->n1 = (int)fvar.size();
+    std::vector<double> dp(coef, coef + nterms);
+    dp.insert(dp.end(), fcut.begin(), fcut.end());
+    std::vector<int> ip(tstart);
+    ip.insert(ip.end(), fvar.begin(), fvar.end());
+    ip.insert(ip.end(), fdir.begin(), fdir.end());
+    int rc = to_device(dp.data(), dp.size(), &m->dpar);
+    if (!rc) rc = to_device(ip.data(), ip.size(), &m->ipar);
+    if (rc) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, double b, double sigma,
+                 const double *x_center, const double *x_scale, double y_center, double y_scale,
+                 mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(alpha && sv && x_center && x_scale && nsv >= 1 && nsv < (1LL << 30), "bad ksvm arguments");
+    MHS_REQUIRE(p <= PMAX, "p exceeds the predictors supported for ksvm");
+    MHS_REQUIRE(sigma > 0, "sigma must be positive");
+    for (int j = 0; j < p; ++j) MHS_REQUIRE(x_scale[j] != 0.0, "x_scale has a zero entry");
+    const int stride = ((p + 2) + 3) & ~3;  // doubles per support vector, 32-byte multiple
+    std::vector<double> h((size_t)nsv * stride + 2 * p, 0.0);
+    for (int64_t v = 0; v < nsv; ++v) {
+        double ss = 0.0;
+        for (int j = 0; j < p; ++j) {
+            const double x = sv[(size_t)v * p + j];
+            h[(size_t)v * stride + j] = 2.0 * sigma * x;
+            ss += x * x;
+        }
+        h[(size_t)v * stride + p] = -sigma * ss;
+        h[(size_t)v * stride + p + 1] = alpha[v];
+    }
+    for (int j = 0; j < p; ++j) { h[(size_t)nsv * stride + j] = x_center[j]; h[(size_t)nsv * stride + p + j] = x_scale[j]; }
+    mhs_model *m = new mhs_model();
+    m->kind = K_SVR; m->p = p; m->n0 = (int)nsv; m->n1 = stride;
+    m->s0 = b; m->s1 = sigma; m->s2 = y_center; m->s3 = y_scale;
+    if (int rc = to_device(h.data(), h.size(), &m->dpar)) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets, const int32_t *split_var,
+                 const double *split_val, const int32_t *left, const int32_t *right,
+                 const int32_t *missing, int p, mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(tree_offsets && split_var && split_val && left && right && missing, "NULL gbm array");
+    MHS_REQUIRE(n_trees >= 0 && n_trees < (1LL << 30) && tree_offsets[0] == 0, "bad tree offsets");
+    const int64_t nn = tree_offsets[n_trees];
+    MHS_REQUIRE(nn < (1LL << 31), "too many nodes");
+    std::vector<Node> nodes((size_t)nn);
+    std::vector<int> off((size_t)n_trees + 1);
+    for (int64_t t = 0; t <= n_trees; ++t) off[t] = (int)tree_offsets[t];
+    for (int64_t t = 0; t < n_trees; ++t) {
+        const int64_t o = tree_offsets[t], cnt = tree_offsets[t + 1] - o;
+        MHS_REQUIRE(cnt >= 1 && cnt <= 65535, "a gbm tree must have 1..65535 nodes");
+        for (int64_t k = 0; k < cnt; ++k) {
+            Node &nd = nodes[(size_t)(o + k)];
+            nd.val = split_val[o + k];
+            nd.var = (short)split_var[o + k];
+            if (split_var[o + k] >= 0) {
+                MHS_REQUIRE(split_var[o + k] < p, "gbm SplitVar out of range");
+                MHS_REQUIRE(left[o + k] >= 0 && left[o + k] < cnt && right[o + k] >= 0 && right[o + k] < cnt &&
+                            missing[o + k] >= 0 && missing[o + k] < cnt, "gbm child index out of range");
+                nd.left = (unsigned short)left[o + k]; nd.right = (unsigned short)right[o + k];
+                nd.missing = (unsigned short)missing[o + k];
+            } else { nd.var = -1; nd.left = nd.right = nd.missing = 0; }
+        }
+    }
+    mhs_model *m = new mhs_model();
+    m->kind = K_GBM; m->p = p; m->n_trees = (int)n_trees; m->init_f = init_f;
+    if (int rc = finish_trees(m, nodes, off)) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *left, const int32_t *right,
+                const int32_t *status, const int32_t *best_var, const double *split,
+                const double *node_pred, int p, mhs_model **out) {
+    if (int rc = check_common(p, out)) return rc;
+    MHS_REQUIRE(tree_offsets && left && right && status && best_var && split && node_pred, "NULL rf array");
+    MHS_REQUIRE(n_trees >= 1 && n_trees < (1LL << 30) && tree_offsets[0] == 0, "bad tree offsets");
+    const int64_t nn = tree_offsets[n_trees];
+    MHS_REQUIRE(nn < (1LL << 31), "too many nodes");
+    std::vector<Node> nodes((size_t)nn);
+    std::vector<int> off((size_t)n_trees + 1);
+    for (int64_t t = 0; t <= n_trees; ++t) off[t] = (int)tree_offsets[t];
+    for (int64_t t = 0; t < n_trees; ++t) {
+        const int64_t o = tree_offsets[t], cnt = tree_offsets[t + 1] - o;
+        MHS_REQUIRE(cnt >= 1 && cnt <= 65535, "a randomForest tree must have 1..65535 nodes");
+        for (int64_t k = 0; k < cnt; ++k) {
+            Node &nd = nodes[(size_t)(o + k)];
+            if (status[o + k] == -1) {
+                nd.val = node_pred[o + k]; nd.var = -1; nd.left = nd.right = nd.missing = 0;
+            } else {
+                MHS_REQUIRE(best_var[o + k] >= 1 && best_var[o + k] <= p, "rf bestvar out of range");
+                MHS_REQUIRE(left[o + k] >= 1 && left[o + k] <= cnt && right[o + k] >= 1 && right[o + k] <= cnt,
+                            "rf daughter index out of range");
+                nd.val = split[o + k]; nd.var = (short)(best_var[o + k] - 1);
+                nd.left = (unsigned short)(left[o + k] - 1); nd.right = (unsigned short)(right[o + k] - 1);
+                nd.missing = 0;
+            }
+        }
+    }
+    mhs_model *m = new mhs_model();
+    m->kind = K_RF; m->p = p; m->n_trees = (int)n_trees;
+    if (int rc = finish_trees(m, nodes, off)) { mhs_model_free(m); return rc; }
+    *out = m;
+    return MHS_OK;
+}
+
+int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
+                    int64_t r1, int64_t c0, int64_t c1, double weight, int accumulate, double *out_dev,
+                    int64_t ld, void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(m && out_dev, "NULL argument");
+    PredGeom pg;
+    StackDev s;
+    if (int rc = make_geom(g, r0, r1, c0, c1, ld, &pg)) return rc;
+    if (int rc = make_stack(m, g, covars, &s)) return rc;
+    return launch_model(m, s, pg, weight, accumulate, out_dev, pick_stream(stream));
+}
+
+int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weights, int n_models,
+                             double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
+                             int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(models && weights && n_models >= 1 && out_dev, "bad ensemble arguments");
+    MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
+    for (int k = 0; k < n_models; ++k)
+        if (int rc = mhs_predict_dev(models[k], g, covars, r0, r1, c0, c1, weights[k], k > 0, out_dev, ld, stream)) return rc;
+    const int64_t total = (r1 - r0) * (c1 - c0);
+    if (total > 0) {
+        hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           pick_stream(stream), out_dev, (int)(r1 - r0), (int)(c1 - c0), ld, wt_total);
+        MHS_HIP(hipGetLastError());
+    }
+    return MHS_OK;
+}
+
+int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, int n_models,
+                         double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
+                         int64_t r1, int64_t c0, int64_t c1, double *out_host) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(models && n_models >= 1 && g && covars && covars->data && out_host, "bad ensemble arguments");
+    MHS_REQUIRE(0 <= r0 && r0 <= r1 && r1 <= g->nrow && 0 <= c0 && c0 <= c1 && c1 <= g->ncol, "window outside the grid");
+    const int64_t nr = r1 - r0, nc = c1 - c0;
+    if (nr == 0 || nc == 0) return MHS_OK;
+    const size_t esz = covars->dtype == MHS_F64 ? 8 : covars->dtype == MHS_F32 ? 4 : 2;
+    hipStream_t s = ctx().stream;
+    // ship rows [r0, r1) of every layer; the device copy is described as a grid of nr rows
+    DevBuf<char> dcov;
+    DevBuf<double> dout;
+    const size_t plane_bytes = (size_t)nr * covars->ld * esz;
+    MHS_HIP(dcov.alloc(plane_bytes * (size_t)covars->n_layers));
+    MHS_HIP(dout.alloc((size_t)(nr * nc)));
+    for (int k = 0; k < covars->n_layers; ++k)
+        MHS_HIP(hipMemcpyAsync(dcov.p + plane_bytes * k,
+                               (const char *)covars->data + ((size_t)k * covars->plane_stride + (size_t)r0 * covars->ld) * esz,
+                               plane_bytes, hipMemcpyHostToDevice, s));
+    // Describe the device copy with the PARENT grid's affine (cell centres stay bit-identical):
+    // plane k, absolute row r lives at base + (k*plane_stride + r*ld)*esz, so shift the base
+    // back by r0 rows once and let plane_stride skip the nr rows that were shipped.
+    mhs_stack ds = *covars;
+    ds.data = dcov.p - (size_t)r0 * covars->ld * esz;
+    ds.plane_stride = (int64_t)nr * covars->ld;
+    for (int k = 0; k < n_models; ++k) {
+        PredGeom pg;
+        StackDev sd;
+        if (int rc = make_geom(g, r0, r1, c0, c1, nc, &pg)) return rc;
+        MHS_REQUIRE(covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
+        sd.data = ds.data; sd.C = ds.n_layers; sd.dtype = ds.dtype; sd.plane_stride = ds.plane_stride;
+        sd.ld = ds.ld; sd.nodata = ds.nodata; sd.has_nodata = !std::isnan(ds.nodata); sd.all_from_planes = 0;
+        if (int rc = launch_model(models[k], sd, pg, weights[k], k > 0, dout.p, s)) return rc;
+    }
+    hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((nr * nc + 255) / 256)), dim3(256), 0, s,
+                       dout.p, (int)nr, (int)nc, nc, wt_total);
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *out_host) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(m && out_host && (X || n == 0) && n >= 0 && n < (1LL << 31), "bad arguments");
+    if (n == 0) return MHS_OK;
+    hipStream_t s = ctx().stream;
+    DevBuf<double> dx, dout;
+    MHS_HIP(dx.alloc((size_t)n * m->p));
+    MHS_HIP(dout.alloc((size_t)n));
+    MHS_HIP(hipMemcpyAsync(dx.p, X, sizeof(double) * (size_t)n * m->p, hipMemcpyHostToDevice, s));
+    PredGeom pg;
+    pg.xmin = pg.ymax = 0; pg.xres = pg.yres = 1; pg.r0 = pg.c0 = 0; pg.nr = 1; pg.nc = (int)n; pg.ld_out = n;
+    StackDev sd;
+    sd.data = dx.p; sd.C = m->p; sd.dtype = MHS_F64; sd.plane_stride = n; sd.ld = n; sd.nodata = NAN;
+    sd.has_nodata = 0; sd.all_from_planes = 1;
+    if (int rc = launch_model(m, sd, pg, 1.0, 0, dout.p, s)) return rc;
+    MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+int mhs_scale_add_dev(const double *a, double divisor, const double *b, double *out, int64_t n, void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(a && out && n >= 0, "bad arguments");
+    if (n == 0) return MHS_OK;
+    hipLaunchKernelGGL(scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pick_stream(stream), a, divisor, b, out, n);
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
+}  // extern "C"

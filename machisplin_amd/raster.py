@@ -67,3 +67,35 @@ class Geometry:
 
     def c_struct(self) -> "_lib.Grid":
         return _lib.Grid(self.xmin, self.ymax, self.xres, self.yres, self.nrow, self.ncol)
+
+
+class RasterStack:
+    """``rast_stack``'s covariate layers (V73:138) resident in HBM: a (C, nrow, ncol) device
+    tensor of float64 / float32 / int16 plus the NoData value (INT2S rasters use -32768).
+    LONG and LAT are not stored: the kernels generate them from the geometry."""
+
+    _DT = None
+
+    def __init__(self, geom: Geometry, planes, nodata: float = float("nan")):
+        import torch
+        if RasterStack._DT is None:
+            RasterStack._DT = {torch.float64: _lib.F64, torch.float32: _lib.F32, torch.int16: _lib.I16}
+        if isinstance(planes, np.ndarray):
+            planes = torch.from_numpy(np.ascontiguousarray(planes))
+        if planes.dim() != 3 or tuple(planes.shape[1:]) != (geom.nrow, geom.ncol):
+            raise ValueError("planes must be (C, nrow, ncol) matching the geometry")
+        if planes.dtype not in RasterStack._DT:
+            raise ValueError("planes must be float64, float32 or int16")
+        dev = torch.device("cuda", _lib.init())
+        self.planes = planes.to(dev).contiguous()
+        self.geom = geom
+        self.nodata = float(nodata)
+
+    @property
+    def n_layers(self) -> int:
+        return self.planes.shape[0]
+
+    def c_struct(self) -> "_lib.Stack":
+        p = self.planes
+        return _lib.Stack(p.data_ptr(), p.shape[0], RasterStack._DT[p.dtype], p.stride(0), p.stride(1),
+                          self.nodata)

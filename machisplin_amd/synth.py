@@ -29,3 +29,193 @@ def stations(geom: Geometry, n: int, seed: int):
 def tps_residual(uv: np.ndarray, seed: int) -> np.ndarray:
     rng = np.random.default_rng(seed + 1)
     return np.sin(6 * uv[:, 0]) * np.cos(5 * uv[:, 1]) + 0.1 * rng.standard_normal(uv.shape[0])
+
+
+# ---------------------------------------------------------------- covariate planes --
+COV_RANGES = [(76.0, 4668.0), (-1.0, 877.0), (-207.0, 152.0), (0.0, 360.0), (-50.0, 50.0),
+              (0.0, 1.0), (10.0, 3000.0), (-5.0, 40.0)]  # alt, slope, TWI (extdata aux.xml), then generic
+
+
+def covariates(geom: Geometry, n_layers: int, seed: int, dtype: str = "f32", nodata_frac: float = 0.0):
+    """cov_k = sum_{m<6} a_km sin(2 pi (f_km col/ncol + g_km row/nrow) + phi_km), rescaled to
+    alt/slope/TWI-like ranges.  Built on the GPU; returns a (C, nrow, ncol)
+    device tensor (float32, float64, or int16 with NoData -32768 on `nodata_frac` of cells)
+    and the NoData value."""
+    import torch
+    from . import _lib
+    dev = torch.device("cuda", _lib.init())
+    rng = np.random.default_rng(seed + 7)
+    col = (torch.arange(geom.ncol, device=dev, dtype=torch.float64) / geom.ncol)[None, :]
+    row = (torch.arange(geom.nrow, device=dev, dtype=torch.float64) / geom.nrow)[:, None]
+    tdt = {"f32": torch.float32, "f64": torch.float64, "i16": torch.int16}[dtype]
+    out = torch.empty((n_layers, geom.nrow, geom.ncol), dtype=tdt, device=dev)
+    for k in range(n_layers):
+        a = rng.uniform(0.3, 1.0, 6)
+        f = rng.uniform(0.5, 6.0, 6)
+        gq = rng.uniform(0.5, 6.0, 6)
+        ph = rng.uniform(0, 2 * np.pi, 6)
+        z = torch.zeros((geom.nrow, geom.ncol), dtype=torch.float64, device=dev)
+        for m in range(6):
+            z += a[m] * torch.sin(2 * np.pi * (f[m] * col + gq[m] * row) + ph[m])
+        lo, hi = COV_RANGES[k % len(COV_RANGES)]
+        z = (z / a.sum() * 0.5 + 0.5) * (hi - lo) + lo
+        if dtype == "i16":
+            z = torch.round(z)
+        out[k] = z.to(tdt)
+        del z
+    nodata = float("nan")
+    if dtype == "i16":
+        nodata = -32768.0
+    if nodata_frac > 0:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 11)
+        mask = torch.rand((geom.nrow, geom.ncol), device=dev, generator=gen) < nodata_frac
+        for k in range(n_layers):
+            out[k][mask] = -32768 if dtype == "i16" else float("nan")
+    return out, nodata
+
+
+# ---------------------------------------------- trainer-free ensemble parameter sets --
+# Structurally faithful stand-ins for the fitted CRAN objects (same array layouts, sizes and
+# tree shapes as a real fit at the BASELINE sizes), generated from the seed in seconds so the
+# GPU box needs neither R nor a long scikit-learn fit.
+
+def response(X: np.ndarray, uv: np.ndarray, seed: int) -> np.ndarray:
+    """y = 250 - 0.0055 alt + 3 sin(4u) + 2 cos(3v) + N(0,1)   (SURVEY.md 8d)."""
+    rng = np.random.default_rng(seed + 3)
+    return 250.0 - 0.0055 * X[:, 0] + 3 * np.sin(4 * uv[:, 0]) + 2 * np.cos(3 * uv[:, 1]) + rng.standard_normal(X.shape[0])
+
+
+def lm_params(X, y):
+    A = np.column_stack([np.ones(X.shape[0]), X])
+    return {"kind": "lm", "coef": np.linalg.lstsq(A, y, rcond=None)[0]}
+
+
+def nnet_params(X, y, seed, size=10):
+    rng = np.random.default_rng(seed + 21)
+    p = X.shape[1]
+    mu, sd = X.mean(0), X.std(0) + 1e-12
+    wts = []
+    for _ in range(size):  # unscaled inputs (V73:463): weights ~ 1/sd so units are not all saturated
+        w = rng.standard_normal(p) / sd
+        wts += [float(-(w * mu).sum() + rng.standard_normal())] + list(w)
+    wts += list(rng.standard_normal(size + 1) * 0.3)
+    ymin = float(y.min())
+    return {"kind": "nnet", "wts": np.array(wts), "p": p, "size": size,
+            "y_scale": float((y - ymin).max()), "y_shift": ymin}
+
+
+def earth_params(X, y, seed, nterms=15):
+    rng = np.random.default_rng(seed + 22)
+    n, p = X.shape
+    dirs = np.zeros((nterms, p), dtype=np.int32)
+    cuts = np.zeros((nterms, p))
+    B = [np.ones(n)]
+    for k in range(1, nterms):
+        v = int(rng.integers(p))
+        d = int(rng.choice([1, -1, 2], p=[0.45, 0.45, 0.1]))
+        c = float(X[rng.integers(n), v]) if d != 2 else 0.0
+        dirs[k, v], cuts[k, v] = d, c
+        B.append(X[:, v] if d == 2 else np.maximum(0.0, d * (X[:, v] - c)))
+    coef = np.linalg.lstsq(np.column_stack(B), y, rcond=None)[0]
+    return {"kind": "earth", "coef": coef, "dirs": dirs, "cuts": cuts}
+
+
+def svr_params(X, y, seed, frac_sv=0.6):
+    rng = np.random.default_rng(seed + 23)
+    n, p = X.shape
+    mu, sd = X.mean(0), X.std(0, ddof=1)
+    nsv = max(4, int(frac_sv * n))
+    idx = rng.choice(n, nsv, replace=False)
+    sv = (X[idx] - mu) / sd
+    return {"kind": "svr", "alpha": rng.uniform(-1, 1, nsv), "sv": sv, "b": float(rng.normal(0, 0.1)),
+            "sigma": float(rng.uniform(0.15, 0.4)), "x_center": mu, "x_scale": sd,
+            "y_center": float(y.mean()), "y_scale": float(y.std(ddof=1))}
+
+
+def gbm_params(X, y, seed, n_trees=10000, n_splits=5, shrinkage=0.001):
+    """interaction.depth = 5 trees (V73:493): 5 splits grown on random leaves, every split
+    owning a left, right and missing child (gbm's node layout: 1 + 3*5 = 16 nodes)."""
+    rng = np.random.default_rng(seed + 24)
+    n, p = X.shape
+    npt = 1 + 3 * n_splits
+    sd_y = float(y.std())
+    split_var = np.full((n_trees, npt), -1, dtype=np.int32)
+    split_val = rng.standard_normal((n_trees, npt)) * sd_y * shrinkage
+    left = np.zeros((n_trees, npt), dtype=np.int32)
+    right = np.zeros((n_trees, npt), dtype=np.int32)
+    missing = np.zeros((n_trees, npt), dtype=np.int32)
+    # leaves[t, :] candidate terminal nodes that may still be split (left/right children only)
+    nleaf = np.ones(n_trees, dtype=np.int64)
+    leaves = np.zeros((n_trees, 1 + 2 * n_splits), dtype=np.int64)
+    T = np.arange(n_trees)
+    for s in range(n_splits):
+        pick = (rng.random(n_trees) * nleaf).astype(np.int64)
+        node = leaves[T, pick]
+        v = rng.integers(0, p, n_trees)
+        thr = X[rng.integers(0, n, n_trees), v]
+        split_var[T, node] = v
+        split_val[T, node] = thr
+        l, r, m = 1 + 3 * s, 2 + 3 * s, 3 + 3 * s
+        left[T, node], right[T, node], missing[T, node] = l, r, m
+        leaves[T, pick] = l          # the split leaf is replaced by its left child ...
+        leaves[T, nleaf] = r         # ... and the right child is appended
+        nleaf += 1
+    off = np.arange(n_trees + 1, dtype=np.int64) * npt
+    return {"kind": "gbm", "init_f": float(y.mean()), "tree_offsets": off, "split_var": split_var.ravel(),
+            "split_val": split_val.ravel(), "left": left.ravel(), "right": right.ravel(),
+            "missing": missing.ravel(), "p": p}
+
+
+def rf_params(X, y, seed, n_trees=500, nodesize=5):
+    """randomForest-shaped regression trees: bootstrap sample, recursive axis splits at the
+    midpoint of two sample values until nodes hold <= nodesize points; node numbering in
+    creation order as randomForest does (leftDaughter = ncur+1, rightDaughter = ncur+2)."""
+    rng = np.random.default_rng(seed + 25)
+    n, p = X.shape
+    offs, L, R, S, V, SP, NP = [0], [], [], [], [], [], []
+    for _ in range(n_trees):
+        boot = rng.integers(0, n, n)
+        Xb, yb = X[boot], y[boot]
+        left, right, status, var, split, pred = [0], [0], [-1], [0], [0.0], [float(yb.mean())]
+        stack = [(0, np.arange(n))]
+        while stack:
+            k, idx = stack.pop()
+            if idx.size <= nodesize:
+                continue
+            for _try in range(4):
+                v = int(rng.integers(p))
+                xv = Xb[idx, v]
+                a, b = xv[rng.integers(idx.size)], xv[rng.integers(idx.size)]
+                if a != b:
+                    break
+            else:
+                continue
+            thr = 0.5 * (a + b)
+            go_left = xv <= thr
+            il, ir = idx[go_left], idx[~go_left]
+            if il.size == 0 or ir.size == 0:
+                continue
+            nl = len(left)
+            for sub in (il, ir):
+                left.append(0); right.append(0); status.append(-1); var.append(0); split.append(0.0)
+                pred.append(float(yb[sub].mean()))
+            left[k], right[k], status[k], var[k], split[k] = nl + 1, nl + 2, -3, v + 1, float(thr)
+            stack.append((nl, il))
+            stack.append((nl + 1, ir))
+        offs.append(offs[-1] + len(left))
+        L += left; R += right; S += status; V += var; SP += split; NP += pred
+    return {"kind": "rf", "tree_offsets": np.array(offs, dtype=np.int64), "left": np.array(L, dtype=np.int32),
+            "right": np.array(R, dtype=np.int32), "status": np.array(S, dtype=np.int32),
+            "best_var": np.array(V, dtype=np.int32), "split": np.array(SP), "node_pred": np.array(NP), "p": p}
+
+
+def ensemble_params(X, y, seed, n_gbm_trees=10000, n_rf_trees=500, which="bgnmrv"):
+    """Parameter dicts in the reference's model order b, g, n, m, r, v (V73:340-362)."""
+    makers = {"b": lambda: gbm_params(X, y, seed, n_trees=n_gbm_trees), "g": lambda: lm_params(X, y),
+              "n": lambda: nnet_params(X, y, seed), "m": lambda: earth_params(X, y, seed),
+              "r": lambda: rf_params(X, y, seed, n_trees=n_rf_trees), "v": lambda: svr_params(X, y, seed)}
+    return [makers[k]() for k in which]
+
+
+OPTX_WEIGHTS = (0.31, 0.22, 0.12, 0.18, 0.27, 0.41)  # SURVEY.md 8d: p1..p6 of the L-BFGS-B fit

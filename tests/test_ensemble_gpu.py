@@ -1,0 +1,146 @@
+"""GPU parity: the six HIP predictors + weighted ensemble (through the C ABI) vs the oracle's
+restatement of the CRAN predict methods on the same covariate planes."""
+import numpy as np
+import pytest
+
+import modelgen
+from oracle import ensemble as oe
+from oracle import tps as otps
+
+pytestmark = pytest.mark.gpu
+
+KINDS = "bgnmrv"
+
+
+def _setup(hip, nrow=70, ncol=93, C=3, dtype="f32", nodata_frac=0.0, n=600, seed=5, gbm_trees=300, rf_trees=20):
+    from machisplin_amd import synth
+    g = synth.grid(nrow, ncol)
+    planes, nodata = synth.covariates(g, C, seed, dtype=dtype, nodata_frac=nodata_frac)
+    stack = hip.RasterStack(g, planes, nodata)
+    host = planes.cpu().numpy().astype(np.float64)
+    if not np.isnan(nodata):
+        host[host == nodata] = np.nan
+    x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, nrow, ncol)
+    X = oe.stack_predictors(host, (x, y))
+    rng = np.random.default_rng(seed)
+    ok = np.flatnonzero(~np.isnan(X).any(axis=1))
+    idx = rng.choice(ok, n, replace=False)
+    Xs = X[idx]
+    uv = np.column_stack([(idx % ncol + 0.5) / ncol, (idx // ncol + 0.5) / nrow])
+    ys = synth.response(Xs, uv, seed)
+    params = synth.ensemble_params(Xs, ys, seed, n_gbm_trees=gbm_trees, n_rf_trees=rf_trees)
+    return g, stack, X, Xs, ys, params
+
+
+def _tol(ref):
+    return 1e-11 * np.nanmax(np.abs(ref))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64", "i16"])
+def test_each_member_matches_oracle(hip, dtype):
+    g, stack, X, Xs, ys, params = _setup(hip, dtype=dtype, nodata_frac=0.01 if dtype != "f64" else 0.0)
+    for prm in params:
+        m = hip.models.from_oracle_dict(prm)
+        got = hip.predict(stack, m).cpu().numpy().ravel()
+        want = oe.predict(prm, X)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), prm["kind"]
+        assert np.nanmax(np.abs(got - want)) <= _tol(want), (prm["kind"], np.nanmax(np.abs(got - want)))
+
+
+def test_gbm_routes_na_through_missing_nodes(hip):
+    g, stack, X, Xs, ys, params = _setup(hip, dtype="f32", nodata_frac=0.05)
+    prm = params[0]
+    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    assert np.isnan(X).any() and np.isfinite(got).all()
+    assert np.abs(got - oe.predict(prm, X)).max() <= _tol(got)
+
+
+def test_sklearn_fitted_structures(hip):
+    """Real fitted trees / SVR / MLP (exported by tests/modelgen.py) rather than synthetic ones."""
+    from sklearn.ensemble import GradientBoostingRegressor, RandomForestRegressor
+    from sklearn.svm import SVR
+    g, stack, X, Xs, ys, _ = _setup(hip, n=400)
+    # sklearn's trees compare float32(x) <= threshold: train off the cell centres so that no cell's
+    # LONG/LAT coincides (in float32) with a split value, where `<` (gbm) and `<=` would differ
+    Xs = Xs.copy()
+    Xs[:, 3:] += np.random.default_rng(0).uniform(-3e-4, 3e-4, (Xs.shape[0], 2))
+    gbr = GradientBoostingRegressor(n_estimators=80, max_leaf_nodes=6, learning_rate=0.01, subsample=0.5, random_state=1).fit(Xs, ys)
+    rf = RandomForestRegressor(n_estimators=15, min_samples_split=6, max_features=1, random_state=2).fit(Xs, ys)
+    mu, sd, ym, ysd = Xs.mean(0), Xs.std(0, ddof=1), ys.mean(), ys.std(ddof=1)
+    svr = SVR(kernel="rbf", C=1.0, epsilon=0.1, gamma=0.2).fit((Xs - mu) / sd, (ys - ym) / ysd)
+    for prm, skl in [(modelgen.gbm_from_sklearn(gbr, 5), gbr.predict(X)), (modelgen.rf_from_sklearn(rf, 5), rf.predict(X)),
+                     (modelgen.svr_from_sklearn(svr, mu, sd, ym, ysd), svr.predict((X - mu) / sd) * ysd + ym)]:
+        got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+        assert np.abs(got - oe.predict(prm, X)).max() <= _tol(got), prm["kind"]
+        # independent evaluator; deep RF trees hold thousands of LONG/LAT thresholds, a few of which
+        # fall between a cell centre and its float32 rounding (what sklearn compares): allow 5 %
+        bad = np.abs(got - skl) > 1e-9 * np.abs(skl).max()
+        assert bad.mean() <= (0.05 if prm["kind"] == "rf" else 0.0), (prm["kind"], bad.mean())
+
+
+def test_weighted_ensemble_window_and_accumulate(hip):
+    import torch
+    g, stack, X, Xs, ys, params = _setup(hip, nodata_frac=0.01)
+    kept, wts, tot = hip.models.select_weights([0.31, 0.22, 0.004, 0.18, 0.27, 0.41])
+    assert kept == "bgmrv"
+    sel = [params[KINDS.index(k)] for k in kept]
+    mods = [hip.models.from_oracle_dict(p) for p in sel]
+    want = oe.ensemble(sel, wts, tot, X).reshape(g.nrow, g.ncol)
+    got = hip.ensemble_predict(stack, mods, wts, tot).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    # a window written into a larger strided buffer touches nothing else
+    win = (11, 57, 20, 81)
+    big = torch.full((g.nrow, 128), -7.0, dtype=torch.float64, device="cuda")
+    hip.ensemble_predict(stack, mods, wts, tot, window=win, out=big[11:57, 20:81])
+    b = big.cpu().numpy()
+    assert np.array_equal(b[11:57, 20:81], got[11:57, 20:81], equal_nan=True)
+    b[11:57, 20:81] = -7.0
+    assert (b == -7.0).all()
+    # step-by-step accumulate == the fused loop (V73:471/475 order)
+    acc = hip.predict(stack, mods[0], weight=wts[0])
+    for m, w in zip(mods[1:], wts[1:]):
+        hip.predict(stack, m, weight=w, accumulate=True, out=acc)
+    # (torch may divide by a scalar as a reciprocal multiply, so compare to 1 ulp-ish)
+    assert np.allclose(acc.cpu().numpy() / tot, got, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def test_predict_points_gives_station_residual_inputs(hip):
+    g, stack, X, Xs, ys, params = _setup(hip)
+    for prm in params:
+        m = hip.models.from_oracle_dict(prm)
+        got = m.predict_points(Xs)
+        want = oe.predict(prm, Xs)
+        assert np.abs(got - want).max() <= _tol(want), prm["kind"]
+
+
+def test_seven_predictors_and_host_entry_point(hip):
+    import ctypes as C
+    from machisplin_amd import _lib
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=40, ncol=50, C=5, n=300, gbm_trees=50, rf_trees=5)
+    mods = [hip.models.from_oracle_dict(p) for p in params]
+    wts = [0.3, 0.2, 0.1, 0.2, 0.3, 0.4]
+    want = oe.ensemble(params, wts, 1.5, X).reshape(40, 50)
+    got = hip.ensemble_predict(stack, mods, wts, 1.5).cpu().numpy()
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    # host-pointer ABI: covariates and output in host memory, a row window
+    host = np.ascontiguousarray(stack.planes.cpu().numpy())
+    out = np.empty((25, 50))
+    hs = (C.c_void_p * 6)(*[m._h for m in mods])
+    ws = (C.c_double * 6)(*wts)
+    st = _lib.Stack(host.ctypes.data, 5, _lib.F32, 40 * 50, 50, float("nan"))
+    gs = g.c_struct()
+    _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, 6, 1.5, C.byref(gs), C.byref(st), 10, 35, 0, 50, out.ctypes.data))
+    assert np.array_equal(out, got[10:35], equal_nan=True)
+
+
+def test_loaders_reject_malformed_models(hip):
+    with pytest.raises(hip.MhsError):
+        hip.models.Gbm(0.0, [0, 2], [0, -1], [1.0, 2.0], [5, 0], [1, 0], [1, 0], p=5)  # child out of range
+    with pytest.raises(hip.MhsError):
+        hip.models.Earth([1.0, 2.0], [[0, 0], [3, 0]], [[0, 0], [0, 0]])  # bad dir code
+    with pytest.raises(hip.MhsError):
+        hip.models.RandomForest([0, 1], [0], [0], [-3], [9], [0.0], [1.0], p=5)  # bestvar out of range
+    g, stack, *_ = _setup(hip, nrow=8, ncol=8, n=40, gbm_trees=2, rf_trees=1)
+    with pytest.raises(ValueError):
+        hip.predict(stack, hip.models.Gam([1.0, 2.0, 3.0]))  # p != layers + 2
