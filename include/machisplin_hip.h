@@ -207,6 +207,48 @@ MHS_API int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, d
 MHS_API int mhs_scale_add_dev(const double *a, double divisor, const double *b, double *out,
                               int64_t n, void *stream);
 
+/* ------------------------------------------------------- tile bookkeeping --
+ * Integer windows are half-open [r0,r1) x [c0,c1) in the full grid, rows from the north;
+ * a window array holds 4 int64 per tile: r0, r1, c0, c1.  Tiles are numbered row-major
+ * from the SOUTH-WEST as the reference does (V73:670-681, 1192-1197).  The host functions
+ * need no GPU.                                                                           */
+
+/* terra::crop(x, e): SpatRaster::align(e, "near") intersected with x's extent, window from
+ * colFromX/rowFromY half a cell inside.  ext4 = xmin, xmax, ymin, ymax (terra::ext order).
+ * replaces the geometry of terra::crop at V73:699,728,779-780,835-836,1207,1415-1416     */
+MHS_API int mhs_crop_window(const mhs_grid *g, const double *ext4, int64_t *win4);
+/* Step-3 TPS tile grid (V73:656-681): nRx = ceil(nrow/tile_edge), nCx likewise; fit box =
+ * tile +- fit_overlap (0.2), keep box = tile +- keep_overlap (0.025); fit_win = crop(rast_stack,
+ * b) (V73:699), keep_win = crop(pred, d) (V73:728) in full-grid indices.  Pass NULL arrays to
+ * query nRx/nCx.  The reference hard-codes tile_edge = 1500.                               */
+MHS_API int mhs_step3_tile_windows(const mhs_grid *g, int64_t tile_edge, double fit_overlap,
+                                   double keep_overlap, int64_t *nRx, int64_t *nCx,
+                                   int64_t *fit_win, int64_t *keep_win, int64_t capacity);
+/* machisplin.tiles.create (V73:1165-1208): tile box = grid cell +- feather_d/2 pixels;
+ * boxes[4*n] (xmin,xmax,ymin,ymax) and crop windows win[4*n].                              */
+MHS_API int mhs_tiles_create_windows(const mhs_grid *g, int64_t out_ncol, int64_t out_nrow,
+                                     double feather_d, double *boxes, int64_t *win);
+/* number of seams of an nRx x nCx layout: (nCx-1) nRx vertical + nCx (nRx-1) horizontal     */
+MHS_API int mhs_seam_count(int64_t nRx, int64_t nCx, int64_t *n_seams);
+/* terra::cellFromXY / extract bookkeeping: rows/cols of the cells holding the points (xy is
+ * n x 2 column-major); -1 outside the grid.  V73:145,701,910                               */
+MHS_API int mhs_cells_from_xy(const mhs_grid *g, const double *xy, int64_t n, int64_t *rows,
+                              int64_t *cols);
+/* mean mosaic + seam feathering + first-non-NA overlay: Step 3 mosaic and Step 4 of
+ * machisplin.mltps (V73:739-747, 760-895; merge_mode = 0) or machisplin.tiles.merge
+ * (V73:1392-1546; merge_mode = 1).  tile_dev[h] is a DEVICE buffer holding tile h on its
+ * window tile_win[4h..] (row-major, ld = window width); out_dev is the full grid.
+ * seam_win_out (may be NULL, 4 int64 per seam in creation order, -1 = no strip) returns the
+ * strip windows actually used.  Blocks until done.                                        */
+MHS_API int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx,
+                                   const int64_t *tile_win, const double *const *tile_dev,
+                                   int merge_mode, double *out_dev, int64_t ld,
+                                   int64_t *seam_win_out, void *stream);
+/* terra::extract(r, xy) after mhs_cells_from_xy: gather n cells of a device plane to the
+ * host (NaN for row/col -1).  Step-5 station check V73:910                                */
+MHS_API int mhs_gather_cells_dev(const double *plane_dev, int64_t ld, const int64_t *rows,
+                                 const int64_t *cols, int64_t n, double *out_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,9 @@ from .raster import Geometry, RasterStack
 from . import models
 from .models import predict, ensemble_predict
 from .tps import Tps, interpolate
+from . import tiles, mltps
+from .mltps import mltps_predict, tps_residual_surface
 
 __all__ = ["MhsError", "init", "Geometry", "RasterStack", "Tps", "interpolate", "predict",
-           "ensemble_predict", "models", "_lib"]
+           "ensemble_predict", "models", "tiles", "mltps", "mltps_predict",
+           "tps_residual_surface", "_lib"]

@@ -75,6 +75,15 @@ SIGNATURES = {
                                        C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp]),
     "mhs_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mhs_scale_add_dev": (C.c_int, [_vp, C.c_double, _vp, _vp, _i64, _vp]),
+    "mhs_crop_window": (C.c_int, [C.POINTER(Grid), _vp, _vp]),
+    "mhs_step3_tile_windows": (C.c_int, [C.POINTER(Grid), _i64, C.c_double, C.c_double, C.POINTER(_i64),
+                                         C.POINTER(_i64), _vp, _vp, _i64]),
+    "mhs_tiles_create_windows": (C.c_int, [C.POINTER(Grid), _i64, _i64, C.c_double, _vp, _vp]),
+    "mhs_seam_count": (C.c_int, [_i64, _i64, C.POINTER(_i64)]),
+    "mhs_cells_from_xy": (C.c_int, [C.POINTER(Grid), _vp, _i64, _vp, _vp]),
+    "mhs_mosaic_feather_dev": (C.c_int, [C.POINTER(Grid), _i64, _i64, _vp, C.POINTER(_vp), C.c_int, _vp, _i64,
+                                         _vp, _vp]),
+    "mhs_gather_cells_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
 }
 
 _lock = threading.Lock()

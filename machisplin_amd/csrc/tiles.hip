@@ -1,0 +1,402 @@
+// Tile bookkeeping of machisplin.mltps Step 3/4/5 and machisplin.tiles.create/merge.
+//
+// Host part (integer windows, bit-exact): terra's extent snapping restated
+// (SpatRaster::origin / align(e,"near") / crop -> colFromX,rowFromY), the Step-3 tile
+// grid (V73:656-681), the tiles.create boxes (V73:1170-1197) and the seam strips
+// (ext(as.points(A+B)) -> crop, V73:772-781 / 829-836 / 1408-1416 / 1469-1476).
+// Device part (HBM-bound, one pass per tile / strip over its own window only):
+// NA-aware mean mosaic, linear cross-fade of the seam strips, "first non-NA" overlay
+// (V73:740-746, 783-806, 853-895, 1419-1546) and the Step-5 station gather (V73:910).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include "common.h"
+
+namespace mhs {
+
+// ------------------------------------------------------------ terra snapping --
+static inline double c_round(double x) { return round(x); }  // half away from zero, as terra (C++)
+
+struct Ext { double xmin, xmax, ymin, ymax; };
+struct Win { int64_t r0, r1, c0, c1; };
+
+static inline double g_xmax(const mhs_grid &g) { return g.xmin + (double)g.ncol * g.xres; }
+static inline double g_ymin(const mhs_grid &g) { return g.ymax - (double)g.nrow * g.yres; }
+
+static void grid_origin(const mhs_grid &g, double *ox, double *oy) {
+    double x = g.xmin - g.xres * c_round(g.xmin / g.xres);
+    double y = g.ymax - g.yres * c_round(g.ymax / g.yres);
+    if (fabs((g.xres + x) - fabs(x)) <= 1e-12 * g.xres) x = fabs(x);
+    if (fabs((g.yres + y) - fabs(y)) <= 1e-12 * g.yres) y = fabs(y);
+    *ox = x; *oy = y;
+}
+
+static int64_t col_from_x(const mhs_grid &g, double x) {
+    const double xmax = g_xmax(g);
+    if (x == xmax) return g.ncol - 1;
+    if (x < g.xmin || x > xmax) return -1;
+    return (int64_t)floor((x - g.xmin) / g.xres);
+}
+
+static int64_t row_from_y(const mhs_grid &g, double y) {
+    const double ymin = g_ymin(g);
+    if (y == ymin) return g.nrow - 1;
+    if (y < ymin || y > g.ymax) return -1;
+    return (int64_t)floor((g.ymax - y) / g.yres);
+}
+
+static Ext align_near(const mhs_grid &g, const Ext &e) {
+    double ox, oy;
+    grid_origin(g, &ox, &oy);
+    Ext a;
+    a.xmin = c_round((e.xmin - ox) / g.xres) * g.xres + ox;
+    a.xmax = c_round((e.xmax - ox) / g.xres) * g.xres + ox;
+    a.ymin = c_round((e.ymin - oy) / g.yres) * g.yres + oy;
+    a.ymax = c_round((e.ymax - oy) / g.yres) * g.yres + oy;
+    if (a.xmin == a.xmax) { if (a.xmin <= e.xmin) a.xmax = a.xmax + g.xres; else a.xmin = a.xmin - g.xres; }
+    if (a.ymin == a.ymax) { if (a.ymin <= e.ymin) a.ymax = a.ymax + g.yres; else a.ymin = a.ymin - g.yres; }
+    return a;
+}
+
+// terra::crop(x, e): false if the extents do not overlap
+static bool crop_window(const mhs_grid &g, const Ext &e, Win *w) {
+    const Ext a = align_near(g, e);
+    const double xmn = std::max(a.xmin, g.xmin), xmx = std::min(a.xmax, g_xmax(g));
+    const double ymn = std::max(a.ymin, g_ymin(g)), ymx = std::min(a.ymax, g.ymax);
+    if (!(xmn < xmx && ymn < ymx)) return false;
+    w->c0 = col_from_x(g, xmn + 0.5 * g.xres);
+    w->c1 = col_from_x(g, xmx - 0.5 * g.xres) + 1;
+    w->r0 = row_from_y(g, ymx - 0.5 * g.yres);
+    w->r1 = row_from_y(g, ymn + 0.5 * g.yres) + 1;
+    return true;
+}
+
+static mhs_grid window_geom(const mhs_grid &g, const Win &w) {
+    mhs_grid s;
+    s.xmin = g.xmin + (double)w.c0 * g.xres;
+    s.ymax = g.ymax - (double)w.r0 * g.yres;
+    s.xres = g.xres; s.yres = g.yres;
+    s.nrow = w.r1 - w.r0; s.ncol = w.c1 - w.c0;
+    return s;
+}
+
+static int check_grid(const mhs_grid *g) {
+    MHS_REQUIRE(g && g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
+    return MHS_OK;
+}
+
+// ------------------------------------------------------------------- kernels --
+// base / strip accumulation planes: double sum + uint8 count
+__global__ __launch_bounds__(256) void accum_tile_kernel(const double *__restrict__ tile, int64_t tld,
+                                                         Win w, double *__restrict__ sum,
+                                                         unsigned char *__restrict__ cnt, int64_t ncol) {
+    const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / nc, c = i - r * nc;
+    const double v = tile[r * tld + c];
+    if (!isnan(v)) {
+        const int64_t o = (w.r0 + r) * ncol + (w.c0 + c);
+        sum[o] = sum[o] + v;
+        cnt[o] = (unsigned char)(cnt[o] + 1);
+    }
+}
+
+// bounding box (rows/cols, grid indices) of the cells of window w where A + B is not NA
+__global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ A, Win wa, int64_t lda,
+                                                   const double *__restrict__ B, Win wb, int64_t ldb,
+                                                   Win w, int *__restrict__ box /* rmin,rmax,cmin,cmax */) {
+    const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = w.r0 + i / nc, c = w.c0 + i % nc;
+    const double a = A[(r - wa.r0) * lda + (c - wa.c0)];
+    const double b = B[(r - wb.r0) * ldb + (c - wb.c0)];
+    if (!isnan(a + b)) {
+        atomicMin(&box[0], (int)r); atomicMax(&box[1], (int)r);
+        atomicMin(&box[2], (int)c); atomicMax(&box[3], (int)c);
+    }
+}
+
+// one seam strip: feath = B * t + A * (1 - t), t = (coord - cmin) / delta   (V73:787-798)
+__global__ __launch_bounds__(256) void strip_kernel(const double *__restrict__ A, Win wa, int64_t lda,
+                                                    const double *__restrict__ B, Win wb, int64_t ldb,
+                                                    Win w, int axis_y, double origin, double res,
+                                                    double cmin, double delta, double *__restrict__ sum,
+                                                    unsigned char *__restrict__ cnt, int64_t ncol) {
+    const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t lr = i / nc, lc = i - lr * nc;
+    const int64_t r = w.r0 + lr, c = w.c0 + lc;
+    const bool ina = r >= wa.r0 && r < wa.r1 && c >= wa.c0 && c < wa.c1;
+    const bool inb = r >= wb.r0 && r < wb.r1 && c >= wb.c0 && c < wb.c1;
+    const double a = ina ? A[(r - wa.r0) * lda + (c - wa.c0)] : NAN;   // extend(): NA outside
+    const double b = inb ? B[(r - wb.r0) * ldb + (c - wb.c0)] : NAN;
+    // strip raster's own cell centres: xmin_s + (col + 0.5) xres  /  ymax_s - (row + 0.5) yres
+    const double coord = axis_y ? origin - ((double)lr + 0.5) * res : origin + ((double)lc + 0.5) * res;
+    const double stD2 = (coord - cmin) / delta;
+    const double stD1 = 1.0 - (coord - cmin) / delta;
+    const double v = b * stD2 + a * stD1;
+    if (!isnan(v)) {
+        const int64_t o = r * ncol + c;
+        sum[o] = sum[o] + v;
+        cnt[o] = (unsigned char)(cnt[o] + 1);
+    }
+}
+
+// final.TPS = first non-NA of (mean of strips, mean of tiles)   (V73:887-889, 1528-1540)
+__global__ __launch_bounds__(256) void compose_kernel(const double *__restrict__ ssum,
+                                                      const unsigned char *__restrict__ scnt,
+                                                      const double *__restrict__ bsum,
+                                                      const unsigned char *__restrict__ bcnt,
+                                                      int64_t nrow, int64_t ncol, double *__restrict__ out,
+                                                      int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrow * ncol) return;
+    const int64_t r = i / ncol, c = i - r * ncol;
+    double v;
+    if (scnt[i] > 0) v = ssum[i] / (double)scnt[i];
+    else if (bcnt[i] > 0) v = bsum[i] / (double)bcnt[i];
+    else v = NAN;
+    out[r * ld + c] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ plane, int64_t ld,
+                                                     const int64_t *__restrict__ rows,
+                                                     const int64_t *__restrict__ cols, int64_t n,
+                                                     double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (rows[i] < 0 || cols[i] < 0) ? NAN : plane[rows[i] * ld + cols[i]];
+}
+
+struct Seam { int64_t a, b; int axis_y; };
+
+// seams in creation order: vertical (V73:764-806) then horizontal (V73:815-877)
+static std::vector<Seam> seam_list(int64_t nRx, int64_t nCx) {
+    std::vector<Seam> s;
+    for (int64_t j = 1; j <= nRx; ++j)
+        for (int64_t h = 1; h <= nCx; ++h) {
+            const int64_t v = h + (j * nCx) - nCx;
+            if (h < nCx) s.push_back(Seam{v - 1, v, 0});
+        }
+    int64_t f_clock = 0;
+    for (int64_t j = 1; j <= nRx; ++j)
+        for (int64_t h = 1; h <= nCx; ++h) {
+            ++f_clock;
+            const int64_t f_timer = (nRx * nCx) - nCx + 1;
+            const int64_t v = h + (j * nCx) - nCx;
+            if (f_clock < f_timer) s.push_back(Seam{v - 1, v + nCx - 1, 1});
+        }
+    return s;
+}
+
+static bool intersect(const Win &a, const Win &b, Win *o) {
+    o->r0 = std::max(a.r0, b.r0); o->r1 = std::min(a.r1, b.r1);
+    o->c0 = std::max(a.c0, b.c0); o->c1 = std::min(a.c1, b.c1);
+    return o->r0 < o->r1 && o->c0 < o->c1;
+}
+
+static unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace mhs
+
+using namespace mhs;
+
+extern "C" {
+
+int mhs_crop_window(const mhs_grid *g, const double *ext4, int64_t *win4) {
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE(ext4 && win4, "NULL argument");
+    Win w;
+    if (!crop_window(*g, Ext{ext4[0], ext4[1], ext4[2], ext4[3]}, &w)) {
+        set_error("mhs_crop_window: extents do not overlap");
+        return MHS_ERR_INVALID;
+    }
+    win4[0] = w.r0; win4[1] = w.r1; win4[2] = w.c0; win4[3] = w.c1;
+    return MHS_OK;
+}
+
+int mhs_step3_tile_windows(const mhs_grid *g, int64_t tile_edge, double fit_overlap, double keep_overlap,
+                           int64_t *nRx_out, int64_t *nCx_out, int64_t *fit_win, int64_t *keep_win,
+                           int64_t capacity) {
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE(tile_edge > 0 && nRx_out && nCx_out, "bad arguments");
+    const int64_t nRx = (int64_t)ceil((double)g->nrow / (double)tile_edge);
+    const int64_t nCx = (int64_t)ceil((double)g->ncol / (double)tile_edge);
+    *nRx_out = nRx; *nCx_out = nCx;
+    if (!fit_win && !keep_win) return MHS_OK;  // size query
+    MHS_REQUIRE(fit_win && keep_win && capacity >= nRx * nCx, "window arrays too small");
+    const double xmin = g->xmin, xmax = g_xmax(*g), ymin = g_ymin(*g), ymax = g->ymax;
+    const double longDist = (xmax - xmin) / (double)nCx;
+    const double latDist = (ymax - ymin) / (double)nRx;
+    int64_t m = 0;
+    for (int64_t j = 1; j <= nRx; ++j)
+        for (int64_t h = 1; h <= nCx; ++h, ++m) {
+            const double hm1 = (double)(h - 1), hh = (double)h, jm1 = (double)(j - 1), jj = (double)j;
+            const Ext b{xmin + ((longDist * hm1) - (longDist * fit_overlap)), xmin + ((longDist * hh) + (longDist * fit_overlap)),
+                        (ymin + ((latDist * jm1))) - (latDist * fit_overlap), (ymin + ((latDist * jj))) + (latDist * fit_overlap)};
+            const Ext d{xmin + ((longDist * hm1) - (longDist * keep_overlap)), xmin + ((longDist * hh) + (longDist * keep_overlap)),
+                        (ymin + ((latDist * jm1))) - (latDist * keep_overlap), (ymin + ((latDist * jj))) + (latDist * keep_overlap)};
+            Win wf, wk;
+            if (!crop_window(*g, b, &wf)) { set_error("step3: empty fit window"); return MHS_ERR_NUMERIC; }
+            const mhs_grid gf = window_geom(*g, wf);
+            if (!crop_window(gf, d, &wk)) { set_error("step3: empty keep window"); return MHS_ERR_NUMERIC; }
+            fit_win[4 * m + 0] = wf.r0; fit_win[4 * m + 1] = wf.r1; fit_win[4 * m + 2] = wf.c0; fit_win[4 * m + 3] = wf.c1;
+            keep_win[4 * m + 0] = wf.r0 + wk.r0; keep_win[4 * m + 1] = wf.r0 + wk.r1;
+            keep_win[4 * m + 2] = wf.c0 + wk.c0; keep_win[4 * m + 3] = wf.c0 + wk.c1;
+        }
+    return MHS_OK;
+}
+
+int mhs_tiles_create_windows(const mhs_grid *g, int64_t out_ncol, int64_t out_nrow, double feather_d,
+                             double *boxes, int64_t *win) {
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE(out_ncol >= 1 && out_nrow >= 1 && boxes && win, "bad arguments");
+    feather_d = feather_d / 2;
+    const double xmin = g->xmin, xmax = g_xmax(*g), ymin = g_ymin(*g), ymax = g->ymax;
+    const double long_pix = (xmax - xmin) / (double)g->ncol, lat_pix = (ymax - ymin) / (double)g->nrow;
+    const double longDist = (xmax - xmin) / (double)out_ncol, latDist = (ymax - ymin) / (double)out_nrow;
+    int64_t m = 0;
+    for (int64_t j = 1; j <= out_nrow; ++j)
+        for (int64_t h = 1; h <= out_ncol; ++h, ++m) {
+            const double hm1 = (double)(h - 1), hh = (double)h, jm1 = (double)(j - 1), jj = (double)j;
+            const Ext b{xmin + ((longDist * hm1) - (long_pix * feather_d)), xmin + ((longDist * hh) + (long_pix * feather_d)),
+                        (ymin + ((latDist * jm1))) - (lat_pix * feather_d), (ymin + ((latDist * jj))) + (lat_pix * feather_d)};
+            boxes[4 * m + 0] = b.xmin; boxes[4 * m + 1] = b.xmax; boxes[4 * m + 2] = b.ymin; boxes[4 * m + 3] = b.ymax;
+            Win w;
+            if (!crop_window(*g, b, &w)) { set_error("tiles.create: empty tile"); return MHS_ERR_NUMERIC; }
+            win[4 * m + 0] = w.r0; win[4 * m + 1] = w.r1; win[4 * m + 2] = w.c0; win[4 * m + 3] = w.c1;
+        }
+    return MHS_OK;
+}
+
+int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
+                           const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
+                           int64_t *seam_win_out, void *stream) {
+    if (int rc = require_ready()) return rc;
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE(nRx >= 1 && nCx >= 1 && tile_win && tile_dev && out_dev && ld >= g->ncol, "bad arguments");
+    hipStream_t s = pick_stream(stream);
+    const int64_t n = nRx * nCx, cells = g->nrow * g->ncol;
+    std::vector<Win> tw((size_t)n);
+    for (int64_t h = 0; h < n; ++h) {
+        tw[h] = Win{tile_win[4 * h], tile_win[4 * h + 1], tile_win[4 * h + 2], tile_win[4 * h + 3]};
+        MHS_REQUIRE(0 <= tw[h].r0 && tw[h].r0 < tw[h].r1 && tw[h].r1 <= g->nrow && 0 <= tw[h].c0 &&
+                    tw[h].c0 < tw[h].c1 && tw[h].c1 <= g->ncol && tile_dev[h], "bad tile window");
+    }
+    DevBuf<double> bsum, ssum;
+    DevBuf<unsigned char> bcnt, scnt;
+    DevBuf<int> box;
+    MHS_HIP(bsum.alloc((size_t)cells)); MHS_HIP(ssum.alloc((size_t)cells));
+    MHS_HIP(bcnt.alloc((size_t)cells)); MHS_HIP(scnt.alloc((size_t)cells));
+    MHS_HIP(hipMemsetAsync(bsum.p, 0, sizeof(double) * cells, s));
+    MHS_HIP(hipMemsetAsync(ssum.p, 0, sizeof(double) * cells, s));
+    MHS_HIP(hipMemsetAsync(bcnt.p, 0, (size_t)cells, s));
+    MHS_HIP(hipMemsetAsync(scnt.p, 0, (size_t)cells, s));
+    // mean mosaic of the tiles; the sprc is built by prepending, so it runs last tile -> first
+    for (int64_t h = n - 1; h >= 0; --h) {
+        const int64_t tot = (tw[h].r1 - tw[h].r0) * (tw[h].c1 - tw[h].c0);
+        hipLaunchKernelGGL(accum_tile_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[h],
+                           tw[h].c1 - tw[h].c0, tw[h], bsum.p, bcnt.p, g->ncol);
+    }
+    MHS_HIP(hipGetLastError());
+    std::vector<Seam> seams = seam_list(nRx, nCx);
+    const size_t ns = seams.size();
+    if (n > 1 && ns > 0) {
+        MHS_HIP(box.alloc(4 * ns));
+        std::vector<int> hbox(4 * ns);
+        std::vector<Win> inter(ns);
+        std::vector<char> has(ns, 0);
+        for (size_t k = 0; k < ns; ++k) { hbox[4 * k] = INT32_MAX; hbox[4 * k + 1] = -1; hbox[4 * k + 2] = INT32_MAX; hbox[4 * k + 3] = -1; }
+        MHS_HIP(hipMemcpyAsync(box.p, hbox.data(), sizeof(int) * 4 * ns, hipMemcpyHostToDevice, s));
+        for (size_t k = 0; k < ns; ++k) {
+            const Win &wa = tw[seams[k].a], &wb = tw[seams[k].b];
+            if (!intersect(wa, wb, &inter[k])) continue;
+            has[k] = 1;
+            const int64_t tot = (inter[k].r1 - inter[k].r0) * (inter[k].c1 - inter[k].c0);
+            hipLaunchKernelGGL(bbox_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[seams[k].a], wa, wa.c1 - wa.c0,
+                               tile_dev[seams[k].b], wb, wb.c1 - wb.c0, inter[k], box.p + 4 * k);
+        }
+        MHS_HIP(hipGetLastError());
+        MHS_HIP(hipMemcpyAsync(hbox.data(), box.p, sizeof(int) * 4 * ns, hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipStreamSynchronize(s));
+        // strips enter the mean in collection order: creation order for Step 4 (the stack is built by
+        // prepending and the sprc prepends again), reversed for tiles.merge (c() appends, sprc prepends).
+        // With exactly two tiles there is one seam and terra::merge takes it as is.
+        for (size_t q = 0; q < ns; ++q) {
+            const size_t k = merge_mode ? ns - 1 - q : q;
+            Win w{-1, -1, -1, -1};
+            if (has[k] && hbox[4 * k + 1] >= 0) {
+                // blend.ext = bbox of the CENTRES of the non-NA cells; crop() snaps it back to cells
+                const Ext e{g->xmin + ((double)hbox[4 * k + 2] + 0.5) * g->xres, g->xmin + ((double)hbox[4 * k + 3] + 0.5) * g->xres,
+                            g->ymax - ((double)hbox[4 * k + 1] + 0.5) * g->yres, g->ymax - ((double)hbox[4 * k] + 0.5) * g->yres};
+                if (!crop_window(*g, e, &w)) w = Win{-1, -1, -1, -1};
+            }
+            if (seam_win_out) { seam_win_out[4 * k] = w.r0; seam_win_out[4 * k + 1] = w.r1; seam_win_out[4 * k + 2] = w.c0; seam_win_out[4 * k + 3] = w.c1; }
+            if (w.r0 < 0) continue;
+            const mhs_grid gs = window_geom(*g, w);
+            double origin, res, cfirst, clast;
+            if (seams[k].axis_y) {
+                origin = gs.ymax; res = gs.yres;
+                cfirst = gs.ymax - (0.0 + 0.5) * gs.yres; clast = gs.ymax - ((double)(gs.nrow - 1) + 0.5) * gs.yres;
+            } else {
+                origin = gs.xmin; res = gs.xres;
+                cfirst = gs.xmin + (0.0 + 0.5) * gs.xres; clast = gs.xmin + ((double)(gs.ncol - 1) + 0.5) * gs.xres;
+            }
+            const double cmin = std::min(cfirst, clast), cmax = std::max(cfirst, clast);
+            const double delta = cmax - cmin;  // 0 for a one-cell-wide strip: 0/0 = NA, as in R
+            const Win &wa = tw[seams[k].a], &wb = tw[seams[k].b];
+            const int64_t tot = (w.r1 - w.r0) * (w.c1 - w.c0);
+            hipLaunchKernelGGL(strip_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[seams[k].a], wa, wa.c1 - wa.c0,
+                               tile_dev[seams[k].b], wb, wb.c1 - wb.c0, w, seams[k].axis_y, origin, res, cmin, delta,
+                               ssum.p, scnt.p, g->ncol);
+        }
+        MHS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(compose_kernel, dim3(nblk(cells)), dim3(256), 0, s, ssum.p, scnt.p, bsum.p, bcnt.p,
+                       g->nrow, g->ncol, out_dev, ld);
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipStreamSynchronize(s));  // the temporaries are freed on return
+    return MHS_OK;
+}
+
+int mhs_seam_count(int64_t nRx, int64_t nCx, int64_t *n_seams) {
+    MHS_REQUIRE(nRx >= 1 && nCx >= 1 && n_seams, "bad arguments");
+    *n_seams = (int64_t)seam_list(nRx, nCx).size();
+    return MHS_OK;
+}
+
+int mhs_gather_cells_dev(const double *plane_dev, int64_t ld, const int64_t *rows, const int64_t *cols,
+                         int64_t n, double *out_host, void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(plane_dev && rows && cols && out_host && n >= 0, "bad arguments");
+    if (n == 0) return MHS_OK;
+    hipStream_t s = pick_stream(stream);
+    DevBuf<int64_t> dr, dc;
+    DevBuf<double> dout;
+    MHS_HIP(dr.alloc((size_t)n)); MHS_HIP(dc.alloc((size_t)n)); MHS_HIP(dout.alloc((size_t)n));
+    MHS_HIP(hipMemcpyAsync(dr.p, rows, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+    MHS_HIP(hipMemcpyAsync(dc.p, cols, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gather_kernel, dim3(nblk(n)), dim3(256), 0, s, plane_dev, ld, dr.p, dc.p, n, dout.p);
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+/* terra::cellFromXY for the stations: rows/cols (-1 outside), host only */
+int mhs_cells_from_xy(const mhs_grid *g, const double *xy, int64_t n, int64_t *rows, int64_t *cols) {
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE((xy || n == 0) && rows && cols && n >= 0, "bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = xy[i], y = xy[n + i];
+        const int64_t c = std::isnan(x) ? -1 : col_from_x(*g, x);
+        const int64_t r = std::isnan(y) ? -1 : row_from_y(*g, y);
+        rows[i] = (c < 0 || r < 0) ? -1 : r;
+        cols[i] = (c < 0 || r < 0) ? -1 : c;
+    }
+    return MHS_OK;
+}
+
+}  // extern "C"

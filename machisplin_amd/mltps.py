@@ -1,0 +1,127 @@
+"""Steps 2-5 of ``machisplin.mltps`` (V73:442-930) with every raster-sized operation on the
+GPU: ensemble prediction over the covariate stack, thin-plate spline of the station
+residuals (tiled exactly as the reference tiles it, or globally), seam feathering, the
+final sum and the R^2 selection.  Model FITTING (Step 1 and the final fits) is out of scope:
+callers pass the fitted members' parameters, as a `.Call()` shim would from R.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib, tiles
+from .models import ensemble_predict
+from .raster import Geometry, RasterStack
+from .tps import Tps, interpolate
+
+
+def station_predictors(stack: RasterStack, xy):
+    """terra::extract(rast_stack, xy) (V73:145): covariates at the stations' cells plus the
+    cell-centre LONG/LAT (the knots are CELL CENTRES, not the input coordinates)."""
+    import torch
+    g = stack.geom
+    rows, cols = tiles.cells_from_xy(g, xy)
+    inside = rows >= 0
+    r = torch.from_numpy(np.where(inside, rows, 0)).to(stack.planes.device)
+    c = torch.from_numpy(np.where(inside, cols, 0)).to(stack.planes.device)
+    cov = stack.planes[:, r, c].to(torch.float64).cpu().numpy().T
+    if not np.isnan(stack.nodata):
+        cov[cov == stack.nodata] = np.nan
+    cov[~inside] = np.nan
+    X = np.column_stack([cov, g.x_from_col(cols), g.y_from_row(rows)])
+    X[~inside, -2:] = np.nan
+    return X, rows, cols
+
+
+def ensemble_residuals(models, weights, wt_total, X, resp):
+    """res.FINAL (V73:477-482 ... 608-611, 620): sum_k (resp - pred_k) * w_k / wt.tot."""
+    res = None
+    for m, w in zip(models, weights):
+        rk = (resp - m.predict_points(X)) * w
+        res = rk if res is None else res + rk
+    return res / wt_total
+
+
+def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None, tile_edge: int = 1500,
+                         lambda_=None, gcv_mode: str = "fields", out=None, info=None):
+    """Step 3 + Step 4 (V73:636-897): thin-plate spline of the residuals over the whole grid.
+    Grids larger than `tile_edge` in either direction are cut into ceil(n/tile_edge) tiles with
+    their own fit on the stations of the +-20 % fit box, kept on the +-2.5 % box, mean-mosaicked
+    and seam-feathered; otherwise one global fit (V73:748-753).  tile_edge=None forces the
+    global fit (the north-star primitive).  Returns final.TPS as a device tensor."""
+    import torch
+    dev = torch.device("cuda", _lib.init())
+    knots_xy = np.asarray(knots_xy, dtype=np.float64)
+    resid = np.asarray(resid, dtype=np.float64)
+    if tile_edge is None:
+        nRx = nCx = 1
+    else:
+        nRx, nCx, fit_win, keep_win = tiles.step3_tile_windows(geom, tile_edge)
+    if info is not None:
+        info.update({"nRx": nRx, "nCx": nCx, "tile_n": [], "lambda": []})
+    if nRx * nCx == 1:
+        fit = Tps(knots_xy, resid, lambda_=lambda_, gcv_mode=gcv_mode)
+        if info is not None:
+            info["tile_n"].append(fit.n); info["lambda"].append(fit.lambda_)
+        return interpolate(geom, fit, out=out)
+    rows, cols = tiles.cells_from_xy(geom, knots_xy)
+    ok = rows >= 0
+    if cov1_at_stations is not None:
+        ok &= ~np.isnan(np.asarray(cov1_at_stations, dtype=np.float64))
+    bufs = []
+    for h in range(nRx * nCx):
+        fr0, fr1, fc0, fc1 = (int(v) for v in fit_win[h])
+        kr0, kr1, kc0, kc1 = (int(v) for v in keep_win[h])
+        sel = np.flatnonzero(ok & (rows >= fr0) & (rows < fr1) & (cols >= fc0) & (cols < fc1))
+        if sel.size < 10:  # V73:710-721: the tile is all zeros
+            bufs.append(torch.zeros((kr1 - kr0, kc1 - kc0), dtype=torch.float64, device=dev))
+            if info is not None:
+                info["tile_n"].append(int(sel.size)); info["lambda"].append(float("nan"))
+            continue
+        fit = Tps(knots_xy[sel], resid[sel], lambda_=lambda_, gcv_mode=gcv_mode)
+        gf = geom.window(fr0, fr1, fc0, fc1)  # terra::rast(rb): geometry of the fit raster
+        bufs.append(interpolate(gf, fit, window=(kr0 - fr0, kr1 - fr0, kc0 - fc0, kc1 - fc0)))
+        if info is not None:
+            info["tile_n"].append(fit.n); info["lambda"].append(fit.lambda_)
+    return tiles.mosaic_feather(geom, nRx, nCx, keep_win, bufs, merge_mode=False, out=out)
+
+
+def mltps_predict(stack: RasterStack, int_xy, resp, models, weights, wt_total, tps: bool = True,
+                  tile_edge: int = 1500, lambda_=None, gcv_mode: str = "fields"):
+    """machisplin.mltps Steps 2-5 for ONE response layer, given the fitted ensemble members.
+
+    Returns a dict mirroring ``omega[[i]]`` (V73:914-930, 946-955): ``final`` (device tensor),
+    ``residuals`` (n x 3: residual, long, lat), ``summary`` (r2 ensemble / r2 final) plus the
+    intermediate ``pred_elev`` and ``final_tps`` planes."""
+    import torch
+    g = stack.geom
+    X, rows, cols = station_predictors(stack, int_xy)
+    keep = ~np.isnan(X).any(axis=1) & ~np.isnan(np.asarray(resp, dtype=np.float64))  # complete.cases, V73:154
+    X, rows, cols = X[keep], rows[keep], cols[keep]
+    y = np.asarray(resp, dtype=np.float64)[keep]
+    # Step 2 (V73:447-620)
+    pred_elev = ensemble_predict(stack, models, weights, wt_total)
+    res_final = ensemble_residuals(models, weights, wt_total, X, y)
+    tss = float(np.sum((y - y.mean()) ** 2))
+    rsq_model = 1.0 - float(np.sum(res_final ** 2)) / tss
+    out = {"pred_elev": pred_elev, "rsq_model": rsq_model, "n_stations": int(y.size)}
+    knots = X[:, -2:]  # LONG, LAT columns of dat_tps (V73:688,751)
+    if not tps:  # V73:934-953
+        out.update({"final": pred_elev, "residuals": np.column_stack([res_final, knots]),
+                    "summary": {"r2 ensemble": rsq_model}})
+        return out
+    # Step 3 + 4 (V73:636-897)
+    info = {}
+    final_tps = tps_residual_surface(g, knots, res_final, cov1_at_stations=X[:, 0], tile_edge=tile_edge,
+                                     lambda_=lambda_, gcv_mode=gcv_mode, info=info)
+    # Step 5 (V73:902-930): sum, extract at the stations, keep the sum iff it improves R^2
+    total = torch.empty_like(pred_elev)
+    st = torch.cuda.current_stream(pred_elev.device).cuda_stream
+    _lib.check(_lib.lib().mhs_scale_add_dev(pred_elev.data_ptr(), 1.0, final_tps.data_ptr(), total.data_ptr(),
+                                            total.numel(), st))
+    f_actual = tiles.extract(total, rows, cols)
+    rsq_final = 1.0 - float(np.sum((y - f_actual) ** 2)) / tss
+    out.update({"final_tps": final_tps, "rsq_final": rsq_final, "tps_info": info,
+                "residuals": np.column_stack([y - f_actual, knots]),
+                "summary": {"r2 ensemble": rsq_model, "r2 final": rsq_final},
+                "final": total if rsq_final > rsq_model else pred_elev})
+    return out

@@ -1,0 +1,163 @@
+"""GPU parity: mosaic / feather / overlay kernels and the tiled Step 2-5 flow (through the
+C ABI) vs the oracle's literal restatement of V73:636-930 and tiles.create/merge."""
+import numpy as np
+import pytest
+
+from oracle import ensemble as oe
+from oracle import tiles as ot
+from oracle import tps as otps
+
+pytestmark = pytest.mark.gpu
+
+
+def _og(g):
+    return ot.Geom(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol)
+
+
+def _rand_tiles(windows, seed, nan_frac=0.0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for w in windows:
+        t = rng.standard_normal((w[1] - w[0], w[3] - w[2]))
+        if nan_frac:
+            t[rng.random(t.shape) < nan_frac] = np.nan
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("nrow,ncol,edge,xmin,ymax", [(300, 400, 100, -78.0, -5.0), (130, 250, 128, 10.25, 45.5),
+                                                      (260, 120, 128, -0.05, 0.11), (90, 95, 100, -78.0, -5.0)])
+def test_step4_mosaic_feather_matches_oracle(hip, nrow, ncol, edge, xmin, ymax):
+    import torch
+    g = hip.Geometry(xmin, ymax, 1 / 1200, 1 / 1200, nrow, ncol)
+    nRx, nCx, fit, keep = hip.tiles.step3_tile_windows(g, edge)
+    tiles = _rand_tiles(keep, nrow)
+    dev = [torch.from_numpy(t).cuda() for t in tiles]
+    got, seams = hip.tiles.mosaic_feather(g, nRx, nCx, keep, dev, return_seams=True)
+    og = _og(g)
+    kw = [tuple(int(v) for v in w) for w in keep]
+    layers = [ot.extend_full(og, kw[h], tiles[h]) for h in range(len(kw))]
+    base = ot.mosaic_mean(layers[::-1])
+    want = ot.feather_and_merge(og, nRx, nCx, kw, tiles, base)
+    assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)  # same operations, same order: same bits
+
+
+def test_tiles_merge_with_na_cells_matches_oracle(hip):
+    import torch
+    g = hip.Geometry(-78.0, -5.0, 1 / 1200, 1 / 1200, 240, 330)
+    xy = np.random.default_rng(0).uniform([g.xmin, g.ymin], [g.xmax, g.ymax], (50, 2))
+    t = hip.tiles.tiles_create(g, xy, out_ncol=3, out_nrow=2, feather_d=30)
+    tiles = _rand_tiles(t["win"], 3, nan_frac=0.05)
+    # a NA band at a tile edge shrinks the as.points() bounding box of the seam
+    tiles[0][:, -4:] = np.nan
+    dev = [torch.from_numpy(x).cuda() for x in tiles]
+    got = hip.tiles.tiles_merge(g, t["win"], dev, in_ncol=3, in_nrow=2).cpu().numpy()
+    wins = [tuple(int(v) for v in w) for w in t["win"]]
+    want = ot.tiles_merge(_og(g), wins, tiles, 3, 2)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.allclose(got, want, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def _ensemble_inputs(hip, nrow, ncol, n, seed):
+    from machisplin_amd import synth
+    g = synth.grid(nrow, ncol)
+    planes, nodata = synth.covariates(g, 3, seed, dtype="f32", nodata_frac=0.002)
+    stack = hip.RasterStack(g, planes, nodata)
+    xy, rows, cols, uv = synth.stations(g, n, seed)
+    host = planes.cpu().numpy().astype(np.float64)
+    x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, nrow, ncol)
+    X = oe.stack_predictors(host, (x, y))
+    Xs = X[rows * ncol + cols]
+    resp = synth.response(np.nan_to_num(Xs), uv, seed)
+    ok = ~np.isnan(Xs).any(axis=1)
+    params = synth.ensemble_params(Xs[ok], resp[ok], seed, n_gbm_trees=150, n_rf_trees=10)
+    return g, stack, host, X, xy, resp, params
+
+
+@pytest.mark.parametrize("tile_edge", [100, 1500])
+def test_mltps_steps_2_to_5_end_to_end(hip, tile_edge):
+    """G8 mini: 600 stations, 3 covariates, 220 x 290 grid; tile edge 100 forces 3 x 3 TPS tiles
+    (edge 1500 takes the single-tile branch V73:748-753)."""
+    g, stack, host, X, xy, resp, params = _ensemble_inputs(hip, 220, 290, 600, 31)
+    kept, wts, tot = hip.models.select_weights([0.31, 0.22, 0.12, 0.18, 0.27, 0.41])
+    mods = [hip.models.from_oracle_dict(p) for p in params]
+    res = hip.mltps_predict(stack, xy, resp, mods, wts, tot, tps=True, tile_edge=tile_edge)
+    # ---- oracle: the same flow, literally (V73:447-930)
+    og = _og(g)
+    rows = np.array([og.row_from_y(v) for v in xy[:, 1]])
+    cols = np.array([og.col_from_x(v) for v in xy[:, 0]])
+    Xs = X[rows * g.ncol + cols]
+    keep = ~np.isnan(Xs).any(axis=1)
+    Xs, y = Xs[keep], resp[keep]
+    pred = oe.ensemble(params, wts, tot, X).reshape(g.nrow, g.ncol)
+    res_final = None
+    for p, w in zip(params, wts):
+        rk = (y - oe.predict(p, Xs)) * w
+        res_final = rk if res_final is None else res_final + rk
+    res_final = res_final / tot
+    assert res["n_stations"] == keep.sum()
+    assert np.nanmax(np.abs(res["pred_elev"].cpu().numpy() - pred)) < 1e-10 * np.nanmax(np.abs(pred))
+    # TPS at the GPU's own lambdas (flat GCV minimum), then the bookkeeping must agree exactly
+    lam = res["tps_info"]["lambda"]
+    nRx, nCx, fw, kw = ot.step3_windows(og, tile_edge)
+    assert (nRx, nCx) == (res["tps_info"]["nRx"], res["tps_info"]["nCx"])
+    knots = Xs[:, -2:]
+    if nRx * nCx == 1:
+        final_tps = otps.predict_grid(otps.fit(knots, res_final, lam=lam[0]), og.xmin, og.ymax, og.xres, og.yres, og.nrow, og.ncol)
+    else:
+        tiles = []
+        for h in range(nRx * nCx):
+            sel = ot.stations_in_window(og, fw[h], knots, host[0])
+            assert sel.size == res["tps_info"]["tile_n"][h]
+            gf = ot.window_geom(og, fw[h])
+            wk = (kw[h][0] - fw[h][0], kw[h][1] - fw[h][0], kw[h][2] - fw[h][2], kw[h][3] - fw[h][2])
+            m = otps.fit(knots[sel], res_final[sel], lam=lam[h])
+            tiles.append(otps.predict_grid(m, gf.xmin, gf.ymax, gf.xres, gf.yres, gf.nrow, gf.ncol, *wk))
+        layers = [ot.extend_full(og, kw[h], tiles[h]) for h in range(len(kw))]
+        final_tps = ot.feather_and_merge(og, nRx, nCx, kw, tiles, ot.mosaic_mean(layers[::-1]))
+    got_tps = res["final_tps"].cpu().numpy()
+    assert np.abs(got_tps - final_tps).max() < 1e-7 * np.abs(final_tps).max()
+    final, rsq_model, rsq_final, resid = ot.step5_combine(og, pred, final_tps, knots, y)
+    assert abs(res["rsq_model"] - rsq_model) < 1e-9 and abs(res["rsq_final"] - rsq_final) < 1e-7
+    got = res["final"].cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(final))
+    assert np.nanmax(np.abs(got - final)) < 1e-7 * np.nanmax(np.abs(final))
+    assert np.abs(res["residuals"][:, 0] - resid).max() < 1e-6
+    # and with the oracle's own GCV lambdas the surface stays within the north-star 1e-6
+    if nRx * nCx == 1:
+        ref = otps.predict_grid(otps.fit(knots, res_final), og.xmin, og.ymax, og.xres, og.yres, og.nrow, og.ncol)
+        assert np.abs(got_tps - ref).max() < 1e-6 * np.abs(ref).max()
+
+
+def test_sparse_tile_becomes_zero_tile(hip):
+    """V73:710-721: fewer than 10 stations in a fit box => that tile is all zeros."""
+    g = hip.Geometry(-78.0, -5.0, 1 / 1200, 1 / 1200, 200, 200)
+    rng = np.random.default_rng(2)
+    # stations only in the western half
+    cols = rng.integers(0, 60, 300)
+    rows = rng.integers(0, 200, 300)
+    cells = np.unique(rows * 200 + cols)
+    rows, cols = np.divmod(cells, 200)
+    xy = np.column_stack([g.x_from_col(cols), g.y_from_row(rows)])
+    resid = rng.standard_normal(xy.shape[0])
+    info = {}
+    surf = hip.tps_residual_surface(g, xy, resid, tile_edge=100, lambda_=1e-2, info=info).cpu().numpy()
+    assert info["nRx"] == 2 and info["nCx"] == 2
+    assert min(info["tile_n"]) < 10 and max(info["tile_n"]) > 100
+    nRx, nCx, fit, keep = hip.tiles.step3_tile_windows(g, 100)
+    east_only = np.zeros((200, 200), dtype=bool)
+    for h in (1, 3):
+        east_only[keep[h][0]:keep[h][1], keep[h][2]:keep[h][3]] = True
+    for h in (0, 2):
+        east_only[keep[h][0]:keep[h][1], keep[h][2]:keep[h][3]] = False
+    assert (surf[east_only] == 0).all() and not np.isnan(surf).any()
+
+
+def test_extract_gathers_station_cells(hip):
+    import torch
+    g = hip.Geometry(-78.0, -5.0, 0.01, 0.01, 50, 60)
+    plane = torch.arange(50 * 60, dtype=torch.float64, device="cuda").reshape(50, 60)
+    xy = np.array([[-77.995, -5.005], [-77.405, -5.495], [-79.0, -5.1]])
+    rows, cols = hip.tiles.cells_from_xy(g, xy)
+    got = hip.tiles.extract(plane, rows, cols)
+    assert got[0] == 0 and got[1] == 49 * 60 + 59 and np.isnan(got[2])
