@@ -1,15 +1,20 @@
 #!/usr/bin/env python
-"""bench.py -- MACHISPLIN hot path on MI355X: one "step" = one pass of the path over one
-synthetic input set already resident in HBM: TPS fit on the station residuals (HIP) +
-ensemble/TPS evaluation of every grid cell (HIP) [+ output all-gather when N > 1].
+"""bench.py -- MACHISPLIN hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+One "step" = one pass of machisplin.mltps Steps 2-5 (V73:442-930) over one synthetic input
+set already resident in HBM: six-member ensemble prediction of every grid cell, station
+residuals, thin-plate-spline fit on the residuals (GCV lambda), TPS evaluation of every
+cell, the final sum and the R^2 selection [+ coefficient broadcast and ONE all-gather of
+the row bands when N > 1].  Model fitting (Step 1) is out of scope.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement); the extra objects are
-`roofline` (dominant kernel, algorithmic flops per launch / HIP-event duration) and
-`cpu_baseline` (the oracle timed on the host cores on a bounded sample).
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (algorithmic work per
+launch from SURVEY.md section 8d divided by its HIP-event duration on the launch stream);
+`cpu_baseline` is the oracle's C restatement timed on this box's host cores on a bounded
+sample of the same workload.
 """
 import argparse
 import json
@@ -22,129 +27,179 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector == FP64 MFMA peak (v_mfma_f64_16x16x4 measured 75.3)
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64: vector == MFMA peak (v_mfma_f64_16x16x4 measured 75.3 TF)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the north-star target is quoted on
+    "cfg3": dict(stations=5000, side=10000, layers=3, gbm_trees=10000, rf_trees=500, ensemble=True,
+                 name="cfg3: 5000 stations, 3 covariates, 10000x10000 grid, 6-model ensemble + TPS residual correction"),
+    # BASELINE.json configs[1]
+    "cfg2": dict(stations=2000, side=2000, layers=3, gbm_trees=0, rf_trees=0, ensemble=False,
+                 name="cfg2: 2000 stations, 2000x2000 grid, TPS only"),
+    # a small version of cfg3 for quick checks (NOT a bench line)
+    "cfg3-mini": dict(stations=1000, side=1500, layers=3, gbm_trees=500, rf_trees=50, ensemble=True,
+                      name="cfg3-mini (debug only)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg2-fixed-lambda"])
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-class TpsOnlyWorkload:
-    """BASELINE.json configs[1]: 2 000 synthetic stations, 2 000 x 2 000 grid, TPS only
-    (global mode: one fit on all stations, every cell evaluated against every knot)."""
-
-    name = "cfg2: 2000 stations, 2000x2000 grid, TPS-only (global fit, GCV lambda)"
-
-    def __init__(self, mhs, torch, dist, rank, world, n_stations=2000, side=2000, fixed_lambda=None):
-        from machisplin_amd import synth
-        self.mhs, self.torch, self.dist, self.rank, self.world = mhs, torch, dist, rank, world
+class Workload:
+    def __init__(self, cfg, mhs, torch, dist, rank, world):
+        from machisplin_amd import sharded, synth
+        self.cfg, self.mhs, self.torch = cfg, mhs, torch
+        self.rank, self.world = rank, world
+        side, n = cfg["side"], cfg["stations"]
         self.geom = synth.grid(side, side)
-        seed = synth.BASE_SEED + 2
-        self.xy, _, _, uv = synth.stations(self.geom, n_stations, seed)
-        self.resid = synth.tps_residual(uv, seed)
-        self.n = n_stations
-        self.fixed_lambda = fixed_lambda
-        self.band = -(-side // world)  # rows per rank (last band may be short)
-        self.r0 = min(rank * self.band, side)
-        self.r1 = min(self.r0 + self.band, side)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.out = torch.zeros((self.band * world, side), dtype=torch.float64, device=dev)
-        self.pack = torch.zeros(3 * n_stations + 16, dtype=torch.float64, device=dev)
-        self.eval_ms = []
-        self.fit_ms = []
+        seed = synth.BASE_SEED + 3
+        planes, nodata = synth.covariates(self.geom, cfg["layers"], seed, dtype="f32")
+        self.stack = mhs.RasterStack(self.geom, planes, nodata)
+        self.xy, rows, cols, uv = synth.stations(self.geom, n, seed)
+        cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+        X = np.column_stack([cov, self.xy])
+        if cfg["ensemble"]:
+            self.resp = synth.response(X, uv, seed)
+            self.params = synth.ensemble_params(X, self.resp, seed, n_gbm_trees=cfg["gbm_trees"], n_rf_trees=cfg["rf_trees"])
+            _, self.weights, self.wt_total = mhs.models.select_weights(synth.OPTX_WEIGHTS)
+        else:  # TPS only: a zero "ensemble" (lm with zero coefficients, weight 1) so resp IS the residual
+            self.resp = synth.tps_residual(uv, seed)
+            self.params = [{"kind": "lm", "coef": np.zeros(cfg["layers"] + 3)}]
+            self.weights, self.wt_total = [1.0], 1.0
+        self.models = [mhs.models.from_oracle_dict(p) for p in self.params]
+        self.X = X
+        self.ops = sharded.HipOps(self.stack, self.xy, self.resp, self.models, self.weights, self.wt_total, timed=True)
+        self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side)
         self.cells = side * side
-        self.last_fit = None
+        self.last = None
 
-    # rank 0 fits; coefficients (KBs) are broadcast; every rank evaluates its row band;
-    # one all-gather stitches the grid (SURVEY.md section 8e)
     def step(self):
-        mhs, torch = self.mhs, self.torch
-        n = self.n
-        if self.rank == 0:
-            t0 = time.perf_counter()
-            fit = mhs.Tps(self.xy, self.resid, lambda_=self.fixed_lambda)
-            self.fit_ms.append((time.perf_counter() - t0) * 1e3)
-            if self.world > 1:
-                host = np.concatenate([fit.knots[:, 0], fit.knots[:, 1], fit.c, fit.d, fit.center,
-                                       fit.scale, [fit.lambda_], np.zeros(8)])
-                self.pack.copy_(torch.from_numpy(host))
-        if self.world > 1:
-            self.dist.broadcast(self.pack, src=0)
-            if self.rank != 0:
-                p = self.pack.cpu().numpy()
-                fit = mhs.Tps.from_coef(np.column_stack([p[:n], p[n:2 * n]]), p[2 * n:3 * n],
-                                        p[3 * n:3 * n + 3], p[3 * n + 7], p[3 * n + 3:3 * n + 5],
-                                        p[3 * n + 5:3 * n + 7])
-        self.last_fit = fit
-        stream = torch.cuda.current_stream().cuda_stream
-        lib = mhs._lib.lib()
-        if self.r1 > self.r0:
-            mhs._lib.check(lib.mhs_timer_start(stream))
-            mhs.interpolate(self.geom, fit, window=(self.r0, self.r1, 0, self.geom.ncol),
-                            out=self.out[self.r0:self.r1])
-            import ctypes
-            ms = ctypes.c_double()
-            mhs._lib.check(lib.mhs_timer_stop(stream, ctypes.byref(ms)))
-            self.eval_ms.append(ms.value)
-        if self.world > 1:
-            band = self.out[self.rank * self.band:(self.rank + 1) * self.band]
-            self.dist.all_gather_into_tensor(self.out, band)
+        self.last = self.run.step()
 
-    def roofline(self):
-        """Dominant GPU kernel of this workload's cell path: tps_eval_grid_kernel.
-        Algorithmic flops (log counted as ONE flop): 8 N + 6 per cell."""
-        ms = float(np.mean(self.eval_ms[-max(1, len(self.eval_ms) // 2):]))
-        cells = (self.r1 - self.r0) * self.geom.ncol
-        flops = cells * (8.0 * self.n + 6.0)
-        ach = flops / (ms * 1e-3) / 1e12
-        return {"kernel": "tps_eval_grid_kernel", "bound": "mfma", "achieved": ach,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                "traffic": None, "launch_ms": ms,
-                "note": "FP64 VALU/transcendental-bound (FP64 MFMA shares the DP pipe and peak); "
-                        "8N+6 algorithmic flop per cell with log counted as one flop"}
+    # ---- algorithmic work per launch of the heavy kernels ----------------
+    def kernel_table(self):
+        ops = self.ops
+        band_cells = (self.run.r1 - self.run.r0) * self.geom.ncol
+        n = ops.X.shape[0]
+        rows = []
 
-    def extras(self):
-        fit_ms = float(np.mean(self.fit_ms)) if self.fit_ms else None
-        ex = {"tps_fit_ms": fit_ms, "tps_eval_ms_per_rank": float(np.mean(self.eval_ms)),
-              "lambda": self.last_fit.lambda_}
-        if fit_ms:
-            m = self.n - 3
-            # model flops of the solve: Cholesky (n-3)^3/3 (fixed lambda) or the tridiagonal
-            # reduction 4/3 (n-3)^3 (GCV)
-            flops = m ** 3 / 3.0 if self.fixed_lambda is not None else 4.0 * m ** 3 / 3.0
-            ex["tps_solve_gflops"] = flops / (fit_ms * 1e-3) / 1e9
-            ex["tps_solve_flop_model"] = "(n-3)^3/3 Cholesky" if self.fixed_lambda is not None else "4/3 (n-3)^3 tridiagonal reduction (GCV)"
-        return ex
+        def mean_ms(key):
+            v = ops.timings.get(key, [])
+            v = v[-max(1, len(v) // 2):]
+            return float(np.mean(v)) if v else None
+
+        ms = mean_ms("tps_eval_ms")
+        if ms:
+            fl = band_cells * (8.0 * n + 6.0)
+            rows.append({"kernel": "tps_eval_grid_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "8N+6 flop/cell, log = 1 flop; FP64 VALU/"
+                         "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
+        for prm in self.params:
+            k = prm["kind"]
+            ms = mean_ms("model_%s_ms" % k)
+            if not ms:
+                continue
+            if k == "svr":
+                nsv, p = prm["sv"].shape
+                fl = band_cells * nsv * (3.0 * p + 2.0)
+                rows.append({"kernel": "svr_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop"})
+            elif k in ("gbm", "rf"):
+                visits = self.mean_visits[k] * band_cells
+                by = visits * 16.0
+                rows.append({"kernel": "tree_kernel<%s>" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "%.1f node visits/cell x 16 B node record "
+                             "(LDS-latency-bound walk; node bytes are served from LDS, not HBM)" % self.mean_visits[k]})
+            else:
+                by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
+                rows.append({"kernel": "%s_kernel" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "read C fp32 planes + read-modify-write fp64 out"})
+        for r in rows:
+            r["frac"] = r["achieved"] / r["peak"]
+            r["traffic"] = None
+        return rows
+
+    def measure_mean_visits(self):
+        """mean node visits per cell of the tree members (host walk over the station sample)."""
+        from machisplin_amd import synth
+        self.mean_visits = {}
+        for prm in self.params:
+            if prm["kind"] in ("gbm", "rf"):
+                self.mean_visits[prm["kind"]] = synth.mean_tree_visits(prm, self.X[:256])
 
     def cpu_baseline(self):
-        """The oracle (kind 'port') on this box's host cores: numpy fit (QR + eigen + GCV)
-        once, and the plain-C pair loop on a row band sized for ~10-20 s of CPU work."""
-        from oracle import cbind, tps as otps
-        threads = min(64, os.cpu_count() or 1)  # one socket of the GPU box
-        t0 = time.perf_counter()
-        m = otps.fit(self.xy, self.resid, lam=self.fixed_lambda)
-        t_fit = time.perf_counter() - t0
+        """kind 'port': the oracle's C restatement (OpenMP over cells, one socket's worth of threads) on a
+        row band sized for ~15 s, plus the numpy QR+eigen+GCV fit; extrapolated linearly to the grid."""
+        from oracle import cbind, ensemble as oe, tps as otps
+        threads = min(64, os.cpu_count() or 1)
         g = self.geom
-        probe_rows = 8
+        X, y = self.ops.X, self.ops.y
+        res = None
+        for p, w in zip(self.params, self.weights):
+            rk = (y - cbind.predict(p, X, threads)) * w
+            res = rk if res is None else res + rk
+        res = res / self.wt_total
         t0 = time.perf_counter()
-        cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, 0, probe_rows, 0, g.ncol, threads=threads)
-        rate = probe_rows * g.ncol / max(time.perf_counter() - t0, 1e-6)  # cells/s, cold
-        rows = int(min(g.nrow, max(threads, rate * 12.0 / g.ncol)))
-        t0 = time.perf_counter()
-        cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, 0, rows, 0, g.ncol, threads=threads)
-        t_eval = time.perf_counter() - t0
-        t_full = t_fit + t_eval * (g.nrow / rows)
-        return {"value": self.cells / t_full / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "port",
-                "sample": f"numpy QR+eigen+GCV fit of {self.n} stations ({t_fit:.2f} s, BLAS threads) + C pair loop on "
-                          f"{rows} of {g.nrow} rows with {threads} OpenMP threads ({t_eval:.2f} s), eval extrapolated "
-                          f"linearly to the full grid",
-                "fit_s": t_fit, "eval_s_full_grid": t_eval * (g.nrow / rows)}
+        m = otps.fit(X[:, -2:], res)
+        t_fit = time.perf_counter() - t0
+        host = None
+
+        def band(rows):
+            nonlocal host
+            cov = self.stack.planes[:, :rows].cpu().numpy().astype(np.float64)
+            xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol, 0, rows)
+            Xg = oe.stack_predictors(cov, (xs, ys))
+            t0 = time.perf_counter()
+            pred = cbind.ensemble(self.params, self.weights, self.wt_total, Xg, threads)
+            tps = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, 0, rows, 0, g.ncol, threads=threads)
+            host = pred.reshape(rows, g.ncol) + tps
+            return time.perf_counter() - t0
+
+        probe = max(1, min(g.nrow, 64 * 10000 // g.ncol // 8))
+        t_probe = band(probe)
+        rows = int(min(g.nrow, max(probe, probe * 15.0 / max(t_probe, 1e-3))))
+        t_band = band(rows)
+        t_cells = t_band * (g.nrow / rows)
+        # the CPU sample doubles as a full-size spot check of the GPU result
+        gpu = self.last["final"][:rows].cpu().numpy()
+        err = float(np.nanmax(np.abs(gpu - host)) / np.nanmax(np.abs(host)))
+        return {"value": self.cells / (t_fit + t_cells) / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "port",
+                "sample": f"C restatement (OpenMP, {threads} threads) of ensemble + TPS evaluation on {rows} of {g.nrow} rows "
+                          f"({t_band:.1f} s, extrapolated linearly to the grid: {t_cells:.0f} s) + numpy QR/eigen/GCV fit of "
+                          f"{X.shape[0]} stations ({t_fit:.1f} s)",
+                "fit_s": t_fit, "cells_s_full_grid": t_cells, "gpu_vs_cpu_sample_max_rel_err": err}
+
+
+class PerModelOps:
+    """HipOps with the Step-2 raster loop issued member by member (same launches, same order as
+    mhs_ensemble_predict_dev) so that each member's kernel gets its own HIP-event timing."""
+
+    def __init__(self, ops):
+        self.o = ops
+        self.device = ops.device
+
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+    def ensemble_band(self, r0, r1, out):
+        o = self.o
+        g = o.stack.geom
+        from machisplin_amd.models import predict
+        kinds = {"Gbm": "gbm", "Gam": "lm", "Nnet": "nnet", "Earth": "earth", "RandomForest": "rf", "Ksvm": "svr"}
+        for k, (m, w) in enumerate(zip(o.models, o.weights)):
+            key = "model_%s_ms" % kinds[type(m).__name__]
+            o.timings.setdefault(key, [])
+            o._timed(key, lambda: predict(o.stack, m, window=(r0, r1, 0, g.ncol), weight=w, accumulate=k > 0, out=out))
+        st = o.torch.cuda.current_stream(o.device).cuda_stream
+        o._lib.check(o._lib.lib().mhs_scale_add_dev(out.data_ptr(), o.wt_total, None, out.data_ptr(), out.numel(), st))
 
 
 def main():
@@ -163,8 +218,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    wl = TpsOnlyWorkload(mhs, torch, dist, rank, world,
-                         fixed_lambda=1e-3 if args.workload == "cfg2-fixed-lambda" else None)
+    cfg = WORKLOADS[args.workload]
+    wl = Workload(cfg, mhs, torch, dist, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -186,6 +241,12 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        wl.measure_mean_visits()
+        table = wl.kernel_table()
+        dom = max(table, key=lambda r: r["launch_ms"])
+        tm = wl.ops.timings
+        fit_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):]))
+        m = wl.ops.X.shape[0] - 3
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
             "value": wl.cells * args.steps / dt / 1e6,
@@ -197,12 +258,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl.name, "stations": wl.n, "grid": [wl.geom.nrow, wl.geom.ncol],
-                       "mode": "global TPS (single fit), row-band shard + all-gather",
-                       "parallelism": f"rowband{world}"},
-            "roofline": wl.roofline(),
+            "config": {"workload": cfg["name"], "stations": cfg["stations"], "grid": [cfg["side"], cfg["side"]],
+                       "covariates": "%d x float32 planes resident in HBM" % cfg["layers"],
+                       "members": [p["kind"] for p in wl.params], "gbm_trees": cfg["gbm_trees"], "rf_trees": cfg["rf_trees"],
+                       "tps_mode": "global (one fit on all stations, GCV lambda, V73:748-753)",
+                       "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world},
+            "roofline": {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")},
+            "kernels": table,
+            "tps_fit_ms": fit_ms,
+            "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,
+            "tps_solve_flop_model": "4/3 (n-3)^3: Householder tridiagonalisation of Q2'KQ2 (GCV path)",
+            "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
-        res.update(wl.extras())
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(res), flush=True)

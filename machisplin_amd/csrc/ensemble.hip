@@ -64,6 +64,24 @@ struct mhs_model {
     int64_t n_nodes = 0;
     double init_f = 0;
     bool lds_ok = true;
+    // gbm predicate-LUT fast path (trees with <= 6 splits): see gbm_lut_kernel
+    int lut_S = 0;                       // splits per tree after padding (0 = path unavailable)
+    double *lut = nullptr;               // device, n_trees_padded << lut_S leaf values
+    int *lut_meta = nullptr;             // device, 12 dwords per tree: tkey[6] (float bits), key offset[6]
+    std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
+    std::vector<double> lut_thr;         // host, n_trees x lut_S split values
+    int n_trees_padded = 0;
+    mhs_grid meta_grid = {0, 0, 0, 0, 0, 0};  // geometry lut_meta / rf_nodes were built for
+    int meta_C = -1;
+    // randomForest level-synchronous walk (rf_walk_kernel): available when every split node has
+    // rightDaughter == leftDaughter + 1 (how randomForest numbers its nodes)
+    bool rf_fast = false;
+    unsigned long long *rf_nodes = nullptr;  // device, 8-byte records {float tkey; u16 left; u16 var}
+    double *rf_lval = nullptr;               // device, node prediction by node id
+    int *rf_depth = nullptr;                 // device, levels to descend per tree
+    std::vector<double> rf_thr;              // host, split value per node
+    std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
+    int rf_max_nodes = 0;
 };
 
 namespace mhs {
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
 // ---------------------------------------------------------------------- trees --
 // gbm_pred / predictRegTree walks.  Dynamic LDS: xs[p][R*256] predictors, then one chunk
 // of node records (LDS_NODES) or nothing (nodes read from global, for trees too large).
-template <bool GBM, bool LDS_NODES, int R>
+template <bool GBM, bool LDS_NODES, int R, bool NA_ONLY>
 __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnodes,
                                                    const int *__restrict__ tree_off,
                                                    const TreeChunk *__restrict__ chunks, int n_chunks,
@@ -265,6 +283,12 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
             xs[(j * R + c) * 256 + threadIdx.x] = xv;
         }
     }
+    if (NA_ONLY) {  // fix-up pass after gbm_lut_kernel: only cells holding an NA covariate are walked
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < R; ++c) any |= na[c] && i0 < half && (i0 + c * half) < total;
+        if (!__syncthreads_or(any)) return;
+    }
     for (int ch = 0; ch < n_chunks; ++ch) {
         const TreeChunk tc = chunks[ch];
         if (LDS_NODES) {
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
             const int tbase = LDS_NODES ? tree_off[t] - tc.node_begin : tree_off[t];
 #pragma unroll
             for (int c = 0; c < R; ++c) {
+                if (NA_ONLY && !na[c]) continue;
                 Node nd;
                 if constexpr (LDS_NODES) nd = lnodes[tbase]; else nd = gnodes[tbase];
                 while (nd.var >= 0) {
@@ -294,12 +319,182 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
 #pragma unroll
     for (int c = 0; c < R; ++c) {
         const int64_t i = i0 + c * half;
-        if (i0 < half && i < total) {
+        if (i0 < half && i < total && (!NA_ONLY || na[c])) {
             double pred;
             if (GBM) pred = init_f + acc[c];
             else pred = na[c] ? NAN : acc[c] / (double)n_trees;
             emit(out, (int64_t)row[c] * g.ld_out + col[c], pred, weight, accumulate);
         }
+    }
+}
+
+
+// ---------------------------------------------------------- gbm: predicate LUT --
+// Trees grown with interaction.depth = 5 (V73:493) have <= 5 splits, so a tree is a function
+// of its S <= 6 split predicates: leaf = LUT[b], b = the S predicate bits.  Per tree a wave
+// evaluates S wave-uniform predicates (threshold and variable arrive through the scalar
+// cache) instead of walking nodes lane by lane:
+//   * every predictor is mapped to an order-preserving float KEY once per cell, thresholds
+//     to key space on the host, so that  x < split  <=>  key < tkey  EXACTLY:
+//       float32/int16 planes: key = the value, tkey = smallest float >= split;
+//       LONG: key = column index, tkey = #columns whose centre is < split (same double formula);
+//       LAT : key = -row index,   tkey = 0.5 - (first row whose centre is < split);
+//   * keys are parked in LDS as [var][lane][4 cells] so one ds_read_b128 at a wave-uniform
+//     var offset fetches the keys of the lane's 4 cells; the bits are gathered with
+//     compare + add-with-carry; the leaf comes from the tree's 2^S-entry LUT (one 256-byte
+//     LDS row for S = 5, conflict-free).
+// Cells with an NA covariate are skipped here and walked through their MissingNode
+// children by tree_kernel<GBM, .., NA_ONLY> afterwards (gbm_pred's NA routing).
+constexpr int LUT_R = 4;            // cells per lane
+constexpr int LUT_CHUNK = 64;       // trees per LDS chunk
+constexpr int LUT_META_DW = 12;     // dwords of meta per tree
+
+// idx[c] = 2 idx[c] + (k[c] < tk) for the lane's 4 cells: compare into an SGPR pair, then
+// add-with-carry folds the predicate bit in (2 VALU per predicate and cell).  The four compares
+// are issued before the four adds so each add sits >= 3 instructions behind the compare whose
+// mask it consumes (VALU-writes-SGPR -> VALU-reads-as-carry needs 2 wait states on gfx950).
+__device__ __forceinline__ void pred4(unsigned (&idx)[4], const float4 k, const float tk) {
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_gt_f32_e64 %4, %12, %8\n\t"
+        "v_cmp_gt_f32_e64 %5, %12, %9\n\t"
+        "v_cmp_gt_f32_e64 %6, %12, %10\n\t"
+        "v_cmp_gt_f32_e64 %7, %12, %11\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+        "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
+        "v_addc_co_u32_e64 %3, %7, %3, %3, %7"
+        : "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(k.x), "v"(k.y), "v"(k.z), "v"(k.w), "s"(tk));
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__ lut,
+                                                      const int *__restrict__ meta, int n_trees_padded,
+                                                      double init_f, int p, StackDev s, PredGeom g,
+                                                      double weight, int accumulate,
+                                                      double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *keys = (float *)smem;                                              // [p][256][4]
+    double *slut = (double *)(smem + (size_t)p * 256 * LUT_R * sizeof(float));  // [LUT_CHUNK << S]
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t quarter = (total + LUT_R - 1) / LUT_R;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int row[LUT_R], col[LUT_R];
+    bool na[LUT_R];
+    double acc[LUT_R];
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        int64_t i = i0 + c * quarter;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0;
+        for (int j = 0; j < p; ++j) {
+            float k;
+            if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k = (float)xv; }
+            else if (j == s.C) k = (float)(g.c0 + col[c]);
+            else k = -(float)(g.r0 + row[c]);
+            keys[(j * 256 + threadIdx.x) * LUT_R + c] = k;
+        }
+    }
+    const float4 *kbase = (const float4 *)(keys + threadIdx.x * LUT_R);
+    for (int t0 = 0; t0 < n_trees_padded; t0 += LUT_CHUNK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < (LUT_CHUNK << S); e += 256) slut[e] = lut[((int64_t)t0 << S) + e];
+        __syncthreads();
+#pragma unroll 2
+        for (int t = 0; t < LUT_CHUNK; ++t) {
+            const int *m = meta + (int64_t)(t0 + t) * LUT_META_DW;
+            unsigned idx[LUT_R] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                const float tk = __int_as_float(m[q]);
+                const float4 k = *(const float4 *)((const char *)kbase + m[6 + q]);
+                pred4(idx, k, tk);
+            }
+#pragma unroll
+            for (int c = 0; c < LUT_R; ++c) acc[c] = acc[c] + slut[(t << S) + idx[c]];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        const int64_t i = i0 + c * quarter;
+        if (i0 < quarter && i < total && !na[c])
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], init_f + acc[c], weight, accumulate);
+    }
+}
+
+// ------------------------------------------------- randomForest: level-synchronous walk --
+// One tree at a time lives in LDS as 8-byte node records {float tkey; u16 left; u16 var} plus the
+// node predictions; right daughter = left + 1.  Terminals point at themselves with tkey = +inf,
+// so every lane descends a fixed, wave-uniform number of levels (the tree's depth) with no
+// divergent control flow:  node <- left + !(key[var] < tkey).  Keys are the order-preserving
+// float keys of gbm_lut_kernel ("x <= split" <=> key < tkey with tkey one float above the
+// largest float <= split), parked in LDS as [var][cell slot][lane].  Four independent walks
+// per lane keep the two dependent LDS reads of a level in flight.
+template <int LOG2R>
+__global__ __launch_bounds__(1024) void rf_walk_kernel(const unsigned long long *__restrict__ gnodes,
+                                                       const double *__restrict__ glval,
+                                                       const int *__restrict__ tree_off,
+                                                       const int *__restrict__ depth, int n_trees,
+                                                       int max_nodes, int p, StackDev s, PredGeom g,
+                                                       double weight, int accumulate,
+                                                       double *__restrict__ out) {
+    constexpr int R = 1 << LOG2R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *keys = (float *)smem;                                               // [p * R][1024]
+    unsigned long long *lnodes = (unsigned long long *)(smem + (size_t)p * R * 4096);
+    double *lval = (double *)(lnodes + max_nodes);
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R];
+    unsigned node[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * part;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0;
+        for (int j = 0; j < p; ++j) {
+            float k;
+            if (j < s.C) {
+                const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]);
+                const bool bad = isnan(xv);
+                na[c] |= bad;
+                k = bad ? 0.0f : (float)xv;
+            } else if (j == s.C) k = (float)(g.c0 + col[c]);
+            else k = -(float)(g.r0 + row[c]);
+            keys[(j * R + c) * 1024 + threadIdx.x] = k;
+        }
+    }
+    const char *kbase = (const char *)(keys + threadIdx.x);
+    for (int t = 0; t < n_trees; ++t) {
+        const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += 1024) { lnodes[e] = gnodes[o + e]; lval[e] = glval[o + e]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = 0u;
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const unsigned long long nd = lnodes[node[c]];
+                const unsigned hi = (unsigned)(nd >> 32);
+                const float tk = __uint_as_float((unsigned)nd);
+                const float k = *(const float *)(kbase + (((hi >> 16) << (12 + LOG2R)) + c * 4096));
+                node[c] = (hi & 0xFFFFu) + (k < tk ? 0u : 1u);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) acc[c] = acc[c] + lval[node[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        const int64_t i = i0 + c * part;
+        if (i0 < part && i < total)
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }
 }
 
@@ -394,7 +589,7 @@ static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g,
                  return MHS_ERR_INVALID;                                             \
     }
 
-template <bool GBM>
+template <bool GBM, bool NA_ONLY>
 static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
                         double *out, hipStream_t st, int64_t total) {
     const int64_t half = (total + TREE_R - 1) / TREE_R;
@@ -402,12 +597,12 @@ static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g
     const size_t xs_bytes = (size_t)m->p * TREE_R * 256 * sizeof(double);
     if (m->lds_ok) {
         const size_t bytes = xs_bytes + (size_t)m->max_chunk_nodes * sizeof(Node);
-        auto kern = tree_kernel<GBM, true, TREE_R>;
+        auto kern = tree_kernel<GBM, true, TREE_R, NA_ONLY>;
         MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks,
                            m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
     } else {
-        auto kern = tree_kernel<GBM, false, TREE_R>;
+        auto kern = tree_kernel<GBM, false, TREE_R, NA_ONLY>;
         MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), xs_bytes, st, m->nodes, m->tree_off, m->chunks,
                            m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
@@ -415,8 +610,151 @@ static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g
     return MHS_OK;
 }
 
+static float ceil_to_float(double thr) {  // smallest float >= thr
+    float f = (float)thr;
+    if ((double)f < thr) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+// key-space thresholds of every split for this grid (see gbm_lut_kernel); cached per geometry
+static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C) {
+    const mhs_grid &o = m->meta_grid;
+    if (m->lut_meta && m->meta_C == C && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
+        o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
+    const int S = m->lut_S;
+    std::vector<int> meta((size_t)m->n_trees_padded * LUT_META_DW, 0);
+    const float ninf = -INFINITY;
+    int ninf_bits;
+    memcpy(&ninf_bits, &ninf, 4);
+    for (int t = 0; t < m->n_trees_padded; ++t) {
+        int *mt = &meta[(size_t)t * LUT_META_DW];
+        for (int q = 0; q < 6; ++q) { mt[q] = ninf_bits; mt[6 + q] = 0; }
+        if (t >= m->n_trees) continue;
+        for (int q = 0; q < S; ++q) {
+            const int v = m->lut_var[(size_t)t * S + q];
+            if (v < 0) continue;
+            const double thr = m->lut_thr[(size_t)t * S + q];
+            float tk;
+            if (v < C) {
+                tk = ceil_to_float(thr);
+            } else if (v == C) {  // LONG: columns whose centre is < thr form a prefix [0, c*)
+                int64_t lo = 0, hi = grid.ncol;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) / 2;
+                    const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
+                    if (x < thr) lo = mid + 1; else hi = mid;
+                }
+                tk = (float)lo;
+            } else {              // LAT: rows whose centre is < thr form a suffix [r*, nrow)
+                int64_t lo = 0, hi = grid.nrow;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) / 2;
+                    const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
+                    if (y < thr) hi = mid; else lo = mid + 1;
+                }
+                tk = 0.5f - (float)lo;
+            }
+            memcpy(&mt[q], &tk, 4);
+            mt[6 + q] = v * 256 * LUT_R * (int)sizeof(float);
+        }
+    }
+    if (!m->lut_meta) MHS_HIP(hipMalloc((void **)&m->lut_meta, meta.size() * sizeof(int)));
+    MHS_HIP(hipMemcpy(m->lut_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+    m->meta_grid = grid;
+    m->meta_C = C;
+    return MHS_OK;
+}
+
+static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
+                          double w, int acc, double *out, hipStream_t st, int64_t total) {
+    if (int rc = build_lut_meta(const_cast<mhs_model *>(m), grid, s.C)) return rc;
+    const int64_t quarter = (total + LUT_R - 1) / LUT_R;
+    const unsigned blocks = (unsigned)((quarter + 255) / 256);
+    const size_t bytes = (size_t)m->p * 256 * LUT_R * sizeof(float) + ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
+    if (m->lut_S == 5) {
+        auto kern = gbm_lut_kernel<5>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
+    } else {
+        auto kern = gbm_lut_kernel<6>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
+    }
+    // cells with an NA covariate: walked through their MissingNode children
+    return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+}
+
+
+static float floor_to_float(double thr) {  // largest float <= thr
+    float f = (float)thr;
+    if ((double)f > thr) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+// key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry
+static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C) {
+    const mhs_grid &o = m->meta_grid;
+    if (m->rf_nodes && m->meta_C == C && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
+        o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
+    const size_t nn = m->rf_thr.size();
+    std::vector<unsigned long long> rec(nn);
+    for (size_t k = 0; k < nn; ++k) {
+        const unsigned v = m->rf_var[k];
+        float tk;
+        unsigned var = v;
+        if (v == 0xFFFFu) { tk = INFINITY; var = 0; }  // terminal: self loop (left = own index)
+        else if ((int)v < C) tk = nextafterf(floor_to_float(m->rf_thr[k]), INFINITY);
+        else if ((int)v == C) {   // LONG: columns with centre <= thr form a prefix [0, c*)
+            int64_t lo = 0, hi = grid.ncol;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
+                if (x <= m->rf_thr[k]) lo = mid + 1; else hi = mid;
+            }
+            tk = (float)lo;
+        } else {                  // LAT: rows with centre <= thr form a suffix [r*, nrow)
+            int64_t lo = 0, hi = grid.nrow;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
+                if (y <= m->rf_thr[k]) hi = mid; else lo = mid + 1;
+            }
+            tk = 0.5f - (float)lo;
+        }
+        unsigned tkb;
+        memcpy(&tkb, &tk, 4);
+        rec[k] = ((unsigned long long)((var << 16) | m->rf_left[k]) << 32) | tkb;
+    }
+    if (!m->rf_nodes) MHS_HIP(hipMalloc((void **)&m->rf_nodes, (nn ? nn : 1) * sizeof(unsigned long long)));
+    MHS_HIP(hipMemcpy(m->rf_nodes, rec.data(), nn * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    m->meta_grid = grid;
+    m->meta_C = C;
+    return MHS_OK;
+}
+
+static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
+                          double w, int acc, double *out, hipStream_t st, int64_t total, int log2r) {
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C)) return rc;
+    const int R = 1 << log2r;
+    const int64_t part = (total + R - 1) / R;
+    const unsigned blocks = (unsigned)((part + 1023) / 1024);
+    const size_t bytes = (size_t)m->p * R * 4096 + (size_t)m->rf_max_nodes * 16;
+    if (log2r == 2) {
+        auto kern = rf_walk_kernel<2>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, m->rf_nodes, m->rf_lval, m->tree_off, m->rf_depth,
+                           m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+    } else {
+        auto kern = rf_walk_kernel<1>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, m->rf_nodes, m->rf_lval, m->tree_off, m->rf_depth,
+                           m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+    }
+    return MHS_OK;
+}
+
 static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g, double weight,
-                        int accumulate, double *out, hipStream_t st) {
+                        int accumulate, double *out, hipStream_t st, const mhs_grid *grid = nullptr) {
     const int64_t total = (int64_t)g.nr * g.nc;
     if (total == 0) return MHS_OK;
     const unsigned blocks = (unsigned)((total + 255) / 256);
@@ -442,10 +780,23 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             break;
         }
         case K_GBM:
-            if (int rc = launch_trees<true>(m, s, g, weight, accumulate, out, st, total)) return rc;
+            // fast path: grid mode, planes whose values are exactly float-representable
+            if (grid && m->lut_S > 0 && !s.all_from_planes && s.dtype != MHS_F64 && (size_t)m->p * 256 * LUT_R * 4 + ((size_t)LUT_CHUNK << m->lut_S) * 8 <= LDS_LIMIT) {
+                if (int rc = launch_gbm_lut(m, s, g, *grid, weight, accumulate, out, st, total)) return rc;
+            } else if (int rc = launch_trees<true, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
             break;
         case K_RF:
-            if (int rc = launch_trees<false>(m, s, g, weight, accumulate, out, st, total)) return rc;
+            if (grid && m->rf_fast && !s.all_from_planes && s.dtype != MHS_F64) {
+                // cells per lane: 4 if keys + one tree fit in LDS, else 2, else the generic walk
+                int log2r = -1;
+                for (int l2 = 2; l2 >= 1 && log2r < 0; --l2)
+                    if ((size_t)m->p * (1 << l2) * 4096 + (size_t)m->rf_max_nodes * 16 <= LDS_LIMIT) log2r = l2;
+                if (log2r > 0) {
+                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r)) return rc;
+                    break;
+                }
+            }
+            if (int rc = launch_trees<false, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
             break;
         default:
             set_error("predict: unknown model kind %d", m->kind);
@@ -488,6 +839,11 @@ int mhs_model_free(mhs_model *m) {
     if (m->nodes) (void)hipFree(m->nodes);
     if (m->tree_off) (void)hipFree(m->tree_off);
     if (m->chunks) (void)hipFree(m->chunks);
+    if (m->lut) (void)hipFree(m->lut);
+    if (m->lut_meta) (void)hipFree(m->lut_meta);
+    if (m->rf_nodes) (void)hipFree(m->rf_nodes);
+    if (m->rf_lval) (void)hipFree(m->rf_lval);
+    if (m->rf_depth) (void)hipFree(m->rf_depth);
     delete m;
     return MHS_OK;
 }
@@ -600,6 +956,43 @@ int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets, co
     mhs_model *m = new mhs_model();
     m->kind = K_GBM; m->p = p; m->n_trees = (int)n_trees; m->init_f = init_f;
     if (int rc = finish_trees(m, nodes, off)) { mhs_model_free(m); return rc; }
+    // predicate-LUT form (gbm_lut_kernel) when every tree has at most 6 splits
+    int max_splits = 0;
+    for (int64_t t = 0; t < n_trees; ++t) {
+        int ns = 0;
+        for (int k = off[t]; k < off[t + 1]; ++k) ns += nodes[(size_t)k].var >= 0;
+        max_splits = std::max(max_splits, ns);
+    }
+    if (n_trees > 0 && max_splits <= 6) {
+        const int S = max_splits <= 5 ? 5 : 6;
+        m->lut_S = S;
+        m->n_trees_padded = (int)((n_trees + LUT_CHUNK - 1) / LUT_CHUNK * LUT_CHUNK);
+        m->lut_var.assign((size_t)n_trees * S, -1);
+        m->lut_thr.assign((size_t)n_trees * S, 0.0);
+        std::vector<double> lut(((size_t)m->n_trees_padded) << S, 0.0);
+        std::vector<int> qmap;
+        for (int64_t t = 0; t < n_trees; ++t) {
+            const int o = off[t], cnt = off[t + 1] - off[t];
+            qmap.assign((size_t)cnt, -1);
+            int q = 0;
+            for (int k = 0; k < cnt; ++k)
+                if (nodes[(size_t)(o + k)].var >= 0) {
+                    qmap[k] = q;
+                    m->lut_var[(size_t)t * S + q] = nodes[(size_t)(o + k)].var;
+                    m->lut_thr[(size_t)t * S + q] = nodes[(size_t)(o + k)].val;
+                    ++q;
+                }
+            for (int b = 0; b < (1 << S); ++b) {
+                int k = 0, guard = 0;
+                while (nodes[(size_t)(o + k)].var >= 0 && guard++ <= cnt) {
+                    const int bit = (b >> (S - 1 - qmap[k])) & 1;  // predicate 0 is the most significant bit
+                    k = bit ? nodes[(size_t)(o + k)].left : nodes[(size_t)(o + k)].right;
+                }
+                lut[((size_t)t << S) + b] = nodes[(size_t)(o + k)].val;
+            }
+        }
+        if (int rc = to_device(lut.data(), lut.size(), &m->lut)) { mhs_model_free(m); return rc; }
+    }
     *out = m;
     return MHS_OK;
 }
@@ -635,6 +1028,49 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
     mhs_model *m = new mhs_model();
     m->kind = K_RF; m->p = p; m->n_trees = (int)n_trees;
     if (int rc = finish_trees(m, nodes, off)) { mhs_model_free(m); return rc; }
+    // level-synchronous form (rf_walk_kernel): needs right daughter == left daughter + 1
+    bool paired = true;
+    for (size_t k = 0; k < nodes.size() && paired; ++k)
+        if (nodes[k].var >= 0 && nodes[k].right != nodes[k].left + 1) paired = false;
+    if (paired) {
+        m->rf_thr.resize(nodes.size());
+        m->rf_left.resize(nodes.size());
+        m->rf_var.resize(nodes.size());
+        std::vector<double> lval(nodes.size());
+        std::vector<int> depth((size_t)n_trees, 0), lev;
+        int max_nodes = 0;
+        for (int64_t t = 0; t < n_trees && paired; ++t) {
+            const int o = off[t], cnt = off[t + 1] - off[t];
+            max_nodes = std::max(max_nodes, cnt);
+            lev.assign((size_t)cnt, -1);
+            lev[0] = 0;
+            int dmax = 0;
+            for (int k = 0; k < cnt; ++k) {  // randomForest numbers children after their parent
+                const Node &nd = nodes[(size_t)(o + k)];
+                if (lev[k] < 0) { paired = false; break; }  // unreachable or out-of-order node
+                m->rf_thr[(size_t)(o + k)] = nd.val;
+                lval[(size_t)(o + k)] = nd.var < 0 ? nd.val : 0.0;
+                if (nd.var >= 0) {
+                    if (nd.left <= k || nd.left + 1 >= cnt) { paired = false; break; }
+                    m->rf_left[(size_t)(o + k)] = nd.left;
+                    m->rf_var[(size_t)(o + k)] = (unsigned short)nd.var;
+                    lev[nd.left] = lev[nd.left + 1] = lev[k] + 1;
+                    dmax = std::max(dmax, lev[k] + 1);
+                } else {
+                    m->rf_left[(size_t)(o + k)] = (unsigned short)k;  // self loop
+                    m->rf_var[(size_t)(o + k)] = 0xFFFFu;
+                }
+            }
+            depth[(size_t)t] = dmax;
+        }
+        if (paired) {
+            m->rf_fast = true;
+            m->rf_max_nodes = max_nodes;
+            int rc = to_device(lval.data(), lval.size(), &m->rf_lval);
+            if (!rc) rc = to_device(depth.data(), depth.size(), &m->rf_depth);
+            if (rc) { mhs_model_free(m); return rc; }
+        }
+    }
     *out = m;
     return MHS_OK;
 }
@@ -648,7 +1084,7 @@ int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_stack *cova
     StackDev s;
     if (int rc = make_geom(g, r0, r1, c0, c1, ld, &pg)) return rc;
     if (int rc = make_stack(m, g, covars, &s)) return rc;
-    return launch_model(m, s, pg, weight, accumulate, out_dev, pick_stream(stream));
+    return launch_model(m, s, pg, weight, accumulate, out_dev, pick_stream(stream), g);
 }
 
 int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weights, int n_models,
@@ -701,7 +1137,7 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         MHS_REQUIRE(covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
         sd.data = ds.data; sd.C = ds.n_layers; sd.dtype = ds.dtype; sd.plane_stride = ds.plane_stride;
         sd.ld = ds.ld; sd.nodata = ds.nodata; sd.has_nodata = !std::isnan(ds.nodata); sd.all_from_planes = 0;
-        if (int rc = launch_model(models[k], sd, pg, weights[k], k > 0, dout.p, s)) return rc;
+        if (int rc = launch_model(models[k], sd, pg, weights[k], k > 0, dout.p, s, g)) return rc;
     }
     hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((nr * nc + 255) / 256)), dim3(256), 0, s,
                        dout.p, (int)nr, (int)nc, nc, wt_total);

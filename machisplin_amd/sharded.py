@@ -1,0 +1,171 @@
+"""One-process-per-GPU sharding of machisplin.mltps Steps 2-5.
+
+Cells are independent given the fitted parameters, so the grid is cut into contiguous
+row bands, one per rank.  The only data-path exchanges are the ones the path really has:
+  * rank 0 fits the thin-plate spline on the station residuals and BROADCASTS its
+    coefficients (3 n + 8 doubles);
+  * ONE ALL-GATHER of the finished row bands stitches the output grid on every rank
+    (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+The per-band arithmetic is injected (`ops`): bench.py passes the HIP implementation, the
+CPU tests pass a numpy stand-in so the collective plumbing is exercised under gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def row_bands(nrow: int, world: int):
+    """Equal-height contiguous bands (all_gather_into_tensor needs equal chunks); the last
+    bands may be short or empty.  Returns band height and [(r0, r1)] per rank."""
+    band = -(-nrow // world)
+    return band, [(min(r * band, nrow), min((r + 1) * band, nrow)) for r in range(world)]
+
+
+def pack_tps(knots, c, d, center, scale, lambda_):
+    """Flat float64 message for the coefficient broadcast: u[n], v[n], c[n], d[3], center[2],
+    scale[2], lambda."""
+    knots = np.asarray(knots, dtype=np.float64)
+    return np.concatenate([knots[:, 0], knots[:, 1], np.asarray(c, dtype=np.float64), np.asarray(d, dtype=np.float64),
+                           np.asarray(center, dtype=np.float64), np.asarray(scale, dtype=np.float64), [float(lambda_)]])
+
+
+def unpack_tps(buf, n):
+    buf = np.asarray(buf, dtype=np.float64)
+    return {"knots": np.column_stack([buf[:n], buf[n:2 * n]]), "c": buf[2 * n:3 * n], "d": buf[3 * n:3 * n + 3],
+            "center": buf[3 * n + 3:3 * n + 5], "scale": buf[3 * n + 5:3 * n + 7], "lambda": float(buf[3 * n + 7])}
+
+
+class ShardedMltps:
+    """Steps 2-5 for one response layer over `world` ranks.
+
+    ops must provide (tensors live on ops.device):
+      ensemble_band(r0, r1, out)      pred.elev rows [r0, r1) written into `out`         (Step 2)
+      station_residuals() -> (knots n x 2, res.FINAL n, resp n, rows n, cols n)          (Step 2)
+      tps_fit(knots, resid) -> packed coefficients (pack_tps)                            (Step 3, rank 0)
+      tps_band(packed, n, r0, r1, out)  final.TPS rows [r0, r1)                          (Step 3)
+      add(a, b, out)                  out = a + b, NA if either is NA                    (Step 5)
+      gather(plane, rows, cols) -> np.ndarray                                            (Step 5)
+    """
+
+    def __init__(self, ops, dist, rank: int, world: int, nrow: int, ncol: int):
+        import torch
+        self.ops, self.dist, self.rank, self.world = ops, dist, rank, world
+        self.nrow, self.ncol = nrow, ncol
+        self.band, self.bands = row_bands(nrow, world)
+        self.r0, self.r1 = self.bands[rank]
+        kw = {"dtype": torch.float64, "device": ops.device}
+        self.pred = torch.zeros((self.band, ncol), **kw)
+        self.tps = torch.zeros((self.band, ncol), **kw)
+        self.total_band = torch.zeros((self.band, ncol), **kw)
+        self.full = torch.zeros((self.band * world, ncol), **kw)  # all-gather target
+        self.torch = torch
+
+    def step(self):
+        ops, torch = self.ops, self.torch
+        nb = self.r1 - self.r0
+        if nb > 0:
+            ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
+        knots, resid, resp, rows, cols = ops.station_residuals()
+        n = knots.shape[0]
+        msg = torch.zeros(3 * n + 8, dtype=torch.float64, device=ops.device)
+        if self.rank == 0:
+            msg.copy_(torch.from_numpy(np.ascontiguousarray(ops.tps_fit(knots, resid))))
+        if self.world > 1:
+            self.dist.broadcast(msg, src=0)
+        packed = msg.cpu().numpy()
+        if nb > 0:
+            ops.tps_band(packed, n, self.r0, self.r1, self.tps[:nb])
+            ops.add(self.pred[:nb], self.tps[:nb], self.total_band[:nb])
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.full, self.total_band)
+        else:
+            self.full.copy_(self.total_band)
+        total = self.full[:self.nrow]
+        # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
+        f_actual = ops.gather(total, rows, cols)
+        tss = float(np.sum((resp - resp.mean()) ** 2))
+        rsq_model = 1.0 - float(np.sum(resid ** 2)) / tss
+        rsq_final = 1.0 - float(np.sum((resp - f_actual) ** 2)) / tss
+        if rsq_final > rsq_model:
+            final = total
+        else:  # keep the ensemble alone: a second all-gather, of pred.elev
+            if self.world > 1:
+                self.dist.all_gather_into_tensor(self.full, self.pred)
+            else:
+                self.full.copy_(self.pred)
+            final = self.full[:self.nrow]
+        return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": float(packed[3 * n + 7])}
+
+
+class HipOps:
+    """The per-band arithmetic of ShardedMltps on one MI355X, through the C ABI (global-TPS
+    mode: one fit on all stations, V73:748-753).  `timings` collects HIP-event durations (ms)
+    of the device phases on the launch stream."""
+
+    def __init__(self, stack, int_xy, resp, models, weights, wt_total, lambda_=None, gcv_mode="fields",
+                 timed: bool = False):
+        import torch
+        from . import _lib, mltps
+        self.torch, self._lib = torch, _lib
+        self.stack, self.models, self.weights, self.wt_total = stack, models, list(weights), float(wt_total)
+        self.lambda_, self.gcv_mode = lambda_, gcv_mode
+        self.device = stack.planes.device
+        X, rows, cols = mltps.station_predictors(stack, int_xy)
+        y = np.asarray(resp, dtype=np.float64)
+        keep = ~np.isnan(X).any(axis=1) & ~np.isnan(y)  # complete.cases (V73:154)
+        self.X, self.rows, self.cols, self.y = X[keep], rows[keep], cols[keep], y[keep]
+        self.timed = timed
+        self.timings = {"ensemble_ms": [], "tps_eval_ms": [], "tps_fit_ms": [], "residuals_ms": []}
+        self.last_fit = None
+
+    def _timed(self, key, fn):
+        if not self.timed:
+            return fn()
+        import ctypes
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        lib = self._lib.lib()
+        self._lib.check(lib.mhs_timer_start(st))
+        r = fn()
+        ms = ctypes.c_double()
+        self._lib.check(lib.mhs_timer_stop(st, ctypes.byref(ms)))
+        self.timings[key].append(ms.value)
+        return r
+
+    def ensemble_band(self, r0, r1, out):
+        from .models import ensemble_predict
+        g = self.stack.geom
+        self._timed("ensemble_ms", lambda: ensemble_predict(self.stack, self.models, self.weights, self.wt_total,
+                                                            window=(r0, r1, 0, g.ncol), out=out))
+
+    def station_residuals(self):
+        import time
+        from .mltps import ensemble_residuals
+        t0 = time.perf_counter()
+        res = ensemble_residuals(self.models, self.weights, self.wt_total, self.X, self.y)
+        self.timings["residuals_ms"].append((time.perf_counter() - t0) * 1e3)
+        return self.X[:, -2:], res, self.y, self.rows, self.cols
+
+    def tps_fit(self, knots, resid):
+        import time
+        from .tps import Tps
+        t0 = time.perf_counter()
+        fit = Tps(knots, resid, lambda_=self.lambda_, gcv_mode=self.gcv_mode)
+        self.timings["tps_fit_ms"].append((time.perf_counter() - t0) * 1e3)
+        self.last_fit = fit
+        return pack_tps(fit.knots, fit.c, fit.d, fit.center, fit.scale, fit.lambda_)
+
+    def tps_band(self, packed, n, r0, r1, out):
+        from .tps import Tps, interpolate
+        d = unpack_tps(packed, n)
+        fit = Tps.from_coef(d["knots"], d["c"], d["d"], d["lambda"], d["center"], d["scale"])
+        g = self.stack.geom
+        self._timed("tps_eval_ms", lambda: interpolate(g, fit, window=(r0, r1, 0, g.ncol), out=out))
+
+    def add(self, a, b, out):
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+        self._lib.check(self._lib.lib().mhs_scale_add_dev(a.data_ptr(), 1.0, b.data_ptr(), out.data_ptr(), a.numel(), st))
+
+    def gather(self, plane, rows, cols):
+        from . import tiles
+        return tiles.extract(plane, rows, cols)

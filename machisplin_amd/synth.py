@@ -219,3 +219,32 @@ def ensemble_params(X, y, seed, n_gbm_trees=10000, n_rf_trees=500, which="bgnmrv
 
 
 OPTX_WEIGHTS = (0.31, 0.22, 0.12, 0.18, 0.27, 0.41)  # p1..p6 of the L-BFGS-B fit
+
+
+def mean_tree_visits(prm: dict, X: np.ndarray) -> float:
+    """Mean number of split-node visits per sample over all trees of a gbm / rf parameter set
+    (host-side walk over a small sample; feeds bench.py's algorithmic node-visit count)."""
+    X = np.asarray(X, dtype=np.float64)
+    n = X.shape[0]
+    off = prm["tree_offsets"]
+    rows = np.arange(n)
+    visits = 0
+    gbm = prm["kind"] == "gbm"
+    for t in range(off.size - 1):
+        o = off[t]
+        node = np.zeros(n, dtype=np.int64)
+        while True:
+            idx = o + node
+            active = (prm["split_var"][idx] >= 0) if gbm else (prm["status"][idx] != -1)
+            if not active.any():
+                break
+            ia = idx[active]
+            visits += int(active.sum())
+            if gbm:
+                x = X[rows[active], prm["split_var"][ia]]
+                node[active] = np.where(np.isnan(x), prm["missing"][ia],
+                                        np.where(x < prm["split_val"][ia], prm["left"][ia], prm["right"][ia]))
+            else:
+                x = X[rows[active], prm["best_var"][ia] - 1]
+                node[active] = np.where(x <= prm["split"][ia], prm["left"][ia], prm["right"][ia]) - 1
+    return visits / float(n)

@@ -52,3 +52,59 @@ def tps_gram(knots, threads=1) -> np.ndarray:
     f.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     f(kn.ctypes.data, n, int(threads), K.ctypes.data)
     return K
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def predict(model, X, threads=1, return_visits=False):
+    """C restatement of oracle.ensemble.predict (same parameter dicts)."""
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    n, p = X.shape
+    out = np.empty(n)
+    L = lib()
+    k = model["kind"]
+    visits = C.c_int64(0)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    if k == "lm":
+        c = f64(model["coef"])
+        L.oracle_predict_lm(C.c_void_p(_p(c)), p, C.c_void_p(_p(X)), C.c_int64(n), int(threads), C.c_void_p(_p(out)))
+    elif k == "nnet":
+        w = f64(model["wts"])
+        L.oracle_predict_nnet(C.c_void_p(_p(w)), p, int(model["size"]), C.c_double(model["y_scale"]), C.c_double(model["y_shift"]),
+                              C.c_void_p(_p(X)), C.c_int64(n), int(threads), C.c_void_p(_p(out)))
+    elif k == "earth":
+        c, d, u = f64(model["coef"]), i32(model["dirs"]), f64(model["cuts"])
+        L.oracle_predict_earth(C.c_void_p(_p(c)), C.c_void_p(_p(d)), C.c_void_p(_p(u)), int(c.size), p, C.c_void_p(_p(X)),
+                               C.c_int64(n), int(threads), C.c_void_p(_p(out)))
+    elif k == "svr":
+        a, sv, xc, xs = f64(model["alpha"]), f64(model["sv"]), f64(model["x_center"]), f64(model["x_scale"])
+        L.oracle_predict_svr(C.c_void_p(_p(a)), C.c_void_p(_p(sv)), C.c_int64(a.size), p, C.c_double(model["b"]),
+                             C.c_double(model["sigma"]), C.c_void_p(_p(xc)), C.c_void_p(_p(xs)), C.c_double(model["y_center"]),
+                             C.c_double(model["y_scale"]), C.c_void_p(_p(X)), C.c_int64(n), int(threads), C.c_void_p(_p(out)))
+    elif k == "gbm":
+        off, var, val = i64(model["tree_offsets"]), i32(model["split_var"]), f64(model["split_val"])
+        l, r, m = i32(model["left"]), i32(model["right"]), i32(model["missing"])
+        L.oracle_predict_gbm(C.c_double(model["init_f"]), C.c_int64(off.size - 1), C.c_void_p(_p(off)), C.c_void_p(_p(var)),
+                             C.c_void_p(_p(val)), C.c_void_p(_p(l)), C.c_void_p(_p(r)), C.c_void_p(_p(m)), p, C.c_void_p(_p(X)),
+                             C.c_int64(n), int(threads), C.c_void_p(_p(out)), C.byref(visits))
+    elif k == "rf":
+        off, l, r, st = i64(model["tree_offsets"]), i32(model["left"]), i32(model["right"]), i32(model["status"])
+        bv, sp, npred = i32(model["best_var"]), f64(model["split"]), f64(model["node_pred"])
+        L.oracle_predict_rf(C.c_int64(off.size - 1), C.c_void_p(_p(off)), C.c_void_p(_p(l)), C.c_void_p(_p(r)), C.c_void_p(_p(st)),
+                            C.c_void_p(_p(bv)), C.c_void_p(_p(sp)), C.c_void_p(_p(npred)), p, C.c_void_p(_p(X)), C.c_int64(n),
+                            int(threads), C.c_void_p(_p(out)), C.byref(visits))
+    else:
+        raise ValueError(k)
+    return (out, visits.value) if return_visits else out
+
+
+def ensemble(models, weights, wt_total, X, threads=1):
+    acc = None
+    for m, w in zip(models, weights):
+        pk = predict(m, X, threads) * w
+        acc = pk if acc is None else acc + pk
+    return acc / wt_total

@@ -1,0 +1,114 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of ShardedMltps (row bands, coefficient
+broadcast, one all-gather, Step-5 selection on every rank) with the per-band arithmetic
+supplied by the numpy oracle.  The stitched grid must equal the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from machisplin_amd import sharded
+from oracle import ensemble as oe
+from oracle import tps as otps
+
+NROW, NCOL, N = 37, 29, 120  # 37 rows over 2 ranks: bands of 19 and 18 (uneven on purpose)
+
+
+class OracleOps:
+    device = torch.device("cpu")
+
+    def __init__(self, w=1.0):
+        rng = np.random.default_rng(0)
+        self.x, self.y = otps.cell_centres(-78.0, -5.0, 0.01, 0.01, NROW, NCOL)
+        cov = rng.uniform(0, 100, (2, NROW, NCOL))
+        self.Xgrid = oe.stack_predictors(cov, (self.x, self.y))
+        cells = rng.choice(NROW * NCOL, N, replace=False)
+        self.rows, self.cols = np.divmod(cells, NCOL)
+        self.Xs = self.Xgrid[cells]
+        self.resp = 3 + 0.05 * self.Xs[:, 0] + np.sin(40 * self.Xs[:, 2]) + 0.1 * rng.standard_normal(N)
+        A = np.column_stack([np.ones(N), self.Xs])
+        self.models = [oe.lm_model(np.linalg.lstsq(A, self.resp, rcond=None)[0])]
+        self.weights, self.tot = [w], 1.0
+
+    def ensemble_band(self, r0, r1, out):
+        p = oe.ensemble(self.models, self.weights, self.tot, self.Xgrid[r0 * NCOL:r1 * NCOL])
+        out.copy_(torch.from_numpy(p.reshape(r1 - r0, NCOL)))
+
+    def station_residuals(self):
+        res = (self.resp - oe.predict(self.models[0], self.Xs)) * self.weights[0] / self.tot
+        return self.Xs[:, -2:], res, self.resp, self.rows, self.cols
+
+    def tps_fit(self, knots, resid):
+        m = otps.fit(knots, resid)
+        return sharded.pack_tps(m["knots"], m["c"], m["d"], m["center"], m["scale"], m["lambda"])
+
+    def tps_band(self, packed, n, r0, r1, out):
+        m = sharded.unpack_tps(packed, n)
+        out.copy_(torch.from_numpy(otps.predict_grid(m, -78.0, -5.0, 0.01, 0.01, NROW, NCOL, r0, r1)))
+
+    def add(self, a, b, out):
+        torch.add(a, b, out=out)
+
+    def gather(self, plane, rows, cols):
+        return plane[torch.from_numpy(rows), torch.from_numpy(cols)].numpy()
+
+
+def _worker(rank, world, port, q, w):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        run = sharded.ShardedMltps(OracleOps(w), dist, rank, world, NROW, NCOL)
+        out = run.step()
+        q.put((rank, out["final"].numpy().copy(), out["rsq_model"], out["rsq_final"], out["lambda"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_row_bands_and_packing():
+    band, bands = sharded.row_bands(37, 2)
+    assert band == 19 and bands == [(0, 19), (19, 37)]
+    assert sharded.row_bands(10, 4) == (3, [(0, 3), (3, 6), (6, 9), (9, 10)])
+    assert sharded.row_bands(2, 4)[1] == [(0, 1), (1, 2), (2, 2), (2, 2)]  # more ranks than rows
+    kn = np.arange(10.0).reshape(5, 2)
+    msg = sharded.pack_tps(kn, np.arange(5.0), [1, 2, 3], [4, 5], [6, 7], 0.5)
+    d = sharded.unpack_tps(msg, 5)
+    assert msg.size == 3 * 5 + 8
+    assert np.array_equal(d["knots"], kn) and list(d["d"]) == [1, 2, 3] and d["lambda"] == 0.5
+    assert list(d["center"]) == [4, 5] and list(d["scale"]) == [6, 7]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("w", [1.0, 0.8])
+def test_two_ranks_equal_one_rank(w):
+    single = sharded.ShardedMltps(OracleOps(w), None, 0, 1, NROW, NCOL).step()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, w)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, final, rsq_m, rsq_f, lam in results:
+        assert final.shape == (NROW, NCOL)
+        # every rank holds the whole stitched grid (numpy's BLAS blocks differ with the band shape: 1e-12)
+        assert np.allclose(final, single["final"].numpy(), rtol=1e-12, atol=1e-12)
+        assert abs(rsq_m - single["rsq_model"]) < 1e-10 and abs(rsq_f - single["rsq_final"]) < 1e-10
+        assert lam == single["lambda"]
+    # w = 1: the TPS correction is kept (one all-gather).  w = 0.8 with wt.tot = 1: the reference does not
+    # renormalise the weights (V73:337,619), the sum is biased, R^2 drops and pred.elev alone is returned
+    # (second all-gather)
+    assert (single["rsq_final"] > single["rsq_model"]) == (w == 1.0)
