@@ -249,6 +249,22 @@ MHS_API int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx,
 MHS_API int mhs_gather_cells_dev(const double *plane_dev, int64_t ld, const int64_t *rows,
                                  const int64_t *cols, int64_t n, double *out_host, void *stream);
 
+/* Step 3 + Step 4 of machisplin.mltps in one call (V73:636-897): the thin-plate spline of the
+ * station residuals over the whole grid.  tile_edge > 0: ceil(nrow/tile_edge) x ceil(ncol/
+ * tile_edge) tiles (the reference hard-codes 1500), each fitted on the stations of its +-20 %
+ * box (fewer than 10 => zero tile), evaluated on its +-2.5 % box, mean-mosaicked and seam-
+ * feathered; tile_edge <= 0 or a single tile: one global fit (V73:748-753).  xy n x 2
+ * column-major = the LONG/LAT columns of dat_tps (cell-centre coordinates); cov1_at_stations
+ * (may be NULL) = first covariate at each station, NaN rows are dropped as complete.cases does
+ * (V73:701-706).  tiles_out (may be NULL) receives nRx, nCx.                               */
+MHS_API int mhs_tps_surface(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
+                            const double *cov1_at_stations, int64_t tile_edge, double lambda,
+                            int gcv_mode, double *out_host, int64_t *tiles_out);
+MHS_API int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
+                                const double *cov1_at_stations, int64_t tile_edge, double lambda,
+                                int gcv_mode, double *out_dev, int64_t ld, int64_t *tiles_out,
+                                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+/* .Call() shim: binds R to the C ABI of include/machisplin_hip.h.  UNTESTED HERE (no R in the
+ * build image); it is mechanically derived from the header: every SEXP is unpacked with
+ * REAL()/INTEGER(), the library is called, a non-zero status becomes Rf_error() AFTER all C
+ * resources are released, handles are external pointers with finalizers.
+ *
+ * Build inside the R package:  PKG_CPPFLAGS=-I<repo>/include  PKG_LIBS=-L<repo>/machisplin_amd -lmachisplin_hip
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <stdint.h>
+#include "machisplin_hip.h"
+
+static void chk(int rc) { if (rc != MHS_OK) Rf_error("machisplin_hip: %s", mhs_last_error()); }
+
+static mhs_grid grid_from(SEXP geom) { /* c(xmin, ymax, xres, yres, nrow, ncol) */
+    double *g = REAL(geom);
+    mhs_grid out = { g[0], g[1], g[2], g[3], (int64_t)g[4], (int64_t)g[5] };
+    return out;
+}
+
+static void tps_finalizer(SEXP p) { mhs_tps_free((mhs_tps *)R_ExternalPtrAddr(p)); R_ClearExternalPtr(p); }
+static void model_finalizer(SEXP p) { mhs_model_free((mhs_model *)R_ExternalPtrAddr(p)); R_ClearExternalPtr(p); }
+static SEXP wrap(void *h, R_CFinalizer_t fin) {
+    SEXP p = PROTECT(R_MakeExternalPtr(h, R_NilValue, R_NilValue));
+    R_RegisterCFinalizerEx(p, fin, TRUE);
+    UNPROTECT(1);
+    return p;
+}
+
+SEXP mhsr_init(SEXP device) { chk(mhs_init(Rf_asInteger(device))); return R_NilValue; }
+
+/* fields::Tps(x, Y)  (V73:722, V73:751).  xy: n x 2 numeric matrix, lambda NA => GCV */
+SEXP mhsr_tps_fit(SEXP xy, SEXP y, SEXP lambda, SEXP mode) {
+    mhs_tps *t = NULL;
+    double lam = Rf_asReal(lambda);
+    chk(mhs_tps_fit(REAL(xy), REAL(y), (int64_t)Rf_length(y), ISNA(lam) ? R_NaN : lam, Rf_asInteger(mode), &t));
+    return wrap(t, tps_finalizer);
+}
+
+/* terra::interpolate(terra::rast(rb), tps)  (V73:726, V73:753): values in terra cell order */
+SEXP mhsr_tps_predict_grid(SEXP tps, SEXP geom, SEXP win) {
+    mhs_grid g = grid_from(geom);
+    int *w = INTEGER(win); /* r0, r1, c0, c1 (0-based, half-open) */
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)(w[1] - w[0]) * (w[3] - w[2])));
+    int rc = mhs_tps_predict_grid((mhs_tps *)R_ExternalPtrAddr(tps), &g, w[0], w[1], w[2], w[3], REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
+/* Step 3 + Step 4 in one call (V73:636-897) */
+SEXP mhsr_tps_surface(SEXP geom, SEXP xy, SEXP resid, SEXP cov1, SEXP tile_edge, SEXP lambda, SEXP mode) {
+    mhs_grid g = grid_from(geom);
+    double lam = Rf_asReal(lambda);
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)g.nrow * g.ncol));
+    int rc = mhs_tps_surface(&g, REAL(xy), REAL(resid), (int64_t)Rf_length(resid),
+                             Rf_isNull(cov1) ? NULL : REAL(cov1), (int64_t)Rf_asInteger(tile_edge),
+                             ISNA(lam) ? R_NaN : lam, Rf_asInteger(mode), REAL(out), NULL);
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
+/* model loaders: flat arrays pulled out of the fitted objects by R/backend_hip.R */
+SEXP mhsr_lm_load(SEXP coef) {
+    mhs_model *m = NULL;
+    chk(mhs_lm_load(REAL(coef), Rf_length(coef) - 1, &m));
+    return wrap(m, model_finalizer);
+}
+SEXP mhsr_nnet_load(SEXP wts, SEXP p, SEXP size, SEXP scale, SEXP shift) {
+    mhs_model *m = NULL;
+    chk(mhs_nnet_load(REAL(wts), Rf_asInteger(p), Rf_asInteger(size), Rf_asReal(scale), Rf_asReal(shift), &m));
+    return wrap(m, model_finalizer);
+}
+SEXP mhsr_earth_load(SEXP coef, SEXP dirs_rowmajor, SEXP cuts_rowmajor, SEXP p) {
+    mhs_model *m = NULL;
+    chk(mhs_earth_load(REAL(coef), INTEGER(dirs_rowmajor), REAL(cuts_rowmajor), Rf_length(coef), Rf_asInteger(p), &m));
+    return wrap(m, model_finalizer);
+}
+SEXP mhsr_svr_load(SEXP alpha, SEXP sv_rowmajor, SEXP p, SEXP b, SEXP sigma, SEXP xc, SEXP xs, SEXP yc, SEXP ys) {
+    mhs_model *m = NULL;
+    chk(mhs_svr_load(REAL(alpha), REAL(sv_rowmajor), (int64_t)Rf_length(alpha), Rf_asInteger(p), Rf_asReal(b),
+                     Rf_asReal(sigma), REAL(xc), REAL(xs), Rf_asReal(yc), Rf_asReal(ys), &m));
+    return wrap(m, model_finalizer);
+}
+SEXP mhsr_gbm_load(SEXP initF, SEXP offsets /* numeric, n.trees+1 */, SEXP var, SEXP val, SEXP left, SEXP right,
+                   SEXP missing, SEXP p) {
+    R_xlen_t nt = Rf_xlength(offsets) - 1;
+    int64_t *off = (int64_t *)R_alloc((size_t)nt + 1, sizeof(int64_t));
+    for (R_xlen_t i = 0; i <= nt; ++i) off[i] = (int64_t)REAL(offsets)[i];
+    mhs_model *m = NULL;
+    chk(mhs_gbm_load(Rf_asReal(initF), (int64_t)nt, off, INTEGER(var), REAL(val), INTEGER(left), INTEGER(right),
+                     INTEGER(missing), Rf_asInteger(p), &m));
+    return wrap(m, model_finalizer);
+}
+SEXP mhsr_rf_load(SEXP offsets, SEXP left, SEXP right, SEXP status, SEXP bestvar, SEXP split, SEXP nodepred, SEXP p) {
+    R_xlen_t nt = Rf_xlength(offsets) - 1;
+    int64_t *off = (int64_t *)R_alloc((size_t)nt + 1, sizeof(int64_t));
+    for (R_xlen_t i = 0; i <= nt; ++i) off[i] = (int64_t)REAL(offsets)[i];
+    mhs_model *m = NULL;
+    chk(mhs_rf_load((int64_t)nt, off, INTEGER(left), INTEGER(right), INTEGER(status), INTEGER(bestvar), REAL(split),
+                    REAL(nodepred), Rf_asInteger(p), &m));
+    return wrap(m, model_finalizer);
+}
+
+/* the Step-2 raster loop (V73:447-619).  covars: terra::values(covar.ras), an ncell x C numeric
+ * matrix -- column-major, i.e. already planar; NA_real_ is a NaN and is treated as NA */
+SEXP mhsr_ensemble_predict(SEXP models, SEXP weights, SEXP wt_total, SEXP geom, SEXP covars) {
+    mhs_grid g = grid_from(geom);
+    int n = Rf_length(models);
+    const mhs_model **h = (const mhs_model **)R_alloc((size_t)n, sizeof(*h));
+    for (int i = 0; i < n; ++i) h[i] = (const mhs_model *)R_ExternalPtrAddr(VECTOR_ELT(models, i));
+    mhs_stack st = { REAL(covars), Rf_ncols(covars), MHS_F64, (int64_t)g.nrow * g.ncol, g.ncol, R_NaN };
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)g.nrow * g.ncol));
+    int rc = mhs_ensemble_predict(h, REAL(weights), n, Rf_asReal(wt_total), &g, &st, 0, g.nrow, 0, g.ncol, REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
+/* predict(model, data.frame) at the stations (V73:477, 501, 525, 586, 608) */
+SEXP mhsr_predict_points(SEXP model, SEXP X) {
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, Rf_nrows(X)));
+    int rc = mhs_predict_points((const mhs_model *)R_ExternalPtrAddr(model), REAL(X), (int64_t)Rf_nrows(X), REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}

@@ -161,3 +161,29 @@ def test_extract_gathers_station_cells(hip):
     rows, cols = hip.tiles.cells_from_xy(g, xy)
     got = hip.tiles.extract(plane, rows, cols)
     assert got[0] == 0 and got[1] == 49 * 60 + 59 and np.isnan(got[2])
+
+
+def test_one_call_surface_equals_composed_steps(hip):
+    """mhs_tps_surface (what the .Call() shim binds for V73:636-897) == the Python composition of
+    tile windows + per-tile Tps + interpolate + mosaic_feather, bit for bit."""
+    import ctypes as C
+    from machisplin_amd import _lib, synth
+    g = synth.grid(230, 310)
+    xy, rows, cols, uv = synth.stations(g, 500, 77)
+    resid = synth.tps_residual(uv, 77)
+    cov1 = np.ones(500)
+    cov1[::37] = np.nan  # stations on NA covariate cells are dropped (V73:701-706)
+    want = hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=100).cpu().numpy()
+    out = np.empty((230, 310))
+    nt = np.zeros(2, dtype=np.int64)
+    gs = g.c_struct()
+    xyf = np.asfortranarray(xy)
+    _lib.check(_lib.lib().mhs_tps_surface(C.byref(gs), xyf.ctypes.data, resid.ctypes.data, 500, cov1.ctypes.data, 100,
+                                          float("nan"), 0, out.ctypes.data, nt.ctypes.data))
+    assert list(nt) == [3, 4]
+    assert np.array_equal(out, want)
+    # single-tile branch
+    _lib.check(_lib.lib().mhs_tps_surface(C.byref(gs), xyf.ctypes.data, resid.ctypes.data, 500, None, 0,
+                                          float("nan"), 0, out.ctypes.data, nt.ctypes.data))
+    assert list(nt) == [1, 1]
+    assert np.array_equal(out, hip.tps_residual_surface(g, xy, resid, tile_edge=None).cpu().numpy())
