@@ -142,6 +142,81 @@ __global__ __launch_bounds__(1024) void backtransform_kernel(const double *__res
     }
 }
 
+// ---- fused tridiagonalisation step (two launches per Householder step) ---------------------
+// tri_step_kernel (single block): given p = A_trail v_k, finish step k -- w_k = tau p - tau^2/2
+// (p'v) v, rotate g -- then bring column k+1 up to date with the rank-2 update, take ITS Householder
+// vector v_{k+1} and store the reflector.  tri_fused_kernel (one wave per column, whole chip):
+// apply the rank-2 update of step k to the remaining (t-1)^2 block and, in the same pass over the
+// matrix, form p_{k+1} = A_new v_{k+1}.  The matrix is read and written once per step (16 B per
+// element; HBM/Infinity-Cache bound) instead of read, read, written by separate symv / syr2 passes.
+__global__ __launch_bounds__(1024) void tri_step_kernel(double *__restrict__ A, int64_t ld, int col, int t,
+                                                        const double *__restrict__ p,
+                                                        const double *__restrict__ v,
+                                                        double *__restrict__ vnext, double *__restrict__ w,
+                                                        double *__restrict__ g, double *__restrict__ tau,
+                                                        double *__restrict__ offd, int k) {
+    __shared__ double scratch[17];
+    const double tk = tau[k];
+    double s = 0.0, sg = 0.0;
+    for (int i = threadIdx.x; i < t; i += blockDim.x) { s = fma(p[i], v[i], s); sg = fma(g[i], v[i], sg); }
+    s = block_sum(s, scratch);
+    sg = block_sum(sg, scratch);
+    const double alpha_w = -0.5 * tk * tk * s;
+    const double v0 = v[0];
+    const double w0 = fma(alpha_w, v0, tk * p[0]);
+    double *x = A + (int64_t)col * ld + col;  // column k+1 of B from its diagonal down
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < t; i += blockDim.x) {
+        const double wi = fma(alpha_w, v[i], tk * p[i]);
+        w[i] = wi;
+        g[i] -= tk * sg * v[i];
+        if (i == 0) x[0] = x[0] - (v0 * w0 + w0 * v0);
+        else {
+            const double xi = x[i] - (v[i] * w0 + wi * v0);
+            x[i] = xi;
+            if (i >= 2) ss = fma(xi, xi, ss);
+        }
+    }
+    if (t < 2) return;
+    ss = block_sum(ss, scratch);  // also orders the x[] writes before the reads below
+    const double alpha = x[1];
+    if (ss == 0.0) {
+        for (int i = threadIdx.x; i + 1 < t; i += blockDim.x) vnext[i] = (i == 0) ? 1.0 : 0.0;
+        if (threadIdx.x == 0) { tau[k + 1] = 0.0; offd[k + 1] = alpha; }
+        return;
+    }
+    const double beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+    const double scal = 1.0 / (alpha - beta);
+    __syncthreads();
+    for (int i = 1 + threadIdx.x; i < t; i += blockDim.x) {
+        const double vi = (i == 1) ? 1.0 : x[i] * scal;
+        vnext[i - 1] = vi;
+        if (i >= 2) x[i] = vi;  // reflector kept for the back-transform
+    }
+    if (threadIdx.x == 0) { tau[k + 1] = (beta - alpha) / beta; offd[k + 1] = beta; }
+}
+
+// block (col0+1.., col0+1..) of size (t-1): a_ji -= v_j w_i + w_j v_i ; pnext_i = sum_j a_ji vnext_j
+__global__ __launch_bounds__(256) void tri_fused_kernel(double *__restrict__ A, int64_t ld, int col0, int t,
+                                                        const double *__restrict__ v,
+                                                        const double *__restrict__ w,
+                                                        const double *__restrict__ vnext,
+                                                        double *__restrict__ pnext) {
+    const int i = 1 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= t) return;
+    const int lane = threadIdx.x & 63;
+    double *a = A + (int64_t)(col0 + i) * ld + col0;
+    const double vi = v[i], wi = w[i];
+    double acc = 0.0;
+    for (int j = 1 + lane; j < t; j += 64) {
+        const double x = a[j] - (v[j] * wi + w[j] * vi);
+        a[j] = x;
+        acc = fma(x, vnext[j - 1], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) pnext[i - 1] = acc;
+}
+
 __global__ void add_diag_kernel(double *A, int64_t ld, int off, int m, double lam) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) A[(int64_t)(off + i) * ld + off + i] += lam;
@@ -436,16 +511,22 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
     } else {
         // tridiagonalise B in place, rotating g = P' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        // step 0: Householder vector of column 0 and p = A_trail v_0; then two launches per step
+        DevBuf<double> vbuf2;
+        MHS_HIP(vbuf2.alloc((size_t)n));
+        double *vcur = vbuf.p, *vnext = vbuf2.p;
+        if (m >= 2) {
+            hipLaunchKernelGGL(house_vec_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m - 1, vcur, tau.p, offd.p, 0);
+            hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((m - 1 + 3) / 4)), dim3(256), 0, s, A.p, ld, 4, m - 1, vcur, pbuf.p);
+        }
         for (int k = 0; k + 1 < m; ++k) {
             const int t = m - k - 1;
-            const int off = 3 + k + 1;
-            hipLaunchKernelGGL(house_vec_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3 + k, t, vbuf.p, tau.p, offd.p, k);
-            if (t >= 2) {
-                hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((t + 3) / 4)), dim3(256), 0, s, A.p, ld, off, t, vbuf.p, pbuf.p);
-                hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + k, t, wbuf.p, gbuf.p + k + 1);
-                dim3 grid((unsigned)((t + 63) / 64), (unsigned)((t + 63) / 64));
-                hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, off, t, vbuf.p, wbuf.p);
-            }
+            hipLaunchKernelGGL(tri_step_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3 + k + 1, t, pbuf.p, vcur, vnext,
+                               wbuf.p, gbuf.p + k + 1, tau.p, offd.p, k);
+            if (t >= 2)
+                hipLaunchKernelGGL(tri_fused_kernel, dim3((unsigned)((t - 1 + 3) / 4)), dim3(256), 0, s, A.p, ld,
+                                   3 + k + 1, t, vcur, wbuf.p, vnext, pbuf.p);
+            std::swap(vcur, vnext);
         }
         MHS_HIP(hipGetLastError());
         std::vector<double> diag((size_t)m), off((size_t)std::max(m - 1, 1)), g((size_t)m), q((size_t)m);
