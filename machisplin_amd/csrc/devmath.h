@@ -10,22 +10,25 @@ constexpr double LOG_BIAS_D = -1023.0 * 0.6931471805599453094;
 // returns log(d2) + 1023 ln2 for finite d2 >= 0 (d2 == 0 gives a finite value, so
 // d2 * log(d2) evaluates to 0 at a knot without a branch; fields floors d2 at 1e-20,
 // where d2 log d2 = -4.6e-19, far below one ulp of any non-trivial sum).
-// tab: LOG_TAB_N x {1/c_i, log c_i} (runtime.hip), normally staged in LDS.
+// tab: LOG_TAB_N x {2^1023 / c_i, log c_i} (runtime.hip), normally staged in LDS.
 // r2 = 2^e m, m in [1,2): log m = log c_i + log1p(m/c_i - 1), |m/c_i - 1| <= 2^-11, cubic
 // log1p => absolute error < 2e-14.
 __device__ __forceinline__ double table_log_biased(double d2, const double2 *tab) {
     const int hi = __double2hiint(d2);
-    const int lo = __double2loint(d2);
-    const unsigned e = (unsigned)hi >> 20;
+    const int e = hi >> 20;  // biased exponent (d2 >= 0)
     const unsigned off = ((unsigned)hi >> (20 - LOG_TAB_BITS - 4)) & ((LOG_TAB_N - 1) << 4);
     const double2 t = *(const double2 *)((const char *)tab + off);
-    const int mh = (hi & 0x000FFFFF) | 0x3FF00000;
-    const double m = __hiloint2double(mh, lo);
-    const double r = fma(m, t.x, -1.0);
+    // t.x = 2^1023 / c_i: subtracting d2's exponent field from its high word gives 2^-E / c_i, so
+    // d2 * that = m / c_i without assembling the mantissa m.  (asm: keeps the two 32-bit ops on
+    // the high word; the compiler otherwise widens them into a 64-bit subtract with carry.)
+    int ih = __double2hiint(t.x), tmp;
+    asm("v_and_b32 %1, 0x7ff00000, %2\n\tv_sub_u32 %0, %0, %1" : "+v"(ih), "=&v"(tmp) : "v"(hi));
+    const double invc = __hiloint2double(ih, __double2loint(t.x));
+    const double r = fma(d2, invc, -1.0);
     const double q = fma(r, 1.0 / 3.0, -0.5);
     const double r2 = r * r;
     const double lp = fma(r2, q, r);
-    const double L = fma((double)(int)e, LN2_D, t.y);
+    const double L = fma((double)e, LN2_D, t.y);
     return L + lp;
 }
 

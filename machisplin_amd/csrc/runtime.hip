@@ -36,7 +36,7 @@ int require_ready() {
     return MHS_OK;
 }
 
-// {1/c_i rounded to double, -log(that double)} with c_i the midpoint of
+// {2^1023 * (1/c_i rounded to double), -log(that 1/c_i)} with c_i the midpoint of
 // [1 + i/N, 1 + (i+1)/N).  log(m) = logc_i + log1p(m*invc_i - 1), |m*invc_i - 1| <= 2^-11.
 static void build_log_table(std::vector<double2> &tab) {
     tab.resize(LOG_TAB_N);
@@ -44,7 +44,9 @@ static void build_log_table(std::vector<double2> &tab) {
         long double c = 1.0L + ((long double)i + 0.5L) / (long double)LOG_TAB_N;
         double invc = (double)(1.0L / c);
         double logc = (double)(-logl((long double)invc));
-        tab[i] = make_double2(invc, logc);
+        // stored pre-scaled by 2^1023 (exact): table_log_biased subtracts the argument's exponent
+        // field from it instead of extracting the argument's mantissa
+        tab[i] = make_double2(ldexp(invc, 1023), logc);
     }
 }
 
