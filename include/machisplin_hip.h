@@ -104,6 +104,11 @@ MHS_API int mhs_host_gcv_tridiag(const double *diag, const double *offdiag, cons
                                  int64_t m, int64_t n_unique, int64_t n_obs, double pure_ss,
                                  double lambda, int gcv_mode, double *lambda_out,
                                  double *gcv_out, double *eff_df_out, double *q_out);
+/* The same on the symmetric BANDED form the GPU fit reduces to (bandwidth bw, lower band
+ * column-major: ab[d + (bw+1) j] = M[j+d][j]); bw = 1 is the tridiagonal case. */
+MHS_API int mhs_host_gcv_band(const double *ab, int bw, const double *g, int64_t m, int64_t n_unique,
+                              int64_t n_obs, double pure_ss, double lambda, int gcv_mode,
+                              double *lambda_out, double *gcv_out, double *eff_df_out, double *q_out);
 /* build a spline object from coefficients captured elsewhere (e.g. from a real
  * fields::Tps object: $c, $d, $knots (scaled), $transform$x.center/$x.scale)   */
 MHS_API int mhs_tps_from_coef(const double *knots_uv /* n x 2 column-major, scaled */,

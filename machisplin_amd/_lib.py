@@ -52,6 +52,8 @@ SIGNATURES = {
     "mhs_tps_fit": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_int, C.POINTER(_vp)]),
     "mhs_host_gcv_tridiag": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_double, C.c_double, C.c_int,
                                        _dp, _dp, _dp, _vp]),
+    "mhs_host_gcv_band": (C.c_int, [_vp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, C.c_double, C.c_int,
+                                    _dp, _dp, _dp, _vp]),
     "mhs_tps_from_coef": (C.c_int, [_vp, _vp, _vp, _i64, C.c_double, _vp, _vp, C.POINTER(_vp)]),
     "mhs_tps_size": (C.c_int, [_vp, C.POINTER(_i64)]),
     "mhs_tps_get": (C.c_int, [_vp, _vp, _vp, _vp, _dp, _vp, _vp, _dp, _dp]),

@@ -5,14 +5,17 @@
 //   GPU    A <- Q' A Q  (three two-sided Householder updates); B = A[3:,3:] is SPD
 //   fixed lambda:  GPU blocked Cholesky of B + lambda I (FP64 MFMA trailing update)
 //                  + triangular solves                                               n^3/3
-//   GCV:           GPU Householder tridiagonalisation B = P T P' (symv + rank-2),
-//                  g = P' Q2' y rotated along; host picks lambda on T in O(n) per
-//                  evaluation (tps_gcv_host.hip); q = (T + lambda I)^-1 g on host;
-//                  GPU back-transform c2 = P q                                      4n^3/3
+//   GCV:           GPU blocked Householder reduction of B to a band of width 8, B = Q Bb Q'
+//                  (panel QR + rank-16 two-sided updates), g = Q' Q2' y rotated along; host
+//                  picks lambda on the band in O(n bw^2) per evaluation (tps_gcv_host.hip);
+//                  q = (Bb + lambda I)^-1 g on host; GPU back-transform c2 = Q q    4n^3/3
 //   host   c = W^1/2 Q [0; c2],  d = R^-1 (Q1'y~ - A[0:3,3:] c2)
 //
 // A is n x n, full symmetric storage, column-major with leading dimension ld.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -94,127 +97,511 @@ __global__ __launch_bounds__(256) void syr2_kernel(double *__restrict__ A, int64
     }
 }
 
-// single block: Householder vector of column k of B (B = A[3:,3:]); x = B[k+1:, k], t = len(x).
-// Writes v (v[0] = 1) to vbuf and into A below the sub-diagonal, tau[k], offd[k] = beta.
-__global__ __launch_bounds__(1024) void house_vec_kernel(double *__restrict__ A, int64_t ld, int col,
-                                                         int t, double *__restrict__ vbuf,
-                                                         double *__restrict__ tau,
-                                                         double *__restrict__ offd, int k) {
-    __shared__ double scratch[17];
-    double *x = A + (int64_t)col * ld + col + 1;
-    double s = 0.0;
-    for (int i = 1 + threadIdx.x; i < t; i += blockDim.x) s = fma(x[i], x[i], s);
-    s = block_sum(s, scratch);
-    const double alpha = x[0];
+// =============================================================================================
+// Blocked reduction of B to a symmetric BAND of width BW (GCV path).  The classical Householder
+// tridiagonalisation needs ~n dependent steps, each a full pass over the matrix plus a single-
+// block latency kernel (n = 5000: 10^4 launches, 180 ms).  Reducing only to bandwidth BW = 8
+// takes n/BW panel steps of four launches, each pass doing BW times the work, and the GCV
+// criterion is then evaluated directly on the band (banded Cholesky + Takahashi trace on the host,
+// tps_gcv_host.hip) -- no tridiagonal form, no eigenvalues.  Per panel at column c (t = m-c-BW):
+//   band_panel_kernel   Householder QR of P = B[c+BW:, c:c+BW] -> V (t x BW), T (compact WY),
+//                       reflectors kept in place, R left in the band; g <- Q' g
+//   band_symm_kernel    Y = A22 V               (A22 = B[c+BW:, c+BW:], read once, 8 B/element)
+//   band_w_kernel       W = Y T - 1/2 V (T' V' Y T)
+//   band_update_kernel  A22 <- A22 - V W' - W V'  (= Q' A22 Q, read + write once)
+// =============================================================================================
+constexpr int BW = 8;
+
+// sum K per-thread values over the block; result in every thread.  lds: >= 17 * K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum_vec(double (&v)[K], double *lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
     __syncthreads();
-    if (s == 0.0) {
-        if (threadIdx.x == 0) { tau[k] = 0.0; offd[k] = alpha; }
-        for (int i = threadIdx.x; i < t; i += blockDim.x) vbuf[i] = (i == 0) ? 1.0 : 0.0;
-        return;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
     }
-    const double beta = -copysign(sqrt(alpha * alpha + s), alpha);
-    const double scal = 1.0 / (alpha - beta);
-    for (int i = threadIdx.x; i < t; i += blockDim.x) {
-        const double vi = (i == 0) ? 1.0 : x[i] * scal;
-        vbuf[i] = vi;
-        if (i > 0) x[i] = vi;  // keep the reflector for the back-transform
+    __syncthreads();
+    if ((int)threadIdx.x < K) {  // thread k adds the per-wave partials of value k, in wave order
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += lds[w * K + threadIdx.x];
+        lds[16 * K + threadIdx.x] = s;
     }
-    if (threadIdx.x == 0) { tau[k] = (beta - alpha) / beta; offd[k] = beta; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = lds[16 * K + k];
 }
 
-// single block: r <- H_0 H_1 ... H_{m-3} r, reflectors stored in A below the sub-diagonal
-__global__ __launch_bounds__(1024) void backtransform_kernel(const double *__restrict__ A, int64_t ld,
-                                                             int off0, int m,
-                                                             const double *__restrict__ tau,
-                                                             double *__restrict__ r) {
-    __shared__ double scratch[17];
-    for (int k = m - 3; k >= 0; --k) {
-        const int t = m - k - 1;
-        const double tk = tau[k];
-        if (tk == 0.0) continue;  // uniform
-        const double *x = A + (int64_t)(off0 + k) * ld + off0 + k + 1;
-        double *rs = r + k + 1;
-        double s = 0.0;
-        for (int i = threadIdx.x; i < t; i += blockDim.x) s = fma(i == 0 ? 1.0 : x[i], rs[i], s);
-        s = block_sum(s, scratch) * tk;
-        for (int i = threadIdx.x; i < t; i += blockDim.x) rs[i] -= s * (i == 0 ? 1.0 : x[i]);
+__global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A, int64_t ld, int c0, int r0,
+                                                          int t, double *__restrict__ Vd, int64_t vs,
+                                                          double *__restrict__ Tm, double *__restrict__ g) {
+    __shared__ double lds[17 * 44];
+    __shared__ double taus[BW];
+    __shared__ double Ts[BW * BW];
+    __shared__ double zs[BW];
+    const int nref = min(BW, t - 1);
+    double *P = A + (int64_t)c0 * ld + r0;  // P[i + j*ld]
+    for (int j = 0; j < BW; ++j) {
+        double *x = P + (int64_t)j * ld;
+        if (j >= nref) {  // nothing left to annihilate in this column
+            for (int i = threadIdx.x; i < t; i += blockDim.x) Vd[j * vs + i] = 0.0;
+            if (threadIdx.x == 0) taus[j] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        double part[1] = {0.0};
+        for (int i = j + 1 + threadIdx.x; i < t; i += blockDim.x) part[0] = fma(x[i], x[i], part[0]);
+        block_sum_vec<1>(part, lds);
+        const double ss = part[0], alpha = x[j];
+        __syncthreads();
+        double beta = alpha, tau = 0.0, scal = 0.0;
+        if (ss != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        for (int i = threadIdx.x; i < t; i += blockDim.x) {
+            const double vi = i < j ? 0.0 : (i == j ? 1.0 : x[i] * scal);
+            Vd[j * vs + i] = vi;
+            if (i == j) x[i] = beta; else if (i > j) x[i] = vi;
+        }
+        if (threadIdx.x == 0) taus[j] = tau;
+        __syncthreads();
+        // apply H_j to the remaining panel columns: s_k = v' P[:,k];  P[:,k] -= tau s_k v
+        double sk[BW - 1];
+#pragma unroll
+        for (int k = 0; k < BW - 1; ++k) sk[k] = 0.0;
+        for (int i = j + threadIdx.x; i < t; i += blockDim.x) {
+            const double vi = Vd[j * vs + i];
+#pragma unroll
+            for (int k = 0; k < BW - 1; ++k)
+                if (j + 1 + k < BW) sk[k] = fma(vi, P[(int64_t)(j + 1 + k) * ld + i], sk[k]);
+        }
+        block_sum_vec<BW - 1>(sk, lds);
+        for (int i = j + threadIdx.x; i < t; i += blockDim.x) {
+            const double vi = tau * Vd[j * vs + i];
+#pragma unroll
+            for (int k = 0; k < BW - 1; ++k)
+                if (j + 1 + k < BW) P[(int64_t)(j + 1 + k) * ld + i] -= sk[k] * vi;
+        }
         __syncthreads();
     }
-}
-
-// ---- fused tridiagonalisation step (two launches per Householder step) ---------------------
-// tri_step_kernel (single block): given p = A_trail v_k, finish step k -- w_k = tau p - tau^2/2
-// (p'v) v, rotate g -- then bring column k+1 up to date with the rank-2 update, take ITS Householder
-// vector v_{k+1} and store the reflector.  tri_fused_kernel (one wave per column, whole chip):
-// apply the rank-2 update of step k to the remaining (t-1)^2 block and, in the same pass over the
-// matrix, form p_{k+1} = A_new v_{k+1}.  The matrix is read and written once per step (16 B per
-// element; HBM/Infinity-Cache bound) instead of read, read, written by separate symv / syr2 passes.
-__global__ __launch_bounds__(1024) void tri_step_kernel(double *__restrict__ A, int64_t ld, int col, int t,
-                                                        const double *__restrict__ p,
-                                                        const double *__restrict__ v,
-                                                        double *__restrict__ vnext, double *__restrict__ w,
-                                                        double *__restrict__ g, double *__restrict__ tau,
-                                                        double *__restrict__ offd, int k) {
-    __shared__ double scratch[17];
-    const double tk = tau[k];
-    double s = 0.0, sg = 0.0;
-    for (int i = threadIdx.x; i < t; i += blockDim.x) { s = fma(p[i], v[i], s); sg = fma(g[i], v[i], sg); }
-    s = block_sum(s, scratch);
-    sg = block_sum(sg, scratch);
-    const double alpha_w = -0.5 * tk * tk * s;
-    const double v0 = v[0];
-    const double w0 = fma(alpha_w, v0, tk * p[0]);
-    double *x = A + (int64_t)col * ld + col;  // column k+1 of B from its diagonal down
-    double ss = 0.0;
+    // G = V'V (upper triangle, 36 values) and sg = V'g (8 values) in one pass
+    double acc[44];
+#pragma unroll
+    for (int k = 0; k < 44; ++k) acc[k] = 0.0;
     for (int i = threadIdx.x; i < t; i += blockDim.x) {
-        const double wi = fma(alpha_w, v[i], tk * p[i]);
-        w[i] = wi;
-        g[i] -= tk * sg * v[i];
-        if (i == 0) x[0] = x[0] - (v0 * w0 + w0 * v0);
-        else {
-            const double xi = x[i] - (v[i] * w0 + wi * v0);
-            x[i] = xi;
-            if (i >= 2) ss = fma(xi, xi, ss);
+        double v[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) v[a] = Vd[a * vs + i];
+        const double gi = g[i];
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < BW; ++a)
+#pragma unroll
+            for (int b = a; b < BW; ++b) { acc[k] = fma(v[a], v[b], acc[k]); ++k; }
+#pragma unroll
+        for (int a = 0; a < BW; ++a) acc[36 + a] = fma(v[a], gi, acc[36 + a]);
+    }
+    block_sum_vec<44>(acc, lds);
+    if (threadIdx.x == 0) {
+        double G[BW][BW];
+        int k = 0;
+        for (int a = 0; a < BW; ++a)
+            for (int b = a; b < BW; ++b) { G[a][b] = acc[k]; G[b][a] = acc[k]; ++k; }
+        // larft: T upper triangular, T[r + BW*c]
+        for (int e = 0; e < BW * BW; ++e) Ts[e] = 0.0;
+        for (int j = 0; j < BW; ++j) {
+            const double tj = taus[j];
+            Ts[j + BW * j] = tj;
+            for (int i = 0; i < j; ++i) {
+                double sum = 0.0;
+                for (int l = i; l < j; ++l) sum += Ts[i + BW * l] * G[l][j];
+                Ts[i + BW * j] = -tj * sum;
+            }
+        }
+        for (int e = 0; e < BW * BW; ++e) Tm[e] = Ts[e];
+        // z = T' (V'g):  g <- g - V z   (Q' = I - V T' V')
+        for (int a = 0; a < BW; ++a) {
+            double sum = 0.0;
+            for (int b = 0; b <= a; ++b) sum += Ts[b + BW * a] * acc[36 + b];
+            zs[a] = sum;
         }
     }
-    if (t < 2) return;
-    ss = block_sum(ss, scratch);  // also orders the x[] writes before the reads below
-    const double alpha = x[1];
-    if (ss == 0.0) {
-        for (int i = threadIdx.x; i + 1 < t; i += blockDim.x) vnext[i] = (i == 0) ? 1.0 : 0.0;
-        if (threadIdx.x == 0) { tau[k + 1] = 0.0; offd[k + 1] = alpha; }
-        return;
-    }
-    const double beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-    const double scal = 1.0 / (alpha - beta);
     __syncthreads();
-    for (int i = 1 + threadIdx.x; i < t; i += blockDim.x) {
-        const double vi = (i == 1) ? 1.0 : x[i] * scal;
-        vnext[i - 1] = vi;
-        if (i >= 2) x[i] = vi;  // reflector kept for the back-transform
+    for (int i = threadIdx.x; i < t; i += blockDim.x) {
+        double gi = g[i];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) gi -= Vd[a * vs + i] * zs[a];
+        g[i] = gi;
     }
-    if (threadIdx.x == 0) { tau[k + 1] = (beta - alpha) / beta; offd[k + 1] = beta; }
 }
 
-// block (col0+1.., col0+1..) of size (t-1): a_ji -= v_j w_i + w_j v_i ; pnext_i = sum_j a_ji vnext_j
-__global__ __launch_bounds__(256) void tri_fused_kernel(double *__restrict__ A, int64_t ld, int col0, int t,
-                                                        const double *__restrict__ v,
-                                                        const double *__restrict__ w,
-                                                        const double *__restrict__ vnext,
-                                                        double *__restrict__ pnext) {
-    const int i = 1 + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= t) return;
-    const int lane = threadIdx.x & 63;
-    double *a = A + (int64_t)(col0 + i) * ld + col0;
-    const double vi = v[i], wi = w[i];
-    double acc = 0.0;
-    for (int j = 1 + lane; j < t; j += 64) {
-        const double x = a[j] - (v[j] * wi + w[j] * vi);
-        a[j] = x;
-        acc = fma(x, vnext[j - 1], acc);
+// Register-resident variant for t <= PANEL_THREADS * PANEL_RPT rows: the whole t x BW panel (320 KB at
+// t = 5000) lives in the register file of ONE CU -- each thread owns PANEL_RPT rows of all BW
+// columns -- so the BW Householder steps touch global memory only to load and store the panel;
+// every step is two block reductions.  (The streaming version above is latency-bound: a single
+// block keeps ~8 KB of loads in flight.)
+constexpr int PANEL_RPT = 10;
+constexpr int PANEL_THREADS = 512;
+
+struct PanelShared {
+    double lds[17 * 16];
+    double Gs[BW][BW];   // Gs[l][j] = v_l' v_j (l < j)
+    double sgs[BW], taus[BW], zs[BW];
+    double Ts[BW * BW];
+    double piv;
+};
+
+// Householder step J of the register-resident panel (J is a template parameter so that every
+// index into x[][] is a compile-time constant and the panel stays in VGPRs)
+template <int J>
+__device__ __forceinline__ void panel_step(double (&x)[PANEL_RPT][BW], int t, int nref, PanelShared &sh) {
+    if (J >= nref) {  // uniform: nothing left to annihilate; H_J = I
+        if (threadIdx.x == 0) { sh.taus[J] = 0.0; for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0; }
+        return;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) pnext[i - 1] = acc;
+    double part[1] = {0.0};
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        const int i = threadIdx.x + PANEL_THREADS * r;
+        if (i > J) part[0] = fma(x[r][J], x[r][J], part[0]);
+        if (i == J) sh.piv = x[r][J];
+    }
+    block_sum_vec<1>(part, sh.lds);  // its barriers also publish piv
+    const double ss = part[0], alpha = sh.piv;
+    __syncthreads();                 // everyone has read piv before the next column's owner rewrites it
+    double beta = alpha, tau = 0.0, scal = 0.0;
+    if (ss != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+    // one fused reduction: red[0..6-J] = v' P[:,k] (k > J), red[7-J..6] = v_l' v (l < J)
+    double red[BW - 1];
+#pragma unroll
+    for (int k = 0; k < BW - 1; ++k) red[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        const int i = threadIdx.x + PANEL_THREADS * r;
+        const double vr = (i < J || i >= t) ? 0.0 : (i == J ? 1.0 : x[r][J] * scal);
+        if (i == J) x[r][J] = beta; else if (i > J) x[r][J] = vr;
+#pragma unroll
+        for (int k = J + 1; k < BW; ++k) red[k - J - 1] = fma(vr, x[r][k], red[k - J - 1]);
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+            const double vl = i < l ? 0.0 : (i == l ? 1.0 : x[r][l]);
+            red[BW - 1 - J + l] = fma(vl, vr, red[BW - 1 - J + l]);
+        }
+    }
+    block_sum_vec<BW - 1>(red, sh.lds);
+    if (threadIdx.x == 0) {
+        sh.taus[J] = tau;
+#pragma unroll
+        for (int l = 0; l < J; ++l) sh.Gs[l][J] = red[BW - 1 - J + l];
+    }
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        const int i = threadIdx.x + PANEL_THREADS * r;
+        const double vr = (i < J || i >= t) ? 0.0 : (i == J ? 1.0 : x[r][J]);  // x[r][J] now holds v below the diagonal
+        const double tv = tau * vr;
+#pragma unroll
+        for (int k = J + 1; k < BW; ++k) x[r][k] -= red[k - J - 1] * tv;
+    }
+}
+
+__global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *__restrict__ A, int64_t ld, int c0,
+                                                                       int r0, int t, double *__restrict__ Vd,
+                                                                       int64_t vs, double *__restrict__ Tm,
+                                                                       double *__restrict__ g) {
+    __shared__ PanelShared sh;
+    const int nref = min(BW, t - 1);
+    double *P = A + (int64_t)c0 * ld + r0;
+    double x[PANEL_RPT][BW];   // x[r][j] = P[tid + PANEL_THREADS r][j]
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        const int i = threadIdx.x + PANEL_THREADS * r;
+#pragma unroll
+        for (int j = 0; j < BW; ++j) { const double *Pj = P + (int64_t)j * ld; x[r][j] = i < t ? Pj[i] : 0.0; }
+    }
+    static_assert(BW == 8, "panel steps are spelled out for BW = 8");
+    panel_step<0>(x, t, nref, sh); panel_step<1>(x, t, nref, sh);
+    panel_step<2>(x, t, nref, sh); panel_step<3>(x, t, nref, sh);
+    panel_step<4>(x, t, nref, sh); panel_step<5>(x, t, nref, sh);
+    panel_step<6>(x, t, nref, sh); panel_step<7>(x, t, nref, sh);
+    {   // sg = V' g (g as it was on entry)
+        double sg[BW];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) sg[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < PANEL_RPT; ++r) {
+            const int i = threadIdx.x + PANEL_THREADS * r;
+            const double gi = i < t ? g[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < BW; ++j) {
+                const double vj = (j >= nref || i < j || i >= t) ? 0.0 : (i == j ? 1.0 : x[r][j]);
+                sg[j] = fma(vj, gi, sg[j]);
+            }
+        }
+        block_sum_vec<BW>(sg, sh.lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < BW; ++j) sh.sgs[j] = sg[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // larft: T upper triangular, T[r + BW*c];  z = T' (V'g)
+        for (int e = 0; e < BW * BW; ++e) sh.Ts[e] = 0.0;
+        for (int j = 0; j < BW; ++j) {
+            const double tj = sh.taus[j];
+            sh.Ts[j + BW * j] = tj;
+            for (int i = 0; i < j; ++i) {
+                double sum = 0.0;
+                for (int l = i; l < j; ++l) sum += sh.Ts[i + BW * l] * sh.Gs[l][j];
+                sh.Ts[i + BW * j] = -tj * sum;
+            }
+        }
+        for (int e = 0; e < BW * BW; ++e) Tm[e] = sh.Ts[e];
+        for (int a = 0; a < BW; ++a) {
+            double sum = 0.0;
+            for (int b = 0; b <= a; ++b) sum += sh.Ts[b + BW * a] * sh.sgs[b];
+            sh.zs[a] = sum;
+        }
+    }
+    __syncthreads();
+    // store the panel (R on/above its diagonal, reflectors below), the dense V, and g <- Q' g
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        const int i = threadIdx.x + PANEL_THREADS * r;
+        if (i < t) {
+            double gi = g[i];
+#pragma unroll
+            for (int j = 0; j < BW; ++j) {
+                P[(int64_t)j * ld + i] = x[r][j];
+                const double vj = (j >= nref || i < j) ? 0.0 : (i == j ? 1.0 : x[r][j]);
+                Vd[j * vs + i] = vj;
+                gi -= vj * sh.zs[j];
+            }
+            g[i] = gi;
+        }
+    }
+}
+
+// Y = A22 V as split-K partial sums: block (cg, sp) owns 32 columns (8 per wave) and one of
+// SYMM_SPLITS row ranges; lanes run over rows, the V rows of the range are staged in LDS in
+// chunks of 64.  Ypart[sp][j][i] partial sums are added up by the consumers; the block also
+// emits its share of M = V'Y (64 values) so that S = T'(V'Y)T needs no second pass over Y.
+constexpr int SYMM_SPLITS = 4;
+constexpr int SYMM_COLS = 32;
+
+__global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict__ A, int64_t ld, int r0, int t,
+                                                        const double *__restrict__ Vd, int64_t vs,
+                                                        double *__restrict__ Ypart, double *__restrict__ Mpart) {
+    __shared__ double Vs[BW][64];
+    __shared__ double Ms[4][BW * BW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col0 = blockIdx.x * SYMM_COLS + wave * 8;
+    const int rows_per = ((t + SYMM_SPLITS - 1) / SYMM_SPLITS + 63) & ~63;
+    const int rbeg = blockIdx.y * rows_per, rend = min(t, rbeg + rows_per);
+    double acc[8][BW];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
+    const double *a0 = A + (int64_t)r0 * ld + r0;
+    for (int rb = rbeg; rb < rend; rb += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < BW * 64; e += 256) {
+            const int j = e >> 6, r = rb + (e & 63);
+            Vs[j][e & 63] = r < rend ? Vd[j * vs + r] : 0.0;
+        }
+        __syncthreads();
+        const int r = rb + lane;
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = (r < rend && col0 + c < t) ? a0[(int64_t)(col0 + c) * ld + r] : 0.0;
+#pragma unroll
+        for (int j = 0; j < BW; ++j) {
+            const double v = Vs[j][lane];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c][j] = fma(a[c], v, acc[c][j]);
+        }
+    }
+    // wave-reduce; lane j keeps column sums y[c] for V-column j, then M += V[:,col]' (x) y
+    double *yp = Ypart + (int64_t)blockIdx.y * BW * vs;
+    double mpart[BW];  // lane l < 64: M[a = l & 7][b = l >> 3] contribution of this wave
+    double mval = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double y[BW];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) y[j] = wave_sum(acc[c][j]);
+        const int col = col0 + c;
+        if (col < t) {
+            if (lane < BW) {
+                double yl = y[0];
+#pragma unroll
+                for (int j = 1; j < BW; ++j) yl = lane == j ? y[j] : yl;
+                yp[lane * vs + col] = yl;
+            }
+            const double va = Vd[(lane & 7) * vs + col];
+            double yb = y[0];
+#pragma unroll
+            for (int j = 1; j < BW; ++j) yb = (lane >> 3) == j ? y[j] : yb;
+            mval = fma(va, yb, mval);
+        }
+    }
+    (void)mpart;
+    Ms[wave][lane] = mval;
+    __syncthreads();
+    if (threadIdx.x < BW * BW)
+        Mpart[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * (BW * BW) + threadIdx.x] =
+            (Ms[0][threadIdx.x] + Ms[1][threadIdx.x]) + (Ms[2][threadIdx.x] + Ms[3][threadIdx.x]);
+}
+
+// S = sym(T' M T), M = sum of the Mpart blocks (M[a + BW*b] = sum_i V[a][i] Y[b][i]).  One block.
+__global__ __launch_bounds__(1024) void band_s_kernel(const double *__restrict__ Mpart, int nparts,
+                                                      const double *__restrict__ Tm, double *__restrict__ Sm) {
+    __shared__ double red[16][BW * BW];
+    __shared__ double M[BW * BW], Ts[BW * BW], MT[BW * BW];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    double sum = 0.0;
+    for (int p = grp; p < nparts; p += 16) sum += Mpart[(int64_t)p * (BW * BW) + e];
+    red[grp][e] = sum;
+    if (threadIdx.x < BW * BW) Ts[threadIdx.x] = Tm[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < BW * BW) {
+        double m = 0.0;
+        for (int q = 0; q < 16; ++q) m += red[q][threadIdx.x];
+        M[threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < BW * BW) {  // MT = M T  (T upper: T[b + BW*c], b <= c)
+        const int a = threadIdx.x % BW, c = threadIdx.x / BW;
+        double m = 0.0;
+        for (int b2 = 0; b2 <= c; ++b2) m += M[a + BW * b2] * Ts[b2 + BW * c];
+        MT[a + BW * c] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < BW * BW) {  // S = T' MT, symmetrised
+        const int a = threadIdx.x % BW, c = threadIdx.x / BW;
+        double s1 = 0.0, s2 = 0.0;
+        for (int d = 0; d <= a; ++d) s1 += Ts[d + BW * a] * MT[d + BW * c];
+        for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a];
+        Sm[a + BW * c] = 0.5 * (s1 + s2);
+    }
+}
+
+// A22 <- A22 - V W' - W V' on 64 x 64 tiles, W = Y T - 1/2 V S formed on the fly for the tile's
+// row set I and column set J from the split-K partial sums of Y.  Bitwise symmetric.
+__global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                          const double *__restrict__ Vd,
+                                                          const double *__restrict__ Ypart, int64_t vs,
+                                                          const double *__restrict__ Tm,
+                                                          const double *__restrict__ Sm) {
+    __shared__ double Vs[2][64][BW + 1], Ws[2][64][BW + 1];
+    __shared__ double Ts[BW * BW], Ss[BW * BW];
+    if (threadIdx.x < BW * BW) { Ts[threadIdx.x] = Tm[threadIdx.x]; Ss[threadIdx.x] = Sm[threadIdx.x]; }
+    __syncthreads();
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    if (threadIdx.x < 128) {  // one thread per row of the I set (0..63) or the J set (64..127)
+        const int set = threadIdx.x >> 6, rr = threadIdx.x & 63;
+        const int row = (set ? j0 : i0) + rr;
+        double y[BW], v[BW];
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+            double sum = 0.0;
+            if (row < t) {
+#pragma unroll
+                for (int sp = 0; sp < SYMM_SPLITS; ++sp) sum += Ypart[(int64_t)sp * BW * vs + b * vs + row];
+            }
+            y[b] = sum;
+            v[b] = row < t ? Vd[b * vs + row] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < BW; ++a) {
+            double x = 0.0, vsum = 0.0;
+#pragma unroll
+            for (int b = 0; b <= a; ++b) x = fma(y[b], Ts[b + BW * a], x);
+#pragma unroll
+            for (int c = 0; c < BW; ++c) vsum = fma(v[c], Ss[c + BW * a], vsum);
+            Vs[set][rr][a] = v[a];
+            Ws[set][rr][a] = x - 0.5 * vsum;
+        }
+    }
+    __syncthreads();
+    const int li = threadIdx.x & 63, i = i0 + li;
+    if (i >= t) return;
+    double vi[BW], wi[BW];
+#pragma unroll
+    for (int l = 0; l < BW; ++l) { vi[l] = Vs[0][li][l]; wi[l] = Ws[0][li][l]; }
+    double *a = A + (int64_t)r0 * ld + r0 + i;
+    const int jb = (threadIdx.x >> 6) * 16;
+#pragma unroll 4
+    for (int jj = jb; jj < jb + 16; ++jj) {
+        const int j = j0 + jj;
+        if (j >= t) break;
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < BW; ++l) sum += vi[l] * Ws[1][jj][l] + wi[l] * Vs[1][jj][l];
+        a[(int64_t)j * ld] -= sum;
+    }
+}
+
+// lower band of B -> ab[d + (BW+1) j]
+__global__ void band_extract_kernel(const double *__restrict__ A, int64_t ld, int off0, int m,
+                                    double *__restrict__ ab) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * (BW + 1)) return;
+    const int j = e / (BW + 1), d = e - j * (BW + 1);
+    ab[e] = (j + d < m) ? A[(int64_t)(off0 + j) * ld + off0 + j + d] : 0.0;
+}
+
+// r <- Q_0 Q_1 ... Q_{P-1} r,  Q_p = I - V_p T_p V_p'  (single block; reflectors read in place)
+__global__ __launch_bounds__(1024) void band_backtransform_kernel(const double *__restrict__ A, int64_t ld,
+                                                                  int off0, int m, int npanels,
+                                                                  const double *__restrict__ Tall,
+                                                                  double *__restrict__ r) {
+    __shared__ double lds[17 * BW];
+    __shared__ double zs[BW];
+    for (int p = npanels - 1; p >= 0; --p) {
+        const int c = p * BW, t = m - c - BW;
+        const double *P = A + (int64_t)(off0 + c) * ld + off0 + c + BW;
+        const double *T = Tall + (int64_t)p * BW * BW;
+        double *rs = r + c + BW;
+        double s[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) s[a] = 0.0;
+        for (int i = threadIdx.x; i < t; i += blockDim.x) {
+            const double ri = rs[i];
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                const double v = i < a ? 0.0 : (i == a ? 1.0 : P[(int64_t)a * ld + i]);
+                s[a] = fma(v, ri, s[a]);
+            }
+        }
+        block_sum_vec<BW>(s, lds);
+        if (threadIdx.x < BW) {  // z = T s
+            const int a = threadIdx.x;
+            double sum = 0.0;
+            for (int b = a; b < BW; ++b) sum += T[a + BW * b] * s[b];
+            zs[a] = sum;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < t; i += blockDim.x) {
+            double ri = rs[i];
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                const double v = i < a ? 0.0 : (i == a ? 1.0 : P[(int64_t)a * ld + i]);
+                ri -= v * zs[a];
+            }
+            rs[i] = ri;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void add_diag_kernel(double *A, int64_t ld, int off, int m, double lam) {
@@ -464,6 +851,16 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
     for (int k = 0; k < 3; ++k) apply_reflector(hv[k], htau[k], wv.data(), n);
 
     hipStream_t s = ctx().stream;
+    const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mhs_tps_fit n=%lld] %-28s %8.3f ms\n", (long long)n, what,
+                std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int64_t ld = (n + 15) & ~(int64_t)15;
     DevBuf<double> A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, offd;
     MHS_HIP(A.alloc((size_t)(ld * n)));
@@ -494,6 +891,7 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         MHS_HIP(hipStreamSynchronize(s));  // vbuf is reused by the next upload
     }
     MHS_HIP(hipGetLastError());
+    lap("gram + projection");
     // rows 0..2 of the projected matrix, columns 3..n-1 (by symmetry: columns 0..2, rows 3..)
     std::vector<double> Atop(3 * (size_t)m);
     for (int k = 0; k < 3; ++k)
@@ -509,42 +907,52 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
     } else {
-        // tridiagonalise B in place, rotating g = P' w2 along
+        // reduce B to bandwidth BW in place (blocked), rotating g = Q' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
-        // step 0: Householder vector of column 0 and p = A_trail v_0; then two launches per step
-        DevBuf<double> vbuf2;
-        MHS_HIP(vbuf2.alloc((size_t)n));
-        double *vcur = vbuf.p, *vnext = vbuf2.p;
-        if (m >= 2) {
-            hipLaunchKernelGGL(house_vec_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m - 1, vcur, tau.p, offd.p, 0);
-            hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((m - 1 + 3) / 4)), dim3(256), 0, s, A.p, ld, 4, m - 1, vcur, pbuf.p);
+        const int64_t vs = n;
+        DevBuf<double> Vd, Yp, Mp, Sm, Tall, abd;
+        MHS_HIP(Vd.alloc((size_t)BW * vs)); MHS_HIP(Yp.alloc((size_t)SYMM_SPLITS * BW * vs));
+        const int max_cg = (m + SYMM_COLS - 1) / SYMM_COLS;
+        MHS_HIP(Mp.alloc((size_t)max_cg * SYMM_SPLITS * BW * BW));
+        MHS_HIP(Sm.alloc((size_t)BW * BW));
+        int npanels = 0;
+        for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
+        MHS_HIP(Tall.alloc((size_t)std::max(npanels, 1) * BW * BW));
+        MHS_HIP(abd.alloc((size_t)m * (BW + 1)));
+        for (int p = 0; p < npanels; ++p) {
+            const int c = p * BW, t = m - c - BW, c0 = 3 + c, r0 = 3 + c + BW;
+            double *Tp = Tall.p + (size_t)p * BW * BW;
+            if (t <= PANEL_THREADS * PANEL_RPT)
+                hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vd.p, vs, Tp, gbuf.p + c + BW);
+            else
+                hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vd.p, vs, Tp, gbuf.p + c + BW);
+            const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS;
+            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, SYMM_SPLITS), dim3(256), 0, s, A.p, ld, r0, t, Vd.p, vs, Yp.p, Mp.p);
+            hipLaunchKernelGGL(band_s_kernel, dim3(1), dim3(1024), 0, s, Mp.p, ncg * SYMM_SPLITS, Tp, Sm.p);
+            dim3 grid((unsigned)((t + 63) / 64), (unsigned)((t + 63) / 64));
+            hipLaunchKernelGGL(band_update_kernel, grid, dim3(256), 0, s, A.p, ld, r0, t, Vd.p, Yp.p, vs, Tp, Sm.p);
         }
-        for (int k = 0; k + 1 < m; ++k) {
-            const int t = m - k - 1;
-            hipLaunchKernelGGL(tri_step_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3 + k + 1, t, pbuf.p, vcur, vnext,
-                               wbuf.p, gbuf.p + k + 1, tau.p, offd.p, k);
-            if (t >= 2)
-                hipLaunchKernelGGL(tri_fused_kernel, dim3((unsigned)((t - 1 + 3) / 4)), dim3(256), 0, s, A.p, ld,
-                                   3 + k + 1, t, vcur, wbuf.p, vnext, pbuf.p);
-            std::swap(vcur, vnext);
-        }
+        hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)((m * (BW + 1) + 255) / 256)), dim3(256), 0, s, A.p, ld, 3, m, abd.p);
         MHS_HIP(hipGetLastError());
-        std::vector<double> diag((size_t)m), off((size_t)std::max(m - 1, 1)), g((size_t)m), q((size_t)m);
-        MHS_HIP(hipMemcpy2DAsync(diag.data(), sizeof(double), A.p + 3 * ld + 3, sizeof(double) * (ld + 1),
-                                 sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
-        if (m > 1) MHS_HIP(hipMemcpyAsync(off.data(), offd.p, sizeof(double) * (m - 1), hipMemcpyDeviceToHost, s));
+        std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
+        MHS_HIP(hipMemcpyAsync(ab.data(), abd.p, sizeof(double) * ab.size(), hipMemcpyDeviceToHost, s));
         MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
-        TridiagGcv tg;
-        tg.a = diag.data(); tg.b = off.data(); tg.g = g.data(); tg.m = m; tg.n = n; tg.N = N; tg.pure_ss = pure_ss;
-        lam = tg.find_lambda(gcv_mode);
+        lap("band reduction (GPU)");
+        BandGcv bg;
+        bg.ab = ab.data(); bg.g = g.data(); bg.m = m; bg.n = n; bg.N = N; bg.bw = BW; bg.pure_ss = pure_ss;
+        lam = bg.find_lambda(gcv_mode);
         if (std::isnan(lam)) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
-        tg.eval(lam, &gcv, &eff_df, q.data());
+        lap("GCV search (host, banded)");
+        BandGcv::Work wk;
+        if (!bg.eval(lam, &gcv, &eff_df, q.data(), wk)) { set_error("mhs_tps_fit: band matrix not positive definite"); return MHS_ERR_NUMERIC; }
         MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(backtransform_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, tau.p, gbuf.p);
+        if (npanels > 0)
+            hipLaunchKernelGGL(band_backtransform_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
         MHS_HIP(hipGetLastError());
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
+        lap("solve + back-transform");
     }
 
     // d = R^-1 (w1 - Atop c2) ; c~ = Q [0; c2] ; c = W^1/2 c~

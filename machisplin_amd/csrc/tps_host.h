@@ -18,6 +18,24 @@ struct TridiagGcv {
     double find_lambda(int mode) const;
 };
 
+// The same criterion on a symmetric BANDED form (bandwidth bw): the GPU reduces B only to a band
+// (blocked, BLAS-3 style; tps_fit.hip) and every GCV evaluation is a banded Cholesky, a banded
+// solve and the trace of the inverse by Takahashi's selected inversion, O(m bw^2).
+// ab: lower band, column-major: ab[d + (bw + 1) * j] = M[j + d][j], d = 0..bw.
+struct BandGcv {
+    const double *ab = nullptr;
+    const double *g = nullptr;
+    int64_t m = 0, n = 0, N = 0;
+    int bw = 1;
+    double pure_ss = 0.0;
+    int threads = 0;  // host threads for the independent evaluations (0 = auto, capped at 16)
+    struct Work { std::vector<double> L, Z, q; };
+    bool eval(double lam, double *gcv, double *tra, double *q_out, Work &w) const;
+    double find_lambda(int mode) const;
+    int inertia_below(double x, Work &w) const;  // eigenvalues < x (unpivoted banded LDL')
+    double eig_kth(int64_t k) const;
+};
+
 void qr_n3(std::vector<double> &T, int64_t n, std::vector<double> v[3], double tau[3], double R[9]);
 void apply_reflector(const std::vector<double> &v, double tau, double *x, int64_t n);
 
