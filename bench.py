@@ -84,6 +84,10 @@ class Workload:
     def step(self):
         self.last = self.run.step()
 
+    def collect(self):
+        self.torch.cuda.synchronize()
+        self.ops.collect()
+
     # ---- algorithmic work per launch of the heavy kernels ----------------
     def kernel_table(self):
         ops = self.ops
@@ -113,18 +117,33 @@ class Workload:
                 rows.append({"kernel": "svr_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop"})
             elif k in ("gbm", "rf"):
-                visits = self.mean_visits[k] * band_cells
-                by = visits * 16.0
-                rows.append({"kernel": "tree_kernel<%s>" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "%.1f node visits/cell x 16 B node record "
-                             "(LDS-latency-bound walk; node bytes are served from LDS, not HBM)" % self.mean_visits[k]})
+                # HBM-level algorithmic bytes: C float32 planes read + fp64 output read-modify-write.  The
+                # kernels are VALU-issue / LDS bound (gbm: 5 key compares + LUT read per tree; rf: two LDS reads
+                # per level), so the HBM fraction is tiny by design; node visits/s is the domain rate.
+                by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
+                name = "gbm_lut_kernel" if k == "gbm" else "rf_walk_kernel"
+                rows.append({"kernel": name, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view); compute view: %.0f node visits/cell "
+                                     "of the reference walk, %.3g visits/s" % (self.cfg["layers"], self.mean_visits[k],
+                                                                             self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
             else:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
                 rows.append({"kernel": "%s_kernel" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "read C fp32 planes + read-modify-write fp64 out"})
+        pmc = {}
+        try:  # bytes per cell measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled as
+            # the gfx950 guide prescribes) on scratch/pmc_probe; committed under profiles/
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                for kn, d in json.load(f)["kernels"].items():
+                    pmc[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
+        except (OSError, KeyError, ValueError):
+            pass
         for r in rows:
             r["frac"] = r["achieved"] / r["peak"]
-            r["traffic"] = None
+            per_cell = pmc.get(r["kernel"].split("<")[0])
+            r["traffic"] = per_cell * band_cells if per_cell is not None else None
         return rows
 
     def measure_mean_visits(self):
@@ -230,11 +249,13 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     fence()
+    wl.collect()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     fence()
     dt = time.perf_counter() - t0
+    wl.collect()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -245,7 +266,16 @@ def main():
         table = wl.kernel_table()
         dom = max(table, key=lambda r: r["launch_ms"])
         tm = wl.ops.timings
-        fit_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):]))
+        fit_overlapped_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):]))
+        # inside a step the fit runs BESIDE the ensemble kernels (it is starved by them and its wall time
+        # is not a kernel property), so the TPS-solve rate is taken from a stand-alone fit after the run
+        knots, resid = wl.ops.X[:, -2:], wl.run.ops.station_residuals()[1]
+        fit_ms = 1e30
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            mhs.Tps(knots, resid)
+            fit_ms = min(fit_ms, (time.perf_counter() - t1) * 1e3)
         m = wl.ops.X.shape[0] - 3
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
@@ -265,9 +295,9 @@ def main():
                        "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world},
             "roofline": {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")},
             "kernels": table,
-            "tps_fit_ms": fit_ms,
+            "tps_fit_ms": fit_ms, "tps_fit_ms_overlapped_with_ensemble": fit_overlapped_ms,
             "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,
-            "tps_solve_flop_model": "4/3 (n-3)^3: Householder tridiagonalisation of Q2'KQ2 (GCV path)",
+            "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline:

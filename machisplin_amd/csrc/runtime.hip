@@ -87,7 +87,12 @@ int mhs_init(int device) {
         return MHS_ERR_NODEVICE;
     }
     c.n_cu = prop.multiProcessorCount;
-    MHS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    // private stream for the host entry points (the fit's thousands of small dependent kernels): non-
+    // blocking w.r.t. the default stream and high priority, so a fit can run beside long ensemble
+    // kernels that a caller has enqueued on its own stream
+    int prio_lo = 0, prio_hi = 0;
+    MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    MHS_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_hi));
     MHS_HIP(hipEventCreate(&c.ev0));
     MHS_HIP(hipEventCreate(&c.ev1));
     std::vector<double2> tab;

@@ -63,10 +63,14 @@ class ShardedMltps:
     def step(self):
         ops, torch = self.ops, self.torch
         nb = self.r1 - self.r0
-        if nb > 0:
-            ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
+        # Step 2 at the stations first (a few thousand points): it is all the fit needs, so rank 0
+        # can fit the spline WHILE every rank's ensemble band is still running -- the band kernels
+        # are only enqueued here (VALU / LDS bound), the fit's many small bandwidth-bound kernels run
+        # on the library's own high-priority stream
         knots, resid, resp, rows, cols = ops.station_residuals()
         n = knots.shape[0]
+        if nb > 0:
+            ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
         msg = torch.zeros(3 * n + 8, dtype=torch.float64, device=ops.device)
         if self.rank == 0:
             msg.copy_(torch.from_numpy(np.ascontiguousarray(ops.tps_fit(knots, resid))))
@@ -117,19 +121,26 @@ class HipOps:
         self.timed = timed
         self.timings = {"ensemble_ms": [], "tps_eval_ms": [], "tps_fit_ms": [], "residuals_ms": []}
         self.last_fit = None
+        self._pending = []
 
     def _timed(self, key, fn):
+        """Bracket `fn`'s launches with HIP events on the stream they are enqueued on (torch's
+        current stream); no host synchronisation here -- collect() reads the durations later."""
         if not self.timed:
             return fn()
-        import ctypes
-        st = self.torch.cuda.current_stream(self.device).cuda_stream
-        lib = self._lib.lib()
-        self._lib.check(lib.mhs_timer_start(st))
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
+        e0.record()
         r = fn()
-        ms = ctypes.c_double()
-        self._lib.check(lib.mhs_timer_stop(st, ctypes.byref(ms)))
-        self.timings[key].append(ms.value)
+        e1.record()
+        self._pending.append((key, e0, e1))
         return r
+
+    def collect(self):
+        """After a device synchronisation: move the recorded event pairs into `timings` (ms)."""
+        for key, e0, e1 in self._pending:
+            self.timings.setdefault(key, []).append(e0.elapsed_time(e1))
+        self._pending = []
 
     def ensemble_band(self, r0, r1, out):
         from .models import ensemble_predict
