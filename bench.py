@@ -80,6 +80,29 @@ class Workload:
         self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side)
         self.cells = side * side
         self.last = None
+        self.rank0_share = None
+        if world > 1:
+            # Load balance (setup, untimed): rank 0 also carries the spline fit, so it gets fewer rows.  One
+            # calibration pass with equal bands gives this GPU's time for all cells and the stand-alone fit time;
+            # rank 0 decides the share and broadcasts it so that every rank builds the same bands.
+            self.run.step()
+            self.collect()
+            share = torch.zeros(1, dtype=torch.float64, device="cuda")
+            if rank == 0:
+                tm = self.ops.timings
+                band_ms = sum(v[-1] for k, v in tm.items() if k.startswith("model_") or k == "tps_eval_ms")
+                cells_ms = band_ms * side / max(1, self.run.r1 - self.run.r0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                mhs.Tps(self.ops.X[:, -2:], self.run.ops.station_residuals()[1])
+                fit_ms = (time.perf_counter() - t1) * 1e3
+                share[0] = sharded.balanced_rank0_share(world, cells_ms, fit_ms)
+            dist.broadcast(share, src=0)
+            self.rank0_share = float(share.item())
+            for v in self.ops.timings.values():
+                v.clear()
+            self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side,
+                                            rank0_share=self.rank0_share)
 
     def step(self):
         self.last = self.run.step()
@@ -292,7 +315,8 @@ def main():
                        "covariates": "%d x float32 planes resident in HBM" % cfg["layers"],
                        "members": [p["kind"] for p in wl.params], "gbm_trees": cfg["gbm_trees"], "rf_trees": cfg["rf_trees"],
                        "tps_mode": "global (one fit on all stations, GCV lambda, V73:748-753)",
-                       "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world},
+                       "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world,
+                       "rank0_row_share": wl.rank0_share},
             "roofline": {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")},
             "kernels": table,
             "tps_fit_ms": fit_ms, "tps_fit_ms_overlapped_with_ensemble": fit_overlapped_ms,

@@ -14,11 +14,36 @@ from __future__ import annotations
 import numpy as np
 
 
-def row_bands(nrow: int, world: int):
-    """Equal-height contiguous bands (all_gather_into_tensor needs equal chunks); the last
-    bands may be short or empty.  Returns band height and [(r0, r1)] per rank."""
-    band = -(-nrow // world)
-    return band, [(min(r * band, nrow), min((r + 1) * band, nrow)) for r in range(world)]
+def row_bands(nrow: int, world: int, rank0_share: float | None = None):
+    """Contiguous row bands, one per rank.  With rank0_share = None the bands are equal
+    (ceil(nrow / world) rows, the last ones may be short or empty).  Otherwise rank 0 -- which
+    also carries the spline fit -- gets round(rank0_share * nrow) rows (possibly none) and the
+    other ranks split the rest evenly.  Returns (rows of the largest band, [(r0, r1)] per rank);
+    the all-gather moves equal chunks of that height and the stitch drops the padding."""
+    if world == 1:
+        return nrow, [(0, nrow)]
+    if rank0_share is None:
+        band = -(-nrow // world)
+        return band, [(min(r * band, nrow), min((r + 1) * band, nrow)) for r in range(world)]
+    n0 = int(round(min(max(rank0_share, 0.0), 1.0) * nrow))
+    rest, others = nrow - n0, world - 1
+    base, extra = divmod(rest, others)
+    bands, r = [(0, n0)], n0
+    for k in range(others):
+        h = base + (1 if k < extra else 0)
+        bands.append((r, r + h))
+        r += h
+    return max(b[1] - b[0] for b in bands), bands
+
+
+def balanced_rank0_share(world: int, cells_ms: float, fit_ms: float) -> float:
+    """Share of the rows for rank 0 so that  fit + its band  takes as long as the other ranks' bands:
+    s0 = 1/N - fit (N-1) / (N cells_ms), clamped to [0, 1/N]  (cells_ms = one GPU's time for ALL the
+    cells, fit_ms = the stand-alone fit)."""
+    if world <= 1:
+        return 1.0
+    s0 = 1.0 / world - fit_ms * (world - 1) / (world * max(cells_ms, 1e-9))
+    return min(max(s0, 0.0), 1.0 / world)
 
 
 def pack_tps(knots, c, d, center, scale, lambda_):
@@ -47,18 +72,29 @@ class ShardedMltps:
       gather(plane, rows, cols) -> np.ndarray                                            (Step 5)
     """
 
-    def __init__(self, ops, dist, rank: int, world: int, nrow: int, ncol: int):
+    def __init__(self, ops, dist, rank: int, world: int, nrow: int, ncol: int, rank0_share: float | None = None):
         import torch
         self.ops, self.dist, self.rank, self.world = ops, dist, rank, world
         self.nrow, self.ncol = nrow, ncol
-        self.band, self.bands = row_bands(nrow, world)
+        self.band, self.bands = row_bands(nrow, world, rank0_share)
         self.r0, self.r1 = self.bands[rank]
+        self.even = all(b[1] - b[0] == self.band for b in self.bands[:-1]) and rank0_share is None
         kw = {"dtype": torch.float64, "device": ops.device}
         self.pred = torch.zeros((self.band, ncol), **kw)
         self.tps = torch.zeros((self.band, ncol), **kw)
         self.total_band = torch.zeros((self.band, ncol), **kw)
-        self.full = torch.zeros((self.band * world, ncol), **kw)  # all-gather target
+        self.full = torch.zeros((self.band * world, ncol), **kw)  # all-gather target (padded bands)
+        self.stitched = None if self.even else torch.zeros((nrow, ncol), **kw)
         self.torch = torch
+
+    def _stitch(self):
+        """The gathered buffer holds `world` chunks of `band` rows; with uneven bands drop the padding."""
+        if self.even:
+            return self.full[:self.nrow]
+        for r, (a, b) in enumerate(self.bands):
+            if b > a:
+                self.stitched[a:b].copy_(self.full[r * self.band:r * self.band + (b - a)])
+        return self.stitched
 
     def step(self):
         ops, torch = self.ops, self.torch
@@ -84,7 +120,7 @@ class ShardedMltps:
             self.dist.all_gather_into_tensor(self.full, self.total_band)
         else:
             self.full.copy_(self.total_band)
-        total = self.full[:self.nrow]
+        total = self._stitch()
         # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
         f_actual = ops.gather(total, rows, cols)
         tss = float(np.sum((resp - resp.mean()) ** 2))
@@ -97,7 +133,7 @@ class ShardedMltps:
                 self.dist.all_gather_into_tensor(self.full, self.pred)
             else:
                 self.full.copy_(self.pred)
-            final = self.full[:self.nrow]
+            final = self._stitch()
         return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": float(packed[3 * n + 7])}
 
 

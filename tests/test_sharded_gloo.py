@@ -56,12 +56,12 @@ class OracleOps:
         return plane[torch.from_numpy(rows), torch.from_numpy(cols)].numpy()
 
 
-def _worker(rank, world, port, q, w):
+def _worker(rank, world, port, q, w, share=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = sharded.ShardedMltps(OracleOps(w), dist, rank, world, NROW, NCOL)
+        run = sharded.ShardedMltps(OracleOps(w), dist, rank, world, NROW, NCOL, rank0_share=share)
         out = run.step()
         q.put((rank, out["final"].numpy().copy(), out["rsq_model"], out["rsq_final"], out["lambda"]))
         dist.barrier()
@@ -78,6 +78,12 @@ def _free_port():
 def test_row_bands_and_packing():
     band, bands = sharded.row_bands(37, 2)
     assert band == 19 and bands == [(0, 19), (19, 37)]
+    # rank 0 also carries the fit: it can be given fewer rows, or none
+    assert sharded.row_bands(100, 4, rank0_share=0.1) == (30, [(0, 10), (10, 40), (40, 70), (70, 100)])
+    assert sharded.row_bands(10, 3, rank0_share=0.0) == (5, [(0, 0), (0, 5), (5, 10)])
+    assert sharded.row_bands(10, 1, rank0_share=0.3) == (10, [(0, 10)])
+    assert sharded.balanced_rank0_share(8, 1050.0, 130.0) == pytest.approx(0.125 - 130 * 7 / (8 * 1050))
+    assert sharded.balanced_rank0_share(8, 500.0, 130.0) == 0.0 and sharded.balanced_rank0_share(2, 1e9, 1.0) == pytest.approx(0.5)
     assert sharded.row_bands(10, 4) == (3, [(0, 3), (3, 6), (6, 9), (9, 10)])
     assert sharded.row_bands(2, 4)[1] == [(0, 1), (1, 2), (2, 2), (2, 2)]  # more ranks than rows
     kn = np.arange(10.0).reshape(5, 2)
@@ -89,13 +95,13 @@ def test_row_bands_and_packing():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("w", [1.0, 0.8])
-def test_two_ranks_equal_one_rank(w):
+@pytest.mark.parametrize("w,share", [(1.0, None), (0.8, None), (1.0, 0.2), (1.0, 0.0)])
+def test_two_ranks_equal_one_rank(w, share):
     single = sharded.ShardedMltps(OracleOps(w), None, 0, 1, NROW, NCOL).step()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, w)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, w, share)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]

@@ -94,3 +94,16 @@ def test_fit_then_grid_end_to_end(hip):
     # and against the oracle's own lambda: 1e-6 is the north-star bound
     ref2 = otps.predict_grid(want, g.xmin, g.ymax, g.xres, g.yres, 160, 200)
     assert _rel(surf, ref2) < 1e-6
+
+
+def test_large_fit_uses_streaming_panel_path(hip):
+    """n > 5 123 stations: the first panels of the band reduction exceed the register-resident
+    panel kernel (512 threads x 10 rows) and go through the streaming variant."""
+    xy, y = synth_stations(5400, 99)
+    got = hip.Tps(xy, y)
+    want = otps.fit(xy, y)
+    assert abs(got.lambda_ - want["lambda"]) / want["lambda"] < 1e-7
+    ref = otps.fit(xy, y, lam=got.lambda_)
+    assert _rel(got.c, ref["c"]) < 1e-7 and _rel(got.d, ref["d"]) < 1e-7
+    fixed = hip.Tps(xy, y, lambda_=got.lambda_)  # Cholesky route agrees with the band route
+    assert _rel(fixed.c, got.c) < 1e-8
