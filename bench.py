@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64: vector == MFMA peak (v_mfma_f64_16x16x4 measured 75.3 TF)
 HBM_PEAK_GBS = 8000.0
+FP32_PEAK_TFLOPS = 157.3  # FP32 vector == FP32 MFMA peak
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the north-star target is quoted on
@@ -139,17 +140,26 @@ class Workload:
                 fl = band_cells * nsv * (3.0 * p + 2.0)
                 rows.append({"kernel": "svr_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop"})
-            elif k in ("gbm", "rf"):
-                # HBM-level algorithmic bytes: C float32 planes read + fp64 output read-modify-write.  The
-                # kernels are VALU-issue / LDS bound (gbm: 5 key compares + LUT read per tree; rf: two LDS reads
-                # per level), so the HBM fraction is tiny by design; node visits/s is the domain rate.
+            elif k == "gbm":
+                # compute view (the kernel is VALU-issue bound, PMC traffic = the 28 B/cell it must move): per
+                # (cell, tree) the predicate-LUT form needs S threshold compares + 1 fp64 add, against the FP32
+                # vector/matrix peak the compares issue at
+                nt = len(prm["tree_offsets"]) - 1
+                ops_ = band_cells * nt * 6.0
+                rows.append({"kernel": "gbm_lut_kernel", "bound": "mfma", "launch_ms": ms, "achieved": ops_ / ms / 1e9,
+                             "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "work": "6 ops per (cell, tree): 5 split compares + 1 fp64 add (predicate-LUT form of gbm_pred); "
+                                     "reference walk = %.0f node visits/cell, %.3g visits/s" % (
+                                         self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
+            elif k == "rf":
+                # LDS-latency/bandwidth bound walk (two LDS reads per level); no clean roof -- HBM view reported
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
-                name = "gbm_lut_kernel" if k == "gbm" else "rf_walk_kernel"
-                rows.append({"kernel": name, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                rows.append({"kernel": "rf_walk_kernel", "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view); compute view: %.0f node visits/cell "
-                                     "of the reference walk, %.3g visits/s" % (self.cfg["layers"], self.mean_visits[k],
-                                                                             self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view; the walk itself is LDS-bound: "
+                                     "%.0f node visits/cell, %.3g visits/s)" % (self.cfg["layers"], self.mean_visits[k],
+                                                                              self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
             else:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
@@ -287,7 +297,7 @@ def main():
     if rank == 0:
         wl.measure_mean_visits()
         table = wl.kernel_table()
-        dom = max(table, key=lambda r: r["launch_ms"])
+        dom = max(table, key=lambda r: r["launch_ms"]) if table else None
         tm = wl.ops.timings
         fit_overlapped_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):]))
         # inside a step the fit runs BESIDE the ensemble kernels (it is starved by them and its wall time
@@ -317,7 +327,8 @@ def main():
                        "tps_mode": "global (one fit on all stations, GCV lambda, V73:748-753)",
                        "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world,
                        "rank0_row_share": wl.rank0_share},
-            "roofline": {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")},
+            "roofline": ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")}
+                         if dom else None),  # None only if rank 0 was given no rows at all
             "kernels": table,
             "tps_fit_ms": fit_ms, "tps_fit_ms_overlapped_with_ensemble": fit_overlapped_ms,
             "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,
