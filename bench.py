@@ -309,6 +309,14 @@ def main():
             t1 = time.perf_counter()
             mhs.Tps(knots, resid)
             fit_ms = min(fit_ms, (time.perf_counter() - t1) * 1e3)
+        # for the record (outside the timed region): the same residual surface the way the REFERENCE computes it at
+        # this size -- ceil(n/1500)^2 overlapping tiles with their own fits, mean mosaic, seam feathering (V73:656-895)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        info = {}
+        mhs.tps_residual_surface(wl.geom, knots, resid, cov1_at_stations=wl.ops.X[:, 0], tile_edge=1500, info=info)
+        torch.cuda.synchronize()
+        tiled_ms = (time.perf_counter() - t1) * 1e3
         m = wl.ops.X.shape[0] - 3
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
@@ -333,6 +341,7 @@ def main():
             "tps_fit_ms": fit_ms, "tps_fit_ms_overlapped_with_ensemble": fit_overlapped_ms,
             "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
+            "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline:

@@ -19,7 +19,13 @@ def stations(geom: Geometry, n: int, seed: int):
     """n stations on distinct cell centres (knots are cell centres, V73:128-133,145);
     returns xy (n x 2: LONG, LAT), the cell rows/cols, and unit-square coordinates."""
     rng = np.random.default_rng(seed)
-    cells = rng.choice(geom.ncell, size=n, replace=False)
+    if geom.ncell <= 50_000_000:
+        cells = rng.choice(geom.ncell, size=n, replace=False)
+    else:  # a permutation of a 4e8-cell grid would need gigabytes: oversample, keep the first n distinct
+        draw = rng.integers(0, geom.ncell, size=int(n * 1.2) + 64)
+        _, first = np.unique(draw, return_index=True)
+        cells = draw[np.sort(first)][:n]
+        assert cells.size == n
     rows, cols = np.divmod(cells, geom.ncol)
     xy = np.column_stack([geom.x_from_col(cols), geom.y_from_row(rows)])
     uv = np.column_stack([(cols + 0.5) / geom.ncol, (rows + 0.5) / geom.nrow])

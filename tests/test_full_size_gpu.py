@@ -1,0 +1,110 @@
+"""GPU, at BASELINE.json's FULL sizes, through size-independent properties (no oracle run at
+these sizes): two independent HIP implementations of the same member must agree bit for bit,
+windows must tile the full-grid result exactly, the fitted spline must satisfy its normal
+equations, and sampled rows must match the C oracle."""
+import numpy as np
+import pytest
+
+from oracle import cbind, ensemble as oe, tps as otps
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg3_stack(hip, side, dtype="f32"):
+    from machisplin_amd import synth
+    g = synth.grid(side, side)
+    planes, nodata = synth.covariates(g, 3, synth.BASE_SEED + 3, dtype=dtype, nodata_frac=0.001)
+    return g, hip.RasterStack(g, planes, nodata), planes
+
+
+def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip):
+    """gbm: predicate-LUT kernel vs node walk; randomForest: level-synchronous LDS walk vs node walk.
+    float32 planes take the fast kernels, the same values as float64 planes take the generic walk;
+    both sum the trees in the same order, so the 10 000 x 10 000 planes must be IDENTICAL."""
+    import torch
+    from machisplin_amd import synth
+    side = 10000
+    g, stack32, planes = _cfg3_stack(hip, side)
+    xy, rows, cols, uv = synth.stations(g, 5000, synth.BASE_SEED + 3)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([np.nan_to_num(cov), xy])
+    y = synth.response(X, uv, 1)
+    stack64 = hip.RasterStack(g, planes.to(torch.float64), float("nan"))  # same values, generic-walk kernels
+    for prm in (synth.gbm_params(X, y, 3, n_trees=10000), synth.rf_params(X, y, 3, n_trees=500)):
+        m = hip.models.from_oracle_dict(prm)
+        a = hip.predict(stack32, m)
+        b = hip.predict(stack64, m)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), prm["kind"]
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), prm["kind"]
+        del a, b
+    del stack64
+    # sampled rows against the C oracle (gbm NA routing included)
+    host = planes[:, 4321:4323].cpu().numpy().astype(np.float64)
+    xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, side, side, 4321, 4323)
+    Xg = oe.stack_predictors(host, (xs, ys))
+    prm = synth.rf_params(X, y, 3, n_trees=500)
+    got = hip.predict(stack32, hip.models.from_oracle_dict(prm), window=(4321, 4323, 0, side)).cpu().numpy().ravel()
+    want = cbind.predict(prm, Xg, threads=8)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) < 1e-11 * np.nanmax(np.abs(want))
+
+
+def test_cfg2_tps_windows_tile_the_full_grid_and_match_c_oracle(hip):
+    import torch
+    from machisplin_amd import synth
+    g = synth.grid(2000, 2000)
+    xy, rows, cols, uv = synth.stations(g, 2000, synth.BASE_SEED + 2)
+    fit = hip.Tps(xy, synth.tps_residual(uv, synth.BASE_SEED + 2))
+    full = hip.interpolate(g, fit)
+    pieces = torch.empty_like(full)
+    for (r0, r1, c0, c1) in [(0, 777, 0, 1001), (0, 777, 1001, 2000), (777, 2000, 0, 63), (777, 2000, 63, 2000)]:
+        hip.interpolate(g, fit, window=(r0, r1, c0, c1), out=pieces[r0:r1, c0:c1])
+    assert torch.equal(full, pieces)  # ragged windows, same cells, same bits
+    m = {"knots": fit.knots, "c": fit.c, "d": fit.d, "center": fit.center, "scale": fit.scale}
+    for r0 in (0, 1234, 1999):
+        want = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, r0, r0 + 1, 0, 2000, threads=8)
+        assert np.abs(full[r0:r0 + 1].cpu().numpy() - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n", [5000, 20000])
+def test_fitted_spline_satisfies_its_normal_equations(hip, n):
+    """(K + lambda I) c + T d = y and T'c = 0, checked through the GPU evaluation at the knots:
+    f(x_i) = y_i - lambda c_i.  n = 20 000 is BASELINE config 5's station count (3.2 GB Gram matrix)."""
+    from machisplin_amd import synth
+    g = synth.grid(20000, 20000)
+    xy, rows, cols, uv = synth.stations(g, n, synth.BASE_SEED + 5)
+    y = synth.tps_residual(uv, synth.BASE_SEED + 5)
+    lam = 1e-4
+    fit = hip.Tps(xy, y, lambda_=lam)
+    f = fit.predict(xy)
+    assert np.abs(f - (y - lam * fit.c)).max() < 1e-7 * np.abs(y).max()
+    T = np.column_stack([np.ones(n), fit.knots])
+    assert np.abs(T.T @ fit.c).max() < 1e-7 * np.abs(fit.c).max() * n ** 0.5
+    if n == 5000:  # GCV route lands on a lambda whose surface obeys the same identity
+        fg = hip.Tps(xy, y)
+        assert np.abs(fg.predict(xy) - (y - fg.lambda_ * fg.c)).max() < 1e-7 * np.abs(y).max()
+        assert 3.0 < fg.eff_df < n
+
+
+def test_cfg3_ensemble_linearity_on_the_full_grid(hip):
+    """pred = (sum_k w_k pred_k) / wt.tot: the fused Step-2 loop equals the members evaluated one by one."""
+    import torch
+    from machisplin_amd import synth
+    side = 10000
+    g, stack, planes = _cfg3_stack(hip, side)
+    xy, rows, cols, uv = synth.stations(g, 2000, 11)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([np.nan_to_num(cov), xy])
+    y = synth.response(X, uv, 2)
+    params = synth.ensemble_params(X, y, 4, n_gbm_trees=300, n_rf_trees=20, which="gnmv")
+    mods = [hip.models.from_oracle_dict(p) for p in params]
+    wts, tot = [0.22, 0.12, 0.18, 0.41], 1.23
+    fused = hip.ensemble_predict(stack, mods, wts, tot)
+    acc = None
+    for m, w in zip(mods, wts):
+        pk = hip.predict(stack, m) * w
+        acc = pk if acc is None else acc + pk
+    ref = (acc.cpu().numpy()) / tot
+    got = fused.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.allclose(got, ref, rtol=1e-15, atol=0, equal_nan=True)
