@@ -187,3 +187,65 @@ def test_one_call_surface_equals_composed_steps(hip):
                                           float("nan"), 0, out.ctypes.data, nt.ctypes.data))
     assert list(nt) == [1, 1]
     assert np.array_equal(out, hip.tps_residual_surface(g, xy, resid, tile_edge=None).cpu().numpy())
+
+
+def test_cfg4_chain_tiles_create_per_tile_mltps_tiles_merge(hip):
+    """BASELINE config 4 in miniature: machisplin.tiles.create (2 x 2, feather.d) -> an independent
+    mltps run per tile and response layer with the smooth members only (g, n, m, v -- V73:366-392)
+    -> machisplin.tiles.merge.  Oracle: the same chain, literally."""
+    import torch
+    from machisplin_amd import synth
+    g, stack, host, X, xy, resp, params = _ensemble_inputs(hip, 260, 340, 900, 43)
+    og = _og(g)
+    smooth = [params[1], params[2], params[3], params[5]]  # g, n, m, v
+    kept, wts, tot = hip.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")
+    assert kept == "gnmv"
+    t = hip.tiles.tiles_create(g, xy, out_ncol=2, out_nrow=2, feather_d=30)
+    boxes, owins, osel = ot.tiles_create(og, xy, 2, 2, 30)
+    assert np.array_equal(t["win"], np.array(owins))
+    for layer in range(2):  # two response layers
+        y = resp + 0.5 * layer * np.sin(3 * xy[:, 0])
+        finals_gpu, finals_cpu = [], []
+        for h in range(4):
+            r0, r1, c0, c1 = (int(v) for v in t["win"][h])
+            sel = t["dat"][h]
+            assert np.array_equal(sel, osel[h])
+            sub = hip.RasterStack(t["geom"][h], stack.planes[:, r0:r1, c0:c1].contiguous(), stack.nodata)
+            mods = [hip.models.from_oracle_dict(p) for p in smooth]
+            res = hip.mltps_predict(sub, xy[sel], y[sel], mods, wts, tot, tps=True, tile_edge=100)
+            finals_gpu.append(res["final"].contiguous())
+            # ---- oracle for this tile
+            tg = ot.window_geom(og, (r0, r1, c0, c1))
+            Xt = oe.stack_predictors(host[:, r0:r1, c0:c1], otps.cell_centres(tg.xmin, tg.ymax, tg.xres, tg.yres, tg.nrow, tg.ncol))
+            rows = np.array([tg.row_from_y(v) for v in xy[sel, 1]])
+            cols = np.array([tg.col_from_x(v) for v in xy[sel, 0]])
+            Xs = Xt[rows * tg.ncol + cols]
+            keep = ~np.isnan(Xs).any(axis=1)
+            Xs, ys = Xs[keep], y[sel][keep]
+            pred = oe.ensemble(smooth, wts, tot, Xt).reshape(tg.nrow, tg.ncol)
+            rf = None
+            for p, w in zip(smooth, wts):
+                rk = (ys - oe.predict(p, Xs)) * w
+                rf = rk if rf is None else rf + rk
+            rf = rf / tot
+            lam = res["tps_info"]["lambda"]
+            nRx, nCx, fw, kw = ot.step3_windows(tg, 100)
+            tl = []
+            for k in range(nRx * nCx):
+                s2 = ot.stations_in_window(tg, fw[k], Xs[:, -2:], host[0, r0:r1, c0:c1])
+                gf = ot.window_geom(tg, fw[k])
+                wk = (kw[k][0] - fw[k][0], kw[k][1] - fw[k][0], kw[k][2] - fw[k][2], kw[k][3] - fw[k][2])
+                if s2.size < 10:
+                    tl.append(np.zeros((kw[k][1] - kw[k][0], kw[k][3] - kw[k][2])))
+                else:
+                    tl.append(otps.predict_grid(otps.fit(Xs[s2, -2:], rf[s2], lam=lam[k]), gf.xmin, gf.ymax, gf.xres, gf.yres,
+                                                gf.nrow, gf.ncol, *wk))
+            layers = [ot.extend_full(tg, kw[k], tl[k]) for k in range(len(kw))]
+            ftps = ot.feather_and_merge(tg, nRx, nCx, kw, tl, ot.mosaic_mean(layers[::-1]))
+            fin, rm, rfin, _ = ot.step5_combine(tg, pred, ftps, Xs[:, -2:], ys)
+            assert abs(res["rsq_final"] - rfin) < 1e-6
+            finals_cpu.append(fin)
+        merged = hip.tiles.tiles_merge(g, t["win"], finals_gpu, in_ncol=2, in_nrow=2).cpu().numpy()
+        want = ot.tiles_merge(og, owins, finals_cpu, 2, 2)
+        assert np.array_equal(np.isnan(merged), np.isnan(want))
+        assert np.nanmax(np.abs(merged - want)) < 1e-7 * np.nanmax(np.abs(want))
