@@ -38,6 +38,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg2": dict(stations=2000, side=2000, layers=3, gbm_trees=0, rf_trees=0, ensemble=False,
                  name="cfg2: 2000 stations, 2000x2000 grid, TPS only"),
+    # BASELINE.json configs[4] (its 8-GPU shape; also runs on one GPU: 3.2 GB Gram matrix, 8e12 TPS pairs)
+    "cfg5": dict(stations=20000, side=20000, layers=5, gbm_trees=10000, rf_trees=500, ensemble=True,
+                 name="cfg5: 20000 stations, 5 covariates, 20000x20000 grid, 6-model ensemble + TPS residual correction"),
     # a small version of cfg3 for quick checks (NOT a bench line)
     "cfg3-mini": dict(stations=1000, side=1500, layers=3, gbm_trees=500, rf_trees=50, ensemble=True,
                       name="cfg3-mini (debug only)"),

@@ -249,6 +249,10 @@ MHS_API int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx,
                                    const int64_t *tile_win, const double *const *tile_dev,
                                    int merge_mode, double *out_dev, int64_t ld,
                                    int64_t *seam_win_out, void *stream);
+/* same with HOST tiles and a host output grid (what a .Call() shim hands over for
+ * machisplin.tiles.merge: each rast.in[[h]] as terra::values in cell order)                 */
+MHS_API int mhs_mosaic_feather(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
+                               const double *const *tile_host, int merge_mode, double *out_host);
 /* terra::extract(r, xy) after mhs_cells_from_xy: gather n cells of a device plane to the
  * host (NaN for row/col -1).  Step-5 station check V73:910                                */
 MHS_API int mhs_gather_cells_dev(const double *plane_dev, int64_t ld, const int64_t *rows,

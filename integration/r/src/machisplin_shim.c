@@ -126,3 +126,19 @@ SEXP mhsr_predict_points(SEXP model, SEXP X) {
     chk(rc);
     return out;
 }
+
+/* machisplin.tiles.merge (V73:1392-1546): tiles = list of numeric vectors (terra::values of each
+ * rast.in[[h]] in cell order), win = integer matrix 4 x n (r0, r1, c0, c1 per tile, 0-based) */
+SEXP mhsr_tiles_merge(SEXP geom, SEXP tiles, SEXP win, SEXP in_ncol, SEXP in_nrow) {
+    mhs_grid g = grid_from(geom);
+    int n = Rf_length(tiles);
+    const double **h = (const double **)R_alloc((size_t)n, sizeof(*h));
+    int64_t *w = (int64_t *)R_alloc((size_t)4 * n, sizeof(int64_t));
+    for (int i = 0; i < n; ++i) h[i] = REAL(VECTOR_ELT(tiles, i));
+    for (int i = 0; i < 4 * n; ++i) w[i] = (int64_t)INTEGER(win)[i];
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)g.nrow * g.ncol));
+    int rc = mhs_mosaic_feather(&g, Rf_asInteger(in_nrow), Rf_asInteger(in_ncol), w, h, 1, REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}

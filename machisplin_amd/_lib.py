@@ -85,6 +85,7 @@ SIGNATURES = {
     "mhs_cells_from_xy": (C.c_int, [C.POINTER(Grid), _vp, _i64, _vp, _vp]),
     "mhs_mosaic_feather_dev": (C.c_int, [C.POINTER(Grid), _i64, _i64, _vp, C.POINTER(_vp), C.c_int, _vp, _i64,
                                          _vp, _vp]),
+    "mhs_mosaic_feather": (C.c_int, [C.POINTER(Grid), _i64, _i64, _vp, C.POINTER(_vp), C.c_int, _vp]),
     "mhs_gather_cells_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "mhs_tps_surface": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _vp]),
     "mhs_tps_surface_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64,

@@ -361,6 +361,29 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
     return MHS_OK;
 }
 
+int mhs_mosaic_feather(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
+                       const double *const *tile_host, int merge_mode, double *out_host) {
+    if (int rc = require_ready()) return rc;
+    if (int rc = check_grid(g)) return rc;
+    MHS_REQUIRE(nRx >= 1 && nCx >= 1 && tile_win && tile_host && out_host, "bad arguments");
+    const int64_t n = nRx * nCx;
+    hipStream_t s = ctx().stream;
+    std::vector<DevBuf<double>> bufs((size_t)n);
+    std::vector<const double *> ptrs((size_t)n);
+    for (int64_t h = 0; h < n; ++h) {
+        const int64_t cells = (tile_win[4 * h + 1] - tile_win[4 * h]) * (tile_win[4 * h + 3] - tile_win[4 * h + 2]);
+        MHS_REQUIRE(cells > 0 && tile_host[h], "bad tile");
+        MHS_HIP(bufs[h].alloc((size_t)cells));
+        MHS_HIP(hipMemcpyAsync(bufs[h].p, tile_host[h], sizeof(double) * (size_t)cells, hipMemcpyHostToDevice, s));
+        ptrs[h] = bufs[h].p;
+    }
+    DevBuf<double> out;
+    MHS_HIP(out.alloc((size_t)(g->nrow * g->ncol)));
+    if (int rc = mhs_mosaic_feather_dev(g, nRx, nCx, tile_win, ptrs.data(), merge_mode, out.p, g->ncol, nullptr, s)) return rc;
+    MHS_HIP(hipMemcpy(out_host, out.p, sizeof(double) * (size_t)(g->nrow * g->ncol), hipMemcpyDeviceToHost));
+    return MHS_OK;
+}
+
 int mhs_seam_count(int64_t nRx, int64_t nCx, int64_t *n_seams) {
     MHS_REQUIRE(nRx >= 1 && nCx >= 1 && n_seams, "bad arguments");
     *n_seams = (int64_t)seam_list(nRx, nCx).size();

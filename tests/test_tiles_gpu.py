@@ -56,6 +56,16 @@ def test_tiles_merge_with_na_cells_matches_oracle(hip):
     want = ot.tiles_merge(_og(g), wins, tiles, 3, 2)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.allclose(got, want, rtol=1e-15, atol=0, equal_nan=True)
+    # host-pointer entry point (what the R shim binds for machisplin.tiles.merge)
+    import ctypes as C
+    from machisplin_amd import _lib
+    host_tiles = [np.ascontiguousarray(x) for x in tiles]
+    ptrs = (C.c_void_p * 6)(*[x.ctypes.data for x in host_tiles])
+    out = np.empty((g.nrow, g.ncol))
+    gs = g.c_struct()
+    win = np.ascontiguousarray(t["win"], dtype=np.int64)
+    _lib.check(_lib.lib().mhs_mosaic_feather(C.byref(gs), 2, 3, win.ctypes.data, ptrs, 1, out.ctypes.data))
+    assert np.array_equal(out, got, equal_nan=True)
 
 
 def _ensemble_inputs(hip, nrow, ncol, n, seed):
