@@ -274,6 +274,38 @@ MHS_API int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const doubl
                                 int gcv_mode, double *out_dev, int64_t ld, int64_t *tiles_out,
                                 void *stream);
 
+/* ------------------------------------------------------------- raster wire formats --
+ * the formats on either side of the path.  Covariates arrive
+ * as GeoTIFF (terra::rast(); the bundled rasters are INT2S, LZW/deflate, NoData -32768,
+ * georeferenced by tags or .tfw sidecars: the .tif.ovr and .tfw files of inst/extdata) and results leave
+ * as FLT4S GeoTIFF, terra::writeRaster's default (machisplin.write.geotiff, V73:1011,1020).
+ * Reader: classic TIFF / BigTIFF, either byte order, strips or tiles, none / LZW / deflate,
+ * predictor 1-3, one band.  Host functions need no GPU.                                   */
+typedef struct mhs_tiff_info {
+    int64_t width, height;
+    int32_t bits, sample_format;   /* TIFF SampleFormat: 1 unsigned, 2 signed, 3 IEEE float       */
+    int32_t compression, n_ifd;    /* TIFF Compression tag; image directories (overview levels)    */
+    int32_t dtype;                 /* MHS_I16 / MHS_F32 / MHS_F64, or -1 if no device plane type   */
+    int32_t has_geo;               /* ModelPixelScale + ModelTiepoint present                      */
+    double nodata;                 /* GDAL_NODATA, NaN if absent                                   */
+    double xmin, ymax, xres, yres; /* north-west corner and cell size when has_geo                 */
+} mhs_tiff_info;
+MHS_API int mhs_tiff_info_read(const char *path, int ifd, mhs_tiff_info *out);
+/* decode image directory `ifd` into a host buffer of the file's native sample type, row-major */
+MHS_API int mhs_tiff_read_host(const char *path, int ifd, void *out, int64_t out_bytes);
+/* decode on host threads and stream into a DEVICE plane (element type = info.dtype, ld in
+ * elements): bands of ~32 MB, band k+1 is decoded while band k is in flight over PCIe         */
+MHS_API int mhs_tiff_read_dev(const char *path, int ifd, void *out_dev, int64_t ld_elems, void *stream);
+/* terra::writeRaster(x, "<layer>.tif") for a double raster: float32 strips, compression 1 (none)
+ * or 8 (deflate); NaN cells are written as `nodata` when it is not NaN (and the GDAL_NODATA tag
+ * is set), else as NaN.  Geo tags: pixel scale, tiepoint, EPSG:4326 (V73:164,775).              */
+MHS_API int mhs_tiff_write_f32_host(const char *path, const mhs_grid *g, const float *data, double nodata,
+                                    int compression);
+MHS_API int mhs_tiff_write_f32_dev(const char *path, const mhs_grid *g, const double *plane_dev, int64_t ld,
+                                   double nodata, int compression, void *stream);
+/* ESRI world file (.tfw): six numbers -- xres, rot, rot, -yres, x centre and y centre of the NW cell */
+MHS_API int mhs_tfw_read(const char *path, double *six);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,14 @@ class Stack(C.Structure):
                 ("plane_stride", C.c_int64), ("ld", C.c_int64), ("nodata", C.c_double)]
 
 
+class TiffInfo(C.Structure):
+    """struct mhs_tiff_info"""
+    _fields_ = [("width", C.c_int64), ("height", C.c_int64), ("bits", C.c_int32), ("sample_format", C.c_int32),
+                ("compression", C.c_int32), ("n_ifd", C.c_int32), ("dtype", C.c_int32), ("has_geo", C.c_int32),
+                ("nodata", C.c_double), ("xmin", C.c_double), ("ymax", C.c_double), ("xres", C.c_double),
+                ("yres", C.c_double)]
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -87,6 +95,12 @@ SIGNATURES = {
                                          _vp, _vp]),
     "mhs_mosaic_feather": (C.c_int, [C.POINTER(Grid), _i64, _i64, _vp, C.POINTER(_vp), C.c_int, _vp]),
     "mhs_gather_cells_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "mhs_tiff_info_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TiffInfo)]),
+    "mhs_tiff_read_host": (C.c_int, [C.c_char_p, C.c_int, _vp, _i64]),
+    "mhs_tiff_read_dev": (C.c_int, [C.c_char_p, C.c_int, _vp, _i64, _vp]),
+    "mhs_tiff_write_f32_host": (C.c_int, [C.c_char_p, C.POINTER(Grid), _vp, C.c_double, C.c_int]),
+    "mhs_tiff_write_f32_dev": (C.c_int, [C.c_char_p, C.POINTER(Grid), _vp, _i64, C.c_double, C.c_int, _vp]),
+    "mhs_tfw_read": (C.c_int, [C.c_char_p, _dp]),
     "mhs_tps_surface": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _vp]),
     "mhs_tps_surface_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64,
                                       _vp, _vp]),
