@@ -8,6 +8,7 @@
 // cache, exp from a 64-entry 2^(j/64) table in LDS); gbm / randomForest are LDS-latency
 // bound tree walks (node records staged chunk-wise in LDS, predictors parked in LDS so a
 // lane can index them by the node's split variable).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -67,7 +68,9 @@ struct mhs_model {
     // gbm predicate-LUT fast path (trees with <= 6 splits): see gbm_lut_kernel
     int lut_S = 0;                       // splits per tree after padding (0 = path unavailable)
     double *lut = nullptr;               // device, n_trees_padded << lut_S leaf values
-    int *lut_meta = nullptr;             // device, 12 dwords per tree: tkey[6] (float bits), key offset[6]
+    int *lut_meta = nullptr;             // device, 12 dwords per tree: c[6] (float bits), key offset[6]
+    float *lut_sorted = nullptr;         // device, sorted distinct key-space thresholds, predictor after predictor
+    int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
     int n_trees_padded = 0;
@@ -344,43 +347,101 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
 //       float32/int16 planes: key = the value, tkey = smallest float >= split;
 //       LONG: key = column index, tkey = #columns whose centre is < split (same double formula);
 //       LAT : key = -row index,   tkey = 0.5 - (first row whose centre is < split);
-//   * keys are parked in LDS as [var][lane][4 cells] so one ds_read_b128 at a wave-uniform
-//     var offset fetches the keys of the lane's 4 cells; the bits are gathered with
-//     compare + add-with-carry; the leaf comes from the tree's 2^S-entry LUT (one 256-byte
-//     LDS row for S = 5, conflict-free).
+//   * the keys are then replaced by their RANK among the model's sorted distinct tkeys of that
+//     predictor (rank = #{tkeys <= key}, found once per cell by a coarse LDS + fine global binary
+//     search), and a split on the j-th tkey carries c = j + 1:  key < tkey_j  <=>  rank <= j
+//     <=>  clamp(c - rank, 0, 1) = 1.  Ranks are small integers, exact in float32, so a
+//     predicate and its accumulation into the leaf index are two PACKED-f32 instructions for
+//     two cells (v_pk_add_f32 with the clamp modifier, v_pk_fma_f32 acc = 2 acc + bit) instead
+//     of compare + add-with-carry per cell: half the VALU issue slots of the kernel's hot loop;
+//   * -rank is parked in LDS as [var][lane][4 cells] so one ds_read_b128 at a wave-uniform var
+//     offset fetches the keys of the lane's 4 cells.  The accumulator starts at 2^(23-S) + t, so
+//     after S doublings its bit pattern is 0x4B000000 + (t << S) + b: the tree's LUT slot, turned
+//     into an LDS address by one shift-add; the leaf comes from the tree's 2^S-entry LUT (one
+//     256-byte LDS row for S = 5, conflict-free).
 // Cells with an NA covariate are skipped here and walked through their MissingNode
 // children by tree_kernel<GBM, .., NA_ONLY> afterwards (gbm_pred's NA routing).
 constexpr int LUT_R = 4;            // cells per lane
 constexpr int LUT_CHUNK = 64;       // trees per LDS chunk
-constexpr int LUT_META_DW = 12;     // dwords of meta per tree
+constexpr int LUT_META_DW = 12;     // dwords of meta per tree: c[6] (float), key offset[6]
+constexpr int LUT_COARSE = 4096;    // floats of the coarse rank table (aliases the LUT chunk buffer)
 
-// idx[c] = 2 idx[c] + (k[c] < tk) for the lane's 4 cells: compare into an SGPR pair, then
-// add-with-carry folds the predicate bit in (2 VALU per predicate and cell).  The four compares
-// are issued before the four adds so each add sits >= 3 instructions behind the compare whose
-// mask it consumes (VALU-writes-SGPR -> VALU-reads-as-carry needs 2 wait states on gfx950).
-__device__ __forceinline__ void pred4(unsigned (&idx)[4], const float4 k, const float tk) {
-    unsigned long long m0, m1, m2, m3;
-    asm("v_cmp_gt_f32_e64 %4, %12, %8\n\t"
-        "v_cmp_gt_f32_e64 %5, %12, %9\n\t"
-        "v_cmp_gt_f32_e64 %6, %12, %10\n\t"
-        "v_cmp_gt_f32_e64 %7, %12, %11\n\t"
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
-        "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
-        "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
-        "v_addc_co_u32_e64 %3, %7, %3, %3, %7"
-        : "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-        : "v"(k.x), "v"(k.y), "v"(k.z), "v"(k.w), "s"(tk));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// bit[c] = clamp(c_q - rank[c], 0, 1) for the lane's 4 cells (k holds -rank); HI selects which
+// dword of the SGPR pair {c_q, c_q+1} is broadcast to both halves of the packed add
+template <bool HI>
+__device__ __forceinline__ void pred_bits(float2v &b01, float2v &b23, const float2v k01, const float2v k23,
+                                          const unsigned long long cpair) {
+    if (!HI)
+        asm("v_pk_add_f32 %0, %2, %4 op_sel_hi:[1,0] clamp\n\t"
+            "v_pk_add_f32 %1, %3, %4 op_sel_hi:[1,0] clamp"
+            : "=&v"(b01), "=&v"(b23) : "v"(k01), "v"(k23), "s"(cpair));
+    else
+        asm("v_pk_add_f32 %0, %2, %4 op_sel:[0,1] op_sel_hi:[1,1] clamp\n\t"
+            "v_pk_add_f32 %1, %3, %4 op_sel:[0,1] op_sel_hi:[1,1] clamp"
+            : "=&v"(b01), "=&v"(b23) : "v"(k01), "v"(k23), "s"(cpair));
+}
+
+// rank[c] = #{sorted distinct tkeys of predictor j that are <= key[c]} for the lane's 4 cells: a
+// binary search of a coarse table (every stride-th tkey, staged in LDS by the whole block) and a
+// short fine search in global memory.  Must be called by every thread of the block.
+__device__ __forceinline__ void lut_ranks(const int j, const float *__restrict__ sorted,
+                                          const int *__restrict__ sorted_off, float *coarse,
+                                          const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
+                                          const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
+    const int o = sorted_off[j], n = sorted_off[j + 1] - o;
+    const float *T = sorted + o;
+    const int stride = (n + LUT_COARSE - 1) / LUT_COARSE;
+    const int nc = stride ? (n + stride - 1) / stride : 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc; e += 256) coarse[e] = T[(int64_t)e * stride];
+    __syncthreads();
+    float k[LUT_R];
+    int lo[LUT_R], cnt[LUT_R];
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k[c] = (float)xv; }
+        else if (j == s.C) k[c] = (float)(g.c0 + col[c]);
+        else k[c] = -(float)(g.r0 + row[c]);
+        lo[c] = 0; cnt[c] = 0;
+    }
+    int top = 1;
+    while (top < nc) top <<= 1;
+    for (int st = top; st > 0; st >>= 1) {      // lo = #{coarse <= k}
+#pragma unroll
+        for (int c = 0; c < LUT_R; ++c) {
+            const int mid = lo[c] + st;
+            if (mid <= nc && coarse[mid - 1] <= k[c]) lo[c] = mid;
+        }
+    }
+    int ftop = 1;
+    while (ftop < stride) ftop <<= 1;
+    for (int st = ftop >> 1; st > 0; st >>= 1) {  // cnt = #{T in (base, base + stride) <= k}, base = (lo-1) stride
+#pragma unroll
+        for (int c = 0; c < LUT_R; ++c) {
+            const int base = (lo[c] - 1) * stride;
+            const int mid = cnt[c] + st;
+            if (lo[c] > 0 && mid < stride && base + mid < n && T[base + mid] <= k[c]) cnt[c] = mid;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) rank[c] = (float)(lo[c] > 0 ? (lo[c] - 1) * stride + 1 + cnt[c] : 0);
 }
 
 template <int S>
 __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__ lut,
-                                                      const int *__restrict__ meta, int n_trees_padded,
+                                                      const int *__restrict__ meta,
+                                                      const float *__restrict__ sorted,
+                                                      const int *__restrict__ sorted_off, int n_trees_padded,
                                                       double init_f, int p, StackDev s, PredGeom g,
                                                       double weight, int accumulate,
                                                       double *__restrict__ out) {
+    static_assert((LUT_CHUNK << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *keys = (float *)smem;                                              // [p][256][4]
     double *slut = (double *)(smem + (size_t)p * 256 * LUT_R * sizeof(float));  // [LUT_CHUNK << S]
+    float *coarse = (float *)slut;
     const int64_t total = (int64_t)g.nr * g.nc;
     const int64_t quarter = (total + LUT_R - 1) / LUT_R;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -393,15 +454,20 @@ __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__
         if (i >= total) i = total - 1;
         row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
         na[c] = false; acc[c] = 0.0;
-        for (int j = 0; j < p; ++j) {
-            float k;
-            if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k = (float)xv; }
-            else if (j == s.C) k = (float)(g.c0 + col[c]);
-            else k = -(float)(g.r0 + row[c]);
-            keys[(j * 256 + threadIdx.x) * LUT_R + c] = k;
-        }
     }
-    const float4 *kbase = (const float4 *)(keys + threadIdx.x * LUT_R);
+    // keys -> ranks among the predictor's sorted distinct tkeys
+    for (int j = 0; j < p; ++j) {
+        float r[LUT_R];
+        lut_ranks(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < LUT_R; ++c) keys[(j * 256 + threadIdx.x) * LUT_R + c] = -r[c];
+    }
+    const char *kbase = (const char *)(keys + threadIdx.x * LUT_R);
+    constexpr unsigned A0_BITS = (unsigned)(127 + 23 - S) << 23;   // float 2^(23-S)
+    // byte offset of LUT slot 0 minus 8 * 0x4B000000 (mod 2^32), kept opaque so that slot -> address
+    // stays one v_lshl_add_u32
+    unsigned lut_base = (unsigned)p * 256u * LUT_R * (unsigned)sizeof(float) - 0x58000000u;
+    asm volatile("" : "+s"(lut_base));
     for (int t0 = 0; t0 < n_trees_padded; t0 += LUT_CHUNK) {
         __syncthreads();
         for (int e = threadIdx.x; e < (LUT_CHUNK << S); e += 256) slut[e] = lut[((int64_t)t0 << S) + e];
@@ -409,15 +475,145 @@ __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__
 #pragma unroll 2
         for (int t = 0; t < LUT_CHUNK; ++t) {
             const int *m = meta + (int64_t)(t0 + t) * LUT_META_DW;
-            unsigned idx[LUT_R] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int q = 0; q < S; ++q) {
-                const float tk = __int_as_float(m[q]);
-                const float4 k = *(const float4 *)((const char *)kbase + m[6 + q]);
-                pred4(idx, k, tk);
+            const unsigned long long *mc = (const unsigned long long *)m;
+            const unsigned long long a0 = A0_BITS + ((unsigned)t << S);      // float 2^(23-S) + t
+            float2v a01, a23, b01, b23;
+            {
+                const float4 k = *(const float4 *)(kbase + m[6]);
+                pred_bits<false>(b01, b23, float2v{k.x, k.y}, float2v{k.z, k.w}, mc[0]);
+                asm("v_pk_fma_f32 %0, %2, 2.0, %3 op_sel_hi:[0,0,1]\n\t"
+                    "v_pk_fma_f32 %1, %2, 2.0, %4 op_sel_hi:[0,0,1]"
+                    : "=&v"(a01), "=&v"(a23) : "s"(a0), "v"(b01), "v"(b23));
             }
 #pragma unroll
-            for (int c = 0; c < LUT_R; ++c) acc[c] = acc[c] + slut[(t << S) + idx[c]];
+            for (int q = 1; q < S; ++q) {
+                const float4 k = *(const float4 *)(kbase + m[6 + q]);
+                if (q & 1) pred_bits<true>(b01, b23, float2v{k.x, k.y}, float2v{k.z, k.w}, mc[q >> 1]);
+                else pred_bits<false>(b01, b23, float2v{k.x, k.y}, float2v{k.z, k.w}, mc[q >> 1]);
+                asm("v_pk_fma_f32 %0, %0, 2.0, %2 op_sel_hi:[1,0,1]\n\t"
+                    "v_pk_fma_f32 %1, %1, 2.0, %3 op_sel_hi:[1,0,1]"
+                    : "+v"(a01), "+v"(a23) : "v"(b01), "v"(b23));
+            }
+            acc[0] = acc[0] + *(const double *)(smem + (__float_as_uint(a01.x) * 8u + lut_base));
+            acc[1] = acc[1] + *(const double *)(smem + (__float_as_uint(a01.y) * 8u + lut_base));
+            acc[2] = acc[2] + *(const double *)(smem + (__float_as_uint(a23.x) * 8u + lut_base));
+            acc[3] = acc[3] + *(const double *)(smem + (__float_as_uint(a23.y) * 8u + lut_base));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        const int64_t i = i0 + c * quarter;
+        if (i0 < quarter && i < total && !na[c])
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], init_f + acc[c], weight, accumulate);
+    }
+}
+
+// Same evaluation with the -rank keys held in 32 VGPRs (v[64:95] = [8 predictors][4 cells]) instead
+// of LDS, for models with <= 8 predictors: a level's predictor is selected with the VGPR index
+// mode (s_set_gpr_idx_on / _idx add the wave-uniform register offset in M0 to src0 of the packed
+// adds), so a level costs no LDS read and no address arithmetic -- 28 VALU per tree and 4 cells
+// (20 packed predicate ops, 4 shift-adds, 4 fp64 adds).  Inside the indexed region every VALU
+// instruction keeps a constant in src0 except the two that are meant to be indexed.
+typedef float float32v __attribute__((ext_vector_type(32)));
+constexpr int LUT_REG_P = 8;
+
+#define MHS_LUT_LEVEL(IDX, CP, SEL)                                                   \
+    "s_set_gpr_idx_idx %[" IDX "]\n\t"                                               \
+    "v_pk_add_f32 %[b01], v[64:65], %[" CP "] " SEL " clamp\n\t"                     \
+    "v_pk_add_f32 %[b23], v[66:67], %[" CP "] " SEL " clamp\n\t"                     \
+    "v_pk_fma_f32 %[a01], 2.0, %[a01], %[b01] op_sel_hi:[0,1,1]\n\t"                 \
+    "v_pk_fma_f32 %[a23], 2.0, %[a23], %[b23] op_sel_hi:[0,1,1]\n\t"
+#define MHS_SEL_LO "op_sel_hi:[1,0]"
+#define MHS_SEL_HI "op_sel:[0,1] op_sel_hi:[1,1]"
+
+template <int S>
+__device__ __forceinline__ void lut_tree_reg(float2v &a01, float2v &a23, const float32v &keys, const int *m,
+                                             const unsigned long long a0) {
+    const unsigned long long *mc = (const unsigned long long *)m;
+    const unsigned long long c01 = mc[0], c23 = mc[1], c45 = mc[2];
+    const int i0 = m[6] >> 10, i1 = m[7] >> 10, i2 = m[8] >> 10, i3 = m[9] >> 10, i4 = m[10] >> 10;
+    float2v b01, b23;
+    if (S == 5) {
+        asm("s_set_gpr_idx_on %[i0], 0x1\n\t"
+            "v_pk_add_f32 %[b01], v[64:65], %[c01] op_sel_hi:[1,0] clamp\n\t"
+            "v_pk_add_f32 %[b23], v[66:67], %[c01] op_sel_hi:[1,0] clamp\n\t"
+            "v_pk_fma_f32 %[a01], 2.0, %[a0], %[b01] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %[a23], 2.0, %[a0], %[b23] op_sel_hi:[0,0,1]\n\t"
+            MHS_LUT_LEVEL("i1", "c01", MHS_SEL_HI)
+            MHS_LUT_LEVEL("i2", "c23", MHS_SEL_LO)
+            MHS_LUT_LEVEL("i3", "c23", MHS_SEL_HI)
+            MHS_LUT_LEVEL("i4", "c45", MHS_SEL_LO)
+            "s_set_gpr_idx_off"
+            : [a01] "=&v"(a01), [a23] "=&v"(a23), [b01] "=&v"(b01), [b23] "=&v"(b23)
+            : "{v[64:95]}"(keys), [i0] "s"(i0), [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3), [i4] "s"(i4),
+              [c01] "s"(c01), [c23] "s"(c23), [c45] "s"(c45), [a0] "s"(a0));
+    } else {
+        const int i5 = m[11] >> 10;
+        asm("s_set_gpr_idx_on %[i0], 0x1\n\t"
+            "v_pk_add_f32 %[b01], v[64:65], %[c01] op_sel_hi:[1,0] clamp\n\t"
+            "v_pk_add_f32 %[b23], v[66:67], %[c01] op_sel_hi:[1,0] clamp\n\t"
+            "v_pk_fma_f32 %[a01], 2.0, %[a0], %[b01] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %[a23], 2.0, %[a0], %[b23] op_sel_hi:[0,0,1]\n\t"
+            MHS_LUT_LEVEL("i1", "c01", MHS_SEL_HI)
+            MHS_LUT_LEVEL("i2", "c23", MHS_SEL_LO)
+            MHS_LUT_LEVEL("i3", "c23", MHS_SEL_HI)
+            MHS_LUT_LEVEL("i4", "c45", MHS_SEL_LO)
+            MHS_LUT_LEVEL("i5", "c45", MHS_SEL_HI)
+            "s_set_gpr_idx_off"
+            : [a01] "=&v"(a01), [a23] "=&v"(a23), [b01] "=&v"(b01), [b23] "=&v"(b23)
+            : "{v[64:95]}"(keys), [i0] "s"(i0), [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3), [i4] "s"(i4), [i5] "s"(i5),
+              [c01] "s"(c01), [c23] "s"(c23), [c45] "s"(c45), [a0] "s"(a0));
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void gbm_lutreg_kernel(const double *__restrict__ lut,
+                                                         const int *__restrict__ meta,
+                                                         const float *__restrict__ sorted,
+                                                         const int *__restrict__ sorted_off, int n_trees_padded,
+                                                         double init_f, int p, StackDev s, PredGeom g,
+                                                         double weight, int accumulate,
+                                                         double *__restrict__ out) {
+    static_assert((LUT_CHUNK << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *slut = (double *)smem;                                            // [LUT_CHUNK << S]
+    float *coarse = (float *)smem;
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t quarter = (total + LUT_R - 1) / LUT_R;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int row[LUT_R], col[LUT_R];
+    bool na[LUT_R];
+    double acc[LUT_R];
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        int64_t i = i0 + c * quarter;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0;
+    }
+    float32v keys;
+#pragma unroll
+    for (int j = 0; j < LUT_REG_P; ++j) {
+        float r[LUT_R] = {0.f, 0.f, 0.f, 0.f};
+        if (j < p) lut_ranks(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < LUT_R; ++c) keys[j * LUT_R + c] = -r[c];
+    }
+    constexpr unsigned A0_BITS = (unsigned)(127 + 23 - S) << 23;   // float 2^(23-S)
+    unsigned lut_base = 0u - 0x58000000u;                          // see gbm_lut_kernel
+    asm volatile("" : "+s"(lut_base));
+    for (int t0 = 0; t0 < n_trees_padded; t0 += LUT_CHUNK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < (LUT_CHUNK << S); e += 256) slut[e] = lut[((int64_t)t0 << S) + e];
+        __syncthreads();
+#pragma unroll 2
+        for (int t = 0; t < LUT_CHUNK; ++t) {
+            float2v a01, a23;
+            lut_tree_reg<S>(a01, a23, keys, meta + (int64_t)(t0 + t) * LUT_META_DW, A0_BITS + ((unsigned)t << S));
+            acc[0] = acc[0] + *(const double *)(smem + (__float_as_uint(a01.x) * 8u + lut_base));
+            acc[1] = acc[1] + *(const double *)(smem + (__float_as_uint(a01.y) * 8u + lut_base));
+            acc[2] = acc[2] + *(const double *)(smem + (__float_as_uint(a23.x) * 8u + lut_base));
+            acc[3] = acc[3] + *(const double *)(smem + (__float_as_uint(a23.y) * 8u + lut_base));
         }
     }
 #pragma unroll
@@ -621,20 +817,16 @@ static float ceil_to_float(double thr) {  // smallest float >= thr
     return f;
 }
 
-// key-space thresholds of every split for this grid (see gbm_lut_kernel); cached per geometry
+// key-space thresholds of every split for this grid, the sorted distinct thresholds of each
+// predictor and every split's rank among them (see gbm_lut_kernel); cached per geometry
 static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C) {
     const mhs_grid &o = m->meta_grid;
     if (m->lut_meta && m->meta_C == C && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
         o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
     const int S = m->lut_S;
-    std::vector<int> meta((size_t)m->n_trees_padded * LUT_META_DW, 0);
-    const float ninf = -INFINITY;
-    int ninf_bits;
-    memcpy(&ninf_bits, &ninf, 4);
-    for (int t = 0; t < m->n_trees_padded; ++t) {
-        int *mt = &meta[(size_t)t * LUT_META_DW];
-        for (int q = 0; q < 6; ++q) { mt[q] = ninf_bits; mt[6 + q] = 0; }
-        if (t >= m->n_trees) continue;
+    std::vector<float> tkey((size_t)m->n_trees * S, 0.f);
+    std::vector<std::vector<float>> sorted((size_t)m->p);
+    for (int t = 0; t < m->n_trees; ++t) {
         for (int q = 0; q < S; ++q) {
             const int v = m->lut_var[(size_t)t * S + q];
             if (v < 0) continue;
@@ -659,10 +851,41 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C) {
                 }
                 tk = 0.5f - (float)lo;
             }
-            memcpy(&mt[q], &tk, 4);
+            if (tk != tk) tk = INFINITY;   // a NaN split value never sends a cell left or right by "<"
+            tkey[(size_t)t * S + q] = tk;
+            sorted[(size_t)v].push_back(tk);
+        }
+    }
+    std::vector<int> off((size_t)m->p + 1, 0);
+    std::vector<float> flat;
+    for (int v = 0; v < m->p; ++v) {
+        std::vector<float> &sv = sorted[(size_t)v];
+        std::sort(sv.begin(), sv.end());
+        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
+        off[(size_t)v + 1] = off[(size_t)v] + (int)sv.size();
+        flat.insert(flat.end(), sv.begin(), sv.end());
+    }
+    if (flat.empty()) flat.push_back(0.f);
+    std::vector<int> meta((size_t)m->n_trees_padded * LUT_META_DW, 0);
+    const float never = -33554432.f;   // c - rank <= 0 for every rank: the padded predicates read 0
+    for (int t = 0; t < m->n_trees_padded; ++t) {
+        int *mt = &meta[(size_t)t * LUT_META_DW];
+        for (int q = 0; q < 6; ++q) { memcpy(&mt[q], &never, 4); mt[6 + q] = 0; }
+        if (t >= m->n_trees) continue;
+        for (int q = 0; q < S; ++q) {
+            const int v = m->lut_var[(size_t)t * S + q];
+            if (v < 0) continue;
+            const std::vector<float> &sv = sorted[(size_t)v];
+            const float tk = tkey[(size_t)t * S + q];
+            const float c = (float)((std::lower_bound(sv.begin(), sv.end(), tk) - sv.begin()) + 1);
+            memcpy(&mt[q], &c, 4);
             mt[6 + q] = v * 256 * LUT_R * (int)sizeof(float);
         }
     }
+    if (m->lut_sorted) { (void)hipFree(m->lut_sorted); m->lut_sorted = nullptr; }
+    if (int rc = to_device(flat.data(), flat.size(), &m->lut_sorted)) return rc;
+    if (!m->lut_sorted_off) MHS_HIP(hipMalloc((void **)&m->lut_sorted_off, off.size() * sizeof(int)));
+    MHS_HIP(hipMemcpy(m->lut_sorted_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
     if (!m->lut_meta) MHS_HIP(hipMalloc((void **)&m->lut_meta, meta.size() * sizeof(int)));
     MHS_HIP(hipMemcpy(m->lut_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
     m->meta_grid = grid;
@@ -675,16 +898,14 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     if (int rc = build_lut_meta(const_cast<mhs_model *>(m), grid, s.C)) return rc;
     const int64_t quarter = (total + LUT_R - 1) / LUT_R;
     const unsigned blocks = (unsigned)((quarter + 255) / 256);
-    const size_t bytes = (size_t)m->p * 256 * LUT_R * sizeof(float) + ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
-    if (m->lut_S == 5) {
-        auto kern = gbm_lut_kernel<5>;
-        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
-    } else {
-        auto kern = gbm_lut_kernel<6>;
-        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
-    }
+    const size_t lut_bytes = ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
+    const bool in_regs = m->p <= LUT_REG_P;
+    const size_t bytes = in_regs ? lut_bytes : (size_t)m->p * 256 * LUT_R * sizeof(float) + lut_bytes;
+    auto kern = in_regs ? (m->lut_S == 5 ? gbm_lutreg_kernel<5> : gbm_lutreg_kernel<6>)
+                        : (m->lut_S == 5 ? gbm_lut_kernel<5> : gbm_lut_kernel<6>);
+    MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->lut_sorted, m->lut_sorted_off,
+                       m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
     // cells with an NA covariate: walked through their MissingNode children
     return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
 }
@@ -846,6 +1067,8 @@ int mhs_model_free(mhs_model *m) {
     if (m->chunks) (void)hipFree(m->chunks);
     if (m->lut) (void)hipFree(m->lut);
     if (m->lut_meta) (void)hipFree(m->lut_meta);
+    if (m->lut_sorted) (void)hipFree(m->lut_sorted);
+    if (m->lut_sorted_off) (void)hipFree(m->lut_sorted_off);
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
     if (m->rf_lval) (void)hipFree(m->rf_lval);
     if (m->rf_depth) (void)hipFree(m->rf_depth);

@@ -134,6 +134,23 @@ def test_seven_predictors_and_host_entry_point(hip):
     assert np.array_equal(out, got[10:35], equal_nan=True)
 
 
+@pytest.mark.parametrize("C,trees,n", [(7, 120, 600), (3, 8000, 7000)])
+def test_gbm_rank_lut_variants(hip, C, trees, n):
+    """The gbm predicate-LUT path works on RANKS of the keys among the model's sorted distinct split values.
+    9 predictors exercise the LDS-key kernel (more than the 8 the register-resident kernel holds); 8 000
+    trees over 7 000 stations give > 4 096 distinct thresholds for a predictor, so the coarse + fine rank
+    search runs."""
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=96, ncol=100, C=C, n=n, gbm_trees=2, rf_trees=1, nodata_frac=0.01)
+    prm = synth.gbm_params(Xs, ys, 11, n_trees=trees)
+    distinct = max(len(np.unique(prm["split_val"][prm["split_var"] == v].astype(np.float32))) for v in range(C))
+    assert distinct > 4096 or trees < 8000
+    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    want = oe.predict(prm, X)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= _tol(want)   # one wrong leaf would be ~1e-3 * sd(y)
+
+
 def test_loaders_reject_malformed_models(hip):
     with pytest.raises(hip.MhsError):
         hip.models.Gbm(0.0, [0, 2], [0, -1], [1.0, 2.0], [5, 0], [1, 0], [1, 0], p=5)  # child out of range
