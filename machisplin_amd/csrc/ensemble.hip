@@ -79,12 +79,13 @@ struct mhs_model {
     // randomForest level-synchronous walk (rf_walk_kernel): available when every split node has
     // rightDaughter == leftDaughter + 1 (how randomForest numbers its nodes)
     bool rf_fast = false;
-    unsigned long long *rf_nodes = nullptr;  // device, 8-byte records {float tkey; u16 left; u16 var}
+    unsigned long long *rf_nodes = nullptr;  // device, 8-byte records {(rank << 8) | key offset; left | right << 16}
     double *rf_lval = nullptr;               // device, node prediction by node id
     int *rf_depth = nullptr;                 // device, levels to descend per tree
     std::vector<double> rf_thr;              // host, split value per node
     std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
     int rf_max_nodes = 0;
+    int rf_log2r = -1;                       // walks per lane rf_nodes were built for
 };
 
 namespace mhs {
@@ -383,9 +384,10 @@ __device__ __forceinline__ void pred_bits(float2v &b01, float2v &b23, const floa
             : "=&v"(b01), "=&v"(b23) : "v"(k01), "v"(k23), "s"(cpair));
 }
 
-// rank[c] = #{sorted distinct tkeys of predictor j that are <= key[c]} for the lane's 4 cells: a
+// rank[c] = #{sorted distinct tkeys of predictor j that are <= key[c]} for the lane's LUT_R cells: a
 // binary search of a coarse table (every stride-th tkey, staged in LDS by the whole block) and a
 // short fine search in global memory.  Must be called by every thread of the block.
+template <int LUT_R, int NT>
 __device__ __forceinline__ void lut_ranks(const int j, const float *__restrict__ sorted,
                                           const int *__restrict__ sorted_off, float *coarse,
                                           const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
@@ -395,7 +397,7 @@ __device__ __forceinline__ void lut_ranks(const int j, const float *__restrict__
     const int stride = (n + LUT_COARSE - 1) / LUT_COARSE;
     const int nc = stride ? (n + stride - 1) / stride : 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < nc; e += 256) coarse[e] = T[(int64_t)e * stride];
+    for (int e = threadIdx.x; e < nc; e += NT) coarse[e] = T[(int64_t)e * stride];
     __syncthreads();
     float k[LUT_R];
     int lo[LUT_R], cnt[LUT_R];
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__
     // keys -> ranks among the predictor's sorted distinct tkeys
     for (int j = 0; j < p; ++j) {
         float r[LUT_R];
-        lut_ranks(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        lut_ranks<LUT_R, 256>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < LUT_R; ++c) keys[(j * 256 + threadIdx.x) * LUT_R + c] = -r[c];
     }
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256) void gbm_lutreg_kernel(const double *__restric
 #pragma unroll
     for (int j = 0; j < LUT_REG_P; ++j) {
         float r[LUT_R] = {0.f, 0.f, 0.f, 0.f};
-        if (j < p) lut_ranks(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        if (j < p) lut_ranks<LUT_R, 256>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < LUT_R; ++c) keys[j * LUT_R + c] = -r[c];
     }
@@ -625,26 +627,47 @@ __global__ __launch_bounds__(256) void gbm_lutreg_kernel(const double *__restric
 }
 
 // ------------------------------------------------- randomForest: level-synchronous walk --
-// One tree at a time lives in LDS as 8-byte node records {float tkey; u16 left; u16 var} plus the
-// node predictions; right daughter = left + 1.  Terminals point at themselves with tkey = +inf,
-// so every lane descends a fixed, wave-uniform number of levels (the tree's depth) with no
-// divergent control flow:  node <- left + !(key[var] < tkey).  Keys are the order-preserving
-// float keys of gbm_lut_kernel ("x <= split" <=> key < tkey with tkey one float above the
-// largest float <= split), parked in LDS as [var][cell slot][lane].  Four independent walks
-// per lane keep the two dependent LDS reads of a level in flight.
+// One tree at a time lives in LDS (from byte 0) as 8-byte node records plus the node predictions.
+// Terminals point at themselves, so every lane descends a fixed, wave-uniform number of levels (the
+// tree's depth) with no divergent control flow.  As in gbm_lut_kernel the cell's predictors are
+// first replaced by their RANK among the forest's sorted distinct key-space thresholds of that
+// predictor ("x <= split" <=> key < tkey_j <=> rank <= j), which makes a level three VALU
+// instructions around its two dependent LDS reads:
+//   node = {(j << 8) | (var * 4R),  left byte address | right byte address << 16}
+//   key address  = lane base + BYTE_0(node.x)             (v_add_u32 with an SDWA byte select)
+//   go right     = (rank << 8) > node.x                   (the var byte cannot flip the compare)
+//   next address = right ? WORD_1(node.y) : WORD_0(node.y)  (v_cndmask_b32 with SDWA word selects)
+// Keys are parked in LDS as [lane][var][cell slot] with an odd lane stride (conflict-free when the
+// lanes of a wave read the same predictor).  R independent walks per lane keep the two dependent
+// LDS reads of a level in flight.
+constexpr int RF_COARSE_BYTES = LUT_COARSE * (int)sizeof(float);
+// LDS accesses by 32-bit byte address (the walk's node addresses come out of LDS data, so no pointer
+// arithmetic may be attached to them); the kernel's dynamic LDS starts at address 0 (no static LDS)
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2v lds_u2(unsigned a) { return *(__attribute__((address_space(3))) const uint2v *)(uintptr_t)a; }
+__device__ __forceinline__ unsigned lds_u32(unsigned a) { return *(__attribute__((address_space(3))) const unsigned *)(uintptr_t)a; }
+__device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
+
 template <int LOG2R>
-__global__ __launch_bounds__(1024) void rf_walk_kernel(const unsigned long long *__restrict__ gnodes,
+__global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__ gnodes,
                                                        const double *__restrict__ glval,
                                                        const int *__restrict__ tree_off,
-                                                       const int *__restrict__ depth, int n_trees,
+                                                       const int *__restrict__ depth,
+                                                       const float *__restrict__ sorted,
+                                                       const int *__restrict__ sorted_off, int n_trees,
                                                        int max_nodes, int p, StackDev s, PredGeom g,
                                                        double weight, int accumulate,
                                                        double *__restrict__ out) {
     constexpr int R = 1 << LOG2R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *keys = (float *)smem;                                               // [p * R][1024]
-    unsigned long long *lnodes = (unsigned long long *)(smem + (size_t)p * R * 4096);
-    double *lval = (double *)(lnodes + max_nodes);
+    uint2 *lnodes = (uint2 *)smem;                                 // [max_nodes], byte address = 8 * node
+    const unsigned lval_off = (unsigned)max_nodes * 8u;            // double [max_nodes]
+    double *lval = (double *)(smem + lval_off);
+    const unsigned tree_bytes = max(lval_off * 2u, (unsigned)RF_COARSE_BYTES);
+    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
+    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
+    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
     const int64_t total = (int64_t)g.nr * g.nc;
     const int64_t part = (total + R - 1) / R;
     const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -658,19 +681,13 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const unsigned long long 
         if (i >= total) i = total - 1;
         row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
         na[c] = false; acc[c] = 0.0;
-        for (int j = 0; j < p; ++j) {
-            float k;
-            if (j < s.C) {
-                const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]);
-                const bool bad = isnan(xv);
-                na[c] |= bad;
-                k = bad ? 0.0f : (float)xv;
-            } else if (j == s.C) k = (float)(g.c0 + col[c]);
-            else k = -(float)(g.r0 + row[c]);
-            keys[(j * R + c) * 1024 + threadIdx.x] = k;
-        }
     }
-    const char *kbase = (const char *)(keys + threadIdx.x);
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        lut_ranks<R, 1024>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
     for (int t = 0; t < n_trees; ++t) {
         const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
         __syncthreads();
@@ -681,15 +698,18 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const unsigned long long 
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
-                const unsigned long long nd = lnodes[node[c]];
-                const unsigned hi = (unsigned)(nd >> 32);
-                const float tk = __uint_as_float((unsigned)nd);
-                const float k = *(const float *)(kbase + (((hi >> 16) << (12 + LOG2R)) + c * 4096));
-                node[c] = (hi & 0xFFFFu) + (k < tk ? 0u : 1u);
+                const uint2v nd = lds_u2(node[c]);
+                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                // node = k > nd.x ? WORD_1(nd.y) : WORD_0(nd.y); an SDWA instruction may read VCC two wait
+                // states after the VALU write at the earliest
+                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
             }
         }
 #pragma unroll
-        for (int c = 0; c < R; ++c) acc[c] = acc[c] + lval[node[c]];
+        for (int c = 0; c < R; ++c) acc[c] = acc[c] + lds_f64(node[c] + lval_off);
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
@@ -917,19 +937,34 @@ static float floor_to_float(double thr) {  // largest float <= thr
     return f;
 }
 
+// LDS bytes of rf_walk_kernel for R = 2^log2r walks per lane
+static size_t rf_walk_lds(const mhs_model *m, int log2r) {
+    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
+    return tree_bytes + (size_t)1024 * (((size_t)m->p << log2r) | 1) * 4;
+}
+
+// walks per lane of rf_walk_kernel: 4 if the keys and one tree fit in LDS, else 2; -1 = generic walk.
+// Child byte addresses are 16-bit and the predictor's key offset is one byte.
+static int rf_walk_log2r(const mhs_model *m) {
+    if (m->rf_max_nodes * 8 > 65535) return -1;
+    for (int l2 = 2; l2 >= 1; --l2)
+        if (((m->p << l2) * 4) <= 255 && rf_walk_lds(m, l2) <= LDS_LIMIT) return l2;
+    return -1;
+}
+
 // key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry
-static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C) {
+static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r) {
     const mhs_grid &o = m->meta_grid;
-    if (m->rf_nodes && m->meta_C == C && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
-        o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
+    if (m->rf_nodes && m->meta_C == C && m->rf_log2r == log2r && o.xmin == grid.xmin && o.ymax == grid.ymax &&
+        o.xres == grid.xres && o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
     const size_t nn = m->rf_thr.size();
-    std::vector<unsigned long long> rec(nn);
+    std::vector<float> tkey(nn, 0.f);
+    std::vector<std::vector<float>> sorted((size_t)m->p);
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
+        if (v == 0xFFFFu) continue;
         float tk;
-        unsigned var = v;
-        if (v == 0xFFFFu) { tk = INFINITY; var = 0; }  // terminal: self loop (left = own index)
-        else if ((int)v < C) tk = nextafterf(floor_to_float(m->rf_thr[k]), INFINITY);
+        if ((int)v < C) tk = nextafterf(floor_to_float(m->rf_thr[k]), INFINITY);
         else if ((int)v == C) {   // LONG: columns with centre <= thr form a prefix [0, c*)
             int64_t lo = 0, hi = grid.ncol;
             while (lo < hi) {
@@ -947,35 +982,59 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C) {
             }
             tk = 0.5f - (float)lo;
         }
-        unsigned tkb;
-        memcpy(&tkb, &tk, 4);
-        rec[k] = ((unsigned long long)((var << 16) | m->rf_left[k]) << 32) | tkb;
+        if (tk != tk) tk = INFINITY;
+        tkey[k] = tk;
+        sorted[(size_t)v].push_back(tk);
     }
+    std::vector<int> off((size_t)m->p + 1, 0);
+    std::vector<float> flat;
+    for (int v = 0; v < m->p; ++v) {
+        std::vector<float> &sv = sorted[(size_t)v];
+        std::sort(sv.begin(), sv.end());
+        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
+        if (sv.size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
+        off[(size_t)v + 1] = off[(size_t)v] + (int)sv.size();
+        flat.insert(flat.end(), sv.begin(), sv.end());
+    }
+    if (flat.empty()) flat.push_back(0.f);
+    std::vector<unsigned long long> rec(nn);
+    const unsigned R = 1u << log2r;
+    for (size_t k = 0; k < nn; ++k) {
+        const unsigned v = m->rf_var[k];
+        const unsigned left = m->rf_left[k];   // node index within the tree (terminal: its own index)
+        unsigned node0 = 0, children;
+        if (v == 0xFFFFu) children = (left * 8u) | ((left * 8u) << 16);
+        else {
+            const std::vector<float> &sv = sorted[(size_t)v];
+            const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[k]) - sv.begin());
+            node0 = (j << 8) | (v * R * 4u);
+            children = (left * 8u) | (((left + 1u) * 8u) << 16);
+        }
+        rec[k] = ((unsigned long long)children << 32) | node0;
+    }
+    if (m->lut_sorted) { (void)hipFree(m->lut_sorted); m->lut_sorted = nullptr; }
+    if (int rc = to_device(flat.data(), flat.size(), &m->lut_sorted)) return rc;
+    if (!m->lut_sorted_off) MHS_HIP(hipMalloc((void **)&m->lut_sorted_off, off.size() * sizeof(int)));
+    MHS_HIP(hipMemcpy(m->lut_sorted_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
     if (!m->rf_nodes) MHS_HIP(hipMalloc((void **)&m->rf_nodes, (nn ? nn : 1) * sizeof(unsigned long long)));
     MHS_HIP(hipMemcpy(m->rf_nodes, rec.data(), nn * sizeof(unsigned long long), hipMemcpyHostToDevice));
     m->meta_grid = grid;
     m->meta_C = C;
+    m->rf_log2r = log2r;
     return MHS_OK;
 }
 
 static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
                           double w, int acc, double *out, hipStream_t st, int64_t total, int log2r) {
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C)) return rc;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r)) return rc;
     const int R = 1 << log2r;
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
-    const size_t bytes = (size_t)m->p * R * 4096 + (size_t)m->rf_max_nodes * 16;
-    if (log2r == 2) {
-        auto kern = rf_walk_kernel<2>;
-        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, m->rf_nodes, m->rf_lval, m->tree_off, m->rf_depth,
-                           m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
-    } else {
-        auto kern = rf_walk_kernel<1>;
-        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, m->rf_nodes, m->rf_lval, m->tree_off, m->rf_depth,
-                           m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
-    }
+    const size_t bytes = rf_walk_lds(m, log2r);
+    auto kern = log2r == 2 ? rf_walk_kernel<2> : rf_walk_kernel<1>;
+    MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)m->rf_nodes, m->rf_lval, m->tree_off,
+                       m->rf_depth, m->lut_sorted, m->lut_sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
     return MHS_OK;
 }
 
@@ -1013,10 +1072,7 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             break;
         case K_RF:
             if (grid && m->rf_fast && !s.all_from_planes && s.dtype != MHS_F64) {
-                // cells per lane: 4 if keys + one tree fit in LDS, else 2, else the generic walk
-                int log2r = -1;
-                for (int l2 = 2; l2 >= 1 && log2r < 0; --l2)
-                    if ((size_t)m->p * (1 << l2) * 4096 + (size_t)m->rf_max_nodes * 16 <= LDS_LIMIT) log2r = l2;
+                const int log2r = rf_walk_log2r(m);
                 if (log2r > 0) {
                     if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r)) return rc;
                     break;
