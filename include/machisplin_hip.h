@@ -126,6 +126,11 @@ MHS_API int mhs_tps_free(mhs_tps *t);
  * Window [r0,r1) x [c0,c1) of grid g; out is (r1-r0) x ld row-major, ld >= c1-c0. */
 MHS_API int mhs_tps_predict_grid(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                          int64_t c0, int64_t c1, double *out_host);
+/* How the grid evaluation sums the knots (process-wide): 0 = choose by cost (default), 1 = direct sum
+ * over all knots for every cell, 2 = far-field-interpolated (direct sum over the knots near a tile,
+ * 16 x 16 Chebyshev interpolation of the analytic sum over the rest; equal to the direct sum to FP64
+ * rounding, see csrc/tps_eval.hip).  predict.Krig itself is the direct sum. */
+MHS_API int mhs_tps_eval_mode(int mode);
 MHS_API int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                              int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream);
 /* predict(tps, xy): arbitrary points, xy n x 2 column-major (Step-5 station check) */

@@ -11,10 +11,10 @@ from ._lib import MhsError, init
 from .raster import Geometry, RasterStack
 from . import models
 from .models import predict, ensemble_predict
-from .tps import Tps, interpolate
+from .tps import Tps, interpolate, eval_mode, EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD
 from . import tiles, mltps
 from .mltps import mltps_predict, tps_residual_surface
 
-__all__ = ["MhsError", "init", "Geometry", "RasterStack", "Tps", "interpolate", "predict",
+__all__ = ["MhsError", "init", "Geometry", "RasterStack", "Tps", "interpolate", "eval_mode", "EVAL_AUTO", "EVAL_DIRECT", "EVAL_FAR_FIELD", "predict",
            "ensemble_predict", "models", "tiles", "mltps", "mltps_predict",
            "tps_residual_surface", "_lib"]

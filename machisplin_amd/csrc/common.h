@@ -78,4 +78,15 @@ struct mhs_tps {
     std::vector<double> c;        // n
     std::vector<double> knots_uv; // n x 2 column-major, scaled
     mhs::Knot *knots_dev = nullptr;
+    // plan of the far-field-interpolated grid evaluation (tps_eval.hip), cached per window geometry
+    struct FarPlan {
+        double xmin = 0, ymax = 0, xres = 0, yres = 0;
+        int64_t r0 = -1, r1 = -1, c0 = -1, c1 = -1;
+        int tx = 0, ty = 0, ntx = 0, nty = 0;   // tile size in cells, tiles per direction
+        mhs::Knot *sorted_dev = nullptr;        // knots ordered by bin (row-major)
+        int *bin_start_dev = nullptr;           // (nty + 4) * (ntx + 4) + 1 offsets into sorted_dev
+        double *nodes_dev = nullptr;            // ntx * nty * 256 far-field values at the tile nodes
+        double *lx_dev = nullptr, *ly_dev = nullptr;  // interpolation matrices, tx x 16 and ty x 16
+        size_t nodes_cap = 0, bins_cap = 0, lx_cap = 0, ly_cap = 0;
+    } far;
 };

@@ -13,8 +13,20 @@
 //     LDS: r2 = 2^e m, log r2 = e ln2 + log c_i + log1p(m/c_i - 1), |m/c_i - 1| <= 2^-11,
 //     cubic log1p => absolute error < 2e-14 (ocml's log costs ~70 FP64 instructions).
 //     Neighbouring lanes see neighbouring r2, so table reads mostly broadcast.
+//
+// Large windows take the FAR-FIELD-INTERPOLATED path (tps_ff_*): the window is cut into
+// tiles that are square in the spline's scaled coordinates; for a tile, knots outside the
+// 3 x 3 block of tiles around it are at least 1.5 tile widths from its centre, where
+// sum_j c_j phi(r_j) is analytic and a 16 x 16 tensor Chebyshev interpolant reproduces it to
+// FP64 rounding (measured 1.5e-15 of sum_j |c_j phi_j| with every far knot on the block's
+// boundary).  So the far knots are summed at the tile's 256 nodes only (one wave per tile, the
+// same inner loop), each cell gets  Ly F Lx'  (32 FMAs) plus the direct sum over the few knots of
+// the 3 x 3 block.  Same result as the direct sum to rounding, ~100x fewer kernel evaluations at
+// 5 000 knots on a 10 000 x 10 000 grid.  mhs_tps_eval_mode() forces either path.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include "common.h"
 #include "devmath.h"
 
@@ -32,6 +44,24 @@ struct EvalGeom {
     int nr, nc;                     // window size
     int64_t ld;                     // output leading dimension
 };
+
+// acc[k] += sum_{j in [j0, j1)} cw_j phi(|(u, v_k) - knot_j|^2): the inner loop of every grid kernel
+__device__ __forceinline__ void tps_accumulate(const Knot *__restrict__ knots, const int j0, const int j1,
+                                               const double u, const double (&v)[EVAL_ROWS],
+                                               double (&acc)[EVAL_ROWS], const double2 *tab) {
+#pragma unroll 2
+    for (int j = j0; j < j1; ++j) {
+        const Knot kn = knots[j];
+        const double dx = u - kn.u;
+        const double dx2 = dx * dx;
+#pragma unroll
+        for (int k = 0; k < EVAL_ROWS; ++k) {
+            const double dy = v[k] - kn.v;
+            const double dd = fma(dy, dy, dx2);
+            acc[k] = fma(kn.cw, r2logr2(dd, tab), acc[k]);
+        }
+    }
+}
 
 __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
     const Knot *__restrict__ knots, int n, const double2 *__restrict__ gtab, EvalGeom g,
@@ -56,18 +86,7 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
         acc[k] = 0.0;
     }
 
-#pragma unroll 2
-    for (int j = 0; j < n; ++j) {
-        const Knot kn = knots[j];
-        const double dx = u - kn.u;
-        const double dx2 = dx * dx;
-#pragma unroll
-        for (int k = 0; k < EVAL_ROWS; ++k) {
-            const double dy = v[k] - kn.v;
-            const double dd = fma(dy, dy, dx2);
-            acc[k] = fma(kn.cw, r2logr2(dd, tab), acc[k]);
-        }
-    }
+    tps_accumulate(knots, 0, n, u, v, acc, tab);
 
     if (col < g.nc) {
 #pragma unroll
@@ -97,6 +116,117 @@ __global__ __launch_bounds__(256) void tps_eval_points_kernel(
     if (i < npts) out[i] = g.d0 + g.d1 * u + g.d2 * v + acc;
 }
 
+// ------------------------------------------------ far-field-interpolated evaluation --
+constexpr int FF_N = 16;                 // Chebyshev nodes per dimension
+constexpr int FF_NODES = FF_N * FF_N;    // per tile
+constexpr int FF_PAD = 2;                // bins beyond the window on every side (never in a 3 x 3 block)
+
+struct FarGeom {
+    int tx, ty, ntx, nty;                // tile size (cells), tiles per direction
+    double t[FF_N];                      // Chebyshev points of the first kind on [-1, 1]
+};
+
+// far-field sum (plus the affine part) at the 16 x 16 nodes of every tile; one wave per tile,
+// lane = (node column a, group of 4 node rows)
+__global__ __launch_bounds__(256) void tps_ff_nodes_kernel(const Knot *__restrict__ knots, int n,
+                                                           const int *__restrict__ bin_start,
+                                                           const double2 *__restrict__ gtab, EvalGeom g,
+                                                           FarGeom f, double *__restrict__ nodes) {
+    __shared__ double2 tab[LOG_TAB_N];
+    stage_log_table(tab, gtab);
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= f.ntx * f.nty) return;
+    const int tyi = tile / f.ntx, txi = tile - tyi * f.ntx;
+    const int a = lane & 15, bg = lane >> 4;
+    const double hx = 0.5 * (double)f.tx * g.xres, hy = 0.5 * (double)f.ty * g.yres;
+    const double xc = g.xmin + (double)(g.c0 + (int64_t)txi * f.tx) * g.xres + hx;
+    const double yc = g.ymax - (double)(g.r0 + (int64_t)tyi * f.ty) * g.yres - hy;
+    const double u = (xc + hx * f.t[a] - g.cx) / g.sx;
+    double v[EVAL_ROWS], acc[EVAL_ROWS];
+#pragma unroll
+    for (int k = 0; k < EVAL_ROWS; ++k) {
+        v[k] = (yc + hy * f.t[bg * EVAL_ROWS + k] - g.cy) / g.sy;
+        acc[k] = 0.0;
+    }
+    const int nbx = f.ntx + 2 * FF_PAD;
+    int j = 0;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {        // skip the three bin-row ranges of the 3 x 3 block
+        const int *row = bin_start + (int64_t)(tyi + FF_PAD - 1 + r) * nbx + (txi + FF_PAD - 1);
+        const int s0 = row[0], e0 = row[3];
+        tps_accumulate(knots, j, s0, u, v, acc, tab);
+        j = e0;
+    }
+    tps_accumulate(knots, j, n, u, v, acc, tab);
+#pragma unroll
+    for (int k = 0; k < EVAL_ROWS; ++k)
+        nodes[(int64_t)tile * FF_NODES + (bg * EVAL_ROWS + k) * FF_N + a] = g.d0 + g.d1 * u + g.d2 * v[k] + acc[k];
+}
+
+// cells: interpolated far field + direct near field.  A block covers 64 columns x 16 rows of one
+// tile (tile widths are multiples of 64, heights of 16); lane = column, 4 rows per lane.
+__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
+    const Knot *__restrict__ knots, const int *__restrict__ bin_start, const double2 *__restrict__ gtab,
+    EvalGeom g, FarGeom f, const double *__restrict__ nodes, const double *__restrict__ lx,
+    const double *__restrict__ ly, double *__restrict__ out) {
+    __shared__ double2 tab[LOG_TAB_N];
+    __shared__ double sF[FF_NODES];
+    __shared__ double sG[FF_N][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cchunks = f.tx / 64, rchunks = f.ty / EVAL_TILE_ROWS;
+    const int txi = blockIdx.x / cchunks, cc = blockIdx.x - txi * cchunks;
+    const int tyi = blockIdx.y / rchunks, rc = blockIdx.y - tyi * rchunks;
+    const int tile = tyi * f.ntx + txi;
+    const int lcol = cc * 64 + lane;                                  // column within the tile
+    const int lrow0 = rc * EVAL_TILE_ROWS + wave * EVAL_ROWS;         // first row within the tile
+    const int col = txi * f.tx + lcol;
+    const int row0 = tyi * f.ty + lrow0;
+    if (tyi * f.ty + rc * EVAL_TILE_ROWS >= g.nr || txi * f.tx + cc * 64 >= g.nc) return;   // whole block outside
+    for (int i = threadIdx.x; i < LOG_TAB_N; i += 64 * EVAL_WAVES) tab[i] = gtab[i];
+    sF[threadIdx.x] = nodes[(int64_t)tile * FF_NODES + threadIdx.x];
+    __syncthreads();
+    {   // G[b][i] = sum_a F[b][a] Lx[i][a] for the block's 64 columns; this wave: b = 4 wave .. 4 wave + 3
+        double lxr[FF_N];
+#pragma unroll
+        for (int a = 0; a < FF_N; ++a) lxr[a] = lx[(int64_t)lcol * FF_N + a];
+#pragma unroll
+        for (int k = 0; k < EVAL_ROWS; ++k) {
+            const int b = wave * EVAL_ROWS + k;
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < FF_N; ++a) s = fma(sF[b * FF_N + a], lxr[a], s);
+            sG[b][lane] = s;
+        }
+    }
+    __syncthreads();
+    const double x = g.xmin + ((double)(g.c0 + col) + 0.5) * g.xres;
+    const double u = (x - g.cx) / g.sx;
+    double v[EVAL_ROWS], acc[EVAL_ROWS];
+#pragma unroll
+    for (int k = 0; k < EVAL_ROWS; ++k) {
+        const double y = g.ymax - ((double)(g.r0 + row0 + k) + 0.5) * g.yres;
+        v[k] = (y - g.cy) / g.sy;
+        const double *lyr = ly + (int64_t)(lrow0 + k) * FF_N;           // wave-uniform row of Ly
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < FF_N; ++b) s = fma(lyr[b], sG[b][lane], s);
+        acc[k] = s;
+    }
+    const int nbx = f.ntx + 2 * FF_PAD;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+        const int *brow = bin_start + (int64_t)(tyi + FF_PAD - 1 + r) * nbx + (txi + FF_PAD - 1);
+        tps_accumulate(knots, brow[0], brow[3], u, v, acc, tab);
+    }
+    if (col < g.nc) {
+#pragma unroll
+        for (int k = 0; k < EVAL_ROWS; ++k)
+            if (row0 + k < g.nr) out[(int64_t)(row0 + k) * g.ld + col] = acc[k];
+    }
+}
+
 int upload_knots(mhs_tps *t) {
     std::vector<Knot> h((size_t)t->n);
     const double k = 0.5 / (8.0 * M_PI);
@@ -106,6 +236,7 @@ int upload_knots(mhs_tps *t) {
         h[j].cw = t->c[j] * k;
         h[j].pad = 0.0;
     }
+    t->far.r0 = -1;   // coefficients changed: the far-field plan's sorted knots are stale
     if (t->knots_dev) { (void)hipFree(t->knots_dev); t->knots_dev = nullptr; }
     MHS_HIP(hipMalloc((void **)&t->knots_dev, sizeof(Knot) * (size_t)(t->n ? t->n : 1)));
     MHS_HIP(hipMemcpy(t->knots_dev, h.data(), sizeof(Knot) * (size_t)t->n, hipMemcpyHostToDevice));
@@ -121,6 +252,113 @@ static EvalGeom make_geom(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64
     e.d0 = t->d[0]; e.d1 = t->d[1]; e.d2 = t->d[2];
     e.r0 = r0; e.c0 = c0; e.nr = (int)(r1 - r0); e.nc = (int)(c1 - c0); e.ld = ld;
     return e;
+}
+
+static int g_eval_mode = 0;   // 0 auto, 1 direct, 2 far-field-interpolated
+
+template <typename T>
+static int grow(T **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return MHS_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    MHS_HIP(hipMalloc((void **)p, (need ? need : 1) * sizeof(T)));
+    *cap = need;
+    return MHS_OK;
+}
+
+// rows of the barycentric Chebyshev interpolation matrix L[i][a] = l_a(tau_i), tau_i the centre of cell
+// i of a tile of `cells` cells mapped to (-1, 1); flip: rows run against the coordinate (raster rows)
+static void cheb_matrix(int cells, bool flip, const double (&t)[FF_N], std::vector<double> &L) {
+    double w[FF_N];
+    for (int a = 0; a < FF_N; ++a) w[a] = ((a & 1) ? -1.0 : 1.0) * sin((2 * a + 1) * M_PI / (2.0 * FF_N));
+    L.assign((size_t)cells * FF_N, 0.0);
+    for (int i = 0; i < cells; ++i) {
+        double tau = (2.0 * i + 1.0) / (double)cells - 1.0;
+        if (flip) tau = -tau;
+        int hit = -1;
+        double q[FF_N], sum = 0.0;
+        for (int a = 0; a < FF_N; ++a) {
+            const double d = tau - t[a];
+            if (d == 0.0) { hit = a; break; }
+            q[a] = w[a] / d;
+            sum += q[a];
+        }
+        for (int a = 0; a < FF_N; ++a) L[(size_t)i * FF_N + a] = hit >= 0 ? (a == hit ? 1.0 : 0.0) : q[a] / sum;
+    }
+}
+
+// Choose tile sizes for the far-field-interpolated path and (re)build its plan.  *use = false when the
+// direct sum is expected to be at least as cheap (few knots, small windows).
+static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1, int64_t c1, FarGeom *f, bool *use) {
+    *use = false;
+    const int64_t N = t->n;
+    if (g_eval_mode == 1 || e.nc < 64 || e.nr < 16 || N < 32) return MHS_OK;
+    // knots in window cell coordinates
+    std::vector<double> kc((size_t)N), kr((size_t)N);
+    int64_t inside = 0;
+    for (int64_t j = 0; j < N; ++j) {
+        const double x = t->knots_uv[j] * e.sx + e.cx, y = t->knots_uv[N + j] * e.sy + e.cy;
+        kc[j] = (x - e.xmin) / e.xres - (double)e.c0;
+        kr[j] = (e.ymax - y) / e.yres - (double)e.r0;
+        if (kc[j] >= 0 && kc[j] < e.nc && kr[j] >= 0 && kr[j] < e.nr) ++inside;
+    }
+    const double cells = (double)e.nr * (double)e.nc;
+    const double rho = (double)(inside > 0 ? inside : 1) / cells;          // knots per cell near the window
+    const double aspect = (e.xres / e.sx) / (e.yres / e.sy);               // scaled width / height of a cell
+    double best = 1e300;
+    int btx = 0, bty = 0;
+    for (int tx = 64; tx <= 1024; tx += 64) {
+        int ty = (int)llround((double)tx * aspect / 16.0) * 16;
+        if (ty < 16) ty = 16;
+        if (ty > 4096) continue;
+        const double ntx = ceil((double)e.nc / tx), nty = ceil((double)e.nr / ty);
+        const double cost = ntx * nty * FF_NODES * (double)N / cells + 9.0 * rho * tx * ty + 4.0;
+        if (cost < best) { best = cost; btx = tx; bty = ty; }
+    }
+    if (btx == 0) return MHS_OK;
+    if (g_eval_mode != 2 && best > 0.5 * (double)N) return MHS_OK;
+    const double tile_aspect = ((double)btx * e.xres / e.sx) / ((double)bty * e.yres / e.sy);
+    if (tile_aspect > 1.25 || tile_aspect < 0.8) return MHS_OK;            // cannot make square tiles: direct
+    mhs_tps::FarPlan &P = t->far;
+    f->tx = btx; f->ty = bty;
+    f->ntx = (int)((e.nc + btx - 1) / btx); f->nty = (int)((e.nr + bty - 1) / bty);
+    for (int a = 0; a < FF_N; ++a) f->t[a] = cos((2 * a + 1) * M_PI / (2.0 * FF_N));
+    *use = true;
+    const bool same = P.sorted_dev && P.xmin == e.xmin && P.ymax == e.ymax && P.xres == e.xres && P.yres == e.yres &&
+                      P.r0 == e.r0 && P.r1 == r1 && P.c0 == e.c0 && P.c1 == c1 && P.tx == btx && P.ty == bty;
+    if (same) return MHS_OK;
+    // counting sort of the knots by bin; bins beyond FF_PAD tiles outside the window collapse onto the rim
+    const int nbx = f->ntx + 2 * FF_PAD, nby = f->nty + 2 * FF_PAD;
+    std::vector<int> bin((size_t)N), start((size_t)nbx * nby + 1, 0);
+    for (int64_t j = 0; j < N; ++j) {
+        double bx = floor(kc[j] / btx), by = floor(kr[j] / bty);
+        bx = std::min(std::max(bx, (double)-FF_PAD), (double)(f->ntx + FF_PAD - 1));
+        by = std::min(std::max(by, (double)-FF_PAD), (double)(f->nty + FF_PAD - 1));
+        bin[j] = ((int)by + FF_PAD) * nbx + ((int)bx + FF_PAD);
+        ++start[(size_t)bin[j] + 1];
+    }
+    for (size_t b = 0; b + 1 < start.size(); ++b) start[b + 1] += start[b];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    std::vector<Knot> sorted((size_t)N);
+    const double kk = 0.5 / (8.0 * M_PI);
+    for (int64_t j = 0; j < N; ++j) {
+        Knot &k = sorted[(size_t)fill[(size_t)bin[j]]++];
+        k.u = t->knots_uv[j]; k.v = t->knots_uv[N + j]; k.cw = t->c[j] * kk; k.pad = 0.0;
+    }
+    std::vector<double> lx, ly;
+    cheb_matrix(btx, false, f->t, lx);
+    cheb_matrix(bty, true, f->t, ly);
+    if (!P.sorted_dev) MHS_HIP(hipMalloc((void **)&P.sorted_dev, sizeof(Knot) * (size_t)N));
+    if (int rc = grow(&P.bin_start_dev, &P.bins_cap, start.size())) return rc;
+    if (int rc = grow(&P.nodes_dev, &P.nodes_cap, (size_t)f->ntx * f->nty * FF_NODES)) return rc;
+    if (int rc = grow(&P.lx_dev, &P.lx_cap, lx.size())) return rc;
+    if (int rc = grow(&P.ly_dev, &P.ly_cap, ly.size())) return rc;
+    MHS_HIP(hipMemcpy(P.sorted_dev, sorted.data(), sizeof(Knot) * (size_t)N, hipMemcpyHostToDevice));
+    MHS_HIP(hipMemcpy(P.bin_start_dev, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+    MHS_HIP(hipMemcpy(P.lx_dev, lx.data(), sizeof(double) * lx.size(), hipMemcpyHostToDevice));
+    MHS_HIP(hipMemcpy(P.ly_dev, ly.data(), sizeof(double) * ly.size(), hipMemcpyHostToDevice));
+    P.xmin = e.xmin; P.ymax = e.ymax; P.xres = e.xres; P.yres = e.yres;
+    P.r0 = e.r0; P.r1 = r1; P.c0 = e.c0; P.c1 = c1; P.tx = btx; P.ty = bty; P.ntx = f->ntx; P.nty = f->nty;
+    return MHS_OK;
 }
 
 }  // namespace mhs
@@ -172,7 +410,18 @@ int mhs_tps_get(const mhs_tps *t, double *c, double *d3, double *knots_uv, doubl
 int mhs_tps_free(mhs_tps *t) {
     if (!t) return MHS_OK;
     if (t->knots_dev) (void)hipFree(t->knots_dev);
+    if (t->far.sorted_dev) (void)hipFree(t->far.sorted_dev);
+    if (t->far.bin_start_dev) (void)hipFree(t->far.bin_start_dev);
+    if (t->far.nodes_dev) (void)hipFree(t->far.nodes_dev);
+    if (t->far.lx_dev) (void)hipFree(t->far.lx_dev);
+    if (t->far.ly_dev) (void)hipFree(t->far.ly_dev);
     delete t;
+    return MHS_OK;
+}
+
+int mhs_tps_eval_mode(int mode) {
+    MHS_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (direct) or 2 (far-field-interpolated)");
+    g_eval_mode = mode;
     return MHS_OK;
 }
 
@@ -187,6 +436,21 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
     MHS_REQUIRE(r1 - r0 < (1LL << 30) && c1 - c0 < (1LL << 30), "window too large");
     if (r1 == r0 || c1 == c0) return MHS_OK;
     const EvalGeom e = make_geom(t, g, r0, r1, c0, c1, ld);
+    FarGeom f;
+    bool far = false;
+    if (int rc = plan_far(const_cast<mhs_tps *>(t), g, e, r1, c1, &f, &far)) return rc;
+    if (far) {
+        const mhs_tps::FarPlan &P = t->far;
+        const int ntiles = f.ntx * f.nty;
+        dim3 cgrid((unsigned)(f.ntx * (f.tx / 64)), (unsigned)(f.nty * (f.ty / EVAL_TILE_ROWS)));
+        MHS_REQUIRE(cgrid.y <= 65535u, "too many rows for one launch");
+        hipLaunchKernelGGL(tps_ff_nodes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, pick_stream(stream),
+                           P.sorted_dev, (int)t->n, P.bin_start_dev, ctx().log_tab, e, f, P.nodes_dev);
+        hipLaunchKernelGGL(tps_ff_cells_kernel, cgrid, dim3(64 * EVAL_WAVES), 0, pick_stream(stream), P.sorted_dev,
+                           P.bin_start_dev, ctx().log_tab, e, f, P.nodes_dev, P.lx_dev, P.ly_dev, out_dev);
+        MHS_HIP(hipGetLastError());
+        return MHS_OK;
+    }
     dim3 grid((unsigned)((e.nc + 63) / 64), (unsigned)((e.nr + EVAL_TILE_ROWS - 1) / EVAL_TILE_ROWS));
     // gridDim.y is limited to 65535: 16 rows per block covers > 1e6 rows
     MHS_REQUIRE(grid.y <= 65535u, "too many rows for one launch");

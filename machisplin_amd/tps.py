@@ -111,3 +111,15 @@ def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None):
     _lib.check(_lib.lib().mhs_tps_predict_grid_dev(model._h, C.byref(g), r0, r1, c0, c1,
                                                    out.data_ptr(), out.stride(0), s))
     return out
+
+
+EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD = 0, 1, 2
+
+
+def eval_mode(mode: int) -> None:
+    """How :func:`interpolate` sums the knots: EVAL_AUTO (by cost), EVAL_DIRECT (every knot for
+    every cell, predict.Krig's own arithmetic) or EVAL_FAR_FIELD (direct sum over the knots near a
+    tile + 16 x 16 Chebyshev interpolation of the analytic sum over the rest; equal to the direct sum
+    to FP64 rounding)."""
+    _lib.init()
+    _lib.check(_lib.lib().mhs_tps_eval_mode(int(mode)))

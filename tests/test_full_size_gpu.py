@@ -55,11 +55,25 @@ def test_cfg2_tps_windows_tile_the_full_grid_and_match_c_oracle(hip):
     g = synth.grid(2000, 2000)
     xy, rows, cols, uv = synth.stations(g, 2000, synth.BASE_SEED + 2)
     fit = hip.Tps(xy, synth.tps_residual(uv, synth.BASE_SEED + 2))
+    windows = [(0, 777, 0, 1001), (0, 777, 1001, 2000), (777, 2000, 0, 63), (777, 2000, 63, 2000)]
+    hip.eval_mode(hip.EVAL_DIRECT)
+    try:
+        direct = hip.interpolate(g, fit)
+        pieces = torch.empty_like(direct)
+        for (r0, r1, c0, c1) in windows:
+            hip.interpolate(g, fit, window=(r0, r1, c0, c1), out=pieces[r0:r1, c0:c1])
+        assert torch.equal(direct, pieces)  # direct sum: ragged windows, same cells, same bits
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+    # default (far-field-interpolated at this size): tiles start at the window origin, so windows agree
+    # with the full grid and with the direct sum to rounding rather than bit for bit
     full = hip.interpolate(g, fit)
-    pieces = torch.empty_like(full)
-    for (r0, r1, c0, c1) in [(0, 777, 0, 1001), (0, 777, 1001, 2000), (777, 2000, 0, 63), (777, 2000, 63, 2000)]:
+    for (r0, r1, c0, c1) in windows:
         hip.interpolate(g, fit, window=(r0, r1, c0, c1), out=pieces[r0:r1, c0:c1])
-    assert torch.equal(full, pieces)  # ragged windows, same cells, same bits
+    scale = direct.abs().max().item()
+    assert (full - pieces).abs().max().item() < 1e-11 * scale
+    assert (full - direct).abs().max().item() < 1e-11 * scale
+    del direct, pieces
     m = {"knots": fit.knots, "c": fit.c, "d": fit.d, "center": fit.center, "scale": fit.scale}
     for r0 in (0, 1234, 1999):
         want = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, r0, r0 + 1, 0, 2000, threads=8)

@@ -38,14 +38,60 @@ def test_window_and_strided_output(hip):
     xy, y = synth_stations(150, 3, g)
     m = otps.fit(xy, y)
     t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
-    full = hip.interpolate(g, t)
-    big = torch.full((300, 512), float("nan"), dtype=torch.float64, device=full.device)
-    win = (17, 203, 33, 390)
-    hip.interpolate(g, t, window=win, out=big[17:203, 33:390])
-    torch.cuda.synchronize()
+    hip.eval_mode(hip.EVAL_DIRECT)   # the far-field path tiles from the window origin: equal to rounding only
+    try:
+        full = hip.interpolate(g, t)
+        big = torch.full((300, 512), float("nan"), dtype=torch.float64, device=full.device)
+        win = (17, 203, 33, 390)
+        hip.interpolate(g, t, window=win, out=big[17:203, 33:390])
+        torch.cuda.synchronize()
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
     assert torch.equal(big[17:203, 33:390], full[17:203, 33:390])  # same cells, same bits
     assert torch.isnan(big[:, :33]).all() and torch.isnan(big[:17]).all()
     assert torch.isnan(big[:, 390:]).all() and torch.isnan(big[203:]).all()
+
+
+@pytest.mark.parametrize("n,nrow,ncol,xres,yres,window", [
+    (813, 400, 600, 1.0 / 1200, 1.0 / 1200, None),           # square cells, stations spread over the grid
+    (500, 700, 300, 1.0 / 600, 1.0 / 1200, None),            # anisotropic cells and a tall grid
+    (300, 500, 500, 1.0 / 1200, 1.0 / 1200, (40, 371, 100, 437)),   # window: most knots lie outside it
+])
+def test_far_field_path_equals_direct_sum(hip, n, nrow, ncol, xres, yres, window):
+    """The far-field-interpolated evaluation (csrc/tps_eval.hip) against the direct sum of the same handle
+    and against the oracle: equal to rounding, not merely to the 1e-6 of the north star."""
+    g = hip.Geometry(-78.0, -5.0, xres, yres, nrow, ncol)
+    xy, y = synth_stations(n, n + 1, g)
+    m = otps.fit(xy, y)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    try:
+        hip.eval_mode(hip.EVAL_DIRECT)
+        direct = hip.interpolate(g, t, window=window).cpu().numpy()
+        hip.eval_mode(hip.EVAL_FAR_FIELD)
+        far = hip.interpolate(g, t, window=window).cpu().numpy()
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+    auto = hip.interpolate(g, t, window=window).cpu().numpy()
+    r0, r1, c0, c1 = window or (0, nrow, 0, ncol)
+    want = otps.predict_grid(m, g.xmin, g.ymax, g.xres, g.yres, nrow, ncol, r0, r1, c0, c1)
+    scale = np.abs(want).max()
+    assert not np.array_equal(far, direct)                     # really a different summation
+    # the bound that holds for any coefficients is relative to S = sum_j |c_j phi_j| (a fitted spline's
+    # terms cancel by 1e3..1e4), like the rounding error of the direct sum itself
+    rr, cc = np.arange(r0, r1, 7), np.arange(c0, c1, 7)
+    x = (g.xmin + (cc + 0.5) * g.xres - m["center"][0]) / m["scale"][0]
+    yy = (g.ymax - (rr + 0.5) * g.yres - m["center"][1]) / m["scale"][1]
+    S = 0.0
+    for j in range(n):
+        d2 = (x[None, :] - m["knots"][j, 0]) ** 2 + (yy[:, None] - m["knots"][j, 1]) ** 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            S = S + np.abs(m["c"][j]) * np.abs(np.where(d2 > 0, d2 * np.log(d2), 0.0)) * (0.5 / (8 * np.pi))
+    # 1e-13 S: both paths carry the table log's 2e-14 absolute error per term (devmath.h), at different
+    # points; the interpolation itself contributes ~1e-15 S
+    assert np.abs(far - direct).max() <= 1e-13 * S.max(), (np.abs(far - direct).max(), S.max())
+    assert np.abs(far - direct).max() / scale < 1e-10
+    assert np.abs(far - want).max() / scale < RTOL
+    assert np.abs(auto - want).max() / scale < RTOL
 
 
 def test_points_match_oracle_and_knot_coincidence(hip):
