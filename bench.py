@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64: vector == MFMA peak (v_mfma_f64_16x16x4 measured 75.3 TF)
 HBM_PEAK_GBS = 8000.0
 FP32_PEAK_TFLOPS = 157.3  # FP32 vector == FP32 MFMA peak
+LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk x 2.4 GHz (ds_read_b64 / b32 rate)
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the north-star target is quoted on
@@ -129,10 +130,20 @@ class Workload:
 
         ms = mean_ms("tps_eval_ms")
         if ms:
-            fl = band_cells * (8.0 * n + 6.0)
-            rows.append({"kernel": "tps_eval_grid_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
-                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "8N+6 flop/cell, log = 1 flop; FP64 VALU/"
-                         "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
+            tc, tr, node_pairs, cell_pairs = getattr(ops, "last_eval_plan", (0, 0, 0, 0))
+            if tc:   # far-field-interpolated path: kernel evaluations actually performed + 32 FMA/cell of interpolation
+                fl = 8.0 * (node_pairs + cell_pairs) + band_cells * 70.0
+                rows.append({"kernel": "tps_ff_nodes_kernel+tps_ff_cells_kernel", "bound": "mfma", "launch_ms": ms,
+                             "achieved": fl / ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "work": "far-field-interpolated sum, tiles %d x %d cells: 8 flop per evaluated (point, knot) pair "
+                                     "(%.3g pairs at tile nodes + %.3g at cells, vs %.3g for the direct sum) + 70 flop/cell of "
+                                     "Chebyshev interpolation; FP64 VALU-bound" % (tc, tr, node_pairs, cell_pairs, band_cells * float(n)),
+                             "direct_sum_equivalent_tflops": band_cells * (8.0 * n + 6.0) / ms / 1e9})
+            else:
+                fl = band_cells * (8.0 * n + 6.0)
+                rows.append({"kernel": "tps_eval_grid_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "8N+6 flop/cell, log = 1 flop; FP64 VALU/"
+                             "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
         for prm in self.params:
             k = prm["kind"]
             ms = mean_ms("model_%s_ms" % k)
@@ -149,21 +160,28 @@ class Workload:
                 # vector/matrix peak the compares issue at
                 nt = len(prm["tree_offsets"]) - 1
                 ops_ = band_cells * nt * 6.0
-                rows.append({"kernel": "gbm_lut_kernel", "bound": "mfma", "launch_ms": ms, "achieved": ops_ / ms / 1e9,
+                rows.append({"kernel": "gbm_lutreg_kernel", "bound": "mfma", "launch_ms": ms, "achieved": ops_ / ms / 1e9,
                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "work": "6 ops per (cell, tree): 5 split compares + 1 fp64 add (predicate-LUT form of gbm_pred); "
+                             "work": "6 ops per (cell, tree): 5 split predicates + 1 fp64 add (predicate-LUT form of gbm_pred; the kernel issues "
+                                     "7 VALU lane-instructions per (cell, tree) at ~90 %% of the VALU issue rate); "
                                      "reference walk = %.0f node visits/cell, %.3g visits/s" % (
                                          self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
             elif k == "rf":
-                # LDS-latency/bandwidth bound walk (two LDS reads per level); no clean roof -- HBM view reported
+                # LDS-bandwidth bound walk: every lane reads an 8-byte node and a 4-byte key per level and descends
+                # each tree's full depth (terminals self-loop); the HBM view is what the JSON contract can express
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
+                lds_bytes = band_cells * float(self.rf_level_sum()) * 12.0
                 rows.append({"kernel": "rf_walk_kernel", "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view; the walk itself is LDS-bound: "
                                      "%.0f node visits/cell, %.3g visits/s)" % (self.cfg["layers"], self.mean_visits[k],
                                                                               self.mean_visits[k] * band_cells / (ms * 1e-3)),
-                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
+                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
+                             "lds_view": {"achieved": lds_bytes / ms / 1e6, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                          "frac": lds_bytes / ms / 1e6 / LDS_PEAK_GBS,
+                                          "work": "12 B of LDS reads per lane and level, sum of tree depths = %d levels/cell"
+                                                  % self.rf_level_sum()}})
             else:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
                 rows.append({"kernel": "%s_kernel" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
@@ -181,6 +199,21 @@ class Workload:
             per_cell = pmc.get(r["kernel"].split("<")[0])
             r["traffic"] = per_cell * band_cells if per_cell is not None else None
         return rows
+
+    def rf_level_sum(self):
+        """sum over the forest's trees of the tree depth (levels every lane descends in rf_walk_kernel)."""
+        if getattr(self, "_rf_levels", None) is None:
+            prm = next(p for p in self.params if p["kind"] == "rf")
+            off, total = prm["tree_offsets"], 0
+            for t in range(len(off) - 1):
+                o, cnt = int(off[t]), int(off[t + 1] - off[t])
+                L, R, st = prm["left"][o:o + cnt] - 1, prm["right"][o:o + cnt] - 1, prm["status"][o:o + cnt]
+                d = np.zeros(cnt, dtype=np.int64)
+                for kk in np.flatnonzero(st != -1):     # children are numbered after their parent
+                    d[L[kk]] = d[R[kk]] = d[kk] + 1
+                total += int(d.max())
+            self._rf_levels = total
+        return self._rf_levels
 
     def measure_mean_visits(self):
         """mean node visits per cell of the tree members (host walk over the station sample)."""

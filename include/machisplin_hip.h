@@ -131,6 +131,10 @@ MHS_API int mhs_tps_predict_grid(const mhs_tps *t, const mhs_grid *g, int64_t r0
  * 16 x 16 Chebyshev interpolation of the analytic sum over the rest; equal to the direct sum to FP64
  * rounding, see csrc/tps_eval.hip).  predict.Krig itself is the direct sum. */
 MHS_API int mhs_tps_eval_mode(int mode);
+/* What the last grid evaluation of this handle did: tile size in cells (0 x 0 = direct sum) and the number of
+ * kernel evaluations phi(r) it performed at tile nodes (far knots) and at cells (near knots).  For profiling. */
+MHS_API int mhs_tps_eval_plan(const mhs_tps *t, int *tile_cols, int *tile_rows, int64_t *node_pairs,
+                      int64_t *cell_pairs);
 MHS_API int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                              int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream);
 /* predict(tps, xy): arbitrary points, xy n x 2 column-major (Step-5 station check) */

@@ -88,5 +88,7 @@ struct mhs_tps {
         double *nodes_dev = nullptr;            // ntx * nty * 256 far-field values at the tile nodes
         double *lx_dev = nullptr, *ly_dev = nullptr;  // interpolation matrices, tx x 16 and ty x 16
         size_t nodes_cap = 0, bins_cap = 0, lx_cap = 0, ly_cap = 0;
+        bool last_used = false;                 // the last grid evaluation took this path
+        int64_t node_pairs = 0, cell_pairs = 0; // (node, far knot) and (cell, near knot) kernel evaluations
     } far;
 };

@@ -344,6 +344,18 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
         Knot &k = sorted[(size_t)fill[(size_t)bin[j]]++];
         k.u = t->knots_uv[j]; k.v = t->knots_uv[N + j]; k.cw = t->c[j] * kk; k.pad = 0.0;
     }
+    P.node_pairs = P.cell_pairs = 0;
+    for (int tyi = 0; tyi < f->nty; ++tyi)
+        for (int txi = 0; txi < f->ntx; ++txi) {
+            int64_t near = 0;
+            for (int r = 0; r < 3; ++r) {
+                const size_t b = (size_t)(tyi + FF_PAD - 1 + r) * nbx + (size_t)(txi + FF_PAD - 1);
+                near += start[b + 3] - start[b];
+            }
+            const int64_t tc = std::min<int64_t>(btx, e.nc - (int64_t)txi * btx) * std::min<int64_t>(bty, e.nr - (int64_t)tyi * bty);
+            P.node_pairs += (int64_t)FF_NODES * (N - near);
+            P.cell_pairs += tc * near;
+        }
     std::vector<double> lx, ly;
     cheb_matrix(btx, false, f->t, lx);
     cheb_matrix(bty, true, f->t, ly);
@@ -425,6 +437,16 @@ int mhs_tps_eval_mode(int mode) {
     return MHS_OK;
 }
 
+int mhs_tps_eval_plan(const mhs_tps *t, int *tile_cols, int *tile_rows, int64_t *node_pairs, int64_t *cell_pairs) {
+    MHS_REQUIRE(t != nullptr, "NULL handle");
+    const mhs_tps::FarPlan &P = t->far;
+    if (tile_cols) *tile_cols = P.last_used ? P.tx : 0;
+    if (tile_rows) *tile_rows = P.last_used ? P.ty : 0;
+    if (node_pairs) *node_pairs = P.last_used ? P.node_pairs : 0;
+    if (cell_pairs) *cell_pairs = P.last_used ? P.cell_pairs : 0;
+    return MHS_OK;
+}
+
 int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                              int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream) {
     if (int rc = require_ready()) return rc;
@@ -439,6 +461,7 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
     FarGeom f;
     bool far = false;
     if (int rc = plan_far(const_cast<mhs_tps *>(t), g, e, r1, c1, &f, &far)) return rc;
+    const_cast<mhs_tps *>(t)->far.last_used = far;
     if (far) {
         const mhs_tps::FarPlan &P = t->far;
         const int ntiles = f.ntx * f.nty;

@@ -207,6 +207,7 @@ class HipOps:
         fit = Tps.from_coef(d["knots"], d["c"], d["d"], d["lambda"], d["center"], d["scale"])
         g = self.stack.geom
         self._timed("tps_eval_ms", lambda: interpolate(g, fit, window=(r0, r1, 0, g.ncol), out=out))
+        self.last_eval_plan = fit.eval_plan()
 
     def add(self, a, b, out):
         st = self.torch.cuda.current_stream(self.device).cuda_stream

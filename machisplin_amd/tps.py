@@ -83,6 +83,13 @@ class Tps:
                                                      out.ctypes.data))
         return out
 
+    def eval_plan(self):
+        """(tile_cols, tile_rows, node_pairs, cell_pairs) of this handle's last grid evaluation; tile 0 x 0 means
+        the direct sum ran."""
+        tc, tr, a, b = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().mhs_tps_eval_plan(self._h, C.byref(tc), C.byref(tr), C.byref(a), C.byref(b)))
+        return tc.value, tr.value, a.value, b.value
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and _lib._lib is not None:
