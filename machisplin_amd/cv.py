@@ -1,0 +1,72 @@
+"""Step 1's data-parallel part: hold-out predictions of the six learners for the
+k-fold cross-validation (V73:225-319) on the GPU, and the ensemble weight search that consumes them
+(V73:326-393).
+
+Fitting the fold models stays in the CRAN packages (R); what runs here is what R does with
+``terra::predict(model, test)`` inside the fold loop: every fold's models evaluated at that fold's hold-out
+rows through ``mhs_predict_points``, the residual vectors concatenated in fold order, and
+``optimx(par = 0.5, lower = 0, upper = 1, method = "L-BFGS-B")`` on
+
+    fit(k) = sum_i ( sum_m k_m r_{i,m} / sum_m k_m )^2 = k' (R'R) k / (1'k)^2 .
+
+The objective is scale-invariant, so the optimiser's end point on the minimising ray decides the rounded
+weights (V73:340-362); this module uses SciPy's L-BFGS-B (the same Nocedal/Zhu code base R's optim wraps)
+with the same start, bounds and objective -- the iterate sequence of R's build is NOT reproduced bit for
+bit, and R-side integration keeps optimx in R."""
+from __future__ import annotations
+
+import numpy as np
+
+from .models import Model, select_weights
+
+ORDER_ALL = "bgnmrv"      # OptX$p1..p6: brt, gam, nn, mars, rf, svm (V73:326-331)
+ORDER_SMOOTH = "gnmv"     # smooth.outputs.only = TRUE (V73:366-372)
+
+
+def holdout_rows(kfolds, v: int, n_rows: int):
+    """V73:228-232: with more than 4000 rows the model is TRAINED on fold v and tested on the other nine."""
+    kfolds = np.asarray(kfolds)
+    return np.flatnonzero(kfolds != v) if n_rows > 4000 else np.flatnonzero(kfolds == v)
+
+
+def cv_residuals(fold_models, X, resp, kfolds, labels: str = ORDER_ALL):
+    """mfit.<model>.full of V73:258-319: for fold v = 1..nfolds, ``test$resp - predict(model_v, test)`` on the
+    hold-out rows, concatenated in fold order.  ``fold_models[v-1]`` maps a label in ``labels`` to the device
+    model (:class:`machisplin_amd.models.Model`) fitted on fold v's training rows; ``X`` is the n x p predictor
+    matrix (covariates, LONG, LAT), ``kfolds`` the 1-based fold label of every row.
+    Returns an (n_holdout_total, len(labels)) float64 matrix, columns in ``labels`` order."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    resp = np.asarray(resp, dtype=np.float64)
+    cols = {lab: [] for lab in labels}
+    for v, models in enumerate(fold_models, start=1):
+        rows = holdout_rows(kfolds, v, X.shape[0])
+        Xt = np.ascontiguousarray(X[rows])
+        for lab in labels:
+            m = models[lab]
+            if not isinstance(m, Model):
+                raise TypeError("fold %d: model %r is not a device model" % (v, lab))
+            cols[lab].append(resp[rows] - m.predict_points(Xt))
+    return np.column_stack([np.concatenate(cols[lab]) for lab in labels])
+
+
+def optx_objective(k, gram):
+    """machisplin.optimx.internal (V73:329-331, 369-371) through the Gram matrix of the residual columns."""
+    k = np.asarray(k, dtype=np.float64)
+    s = k.sum()
+    return float(k @ gram @ k) / (s * s)
+
+
+def optx_weights(residuals, smooth_only: bool = False):
+    """OptX of V73:333 / 373: minimise the objective from par = 0.5 in [0, 1]^m with L-BFGS-B (numerical
+    gradient, as optimx does without ``gr``), then apply V73:336-362.  Returns (p, kept labels, kept rounded
+    weights, unrounded total)."""
+    from scipy.optimize import minimize
+    R = np.asarray(residuals, dtype=np.float64)
+    labels = ORDER_SMOOTH if smooth_only else ORDER_ALL
+    if R.ndim != 2 or R.shape[1] != len(labels):
+        raise ValueError("residuals must have %d columns (%s)" % (len(labels), labels))
+    gram = R.T @ R
+    res = minimize(optx_objective, np.full(len(labels), 0.5), args=(gram,), method="L-BFGS-B",
+                   bounds=[(0.0, 1.0)] * len(labels))
+    kept, wts, tot = select_weights(res.x, labels)
+    return res.x, kept, wts, tot

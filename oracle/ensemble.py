@@ -247,3 +247,33 @@ def stack_predictors(covars, geom_xy):
     X[:, C] = np.tile(x, nrow)
     X[:, C + 1] = np.repeat(y, ncol)
     return X
+
+
+# ------------------------------------------------- Step 1: CV residuals + weight search --
+def holdout_rows(kfolds, v, n_rows):
+    """V73:228-232: train on fold v / test on the rest when the table has more than 4000 rows."""
+    kfolds = np.asarray(kfolds)
+    return np.flatnonzero(kfolds != v) if n_rows > 4000 else np.flatnonzero(kfolds == v)
+
+
+def cv_residuals(fold_params, X, resp, kfolds, labels="bgnmrv"):
+    """V73:258-319: mfit.<model>.full = c(test$resp - predict(model_v, test)) over v = 1..nfolds."""
+    cols = {lab: [] for lab in labels}
+    for v, params in enumerate(fold_params, start=1):
+        rows = holdout_rows(kfolds, v, X.shape[0])
+        for lab in labels:
+            cols[lab].append(resp[rows] - predict(params[lab], X[rows]))
+    return np.column_stack([np.concatenate(cols[lab]) for lab in labels])
+
+
+def optx_objective_literal(k, R):
+    """machisplin.optimx.internal exactly as written at V73:329-331 (and 369-371 for four columns):
+    sum(((r1*k1)/(k1+..+k6) + (r2*k2)/(k1+..+k6) + ...)^2)."""
+    tot = 0.0
+    for kk in k:
+        tot = tot + kk
+    acc = None
+    for j, kk in enumerate(k):
+        term = (R[:, j] * kk) / tot
+        acc = term if acc is None else acc + term
+    return float(np.sum(acc ** 2))
