@@ -196,8 +196,8 @@ class Workload:
             pass
         for r in rows:
             r["frac"] = r["achieved"] / r["peak"]
-            per_cell = pmc.get(r["kernel"].split("<")[0])
-            r["traffic"] = per_cell * band_cells if per_cell is not None else None
+            parts = [pmc.get(kn.split("<")[0]) for kn in r["kernel"].split("+")]
+            r["traffic"] = sum(parts) * band_cells if all(x is not None for x in parts) else None
         return rows
 
     def rf_level_sum(self):
