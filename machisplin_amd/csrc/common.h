@@ -30,6 +30,8 @@ struct Context {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // the fit's panel factorisations run ahead on this one (tps_fit.hip)
+    std::vector<hipEvent_t> event_pool;   // timing-disabled events for the two-stream fit, reused across calls
     double2 *log_tab = nullptr;  // device, LOG_TAB_N entries
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 0;

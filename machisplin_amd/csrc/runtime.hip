@@ -93,6 +93,7 @@ int mhs_init(int device) {
     int prio_lo = 0, prio_hi = 0;
     MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     MHS_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_hi));
+    MHS_HIP(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, prio_hi));
     MHS_HIP(hipEventCreate(&c.ev0));
     MHS_HIP(hipEventCreate(&c.ev1));
     std::vector<double2> tab;
@@ -111,6 +112,8 @@ int mhs_shutdown(void) {
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
+    for (hipEvent_t e : c.event_pool) (void)hipEventDestroy(e);
+    if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); }
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c = Context();
     return MHS_OK;

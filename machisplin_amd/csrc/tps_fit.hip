@@ -244,8 +244,8 @@ __global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A
 // columns -- so the BW Householder steps touch global memory only to load and store the panel;
 // every step is two block reductions.  (The streaming version above is latency-bound: a single
 // block keeps ~8 KB of loads in flight.)
-constexpr int PANEL_RPT = 10;
-constexpr int PANEL_THREADS = 512;
+constexpr int PANEL_RPT = 7;
+constexpr int PANEL_THREADS = 768;
 
 struct PanelShared {
     double lds[17 * 16];
@@ -255,60 +255,77 @@ struct PanelShared {
     double piv;
 };
 
-// Householder step J of the register-resident panel (J is a template parameter so that every
-// index into x[][] is a compile-time constant and the panel stays in VGPRs)
-template <int J>
-__device__ __forceinline__ void panel_step(double (&x)[PANEL_RPT][BW], int t, int nref, PanelShared &sh) {
-    if (J >= nref) {  // uniform: nothing left to annihilate; H_J = I
-        if (threadIdx.x == 0) { sh.taus[J] = 0.0; for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0; }
-        return;
-    }
-    double part[1] = {0.0};
+// The BW Householder steps of the register-resident panel as ONE loop body: the columns are kept
+// rotated so that the pivot column is always x[.][0], the columns still to be updated follow it and
+// the reflectors already formed sit at the end (step J: positions 1..BW-1-J are columns J+1.., positions
+// BW-J.. are v_0..v_{J-1}); after the step the columns rotate left by one, and BW rotations restore the
+// original order.  Every index into x[][] stays a compile-time constant (the panel lives in VGPRs)
+// while the code is BW times smaller than BW specialised steps -- the kernel is one block, launched
+// ~n/BW times on whichever CU is free, so its instruction footprint is fetched cold every time.
+// Row i = tid + PANEL_THREADS r: only r = 0 can hold rows on or above the diagonal; rows past the end
+// of the panel hold zeros and stay zero.
+__device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared &sh) {
+    const int i0 = threadIdx.x;     // the row held in x[0][.]
+#pragma unroll 1
+    for (int J = 0; J < BW; ++J) {
+        if (J < nref) {
+            double part[1] = {0.0};
+            if (i0 > J) part[0] = x[0][0] * x[0][0];
+            if (i0 == J) sh.piv = x[0][0];
 #pragma unroll
-    for (int r = 0; r < PANEL_RPT; ++r) {
-        const int i = threadIdx.x + PANEL_THREADS * r;
-        if (i > J) part[0] = fma(x[r][J], x[r][J], part[0]);
-        if (i == J) sh.piv = x[r][J];
-    }
-    block_sum_vec<1>(part, sh.lds);  // its barriers also publish piv
-    const double ss = part[0], alpha = sh.piv;
-    __syncthreads();                 // everyone has read piv before the next column's owner rewrites it
-    double beta = alpha, tau = 0.0, scal = 0.0;
-    if (ss != 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-        tau = (beta - alpha) / beta;
-        scal = 1.0 / (alpha - beta);
-    }
-    // one fused reduction: red[0..6-J] = v' P[:,k] (k > J), red[7-J..6] = v_l' v (l < J)
-    double red[BW - 1];
+            for (int r = 1; r < PANEL_RPT; ++r) part[0] = fma(x[r][0], x[r][0], part[0]);
+            block_sum_vec<1>(part, sh.lds);  // its barriers also publish piv
+            const double ss = part[0], alpha = sh.piv;
+            __syncthreads();                 // everyone has read piv before the next column's owner rewrites it
+            double beta = alpha, tau = 0.0, scal = 0.0;
+            if (ss != 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            // one fused reduction over the other BW-1 positions: v' P[:,k] for the columns still to be
+            // updated, v_l' v for the reflectors already formed
+            double red[BW - 1];
+            const double v0 = i0 < J ? 0.0 : (i0 == J ? 1.0 : x[0][0] * scal);
+            if (i0 == J) x[0][0] = beta; else if (i0 > J) x[0][0] = v0;
 #pragma unroll
-    for (int k = 0; k < BW - 1; ++k) red[k] = 0.0;
+            for (int p = 1; p < BW; ++p) {
+                const int l = p + J - BW;     // >= 0: position p holds reflector v_l
+                const double other = l < 0 ? x[0][p] : (i0 < l ? 0.0 : (i0 == l ? 1.0 : x[0][p]));
+                red[p - 1] = other * v0;
+            }
 #pragma unroll
-    for (int r = 0; r < PANEL_RPT; ++r) {
-        const int i = threadIdx.x + PANEL_THREADS * r;
-        const double vr = (i < J || i >= t) ? 0.0 : (i == J ? 1.0 : x[r][J] * scal);
-        if (i == J) x[r][J] = beta; else if (i > J) x[r][J] = vr;
+            for (int r = 1; r < PANEL_RPT; ++r) {
+                const double vr = x[r][0] * scal;
+                x[r][0] = vr;
 #pragma unroll
-        for (int k = J + 1; k < BW; ++k) red[k - J - 1] = fma(vr, x[r][k], red[k - J - 1]);
+                for (int p = 1; p < BW; ++p) red[p - 1] = fma(vr, x[r][p], red[p - 1]);
+            }
+            block_sum_vec<BW - 1>(red, sh.lds);
+            if (threadIdx.x == 0) {
+                sh.taus[J] = tau;
+                for (int l = 0; l < J; ++l) sh.Gs[l][J] = sh.lds[16 * (BW - 1) + (BW - J + l - 1)];
+            }
 #pragma unroll
-        for (int l = 0; l < J; ++l) {
-            const double vl = i < l ? 0.0 : (i == l ? 1.0 : x[r][l]);
-            red[BW - 1 - J + l] = fma(vl, vr, red[BW - 1 - J + l]);
+            for (int p = 1; p < BW; ++p) red[p - 1] = p < BW - J ? red[p - 1] * tau : 0.0;
+#pragma unroll
+            for (int p = 1; p < BW; ++p) x[0][p] -= red[p - 1] * v0;
+#pragma unroll
+            for (int r = 1; r < PANEL_RPT; ++r) {
+#pragma unroll
+                for (int p = 1; p < BW; ++p) x[r][p] -= red[p - 1] * x[r][0];   // x[r][0] now holds v
+            }
+        } else if (threadIdx.x == 0) {   // uniform: nothing left to annihilate; H_J = I
+            sh.taus[J] = 0.0;
+            for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0;
         }
-    }
-    block_sum_vec<BW - 1>(red, sh.lds);
-    if (threadIdx.x == 0) {
-        sh.taus[J] = tau;
 #pragma unroll
-        for (int l = 0; l < J; ++l) sh.Gs[l][J] = red[BW - 1 - J + l];
-    }
+        for (int r = 0; r < PANEL_RPT; ++r) {
+            const double first = x[r][0];
 #pragma unroll
-    for (int r = 0; r < PANEL_RPT; ++r) {
-        const int i = threadIdx.x + PANEL_THREADS * r;
-        const double vr = (i < J || i >= t) ? 0.0 : (i == J ? 1.0 : x[r][J]);  // x[r][J] now holds v below the diagonal
-        const double tv = tau * vr;
-#pragma unroll
-        for (int k = J + 1; k < BW; ++k) x[r][k] -= red[k - J - 1] * tv;
+            for (int p = 0; p + 1 < BW; ++p) x[r][p] = x[r][p + 1];
+            x[r][BW - 1] = first;
+        }
     }
 }
 
@@ -320,17 +337,22 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
     const int nref = min(BW, t - 1);
     double *P = A + (int64_t)c0 * ld + r0;
     double x[PANEL_RPT][BW];   // x[r][j] = P[tid + PANEL_THREADS r][j]
+    // unconditional loads at a clamped row (one batch in flight), zeroed past the end of the panel
 #pragma unroll
     for (int r = 0; r < PANEL_RPT; ++r) {
         const int i = threadIdx.x + PANEL_THREADS * r;
+        const unsigned ii = i < t ? (unsigned)i : 0u;
 #pragma unroll
-        for (int j = 0; j < BW; ++j) { const double *Pj = P + (int64_t)j * ld; x[r][j] = i < t ? Pj[i] : 0.0; }
+        for (int j = 0; j < BW; ++j) { const double *Pj = P + (int64_t)j * ld; x[r][j] = Pj[ii]; }
     }
-    static_assert(BW == 8, "panel steps are spelled out for BW = 8");
-    panel_step<0>(x, t, nref, sh); panel_step<1>(x, t, nref, sh);
-    panel_step<2>(x, t, nref, sh); panel_step<3>(x, t, nref, sh);
-    panel_step<4>(x, t, nref, sh); panel_step<5>(x, t, nref, sh);
-    panel_step<6>(x, t, nref, sh); panel_step<7>(x, t, nref, sh);
+#pragma unroll
+    for (int r = 0; r < PANEL_RPT; ++r) {
+        if ((int)threadIdx.x + PANEL_THREADS * r >= t) {
+#pragma unroll
+            for (int j = 0; j < BW; ++j) x[r][j] = 0.0;
+        }
+    }
+    panel_steps(x, nref, sh);
     {   // sg = V' g (g as it was on entry)
         double sg[BW];
 #pragma unroll
@@ -338,10 +360,11 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
 #pragma unroll
         for (int r = 0; r < PANEL_RPT; ++r) {
             const int i = threadIdx.x + PANEL_THREADS * r;
-            const double gi = i < t ? g[i] : 0.0;
+            const double gi = i < t ? g[(unsigned)i] : 0.0;
 #pragma unroll
             for (int j = 0; j < BW; ++j) {
-                const double vj = (j >= nref || i < j || i >= t) ? 0.0 : (i == j ? 1.0 : x[r][j]);
+                // rows of r > 0 lie below every diagonal entry (and are zero when the panel is shorter)
+                const double vj = r > 0 ? x[r][j] : ((j >= nref || i < j || i >= t) ? 0.0 : (i == j ? 1.0 : x[r][j]));
                 sg[j] = fma(vj, gi, sg[j]);
             }
         }
@@ -377,15 +400,16 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
     for (int r = 0; r < PANEL_RPT; ++r) {
         const int i = threadIdx.x + PANEL_THREADS * r;
         if (i < t) {
-            double gi = g[i];
+            double gi = g[(unsigned)i];
 #pragma unroll
             for (int j = 0; j < BW; ++j) {
-                P[(int64_t)j * ld + i] = x[r][j];
-                const double vj = (j >= nref || i < j) ? 0.0 : (i == j ? 1.0 : x[r][j]);
-                Vd[j * vs + i] = vj;
+                double *Pj = P + (int64_t)j * ld, *Vj = Vd + (int64_t)j * vs;
+                Pj[(unsigned)i] = x[r][j];
+                const double vj = r > 0 ? x[r][j] : ((j >= nref || i < j) ? 0.0 : (i == j ? 1.0 : x[r][j]));
+                Vj[(unsigned)i] = vj;
                 gi -= vj * sh.zs[j];
             }
-            g[i] = gi;
+            g[(unsigned)i] = gi;
         }
     }
 }
@@ -501,12 +525,12 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
                                                           const double *__restrict__ Vd,
                                                           const double *__restrict__ Ypart, int64_t vs,
                                                           const double *__restrict__ Tm,
-                                                          const double *__restrict__ Sm) {
+                                                          const double *__restrict__ Sm, int jblock0) {
     __shared__ double Vs[2][64][BW + 1], Ws[2][64][BW + 1];
     __shared__ double Ts[BW * BW], Ss[BW * BW];
     if (threadIdx.x < BW * BW) { Ts[threadIdx.x] = Tm[threadIdx.x]; Ss[threadIdx.x] = Sm[threadIdx.x]; }
     __syncthreads();
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int i0 = blockIdx.x * 64, j0 = (blockIdx.y + jblock0) * 64;
     if (threadIdx.x < 128) {  // one thread per row of the I set (0..63) or the J set (64..127)
         const int set = threadIdx.x >> 6, rr = threadIdx.x & 63;
         const int row = (set ? j0 : i0) + rr;
@@ -919,19 +943,43 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
         MHS_HIP(Tall.alloc((size_t)std::max(npanels, 1) * BW * BW));
         MHS_HIP(abd.alloc((size_t)m * (BW + 1)));
+        // Two streams: the panel factorisation of step p+1 needs only the first column block of the trailing
+        // matrix as updated by step p.  That block is updated first, on the main stream, which goes straight on
+        // to the (single-block, latency-bound) panel kernel of step p+1, while the rest of step p's update runs
+        // on stream2 behind an event.  The panel block needs a whole CU's registers: it must reach the
+        // dispatcher before the flood of update blocks, which the event's latency ensures.  Per step the
+        // critical path is panel + symm + s + one column block instead of panel + symm + s + the whole update.
+        hipStream_t s2 = ctx().stream2;
+        std::vector<hipEvent_t> &pool = ctx().event_pool;
+        while ((int)pool.size() < 2 * npanels) {
+            hipEvent_t e;
+            MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pool.push_back(e);
+        }
+        DevBuf<double> Vd2;
+        MHS_HIP(Vd2.alloc((size_t)BW * vs));
         for (int p = 0; p < npanels; ++p) {
             const int c = p * BW, t = m - c - BW, c0 = 3 + c, r0 = 3 + c + BW;
             double *Tp = Tall.p + (size_t)p * BW * BW;
+            double *Vp = (p & 1) ? Vd2.p : Vd.p;
+            hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
             if (t <= PANEL_THREADS * PANEL_RPT)
-                hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vd.p, vs, Tp, gbuf.p + c + BW);
+                hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
             else
-                hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vd.p, vs, Tp, gbuf.p + c + BW);
+                hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
+            if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));     // rest of step p-1's update
             const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS;
-            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, SYMM_SPLITS), dim3(256), 0, s, A.p, ld, r0, t, Vd.p, vs, Yp.p, Mp.p);
+            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, SYMM_SPLITS), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
             hipLaunchKernelGGL(band_s_kernel, dim3(1), dim3(1024), 0, s, Mp.p, ncg * SYMM_SPLITS, Tp, Sm.p);
-            dim3 grid((unsigned)((t + 63) / 64), (unsigned)((t + 63) / 64));
-            hipLaunchKernelGGL(band_update_kernel, grid, dim3(256), 0, s, A.p, ld, r0, t, Vd.p, Yp.p, vs, Tp, Sm.p);
+            const unsigned nb = (unsigned)((t + 63) / 64);
+            hipLaunchKernelGGL(band_update_kernel, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, vs, Tp, Sm.p, 0);
+            MHS_HIP(hipEventRecord(ev_block, s));
+            MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
+            if (nb > 1)
+                hipLaunchKernelGGL(band_update_kernel, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, vs, Tp, Sm.p, 1);
+            MHS_HIP(hipEventRecord(ev_rest, s2));
         }
+        if (npanels > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (npanels - 1) + 1], 0));
         hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)((m * (BW + 1) + 255) / 256)), dim3(256), 0, s, A.p, ld, 3, m, abd.p);
         MHS_HIP(hipGetLastError());
         std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
