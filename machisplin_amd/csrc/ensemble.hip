@@ -65,6 +65,7 @@ struct mhs_model {
     int64_t n_nodes = 0;
     double init_f = 0;
     bool lds_ok = true;
+    double *split_scratch = nullptr;     // device, partial tree sums of the few-cells path (launch_trees)
     // gbm predicate-LUT fast path (trees with <= 6 splits): see gbm_lut_kernel
     int lut_S = 0;                       // splits per tree after padding (0 = path unavailable)
     double *lut = nullptr;               // device, n_trees_padded << lut_S leaf values
@@ -263,7 +264,10 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
 // ---------------------------------------------------------------------- trees --
 // gbm_pred / predictRegTree walks.  Dynamic LDS: xs[p][R*256] predictors, then one chunk
 // of node records (LDS_NODES) or nothing (nodes read from global, for trees too large).
-template <bool GBM, bool LDS_NODES, int R, bool NA_ONLY>
+// SPLIT (few cells, e.g. the station rows): blockIdx.y owns a contiguous share of the LDS chunks and writes its
+// partial tree sum to out[blockIdx.y * total + cell] (NaN marks an NA row of a forest); tree_finalize_kernel adds
+// the shares in order.  Without it the 5 000 station rows of a step occupy 10 blocks for 10 000 trees' worth of time.
+template <bool GBM, bool LDS_NODES, int R, bool NA_ONLY, bool SPLIT = false>
 __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnodes,
                                                    const int *__restrict__ tree_off,
                                                    const TreeChunk *__restrict__ chunks, int n_chunks,
@@ -298,7 +302,13 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
         for (int c = 0; c < R; ++c) any |= na[c] && i0 < half && (i0 + c * half) < total;
         if (!__syncthreads_or(any)) return;
     }
-    for (int ch = 0; ch < n_chunks; ++ch) {
+    int ch_begin = 0, ch_end = n_chunks;
+    if (SPLIT) {
+        const int per = (n_chunks + (int)gridDim.y - 1) / (int)gridDim.y;
+        ch_begin = min((int)blockIdx.y * per, n_chunks);
+        ch_end = min(ch_begin + per, n_chunks);
+    }
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const TreeChunk tc = chunks[ch];
         if (LDS_NODES) {
             __syncthreads();
@@ -324,6 +334,14 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
                 acc[c] = acc[c] + nd.val;
             }
         }
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int64_t i = i0 + c * half;
+            if (i0 < half && i < total) out[(int64_t)blockIdx.y * total + i] = (!GBM && na[c]) ? NAN : acc[c];
+        }
+        return;
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
@@ -810,12 +828,40 @@ static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g,
                  return MHS_ERR_INVALID;                                             \
     }
 
+template <bool GBM>
+__global__ __launch_bounds__(256) void tree_finalize_kernel(const double *__restrict__ part, int shares, int64_t total,
+                                                            double init_f, int n_trees, PredGeom g, double weight,
+                                                            int accumulate, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    double acc = 0.0;
+    for (int y = 0; y < shares; ++y) acc = acc + part[(int64_t)y * total + i];
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    emit(out, (int64_t)row * g.ld_out + col, GBM ? init_f + acc : acc / (double)n_trees, weight, accumulate);
+}
+
+constexpr int64_t TREE_SPLIT_MAX_CELLS = 16384;   // below this the tree loop is shared out over blockIdx.y
+constexpr int TREE_SPLIT_SHARES = 64;
+
 template <bool GBM, bool NA_ONLY>
 static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
                         double *out, hipStream_t st, int64_t total) {
     const int64_t half = (total + TREE_R - 1) / TREE_R;
     const unsigned blocks = (unsigned)((half + 255) / 256);
     const size_t xs_bytes = (size_t)m->p * TREE_R * 256 * sizeof(double);
+    if (!NA_ONLY && m->lds_ok && total <= TREE_SPLIT_MAX_CELLS && m->n_chunks >= 4) {
+        const int shares = std::min(m->n_chunks, TREE_SPLIT_SHARES);
+        mhs_model *mm = const_cast<mhs_model *>(m);
+        if (!mm->split_scratch) MHS_HIP(hipMalloc((void **)&mm->split_scratch, sizeof(double) * TREE_SPLIT_MAX_CELLS * TREE_SPLIT_SHARES));
+        const size_t bytes = xs_bytes + (size_t)m->max_chunk_nodes * sizeof(Node);
+        auto kern = tree_kernel<GBM, true, TREE_R, false, true>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks, (unsigned)shares), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks,
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, mm->split_scratch);
+        hipLaunchKernelGGL(tree_finalize_kernel<GBM>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           mm->split_scratch, shares, total, m->init_f, m->n_trees, g, w, acc, out);
+        return MHS_OK;
+    }
     if (m->lds_ok) {
         const size_t bytes = xs_bytes + (size_t)m->max_chunk_nodes * sizeof(Node);
         auto kern = tree_kernel<GBM, true, TREE_R, NA_ONLY>;
@@ -1121,6 +1167,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->nodes) (void)hipFree(m->nodes);
     if (m->tree_off) (void)hipFree(m->tree_off);
     if (m->chunks) (void)hipFree(m->chunks);
+    if (m->split_scratch) (void)hipFree(m->split_scratch);
     if (m->lut) (void)hipFree(m->lut);
     if (m->lut_meta) (void)hipFree(m->lut_meta);
     if (m->lut_sorted) (void)hipFree(m->lut_sorted);
