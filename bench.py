@@ -95,7 +95,7 @@ class Workload:
             share = torch.zeros(1, dtype=torch.float64, device="cuda")
             if rank == 0:
                 tm = self.ops.timings
-                band_ms = sum(v[-1] for k, v in tm.items() if k.startswith("model_") or k == "tps_eval_ms")
+                band_ms = sum(v[-1] for k, v in tm.items() if k.startswith("model_"))   # the TPS is evaluated on the whole grid by every rank
                 cells_ms = band_ms * side / max(1, self.run.r1 - self.run.r0)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -130,6 +130,7 @@ class Workload:
 
         ms = mean_ms("tps_eval_ms")
         if ms:
+            ens_band_cells, band_cells = band_cells, self.geom.nrow * self.geom.ncol   # the spline covers the whole grid on every rank
             tc, tr, node_pairs, cell_pairs = getattr(ops, "last_eval_plan", (0, 0, 0, 0))
             if tc:   # far-field-interpolated path: kernel evaluations actually performed + 32 FMA/cell of interpolation
                 fl = 8.0 * (node_pairs + cell_pairs) + band_cells * 70.0
@@ -144,6 +145,8 @@ class Workload:
                 rows.append({"kernel": "tps_eval_grid_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "8N+6 flop/cell, log = 1 flop; FP64 VALU/"
                              "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
+        if mean_ms("tps_eval_ms"):
+            band_cells = ens_band_cells
         for prm in self.params:
             k = prm["kind"]
             ms = mean_ms("model_%s_ms" % k)

@@ -4,8 +4,11 @@ Cells are independent given the fitted parameters, so the grid is cut into conti
 row bands, one per rank.  The only data-path exchanges are the ones the path really has:
   * rank 0 fits the thin-plate spline on the station residuals and BROADCASTS its
     coefficients (3 n + 8 doubles);
-  * ONE ALL-GATHER of the finished row bands stitches the output grid on every rank
-    (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+  * ONE ALL-GATHER of the ensemble row bands stitches the grid on every rank (RCCL over xGMI
+    on the GPU box; gloo in the CPU tests).  It is started as soon as the band is enqueued and
+    runs behind rank 0's fit; every rank then evaluates the spline on the whole grid itself
+    (milliseconds with the far-field-interpolated sum) and adds it, so the result is the
+    one-GPU result bit for bit and Step 5 never needs a second exchange.
 The per-band arithmetic is injected (`ops`): bench.py passes the HIP implementation, the
 CPU tests pass a numpy stand-in so the collective plumbing is exercised under gloo.
 """
@@ -80,11 +83,11 @@ class ShardedMltps:
         self.r0, self.r1 = self.bands[rank]
         self.even = all(b[1] - b[0] == self.band for b in self.bands[:-1]) and rank0_share is None
         kw = {"dtype": torch.float64, "device": ops.device}
-        self.pred = torch.zeros((self.band, ncol), **kw)
-        self.tps = torch.zeros((self.band, ncol), **kw)
-        self.total_band = torch.zeros((self.band, ncol), **kw)
-        self.full = torch.zeros((self.band * world, ncol), **kw)  # all-gather target (padded bands)
+        self.pred = torch.zeros((self.band, ncol), **kw)              # this rank's ensemble band (padded)
+        self.full = torch.zeros((self.band * world, ncol), **kw)      # all-gather target (padded bands)
         self.stitched = None if self.even else torch.zeros((nrow, ncol), **kw)
+        self.tps = torch.zeros((nrow, ncol), **kw)                    # final.TPS, whole grid, on every rank
+        self.total = torch.zeros((nrow, ncol), **kw)
         self.torch = torch
 
     def _stitch(self):
@@ -102,38 +105,35 @@ class ShardedMltps:
         # Step 2 at the stations first (a few thousand points): it is all the fit needs, so rank 0
         # can fit the spline WHILE every rank's ensemble band is still running -- the band kernels
         # are only enqueued here (VALU / LDS bound), the fit's many small bandwidth-bound kernels run
-        # on the library's own high-priority stream
+        # on the library's own high-priority streams
         knots, resid, resp, rows, cols = ops.station_residuals()
         n = knots.shape[0]
         if nb > 0:
             ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
+        # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
+        work = None
+        if self.world > 1:
+            work = self.dist.all_gather_into_tensor(self.full, self.pred, async_op=True)
         msg = torch.zeros(3 * n + 8, dtype=torch.float64, device=ops.device)
         if self.rank == 0:
             msg.copy_(torch.from_numpy(np.ascontiguousarray(ops.tps_fit(knots, resid))))
         if self.world > 1:
             self.dist.broadcast(msg, src=0)
         packed = msg.cpu().numpy()
-        if nb > 0:
-            ops.tps_band(packed, n, self.r0, self.r1, self.tps[:nb])
-            ops.add(self.pred[:nb], self.tps[:nb], self.total_band[:nb])
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.full, self.total_band)
+        if work is not None:
+            work.wait()
+            pred_full = self._stitch()
         else:
-            self.full.copy_(self.total_band)
-        total = self._stitch()
+            pred_full = self.pred[:self.nrow]
+        # Step 3 on the whole grid on every rank, Step 5's sum
+        ops.tps_band(packed, n, 0, self.nrow, self.tps)
+        ops.add(pred_full, self.tps, self.total)
         # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
-        f_actual = ops.gather(total, rows, cols)
+        f_actual = ops.gather(self.total, rows, cols)
         tss = float(np.sum((resp - resp.mean()) ** 2))
         rsq_model = 1.0 - float(np.sum(resid ** 2)) / tss
         rsq_final = 1.0 - float(np.sum((resp - f_actual) ** 2)) / tss
-        if rsq_final > rsq_model:
-            final = total
-        else:  # keep the ensemble alone: a second all-gather, of pred.elev
-            if self.world > 1:
-                self.dist.all_gather_into_tensor(self.full, self.pred)
-            else:
-                self.full.copy_(self.pred)
-            final = self._stitch()
+        final = self.total if rsq_final > rsq_model else pred_full   # V73:925-930
         return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": float(packed[3 * n + 7])}
 
 

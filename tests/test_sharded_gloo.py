@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the N>1 plumbing of ShardedMltps (row bands, coefficient
-broadcast, one all-gather, Step-5 selection on every rank) with the per-band arithmetic
-supplied by the numpy oracle.  The stitched grid must equal the single-process result."""
+broadcast, one asynchronous all-gather of the ensemble bands behind the fit, the spline evaluated
+on the whole grid by every rank, Step-5 selection on every rank) with the arithmetic supplied by
+the numpy oracle.  The grid must equal the single-process result."""
 import os
 import socket
 
@@ -114,7 +115,6 @@ def test_two_ranks_equal_one_rank(w, share):
         assert np.allclose(final, single["final"].numpy(), rtol=1e-12, atol=1e-12)
         assert abs(rsq_m - single["rsq_model"]) < 1e-10 and abs(rsq_f - single["rsq_final"]) < 1e-10
         assert lam == single["lambda"]
-    # w = 1: the TPS correction is kept (one all-gather).  w = 0.8 with wt.tot = 1: the reference does not
-    # renormalise the weights (V73:337,619), the sum is biased, R^2 drops and pred.elev alone is returned
-    # (second all-gather)
+    # w = 1: the TPS correction is kept.  w = 0.8 with wt.tot = 1: the reference does not renormalise the
+    # weights (V73:337,619), the sum is biased, R^2 drops and pred.elev alone is returned (already gathered)
     assert (single["rsq_final"] > single["rsq_model"]) == (w == 1.0)
