@@ -352,10 +352,11 @@ def main():
         # this size -- ceil(n/1500)^2 overlapping tiles with their own fits, mean mosaic, seam feathering (V73:656-895)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        info = {}
-        mhs.tps_residual_surface(wl.geom, knots, resid, cov1_at_stations=wl.ops.X[:, 0], tile_edge=1500, info=info)
+        mhs.tps_residual_surface(wl.geom, knots, resid, cov1_at_stations=wl.ops.X[:, 0], tile_edge=1500)
         torch.cuda.synchronize()
         tiled_ms = (time.perf_counter() - t1) * 1e3
+        nRx, nCx = mhs.tiles.step3_tile_windows(wl.geom, 1500)[:2]
+        info = {"nRx": int(nRx), "nCx": int(nCx)}
         m = wl.ops.X.shape[0] - 3
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",

@@ -26,17 +26,34 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 constexpr int LOG_TAB_BITS = 10;
 constexpr int LOG_TAB_N = 1 << LOG_TAB_BITS;
 
+// Everything one spline fit needs to run independently of another one: two streams (the panel
+// factorisations run ahead of the trailing update, tps_fit.hip), a pool of timing-disabled events and a
+// grow-only device arena its work buffers are carved from (no hipMalloc / hipFree -- a device-wide
+// synchronisation -- per fit).  mhs_tps_fit uses lane 0; mhs_tps_surface fits its tiles on several lanes
+// from host threads.
+struct FitLane {
+    hipStream_t s = nullptr, s2 = nullptr;
+    std::vector<hipEvent_t> pool;
+    char *arena = nullptr;
+    size_t arena_cap = 0;
+};
+
 struct Context {
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;        // the fit's panel factorisations run ahead on this one (tps_fit.hip)
-    std::vector<hipEvent_t> event_pool;   // timing-disabled events for the two-stream fit, reused across calls
+    hipStream_t stream = nullptr;         // = lanes[0]->s: the stream of the blocking host entry points
+    std::vector<FitLane *> lanes;         // lanes[0] is created by mhs_init, the others on demand (fit_lane)
     double2 *log_tab = nullptr;  // device, LOG_TAB_N entries
+    double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
+    size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 0;
 };
 Context &ctx();
+int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)
+// mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)
+int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
+                 int gcv_threads, mhs_tps **out);
 int require_ready();
 // _dev entry points launch on exactly the stream they are given; NULL is HIP's default
 // (null) stream, which is also torch's default stream.

@@ -28,6 +28,20 @@ Context &ctx() {
     return c;
 }
 
+int fit_lane(int i, FitLane **out) {
+    Context &c = ctx();
+    while ((int)c.lanes.size() <= i) {
+        FitLane *L = new FitLane();
+        int prio_lo = 0, prio_hi = 0;
+        MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MHS_HIP(hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi));
+        MHS_HIP(hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio_hi));
+        c.lanes.push_back(L);
+    }
+    *out = c.lanes[(size_t)i];
+    return MHS_OK;
+}
+
 int require_ready() {
     if (!ctx().ready) {
         set_error("mhs_init() has not been called (or failed): no gfx950 device selected");
@@ -87,13 +101,14 @@ int mhs_init(int device) {
         return MHS_ERR_NODEVICE;
     }
     c.n_cu = prop.multiProcessorCount;
-    // private stream for the host entry points (the fit's thousands of small dependent kernels): non-
+    // private streams for the host entry points (the fit's thousands of small dependent kernels): non-
     // blocking w.r.t. the default stream and high priority, so a fit can run beside long ensemble
     // kernels that a caller has enqueued on its own stream
-    int prio_lo = 0, prio_hi = 0;
-    MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    MHS_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_hi));
-    MHS_HIP(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, prio_hi));
+    {
+        FitLane *L0 = nullptr;
+        if (int rc = fit_lane(0, &L0)) return rc;
+        c.stream = L0->s;
+    }
     MHS_HIP(hipEventCreate(&c.ev0));
     MHS_HIP(hipEventCreate(&c.ev1));
     std::vector<double2> tab;
@@ -110,11 +125,16 @@ int mhs_shutdown(void) {
     if (!c.ready) return MHS_OK;
     (void)hipStreamSynchronize(c.stream);
     if (c.log_tab) (void)hipFree(c.log_tab);
+    if (c.surface_arena) (void)hipFree(c.surface_arena);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
-    for (hipEvent_t e : c.event_pool) (void)hipEventDestroy(e);
-    if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); }
-    if (c.stream) (void)hipStreamDestroy(c.stream);
+    for (FitLane *L : c.lanes) {
+        (void)hipStreamSynchronize(L->s); (void)hipStreamSynchronize(L->s2);
+        for (hipEvent_t e : L->pool) (void)hipEventDestroy(e);
+        if (L->arena) (void)hipFree(L->arena);
+        (void)hipStreamDestroy(L->s2); (void)hipStreamDestroy(L->s);
+        delete L;
+    }
     c = Context();
     return MHS_OK;
 }

@@ -772,9 +772,8 @@ __global__ __launch_bounds__(1024) void potrs_kernel(const double *__restrict__ 
     }
 }
 
-static int cholesky_solve(double *A, int64_t ld, int off, int m, double *x_dev, hipStream_t s) {
-    DevBuf<int> info;
-    MHS_HIP(info.alloc(1));
+static int cholesky_solve(double *A, int64_t ld, int off, int m, double *x_dev, int *info_dev, hipStream_t s) {
+    struct { int *p; } info = {info_dev};
     MHS_HIP(hipMemsetAsync(info.p, 0, sizeof(int), s));
     for (int j = 0; j < m; j += NB) {
         const int nb = std::min(NB, m - j);
@@ -829,9 +828,22 @@ static void collapse_replicates(const double *xy, const double *y, int64_t N, st
 
 using namespace mhs;
 
-extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
-                           mhs_tps **out) {
-    if (int rc = require_ready()) return rc;
+// carves the work buffers of one fit out of the lane's arena (256-byte aligned); a dry run sizes it
+struct ArenaCarver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+namespace mhs {
+int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
+                 int gcv_threads, mhs_tps **out) {
     MHS_REQUIRE(xy && y && out, "NULL argument");
     MHS_REQUIRE(N > 3 && N < (1LL << 30), "need more than 3 observations");
     MHS_REQUIRE(std::isnan(lambda) || lambda >= 0, "lambda must be >= 0 or NaN");
@@ -874,7 +886,7 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
     for (int64_t i = 0; i < n; ++i) wv[i] = sw[i] * ym[i];
     for (int k = 0; k < 3; ++k) apply_reflector(hv[k], htau[k], wv.data(), n);
 
-    hipStream_t s = ctx().stream;
+    hipStream_t s = L.s;
     const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -886,16 +898,43 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         t_last = now;
     };
     const int64_t ld = (n + 15) & ~(int64_t)15;
-    DevBuf<double> A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, offd;
-    MHS_HIP(A.alloc((size_t)(ld * n)));
-    MHS_HIP(duv.alloc((size_t)(2 * n)));
-    MHS_HIP(dsw.alloc((size_t)n));
-    MHS_HIP(vbuf.alloc((size_t)n));
-    MHS_HIP(pbuf.alloc((size_t)n));
-    MHS_HIP(wbuf.alloc((size_t)n));
-    MHS_HIP(gbuf.alloc((size_t)n));
-    MHS_HIP(tau.alloc((size_t)n + 3));
-    MHS_HIP(offd.alloc((size_t)n));
+    const int64_t vs = n;
+    const int max_cg = (m + SYMM_COLS - 1) / SYMM_COLS;
+    int npanels = 0;
+    for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
+    struct P { double *p; };
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Yp, Mp, Sm, Tall, abd;
+    int *info_dev = nullptr;
+    auto layout = [&](ArenaCarver &ar) {
+        A.p = ar.take<double>((size_t)(ld * n));
+        duv.p = ar.take<double>((size_t)(2 * n));
+        dsw.p = ar.take<double>((size_t)n);
+        vbuf.p = ar.take<double>((size_t)n);
+        pbuf.p = ar.take<double>((size_t)n);
+        wbuf.p = ar.take<double>((size_t)n);
+        gbuf.p = ar.take<double>((size_t)n);
+        tau.p = ar.take<double>((size_t)n + 3);
+        Vd.p = ar.take<double>((size_t)BW * vs);
+        Vd2.p = ar.take<double>((size_t)BW * vs);
+        Yp.p = ar.take<double>((size_t)SYMM_SPLITS * BW * vs);
+        Mp.p = ar.take<double>((size_t)std::max(max_cg, 1) * SYMM_SPLITS * BW * BW);
+        Sm.p = ar.take<double>((size_t)BW * BW);
+        Tall.p = ar.take<double>((size_t)std::max(npanels, 1) * BW * BW);
+        abd.p = ar.take<double>((size_t)m * (BW + 1));
+        info_dev = ar.take<int>(1);
+    };
+    {
+        ArenaCarver dry{nullptr};
+        layout(dry);
+        if (dry.off > L.arena_cap) {   // grow-only; growing synchronises the device, a lane's first fits only
+            if (L.arena) { (void)hipStreamSynchronize(L.s); (void)hipStreamSynchronize(L.s2); (void)hipFree(L.arena); L.arena = nullptr; L.arena_cap = 0; }
+            const size_t cap = dry.off + dry.off / 8;
+            MHS_HIP(hipMalloc((void **)&L.arena, cap));
+            L.arena_cap = cap;
+        }
+        ArenaCarver real{L.arena};
+        layout(real);
+    }
     MHS_HIP(hipMemcpyAsync(duv.p, uv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(dsw.p, sw.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
 
@@ -927,37 +966,25 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         // fixed lambda: Cholesky of B + lambda I, solve for c2 = (B + lambda I)^-1 w2
         hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, s, A.p, ld, 3, m, lam);
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
-        if (int rc = cholesky_solve(A.p, ld, 3, m, gbuf.p, s)) return rc;
+        if (int rc = cholesky_solve(A.p, ld, 3, m, gbuf.p, info_dev, s)) return rc;
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
     } else {
         // reduce B to bandwidth BW in place (blocked), rotating g = Q' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
-        const int64_t vs = n;
-        DevBuf<double> Vd, Yp, Mp, Sm, Tall, abd;
-        MHS_HIP(Vd.alloc((size_t)BW * vs)); MHS_HIP(Yp.alloc((size_t)SYMM_SPLITS * BW * vs));
-        const int max_cg = (m + SYMM_COLS - 1) / SYMM_COLS;
-        MHS_HIP(Mp.alloc((size_t)max_cg * SYMM_SPLITS * BW * BW));
-        MHS_HIP(Sm.alloc((size_t)BW * BW));
-        int npanels = 0;
-        for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
-        MHS_HIP(Tall.alloc((size_t)std::max(npanels, 1) * BW * BW));
-        MHS_HIP(abd.alloc((size_t)m * (BW + 1)));
         // Two streams: the panel factorisation of step p+1 needs only the first column block of the trailing
         // matrix as updated by step p.  That block is updated first, on the main stream, which goes straight on
         // to the (single-block, latency-bound) panel kernel of step p+1, while the rest of step p's update runs
         // on stream2 behind an event.  The panel block needs a whole CU's registers: it must reach the
         // dispatcher before the flood of update blocks, which the event's latency ensures.  Per step the
         // critical path is panel + symm + s + one column block instead of panel + symm + s + the whole update.
-        hipStream_t s2 = ctx().stream2;
-        std::vector<hipEvent_t> &pool = ctx().event_pool;
+        hipStream_t s2 = L.s2;
+        std::vector<hipEvent_t> &pool = L.pool;
         while ((int)pool.size() < 2 * npanels) {
             hipEvent_t e;
             MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             pool.push_back(e);
         }
-        DevBuf<double> Vd2;
-        MHS_HIP(Vd2.alloc((size_t)BW * vs));
         for (int p = 0; p < npanels; ++p) {
             const int c = p * BW, t = m - c - BW, c0 = 3 + c, r0 = 3 + c + BW;
             double *Tp = Tall.p + (size_t)p * BW * BW;
@@ -988,7 +1015,7 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
         MHS_HIP(hipStreamSynchronize(s));
         lap("band reduction (GPU)");
         BandGcv bg;
-        bg.ab = ab.data(); bg.g = g.data(); bg.m = m; bg.n = n; bg.N = N; bg.bw = BW; bg.pure_ss = pure_ss;
+        bg.ab = ab.data(); bg.g = g.data(); bg.m = m; bg.n = n; bg.N = N; bg.bw = BW; bg.pure_ss = pure_ss; bg.threads = gcv_threads;
         lam = bg.find_lambda(gcv_mode);
         if (std::isnan(lam)) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
         lap("GCV search (host, banded)");
@@ -1030,4 +1057,13 @@ extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double 
     if (int rc = upload_knots(t)) { mhs_tps_free(t); return rc; }
     *out = t;
     return MHS_OK;
+}
+}  // namespace mhs
+
+extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
+                           mhs_tps **out) {
+    if (int rc = require_ready()) return rc;
+    FitLane *L = nullptr;
+    if (int rc = fit_lane(0, &L)) return rc;
+    return tps_fit_lane(*L, xy, y, N, lambda, gcv_mode, 0, out);
 }

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -277,6 +278,7 @@ private:
 };
 int pick_threads(int requested) {
     if (requested > 0) return requested;
+    if (const char *e = getenv("MHS_GCV_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
     const unsigned hc = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(16u, hc ? hc : 1u));
 }

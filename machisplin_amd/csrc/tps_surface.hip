@@ -3,11 +3,20 @@
 // seam feathering, overlay.  This is the entry point a .Call() shim binds so that the R
 // side replaces the whole block by a single call; the Python mirror composes the same
 // steps from the finer-grained entry points (machisplin_amd/mltps.py).
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include "common.h"
 
 using namespace mhs;
+
+constexpr int64_t TILE_LANES = 8;   // tiles fitted side by side (mhs_tps_surface)
 
 extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
                                    const double *cov1_at_stations, int64_t tile_edge, double lambda,
@@ -32,42 +41,113 @@ extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const do
     std::vector<int64_t> fit((size_t)nt * 4), keep((size_t)nt * 4), rows((size_t)n), cols((size_t)n);
     if (int rc = mhs_step3_tile_windows(g, tile_edge, 0.2, 0.025, &nRx, &nCx, fit.data(), keep.data(), nt)) return rc;
     if (int rc = mhs_cells_from_xy(g, xy, n, rows.data(), cols.data())) return rc;
-    std::vector<DevBuf<double>> bufs((size_t)nt);
+    const bool timing = getenv("MHS_SURFACE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mhs_tps_surface] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    // the tiles' keep windows (~1.1 x the grid in total) live in one grow-only scratch buffer of the library
+    struct TileBuf { double *p; };
+    std::vector<TileBuf> bufs((size_t)nt);
     std::vector<const double *> ptrs((size_t)nt);
-    std::vector<double> sx, sy, sr;
-    int rc = MHS_OK;
-    for (int64_t h = 0; h < nt && !rc; ++h) {
-        const int64_t *f = &fit[(size_t)h * 4], *k = &keep[(size_t)h * 4];
-        const int64_t kr = k[1] - k[0], kc = k[3] - k[2];
-        if (hipError_t e = bufs[h].alloc((size_t)(kr * kc)); e != hipSuccess) return hip_fail(e, "alloc tile", __FILE__, __LINE__);
-        ptrs[h] = bufs[h].p;
-        sx.clear(); sy.clear(); sr.clear();
-        for (int64_t i = 0; i < n; ++i) {  // terra::extract(rb[[1]], Full.cords) + complete.cases (V73:701-706)
-            if (rows[i] < f[0] || rows[i] >= f[1] || cols[i] < f[2] || cols[i] >= f[3]) continue;
-            if (cov1_at_stations && std::isnan(cov1_at_stations[i])) continue;
-            if (std::isnan(resid[i])) continue;
-            sx.push_back(xy[i]); sy.push_back(xy[n + i]); sr.push_back(resid[i]);
+    {
+        size_t total = 0;
+        for (int64_t h = 0; h < nt; ++h) {
+            const int64_t *k = &keep[(size_t)h * 4];
+            total += ((size_t)((k[1] - k[0]) * (k[3] - k[2])) + 31) & ~(size_t)31;
         }
-        const int64_t m = (int64_t)sr.size();
-        if (m < 10) {  // V73:710-721: the tile is all zeros
-            if (hipMemsetAsync(bufs[h].p, 0, sizeof(double) * (size_t)(kr * kc), s) != hipSuccess) return MHS_ERR_HIP;
-            continue;
+        Context &c = ctx();
+        if (total > c.surface_arena_cap) {
+            if (c.surface_arena) { (void)hipDeviceSynchronize(); (void)hipFree(c.surface_arena); c.surface_arena = nullptr; c.surface_arena_cap = 0; }
+            MHS_HIP(hipMalloc((void **)&c.surface_arena, total * sizeof(double)));
+            c.surface_arena_cap = total;
         }
-        std::vector<double> txy((size_t)2 * m);
-        for (int64_t i = 0; i < m; ++i) { txy[i] = sx[i]; txy[m + i] = sy[i]; }
-        mhs_tps *t = nullptr;
-        rc = mhs_tps_fit(txy.data(), sr.data(), m, lambda, gcv_mode, &t);
-        if (rc) break;
-        // terra::interpolate(terra::rast(rb), tps): cell centres of the FIT raster (V73:726)
-        mhs_grid gf = *g;
-        gf.xmin = g->xmin + (double)f[2] * g->xres;
-        gf.ymax = g->ymax - (double)f[0] * g->yres;
-        gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
-        rc = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], bufs[h].p, kc, s);
-        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = MHS_ERR_HIP;  // knots are freed with the handle
-        mhs_tps_free(t);
+        size_t off = 0;
+        for (int64_t h = 0; h < nt; ++h) {
+            const int64_t *k = &keep[(size_t)h * 4];
+            bufs[h].p = c.surface_arena + off;
+            ptrs[h] = bufs[h].p;
+            off += ((size_t)((k[1] - k[0]) * (k[3] - k[2])) + 31) & ~(size_t)31;
+        }
     }
-    if (rc) return rc;
+    // The tiles' fits are chains of small, latency-bound kernels: several of them run side by side, each on
+    // its own lane (two streams + work arena) driven by its own host thread.
+    int64_t want_lanes = TILE_LANES;
+    if (const char *e = getenv("MHS_TILE_LANES")) { const int v = atoi(e); if (v > 0 && v <= 64) want_lanes = v; }
+    const int nlanes = (int)std::min<int64_t>(nt, want_lanes);
+    std::vector<FitLane *> lanes((size_t)nlanes);
+    for (int l = 0; l < nlanes; ++l)
+        if (int rc = fit_lane(1 + l, &lanes[(size_t)l])) return rc;
+    lap("windows + tile buffers");
+    std::vector<mhs_tps *> handles((size_t)nt, nullptr);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> first_rc{MHS_OK};
+    std::mutex err_mu;
+    std::string err_msg;
+    auto worker = [&](int lane_id) {
+        FitLane &L = *lanes[(size_t)lane_id];
+        (void)hipSetDevice(ctx().device);   // the current device is per host thread
+        std::vector<double> sx, sy, sr, txy;
+        for (;;) {
+            const int64_t h = next.fetch_add(1);
+            if (h >= nt || first_rc.load() != MHS_OK) break;
+            const int64_t *f = &fit[(size_t)h * 4], *k = &keep[(size_t)h * 4];
+            const int64_t kr = k[1] - k[0], kc = k[3] - k[2];
+            sx.clear(); sy.clear(); sr.clear();
+            for (int64_t i = 0; i < n; ++i) {  // terra::extract(rb[[1]], Full.cords) + complete.cases (V73:701-706)
+                if (rows[i] < f[0] || rows[i] >= f[1] || cols[i] < f[2] || cols[i] >= f[3]) continue;
+                if (cov1_at_stations && std::isnan(cov1_at_stations[i])) continue;
+                if (std::isnan(resid[i])) continue;
+                sx.push_back(xy[i]); sy.push_back(xy[n + i]); sr.push_back(resid[i]);
+            }
+            const int64_t m = (int64_t)sr.size();
+            int rc = MHS_OK;
+            if (m < 10) {  // V73:710-721: the tile is all zeros
+                if (hipMemsetAsync(bufs[h].p, 0, sizeof(double) * (size_t)(kr * kc), L.s) != hipSuccess) rc = MHS_ERR_HIP;
+            } else {
+                txy.resize((size_t)2 * m);
+                for (int64_t i = 0; i < m; ++i) { txy[i] = sx[i]; txy[m + i] = sy[i]; }
+                mhs_tps *t = nullptr;
+                rc = tps_fit_lane(L, txy.data(), sr.data(), m, lambda, gcv_mode, m < 1500 ? 2 : 0, &t);
+                if (!rc) {
+                    handles[(size_t)h] = t;   // freed after the last tile: hipFree synchronises the device
+                    // terra::interpolate(terra::rast(rb), tps): cell centres of the FIT raster (V73:726)
+                    mhs_grid gf = *g;
+                    gf.xmin = g->xmin + (double)f[2] * g->xres;
+                    gf.ymax = g->ymax - (double)f[0] * g->yres;
+                    gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
+                    rc = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], bufs[h].p, kc, L.s);
+                }
+            }
+            if (rc) {
+                int expected = MHS_OK;
+                if (first_rc.compare_exchange_strong(expected, rc)) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    err_msg = mhs_last_error();   // thread-local in the worker: carry it to the caller
+                }
+                break;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int l = 1; l < nlanes; ++l) threads.emplace_back(worker, l);
+        worker(0);
+        for (std::thread &th : threads) th.join();
+    }
+    int rc = first_rc.load();
+    for (FitLane *L : lanes)
+        if (hipStreamSynchronize(L->s) != hipSuccess && !rc) rc = MHS_ERR_HIP;
+    lap("tile fits + evaluation");
+    for (mhs_tps *t : handles) mhs_tps_free(t);
+    if (rc) { if (!err_msg.empty()) set_error("%s", err_msg.c_str()); return rc; }
+    lap("free handles");
+    rc = mhs_mosaic_feather_dev(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s);
+    if (timing) { (void)hipStreamSynchronize(s); lap("mosaic + feather"); }
+    return rc;
     return mhs_mosaic_feather_dev(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s);
 }
 

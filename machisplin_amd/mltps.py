@@ -52,6 +52,27 @@ def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None,
     dev = torch.device("cuda", _lib.init())
     knots_xy = np.asarray(knots_xy, dtype=np.float64)
     resid = np.asarray(resid, dtype=np.float64)
+    if info is None:
+        # one call into the library (what the R shim binds): the tiles' fits run side by side on several lanes.
+        # With `info` the same steps are composed here, tile by tile, and the per-tile station counts and
+        # lambdas are reported (bit-identical result, tests/test_tiles_gpu.py).
+        import ctypes as C
+        if out is None:
+            out = torch.empty((geom.nrow, geom.ncol), dtype=torch.float64, device=dev)
+        if out.dtype != torch.float64 or not out.is_cuda or out.dim() != 2 or out.stride(1) != 1:
+            raise ValueError("out must be a 2-D float64 device tensor with unit column stride")
+        g = geom.c_struct()
+        xyf = np.asfortranarray(knots_xy)
+        cov = None if cov1_at_stations is None else np.ascontiguousarray(cov1_at_stations, dtype=np.float64)
+        nt = (C.c_int64 * 2)()
+        mode = {"fields": _lib.GCV_FIELDS, "converged": _lib.GCV_CONVERGED}[gcv_mode]
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().mhs_tps_surface_dev(C.byref(g), xyf.ctypes.data, resid.ctypes.data, resid.shape[0],
+                                                  None if cov is None else cov.ctypes.data,
+                                                  0 if tile_edge is None else int(tile_edge),
+                                                  float("nan") if lambda_ is None else float(lambda_), mode,
+                                                  out.data_ptr(), out.stride(0), nt, st))
+        return out
     if tile_edge is None:
         nRx = nCx = 1
     else:

@@ -183,7 +183,11 @@ def test_one_call_surface_equals_composed_steps(hip):
     resid = synth.tps_residual(uv, 77)
     cov1 = np.ones(500)
     cov1[::37] = np.nan  # stations on NA covariate cells are dropped (V73:701-706)
-    want = hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=100).cpu().numpy()
+    info = {}   # with `info` the Python mirror composes the steps itself, tile by tile
+    want = hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=100, info=info).cpu().numpy()
+    assert (info["nRx"], info["nCx"]) == (3, 4) and len(info["tile_n"]) == 12
+    # without it, the mirror makes the one library call (device output)
+    assert np.array_equal(hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=100).cpu().numpy(), want)
     out = np.empty((230, 310))
     nt = np.zeros(2, dtype=np.int64)
     gs = g.c_struct()
@@ -196,7 +200,7 @@ def test_one_call_surface_equals_composed_steps(hip):
     _lib.check(_lib.lib().mhs_tps_surface(C.byref(gs), xyf.ctypes.data, resid.ctypes.data, 500, None, 0,
                                           float("nan"), 0, out.ctypes.data, nt.ctypes.data))
     assert list(nt) == [1, 1]
-    assert np.array_equal(out, hip.tps_residual_surface(g, xy, resid, tile_edge=None).cpu().numpy())
+    assert np.array_equal(out, hip.tps_residual_surface(g, xy, resid, tile_edge=None, info={}).cpu().numpy())
 
 
 def test_cfg4_chain_tiles_create_per_tile_mltps_tiles_merge(hip):
