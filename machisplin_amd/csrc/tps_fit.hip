@@ -252,7 +252,7 @@ struct PanelShared {
     double Gs[BW][BW];   // Gs[l][j] = v_l' v_j (l < j)
     double sgs[BW], taus[BW], zs[BW];
     double Ts[BW * BW];
-    double piv;
+    double piv, cn0[BW], rmat[BW][BW];   // pivot, initial column norms^2, R entries above the diagonal
 };
 
 // The BW Householder steps of the register-resident panel as ONE loop body: the columns are kept
@@ -266,17 +266,41 @@ struct PanelShared {
 // of the panel hold zeros and stay zero.
 __device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared &sh) {
     const int i0 = threadIdx.x;     // the row held in x[0][.]
+    // Column norms are computed once and DOWNDATED (LAPACK's dlaqps idea): below row J the squared norm of
+    // column J is its initial value minus the squares of its entries in rows 0..J-1 (R entries, published by the
+    // rows' owners together with the next pivot) -- one barrier instead of a block reduction per step.  When the
+    // difference cancels (below 1 % of the initial norm) the norm is summed afresh.  Everything stays in LDS:
+    // per-thread copies would cost 32 VGPRs the panel needs.
+    {
+        double part[BW];
+#pragma unroll
+        for (int p = 0; p < BW; ++p) {
+            part[p] = 0.0;
+#pragma unroll
+            for (int r = 0; r < PANEL_RPT; ++r) part[p] = fma(x[r][p], x[r][p], part[p]);
+        }
+        block_sum_vec<BW>(part, sh.lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int p = 0; p < BW; ++p) sh.cn0[p] = part[p];
+        }
+    }
+    if (i0 == 0) sh.piv = x[0][0];
+    __syncthreads();
 #pragma unroll 1
     for (int J = 0; J < BW; ++J) {
         if (J < nref) {
-            double part[1] = {0.0};
-            if (i0 > J) part[0] = x[0][0] * x[0][0];
-            if (i0 == J) sh.piv = x[0][0];
+            const double alpha = sh.piv, c0 = sh.cn0[J];
+            double ss = c0 - alpha * alpha;
+            for (int sr = 0; sr < J; ++sr) { const double rj = sh.rmat[sr][J]; ss -= rj * rj; }
+            if (!(ss > 0.01 * c0)) {   // uniform: every thread reads the same values
+                double part[1] = {0.0};
+                if (i0 > J) part[0] = x[0][0] * x[0][0];
 #pragma unroll
-            for (int r = 1; r < PANEL_RPT; ++r) part[0] = fma(x[r][0], x[r][0], part[0]);
-            block_sum_vec<1>(part, sh.lds);  // its barriers also publish piv
-            const double ss = part[0], alpha = sh.piv;
-            __syncthreads();                 // everyone has read piv before the next column's owner rewrites it
+                for (int r = 1; r < PANEL_RPT; ++r) part[0] = fma(x[r][0], x[r][0], part[0]);
+                block_sum_vec<1>(part, sh.lds);
+                ss = part[0];
+            }
             double beta = alpha, tau = 0.0, scal = 0.0;
             if (ss != 0.0) {
                 beta = -copysign(sqrt(alpha * alpha + ss), alpha);
@@ -315,6 +339,14 @@ __device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref
 #pragma unroll
                 for (int p = 1; p < BW; ++p) x[r][p] -= red[p - 1] * x[r][0];   // x[r][0] now holds v
             }
+            // row J of the updated columns (their R entries) and the next pivot, for the downdate
+            if (i0 == J) {
+#pragma unroll
+                for (int p = 1; p < BW; ++p)
+                    if (J + p < BW) sh.rmat[J][J + p] = x[0][p];
+            }
+            if (i0 == J + 1) sh.piv = x[0][1];
+            __syncthreads();
         } else if (threadIdx.x == 0) {   // uniform: nothing left to annihilate; H_J = I
             sh.taus[J] = 0.0;
             for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0;
@@ -415,8 +447,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
 }
 
 // Y = A22 V as split-K partial sums: block (cg, sp) owns 32 columns (8 per wave) and one of
-// SYMM_SPLITS row ranges; lanes run over rows, the V rows of the range are staged in LDS in
-// chunks of 64.  Ypart[sp][j][i] partial sums are added up by the consumers; the block also
+// SYMM_SPLITS row ranges; lanes run over rows (barrier-free loop, 16 loads per lane and 64 rows in
+// flight).  Ypart[sp][j][i] partial sums are added up by the consumers; the block also
 // emits its share of M = V'Y (64 values) so that S = T'(V'Y)T needs no second pass over Y.
 constexpr int SYMM_SPLITS = 4;
 constexpr int SYMM_COLS = 32;
@@ -424,7 +456,6 @@ constexpr int SYMM_COLS = 32;
 __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict__ A, int64_t ld, int r0, int t,
                                                         const double *__restrict__ Vd, int64_t vs,
                                                         double *__restrict__ Ypart, double *__restrict__ Mpart) {
-    __shared__ double Vs[BW][64];
     __shared__ double Ms[4][BW * BW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col0 = blockIdx.x * SYMM_COLS + wave * 8;
@@ -436,24 +467,36 @@ __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict
 #pragma unroll
         for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
     const double *a0 = A + (int64_t)r0 * ld + r0;
-    for (int rb = rbeg; rb < rend; rb += 64) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < BW * 64; e += 256) {
-            const int j = e >> 6, r = rb + (e & 63);
-            Vs[j][e & 63] = r < rend ? Vd[j * vs + r] : 0.0;
-        }
-        __syncthreads();
-        const int r = rb + lane;
-        double a[8];
+    // lane = row: the lane's V row comes straight from global memory (V is t x 8, L2-resident), so the loop has
+    // no barrier and the loads of the next 64 rows are in flight while these are multiplied.  Rows and columns
+    // past the end are read at a clamped index and multiplied by zero.
+    const int ncol_ok = min(8, t - col0);   // <= 0: this wave has no column
+    const double *ac[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = (r < rend && col0 + c < t) ? a0[(int64_t)(col0 + c) * ld + r] : 0.0;
+    for (int c = 0; c < 8; ++c) ac[c] = a0 + (int64_t)(col0 + (c < ncol_ok ? c : 0)) * ld;
+    if (ncol_ok > 0) {
+#pragma unroll 2
+        for (int rb = rbeg; rb < rend; rb += 64) {
+            const int r = rb + lane;
+            const unsigned rr = (unsigned)min(r, rend - 1);
+            const double keep = r < rend ? 1.0 : 0.0;
+            double a[8], v[BW];
 #pragma unroll
-        for (int j = 0; j < BW; ++j) {
-            const double v = Vs[j][lane];
+            for (int c = 0; c < 8; ++c) a[c] = ac[c][rr];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c][j] = fma(a[c], v, acc[c][j]);
+            for (int j = 0; j < BW; ++j) v[j] = Vd[(int64_t)j * vs + rr] * keep;
+#pragma unroll
+            for (int j = 0; j < BW; ++j)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c][j] = fma(a[c], v[j], acc[c][j]);
         }
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c >= ncol_ok) {
+#pragma unroll
+            for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
+        }
     // wave-reduce; lane j keeps column sums y[c] for V-column j, then M += V[:,col]' (x) y
     double *yp = Ypart + (int64_t)blockIdx.y * BW * vs;
     double mpart[BW];  // lane l < 64: M[a = l & 7][b = l >> 3] contribution of this wave
