@@ -187,37 +187,40 @@ __global__ __launch_bounds__(256) void earth_kernel(const double *__restrict__ c
 }
 
 // ------------------------------------------------------------------------ svr --
-// exp(x) for x <= ~0: x = (64 e + j) ln2/64 + r, |r| <= ln2/128; 2^(j/64) from LDS.
-constexpr int EXP_TAB_N = 64;
-__device__ __forceinline__ double table_exp(double x, const double *tab) {
-    x = fmax(x, -700.0);
-    // k = round(x 64/ln2) by the 1.5*2^52 trick: the integer lands in the low word of t (no
-    // v_rndne / v_cvt), kd = t - magic is its exact double
+// exp(x) for x <= ~0 with the argument already in units of ln2/4096 (y = x 4096/ln2; the factor is folded
+// into the per-support-vector coefficients): y = 4096 e + j + r, |r| <= 1/2; 2^(j/4096) from a 32 KB LDS
+// table, exp(r ln2/4096) = 1 + c r + c^2 r^2 / 2 (truncation < 1e-13 relative).  10 FP64-rate and 4 integer
+// instructions against 16 for a 64-entry table with a quartic.
+constexpr int EXP_TAB_BITS = 12;
+constexpr int EXP_TAB_N = 1 << EXP_TAB_BITS;
+constexpr double EXP_SCALE = 4096.0 / 0.6931471805599453094;   // 4096 / ln 2
+__device__ __forceinline__ double table_exp_scaled(double y, const double *tab) {
+    y = fmax(y, -700.0 * EXP_SCALE);
+    // k = round(y) by the 1.5*2^52 trick: the integer lands in the low word of t (no v_rndne / v_cvt),
+    // kd = t - magic is its exact double
     const double MAGIC = 0x1.8p52;
-    const double t = fma(x, 0x1.71547652b82fep+6, MAGIC);  // 64/ln2
+    const double t = y + MAGIC;
     const double kd = t - MAGIC;
     const int k = __double2loint(t);
-    double r = fma(kd, -0x1.62e42fefa0000p-7, x);    // ln2/64, high part (17 trailing zero bits)
-    r = fma(kd, -0x1.cf79abc9e3b3ap-46, r);           // ln2/64, low part
+    const double r = y - kd;
     const double sj = tab[k & (EXP_TAB_N - 1)];
-    // exp(r) = 1 + r(1 + r(1/2 + r(1/6 + r/24))), |r| <= ln2/128: truncation r^5/120 < 4e-14 relative
-    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-    q = fma(q, r, 0.5);
-    q = fma(q, r, 1.0);
+    const double C1 = 1.0 / EXP_SCALE, C2 = 0.5 / (EXP_SCALE * EXP_SCALE);
+    double q = fma(r, C2, C1);
     q = fma(q, r, 1.0);
     const double v = sj * q;
-    const int hi = __double2hiint(v) + ((k >> 6) << 20);
+    const int hi = __double2hiint(v) + ((k >> EXP_TAB_BITS) << 20);
     return __hiloint2double(hi, __double2loint(v));
 }
 
-// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = 2 sigma sv_k, a = -sigma |sv|^2
+// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = 2 sigma sv_k, a = -sigma |sv|^2, both times 4096/ln2
 template <int P, int R>
 __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp, int nsv, int stride,
-                                                  const double *__restrict__ xcs, double sigma, double b,
+                                                  const double *__restrict__ xcs, const double *__restrict__ gtab,
+                                                  double sigma, double b,
                                                   double y_center, double y_scale, StackDev s, PredGeom g,
                                                   double weight, int accumulate, double *__restrict__ out) {
     __shared__ double etab[EXP_TAB_N];
-    if (threadIdx.x < EXP_TAB_N) etab[threadIdx.x] = exp2((double)threadIdx.x / EXP_TAB_N);
+    for (int i = threadIdx.x; i < EXP_TAB_N; i += 256) etab[i] = gtab[i];
     __syncthreads();
     const int64_t total = (int64_t)g.nr * g.nc;
     const int64_t half = (total + R - 1) / R;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             x[c][j] = (xv - xcs[j]) / xcs[P + j];
             q[c] = fma(x[c][j], x[c][j], q[c]);
         }
-        q[c] = -sigma * q[c];
+        q[c] = (-sigma * EXP_SCALE) * q[c];
     }
     for (int v = 0; v < nsv; ++v) {
         const double *sp = svp + (int64_t)v * stride;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             double arg = q[c] + sp[P];
 #pragma unroll
             for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
-            acc[c] = fma(sp[P + 1], table_exp(arg, etab), acc[c]);
+            acc[c] = fma(sp[P + 1], table_exp_scaled(arg, etab), acc[c]);
         }
     }
 #pragma unroll
@@ -814,7 +817,7 @@ static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g,
     constexpr int R = 2;
     const int64_t half = (total + R - 1) / R;
     hipLaunchKernelGGL((svr_kernel<P, R>), dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st,
-                       m->dpar, m->n0, m->n1, m->dpar + (size_t)m->n0 * m->n1, m->s1, m->s0, m->s2, m->s3,
+                       m->dpar, m->n0, m->n1, m->dpar + (size_t)m->n0 * m->n1, ctx().exp_tab, m->s1, m->s0, m->s2, m->s3,
                        s, g, w, acc, out);
 }
 
@@ -1242,10 +1245,10 @@ int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, doub
         double ss = 0.0;
         for (int j = 0; j < p; ++j) {
             const double x = sv[(size_t)v * p + j];
-            h[(size_t)v * stride + j] = 2.0 * sigma * x;
+            h[(size_t)v * stride + j] = 2.0 * sigma * x * EXP_SCALE;
             ss += x * x;
         }
-        h[(size_t)v * stride + p] = -sigma * ss;
+        h[(size_t)v * stride + p] = -sigma * ss * EXP_SCALE;
         h[(size_t)v * stride + p + 1] = alpha[v];
     }
     for (int j = 0; j < p; ++j) { h[(size_t)nsv * stride + j] = x_center[j]; h[(size_t)nsv * stride + p + j] = x_scale[j]; }

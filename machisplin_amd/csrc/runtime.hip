@@ -115,6 +115,12 @@ int mhs_init(int device) {
     build_log_table(tab);
     MHS_HIP(hipMalloc((void **)&c.log_tab, sizeof(double2) * LOG_TAB_N));
     MHS_HIP(hipMemcpy(c.log_tab, tab.data(), sizeof(double2) * LOG_TAB_N, hipMemcpyHostToDevice));
+    {   // 2^(j/4096), correctly rounded by the host libm (svr_kernel's exp)
+        std::vector<double> et(4096);
+        for (int j = 0; j < 4096; ++j) et[(size_t)j] = (double)exp2l((long double)j / 4096.0L);
+        MHS_HIP(hipMalloc((void **)&c.exp_tab, sizeof(double) * et.size()));
+        MHS_HIP(hipMemcpy(c.exp_tab, et.data(), sizeof(double) * et.size(), hipMemcpyHostToDevice));
+    }
     c.device = device;
     c.ready = true;
     return MHS_OK;
@@ -126,6 +132,7 @@ int mhs_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
+    if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     for (FitLane *L : c.lanes) {
