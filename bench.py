@@ -384,7 +384,7 @@ def main():
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
             res["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:
