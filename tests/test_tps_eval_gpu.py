@@ -94,6 +94,57 @@ def test_far_field_path_equals_direct_sum(hip, n, nrow, ncol, xres, yres, window
     assert np.abs(auto - want).max() / scale < RTOL
 
 
+def test_eval_mode_and_plan_reporting(hip):
+    """mhs_tps_eval_mode / mhs_tps_eval_plan: small windows and few knots take the direct sum whatever the mode,
+    the plan reports what the last evaluation did, bad modes are refused."""
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 512, 512)
+    xy, y = synth_stations(400, 21, g)
+    m = otps.fit(xy, y, lam=1e-3)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    try:
+        hip.eval_mode(hip.EVAL_FAR_FIELD)
+        hip.interpolate(g, t)
+        tc, tr, node_pairs, cell_pairs = t.eval_plan()
+        assert tc >= 64 and tc % 64 == 0 and tr >= 16 and tr % 16 == 0
+        ntiles = -(-512 // tc) * -(-512 // tr)
+        assert 0 < node_pairs <= ntiles * 256 * 400 and 0 < cell_pairs < 512 * 512 * 400
+        hip.interpolate(g, t, window=(0, 512, 0, 40))          # narrower than one tile column block: direct
+        assert t.eval_plan() == (0, 0, 0, 0)
+        hip.eval_mode(hip.EVAL_DIRECT)
+        hip.interpolate(g, t)
+        assert t.eval_plan() == (0, 0, 0, 0)
+        few = hip.Tps.from_coef(m["knots"][:20], m["c"][:20], m["d"], m["lambda"], m["center"], m["scale"])
+        hip.eval_mode(hip.EVAL_FAR_FIELD)
+        hip.interpolate(g, few)
+        assert few.eval_plan() == (0, 0, 0, 0)                 # 20 knots: not worth tiling
+        with pytest.raises(hip.MhsError):
+            hip.eval_mode(7)
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+
+
+def test_far_field_with_every_knot_outside_the_window(hip):
+    """A band far from the stations: every knot sits in the rim bins, the whole sum is interpolated."""
+    g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 1200, 400)
+    rng = np.random.default_rng(8)
+    rows, cols = rng.integers(0, 150, 300), rng.integers(0, 400, 300)          # stations in the top 150 rows only
+    cells = np.unique(rows * 400 + cols)
+    rows, cols = np.divmod(cells, 400)
+    xy = np.column_stack([g.x_from_col(cols), g.y_from_row(rows)])
+    y = np.sin(0.01 * cols) + 0.1 * rng.standard_normal(cells.size)
+    m = otps.fit(xy, y, lam=1e-2)
+    t = hip.Tps.from_coef(m["knots"], m["c"], m["d"], m["lambda"], m["center"], m["scale"])
+    win = (900, 1200, 0, 400)
+    try:
+        hip.eval_mode(hip.EVAL_FAR_FIELD)
+        far = hip.interpolate(g, t, window=win).cpu().numpy()
+        assert t.eval_plan()[0] > 0 and t.eval_plan()[3] == 0              # no (cell, near knot) pair at all
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+    want = otps.predict_grid(m, g.xmin, g.ymax, g.xres, g.yres, 1200, 400, *win)
+    assert np.abs(far - want).max() / np.abs(want).max() < RTOL
+
+
 def test_points_match_oracle_and_knot_coincidence(hip):
     g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 200, 200)
     xy, y = synth_stations(300, 11, g)
