@@ -450,49 +450,50 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
 // SYMM_SPLITS row ranges; lanes run over rows (barrier-free loop, 16 loads per lane and 64 rows in
 // flight).  Ypart[sp][j][i] partial sums are added up by the consumers; the block also
 // emits its share of M = V'Y (64 values) so that S = T'(V'Y)T needs no second pass over Y.
-constexpr int SYMM_SPLITS = 4;
-constexpr int SYMM_COLS = 32;
+constexpr int SYMM_SPLITS = 2;
+constexpr int SYMM_CPW = 8;              // columns per wave
+constexpr int SYMM_COLS = 4 * SYMM_CPW;  // per block
 
 __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict__ A, int64_t ld, int r0, int t,
                                                         const double *__restrict__ Vd, int64_t vs,
                                                         double *__restrict__ Ypart, double *__restrict__ Mpart) {
     __shared__ double Ms[4][BW * BW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col0 = blockIdx.x * SYMM_COLS + wave * 8;
+    const int col0 = blockIdx.x * SYMM_COLS + wave * SYMM_CPW;
     const int rows_per = ((t + SYMM_SPLITS - 1) / SYMM_SPLITS + 63) & ~63;
     const int rbeg = blockIdx.y * rows_per, rend = min(t, rbeg + rows_per);
-    double acc[8][BW];
+    double acc[SYMM_CPW][BW];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < SYMM_CPW; ++c)
 #pragma unroll
         for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
     const double *a0 = A + (int64_t)r0 * ld + r0;
     // lane = row: the lane's V row comes straight from global memory (V is t x 8, L2-resident), so the loop has
     // no barrier and the loads of the next 64 rows are in flight while these are multiplied.  Rows and columns
     // past the end are read at a clamped index and multiplied by zero.
-    const int ncol_ok = min(8, t - col0);   // <= 0: this wave has no column
-    const double *ac[8];
+    const int ncol_ok = min(SYMM_CPW, t - col0);   // <= 0: this wave has no column
+    const double *ac[SYMM_CPW];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) ac[c] = a0 + (int64_t)(col0 + (c < ncol_ok ? c : 0)) * ld;
+    for (int c = 0; c < SYMM_CPW; ++c) ac[c] = a0 + (int64_t)(col0 + (c < ncol_ok ? c : 0)) * ld;
     if (ncol_ok > 0) {
 #pragma unroll 2
         for (int rb = rbeg; rb < rend; rb += 64) {
             const int r = rb + lane;
             const unsigned rr = (unsigned)min(r, rend - 1);
             const double keep = r < rend ? 1.0 : 0.0;
-            double a[8], v[BW];
+            double a[SYMM_CPW], v[BW];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = ac[c][rr];
+            for (int c = 0; c < SYMM_CPW; ++c) a[c] = ac[c][rr];
 #pragma unroll
             for (int j = 0; j < BW; ++j) v[j] = Vd[(int64_t)j * vs + rr] * keep;
 #pragma unroll
             for (int j = 0; j < BW; ++j)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c][j] = fma(a[c], v[j], acc[c][j]);
+                for (int c = 0; c < SYMM_CPW; ++c) acc[c][j] = fma(a[c], v[j], acc[c][j]);
         }
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < SYMM_CPW; ++c)
         if (c >= ncol_ok) {
 #pragma unroll
             for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict
     double mpart[BW];  // lane l < 64: M[a = l & 7][b = l >> 3] contribution of this wave
     double mval = 0.0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < SYMM_CPW; ++c) {
         double y[BW];
 #pragma unroll
         for (int j = 0; j < BW; ++j) y[j] = wave_sum(acc[c][j]);
