@@ -790,6 +790,113 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double *__restrict__ A, 
             }
 }
 
+// =============================================================================================
+// Small matrices (the reference-tiled mode fits 130-750 stations per tile, V73:690-722): the blocked
+// band reduction above is four launches and two events per panel, and with several tiles being fitted
+// side by side the HIP launch path itself becomes the bottleneck.  Up to TRI_SMALL_CUT the whole
+// Householder TRIDIAGONALISATION runs in ONE block (matrix in L2, reflectors kept below the subdiagonal,
+// g <- Q'g carried along) and the GCV search uses the tridiagonal criterion on the host (TridiagGcv);
+// a second single-block kernel applies Q to the solution.  Three launches per fit.
+// Thread layout: rows over the low bits, up to 1024 / rows column groups over the high bits.
+// =============================================================================================
+constexpr int TRI_SMALL_MAX = 768;   // rows the kernel can hold
+constexpr int TRI_SMALL_CUT = 256;   // largest order it is used for: one CU's bandwidth bounds it (~m^3 x 8 B through
+                                     // a single block), the band reduction overtakes it near m = 300
+
+__global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict__ A, int64_t ld, int off, int m,
+                                                             double *__restrict__ d, double *__restrict__ e,
+                                                             double *__restrict__ tau, double *__restrict__ g) {
+    __shared__ double vs[TRI_SMALL_MAX], ws[TRI_SMALL_MAX], part[1024];
+    __shared__ double lds[17 * 2 + 2];
+    double *B = A + (int64_t)off * ld + off;
+    for (int k = 0; k < m - 1; ++k) {
+        const int t = m - k - 1;                       // order of the trailing block B22 = B[k+1:, k+1:]
+        double *x = B + (int64_t)k * ld + (k + 1);     // column k below the diagonal
+        double *B22 = B + (int64_t)(k + 1) * ld + (k + 1);
+        if (threadIdx.x == 0) d[k] = B[(int64_t)k * ld + k];
+        if (t == 1) {
+            if (threadIdx.x == 0) { e[k] = x[0]; tau[k] = 0.0; }
+            break;
+        }
+        const int rows_pad = (t + 63) & ~63;
+        const int G = max(1, 1024 / rows_pad);         // column groups
+        const int ii = threadIdx.x % rows_pad, jg = threadIdx.x / rows_pad;
+        const bool act = jg < G && ii < t;
+        // Householder vector of x (dlarfg)
+        const double xi = (threadIdx.x < t) ? x[threadIdx.x] : 0.0;
+        double red1[1] = {threadIdx.x >= 1 && threadIdx.x < t ? xi * xi : 0.0};
+        block_sum_vec<1>(red1, lds);
+        const double ss = red1[0];
+        __shared__ double alpha_s;
+        if (threadIdx.x == 0) alpha_s = xi;
+        __syncthreads();
+        const double alpha = alpha_s;
+        double beta = alpha, tk = 0.0, scal = 0.0;
+        if (ss != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+            tk = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        if (threadIdx.x < t) {
+            const double v = threadIdx.x == 0 ? 1.0 : xi * scal;
+            vs[threadIdx.x] = v;
+            if (threadIdx.x > 0) x[threadIdx.x] = v;   // reflector kept for the back-transform
+        }
+        if (threadIdx.x == 0) { e[k] = beta; tau[k] = tk; }
+        __syncthreads();
+        // p = tau B22 v (partial sums per column group), w = p - 1/2 tau (p'v) v ; g <- H g
+        double acc = 0.0;
+        if (act) {
+            const double *row = B22 + ii;
+#pragma unroll 4
+            for (int j = jg; j < t; j += G) acc = fma(row[(int64_t)j * ld], vs[j], acc);
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        double pi = 0.0, vi = 0.0, gi = 0.0;
+        if (threadIdx.x < t) {
+            for (int q = 0; q < G; ++q) pi += part[q * rows_pad + threadIdx.x];
+            pi *= tk;
+            vi = vs[threadIdx.x];
+            gi = g[k + 1 + threadIdx.x];
+        }
+        double red2[2] = {pi * vi, vi * gi};
+        block_sum_vec<2>(red2, lds);
+        if (threadIdx.x < t) {
+            ws[threadIdx.x] = pi - 0.5 * tk * red2[0] * vi;
+            g[k + 1 + threadIdx.x] = gi - tk * red2[1] * vi;
+        }
+        __syncthreads();
+        // B22 <- B22 - v w' - w v'
+        if (act) {
+            double *row = B22 + ii;
+            const double vi2 = vs[ii], wi2 = ws[ii];
+#pragma unroll 4
+            for (int j = jg; j < t; j += G) row[(int64_t)j * ld] -= vi2 * ws[j] + wi2 * vs[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d[m - 1] = B[(int64_t)(m - 1) * ld + (m - 1)];
+}
+
+// q <- Q q = H_0 H_1 ... H_{m-3} q with the reflectors tridiag_small_kernel left below the subdiagonal
+__global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
+                                                            const double *__restrict__ tau, double *__restrict__ q) {
+    __shared__ double lds[17 + 1];
+    const double *B = A + (int64_t)off * ld + off;
+    for (int k = m - 3; k >= 0; --k) {
+        const int t = m - k - 1;
+        const double tk = tau[k];
+        const double *x = B + (int64_t)k * ld + (k + 1);
+        double vi = 0.0, qi = 0.0;
+        if (threadIdx.x < t) { vi = threadIdx.x == 0 ? 1.0 : x[threadIdx.x]; qi = q[k + 1 + threadIdx.x]; }
+        double red[1] = {vi * qi};
+        block_sum_vec<1>(red, lds);
+        if (threadIdx.x < t) q[k + 1 + threadIdx.x] = qi - tk * red[0] * vi;
+        __syncthreads();
+    }
+}
+
 // single block: solve L L' x = b in place (L = lower triangle of A[off:off+m, off:off+m])
 __global__ __launch_bounds__(1024) void potrs_kernel(const double *__restrict__ A, int64_t ld, int off,
                                                      int m, double *__restrict__ x) {
@@ -1013,6 +1120,30 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (int rc = cholesky_solve(A.p, ld, 3, m, gbuf.p, info_dev, s)) return rc;
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
+    } else if (m <= TRI_SMALL_CUT && m >= 3) {
+        // small matrix: single-block tridiagonalisation + tridiagonal GCV on the host + single-block back-transform
+        MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        double *dd_dev = pbuf.p, *ee_dev = wbuf.p;
+        hipLaunchKernelGGL(tridiag_small_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, dd_dev, ee_dev, tau.p, gbuf.p);
+        MHS_HIP(hipGetLastError());
+        std::vector<double> td((size_t)m), te((size_t)m), g((size_t)m), q((size_t)m);
+        MHS_HIP(hipMemcpyAsync(td.data(), dd_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipMemcpyAsync(te.data(), ee_dev, sizeof(double) * (m - 1), hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipStreamSynchronize(s));
+        lap("tridiagonalisation (GPU, one block)");
+        TridiagGcv tg;
+        tg.a = td.data(); tg.b = te.data(); tg.g = g.data(); tg.m = m; tg.n = n; tg.N = N; tg.pure_ss = pure_ss;
+        lam = tg.find_lambda(gcv_mode);
+        if (std::isnan(lam) || lam < 0) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
+        tg.eval(lam, &gcv, &eff_df, q.data());
+        lap("GCV search (host, tridiagonal)");
+        MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(tridiag_back_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, tau.p, gbuf.p);
+        MHS_HIP(hipGetLastError());
+        MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipStreamSynchronize(s));
+        lap("solve + back-transform");
     } else {
         // reduce B to bandwidth BW in place (blocked), rotating g = Q' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
