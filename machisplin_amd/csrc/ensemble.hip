@@ -87,6 +87,7 @@ struct mhs_model {
     std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
     int rf_max_nodes = 0;
     int rf_log2r = -1;                       // walks per lane rf_nodes were built for
+    bool rf_big = false;                     // ... and whether in the BIG form (node indices, predictions in global memory)
 };
 
 namespace mhs {
@@ -669,7 +670,10 @@ __device__ __forceinline__ uint2v lds_u2(unsigned a) { return *(__attribute__((a
 __device__ __forceinline__ unsigned lds_u32(unsigned a) { return *(__attribute__((address_space(3))) const unsigned *)(uintptr_t)a; }
 __device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
 
-template <int LOG2R>
+// BIG: trees of more than 8191 nodes (or whose predictions do not fit beside the keys): the children words hold
+// node INDICES (one extra shift per level) and the node predictions stay in global memory -- one read per tree
+// and walk -- so that a 12 000-node tree of a 20 000-station forest (96 KB of nodes) still walks in LDS.
+template <int LOG2R, bool BIG>
 __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__ gnodes,
                                                        const double *__restrict__ glval,
                                                        const int *__restrict__ tree_off,
@@ -682,9 +686,9 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
     constexpr int R = 1 << LOG2R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *lnodes = (uint2 *)smem;                                 // [max_nodes], byte address = 8 * node
-    const unsigned lval_off = (unsigned)max_nodes * 8u;            // double [max_nodes]
+    const unsigned lval_off = (unsigned)max_nodes * 8u;            // double [max_nodes] (not BIG)
     double *lval = (double *)(smem + lval_off);
-    const unsigned tree_bytes = max(lval_off * 2u, (unsigned)RF_COARSE_BYTES);
+    const unsigned tree_bytes = max(BIG ? lval_off : lval_off * 2u, (unsigned)RF_COARSE_BYTES);
     float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
     const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
     const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
@@ -712,14 +716,14 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
     for (int t = 0; t < n_trees; ++t) {
         const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 1024) { lnodes[e] = gnodes[o + e]; lval[e] = glval[o + e]; }
+        for (int e = threadIdx.x; e < cnt; e += 1024) { lnodes[e] = gnodes[o + e]; if (!BIG) lval[e] = glval[o + e]; }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = 0u;
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
-                const uint2v nd = lds_u2(node[c]);
+                const uint2v nd = lds_u2(BIG ? node[c] << 3 : node[c]);
                 const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
                 // node = k > nd.x ? WORD_1(nd.y) : WORD_0(nd.y); an SDWA instruction may read VCC two wait
                 // states after the VALU write at the earliest
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
             }
         }
 #pragma unroll
-        for (int c = 0; c < R; ++c) acc[c] = acc[c] + lds_f64(node[c] + lval_off);
+        for (int c = 0; c < R; ++c) acc[c] = acc[c] + (BIG ? glval[o + (int)node[c]] : lds_f64(node[c] + lval_off));
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
@@ -768,6 +772,7 @@ static int to_device(const T *h, size_t n, T **d) {
 
 constexpr int TREE_R = 2;
 constexpr size_t LDS_LIMIT = 150 * 1024;     // of the 160 KiB per CU
+constexpr size_t LDS_MAX = 160 * 1024;       // all of it (one block per CU)
 constexpr int GBM_CHUNK_NODES = 1024;        // 16 KiB of node records per chunk
 
 static int finish_trees(mhs_model *m, const std::vector<Node> &nodes, const std::vector<int> &off) {
@@ -987,24 +992,31 @@ static float floor_to_float(double thr) {  // largest float <= thr
 }
 
 // LDS bytes of rf_walk_kernel for R = 2^log2r walks per lane
-static size_t rf_walk_lds(const mhs_model *m, int log2r) {
-    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
+static size_t rf_walk_lds(const mhs_model *m, int log2r, bool big) {
+    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * (big ? 8 : 16), (size_t)RF_COARSE_BYTES);
     return tree_bytes + (size_t)1024 * (((size_t)m->p << log2r) | 1) * 4;
 }
 
-// walks per lane of rf_walk_kernel: 4 if the keys and one tree fit in LDS, else 2; -1 = generic walk.
-// Child byte addresses are 16-bit and the predictor's key offset is one byte.
-static int rf_walk_log2r(const mhs_model *m) {
-    if (m->rf_max_nodes * 8 > 65535) return -1;
-    for (int l2 = 2; l2 >= 1; --l2)
-        if (((m->p << l2) * 4) <= 255 && rf_walk_lds(m, l2) <= LDS_LIMIT) return l2;
-    return -1;
+// Configuration of rf_walk_kernel: walks per lane (4, else 2) and whether the trees need the BIG form (node
+// indices instead of 16-bit byte addresses, predictions left in global memory); false = generic walk.
+// The predictor's key offset is one byte.
+static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 && m->rf_max_nodes * 8 > 65535) continue;
+        if (b == 1 && m->rf_max_nodes > 65535) continue;
+        for (int l2 = 2; l2 >= 1; --l2)
+            if (((m->p << l2) * 4) <= 255 && rf_walk_lds(m, l2, b == 1) <= (b == 1 ? LDS_MAX : LDS_LIMIT)) {
+                *log2r = l2; *big = b == 1;
+                return true;
+            }
+    }
+    return false;
 }
 
 // key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry
-static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r) {
+static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big) {
     const mhs_grid &o = m->meta_grid;
-    if (m->rf_nodes && m->meta_C == C && m->rf_log2r == log2r && o.xmin == grid.xmin && o.ymax == grid.ymax &&
+    if (m->rf_nodes && m->meta_C == C && m->rf_log2r == log2r && m->rf_big == big && o.xmin == grid.xmin && o.ymax == grid.ymax &&
         o.xres == grid.xres && o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
     const size_t nn = m->rf_thr.size();
     std::vector<float> tkey(nn, 0.f);
@@ -1051,13 +1063,14 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r) 
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
         const unsigned left = m->rf_left[k];   // node index within the tree (terminal: its own index)
+        const unsigned unit = big ? 1u : 8u;   // children as node indices or as LDS byte addresses
         unsigned node0 = 0, children;
-        if (v == 0xFFFFu) children = (left * 8u) | ((left * 8u) << 16);
+        if (v == 0xFFFFu) children = (left * unit) | ((left * unit) << 16);
         else {
             const std::vector<float> &sv = sorted[(size_t)v];
             const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[k]) - sv.begin());
             node0 = (j << 8) | (v * R * 4u);
-            children = (left * 8u) | (((left + 1u) * 8u) << 16);
+            children = (left * unit) | (((left + 1u) * unit) << 16);
         }
         rec[k] = ((unsigned long long)children << 32) | node0;
     }
@@ -1070,17 +1083,19 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r) 
     m->meta_grid = grid;
     m->meta_C = C;
     m->rf_log2r = log2r;
+    m->rf_big = big;
     return MHS_OK;
 }
 
 static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
-                          double w, int acc, double *out, hipStream_t st, int64_t total, int log2r) {
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r)) return rc;
+                          double w, int acc, double *out, hipStream_t st, int64_t total, int log2r, bool big) {
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big)) return rc;
     const int R = 1 << log2r;
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
-    const size_t bytes = rf_walk_lds(m, log2r);
-    auto kern = log2r == 2 ? rf_walk_kernel<2> : rf_walk_kernel<1>;
+    const size_t bytes = rf_walk_lds(m, log2r, big);
+    auto kern = big ? (log2r == 2 ? rf_walk_kernel<2, true> : rf_walk_kernel<1, true>)
+                    : (log2r == 2 ? rf_walk_kernel<2, false> : rf_walk_kernel<1, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)m->rf_nodes, m->rf_lval, m->tree_off,
                        m->rf_depth, m->lut_sorted, m->lut_sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
@@ -1121,9 +1136,10 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             break;
         case K_RF:
             if (grid && m->rf_fast && !s.all_from_planes && s.dtype != MHS_F64) {
-                const int log2r = rf_walk_log2r(m);
-                if (log2r > 0) {
-                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r)) return rc;
+                int log2r = 0;
+                bool big = false;
+                if (rf_walk_config(m, &log2r, &big)) {
+                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r, big)) return rc;
                     break;
                 }
             }
@@ -1375,6 +1391,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
         int max_nodes = 0;
         for (int64_t t = 0; t < n_trees && paired; ++t) {
             const int o = off[t], cnt = off[t + 1] - off[t];
+            if (cnt > 65535) { paired = false; break; }   // node indices within a tree are 16-bit in the walk kernels
             max_nodes = std::max(max_nodes, cnt);
             lev.assign((size_t)cnt, -1);
             lev[0] = 0;

@@ -151,6 +151,19 @@ def test_gbm_rank_lut_variants(hip, C, trees, n):
     assert np.abs(got - want).max() <= _tol(want)   # one wrong leaf would be ~1e-3 * sd(y)
 
 
+def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
+    """Trees of ~18 000 nodes (30 000 stations): too many for 16-bit byte addresses and for nodes + predictions in
+    LDS, so the walk takes its BIG form (node indices, predictions read from global memory).  Same results."""
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=256, ncol=256, C=3, n=30000, gbm_trees=2, rf_trees=1)
+    prm = synth.rf_params(Xs, ys, 5, n_trees=3)
+    assert np.diff(prm["tree_offsets"]).max() > 8191
+    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    want = oe.predict(prm, X)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
 def test_loaders_reject_malformed_models(hip):
     with pytest.raises(hip.MhsError):
         hip.models.Gbm(0.0, [0, 2], [0, -1], [1.0, 2.0], [5, 0], [1, 0], [1, 0], p=5)  # child out of range
