@@ -298,6 +298,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MHS_BENCH_ONE_GPU"):   # plumbing tests: every rank on GPU 0
+        local = 0
     import torch
     import torch.distributed as dist
     import machisplin_amd as mhs
@@ -306,7 +308,11 @@ def main():
     mhs.init(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MHS_BENCH_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU (plumbing tests only)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     cfg = WORKLOADS[args.workload]

@@ -160,6 +160,8 @@ def init(device: int | None = None) -> int:
     global _inited_device
     lib = load()
     if device is None:
+        if _inited_device is not None:   # an explicit earlier init() wins
+            return _inited_device
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if _inited_device == device:
         return device
