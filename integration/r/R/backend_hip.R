@@ -54,3 +54,10 @@ mhs_tps_surface <- function(rast_stack, dat, res.FINAL, n.covars, tile.edge = 15
              as.integer(tile.edge), lambda, 0L)
   terra::setValues(terra::rast(rast_stack[[1]]), v)
 }
+
+# How terra::interpolate's replacement sums the knots: "auto" (by cost), "direct" (predict.Krig's own loop, results
+# bit-identical across windows -- use it when comparing against captured fields output) or "far.field".
+mhs_tps_eval_mode <- function(mode = c("auto", "direct", "far.field")) {
+  mode <- match.arg(mode)
+  invisible(.Call("mhsr_tps_eval_mode", match(mode, c("auto", "direct", "far.field")) - 1L))
+}

@@ -28,6 +28,9 @@ static SEXP wrap(void *h, R_CFinalizer_t fin) {
 }
 
 SEXP mhsr_init(SEXP device) { chk(mhs_init(Rf_asInteger(device))); return R_NilValue; }
+/* 0 = by cost (default), 1 = direct sum (predict.Krig's own loop; bit-identical across windows), 2 = far-field-
+   interpolated sum; see mhs_tps_eval_mode in machisplin_hip.h */
+SEXP mhsr_tps_eval_mode(SEXP mode) { chk(mhs_tps_eval_mode(Rf_asInteger(mode))); return R_NilValue; }
 
 /* fields::Tps(x, Y)  (V73:722, V73:751).  xy: n x 2 numeric matrix, lambda NA => GCV */
 SEXP mhsr_tps_fit(SEXP xy, SEXP y, SEXP lambda, SEXP mode) {
