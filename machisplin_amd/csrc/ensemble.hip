@@ -10,6 +10,7 @@
 // lane can index them by the node's split variable).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "common.h"
@@ -744,6 +745,110 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
     }
 }
 
+// Double-buffered form for trees of up to 4095 nodes (two buffers stay within the 16-bit child addresses): the
+// next tree travels global -> registers -> the other LDS buffer WHILE this one is walked, the node predictions are
+// read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
+// tree costs one barrier.  In the single-buffer form a third of the kernel was staging: every wave idle while
+// 48 KB are copied between two barriers, 500 times per block.
+template <int LOG2R>
+__global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restrict__ gnodes,
+                                                          const double *__restrict__ glval,
+                                                          const int *__restrict__ tree_off,
+                                                          const int *__restrict__ depth,
+                                                          const float *__restrict__ sorted,
+                                                          const int *__restrict__ sorted_off, int n_trees,
+                                                          int max_nodes, int p, StackDev s, PredGeom g,
+                                                          double weight, int accumulate,
+                                                          double *__restrict__ out) {
+    constexpr int R = 1 << LOG2R;
+    constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned buf_bytes = (unsigned)max_nodes * 8u;           // one tree's nodes; the two buffers sit at 0 and buf_bytes
+    const unsigned tree_bytes = max(2u * buf_bytes, (unsigned)RF_COARSE_BYTES);
+    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
+    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
+    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R], pending[R];
+    unsigned node[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * part;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
+    }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        lut_ranks<R, 1024>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    __syncthreads();                                               // coarse table no longer needed: buffer 0 may be written
+    {
+        const int o = tree_off[0], cnt = tree_off[1] - o;
+        for (int e = threadIdx.x; e < cnt; e += 1024) ((uint2 *)smem)[e] = gnodes[o + e];
+    }
+    __syncthreads();
+    // tree t's scalars (offsets, depth) are fetched one iteration ahead: an s_load at the top of every tree
+    // would stall all 16 waves for its latency, 500 times
+    int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1;
+    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+    for (int t = 0; t < n_trees; ++t) {
+        const unsigned boff = (t & 1) ? buf_bytes : 0u, noff = (t & 1) ? 0u : buf_bytes;
+        const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0;
+        const int o3 = t + 3 <= n_trees ? tree_off[t + 3] : o2;        // consumed two iterations from now
+        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+        uint2 pn[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = threadIdx.x + q * 1024;
+            if (e < cnt1) pn[q] = gnodes[o1 + e];
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = boff;
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const uint2v nd = lds_u2(node[c]);
+                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+            }
+        }
+        // the previous tree's predictions have arrived by now; this tree's are requested
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            pending[c] = glval[o + (int)((node[c] - boff) >> 3)];
+        }
+        // park the next tree in the other buffer, child addresses moved there
+        const unsigned reloc = noff * 0x10001u;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = threadIdx.x + q * 1024;
+            if (e < cnt1) { uint2 nd = pn[q]; nd.y += reloc; *(uint2 *)(smem + noff + (unsigned)e * 8u) = nd; }
+        }
+        __syncthreads();
+        o = o1; o1 = o2; o2 = o3;
+        levels = levels1; levels1 = levels2;
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        const int64_t i = i0 + c * part;
+        if (i0 < part && i < total)
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(const double *__restrict__ a, double divisor,
                                                         const double *__restrict__ b,
                                                         double *__restrict__ out, int64_t n) {
@@ -1000,6 +1105,18 @@ static size_t rf_walk_lds(const mhs_model *m, int log2r, bool big) {
 // Configuration of rf_walk_kernel: walks per lane (4, else 2) and whether the trees need the BIG form (node
 // indices instead of 16-bit byte addresses, predictions left in global memory); false = generic walk.
 // The predictor's key offset is one byte.
+// the double-buffered kernel: two node buffers within 16-bit byte addresses, predictions in global memory
+static size_t rf_walk_db_lds(const mhs_model *m, int log2r) {
+    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
+    return tree_bytes + (size_t)1024 * (((size_t)m->p << log2r) | 1) * 4;
+}
+static int rf_walk_db_log2r(const mhs_model *m) {
+    if (m->rf_max_nodes > 4095) return -1;
+    for (int l2 = 2; l2 >= 1; --l2)
+        if (((m->p << l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
+    return -1;
+}
+
 static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
     for (int b = 0; b < 2; ++b) {
         if (b == 0 && m->rf_max_nodes * 8 > 65535) continue;
@@ -1093,6 +1210,14 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     const int R = 1 << log2r;
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
+    if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
+        const size_t dbytes = rf_walk_db_lds(m, log2r);
+        auto dk = log2r == 2 ? rf_walk_db_kernel<2> : rf_walk_db_kernel<1>;
+        MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
+        hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)m->rf_nodes, m->rf_lval, m->tree_off,
+                           m->rf_depth, m->lut_sorted, m->lut_sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+        return MHS_OK;
+    }
     const size_t bytes = rf_walk_lds(m, log2r, big);
     auto kern = big ? (log2r == 2 ? rf_walk_kernel<2, true> : rf_walk_kernel<1, true>)
                     : (log2r == 2 ? rf_walk_kernel<2, false> : rf_walk_kernel<1, false>);
