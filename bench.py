@@ -191,7 +191,7 @@ class Workload:
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "read C fp32 planes + read-modify-write fp64 out"})
         pmc = {}
         try:  # bytes per cell measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled as
-            # the gfx950 guide prescribes) on scratch/pmc_probe; committed under profiles/
+            # the gfx950 guide prescribes) on tools/pmc_probe; committed under profiles/
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 for kn, d in json.load(f)["kernels"].items():
                     pmc[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
