@@ -1,5 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 P=$GRAFT_REPO_ROOT/tools/pmc_probe
+[ -x $P ] || /opt/rocm/bin/hipcc -O2 -I$GRAFT_REPO_ROOT/include -o $P $GRAFT_REPO_ROOT/tools/pmc_probe.cpp -L$GRAFT_REPO_ROOT/machisplin_amd -lmachisplin_hip -Wl,-rpath,$GRAFT_REPO_ROOT/machisplin_amd
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
 for C in LdsUtil LdsBankConflict "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   T=$(echo $C | tr ' ' '_')

@@ -1,5 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 P=$GRAFT_REPO_ROOT/tools/pmc_probe
+[ -x $P ] || /opt/rocm/bin/hipcc -O2 -I$GRAFT_REPO_ROOT/include -o $P $GRAFT_REPO_ROOT/tools/pmc_probe.cpp -L$GRAFT_REPO_ROOT/machisplin_amd -lmachisplin_hip -Wl,-rpath,$GRAFT_REPO_ROOT/machisplin_amd
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- $P 4000 > /tmp/pmc_$C.log 2>&1
