@@ -79,7 +79,7 @@ class Workload:
             self.resp = synth.tps_residual(uv, seed)
             self.params = [{"kind": "lm", "coef": np.zeros(cfg["layers"] + 3)}]
             self.weights, self.wt_total = [1.0], 1.0
-        self.models = [mhs.models.from_oracle_dict(p) for p in self.params]
+        self.models = [mhs.models.from_param_dict(p) for p in self.params]
         self.X = X
         self.ops = sharded.HipOps(self.stack, self.xy, self.resp, self.models, self.weights, self.wt_total, timed=True)
         self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side)

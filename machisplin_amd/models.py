@@ -137,7 +137,7 @@ class RandomForest(Model):
         super().__init__(h, p)
 
 
-def from_oracle_dict(m: dict) -> Model:
+def from_param_dict(m: dict) -> Model:
     """Build a device model from the plain parameter dict the tests and bench.py use
     (same fields as the flat R arrays; see the loaders in include/machisplin_hip.h)."""
     k = m["kind"]

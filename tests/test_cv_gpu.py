@@ -22,7 +22,7 @@ def test_cv_residual_columns_match_oracle_and_feed_the_weight_search(hip, n, nfo
         train = np.flatnonzero(kfolds == v) if n > 4000 else np.flatnonzero(kfolds != v)   # V73:228-232
         params = synth.ensemble_params(X[train], y[train], 100 + v, n_gbm_trees=200, n_rf_trees=15)
         fold_params.append(dict(zip(cv.ORDER_ALL, params)))
-        fold_models.append({lab: hip.models.from_oracle_dict(p) for lab, p in zip(cv.ORDER_ALL, params)})
+        fold_models.append({lab: hip.models.from_param_dict(p) for lab, p in zip(cv.ORDER_ALL, params)})
     got = cv.cv_residuals(fold_models, X, y, kfolds)
     want = oe.cv_residuals(fold_params, X, y, kfolds)
     assert got.shape == want.shape == ((nfolds - 1) * n if n > 4000 else n, 6)

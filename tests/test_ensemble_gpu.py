@@ -40,7 +40,7 @@ def _tol(ref):
 def test_each_member_matches_oracle(hip, dtype):
     g, stack, X, Xs, ys, params = _setup(hip, dtype=dtype, nodata_frac=0.01 if dtype != "f64" else 0.0)
     for prm in params:
-        m = hip.models.from_oracle_dict(prm)
+        m = hip.models.from_param_dict(prm)
         got = hip.predict(stack, m).cpu().numpy().ravel()
         want = oe.predict(prm, X)
         assert np.array_equal(np.isnan(got), np.isnan(want)), prm["kind"]
@@ -50,7 +50,7 @@ def test_each_member_matches_oracle(hip, dtype):
 def test_gbm_routes_na_through_missing_nodes(hip):
     g, stack, X, Xs, ys, params = _setup(hip, dtype="f32", nodata_frac=0.05)
     prm = params[0]
-    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    got = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
     assert np.isnan(X).any() and np.isfinite(got).all()
     assert np.abs(got - oe.predict(prm, X)).max() <= _tol(got)
 
@@ -70,7 +70,7 @@ def test_sklearn_fitted_structures(hip):
     svr = SVR(kernel="rbf", C=1.0, epsilon=0.1, gamma=0.2).fit((Xs - mu) / sd, (ys - ym) / ysd)
     for prm, skl in [(modelgen.gbm_from_sklearn(gbr, 5), gbr.predict(X)), (modelgen.rf_from_sklearn(rf, 5), rf.predict(X)),
                      (modelgen.svr_from_sklearn(svr, mu, sd, ym, ysd), svr.predict((X - mu) / sd) * ysd + ym)]:
-        got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+        got = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
         assert np.abs(got - oe.predict(prm, X)).max() <= _tol(got), prm["kind"]
         # independent evaluator; deep RF trees hold thousands of LONG/LAT thresholds, a few of which
         # fall between a cell centre and its float32 rounding (what sklearn compares): allow 5 %
@@ -84,7 +84,7 @@ def test_weighted_ensemble_window_and_accumulate(hip):
     kept, wts, tot = hip.models.select_weights([0.31, 0.22, 0.004, 0.18, 0.27, 0.41])
     assert kept == "bgmrv"
     sel = [params[KINDS.index(k)] for k in kept]
-    mods = [hip.models.from_oracle_dict(p) for p in sel]
+    mods = [hip.models.from_param_dict(p) for p in sel]
     want = oe.ensemble(sel, wts, tot, X).reshape(g.nrow, g.ncol)
     got = hip.ensemble_predict(stack, mods, wts, tot).cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -108,7 +108,7 @@ def test_weighted_ensemble_window_and_accumulate(hip):
 def test_predict_points_gives_station_residual_inputs(hip):
     g, stack, X, Xs, ys, params = _setup(hip)
     for prm in params:
-        m = hip.models.from_oracle_dict(prm)
+        m = hip.models.from_param_dict(prm)
         got = m.predict_points(Xs)
         want = oe.predict(prm, Xs)
         assert np.abs(got - want).max() <= _tol(want), prm["kind"]
@@ -118,7 +118,7 @@ def test_seven_predictors_and_host_entry_point(hip):
     import ctypes as C
     from machisplin_amd import _lib
     g, stack, X, Xs, ys, params = _setup(hip, nrow=40, ncol=50, C=5, n=300, gbm_trees=50, rf_trees=5)
-    mods = [hip.models.from_oracle_dict(p) for p in params]
+    mods = [hip.models.from_param_dict(p) for p in params]
     wts = [0.3, 0.2, 0.1, 0.2, 0.3, 0.4]
     want = oe.ensemble(params, wts, 1.5, X).reshape(40, 50)
     got = hip.ensemble_predict(stack, mods, wts, 1.5).cpu().numpy()
@@ -145,7 +145,7 @@ def test_gbm_rank_lut_variants(hip, C, trees, n):
     prm = synth.gbm_params(Xs, ys, 11, n_trees=trees)
     distinct = max(len(np.unique(prm["split_val"][prm["split_var"] == v].astype(np.float32))) for v in range(C))
     assert distinct > 4096 or trees < 8000
-    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    got = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
     want = oe.predict(prm, X)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= _tol(want)   # one wrong leaf would be ~1e-3 * sd(y)
@@ -158,7 +158,7 @@ def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     g, stack, X, Xs, ys, params = _setup(hip, nrow=256, ncol=256, C=3, n=30000, gbm_trees=2, rf_trees=1)
     prm = synth.rf_params(Xs, ys, 5, n_trees=3)
     assert np.diff(prm["tree_offsets"]).max() > 8191
-    got = hip.predict(stack, hip.models.from_oracle_dict(prm)).cpu().numpy().ravel()
+    got = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
     want = oe.predict(prm, X)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= _tol(want)

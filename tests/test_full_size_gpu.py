@@ -31,7 +31,7 @@ def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip):
     y = synth.response(X, uv, 1)
     stack64 = hip.RasterStack(g, planes.to(torch.float64), float("nan"))  # same values, generic-walk kernels
     for prm in (synth.gbm_params(X, y, 3, n_trees=10000), synth.rf_params(X, y, 3, n_trees=500)):
-        m = hip.models.from_oracle_dict(prm)
+        m = hip.models.from_param_dict(prm)
         a = hip.predict(stack32, m)
         b = hip.predict(stack64, m)
         assert torch.equal(torch.isnan(a), torch.isnan(b)), prm["kind"]
@@ -43,7 +43,7 @@ def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip):
     xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, side, side, 4321, 4323)
     Xg = oe.stack_predictors(host, (xs, ys))
     prm = synth.rf_params(X, y, 3, n_trees=500)
-    got = hip.predict(stack32, hip.models.from_oracle_dict(prm), window=(4321, 4323, 0, side)).cpu().numpy().ravel()
+    got = hip.predict(stack32, hip.models.from_param_dict(prm), window=(4321, 4323, 0, side)).cpu().numpy().ravel()
     want = cbind.predict(prm, Xg, threads=8)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) < 1e-11 * np.nanmax(np.abs(want))
@@ -111,7 +111,7 @@ def test_cfg3_ensemble_linearity_on_the_full_grid(hip):
     X = np.column_stack([np.nan_to_num(cov), xy])
     y = synth.response(X, uv, 2)
     params = synth.ensemble_params(X, y, 4, n_gbm_trees=300, n_rf_trees=20, which="gnmv")
-    mods = [hip.models.from_oracle_dict(p) for p in params]
+    mods = [hip.models.from_param_dict(p) for p in params]
     wts, tot = [0.22, 0.12, 0.18, 0.41], 1.23
     fused = hip.ensemble_predict(stack, mods, wts, tot)
     acc = None

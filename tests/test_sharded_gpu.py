@@ -25,7 +25,7 @@ def _build(hip):
     X = np.column_stack([cov, xy])
     resp = synth.response(X, uv, 11)
     params = synth.ensemble_params(X, resp, 11, n_gbm_trees=150, n_rf_trees=8)
-    models = [hip.models.from_oracle_dict(p) for p in params]
+    models = [hip.models.from_param_dict(p) for p in params]
     _, weights, wt_total = hip.models.select_weights(synth.OPTX_WEIGHTS)
     return sharded.HipOps(stack, xy, resp, models, weights, wt_total)
 

@@ -90,7 +90,7 @@ def test_mltps_steps_2_to_5_end_to_end(hip, tile_edge):
     (edge 1500 takes the single-tile branch V73:748-753)."""
     g, stack, host, X, xy, resp, params = _ensemble_inputs(hip, 220, 290, 600, 31)
     kept, wts, tot = hip.models.select_weights([0.31, 0.22, 0.12, 0.18, 0.27, 0.41])
-    mods = [hip.models.from_oracle_dict(p) for p in params]
+    mods = [hip.models.from_param_dict(p) for p in params]
     res = hip.mltps_predict(stack, xy, resp, mods, wts, tot, tps=True, tile_edge=tile_edge)
     # ---- oracle: the same flow, literally (V73:447-930)
     og = _og(g)
@@ -225,7 +225,7 @@ def test_cfg4_chain_tiles_create_per_tile_mltps_tiles_merge(hip):
             sel = t["dat"][h]
             assert np.array_equal(sel, osel[h])
             sub = hip.RasterStack(t["geom"][h], stack.planes[:, r0:r1, c0:c1].contiguous(), stack.nodata)
-            mods = [hip.models.from_oracle_dict(p) for p in smooth]
+            mods = [hip.models.from_param_dict(p) for p in smooth]
             res = hip.mltps_predict(sub, xy[sel], y[sel], mods, wts, tot, tps=True, tile_edge=100)
             finals_gpu.append(res["final"].contiguous())
             # ---- oracle for this tile

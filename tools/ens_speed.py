@@ -15,7 +15,7 @@ y = synth.response(X, uv, seed)
 t0 = time.time(); params = synth.ensemble_params(X, y, seed); print("gen", time.time() - t0)
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 for prm in params:
-    mod = m.models.from_oracle_dict(prm)
+    mod = m.models.from_param_dict(prm)
     m.predict(stack, mod, out=out); torch.cuda.synchronize()
     t0 = time.time(); m.predict(stack, mod, out=out); torch.cuda.synchronize(); dt = time.time() - t0
     extra = ""
