@@ -145,6 +145,38 @@ def test_far_field_with_every_knot_outside_the_window(hip):
     assert np.abs(far - want).max() / np.abs(want).max() < RTOL
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_far_field_equals_direct_on_random_geometries(hip, seed):
+    """Random cell sizes (anisotropic), grid shapes, windows and station layouts (clustered, partly outside the
+    window): the far-field-interpolated sum against the direct sum of the same handle."""
+    rng = np.random.default_rng(1000 + seed)
+    nrow, ncol = int(rng.integers(200, 900)), int(rng.integers(200, 900))
+    xres, yres = 1.0 / rng.integers(300, 2400), 1.0 / rng.integers(300, 2400)
+    g = hip.Geometry(-78.0, -5.0, xres, yres, nrow, ncol)
+    n = int(rng.integers(60, 700))
+    # clustered stations: a mixture of a uniform cloud and two blobs
+    u = np.vstack([rng.uniform(0, 1, (n // 2, 2)), rng.normal([0.2, 0.7], 0.05, (n // 4, 2)),
+                   rng.normal([0.8, 0.3], 0.1, (n - n // 2 - n // 4, 2))]).clip(0.001, 0.999)
+    cells = np.unique((u[:, 1] * nrow).astype(int) * ncol + (u[:, 0] * ncol).astype(int))
+    rows, cols = np.divmod(cells, ncol)
+    xy = np.column_stack([g.x_from_col(cols), g.y_from_row(rows)])
+    y = np.sin(5 * u[:len(cells), 0]) + rng.standard_normal(len(cells)) * 0.2
+    t = hip.Tps(xy, y)
+    r0 = int(rng.integers(0, nrow // 3)); r1 = int(rng.integers(2 * nrow // 3, nrow + 1))
+    c0 = int(rng.integers(0, ncol // 3)); c1 = int(rng.integers(2 * ncol // 3, ncol + 1))
+    win = (r0, r1, c0, c1)
+    try:
+        hip.eval_mode(hip.EVAL_DIRECT)
+        direct = hip.interpolate(g, t, window=win).cpu().numpy()
+        hip.eval_mode(hip.EVAL_FAR_FIELD)
+        far = hip.interpolate(g, t, window=win).cpu().numpy()
+        used = t.eval_plan()[0] > 0
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+    assert np.isfinite(far).all()
+    assert np.abs(far - direct).max() <= 1e-9 * np.abs(direct).max(), (used, t.eval_plan())
+
+
 def test_points_match_oracle_and_knot_coincidence(hip):
     g = hip.Geometry(-78.0, -5.0, 1.0 / 1200, 1.0 / 1200, 200, 200)
     xy, y = synth_stations(300, 11, g)
