@@ -61,3 +61,17 @@ mhs_tps_eval_mode <- function(mode = c("auto", "direct", "far.field")) {
   mode <- match.arg(mode)
   invisible(.Call("mhsr_tps_eval_mode", match(mode, c("auto", "direct", "far.field")) - 1L))
 }
+
+
+# ---- a drop-in for the fields::Tps object itself (keeps the R loop of V73:690-753 as it is) ----
+# mhs_Tps(xy, y) returns an object of class "machisplin_tps"; terra::interpolate(rast, obj) then works through
+# the predict method below (points, block by block), and mhs_interpolate() is the whole-grid fast path.
+mhs_Tps <- function(x, Y, lambda = NA_real_) {
+  structure(list(handle = .Call("mhsr_tps_fit", as.matrix(x), as.numeric(unlist(Y)), lambda, 0L)),
+            class = "machisplin_tps")
+}
+predict.machisplin_tps <- function(object, x, ...) .Call("mhsr_tps_predict_points", object$handle, as.matrix(x))
+mhs_interpolate <- function(r, object) {
+  v <- .Call("mhsr_tps_predict_grid", object$handle, .mhs_geom(r), c(0L, nrow(r), 0L, ncol(r)))
+  terra::setValues(terra::rast(r), v)
+}

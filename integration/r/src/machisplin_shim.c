@@ -40,6 +40,17 @@ SEXP mhsr_tps_fit(SEXP xy, SEXP y, SEXP lambda, SEXP mode) {
     return wrap(t, tps_finalizer);
 }
 
+/* predict(tps, xy): the spline at arbitrary points -- what terra::interpolate feeds an S3 predict method
+ * block by block; xy is an n x 2 numeric matrix */
+SEXP mhsr_tps_predict_points(SEXP tps, SEXP xy) {
+    R_xlen_t n = Rf_xlength(xy) / 2;
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, n));
+    int rc = mhs_tps_predict_points((mhs_tps *)R_ExternalPtrAddr(tps), REAL(xy), (int64_t)n, REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
 /* terra::interpolate(terra::rast(rb), tps)  (V73:726, V73:753): values in terra cell order */
 SEXP mhsr_tps_predict_grid(SEXP tps, SEXP geom, SEXP win) {
     mhs_grid g = grid_from(geom);
