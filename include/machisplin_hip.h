@@ -215,6 +215,11 @@ MHS_API int mhs_ensemble_predict(const mhs_model *const *models, const double *w
 /* predict(model, data.frame): X is n x p COLUMN-major (all p predictors given, LONG and
  * LAT included), out[n].  Station residuals V73:477-482,501-505,...                     */
 MHS_API int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *out_host);
+/* res.FINAL in one call (V73:477-482, 501-505, 525-528, 547-549, 586-589, 608-611, 620): the kept members at the
+ * n station rows X (as above), out[i] = ((resp_i - pred_1) w_1 + (resp_i - pred_2) w_2 + ...) / wt_total, accumulated
+ * member after member; weights = the rounded kept weights, wt_total the unrounded total (at most 8 members). */
+MHS_API int mhs_residual_points(const mhs_model *const *models, const double *weights, int n_models, double wt_total,
+                                const double *X, const double *resp, int64_t n, double *out_host);
 
 /* out = a / divisor (b == NULL) or a / divisor + b: pred.elev / wt.tot (V73:619) and the
  * Step-5 sum pred + TPS (V73:906-907); NaN if either is NaN.  n elements, device. */

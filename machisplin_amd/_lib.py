@@ -86,6 +86,7 @@ SIGNATURES = {
     "mhs_ensemble_predict": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),
                                        C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp]),
     "mhs_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mhs_residual_points": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_scale_add_dev": (C.c_int, [_vp, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_crop_window": (C.c_int, [C.POINTER(Grid), _vp, _vp]),
     "mhs_step3_tile_windows": (C.c_int, [C.POINTER(Grid), _i64, C.c_double, C.c_double, C.POINTER(_i64),

@@ -45,6 +45,8 @@ struct Context {
     std::vector<FitLane *> lanes;         // lanes[0] is created by mhs_init, the others on demand (fit_lane)
     double2 *log_tab = nullptr;  // device, LOG_TAB_N entries
     double *exp_tab = nullptr;   // device, 4096 entries 2^(j/4096) (svr_kernel)
+    double *points_arena = nullptr;       // grow-only device scratch of mhs_residual_points
+    size_t points_arena_cap = 0;          // in doubles
     double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

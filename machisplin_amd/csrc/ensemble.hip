@@ -849,6 +849,20 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     }
 }
 
+// res.FINAL at the stations (V73:477-482 ... 608-611, 620): ((resp - pred_1) w_1 + (resp - pred_2) w_2 + ...) / wt.tot,
+// member after member as the reference accumulates it
+struct ResidualArgs { double w[8]; };
+__global__ __launch_bounds__(256) void residual_points_kernel(const double *__restrict__ pred, const double *__restrict__ resp,
+                                                              int64_t n, int n_models, ResidualArgs a, double wt_total,
+                                                              double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double y = resp[i];
+    double res = (y - pred[i]) * a.w[0];
+    for (int k = 1; k < n_models; ++k) res = res + (y - pred[(int64_t)k * n + i]) * a.w[k];
+    out[i] = res / wt_total;
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(const double *__restrict__ a, double divisor,
                                                         const double *__restrict__ b,
                                                         double *__restrict__ out, int64_t n) {
@@ -1639,6 +1653,42 @@ int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *o
     sd.has_nodata = 0; sd.all_from_planes = 1;
     if (int rc = launch_model(m, sd, pg, 1.0, 0, dout.p, s)) return rc;
     MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+int mhs_residual_points(const mhs_model *const *models, const double *weights, int n_models, double wt_total,
+                        const double *X, const double *resp, int64_t n, double *out_host) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(models && weights && X && resp && out_host && n_models >= 1 && n >= 1 && n < (1LL << 31), "bad arguments");
+    const int p = models[0]->p;
+    for (int k = 0; k < n_models; ++k) MHS_REQUIRE(models[k] && models[k]->p == p, "models disagree on the number of predictors");
+    hipStream_t s = ctx().stream;
+    // one grow-only scratch: X (n x p), the members' predictions (n x K), resp, out
+    Context &c = ctx();
+    const size_t need = (size_t)n * ((size_t)p + (size_t)n_models + 2);
+    if (need > c.points_arena_cap) {
+        if (c.points_arena) { (void)hipStreamSynchronize(s); (void)hipFree(c.points_arena); c.points_arena = nullptr; c.points_arena_cap = 0; }
+        MHS_HIP(hipMalloc((void **)&c.points_arena, need * sizeof(double)));
+        c.points_arena_cap = need;
+    }
+    double *dx = c.points_arena, *dpred = dx + (size_t)n * p, *dresp = dpred + (size_t)n * n_models, *dout = dresp + n;
+    MHS_HIP(hipMemcpyAsync(dx, X, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice, s));
+    MHS_HIP(hipMemcpyAsync(dresp, resp, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    PredGeom pg;
+    pg.xmin = pg.ymax = 0; pg.xres = pg.yres = 1; pg.r0 = pg.c0 = 0; pg.nr = 1; pg.nc = (int)n; pg.ld_out = n;
+    StackDev sd;
+    sd.data = dx; sd.C = p; sd.dtype = MHS_F64; sd.plane_stride = n; sd.ld = n; sd.nodata = NAN;
+    sd.has_nodata = 0; sd.all_from_planes = 1;
+    for (int k = 0; k < n_models; ++k)
+        if (int rc = launch_model(models[k], sd, pg, 1.0, 0, dpred + (size_t)k * n, s)) return rc;
+    ResidualArgs ra;
+    MHS_REQUIRE(n_models <= 8, "at most 8 members");
+    for (int k = 0; k < 8; ++k) ra.w[k] = k < n_models ? weights[k] : 0.0;
+    hipLaunchKernelGGL(residual_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpred, dresp, n, n_models, ra,
+                       wt_total, dout);
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipMemcpyAsync(out_host, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
     MHS_HIP(hipStreamSynchronize(s));
     return MHS_OK;
 }

@@ -132,6 +132,7 @@ int mhs_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
+    if (c.points_arena) (void)hipFree(c.points_arena);
     if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);

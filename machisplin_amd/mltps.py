@@ -34,11 +34,21 @@ def station_predictors(stack: RasterStack, xy):
 
 def ensemble_residuals(models, weights, wt_total, X, resp):
     """res.FINAL (V73:477-482 ... 608-611, 620): sum_k (resp - pred_k) * w_k / wt.tot."""
-    res = None
-    for m, w in zip(models, weights):
-        rk = (resp - m.predict_points(X)) * w
-        res = rk if res is None else res + rk
-    return res / wt_total
+    import ctypes as C
+    X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+    resp = np.ascontiguousarray(resp, dtype=np.float64)
+    if len(models) > 8:      # the one-call entry point takes up to 8 members
+        res = None
+        for m, w in zip(models, weights):
+            rk = (resp - m.predict_points(X)) * w
+            res = rk if res is None else res + rk
+        return res / wt_total
+    hs = (C.c_void_p * len(models))(*[m._h for m in models])
+    ws = (C.c_double * len(models))(*[float(w) for w in weights])
+    out = np.empty(X.shape[0])
+    _lib.check(_lib.lib().mhs_residual_points(hs, ws, len(models), float(wt_total), X.ctypes.data, resp.ctypes.data,
+                                              X.shape[0], out.ctypes.data))
+    return out
 
 
 def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None, tile_edge: int = 1500,

@@ -107,11 +107,26 @@ def test_weighted_ensemble_window_and_accumulate(hip):
 
 def test_predict_points_gives_station_residual_inputs(hip):
     g, stack, X, Xs, ys, params = _setup(hip)
+    mods = []
     for prm in params:
         m = hip.models.from_param_dict(prm)
+        mods.append(m)
         got = m.predict_points(Xs)
         want = oe.predict(prm, Xs)
         assert np.abs(got - want).max() <= _tol(want), prm["kind"]
+    # res.FINAL in one call (mhs_residual_points) == the member-by-member accumulation of V73:477-620
+    wts = [0.31, 0.22, 0.12, 0.18, 0.27, 0.41]
+    got = hip.mltps.ensemble_residuals(mods, wts, 1.51, Xs, ys)
+    want = None
+    for m, w in zip(mods, wts):
+        rk = (ys - m.predict_points(Xs)) * w
+        want = rk if want is None else want + rk
+    assert np.array_equal(got, want / 1.51)
+    ref = None
+    for prm, w in zip(params, wts):
+        rk = (ys - oe.predict(prm, Xs)) * w
+        ref = rk if ref is None else ref + rk
+    assert np.abs(got - ref / 1.51).max() <= _tol(ys)
 
 
 def test_seven_predictors_and_host_entry_point(hip):
