@@ -30,7 +30,8 @@ def test_fixed_lambda_cholesky_path(hip, n):
     assert _rel(got.predict(pts), otps.predict_points(want, pts)) < 1e-9
 
 
-@pytest.mark.parametrize("n,mode", [(12, "fields"), (200, "fields"), (200, "converged"), (813, "fields")])
+@pytest.mark.parametrize("n,mode", [(12, "fields"), (200, "fields"), (200, "converged"), (259, "fields"), (260, "fields"),
+                                    (260, "converged"), (813, "fields")])   # 259 / 260: last size of the single-block tridiagonal path, first of the band path
 def test_gcv_path(hip, n, mode):
     xy, y = synth_stations(n, 200 + n)
     want = otps.fit(xy, y, gcv_mode=mode)
