@@ -13,7 +13,7 @@ from . import models
 from .models import predict, ensemble_predict
 from .tps import Tps, interpolate, eval_mode, EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD
 from . import tiles, mltps, cv
-from .mltps import mltps_predict, tps_residual_surface
+from .mltps import mltps as mltps_layers, mltps_predict, tps_residual_surface
 
 __all__ = ["MhsError", "init", "Geometry", "RasterStack", "Tps", "interpolate", "eval_mode", "EVAL_AUTO", "EVAL_DIRECT", "EVAL_FAR_FIELD", "predict",
            "ensemble_predict", "models", "tiles", "mltps", "mltps_predict",

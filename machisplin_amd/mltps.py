@@ -117,12 +117,13 @@ def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None,
 
 
 def mltps_predict(stack: RasterStack, int_xy, resp, models, weights, wt_total, tps: bool = True,
-                  tile_edge: int = 1500, lambda_=None, gcv_mode: str = "fields"):
+                  tile_edge: int = 1500, lambda_=None, gcv_mode: str = "fields", tps_info: bool = False):
     """machisplin.mltps Steps 2-5 for ONE response layer, given the fitted ensemble members.
 
     Returns a dict mirroring ``omega[[i]]`` (V73:914-930, 946-955): ``final`` (device tensor),
     ``residuals`` (n x 3: residual, long, lat), ``summary`` (r2 ensemble / r2 final) plus the
-    intermediate ``pred_elev`` and ``final_tps`` planes."""
+    intermediate ``pred_elev`` and ``final_tps`` planes.  ``tps_info=True`` composes Step 3 tile by tile and
+    reports the per-tile station counts and lambdas in ``tps_info`` (same surface, slower)."""
     import torch
     g = stack.geom
     X, rows, cols = station_predictors(stack, int_xy)
@@ -141,7 +142,7 @@ def mltps_predict(stack: RasterStack, int_xy, resp, models, weights, wt_total, t
                     "summary": {"r2 ensemble": rsq_model}})
         return out
     # Step 3 + 4 (V73:636-897)
-    info = {}
+    info = {} if tps_info else None
     final_tps = tps_residual_surface(g, knots, res_final, cov1_at_stations=X[:, 0], tile_edge=tile_edge,
                                      lambda_=lambda_, gcv_mode=gcv_mode, info=info)
     # Step 5 (V73:902-930): sum, extract at the stations, keep the sum iff it improves R^2
@@ -156,3 +157,23 @@ def mltps_predict(stack: RasterStack, int_xy, resp, models, weights, wt_total, t
                 "summary": {"r2 ensemble": rsq_model, "r2 final": rsq_final},
                 "final": total if rsq_final > rsq_model else pred_elev})
     return out
+
+
+def mltps(stack: RasterStack, int_values, fitted, tps: bool = True, tile_edge: int = 1500, lambda_=None,
+          gcv_mode: str = "fields"):
+    """The layer loop of machisplin.mltps (V73:176-957) over fitted members: ``int_values`` is the reference's
+    table as an array (columns long, lat, then one response column per layer, V73:120-154); ``fitted[i]`` holds
+    layer i's ``models`` (device models in ``mods.run`` order), ``weights`` (rounded kept weights) and ``wt_total``
+    (V73:337-392).  Returns the list ``omega``: one :func:`mltps_predict` result per layer plus ``n_layers``
+    (V73:955) -- Step 1 (fitting, CV, weight search) happens before this call, in R or through :mod:`cv`."""
+    int_values = np.asarray(int_values, dtype=np.float64)
+    n_layers = int_values.shape[1] - 2
+    if n_layers != len(fitted):
+        raise ValueError("fitted must hold one entry per response column of int_values")
+    omega = []
+    for i, f in enumerate(fitted):
+        out = mltps_predict(stack, int_values[:, :2], int_values[:, 2 + i], f["models"], f["weights"], f["wt_total"],
+                            tps=tps, tile_edge=tile_edge, lambda_=lambda_, gcv_mode=gcv_mode)
+        out["n_layers"] = n_layers
+        omega.append(out)
+    return omega

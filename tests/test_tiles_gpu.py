@@ -91,7 +91,18 @@ def test_mltps_steps_2_to_5_end_to_end(hip, tile_edge):
     g, stack, host, X, xy, resp, params = _ensemble_inputs(hip, 220, 290, 600, 31)
     kept, wts, tot = hip.models.select_weights([0.31, 0.22, 0.12, 0.18, 0.27, 0.41])
     mods = [hip.models.from_param_dict(p) for p in params]
-    res = hip.mltps_predict(stack, xy, resp, mods, wts, tot, tps=True, tile_edge=tile_edge)
+    res = hip.mltps_predict(stack, xy, resp, mods, wts, tot, tps=True, tile_edge=tile_edge, tps_info=True)
+    # the default takes the one-call Step 3 + 4 (tiles fitted side by side): same planes, bit for bit
+    fast = hip.mltps_predict(stack, xy, resp, mods, wts, tot, tps=True, tile_edge=tile_edge)
+    assert "tps_info" in fast and fast["tps_info"] is None
+    assert np.array_equal(fast["final"].cpu().numpy(), res["final"].cpu().numpy(), equal_nan=True)
+    assert fast["rsq_final"] == res["rsq_final"]
+    # the layer loop of machisplin.mltps over two response columns (the second one shifted)
+    iv = np.column_stack([xy, resp, resp + 3.0])
+    omega = hip.mltps.mltps(stack, iv, [{"models": mods, "weights": wts, "wt_total": tot}] * 2, tile_edge=tile_edge)
+    assert len(omega) == 2 and omega[0]["n_layers"] == 2
+    assert np.array_equal(omega[0]["final"].cpu().numpy(), res["final"].cpu().numpy(), equal_nan=True)
+    assert omega[1]["rsq_model"] < omega[0]["rsq_model"]      # same members, response shifted by 3: a worse ensemble fit
     # ---- oracle: the same flow, literally (V73:447-930)
     og = _og(g)
     rows = np.array([og.row_from_y(v) for v in xy[:, 1]])
@@ -226,7 +237,7 @@ def test_cfg4_chain_tiles_create_per_tile_mltps_tiles_merge(hip):
             assert np.array_equal(sel, osel[h])
             sub = hip.RasterStack(t["geom"][h], stack.planes[:, r0:r1, c0:c1].contiguous(), stack.nodata)
             mods = [hip.models.from_param_dict(p) for p in smooth]
-            res = hip.mltps_predict(sub, xy[sel], y[sel], mods, wts, tot, tps=True, tile_edge=100)
+            res = hip.mltps_predict(sub, xy[sel], y[sel], mods, wts, tot, tps=True, tile_edge=100, tps_info=True)
             finals_gpu.append(res["final"].contiguous())
             # ---- oracle for this tile
             tg = ot.window_geom(og, (r0, r1, c0, c1))
