@@ -363,6 +363,41 @@ def main():
         tiled_ms = (time.perf_counter() - t1) * 1e3
         nRx, nCx = mhs.tiles.step3_tile_windows(wl.geom, 1500)[:2]
         info = {"nRx": int(nRx), "nCx": int(nCx)}
+        # for the record (outside the timed region): the spline of the last step evaluated by the direct sum
+        # (predict.Krig's own loop) next to the far-field-interpolated sum the timed steps use
+        eval_check = None
+        if world == 1 and wl.ops.last_fit is not None:
+            fit = wl.ops.last_fit
+            far = mhs.interpolate(wl.geom, fit)
+            plan = fit.eval_plan()
+            mhs.eval_mode(mhs.EVAL_DIRECT)
+            try:
+                direct = torch.empty_like(far)
+                mhs.interpolate(wl.geom, fit, out=direct)           # warm-up
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                mhs.interpolate(wl.geom, fit, out=direct)
+                torch.cuda.synchronize()
+                direct_ms = (time.perf_counter() - t1) * 1e3
+            finally:
+                mhs.eval_mode(mhs.EVAL_AUTO)
+            # the yardstick for both sums' rounding is S = sum_j |c_j phi_j| (the terms cancel by orders of magnitude in
+            # a fitted spline); S on 2 000 sampled cells, on the host
+            rng = np.random.default_rng(0)
+            rr, cc = rng.integers(0, wl.geom.nrow, 2000), rng.integers(0, wl.geom.ncol, 2000)
+            u = (wl.geom.x_from_col(cc) - fit.center[0]) / fit.scale[0]
+            v = (wl.geom.y_from_row(rr) - fit.center[1]) / fit.scale[1]
+            S = np.zeros(2000)
+            for j0 in range(0, fit.n, 500):
+                d2 = (u[:, None] - fit.knots[j0:j0 + 500, 0]) ** 2 + (v[:, None] - fit.knots[j0:j0 + 500, 1]) ** 2
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    S += (np.abs(fit.c[j0:j0 + 500]) * np.abs(np.where(d2 > 0, d2 * np.log(d2), 0.0))).sum(axis=1) * (0.5 / (8 * np.pi))
+            diff = float((far - direct).abs().max())
+            eval_check = {"timed_path": "far-field-interpolated, tiles %d x %d" % plan[:2] if plan[0] else "direct sum",
+                          "direct_sum_ms": direct_ms,
+                          "max_abs_diff_over_max_abs": diff / float(direct.abs().max()),
+                          "max_abs_diff_over_sum_abs_terms": diff / float(S.max())}
+            del far, direct
         m = wl.ops.X.shape[0] - 3
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
@@ -388,6 +423,7 @@ def main():
             "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
+            "tps_eval_check": eval_check,
             "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
