@@ -112,24 +112,39 @@ __global__ __launch_bounds__(256) void syr2_kernel(double *__restrict__ A, int64
 // =============================================================================================
 constexpr int BW = 8;
 
+#ifdef MHS_PANEL_TRACE
+__device__ unsigned long long g_panel_trace[2][32];
+__device__ int g_trace_slot = -1;
+__device__ int g_trace_inner = 0;
+#define PTRACE(k) do { if (threadIdx.x == 0 && g_trace_slot >= 0) g_panel_trace[g_trace_slot][k] = __builtin_readcyclecounter(); } while (0)
+#define PTRACE_IN(k) do { if (threadIdx.x == 0 && g_trace_slot >= 0 && g_trace_inner) g_panel_trace[g_trace_slot][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PTRACE(k) do {} while (0)
+#define PTRACE_IN(k) do {} while (0)
+#endif
 // sum K per-thread values over the block; result in every thread.  lds: >= 17 * K doubles.
 template <int K>
 __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *lds) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    PTRACE_IN(18);
     __syncthreads();
+    PTRACE_IN(19);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
     }
     __syncthreads();
+    PTRACE_IN(20);
     if ((int)threadIdx.x < K) {  // thread k adds the per-wave partials of value k, in wave order
         double s = 0.0;
         for (int w = 0; w < nw; ++w) s += lds[w * K + threadIdx.x];
         lds[16 * K + threadIdx.x] = s;
     }
+    PTRACE_IN(21);
     __syncthreads();
+    PTRACE_IN(22);
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = lds[16 * K + k];
 }
@@ -241,19 +256,74 @@ __global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A
 
 // Register-resident variant for t <= PANEL_THREADS * PANEL_RPT rows: the whole t x BW panel (320 KB at
 // t = 5000) lives in the register file of ONE CU -- each thread owns PANEL_RPT rows of all BW
-// columns -- so the BW Householder steps touch global memory only to load and store the panel;
-// every step is two block reductions.  (The streaming version above is latency-bound: a single
-// block keeps ~8 KB of loads in flight.)
-constexpr int PANEL_RPT = 7;
-constexpr int PANEL_THREADS = 768;
+// columns -- so the BW Householder steps touch global memory only to load and store the panel.
+// (The streaming version above is latency-bound: a single block keeps ~8 KB of loads in flight.)
+// The kernel is a chain of BW + 2 block reductions and nothing else hides their latency, so each one
+// is pared down to: DPP row/wave reduction (no LDS crossbar traffic), lane 63 of every wave stores its
+// partials, ONE barrier, then every wave adds the partials itself in its first lanes (fixed order) and
+// broadcasts the totals with v_readlane -- the partial buffers alternate, so no second barrier
+// guards their reuse, and everything a step derives from the totals (next pivot, R entries, the
+// downdated column norms) is recomputed by every wave instead of being published through LDS.
+#ifndef PANEL_RPT_V
+#define PANEL_RPT_V 7
+#define PANEL_THREADS_V 768
+#endif
+constexpr int PANEL_RPT = PANEL_RPT_V;
+constexpr int PANEL_THREADS = PANEL_THREADS_V;
+constexpr int PANEL_WAVES = PANEL_THREADS / 64;
 
 struct PanelShared {
-    double lds[17 * 16];
-    double Gs[BW][BW];   // Gs[l][j] = v_l' v_j (l < j)
-    double sgs[BW], taus[BW], zs[BW];
-    double Ts[BW * BW];
-    double piv, cn0[BW], rmat[BW][BW];   // pivot, initial column norms^2, R entries above the diagonal
+    double part[2][PANEL_WAVES][BW];   // per-wave partial sums of a reduction (alternating buffers)
+    double rowj[2][BW];                // entries of the pivot row before the step's update (positions 1..BW-1)
+    double nxt[2][2];                  // row J+1 before the update: its entries in the pivot column and the next one
+    double cn0[PANEL_WAVES][BW];       // per wave: initial squared column norms ...
+    double cn[PANEL_WAVES][BW];        // ... and the norms downdated by the R entries formed so far
+    double Gs[BW][BW];                 // Gs[l][j] = v_l' v_j (l < j)
+    double taus[BW];
 };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double x) {   // rows outside ROW_MASK read 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the wave, valid in lanes 48..63: xor 1, xor 2, mirror within 8, mirror within 16, then the row totals
+// are chained with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+__device__ __forceinline__ double wave_sum_top(double x) {
+    x += dpp_fetch<0xB1, 0xf>(x);
+    x += dpp_fetch<0x4E, 0xf>(x);
+    x += dpp_fetch<0x141, 0xf>(x);
+    x += dpp_fetch<0x140, 0xf>(x);
+    x += dpp_fetch<0x142, 0xa>(x);
+    x += dpp_fetch<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ double lane_value(double x, int lane) {   // uniform: lands in SGPRs
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
+                            __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// Wave-reduce K values and publish them to a partial buffer buf[wave][k]; after the caller's barrier,
+// block_total() adds them.
+template <int K>
+__device__ __forceinline__ void wave_publish(double (&v)[K], double (*buf)[BW]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum_top(v[k]);
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) buf[wave][k] = v[k];
+    }
+}
+// lane k (< K; the other lanes repeat lane K-1's work) returns total k, added in wave order
+template <int K, int NW>
+__device__ __forceinline__ double block_total(const double (*buf)[BW]) {
+    const int lane = threadIdx.x & 63, k = lane < K ? lane : K - 1;
+    double s = buf[0][k];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += buf[w][k];
+    return s;
+}
 
 // The BW Householder steps of the register-resident panel as ONE loop body: the columns are kept
 // rotated so that the pivot column is always x[.][0], the columns still to be updated follow it and
@@ -264,13 +334,19 @@ struct PanelShared {
 // ~n/BW times on whichever CU is free, so its instruction footprint is fetched cold every time.
 // Row i = tid + PANEL_THREADS r: only r = 0 can hold rows on or above the diagonal; rows past the end
 // of the panel hold zeros and stay zero.
-__device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared &sh) {
+//
+// One reduction per step, over raw products: S_p = sum_{i > J} x[i][0] x[i][p].  With v = e_J + scal x[J+1:][0]
+// the step needs w_p = v' x[:, p] = x[J][p] + scal S_p (for a reflector position: v_l' v_J, since v_l[J] is what
+// the panel stores there), so beta / tau / scal (a square root and two divisions) are off the critical path of
+// the reduction.  Column norms are computed once and DOWNDATED (LAPACK's dlaqps idea): below row J the
+// squared norm of column J is its initial value minus the squares of its entries in rows 0..J-1, the R entries,
+// which every wave recomputes from the step's totals; when the difference cancels (below 1 % of the initial
+// norm) the norm is summed afresh.
+__device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared &sh) {
     const int i0 = threadIdx.x;     // the row held in x[0][.]
-    // Column norms are computed once and DOWNDATED (LAPACK's dlaqps idea): below row J the squared norm of
-    // column J is its initial value minus the squares of its entries in rows 0..J-1 (R entries, published by the
-    // rows' owners together with the next pivot) -- one barrier instead of a block reduction per step.  When the
-    // difference cancels (below 1 % of the initial norm) the norm is summed afresh.  Everything stays in LDS:
-    // per-thread copies would cost 32 VGPRs the panel needs.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ph = 0;
+    double alpha;
     {
         double part[BW];
 #pragma unroll
@@ -279,27 +355,44 @@ __device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref
 #pragma unroll
             for (int r = 0; r < PANEL_RPT; ++r) part[p] = fma(x[r][p], x[r][p], part[p]);
         }
-        block_sum_vec<BW>(part, sh.lds);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int p = 0; p < BW; ++p) sh.cn0[p] = part[p];
-        }
+        if (i0 == 0) sh.nxt[ph][1] = x[0][0];
+        wave_publish<BW>(part, sh.part[ph]);
+        __syncthreads();
+        const double tot = block_total<BW, PANEL_WAVES>(sh.part[ph]);
+        if (lane < BW) { sh.cn0[wave][lane] = tot; sh.cn[wave][lane] = tot; }
+        alpha = sh.nxt[ph][1];
+        ph ^= 1;
     }
-    if (i0 == 0) sh.piv = x[0][0];
-    __syncthreads();
+    PTRACE(2);
 #pragma unroll 1
     for (int J = 0; J < BW; ++J) {
+        PTRACE(3 + J);
         if (J < nref) {
-            const double alpha = sh.piv, c0 = sh.cn0[J];
-            double ss = c0 - alpha * alpha;
-            for (int sr = 0; sr < J; ++sr) { const double rj = sh.rmat[sr][J]; ss -= rj * rj; }
-            if (!(ss > 0.01 * c0)) {   // uniform: every thread reads the same values
-                double part[1] = {0.0};
-                if (i0 > J) part[0] = x[0][0] * x[0][0];
+            // raw products with the pivot column, rows below J only
+            double red[BW - 1];
 #pragma unroll
-                for (int r = 1; r < PANEL_RPT; ++r) part[0] = fma(x[r][0], x[r][0], part[0]);
-                block_sum_vec<1>(part, sh.lds);
-                ss = part[0];
+            for (int p = 1; p < BW; ++p) red[p - 1] = i0 > J ? x[0][0] * x[0][p] : 0.0;
+#pragma unroll
+            for (int r = 1; r < PANEL_RPT; ++r) {
+#pragma unroll
+                for (int p = 1; p < BW; ++p) red[p - 1] = fma(x[r][0], x[r][p], red[p - 1]);
+            }
+            if (i0 == J) {
+#pragma unroll
+                for (int p = 1; p < BW; ++p) sh.rowj[ph][p] = x[0][p];
+            }
+            if (i0 == J + 1) { sh.nxt[ph][0] = x[0][0]; sh.nxt[ph][1] = x[0][1]; }
+            wave_publish<BW - 1>(red, sh.part[ph]);
+            const double c0 = sh.cn0[wave][J];
+            double ss = sh.cn[wave][J] - alpha * alpha;
+            if (!(ss > 0.01 * c0)) {   // uniform
+                double fresh[1] = {i0 > J ? x[0][0] * x[0][0] : 0.0};
+#pragma unroll
+                for (int r = 1; r < PANEL_RPT; ++r) fresh[0] = fma(x[r][0], x[r][0], fresh[0]);
+                __syncthreads();     // the step's own partials sit in part[ph]: use the other buffer, fenced
+                wave_publish<1>(fresh, sh.part[ph ^ 1]);
+                __syncthreads();
+                ss = lane_value(block_total<1, PANEL_WAVES>(sh.part[ph ^ 1]), 0);
             }
             double beta = alpha, tau = 0.0, scal = 0.0;
             if (ss != 0.0) {
@@ -307,46 +400,45 @@ __device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref
                 tau = (beta - alpha) / beta;
                 scal = 1.0 / (alpha - beta);
             }
-            // one fused reduction over the other BW-1 positions: v' P[:,k] for the columns still to be
-            // updated, v_l' v for the reflectors already formed
-            double red[BW - 1];
-            const double v0 = i0 < J ? 0.0 : (i0 == J ? 1.0 : x[0][0] * scal);
-            if (i0 == J) x[0][0] = beta; else if (i0 > J) x[0][0] = v0;
+            __syncthreads();
+            // lane k < BW-1 of every wave: total k, i.e. position p = k + 1
+            const int k = lane < BW - 1 ? lane : BW - 2;
+            const double xj = sh.rowj[ph][k + 1];
+            const double wk = fma(scal, block_total<BW - 1, PANEL_WAVES>(sh.part[ph]), xj);
+            const bool live = k + 1 < BW - J;              // a column still to be updated (else: reflector k+1+J-BW)
+            const double twk = live ? tau * wk : 0.0;
+            if (live && lane < BW - 1) {                   // R entry of column J+1+k in row J: downdate its norm
+                const double rk = xj - twk;
+                sh.cn[wave][J + 1 + k] -= rk * rk;
+            }
+            if (wave == 0 && lane < BW - 1 && !live) sh.Gs[k + 1 + J - BW][J] = wk;
+            if (threadIdx.x == 0) sh.taus[J] = tau;
+            // next pivot: row J+1 of position 1 after the update (meaningless, and unused, after the last step)
+            const double vn = sh.nxt[ph][0] * scal;
+            const double an = sh.nxt[ph][1] - twk * vn;    // lane 0's twk
+            alpha = lane_value(an, 0);
+            double tw[BW - 1];
 #pragma unroll
-            for (int p = 1; p < BW; ++p) {
-                const int l = p + J - BW;     // >= 0: position p holds reflector v_l
-                const double other = l < 0 ? x[0][p] : (i0 < l ? 0.0 : (i0 == l ? 1.0 : x[0][p]));
-                red[p - 1] = other * v0;
+            for (int p = 1; p < BW; ++p) tw[p - 1] = lane_value(twk, p - 1);
+            ph ^= 1;
+            // apply: rows above J untouched, row J has v = 1, rows below v = scal x
+            if (i0 == J) {
+                x[0][0] = beta;
+#pragma unroll
+                for (int p = 1; p < BW; ++p) x[0][p] -= tw[p - 1];
+            } else if (i0 > J) {
+                const double v0 = x[0][0] * scal;
+                x[0][0] = v0;
+#pragma unroll
+                for (int p = 1; p < BW; ++p) x[0][p] -= tw[p - 1] * v0;
             }
 #pragma unroll
             for (int r = 1; r < PANEL_RPT; ++r) {
                 const double vr = x[r][0] * scal;
                 x[r][0] = vr;
 #pragma unroll
-                for (int p = 1; p < BW; ++p) red[p - 1] = fma(vr, x[r][p], red[p - 1]);
+                for (int p = 1; p < BW; ++p) x[r][p] -= tw[p - 1] * vr;
             }
-            block_sum_vec<BW - 1>(red, sh.lds);
-            if (threadIdx.x == 0) {
-                sh.taus[J] = tau;
-                for (int l = 0; l < J; ++l) sh.Gs[l][J] = sh.lds[16 * (BW - 1) + (BW - J + l - 1)];
-            }
-#pragma unroll
-            for (int p = 1; p < BW; ++p) red[p - 1] = p < BW - J ? red[p - 1] * tau : 0.0;
-#pragma unroll
-            for (int p = 1; p < BW; ++p) x[0][p] -= red[p - 1] * v0;
-#pragma unroll
-            for (int r = 1; r < PANEL_RPT; ++r) {
-#pragma unroll
-                for (int p = 1; p < BW; ++p) x[r][p] -= red[p - 1] * x[r][0];   // x[r][0] now holds v
-            }
-            // row J of the updated columns (their R entries) and the next pivot, for the downdate
-            if (i0 == J) {
-#pragma unroll
-                for (int p = 1; p < BW; ++p)
-                    if (J + p < BW) sh.rmat[J][J + p] = x[0][p];
-            }
-            if (i0 == J + 1) sh.piv = x[0][1];
-            __syncthreads();
         } else if (threadIdx.x == 0) {   // uniform: nothing left to annihilate; H_J = I
             sh.taus[J] = 0.0;
             for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0;
@@ -359,6 +451,7 @@ __device__ __forceinline__ void panel_steps(double (&x)[PANEL_RPT][BW], int nref
             x[r][BW - 1] = first;
         }
     }
+    return ph;
 }
 
 __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *__restrict__ A, int64_t ld, int c0,
@@ -366,7 +459,13 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
                                                                        int64_t vs, double *__restrict__ Tm,
                                                                        double *__restrict__ g) {
     __shared__ PanelShared sh;
+#ifdef MHS_PANEL_TRACE
+    if (threadIdx.x == 0) g_trace_slot = (c0 == 3) ? 0 : ((t >= 2497 && t < 2505) ? 1 : -1);
+    __syncthreads();
+#endif
+    PTRACE(0);
     const int nref = min(BW, t - 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *P = A + (int64_t)c0 * ld + r0;
     double x[PANEL_RPT][BW];   // x[r][j] = P[tid + PANEL_THREADS r][j]
     // unconditional loads at a clamped row (one batch in flight), zeroed past the end of the panel
@@ -384,7 +483,10 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
             for (int j = 0; j < BW; ++j) x[r][j] = 0.0;
         }
     }
-    panel_steps(x, nref, sh);
+    PTRACE(1);
+    const int ph = panel_steps(x, nref, sh);   // the partial buffer the next reduction may use
+    PTRACE(11);
+    double z[BW];   // z = T' (V'g), uniform
     {   // sg = V' g (g as it was on entry)
         double sg[BW];
 #pragma unroll
@@ -400,33 +502,27 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
                 sg[j] = fma(vj, gi, sg[j]);
             }
         }
-        block_sum_vec<BW>(sg, sh.lds);
-        if (threadIdx.x == 0) {
+        wave_publish<BW>(sg, sh.part[ph]);
+        __syncthreads();
+        PTRACE(12);
+        // z = T' sg without T: inv(T) is upper triangular with 1/tau on the diagonal and G above it, so
+        // z_a = tau_a (sg_a - sum_{b < a} G[b][a] z_b).  Every wave runs the recurrence in its lanes 0..BW-1
+        // (lane b holds z_b and row b of G; the sum is a DPP reduction over the 8 lanes).
+        const int b = lane < BW ? lane : BW - 1;
+        const double sgb = block_total<BW, PANEL_WAVES>(sh.part[ph]), taub = sh.taus[b];
+        double zb = 0.0;
 #pragma unroll
-            for (int j = 0; j < BW; ++j) sh.sgs[j] = sg[j];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // larft: T upper triangular, T[r + BW*c];  z = T' (V'g)
-        for (int e = 0; e < BW * BW; ++e) sh.Ts[e] = 0.0;
-        for (int j = 0; j < BW; ++j) {
-            const double tj = sh.taus[j];
-            sh.Ts[j + BW * j] = tj;
-            for (int i = 0; i < j; ++i) {
-                double sum = 0.0;
-                for (int l = i; l < j; ++l) sum += sh.Ts[i + BW * l] * sh.Gs[l][j];
-                sh.Ts[i + BW * j] = -tj * sum;
-            }
-        }
-        for (int e = 0; e < BW * BW; ++e) Tm[e] = sh.Ts[e];
         for (int a = 0; a < BW; ++a) {
-            double sum = 0.0;
-            for (int b = 0; b <= a; ++b) sum += sh.Ts[b + BW * a] * sh.sgs[b];
-            sh.zs[a] = sum;
+            double c = b < a ? sh.Gs[b][a] * zb : 0.0;
+            c += dpp_fetch<0xB1, 0xf>(c);
+            c += dpp_fetch<0x4E, 0xf>(c);
+            c += dpp_fetch<0x141, 0xf>(c);
+            if (b == a) zb = taub * (sgb - c);
         }
+#pragma unroll
+        for (int a = 0; a < BW; ++a) z[a] = lane_value(zb, a);
     }
-    __syncthreads();
+    PTRACE(13);
     // store the panel (R on/above its diagonal, reflectors below), the dense V, and g <- Q' g
 #pragma unroll
     for (int r = 0; r < PANEL_RPT; ++r) {
@@ -439,20 +535,82 @@ __global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *_
                 Pj[(unsigned)i] = x[r][j];
                 const double vj = r > 0 ? x[r][j] : ((j >= nref || i < j) ? 0.0 : (i == j ? 1.0 : x[r][j]));
                 Vj[(unsigned)i] = vj;
-                gi -= vj * sh.zs[j];
+                gi -= vj * z[j];
             }
             g[(unsigned)i] = gi;
         }
     }
+    if (wave == 0) {
+        // larft, after the stores so that the panel's registers are free: lane i < BW forms row i of T
+        // (T[i][j] = -tau_j sum_{l=i}^{j-1} T[i][l] G[l][j], a recurrence along the row only)
+        const int i = lane < BW ? lane : BW - 1;
+        double Trow[BW];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) {
+            const double tj = sh.taus[j];
+            double sum = 0.0;
+#pragma unroll
+            for (int l = 0; l < j; ++l) sum += (l >= i ? Trow[l] : 0.0) * sh.Gs[l][j];
+            Trow[j] = j < i ? 0.0 : (j == i ? tj : -tj * sum);
+        }
+        if (lane < BW) {
+#pragma unroll
+            for (int j = 0; j < BW; ++j) Tm[i + BW * j] = Trow[j];
+        }
+    }
+    PTRACE(14);
+}
+#ifdef MHS_PANEL_TRACE
+extern "C" __attribute__((visibility("default"))) int mhs_debug_panel_trace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_trace), sizeof(unsigned long long) * 64);
+}
+#endif
+
+// Sum 64 per-lane values over the wave: two halving stages with the gfx950 lane-swap instructions
+// (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd and even rows between two registers, so
+// each output costs two swaps and an add), then a DPP reduction within the rows of 16 lanes.  Afterwards
+// every lane of row r = lane >> 4 holds, in w[i], the total of value 4 i + rho(r), rho = {0, 2, 1, 3}.
+// ~340 VALU instructions and no LDS traffic, against 768 ds_bpermute for 64 butterfly sums.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ int wave_sum64_slot(int row, int i) { return 4 * i + ((row & 1) << 1 | (row >> 1)); }
+__device__ __forceinline__ void wave_sum64(const double (&v)[64], double (&w)[16]) {
+    double u[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) u[i] = swap_add32(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = swap_add16(u[2 * i], u[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        w[i] += dpp_fetch<0xB1, 0xf>(w[i]);
+        w[i] += dpp_fetch<0x4E, 0xf>(w[i]);
+        w[i] += dpp_fetch<0x141, 0xf>(w[i]);
+        w[i] += dpp_fetch<0x140, 0xf>(w[i]);
+    }
 }
 
-// Y = A22 V as split-K partial sums: block (cg, sp) owns 32 columns (8 per wave) and one of
-// SYMM_SPLITS row ranges; lanes run over rows (barrier-free loop, 16 loads per lane and 64 rows in
-// flight).  Ypart[sp][j][i] partial sums are added up by the consumers; the block also
-// emits its share of M = V'Y (64 values) so that S = T'(V'Y)T needs no second pass over Y.
-constexpr int SYMM_SPLITS = 2;
+// Y = A22 V as split-K partial sums: block (cg, sp) owns 32 columns (8 per wave) and one of nsplit = gridDim.y
+// row ranges; lanes run over rows (barrier-free loop, 16 loads per lane and 64 rows in flight).
+// Ypart[sp][j][i] partial sums are added up by the consumers; the block also emits its share of M = V'Y
+// (64 values) so that S = T'(V'Y)T needs no second pass over Y.
+constexpr int SYMM_MAX_SPLITS = 8;
 constexpr int SYMM_CPW = 8;              // columns per wave
 constexpr int SYMM_COLS = 4 * SYMM_CPW;  // per block
+// Two row ranges measured best at n = 5000 (more blocks shorten this kernel but every consumer of Y and M then
+// adds more partials: 1 -> 85.8, 2 -> 81.6, 3 -> 82.5, 4 -> 84.3, 8 -> 91.3 ms per fit); MHS_SYMM_SPLITS overrides.
+static inline int symm_splits(int t) {
+    static const int forced = getenv("MHS_SYMM_SPLITS") ? atoi(getenv("MHS_SYMM_SPLITS")) : 0;
+    const int want = forced > 0 ? std::min(forced, SYMM_MAX_SPLITS) : 2;
+    return std::max(1, std::min(want, (t + 63) / 64));
+}
 
 __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict__ A, int64_t ld, int r0, int t,
                                                         const double *__restrict__ Vd, int64_t vs,
@@ -460,70 +618,54 @@ __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict
     __shared__ double Ms[4][BW * BW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col0 = blockIdx.x * SYMM_COLS + wave * SYMM_CPW;
-    const int rows_per = ((t + SYMM_SPLITS - 1) / SYMM_SPLITS + 63) & ~63;
+    const int rows_per = ((t + (int)gridDim.y - 1) / (int)gridDim.y + 63) & ~63;
     const int rbeg = blockIdx.y * rows_per, rend = min(t, rbeg + rows_per);
-    double acc[SYMM_CPW][BW];
+    const int ncol_ok = min(SYMM_CPW, t - col0);   // <= 0: this wave has no column
+    double acc[SYMM_CPW * BW];   // acc[c * BW + j]
 #pragma unroll
-    for (int c = 0; c < SYMM_CPW; ++c)
-#pragma unroll
-        for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
+    for (int e = 0; e < SYMM_CPW * BW; ++e) acc[e] = 0.0;
     const double *a0 = A + (int64_t)r0 * ld + r0;
     // lane = row: the lane's V row comes straight from global memory (V is t x 8, L2-resident), so the loop has
     // no barrier and the loads of the next 64 rows are in flight while these are multiplied.  Rows and columns
     // past the end are read at a clamped index and multiplied by zero.
-    const int ncol_ok = min(SYMM_CPW, t - col0);   // <= 0: this wave has no column
     const double *ac[SYMM_CPW];
 #pragma unroll
     for (int c = 0; c < SYMM_CPW; ++c) ac[c] = a0 + (int64_t)(col0 + (c < ncol_ok ? c : 0)) * ld;
-    if (ncol_ok > 0) {
 #pragma unroll 2
-        for (int rb = rbeg; rb < rend; rb += 64) {
-            const int r = rb + lane;
-            const unsigned rr = (unsigned)min(r, rend - 1);
-            const double keep = r < rend ? 1.0 : 0.0;
-            double a[SYMM_CPW], v[BW];
+    for (int rb = ncol_ok > 0 ? rbeg : rend; rb < rend; rb += 64) {
+        const int r = rb + lane;
+        const unsigned rr = (unsigned)min(r, rend - 1);
+        const double keep = r < rend ? 1.0 : 0.0;
+        double a[SYMM_CPW], v[BW];
 #pragma unroll
-            for (int c = 0; c < SYMM_CPW; ++c) a[c] = ac[c][rr];
+        for (int c = 0; c < SYMM_CPW; ++c) a[c] = ac[c][rr];
 #pragma unroll
-            for (int j = 0; j < BW; ++j) v[j] = Vd[(int64_t)j * vs + rr] * keep;
+        for (int j = 0; j < BW; ++j) v[j] = Vd[(int64_t)j * vs + rr] * keep;
 #pragma unroll
-            for (int j = 0; j < BW; ++j)
+        for (int j = 0; j < BW; ++j)
 #pragma unroll
-                for (int c = 0; c < SYMM_CPW; ++c) acc[c][j] = fma(a[c], v[j], acc[c][j]);
-        }
+            for (int c = 0; c < SYMM_CPW; ++c) acc[c * BW + j] = fma(a[c], v[j], acc[c * BW + j]);
     }
-#pragma unroll
-    for (int c = 0; c < SYMM_CPW; ++c)
-        if (c >= ncol_ok) {
-#pragma unroll
-            for (int j = 0; j < BW; ++j) acc[c][j] = 0.0;
-        }
-    // wave-reduce; lane j keeps column sums y[c] for V-column j, then M += V[:,col]' (x) y
-    double *yp = Ypart + (int64_t)blockIdx.y * BW * vs;
-    double mpart[BW];  // lane l < 64: M[a = l & 7][b = l >> 3] contribution of this wave
-    double mval = 0.0;
+    double w[16];
+    wave_sum64(acc, w);
+    // row r of the wave now holds y_c[j] for every column c and j in {rho, rho + 4} (value 4 i + rho: c = i / 2,
+    // j = rho + 4 (i & 1)).  Its first lane stores them; lanes a = 0..7 of the row form this wave's share of
+    // M = V'Y for those two j: M[a][j] += V[a][col c] y_c[j].
+    const int row = lane >> 4, rho = (row & 1) << 1 | (row >> 1), la = lane & 15;
+    double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int c = 0; c < SYMM_CPW; ++c) {
-        double y[BW];
-#pragma unroll
-        for (int j = 0; j < BW; ++j) y[j] = wave_sum(acc[c][j]);
-        const int col = col0 + c;
-        if (col < t) {
-            if (lane < BW) {
-                double yl = y[0];
-#pragma unroll
-                for (int j = 1; j < BW; ++j) yl = lane == j ? y[j] : yl;
-                yp[lane * vs + col] = yl;
+        if (c < ncol_ok) {
+            if (la == 0) {
+                Ypart[(int64_t)blockIdx.y * BW * vs + (int64_t)rho * vs + col0 + c] = w[2 * c];
+                Ypart[(int64_t)blockIdx.y * BW * vs + (int64_t)(rho + 4) * vs + col0 + c] = w[2 * c + 1];
             }
-            const double va = Vd[(lane & 7) * vs + col];
-            double yb = y[0];
-#pragma unroll
-            for (int j = 1; j < BW; ++j) yb = (lane >> 3) == j ? y[j] : yb;
-            mval = fma(va, yb, mval);
+            const double va = Vd[(int64_t)(la & 7) * vs + col0 + c];
+            m0 = fma(va, w[2 * c], m0);
+            m1 = fma(va, w[2 * c + 1], m1);
         }
     }
-    (void)mpart;
-    Ms[wave][lane] = mval;
+    if (la < BW) { Ms[wave][la + BW * rho] = m0; Ms[wave][la + BW * (rho + 4)] = m1; }
     __syncthreads();
     if (threadIdx.x < BW * BW)
         Mpart[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * (BW * BW) + threadIdx.x] =
@@ -567,8 +709,8 @@ __global__ __launch_bounds__(1024) void band_s_kernel(const double *__restrict__
 // row set I and column set J from the split-K partial sums of Y.  Bitwise symmetric.
 __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
                                                           const double *__restrict__ Vd,
-                                                          const double *__restrict__ Ypart, int64_t vs,
-                                                          const double *__restrict__ Tm,
+                                                          const double *__restrict__ Ypart, int nsplit,
+                                                          int64_t vs, const double *__restrict__ Tm,
                                                           const double *__restrict__ Sm, int jblock0) {
     __shared__ double Vs[2][64][BW + 1], Ws[2][64][BW + 1];
     __shared__ double Ts[BW * BW], Ss[BW * BW];
@@ -581,13 +723,12 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
         double y[BW], v[BW];
 #pragma unroll
         for (int b = 0; b < BW; ++b) {
-            double sum = 0.0;
-            if (row < t) {
-#pragma unroll
-                for (int sp = 0; sp < SYMM_SPLITS; ++sp) sum += Ypart[(int64_t)sp * BW * vs + b * vs + row];
-            }
-            y[b] = sum;
+            y[b] = row < t ? Ypart[b * vs + row] : 0.0;
             v[b] = row < t ? Vd[b * vs + row] : 0.0;
+        }
+        for (int sp = 1; sp < nsplit; ++sp) {
+#pragma unroll
+            for (int b = 0; b < BW; ++b) y[b] += row < t ? Ypart[(int64_t)sp * BW * vs + b * vs + row] : 0.0;
         }
 #pragma unroll
         for (int a = 0; a < BW; ++a) {
@@ -629,6 +770,86 @@ __global__ void band_extract_kernel(const double *__restrict__ A, int64_t ld, in
 }
 
 // r <- Q_0 Q_1 ... Q_{P-1} r,  Q_p = I - V_p T_p V_p'  (single block; reflectors read in place)
+// r <- Q r, Q = H_0 H_1 ... (block reflectors, applied last to first).  One block (each step needs a sum over all
+// rows), so it is a chain of npanels latencies: the vector stays in registers (thread = fixed rows), each panel's
+// reflectors are read once and used for both the products and the update, the next panel's lines are touched
+// into L2 while this one is reduced, and the reduction is the single-barrier one of the panel kernel.
+constexpr int BT_THREADS = 1024, BT_RPT = 5;
+__global__ __launch_bounds__(BT_THREADS) void band_backtransform_reg_kernel(const double *__restrict__ A,
+                                                                            int64_t ld, int off0, int m,
+                                                                            int npanels,
+                                                                            const double *__restrict__ Tall,
+                                                                            double *__restrict__ r) {
+    __shared__ double part[2][BT_THREADS / 64][BW];
+    double rr[BT_RPT];
+#pragma unroll
+    for (int k = 0; k < BT_RPT; ++k) {
+        const int q = threadIdx.x + BT_THREADS * k;
+        rr[k] = q < m ? r[q] : 0.0;
+    }
+    int ph = 0;
+    for (int p = npanels - 1; p >= 0; --p) {
+        const int base = p * BW + BW;
+        const double *P = A + (int64_t)(off0 + p * BW) * ld + off0 + base;
+        const double *T = Tall + (int64_t)p * BW * BW;
+        double v[BT_RPT][BW], s[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) s[a] = 0.0;
+#pragma unroll
+        for (int k = 0; k < BT_RPT; ++k) {
+            const int q = threadIdx.x + BT_THREADS * k, i = q - base;
+            const bool ok = i >= 0 && q < m;
+            const unsigned ii = ok ? (unsigned)i : 0u;
+#pragma unroll
+            for (int a = 0; a < BW; ++a) v[k][a] = P[(int64_t)a * ld + ii];
+        }
+        if (p > 0) {   // touch one double per 128-byte line of the next panel
+            const double *Pn = P - (int64_t)BW * ld - BW;
+            const int tn = m - base + BW, nline = (tn + 15) / 16;
+            double sink = 0.0;
+            for (int e = threadIdx.x; e < nline * BW; e += BT_THREADS) {
+                const int a = e / nline, l = e - a * nline;
+                sink += Pn[(int64_t)a * ld + min(l * 16, tn - 1)];
+            }
+            if (sink == 1.2345e-300) part[0][0][0] = sink;   // never true: keeps the loads
+        }
+#pragma unroll
+        for (int k = 0; k < BT_RPT; ++k) {
+            const int q = threadIdx.x + BT_THREADS * k, i = q - base;
+            const bool ok = i >= 0 && q < m;
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                v[k][a] = (!ok || i < a) ? 0.0 : (i == a ? 1.0 : v[k][a]);
+                s[a] = fma(v[k][a], rr[k], s[a]);
+            }
+        }
+        wave_publish<BW>(s, part[ph]);
+        __syncthreads();
+        const double sb = block_total<BW, BT_THREADS / 64>(part[ph]);
+        ph ^= 1;
+        double sv[BW];
+#pragma unroll
+        for (int b = 0; b < BW; ++b) sv[b] = lane_value(sb, b);
+        double z[BW];   // z = T s, T upper triangular
+#pragma unroll
+        for (int a = 0; a < BW; ++a) {
+            z[a] = 0.0;
+#pragma unroll
+            for (int b = a; b < BW; ++b) z[a] += T[a + BW * b] * sv[b];
+        }
+#pragma unroll
+        for (int k = 0; k < BT_RPT; ++k) {
+#pragma unroll
+            for (int a = 0; a < BW; ++a) rr[k] -= v[k][a] * z[a];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BT_RPT; ++k) {
+        const int q = threadIdx.x + BT_THREADS * k;
+        if (q < m) r[q] = rr[k];
+    }
+}
+
 __global__ __launch_bounds__(1024) void band_backtransform_kernel(const double *__restrict__ A, int64_t ld,
                                                                   int off0, int m, int npanels,
                                                                   const double *__restrict__ Tall,
@@ -1050,7 +1271,6 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     };
     const int64_t ld = (n + 15) & ~(int64_t)15;
     const int64_t vs = n;
-    const int max_cg = (m + SYMM_COLS - 1) / SYMM_COLS;
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
@@ -1067,8 +1287,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         tau.p = ar.take<double>((size_t)n + 3);
         Vd.p = ar.take<double>((size_t)BW * vs);
         Vd2.p = ar.take<double>((size_t)BW * vs);
-        Yp.p = ar.take<double>((size_t)SYMM_SPLITS * BW * vs);
-        Mp.p = ar.take<double>((size_t)std::max(max_cg, 1) * SYMM_SPLITS * BW * BW);
+        Yp.p = ar.take<double>((size_t)SYMM_MAX_SPLITS * BW * vs);
+        Mp.p = ar.take<double>((size_t)((m + SYMM_COLS - 1) / SYMM_COLS + 1) * SYMM_MAX_SPLITS * BW * BW);
         Sm.p = ar.take<double>((size_t)BW * BW);
         Tall.p = ar.take<double>((size_t)std::max(npanels, 1) * BW * BW);
         abd.p = ar.take<double>((size_t)m * (BW + 1));
@@ -1170,15 +1390,15 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             else
                 hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
             if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));     // rest of step p-1's update
-            const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS;
-            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, SYMM_SPLITS), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
-            hipLaunchKernelGGL(band_s_kernel, dim3(1), dim3(1024), 0, s, Mp.p, ncg * SYMM_SPLITS, Tp, Sm.p);
+            const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS, nsplit = symm_splits(t);
+            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
+            hipLaunchKernelGGL(band_s_kernel, dim3(1), dim3(1024), 0, s, Mp.p, ncg * nsplit, Tp, Sm.p);
             const unsigned nb = (unsigned)((t + 63) / 64);
-            hipLaunchKernelGGL(band_update_kernel, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, vs, Tp, Sm.p, 0);
+            hipLaunchKernelGGL(band_update_kernel, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Sm.p, 0);
             MHS_HIP(hipEventRecord(ev_block, s));
             MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
             if (nb > 1)
-                hipLaunchKernelGGL(band_update_kernel, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, vs, Tp, Sm.p, 1);
+                hipLaunchKernelGGL(band_update_kernel, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Sm.p, 1);
             MHS_HIP(hipEventRecord(ev_rest, s2));
         }
         if (npanels > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (npanels - 1) + 1], 0));
@@ -1197,8 +1417,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         BandGcv::Work wk;
         if (!bg.eval(lam, &gcv, &eff_df, q.data(), wk)) { set_error("mhs_tps_fit: band matrix not positive definite"); return MHS_ERR_NUMERIC; }
         MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
-        if (npanels > 0)
-            hipLaunchKernelGGL(band_backtransform_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
+        if (npanels > 0) {
+            if (m <= BT_THREADS * BT_RPT)
+                hipLaunchKernelGGL(band_backtransform_reg_kernel, dim3(1), dim3(BT_THREADS), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
+            else
+                hipLaunchKernelGGL(band_backtransform_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
+        }
         MHS_HIP(hipGetLastError());
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
