@@ -303,16 +303,47 @@ __device__ __forceinline__ double lane_value(double x, int lane) {   // uniform:
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
                             __builtin_amdgcn_readlane(__double2loint(x), lane));
 }
-// Wave-reduce K values and publish them to a partial buffer buf[wave][k]; after the caller's barrier,
-// block_total() adds them.
+// gfx950 lane swaps: v_permlane32_swap exchanges the upper half-wave of one register with the lower half-wave of
+// another, v_permlane16_swap the odd rows of one with the even rows of the other -- so "two swaps and an add" folds
+// two values into one register holding the half-sums of the first in one half (even rows) and of the second in
+// the other: a reduction of several values costs about one DPP row reduction per FOUR values.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// Wave-reduce K <= 8 values and publish them to a partial buffer buf[wave][k]; after the caller's barrier,
+// block_total() adds them.  Two lane-swap stages leave row r = lane >> 4 with values 4 i + rho(r),
+// rho = {0, 2, 1, 3}, i = 0, 1; a DPP reduction within the rows finishes them.
 template <int K>
 __device__ __forceinline__ void wave_publish(double (&v)[K], double (*buf)[BW]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (K == 1) {
+        const double tot = wave_sum_top(v[0]);
+        if (lane == 63) buf[wave][0] = tot;
+    } else {
+        static_assert(K <= 8, "at most 8 values");
+        double u[4], w[2];
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum_top(v[k]);
-    if (lane == 63) {
+        for (int i = 0; i < 4; ++i) u[i] = swap_add32(2 * i < K ? v[2 * i] : 0.0, 2 * i + 1 < K ? v[2 * i + 1] : 0.0);
 #pragma unroll
-        for (int k = 0; k < K; ++k) buf[wave][k] = v[k];
+        for (int i = 0; i < 2; ++i) {
+            w[i] = swap_add16(u[2 * i], u[2 * i + 1]);
+            w[i] += dpp_fetch<0xB1, 0xf>(w[i]);
+            w[i] += dpp_fetch<0x4E, 0xf>(w[i]);
+            w[i] += dpp_fetch<0x141, 0xf>(w[i]);
+            w[i] += dpp_fetch<0x140, 0xf>(w[i]);
+        }
+        if ((lane & 15) == 0) {
+            const int row = lane >> 4, rho = (row & 1) << 1 | (row >> 1);
+            if (rho < K) buf[wave][rho] = w[0];
+            if (4 + rho < K) buf[wave][4 + rho] = w[1];
+        }
     }
 }
 // lane k (< K; the other lanes repeat lane K-1's work) returns total k, added in wave order
@@ -367,7 +398,11 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
 #pragma unroll 1
     for (int J = 0; J < BW; ++J) {
         PTRACE(3 + J);
+#ifdef MHS_PANEL_TRACE
+        if (threadIdx.x == 0) g_trace_inner = (J == 3);
+#endif
         if (J < nref) {
+            PTRACE_IN(15);
             // raw products with the pivot column, rows below J only
             double red[BW - 1];
 #pragma unroll
@@ -382,7 +417,9 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
                 for (int p = 1; p < BW; ++p) sh.rowj[ph][p] = x[0][p];
             }
             if (i0 == J + 1) { sh.nxt[ph][0] = x[0][0]; sh.nxt[ph][1] = x[0][1]; }
+            PTRACE_IN(16);
             wave_publish<BW - 1>(red, sh.part[ph]);
+            PTRACE_IN(17);
             const double c0 = sh.cn0[wave][J];
             double ss = sh.cn[wave][J] - alpha * alpha;
             if (!(ss > 0.01 * c0)) {   // uniform
@@ -400,7 +437,9 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
                 tau = (beta - alpha) / beta;
                 scal = 1.0 / (alpha - beta);
             }
+            PTRACE_IN(18);
             __syncthreads();
+            PTRACE_IN(19);
             // lane k < BW-1 of every wave: total k, i.e. position p = k + 1
             const int k = lane < BW - 1 ? lane : BW - 2;
             const double xj = sh.rowj[ph][k + 1];
@@ -421,6 +460,7 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
 #pragma unroll
             for (int p = 1; p < BW; ++p) tw[p - 1] = lane_value(twk, p - 1);
             ph ^= 1;
+            PTRACE_IN(20);
             // apply: rows above J untouched, row J has v = 1, rows below v = scal x
             if (i0 == J) {
                 x[0][0] = beta;
@@ -439,6 +479,7 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
 #pragma unroll
                 for (int p = 1; p < BW; ++p) x[r][p] -= tw[p - 1] * vr;
             }
+            PTRACE_IN(21);
         } else if (threadIdx.x == 0) {   // uniform: nothing left to annihilate; H_J = I
             sh.taus[J] = 0.0;
             for (int l = 0; l < BW; ++l) sh.Gs[l][J] = 0.0;
@@ -571,16 +612,6 @@ extern "C" __attribute__((visibility("default"))) int mhs_debug_panel_trace(unsi
 // each output costs two swaps and an add), then a DPP reduction within the rows of 16 lanes.  Afterwards
 // every lane of row r = lane >> 4 holds, in w[i], the total of value 4 i + rho(r), rho = {0, 2, 1, 3}.
 // ~340 VALU instructions and no LDS traffic, against 768 ds_bpermute for 64 butterfly sums.
-__device__ __forceinline__ double swap_add32(double a, double b) {
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ double swap_add16(double a, double b) {
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
 __device__ __forceinline__ int wave_sum64_slot(int row, int i) { return 4 * i + ((row & 1) << 1 | (row >> 1)); }
 __device__ __forceinline__ void wave_sum64(const double (&v)[64], double (&w)[16]) {
     double u[32];
@@ -1375,7 +1406,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         // critical path is panel + symm + s + one column block instead of panel + symm + s + the whole update.
         hipStream_t s2 = L.s2;
         std::vector<hipEvent_t> &pool = L.pool;
-        while ((int)pool.size() < 2 * npanels) {
+        while ((int)pool.size() < 2 * npanels + 1) {
             hipEvent_t e;
             MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             pool.push_back(e);
@@ -1389,6 +1420,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
             else
                 hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
+            if (p == std::max(0, npanels - 12)) MHS_HIP(hipEventRecord(pool[2 * npanels], s));   // ~1 ms before the end
             if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));     // rest of step p-1's update
             const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS, nsplit = symm_splits(t);
             hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
@@ -1407,10 +1439,15 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
         MHS_HIP(hipMemcpyAsync(ab.data(), abd.p, sizeof(double) * ab.size(), hipMemcpyDeviceToHost, s));
         MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+        // wake the GCV workers while the last panels are still running
+        struct Lease { GcvPool *p = nullptr; ~Lease() { gcv_pool_release(p); } } lease;
+        if (npanels > 0) MHS_HIP(hipEventSynchronize(pool[2 * npanels]));
+        lease.p = gcv_pool_lease(gcv_threads);
         MHS_HIP(hipStreamSynchronize(s));
         lap("band reduction (GPU)");
         BandGcv bg;
         bg.ab = ab.data(); bg.g = g.data(); bg.m = m; bg.n = n; bg.N = N; bg.bw = BW; bg.pure_ss = pure_ss; bg.threads = gcv_threads;
+        bg.pool = lease.p;
         lam = bg.find_lambda(gcv_mode);
         if (std::isnan(lam)) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
         lap("GCV search (host, banded)");

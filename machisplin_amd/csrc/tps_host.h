@@ -5,6 +5,8 @@
 
 namespace mhs {
 
+struct GcvPool;
+
 // GCV machinery on the tridiagonal form; see tps_gcv_host.hip
 struct TridiagGcv {
     const double *a = nullptr;  // diagonal of T, m
@@ -28,13 +30,20 @@ struct BandGcv {
     int64_t m = 0, n = 0, N = 0;
     int bw = 1;
     double pure_ss = 0.0;
-    int threads = 0;  // host threads for the independent evaluations (0 = auto, capped at 16)
+    int threads = 0;  // host threads for the independent evaluations (0 = the process-wide pool)
+    struct GcvPool *pool = nullptr;   // a pool already leased (and awake) for this search, or NULL
     struct Work { std::vector<double> L, Z, q; };
     bool eval(double lam, double *gcv, double *tra, double *q_out, Work &w) const;
+    bool finish(double lam, double qq, double tr_inv, double *gcv, double *tra) const;
     double find_lambda(int mode) const;
     int inertia_below(double x, Work &w) const;  // eigenvalues < x (unpivoted banded LDL')
     double eig_kth(int64_t k) const;
 };
+
+// Lease the worker pool of a GCV search ahead of time: waking sleeping workers costs about a millisecond, which
+// the fit hides behind the tail of the band reduction.  gcv_pool_release(NULL) is a no-op.
+GcvPool *gcv_pool_lease(int threads);
+void gcv_pool_release(GcvPool *p);
 
 void qr_n3(std::vector<double> &T, int64_t n, std::vector<double> v[3], double tau[3], double R[9]);
 void apply_reflector(const std::vector<double> &v, double tau, double *x, int64_t n);
