@@ -104,11 +104,13 @@ __global__ __launch_bounds__(256) void syr2_kernel(double *__restrict__ A, int64
 // takes n/BW panel steps of four launches, each pass doing BW times the work, and the GCV
 // criterion is then evaluated directly on the band (banded Cholesky + Takahashi trace on the host,
 // tps_gcv_host.hip) -- no tridiagonal form, no eigenvalues.  Per panel at column c (t = m-c-BW):
-//   band_panel_kernel   Householder QR of P = B[c+BW:, c:c+BW] -> V (t x BW), T (compact WY),
-//                       reflectors kept in place, R left in the band; g <- Q' g
-//   band_symm_kernel    Y = A22 V               (A22 = B[c+BW:, c+BW:], read once, 8 B/element)
-//   band_w_kernel       W = Y T - 1/2 V (T' V' Y T)
-//   band_update_kernel  A22 <- A22 - V W' - W V'  (= Q' A22 Q, read + write once)
+//   band_panel_reg_kernel   Householder QR of P = B[c+BW:, c:c+BW] -> V (t x BW), T (compact WY),
+//                           reflectors kept in place, R left in the band; g <- Q' g       (one block)
+//   band_symm_kernel        Y = A22 V as split-K partial sums, and the partial sums of M = V'Y
+//                           (A22 = B[c+BW:, c+BW:], read once, 8 B/element)
+//   band_update_kernel<1>   S = sym(T' M T), W = Y T - 1/2 V S, first 64-column block of
+//                           A22 <- A22 - V W' - W V' (= Q' A22 Q); the next panel starts behind it
+//   band_update_kernel<0>   the other column blocks, on the second stream (read + write once)
 // =============================================================================================
 constexpr int BW = 8;
 
@@ -265,8 +267,8 @@ __global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A
 // guards their reuse, and everything a step derives from the totals (next pivot, R entries, the
 // downdated column norms) is recomputed by every wave instead of being published through LDS.
 #ifndef PANEL_RPT_V
-#define PANEL_RPT_V 7
-#define PANEL_THREADS_V 768
+#define PANEL_RPT_V 10
+#define PANEL_THREADS_V 512
 #endif
 constexpr int PANEL_RPT = PANEL_RPT_V;
 constexpr int PANEL_THREADS = PANEL_THREADS_V;
@@ -703,73 +705,83 @@ __global__ __launch_bounds__(256) void band_symm_kernel(const double *__restrict
             (Ms[0][threadIdx.x] + Ms[1][threadIdx.x]) + (Ms[2][threadIdx.x] + Ms[3][threadIdx.x]);
 }
 
-// S = sym(T' M T), M = sum of the Mpart blocks (M[a + BW*b] = sum_i V[a][i] Y[b][i]).  One block.
-__global__ __launch_bounds__(1024) void band_s_kernel(const double *__restrict__ Mpart, int nparts,
-                                                      const double *__restrict__ Tm, double *__restrict__ Sm) {
-    __shared__ double red[16][BW * BW];
-    __shared__ double M[BW * BW], Ts[BW * BW], MT[BW * BW];
-    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    double sum = 0.0;
-    for (int p = grp; p < nparts; p += 16) sum += Mpart[(int64_t)p * (BW * BW) + e];
-    red[grp][e] = sum;
-    if (threadIdx.x < BW * BW) Ts[threadIdx.x] = Tm[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < BW * BW) {
-        double m = 0.0;
-        for (int q = 0; q < 16; ++q) m += red[q][threadIdx.x];
-        M[threadIdx.x] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x < BW * BW) {  // MT = M T  (T upper: T[b + BW*c], b <= c)
-        const int a = threadIdx.x % BW, c = threadIdx.x / BW;
-        double m = 0.0;
-        for (int b2 = 0; b2 <= c; ++b2) m += M[a + BW * b2] * Ts[b2 + BW * c];
-        MT[a + BW * c] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x < BW * BW) {  // S = T' MT, symmetrised
-        const int a = threadIdx.x % BW, c = threadIdx.x / BW;
-        double s1 = 0.0, s2 = 0.0;
-        for (int d = 0; d <= a; ++d) s1 += Ts[d + BW * a] * MT[d + BW * c];
-        for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a];
-        Sm[a + BW * c] = 0.5 * (s1 + s2);
-    }
-}
-
-// A22 <- A22 - V W' - W V' on 64 x 64 tiles, W = Y T - 1/2 V S formed on the fly for the tile's
-// row set I and column set J from the split-K partial sums of Y.  Bitwise symmetric.
+// A22 <- A22 - V W' - W V' on 64 x 64 tiles, W = Y T - 1/2 V S.  Bitwise symmetric.  The launch for the first
+// column block (FIRST; it is on the critical path, the next panel waits for it) forms W for its tile's row set
+// from the split-K partial sums of Y and also stores it; the launch for the other column blocks, which runs
+// behind it on the second stream, just reads W.  Every FIRST block also forms S = sym(T' M T), M = V'Y = the sum
+// of the symmetric product's Mpart blocks, for itself (same order in every block, hence the same bits): a
+// few hundred L2-resident loads per thread cost less than a single-block kernel in the dependency chain.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
                                                           const double *__restrict__ Vd,
                                                           const double *__restrict__ Ypart, int nsplit,
                                                           int64_t vs, const double *__restrict__ Tm,
-                                                          const double *__restrict__ Sm, int jblock0) {
+                                                          const double *__restrict__ Mpart, int nparts,
+                                                          double *__restrict__ Wd) {
     __shared__ double Vs[2][64][BW + 1], Ws[2][64][BW + 1];
     __shared__ double Ts[BW * BW], Ss[BW * BW];
-    if (threadIdx.x < BW * BW) { Ts[threadIdx.x] = Tm[threadIdx.x]; Ss[threadIdx.x] = Sm[threadIdx.x]; }
-    __syncthreads();
-    const int i0 = blockIdx.x * 64, j0 = (blockIdx.y + jblock0) * 64;
+    const int i0 = blockIdx.x * 64, j0 = FIRST ? 0 : (blockIdx.y + 1) * 64;
+    if (FIRST) {
+        __shared__ double red[4][BW * BW], Mm[BW * BW], MT[BW * BW];
+        const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        double sum = 0.0;
+#pragma unroll 8
+        for (int p = grp; p < nparts; p += 4) sum += Mpart[(int64_t)p * (BW * BW) + e];
+        red[grp][e] = sum;
+        if (threadIdx.x < BW * BW) Ts[threadIdx.x] = Tm[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < BW * BW) Mm[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        __syncthreads();
+        if (threadIdx.x < BW * BW) {  // MT = M T  (T upper: T[b + BW*c], b <= c)
+            const int a = e % BW, c = e / BW;
+            double m = 0.0;
+            for (int b2 = 0; b2 <= c; ++b2) m += Mm[a + BW * b2] * Ts[b2 + BW * c];
+            MT[a + BW * c] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < BW * BW) {  // S = T' MT, symmetrised
+            const int a = e % BW, c = e / BW;
+            double s1 = 0.0, s2 = 0.0;
+            for (int d = 0; d <= a; ++d) s1 += Ts[d + BW * a] * MT[d + BW * c];
+            for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a];
+            Ss[a + BW * c] = 0.5 * (s1 + s2);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < 128) {  // one thread per row of the I set (0..63) or the J set (64..127)
         const int set = threadIdx.x >> 6, rr = threadIdx.x & 63;
         const int row = (set ? j0 : i0) + rr;
-        double y[BW], v[BW];
+        const bool ok = row < t;
+        const unsigned rc = ok ? (unsigned)row : 0u;
+        double v[BW];
 #pragma unroll
-        for (int b = 0; b < BW; ++b) {
-            y[b] = row < t ? Ypart[b * vs + row] : 0.0;
-            v[b] = row < t ? Vd[b * vs + row] : 0.0;
-        }
-        for (int sp = 1; sp < nsplit; ++sp) {
+        for (int b = 0; b < BW; ++b) v[b] = ok ? Vd[b * vs + rc] : 0.0;
+        if (FIRST) {
+            double y[BW];
 #pragma unroll
-            for (int b = 0; b < BW; ++b) y[b] += row < t ? Ypart[(int64_t)sp * BW * vs + b * vs + row] : 0.0;
-        }
+            for (int b = 0; b < BW; ++b) y[b] = ok ? Ypart[b * vs + rc] : 0.0;
+            for (int sp = 1; sp < nsplit; ++sp) {
 #pragma unroll
-        for (int a = 0; a < BW; ++a) {
-            double x = 0.0, vsum = 0.0;
+                for (int b = 0; b < BW; ++b) y[b] += ok ? Ypart[(int64_t)sp * BW * vs + b * vs + rc] : 0.0;
+            }
 #pragma unroll
-            for (int b = 0; b <= a; ++b) x = fma(y[b], Ts[b + BW * a], x);
+            for (int a = 0; a < BW; ++a) {
+                double x = 0.0, vsum = 0.0;
 #pragma unroll
-            for (int c = 0; c < BW; ++c) vsum = fma(v[c], Ss[c + BW * a], vsum);
-            Vs[set][rr][a] = v[a];
-            Ws[set][rr][a] = x - 0.5 * vsum;
+                for (int b = 0; b <= a; ++b) x = fma(y[b], Ts[b + BW * a], x);
+#pragma unroll
+                for (int c = 0; c < BW; ++c) vsum = fma(v[c], Ss[c + BW * a], vsum);
+                const double wv = x - 0.5 * vsum;
+                Vs[set][rr][a] = v[a];
+                Ws[set][rr][a] = wv;
+                if (set == 0 && ok) Wd[a * vs + rc] = wv;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                Vs[set][rr][a] = v[a];
+                Ws[set][rr][a] = ok ? Wd[a * vs + rc] : 0.0;
+            }
         }
     }
     __syncthreads();
@@ -780,14 +792,17 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
     for (int l = 0; l < BW; ++l) { vi[l] = Vs[0][li][l]; wi[l] = Ws[0][li][l]; }
     double *a = A + (int64_t)r0 * ld + r0 + i;
     const int jb = (threadIdx.x >> 6) * 16;
-#pragma unroll 4
-    for (int jj = jb; jj < jb + 16; ++jj) {
-        const int j = j0 + jj;
-        if (j >= t) break;
+    // all 16 loads of the thread in flight: columns past the end are read at a clamped index and not written
+    double old[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) old[jj] = a[(int64_t)min(j0 + jb + jj, t - 1) * ld];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jb + jj;
         double sum = 0.0;
 #pragma unroll
-        for (int l = 0; l < BW; ++l) sum += vi[l] * Ws[1][jj][l] + wi[l] * Vs[1][jj][l];
-        a[(int64_t)j * ld] -= sum;
+        for (int l = 0; l < BW; ++l) sum += vi[l] * Ws[1][jb + jj][l] + wi[l] * Vs[1][jb + jj][l];
+        if (j < t) a[(int64_t)j * ld] = old[jj] - sum;
     }
 }
 
@@ -803,8 +818,8 @@ __global__ void band_extract_kernel(const double *__restrict__ A, int64_t ld, in
 // r <- Q_0 Q_1 ... Q_{P-1} r,  Q_p = I - V_p T_p V_p'  (single block; reflectors read in place)
 // r <- Q r, Q = H_0 H_1 ... (block reflectors, applied last to first).  One block (each step needs a sum over all
 // rows), so it is a chain of npanels latencies: the vector stays in registers (thread = fixed rows), each panel's
-// reflectors are read once and used for both the products and the update, the next panel's lines are touched
-// into L2 while this one is reduced, and the reduction is the single-barrier one of the panel kernel.
+// reflectors are read once and used for both the products and the update, and the reduction is the
+// single-barrier one of the panel kernel.  (Touching the next panel's lines into L2 ahead of time measured slower.)
 constexpr int BT_THREADS = 1024, BT_RPT = 5;
 __global__ __launch_bounds__(BT_THREADS) void band_backtransform_reg_kernel(const double *__restrict__ A,
                                                                             int64_t ld, int off0, int m,
@@ -833,16 +848,6 @@ __global__ __launch_bounds__(BT_THREADS) void band_backtransform_reg_kernel(cons
             const unsigned ii = ok ? (unsigned)i : 0u;
 #pragma unroll
             for (int a = 0; a < BW; ++a) v[k][a] = P[(int64_t)a * ld + ii];
-        }
-        if (p > 0) {   // touch one double per 128-byte line of the next panel
-            const double *Pn = P - (int64_t)BW * ld - BW;
-            const int tn = m - base + BW, nline = (tn + 15) / 16;
-            double sink = 0.0;
-            for (int e = threadIdx.x; e < nline * BW; e += BT_THREADS) {
-                const int a = e / nline, l = e - a * nline;
-                sink += Pn[(int64_t)a * ld + min(l * 16, tn - 1)];
-            }
-            if (sink == 1.2345e-300) part[0][0][0] = sink;   // never true: keeps the loads
         }
 #pragma unroll
         for (int k = 0; k < BT_RPT; ++k) {
@@ -1305,7 +1310,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
-    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Yp, Mp, Sm, Tall, abd;
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd;
     int *info_dev = nullptr;
     auto layout = [&](ArenaCarver &ar) {
         A.p = ar.take<double>((size_t)(ld * n));
@@ -1318,9 +1323,10 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         tau.p = ar.take<double>((size_t)n + 3);
         Vd.p = ar.take<double>((size_t)BW * vs);
         Vd2.p = ar.take<double>((size_t)BW * vs);
+        Wd.p = ar.take<double>((size_t)BW * vs);
+        Wd2.p = ar.take<double>((size_t)BW * vs);
         Yp.p = ar.take<double>((size_t)SYMM_MAX_SPLITS * BW * vs);
         Mp.p = ar.take<double>((size_t)((m + SYMM_COLS - 1) / SYMM_COLS + 1) * SYMM_MAX_SPLITS * BW * BW);
-        Sm.p = ar.take<double>((size_t)BW * BW);
         Tall.p = ar.take<double>((size_t)std::max(npanels, 1) * BW * BW);
         abd.p = ar.take<double>((size_t)m * (BW + 1));
         info_dev = ar.take<int>(1);
@@ -1414,7 +1420,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         for (int p = 0; p < npanels; ++p) {
             const int c = p * BW, t = m - c - BW, c0 = 3 + c, r0 = 3 + c + BW;
             double *Tp = Tall.p + (size_t)p * BW * BW;
-            double *Vp = (p & 1) ? Vd2.p : Vd.p;
+            double *Vp = (p & 1) ? Vd2.p : Vd.p, *Wp = (p & 1) ? Wd2.p : Wd.p;
             hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
             if (t <= PANEL_THREADS * PANEL_RPT)
                 hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
@@ -1424,13 +1430,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));     // rest of step p-1's update
             const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS, nsplit = symm_splits(t);
             hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
-            hipLaunchKernelGGL(band_s_kernel, dim3(1), dim3(1024), 0, s, Mp.p, ncg * nsplit, Tp, Sm.p);
             const unsigned nb = (unsigned)((t + 63) / 64);
-            hipLaunchKernelGGL(band_update_kernel, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Sm.p, 0);
+            hipLaunchKernelGGL(band_update_kernel<true>, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Mp.p, ncg * nsplit, Wp);
             MHS_HIP(hipEventRecord(ev_block, s));
             MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
             if (nb > 1)
-                hipLaunchKernelGGL(band_update_kernel, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Sm.p, 1);
+                hipLaunchKernelGGL(band_update_kernel<false>, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Mp.p, ncg * nsplit, Wp);
             MHS_HIP(hipEventRecord(ev_rest, s2));
         }
         if (npanels > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (npanels - 1) + 1], 0));
