@@ -189,22 +189,23 @@ __global__ __launch_bounds__(256) void earth_kernel(const double *__restrict__ c
 }
 
 // ------------------------------------------------------------------------ svr --
-// exp(x) for x <= ~0 with the argument already in units of ln2/4096 (y = x 4096/ln2; the factor is folded
-// into the per-support-vector coefficients): y = 4096 e + j + r, |r| <= 1/2; 2^(j/4096) from a 32 KB LDS
-// table, exp(r ln2/4096) = 1 + c r + c^2 r^2 / 2 (truncation < 1e-13 relative).  10 FP64-rate and 4 integer
-// instructions against 16 for a 64-entry table with a quartic.
+// exp(-700 u) for u in [0, 1] (u = -x / 700: the factor is folded into the per-support-vector coefficients, and
+// the range check is the free `clamp` output modifier of the fma that produces u).  In units of ln2/4096,
+// y = -700 u 4096/ln2 = 4096 e + j + r, |r| <= 1/2; 2^(j/4096) from a 32 KB LDS table, exp(r ln2/4096) =
+// 1 + c r + c^2 r^2 / 2 (truncation < 1e-13 relative).  9 FP64-rate and 4 integer instructions against 16 for a
+// 64-entry table with a quartic.
 constexpr int EXP_TAB_BITS = 12;
 constexpr int EXP_TAB_N = 1 << EXP_TAB_BITS;
 constexpr double EXP_SCALE = 4096.0 / 0.6931471805599453094;   // 4096 / ln 2
-__device__ __forceinline__ double table_exp_scaled(double y, const double *tab) {
-    y = fmax(y, -700.0 * EXP_SCALE);
+constexpr double EXP_RANGE = 700.0;                            // arguments below -700 count as -700 (1e-304)
+__device__ __forceinline__ double table_exp_neg(double u, const double *tab) {
     // k = round(y) by the 1.5*2^52 trick: the integer lands in the low word of t (no v_rndne / v_cvt),
-    // kd = t - magic is its exact double
-    const double MAGIC = 0x1.8p52;
-    const double t = y + MAGIC;
+    // kd = t - magic is its exact double; y itself only ever exists inside the two fmas
+    const double MAGIC = 0x1.8p52, NK = -EXP_RANGE * EXP_SCALE;
+    const double t = fma(u, NK, MAGIC);
     const double kd = t - MAGIC;
     const int k = __double2loint(t);
-    const double r = y - kd;
+    const double r = fma(u, NK, -kd);
     const double sj = tab[k & (EXP_TAB_N - 1)];
     const double C1 = 1.0 / EXP_SCALE, C2 = 0.5 / (EXP_SCALE * EXP_SCALE);
     double q = fma(r, C2, C1);
@@ -214,7 +215,8 @@ __device__ __forceinline__ double table_exp_scaled(double y, const double *tab) 
     return __hiloint2double(hi, __double2loint(v));
 }
 
-// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = 2 sigma sv_k, a = -sigma |sv|^2, both times 4096/ln2
+// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = -2 sigma sv_k / 700, a = sigma |sv|^2 / 700:
+// u = a + sigma |x|^2 / 700 + b.x = sigma |x - sv|^2 / 700
 template <int P, int R>
 __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp, int nsv, int stride,
                                                   const double *__restrict__ xcs, const double *__restrict__ gtab,
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             x[c][j] = (xv - xcs[j]) / xcs[P + j];
             q[c] = fma(x[c][j], x[c][j], q[c]);
         }
-        q[c] = (-sigma * EXP_SCALE) * q[c];
+        q[c] = (sigma / EXP_RANGE) * q[c];
     }
     for (int v = 0; v < nsv; ++v) {
         const double *sp = svp + (int64_t)v * stride;
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             double arg = q[c] + sp[P];
 #pragma unroll
             for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
-            acc[c] = fma(sp[P + 1], table_exp_scaled(arg, etab), acc[c]);
+            arg = fmin(fmax(arg, 0.0), 1.0);   // folds into the clamp modifier of the last fma
+            acc[c] = fma(sp[P + 1], table_exp_neg(arg, etab), acc[c]);
         }
     }
 #pragma unroll
@@ -1400,10 +1403,10 @@ int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, doub
         double ss = 0.0;
         for (int j = 0; j < p; ++j) {
             const double x = sv[(size_t)v * p + j];
-            h[(size_t)v * stride + j] = 2.0 * sigma * x * EXP_SCALE;
+            h[(size_t)v * stride + j] = -2.0 * sigma * x / EXP_RANGE;
             ss += x * x;
         }
-        h[(size_t)v * stride + p] = -sigma * ss * EXP_SCALE;
+        h[(size_t)v * stride + p] = sigma * ss / EXP_RANGE;
         h[(size_t)v * stride + p + 1] = alpha[v];
     }
     for (int j = 0; j < p; ++j) { h[(size_t)nsv * stride + j] = x_center[j]; h[(size_t)nsv * stride + p + j] = x_scale[j]; }
