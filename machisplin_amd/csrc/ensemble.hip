@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256) void earth_kernel(const double *__restrict__ c
 // exp(-700 u) for u in [0, 1] (u = -x / 700: the factor is folded into the per-support-vector coefficients, and
 // the range check is the free `clamp` output modifier of the fma that produces u).  In units of ln2/4096,
 // y = -700 u 4096/ln2 = 4096 e + j + r, |r| <= 1/2; 2^(j/4096) from a 32 KB LDS table, exp(r ln2/4096) =
-// 1 + c r + c^2 r^2 / 2 (truncation < 1e-13 relative).  9 FP64-rate and 4 integer instructions against 16 for a
-// 64-entry table with a quartic.
+// 1 + c r + c^2 r^2 / 2 (truncation < 1e-13 relative).  The magic constant carries the exponent bias, so the low
+// word of t is k = (e + 1023) 4096 + j and k << 8 has the finished exponent field on top and j in bits 8..19:
+// one bit-field extract gives the table's byte offset and one and-or drops the exponent onto the table entry,
+// which is stored as its mantissa bits only.  7 FP64-rate and 3 integer instructions (16 for a 64-entry
+// table with a quartic).
 constexpr int EXP_TAB_BITS = 12;
 constexpr int EXP_TAB_N = 1 << EXP_TAB_BITS;
 constexpr double EXP_SCALE = 4096.0 / 0.6931471805599453094;   // 4096 / ln 2
@@ -201,18 +204,18 @@ constexpr double EXP_RANGE = 700.0;                            // arguments belo
 __device__ __forceinline__ double table_exp_neg(double u, const double *tab) {
     // k = round(y) by the 1.5*2^52 trick: the integer lands in the low word of t (no v_rndne / v_cvt),
     // kd = t - magic is its exact double; y itself only ever exists inside the two fmas
-    const double MAGIC = 0x1.8p52, NK = -EXP_RANGE * EXP_SCALE;
+    const double MAGIC = 0x1.8p52 + 1023.0 * EXP_TAB_N, NK = -EXP_RANGE * EXP_SCALE;
     const double t = fma(u, NK, MAGIC);
     const double kd = t - MAGIC;
-    const int k = __double2loint(t);
+    unsigned k8 = (unsigned)__double2loint(t) << 8;   // k >= 1023 * 4096 - 700 * 5910 > 0
+    asm("" : "+v"(k8));   // or the extract below is rewritten as a shift and a mask of t's low word
     const double r = fma(u, NK, -kd);
-    const double sj = tab[k & (EXP_TAB_N - 1)];
+    const double mj = *(const double *)((const char *)tab + __builtin_amdgcn_ubfe(k8, 5, EXP_TAB_BITS + 3));
+    const double sj = __hiloint2double((int)((k8 & 0xfff00000u) | (unsigned)__double2hiint(mj)), __double2loint(mj));
     const double C1 = 1.0 / EXP_SCALE, C2 = 0.5 / (EXP_SCALE * EXP_SCALE);
     double q = fma(r, C2, C1);
     q = fma(q, r, 1.0);
-    const double v = sj * q;
-    const int hi = __double2hiint(v) + ((k >> EXP_TAB_BITS) << 20);
-    return __hiloint2double(hi, __double2loint(v));
+    return sj * q;
 }
 
 // per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = -2 sigma sv_k / 700, a = sigma |sv|^2 / 700:
@@ -224,7 +227,10 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
                                                   double y_center, double y_scale, StackDev s, PredGeom g,
                                                   double weight, int accumulate, double *__restrict__ out) {
     __shared__ double etab[EXP_TAB_N];
-    for (int i = threadIdx.x; i < EXP_TAB_N; i += 256) etab[i] = gtab[i];
+    for (int i = threadIdx.x; i < EXP_TAB_N; i += 256) {   // mantissa bits of 2^(j/4096)
+        const double e = gtab[i];
+        etab[i] = __hiloint2double(__double2hiint(e) & 0x000fffff, __double2loint(e));
+    }
     __syncthreads();
     const int64_t total = (int64_t)g.nr * g.nc;
     const int64_t half = (total + R - 1) / R;
