@@ -56,8 +56,8 @@ struct mhs_model {
     // lm / nnet / earth / svr parameters (device)
     double *dpar = nullptr;
     int *ipar = nullptr;
-    int n0 = 0, n1 = 0;       // nnet: size ; earth: nterms, nfactors ; svr: nsv, row stride
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // nnet: y_scale,y_shift ; svr: b, sigma, y_center, y_scale
+    int n0 = 0, n1 = 0, n2 = 0;   // nnet: size ; earth: nterms, nfactors ; svr: SVs kept, row stride, SVs with alpha > 0
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;  // nnet: y_scale,y_shift ; svr: b, sigma, y_center, y_scale, max|alpha|
     // trees
     mhs::Node *nodes = nullptr;
     int *tree_off = nullptr;       // n_trees + 1 node offsets
@@ -201,7 +201,7 @@ constexpr int EXP_TAB_BITS = 12;
 constexpr int EXP_TAB_N = 1 << EXP_TAB_BITS;
 constexpr double EXP_SCALE = 4096.0 / 0.6931471805599453094;   // 4096 / ln 2
 constexpr double EXP_RANGE = 700.0;                            // arguments below -700 count as -700 (1e-304)
-__device__ __forceinline__ double table_exp_neg(double u, const double *tab) {
+__device__ __forceinline__ double table_exp_neg_acc(double u, const double *tab, double acc) {   // acc + exp(-700 u)
     // k = round(y) by the 1.5*2^52 trick: the integer lands in the low word of t (no v_rndne / v_cvt),
     // kd = t - magic is its exact double; y itself only ever exists inside the two fmas
     const double MAGIC = 0x1.8p52 + 1023.0 * EXP_TAB_N, NK = -EXP_RANGE * EXP_SCALE;
@@ -215,15 +215,19 @@ __device__ __forceinline__ double table_exp_neg(double u, const double *tab) {
     const double C1 = 1.0 / EXP_SCALE, C2 = 0.5 / (EXP_SCALE * EXP_SCALE);
     double q = fma(r, C2, C1);
     q = fma(q, r, 1.0);
-    return sj * q;
+    return fma(sj, q, acc);
 }
 
-// per support vector: [b_0 .. b_{P-1}, a, alpha], b_k = -2 sigma sv_k / 700, a = sigma |sv|^2 / 700:
-// u = a + sigma |x|^2 / 700 + b.x = sigma |x - sv|^2 / 700
+// per support vector: [b_0 .. b_{P-1}, a], b_k = -2 sigma sv_k / 700, a = (sigma |sv|^2 - ln(|alpha| / amax)) / 700:
+// u = a + sigma |x|^2 / 700 + b.x = (sigma |x - sv|^2 - ln(|alpha| / amax)) / 700 >= 0 and exp(-700 u) =
+// |alpha| / amax K(x, sv).  With the coefficient inside the exponent the term is accumulated by the fma that
+// finishes the exponential (acc += 2^e 2^(j/4096) * q); the support vectors with alpha > 0 come first, the
+// others are summed separately and subtracted.
 template <int P, int R>
 __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp, int nsv, int stride,
-                                                  const double *__restrict__ xcs, const double *__restrict__ gtab,
-                                                  double sigma, double b,
+                                                  int npos, const double *__restrict__ xcs,
+                                                  const double *__restrict__ gtab, double sigma, double b,
+                                                  double amax,
                                                   double y_center, double y_scale, StackDev s, PredGeom g,
                                                   double weight, int accumulate, double *__restrict__ out) {
     __shared__ double etab[EXP_TAB_N];
@@ -254,22 +258,29 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
         }
         q[c] = (sigma / EXP_RANGE) * q[c];
     }
-    for (int v = 0; v < nsv; ++v) {
-        const double *sp = svp + (int64_t)v * stride;
+    double accn[R];
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-            double arg = q[c] + sp[P];
+    for (int c = 0; c < R; ++c) accn[c] = 0.0;
+    auto sum_range = [&](int v0, int v1, double (&a)[R]) {
+        for (int v = v0; v < v1; ++v) {
+            const double *sp = svp + (int64_t)v * stride;
 #pragma unroll
-            for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
-            arg = fmin(fmax(arg, 0.0), 1.0);   // folds into the clamp modifier of the last fma
-            acc[c] = fma(sp[P + 1], table_exp_neg(arg, etab), acc[c]);
+            for (int c = 0; c < R; ++c) {
+                double arg = q[c] + sp[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
+                arg = fmin(fmax(arg, 0.0), 1.0);   // folds into the clamp modifier of the last fma
+                a[c] = table_exp_neg_acc(arg, etab, a[c]);
+            }
         }
-    }
+    };
+    sum_range(0, npos, acc);
+    sum_range(npos, nsv, accn);
 #pragma unroll
     for (int c = 0; c < R; ++c) {
         const int64_t i = i0 + c * half;
         if (i < total) {
-            const double pred = (acc[c] - b) * y_scale + y_center;
+            const double pred = ((acc[c] - accn[c]) * amax - b) * y_scale + y_center;
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : pred, weight, accumulate);
         }
     }
@@ -950,7 +961,8 @@ static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g,
     constexpr int R = 2;
     const int64_t half = (total + R - 1) / R;
     hipLaunchKernelGGL((svr_kernel<P, R>), dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st,
-                       m->dpar, m->n0, m->n1, m->dpar + (size_t)m->n0 * m->n1, ctx().exp_tab, m->s1, m->s0, m->s2, m->s3,
+                       m->dpar, m->n0, m->n1, m->n2, m->dpar + (size_t)m->n0 * m->n1, ctx().exp_tab, m->s1, m->s0, m->s4,
+                       m->s2, m->s3,
                        s, g, w, acc, out);
 }
 
@@ -1403,21 +1415,33 @@ int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, doub
     MHS_REQUIRE(p <= PMAX, "p exceeds the predictors supported for ksvm");
     MHS_REQUIRE(sigma > 0, "sigma must be positive");
     for (int j = 0; j < p; ++j) MHS_REQUIRE(x_scale[j] != 0.0, "x_scale has a zero entry");
-    const int stride = ((p + 2) + 3) & ~3;  // doubles per support vector, 32-byte multiple
-    std::vector<double> h((size_t)nsv * stride + 2 * p, 0.0);
+    const int stride = ((p + 1) + 3) & ~3;  // doubles per support vector, 32-byte multiple
+    // support vectors with alpha > 0 first, then alpha < 0 (alpha = 0 contributes nothing), |alpha| / amax folded
+    // into the exponent
+    double amax = 0.0;
+    std::vector<int64_t> order;
     for (int64_t v = 0; v < nsv; ++v) {
+        MHS_REQUIRE(std::isfinite(alpha[v]), "non-finite alpha");
+        amax = std::max(amax, fabs(alpha[v]));
+        if (alpha[v] > 0) order.push_back(v);
+    }
+    const int npos = (int)order.size();
+    for (int64_t v = 0; v < nsv; ++v) if (alpha[v] < 0) order.push_back(v);
+    const int64_t nkeep = (int64_t)order.size();
+    std::vector<double> h((size_t)nkeep * stride + 2 * p, 0.0);
+    for (int64_t e = 0; e < nkeep; ++e) {
+        const int64_t v = order[(size_t)e];
         double ss = 0.0;
         for (int j = 0; j < p; ++j) {
             const double x = sv[(size_t)v * p + j];
-            h[(size_t)v * stride + j] = -2.0 * sigma * x / EXP_RANGE;
+            h[(size_t)e * stride + j] = -2.0 * sigma * x / EXP_RANGE;
             ss += x * x;
         }
-        h[(size_t)v * stride + p] = sigma * ss / EXP_RANGE;
-        h[(size_t)v * stride + p + 1] = alpha[v];
+        h[(size_t)e * stride + p] = (sigma * ss - log(fabs(alpha[v]) / amax)) / EXP_RANGE;
     }
-    for (int j = 0; j < p; ++j) { h[(size_t)nsv * stride + j] = x_center[j]; h[(size_t)nsv * stride + p + j] = x_scale[j]; }
+    for (int j = 0; j < p; ++j) { h[(size_t)nkeep * stride + j] = x_center[j]; h[(size_t)nkeep * stride + p + j] = x_scale[j]; }
     mhs_model *m = new mhs_model();
-    m->kind = K_SVR; m->p = p; m->n0 = (int)nsv; m->n1 = stride;
+    m->kind = K_SVR; m->p = p; m->n0 = (int)nkeep; m->n1 = stride; m->n2 = npos; m->s4 = amax;
     m->s0 = b; m->s1 = sigma; m->s2 = y_center; m->s3 = y_scale;
     if (int rc = to_device(h.data(), h.size(), &m->dpar)) { mhs_model_free(m); return rc; }
     *out = m;
