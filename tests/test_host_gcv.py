@@ -101,3 +101,64 @@ def test_banded_gcv_matches_eigen_gcv(n, bw, mode):
     assert abs(gcv.value - m["gcv"]) < 1e-9 * m["gcv"] and abs(edf.value - m["eff_df"]) < 1e-5 * m["eff_df"]
     ref = tps.fit(xy, y, lam=lam.value)
     assert np.abs(Q2 @ (P @ q) - ref["c"]).max() < 1e-8 * np.abs(ref["c"]).max()
+
+
+def _random_band(m, bw, seed):
+    rng = np.random.default_rng(seed)
+    ab = np.zeros((m, bw + 1))
+    ab[:, 0] = 10.0 + rng.uniform(0, 1, m)
+    for d in range(1, bw + 1):
+        ab[:m - d, d] = rng.uniform(-0.5, 0.5, m - d)
+    return ab, rng.standard_normal(m)
+
+
+def _band_eval(ab, g, lam):
+    m, w = ab.shape
+    lam_o, gcv, edf = C.c_double(), C.c_double(), C.c_double()
+    q = np.empty(m)
+    rc = _lib.load().mhs_host_gcv_band(ab.ctypes.data, w - 1, g.ctypes.data, m, m + 3, m + 3, 0.0, float(lam), 0,
+                                       C.byref(lam_o), C.byref(gcv), C.byref(edf), q.ctypes.data)
+    assert rc == 0
+    return lam_o.value, gcv.value, edf.value, q
+
+
+def test_fixed_bandwidth_path_matches_the_general_one():
+    """Bandwidth 8 takes the compile-time-sized LDL' evaluation; the same matrix stored with a ninth, all-zero
+    sub-diagonal takes the general banded Cholesky.  Both against a dense solve."""
+    m = 300
+    ab8, g = _random_band(m, 8, 5)
+    ab9 = np.ascontiguousarray(np.column_stack([ab8, np.zeros(m)]))
+    A = np.zeros((m, m))
+    for d in range(9):
+        A += np.diag(ab8[:m - d, d], -d)
+    A = A + np.tril(A, -1).T
+    for lam in (1e-3, 0.7, 40.0):
+        _, gcv8, edf8, q8 = _band_eval(ab8, g, lam)
+        _, gcv9, edf9, q9 = _band_eval(ab9, g, lam)
+        assert abs(gcv8 - gcv9) < 1e-12 * abs(gcv9) and abs(edf8 - edf9) < 1e-10 * abs(edf9)
+        assert np.abs(q8 - q9).max() < 1e-12 * np.abs(q9).max()
+        Ai = np.linalg.inv(A + lam * np.eye(m))
+        assert np.abs(q8 - Ai @ g).max() < 1e-11 * np.abs(q8).max()
+        assert abs(edf8 - (3.0 + m - lam * np.trace(Ai))) < 1e-9 * m
+
+
+def test_concurrent_gcv_searches_share_and_release_the_worker_pool():
+    """One search leases the process-wide pool, the others build their own; every pool must wind down (a worker
+    that misses the stop flag hangs the join) and every search must find the same lambda."""
+    import threading
+    ab, g = _random_band(500, 8, 11)
+    ref = _band_eval(ab, g, float("nan"))[0]
+    out, errs = [], []
+
+    def work():
+        try:
+            for _ in range(8):
+                out.append(_band_eval(ab, g, float("nan"))[0])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work) for _ in range(5)]
+    [t.start() for t in ths]
+    [t.join(timeout=120) for t in ths]
+    assert not any(t.is_alive() for t in ths), "a GCV search did not return"
+    assert not errs and len(out) == 40 and all(abs(v - ref) < 1e-9 * ref for v in out)   # pools may differ in size
