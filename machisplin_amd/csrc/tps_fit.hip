@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void syr2_kernel(double *__restrict__ A, int64
 // =============================================================================================
 constexpr int BW = 8;
 
+// -DMHS_PANEL_TRACE: s_memtime stamps per phase of band_panel_reg_kernel (first panel and the one at t ~ 2500),
+// read back with mhs_debug_panel_trace(); how the reductions were found to be 80 % of the kernel.  Off by default.
 #ifdef MHS_PANEL_TRACE
 __device__ unsigned long long g_panel_trace[2][32];
 __device__ int g_trace_slot = -1;
@@ -130,23 +132,18 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *lds) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-    PTRACE_IN(18);
     __syncthreads();
-    PTRACE_IN(19);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
     }
     __syncthreads();
-    PTRACE_IN(20);
     if ((int)threadIdx.x < K) {  // thread k adds the per-wave partials of value k, in wave order
         double s = 0.0;
         for (int w = 0; w < nw; ++w) s += lds[w * K + threadIdx.x];
         lds[16 * K + threadIdx.x] = s;
     }
-    PTRACE_IN(21);
     __syncthreads();
-    PTRACE_IN(22);
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = lds[16 * K + k];
 }
