@@ -635,10 +635,22 @@ constexpr int SYMM_MAX_SPLITS = 8;
 constexpr int SYMM_CPW = 8;              // columns per wave
 constexpr int SYMM_COLS = 4 * SYMM_CPW;  // per block
 // Two row ranges measured best at n = 5000 (more blocks shorten this kernel but every consumer of Y and M then
-// adds more partials: 1 -> 85.8, 2 -> 81.6, 3 -> 82.5, 4 -> 84.3, 8 -> 91.3 ms per fit); MHS_SYMM_SPLITS overrides.
+// adds more partials: 1 -> 85.8, 2 -> 81.6, 3 -> 82.5, 4 -> 84.3, 8 -> 91.3 ms per fit) -- except where two ranges
+// make slightly more than one block per CU: a block streams its columns at ~35 GB/s whatever else runs, so
+// 264 blocks on 256 CUs take twice as long as 256 (t = 4197: 39 us, t = 3397: 20 us).  Then the split count with
+// the fewest (rounds of 256 blocks) x (rows per block) is taken.  MHS_SYMM_SPLITS overrides.
 static inline int symm_splits(int t) {
     static const int forced = getenv("MHS_SYMM_SPLITS") ? atoi(getenv("MHS_SYMM_SPLITS")) : 0;
-    const int want = forced > 0 ? std::min(forced, SYMM_MAX_SPLITS) : 2;
+    const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS;
+    int want = 2;
+    if (forced > 0) want = std::min(forced, SYMM_MAX_SPLITS);
+    else if (ncg * 2 > 256) {
+        double best = 1e30;
+        for (int sp = 2; sp <= SYMM_MAX_SPLITS; ++sp) {
+            const double cost = (double)((ncg * sp + 255) / 256) / sp;
+            if (cost < best - 1e-12) { best = cost; want = sp; }
+        }
+    }
     return std::max(1, std::min(want, (t + 63) / 64));
 }
 
@@ -719,15 +731,26 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
     __shared__ double Ts[BW * BW], Ss[BW * BW];
     const int i0 = blockIdx.x * 64, j0 = FIRST ? 0 : (blockIdx.y + 1) * 64;
     if (FIRST) {
-        __shared__ double red[4][BW * BW], Mm[BW * BW], MT[BW * BW];
-        const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-        double sum = 0.0;
-#pragma unroll 8
-        for (int p = grp; p < nparts; p += 4) sum += Mpart[(int64_t)p * (BW * BW) + e];
-        red[grp][e] = sum;
+        __shared__ double red[16][BW * BW], Mm[BW * BW], MT[BW * BW];
+        {   // 16 groups of 16 threads, 32-byte loads: the sum is a chain of L2 latencies, so it is kept short
+            const int e4 = (threadIdx.x & 15) * 4, grp = threadIdx.x >> 4;
+            double4 sum = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int p = grp; p < nparts; p += 16) {
+                const double4 v = *(const double4 *)(Mpart + (int64_t)p * (BW * BW) + e4);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            red[grp][e4] = sum.x; red[grp][e4 + 1] = sum.y; red[grp][e4 + 2] = sum.z; red[grp][e4 + 3] = sum.w;
+        }
+        const int e = threadIdx.x & 63;
         if (threadIdx.x < BW * BW) Ts[threadIdx.x] = Tm[threadIdx.x];
         __syncthreads();
-        if (threadIdx.x < BW * BW) Mm[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (threadIdx.x < BW * BW) {
+            double m = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m += red[q][e];
+            Mm[e] = m;
+        }
         __syncthreads();
         if (threadIdx.x < BW * BW) {  // MT = M T  (T upper: T[b + BW*c], b <= c)
             const int a = e % BW, c = e / BW;
