@@ -281,12 +281,6 @@ struct PanelShared {
     double taus[BW];
 };
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double x) {   // rows outside ROW_MASK read 0.0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 // sum over the wave, valid in lanes 48..63: xor 1, xor 2, mirror within 8, mirror within 16, then the row totals
 // are chained with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
 __device__ __forceinline__ double wave_sum_top(double x) {
@@ -297,10 +291,6 @@ __device__ __forceinline__ double wave_sum_top(double x) {
     x += dpp_fetch<0x142, 0xa>(x);
     x += dpp_fetch<0x143, 0xc>(x);
     return x;
-}
-__device__ __forceinline__ double lane_value(double x, int lane) {   // uniform: lands in SGPRs
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
-                            __builtin_amdgcn_readlane(__double2loint(x), lane));
 }
 // gfx950 lane swaps: v_permlane32_swap exchanges the upper half-wave of one register with the lower half-wave of
 // another, v_permlane16_swap the odd rows of one with the even rows of the other -- so "two swaps and an add" folds
