@@ -719,20 +719,49 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
                                                           double *__restrict__ Wd) {
     __shared__ double Vs[2][64][BW + 1], Ws[2][64][BW + 1];
     __shared__ double Ts[BW * BW], Ss[BW * BW];
+    __shared__ double red[16][BW * BW], Mm[BW * BW], MT[BW * BW];
     const int i0 = blockIdx.x * 64, j0 = FIRST ? 0 : (blockIdx.y + 1) * 64;
-    if (FIRST) {
-        __shared__ double red[16][BW * BW], Mm[BW * BW], MT[BW * BW];
-        {   // 16 groups of 16 threads, 32-byte loads: the sum is a chain of L2 latencies, so it is kept short
-            const int e4 = (threadIdx.x & 15) * 4, grp = threadIdx.x >> 4;
-            double4 sum = {0.0, 0.0, 0.0, 0.0};
+    // What the previous kernels wrote comes from memory, not from this XCD's L2: a load costs ~2 us and the launch
+    // is a chain of them unless they are all issued before anything waits -- first the partial sums of M (the
+    // longest dependent path), then the rows of V and Y (or W), then the tile itself.
+    double4 msum = {0.0, 0.0, 0.0, 0.0};
+    if (FIRST) {   // 16 groups of 16 threads, 32-byte loads
+        const int e4 = (threadIdx.x & 15) * 4, grp = threadIdx.x >> 4;
 #pragma unroll 4
-            for (int p = grp; p < nparts; p += 16) {
-                const double4 v = *(const double4 *)(Mpart + (int64_t)p * (BW * BW) + e4);
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            }
-            red[grp][e4] = sum.x; red[grp][e4 + 1] = sum.y; red[grp][e4 + 2] = sum.z; red[grp][e4 + 3] = sum.w;
+        for (int p = grp; p < nparts; p += 16) {
+            const double4 m4 = *(const double4 *)(Mpart + (int64_t)p * (BW * BW) + e4);
+            msum.x += m4.x; msum.y += m4.y; msum.z += m4.z; msum.w += m4.w;
         }
-        const int e = threadIdx.x & 63;
+    }
+    const int set = (threadIdx.x >> 6) & 1, rr = threadIdx.x & 63;   // threads 0..127: one per row of the I / J set
+    const int row = (set ? j0 : i0) + rr;
+    const bool ok = row < t;
+    const unsigned rc = ok ? (unsigned)row : 0u;
+    double v[BW], y[BW];
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int b = 0; b < BW; ++b) v[b] = ok ? Vd[b * vs + rc] : 0.0;
+        if (FIRST) {
+#pragma unroll
+            for (int b = 0; b < BW; ++b) y[b] = ok ? Ypart[b * vs + rc] : 0.0;
+            for (int sp = 1; sp < nsplit; ++sp) {
+#pragma unroll
+                for (int b = 0; b < BW; ++b) y[b] += ok ? Ypart[(int64_t)sp * BW * vs + b * vs + rc] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < BW; ++b) y[b] = ok ? Wd[b * vs + rc] : 0.0;     // W itself
+        }
+    }
+    const int li = threadIdx.x & 63, i = i0 + li;
+    double *a = A + (int64_t)r0 * ld + r0 + min(i, t - 1);
+    const int jb = (threadIdx.x >> 6) * 16;
+    double old[16];   // columns and rows past the end are read at a clamped index and not written
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) old[jj] = a[(int64_t)min(j0 + jb + jj, t - 1) * ld];
+    if (FIRST) {
+        const int e4 = (threadIdx.x & 15) * 4, grp = threadIdx.x >> 4, e = threadIdx.x & 63;
+        red[grp][e4] = msum.x; red[grp][e4 + 1] = msum.y; red[grp][e4 + 2] = msum.z; red[grp][e4 + 3] = msum.w;
         if (threadIdx.x < BW * BW) Ts[threadIdx.x] = Tm[threadIdx.x];
         __syncthreads();
         if (threadIdx.x < BW * BW) {
@@ -743,69 +772,45 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
         }
         __syncthreads();
         if (threadIdx.x < BW * BW) {  // MT = M T  (T upper: T[b + BW*c], b <= c)
-            const int a = e % BW, c = e / BW;
+            const int a2 = e % BW, c = e / BW;
             double m = 0.0;
-            for (int b2 = 0; b2 <= c; ++b2) m += Mm[a + BW * b2] * Ts[b2 + BW * c];
-            MT[a + BW * c] = m;
+            for (int b2 = 0; b2 <= c; ++b2) m += Mm[a2 + BW * b2] * Ts[b2 + BW * c];
+            MT[a2 + BW * c] = m;
         }
         __syncthreads();
         if (threadIdx.x < BW * BW) {  // S = T' MT, symmetrised
-            const int a = e % BW, c = e / BW;
+            const int a2 = e % BW, c = e / BW;
             double s1 = 0.0, s2 = 0.0;
-            for (int d = 0; d <= a; ++d) s1 += Ts[d + BW * a] * MT[d + BW * c];
-            for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a];
-            Ss[a + BW * c] = 0.5 * (s1 + s2);
+            for (int d = 0; d <= a2; ++d) s1 += Ts[d + BW * a2] * MT[d + BW * c];
+            for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a2];
+            Ss[a2 + BW * c] = 0.5 * (s1 + s2);
         }
         __syncthreads();
     }
-    if (threadIdx.x < 128) {  // one thread per row of the I set (0..63) or the J set (64..127)
-        const int set = threadIdx.x >> 6, rr = threadIdx.x & 63;
-        const int row = (set ? j0 : i0) + rr;
-        const bool ok = row < t;
-        const unsigned rc = ok ? (unsigned)row : 0u;
-        double v[BW];
-#pragma unroll
-        for (int b = 0; b < BW; ++b) v[b] = ok ? Vd[b * vs + rc] : 0.0;
+    if (threadIdx.x < 128) {
         if (FIRST) {
-            double y[BW];
 #pragma unroll
-            for (int b = 0; b < BW; ++b) y[b] = ok ? Ypart[b * vs + rc] : 0.0;
-            for (int sp = 1; sp < nsplit; ++sp) {
-#pragma unroll
-                for (int b = 0; b < BW; ++b) y[b] += ok ? Ypart[(int64_t)sp * BW * vs + b * vs + rc] : 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < BW; ++a) {
+            for (int a2 = 0; a2 < BW; ++a2) {
                 double x = 0.0, vsum = 0.0;
 #pragma unroll
-                for (int b = 0; b <= a; ++b) x = fma(y[b], Ts[b + BW * a], x);
+                for (int b = 0; b <= a2; ++b) x = fma(y[b], Ts[b + BW * a2], x);
 #pragma unroll
-                for (int c = 0; c < BW; ++c) vsum = fma(v[c], Ss[c + BW * a], vsum);
+                for (int c = 0; c < BW; ++c) vsum = fma(v[c], Ss[c + BW * a2], vsum);
                 const double wv = x - 0.5 * vsum;
-                Vs[set][rr][a] = v[a];
-                Ws[set][rr][a] = wv;
-                if (set == 0 && ok) Wd[a * vs + rc] = wv;
+                Vs[set][rr][a2] = v[a2];
+                Ws[set][rr][a2] = wv;
+                if (set == 0 && ok) Wd[a2 * vs + rc] = wv;
             }
         } else {
 #pragma unroll
-            for (int a = 0; a < BW; ++a) {
-                Vs[set][rr][a] = v[a];
-                Ws[set][rr][a] = ok ? Wd[a * vs + rc] : 0.0;
-            }
+            for (int a2 = 0; a2 < BW; ++a2) { Vs[set][rr][a2] = v[a2]; Ws[set][rr][a2] = y[a2]; }
         }
     }
     __syncthreads();
-    const int li = threadIdx.x & 63, i = i0 + li;
     if (i >= t) return;
     double vi[BW], wi[BW];
 #pragma unroll
     for (int l = 0; l < BW; ++l) { vi[l] = Vs[0][li][l]; wi[l] = Ws[0][li][l]; }
-    double *a = A + (int64_t)r0 * ld + r0 + i;
-    const int jb = (threadIdx.x >> 6) * 16;
-    // all 16 loads of the thread in flight: columns past the end are read at a clamped index and not written
-    double old[16];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) old[jj] = a[(int64_t)min(j0 + jb + jj, t - 1) * ld];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = j0 + jb + jj;
