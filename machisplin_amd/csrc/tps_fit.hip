@@ -269,8 +269,9 @@ __global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A
 #endif
 constexpr int PANEL_RPT = PANEL_RPT_V;
 constexpr int PANEL_THREADS = PANEL_THREADS_V;
-constexpr int PANEL_WAVES = PANEL_THREADS / 64;
-
+// Shorter panels take fewer waves (1 .. 8 of them, 640 rows each): every reduction then adds fewer partials behind
+// a cheaper barrier, and a panel of up to 640 rows is reduced inside one wave (t = 197: 24.7 -> 13.4 us).
+template <int PANEL_WAVES>
 struct PanelShared {
     double part[2][PANEL_WAVES][BW];   // per-wave partial sums of a reduction (alternating buffers)
     double rowj[2][BW];                // entries of the pivot row before the step's update (positions 1..BW-1)
@@ -362,7 +363,8 @@ __device__ __forceinline__ double block_total(const double (*buf)[BW]) {
 // squared norm of column J is its initial value minus the squares of its entries in rows 0..J-1, the R entries,
 // which every wave recomputes from the step's totals; when the difference cancels (below 1 % of the initial
 // norm) the norm is summed afresh.
-__device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared &sh) {
+template <int PANEL_WAVES>
+__device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref, PanelShared<PANEL_WAVES> &sh) {
     const int i0 = threadIdx.x;     // the row held in x[0][.]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int ph = 0;
@@ -484,11 +486,13 @@ __device__ __forceinline__ int panel_steps(double (&x)[PANEL_RPT][BW], int nref,
     return ph;
 }
 
-__global__ __launch_bounds__(PANEL_THREADS) void band_panel_reg_kernel(double *__restrict__ A, int64_t ld, int c0,
-                                                                       int r0, int t, double *__restrict__ Vd,
-                                                                       int64_t vs, double *__restrict__ Tm,
-                                                                       double *__restrict__ g) {
-    __shared__ PanelShared sh;
+template <int PANEL_WAVES>
+__global__ __launch_bounds__(64 * PANEL_WAVES) void band_panel_reg_kernel(double *__restrict__ A, int64_t ld, int c0,
+                                                                          int r0, int t, double *__restrict__ Vd,
+                                                                          int64_t vs, double *__restrict__ Tm,
+                                                                          double *__restrict__ g) {
+    constexpr int PANEL_THREADS = 64 * PANEL_WAVES;   // shadows the largest form's constant
+    __shared__ PanelShared<PANEL_WAVES> sh;
 #ifdef MHS_PANEL_TRACE
     if (threadIdx.x == 0) g_trace_slot = (c0 == 3) ? 0 : ((t >= 2497 && t < 2505) ? 1 : -1);
     __syncthreads();
@@ -1437,8 +1441,14 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             double *Tp = Tall.p + (size_t)p * BW * BW;
             double *Vp = (p & 1) ? Vd2.p : Vd.p, *Wp = (p & 1) ? Wd2.p : Wd.p;
             hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
-            if (t <= PANEL_THREADS * PANEL_RPT)
-                hipLaunchKernelGGL(band_panel_reg_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
+            if (t <= PANEL_THREADS * PANEL_RPT) {
+                // 640 rows per wave up to one wave per SIMD; beyond that all 8 (5 .. 7 waves load the SIMDs unevenly:
+                // t = 4197 took 44 us with 7 against 38.5 with 8)
+                const int nw = t <= 256 * PANEL_RPT ? (t + 64 * PANEL_RPT - 1) / (64 * PANEL_RPT) : PANEL_THREADS / 64;
+#define MHS_PANEL(NW) case NW: hipLaunchKernelGGL(band_panel_reg_kernel<NW>, dim3(1), dim3(64 * NW), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW); break;
+                switch (nw) { MHS_PANEL(1) MHS_PANEL(2) MHS_PANEL(3) MHS_PANEL(4) default: MHS_PANEL(8) }
+#undef MHS_PANEL
+            }
             else
                 hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
             if (p == std::max(0, npanels - 12)) MHS_HIP(hipEventRecord(pool[2 * npanels], s));   // ~1 ms before the end
