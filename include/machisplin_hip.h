@@ -148,6 +148,11 @@ MHS_API int mhs_tps_predict_points(const mhs_tps *t, const double *xy, int64_t n
 /* mgcv::gam(resp ~ a+b+...) has no s() terms (V73:195,600): a linear model.
  * coef[p+1], intercept first.  replaces terra::predict(rast_stack, gam) V73:604,606 */
 MHS_API int mhs_lm_load(const double *coef, int p, mhs_model **out);
+/* The fit of that member: least squares by Householder QR of [1 X] on the device, as mgcv::gam / stats::lm solve a
+ * purely parametric formula.  X: n x p column-major (rast_stack order), y: n responses, no NA rows (V73:154);
+ * coef[p+1], intercept first; MHS_ERR_NUMERIC for a rank-deficient design.
+ * replaces mgcv::gam(mod.form, data = train) V73:252 (CV folds) and V73:600 (final fit)      */
+MHS_API int mhs_lm_fit(const double *X, const double *y, int64_t n, int p, double *coef);
 /* nnet::nnet(size, linout=TRUE) (V73:463): wts in nnet order -- per hidden unit its bias
  * then p input weights, then output bias and `size` hidden->output weights.  The
  * response un-scaling pred*max2.resp.f + min.resp.f (V73:469-470) is y_scale/y_shift.

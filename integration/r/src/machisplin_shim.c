@@ -141,6 +141,15 @@ SEXP mhsr_predict_points(SEXP model, SEXP X) {
     return out;
 }
 
+/* mgcv::gam(mod.form, data) with the parametric formula (V73:252, V73:600): X = as.matrix(data[, predictors]) */
+SEXP mhsr_lm_fit(SEXP X, SEXP y) {
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, Rf_ncols(X) + 1));
+    int rc = mhs_lm_fit(REAL(X), REAL(y), (int64_t)Rf_nrows(X), Rf_ncols(X), REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
 /* machisplin.tiles.merge (V73:1392-1546): tiles = list of numeric vectors (terra::values of each
  * rast.in[[h]] in cell order), win = integer matrix 4 x n (r0, r1, c0, c1 per tile, 0-based) */
 SEXP mhsr_tiles_merge(SEXP geom, SEXP tiles, SEXP win, SEXP in_ncol, SEXP in_nrow) {

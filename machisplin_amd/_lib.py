@@ -72,6 +72,7 @@ SIGNATURES = {
     "mhs_tps_eval_mode": (C.c_int, [C.c_int]),
     "mhs_tps_eval_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "mhs_lm_load": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "mhs_lm_fit": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "mhs_nnet_load": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(_vp)]),
     "mhs_earth_load": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "mhs_svr_load": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_double, C.c_double, _vp, _vp, C.c_double,

@@ -61,6 +61,19 @@ class Gam(Model):
         h = C.c_void_p()
         _lib.check(_lib.lib().mhs_lm_load(c.ctypes.data, c.size - 1, C.byref(h)))
         super().__init__(h, c.size - 1)
+        self.coefficients = c
+
+    @classmethod
+    def fit(cls, X, y) -> "Gam":
+        """mgcv::gam(resp ~ a + b + ..., data) (V73:252, V73:600): least squares on the device (Householder QR of
+        [1 X]).  X is n x p in rast_stack order, rows with NA already dropped (V73:154)."""
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        y = _f64(y)
+        if X.ndim != 2 or X.shape[0] != y.size:
+            raise ValueError("X must be n x p with one response per row")
+        coef = np.empty(X.shape[1] + 1)
+        _lib.check(_lib.lib().mhs_lm_fit(X.ctypes.data, y.ctypes.data, X.shape[0], X.shape[1], coef.ctypes.data))
+        return cls(coef)
 
 
 class Nnet(Model):

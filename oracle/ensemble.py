@@ -31,6 +31,15 @@ def lm_model(coef):
     return {"kind": "lm", "coef": np.asarray(coef, dtype=np.float64)}
 
 
+def lm_fit(X, y):
+    """mgcv::gam(mod.form, data) with the purely parametric formula of V73:195 (V73:252 in the CV loop, V73:600
+    for the final model) = ordinary least squares on [1 X]; returns coefficients[p+1], intercept first."""
+    X = np.asarray(X, dtype=np.float64)
+    A = np.column_stack([np.ones(X.shape[0]), X])
+    coef, *_ = np.linalg.lstsq(A, np.asarray(y, dtype=np.float64), rcond=None)
+    return coef
+
+
 def nnet_model(wts, p, size, y_scale, y_shift):
     """nnet(size=10, linout=TRUE) (V73:463).  wts in nnet order: for each hidden unit its
     bias then its p input weights; then the output bias and the `size` hidden->output

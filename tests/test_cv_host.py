@@ -65,3 +65,13 @@ def test_holdout_rule_swaps_above_4000_rows():
     assert np.array_equal(cv.holdout_rows(k[:4000], 3, 4000), np.flatnonzero(k[:4000] == 3))     # test on fold v
     assert np.array_equal(cv.holdout_rows(k, 3, 5000), np.flatnonzero(k != 3))                   # V73:228-230
     assert np.array_equal(cv.holdout_rows(k, 3, 5000), oe.holdout_rows(k, 3, 5000))
+
+
+def test_oracle_lm_fit_known_answer():
+    """oracle lm_fit (V73:252 / V73:600): exact recovery on noise-free data, intercept first."""
+    from oracle import ensemble as oe
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(40, 3))
+    beta = np.array([2.0, -1.0, 0.5, 3.0])
+    coef = oe.lm_fit(X, beta[0] + X @ beta[1:])
+    assert np.abs(coef - beta).max() < 1e-12
