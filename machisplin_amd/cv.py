@@ -29,6 +29,26 @@ def holdout_rows(kfolds, v: int, n_rows: int):
     return np.flatnonzero(kfolds != v) if n_rows > 4000 else np.flatnonzero(kfolds == v)
 
 
+def train_rows(kfolds, v: int, n_rows: int):
+    """The complement of :func:`holdout_rows` (V73:228-232): fold v itself when there are more than 4000 rows."""
+    kfolds = np.asarray(kfolds)
+    return np.flatnonzero(kfolds == v) if n_rows > 4000 else np.flatnonzero(kfolds != v)
+
+
+def fit_linear_folds(X, resp, kfolds):
+    """``mod.gam.tps.elev <- mgcv::gam(mod.form, data = train)`` for every fold (V73:252) on the device: the one
+    member whose fit is deterministic (least squares, :meth:`models.Gam.fit`).  Returns the fold models in fold
+    order, ready for the ``g`` slot of ``fold_models`` in :func:`cv_residuals`."""
+    from .models import Gam
+    X = np.asarray(X, dtype=np.float64)
+    resp = np.asarray(resp, dtype=np.float64)
+    out = []
+    for v in range(1, int(np.max(kfolds)) + 1):
+        tr = train_rows(kfolds, v, X.shape[0])
+        out.append(Gam.fit(X[tr], resp[tr]))
+    return out
+
+
 def cv_residuals(fold_models, X, resp, kfolds, labels: str = ORDER_ALL):
     """mfit.<model>.full of V73:258-319: for fold v = 1..nfolds, ``test$resp - predict(model_v, test)`` on the
     hold-out rows, concatenated in fold order.  ``fold_models[v-1]`` maps a label in ``labels`` to the device

@@ -30,3 +30,24 @@ def test_cv_residual_columns_match_oracle_and_feed_the_weight_search(hip, n, nfo
     p_gpu = cv.optx_weights(got)
     p_ref = cv.optx_weights(want)
     assert np.allclose(p_gpu[0], p_ref[0], atol=1e-6) and p_gpu[1] == p_ref[1]
+
+
+@pytest.mark.parametrize("n,nfolds", [(600, 10), (4100, 4)])
+def test_linear_member_fitted_per_fold_on_the_device(hip, n, nfolds):
+    """V73:252 for the `g` member: the fold models come from mhs_lm_fit; their hold-out residual column equals the
+    oracle's (least squares on the fold's training rows, predict on its hold-out rows)."""
+    from machisplin_amd import cv
+    rng = np.random.default_rng(7 * n)
+    X = np.column_stack([rng.uniform(76, 4668, n), rng.uniform(-1, 877, n), rng.uniform(-207, 152, n),
+                         rng.uniform(-78.0, -77.0, n), rng.uniform(-6.0, -5.0, n)])
+    y = 0.004 * X[:, 0] - 0.01 * X[:, 1] + 3.0 * X[:, 3] + rng.standard_normal(n)
+    kfolds = rng.permutation(np.arange(n) % nfolds) + 1
+    gams = cv.fit_linear_folds(X, y, kfolds)
+    assert len(gams) == nfolds
+    got = cv.cv_residuals([{"g": m} for m in gams], X, y, kfolds, labels="g")
+    fold_params = []
+    for v in range(1, nfolds + 1):
+        tr = np.flatnonzero(kfolds == v) if n > 4000 else np.flatnonzero(kfolds != v)
+        fold_params.append({"g": oe.lm_model(oe.lm_fit(X[tr], y[tr]))})
+    want = oe.cv_residuals(fold_params, X, y, kfolds, labels="g")
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-8 * np.abs(y).max()
