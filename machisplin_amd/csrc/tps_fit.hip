@@ -1378,7 +1378,6 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
         hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
-        MHS_HIP(hipStreamSynchronize(s));  // vbuf is reused by the next upload
     }
     MHS_HIP(hipGetLastError());
     lap("gram + projection");
