@@ -1083,7 +1083,8 @@ __global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict_
                                                              double *__restrict__ d, double *__restrict__ e,
                                                              double *__restrict__ tau, double *__restrict__ g) {
     __shared__ double vs[TRI_SMALL_MAX], ws[TRI_SMALL_MAX], part[1024];
-    __shared__ double lds[17 * 2 + 2];
+    __shared__ double pbuf[2][16][BW];   // per-wave partials of the two reductions of a column
+    __shared__ double alpha_s;
     double *B = A + (int64_t)off * ld + off;
     for (int k = 0; k < m - 1; ++k) {
         const int t = m - k - 1;                       // order of the trailing block B22 = B[k+1:, k+1:]
@@ -1098,14 +1099,14 @@ __global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict_
         const int G = max(1, 1024 / rows_pad);         // column groups
         const int ii = threadIdx.x % rows_pad, jg = threadIdx.x / rows_pad;
         const bool act = jg < G && ii < t;
-        // Householder vector of x (dlarfg)
+        // Householder vector of x (dlarfg).  Reductions as in the panel kernel: lane-swap / DPP partials, one
+        // barrier, every wave adds the 16 partials itself (alternating buffers): 6 barriers per column, not 11.
         const double xi = (threadIdx.x < t) ? x[threadIdx.x] : 0.0;
         double red1[1] = {threadIdx.x >= 1 && threadIdx.x < t ? xi * xi : 0.0};
-        block_sum_vec<1>(red1, lds);
-        const double ss = red1[0];
-        __shared__ double alpha_s;
+        wave_publish<1>(red1, pbuf[0]);
         if (threadIdx.x == 0) alpha_s = xi;
         __syncthreads();
+        const double ss = lane_value(block_total<1, 16>(pbuf[0]), 0);
         const double alpha = alpha_s;
         double beta = alpha, tk = 0.0, scal = 0.0;
         if (ss != 0.0) {
@@ -1137,10 +1138,13 @@ __global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict_
             gi = g[k + 1 + threadIdx.x];
         }
         double red2[2] = {pi * vi, vi * gi};
-        block_sum_vec<2>(red2, lds);
+        wave_publish<2>(red2, pbuf[1]);
+        __syncthreads();
+        const double tot2 = block_total<2, 16>(pbuf[1]);
+        const double pv = lane_value(tot2, 0), vg = lane_value(tot2, 1);
         if (threadIdx.x < t) {
-            ws[threadIdx.x] = pi - 0.5 * tk * red2[0] * vi;
-            g[k + 1 + threadIdx.x] = gi - tk * red2[1] * vi;
+            ws[threadIdx.x] = pi - 0.5 * tk * pv * vi;
+            g[k + 1 + threadIdx.x] = gi - tk * vg * vi;
         }
         __syncthreads();
         // B22 <- B22 - v w' - w v'
@@ -1158,8 +1162,9 @@ __global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict_
 // q <- Q q = H_0 H_1 ... H_{m-3} q with the reflectors tridiag_small_kernel left below the subdiagonal
 __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
                                                             const double *__restrict__ tau, double *__restrict__ q) {
-    __shared__ double lds[17 + 1];
+    __shared__ double pbuf[2][16][BW];
     const double *B = A + (int64_t)off * ld + off;
+    int ph = 0;
     for (int k = m - 3; k >= 0; --k) {
         const int t = m - k - 1;
         const double tk = tau[k];
@@ -1167,8 +1172,11 @@ __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__rest
         double vi = 0.0, qi = 0.0;
         if (threadIdx.x < t) { vi = threadIdx.x == 0 ? 1.0 : x[threadIdx.x]; qi = q[k + 1 + threadIdx.x]; }
         double red[1] = {vi * qi};
-        block_sum_vec<1>(red, lds);
-        if (threadIdx.x < t) q[k + 1 + threadIdx.x] = qi - tk * red[0] * vi;
+        wave_publish<1>(red, pbuf[ph]);
+        __syncthreads();
+        const double vq = lane_value(block_total<1, 16>(pbuf[ph]), 0);
+        ph ^= 1;
+        if (threadIdx.x < t) q[k + 1 + threadIdx.x] = qi - tk * vq * vi;
         __syncthreads();
     }
 }
