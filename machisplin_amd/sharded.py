@@ -102,14 +102,14 @@ class ShardedMltps:
     def step(self):
         ops, torch = self.ops, self.torch
         nb = self.r1 - self.r0
-        # Step 2 at the stations first (a few thousand points): it is all the fit needs, so rank 0
-        # can fit the spline WHILE every rank's ensemble band is still running -- the band kernels
-        # are only enqueued here (VALU / LDS bound), the fit's many small bandwidth-bound kernels run
-        # on the library's own high-priority streams
-        knots, resid, resp, rows, cols = ops.station_residuals()
-        n = knots.shape[0]
+        # The band kernels are only enqueued here (VALU / LDS bound, ~0.5 s at N = 1).  Step 2 at the stations (a
+        # few thousand points, all the fit needs) follows on the library's own high-priority stream: a
+        # prioritised small grid gets its slots within a millisecond or two of its launch, so the residuals cost
+        # nothing on the critical path, and rank 0 fits the spline while every rank's band is still running
         if nb > 0:
             ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
+        knots, resid, resp, rows, cols = ops.station_residuals()
+        n = knots.shape[0]
         # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
         work = None
         if self.world > 1:
