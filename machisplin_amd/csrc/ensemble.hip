@@ -1694,6 +1694,7 @@ int mhs_residual_points(const mhs_model *const *models, const double *weights, i
                         const double *X, const double *resp, int64_t n, double *out_host) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(models && weights && X && resp && out_host && n_models >= 1 && n >= 1 && n < (1LL << 31), "bad arguments");
+    MHS_REQUIRE(n_models <= 8, "at most 8 members");
     const int p = models[0]->p;
     for (int k = 0; k < n_models; ++k) MHS_REQUIRE(models[k] && models[k]->p == p, "models disagree on the number of predictors");
     hipStream_t s = ctx().stream;
@@ -1716,7 +1717,6 @@ int mhs_residual_points(const mhs_model *const *models, const double *weights, i
     for (int k = 0; k < n_models; ++k)
         if (int rc = launch_model(models[k], sd, pg, 1.0, 0, dpred + (size_t)k * n, s)) return rc;
     ResidualArgs ra;
-    MHS_REQUIRE(n_models <= 8, "at most 8 members");
     for (int k = 0; k < 8; ++k) ra.w[k] = k < n_models ? weights[k] : 0.0;
     hipLaunchKernelGGL(residual_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpred, dresp, n, n_models, ra,
                        wt_total, dout);

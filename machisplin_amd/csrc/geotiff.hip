@@ -15,7 +15,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +38,7 @@ struct Ifd {
 struct TiffFile {
     FILE *f = nullptr;
     bool big = false, swap = false;
+    uint64_t size = 0;   // bytes in the file: every offset / count a header field names is checked against it
     std::vector<Ifd> ifds;
     ~TiffFile() { if (f) fclose(f); }
 };
@@ -67,6 +70,7 @@ static const int TYPE_SIZE[] = {0, 1, 1, 2, 4, 8, 1, 1, 2, 4, 8, 4, 8, 4, 0, 0, 
 static bool entry_values(TiffFile &t, int type, uint64_t count, uint64_t valoff_pos, std::vector<double> *out,
                          std::string *ascii) {
     if (type <= 0 || type > 18 || TYPE_SIZE[type] == 0) return false;
+    if (count > t.size) return false;   // a value array cannot be longer than the file (bounds the allocations below)
     const uint64_t bytes = (uint64_t)TYPE_SIZE[type] * count;
     const uint64_t inline_cap = t.big ? 8 : 4;
     uint64_t pos = valoff_pos;
@@ -74,6 +78,7 @@ static bool entry_values(TiffFile &t, int type, uint64_t count, uint64_t valoff_
         if (t.big) { uint64_t o; if (!rdv(t, valoff_pos, &o)) return false; pos = o; }
         else { uint32_t o; if (!rdv(t, valoff_pos, &o)) return false; pos = o; }
     }
+    if (pos > t.size || bytes > t.size - pos) return false;
     std::vector<uint8_t> raw((size_t)bytes);
     if (bytes && !rd(t.f, pos, raw.data(), (size_t)bytes)) return false;
     if (type == 2) { if (ascii) ascii->assign((const char *)raw.data(), (size_t)bytes); return true; }
@@ -107,6 +112,8 @@ static bool entry_values(TiffFile &t, int type, uint64_t count, uint64_t valoff_
 static int open_tiff(const char *path, TiffFile *t) {
     t->f = fopen(path, "rb");
     if (!t->f) { set_error("cannot open %s", path); return MHS_ERR_INVALID; }
+    if (fseeko(t->f, 0, SEEK_END) != 0) { set_error("%s: cannot seek", path); return MHS_ERR_INVALID; }
+    { const off_t end = ftello(t->f); t->size = end > 0 ? (uint64_t)end : 0; }
     uint8_t hdr[16];
     if (!rd(t->f, 0, hdr, 8)) { set_error("%s: not a TIFF (short file)", path); return MHS_ERR_INVALID; }
     const bool le = hdr[0] == 'I' && hdr[1] == 'I', be = hdr[0] == 'M' && hdr[1] == 'M';
@@ -124,6 +131,7 @@ static int open_tiff(const char *path, TiffFile *t) {
         if (t->big) { if (!rdv(*t, next, &n_entries)) break; }
         else { uint16_t n16; if (!rdv(*t, next, &n16)) break; n_entries = n16; }
         const uint64_t esz = t->big ? 20 : 12, base = next + (t->big ? 8 : 2);
+        if (n_entries > 4096 || base > t->size || n_entries * esz > t->size - base) { set_error("%s: corrupt image directory", path); return MHS_ERR_INVALID; }
         Ifd d;
         for (uint64_t e = 0; e < n_entries; ++e) {
             const uint64_t p = base + e * esz;
@@ -181,6 +189,32 @@ static int check_ifd(const char *path, const Ifd &d) {
     if (!(d.comp == 1 || d.comp == 5 || d.comp == 8 || d.comp == 32946)) { set_error("%s: compression %d unsupported (none, LZW, deflate)", path, d.comp); return MHS_ERR_INVALID; }
     if (!(d.pred == 1 || d.pred == 2 || d.pred == 3)) { set_error("%s: predictor %d unsupported", path, d.pred); return MHS_ERR_INVALID; }
     if (d.offsets.empty() || d.offsets.size() != d.counts.size()) { set_error("%s: missing strip/tile offsets", path); return MHS_ERR_INVALID; }
+    return MHS_OK;
+}
+
+// Everything the decoder derives from header fields, checked BEFORE any buffer is sized from them: a crafted
+// width / height / tile size must not overflow the byte counts, every chunk the directory names must lie inside
+// the file, and the directory must name as many chunks as the geometry needs.
+constexpr int64_t TIFF_MAX_DIM = (int64_t)1 << 30;          // samples per row / rows
+constexpr int64_t TIFF_MAX_CHUNK_BYTES = (int64_t)1 << 31;  // one decoded strip / tile
+static int check_layout(const char *path, const TiffFile &t, const Ifd &d) {
+    if (int rc = check_ifd(path, d)) return rc;
+    const int64_t bps = d.bits / 8;
+    if (d.width > TIFF_MAX_DIM || d.height > TIFF_MAX_DIM || d.width > ((int64_t)1 << 46) / d.height / bps) {
+        set_error("%s: image dimensions %lld x %lld out of range", path, (long long)d.width, (long long)d.height);
+        return MHS_ERR_INVALID;
+    }
+    if ((d.tile_w > 0) != (d.tile_h > 0) || d.tile_w < 0 || d.tile_h < 0 || d.tile_w > TIFF_MAX_DIM || d.tile_h > TIFF_MAX_DIM) {
+        set_error("%s: bad tile dimensions", path);
+        return MHS_ERR_INVALID;
+    }
+    const bool tiled = d.tile_w > 0;
+    const int64_t cw = tiled ? d.tile_w : d.width, chh = tiled ? d.tile_h : d.rows_per_strip;
+    if (chh <= 0 || cw > TIFF_MAX_CHUNK_BYTES / bps / chh) { set_error("%s: strip/tile of %lld x %lld samples is too large", path, (long long)cw, (long long)chh); return MHS_ERR_INVALID; }
+    const int64_t across = tiled ? (d.width + cw - 1) / cw : 1, down = (d.height + chh - 1) / chh;
+    if ((uint64_t)across * (uint64_t)down > d.offsets.size()) { set_error("%s: directory names %zu strips/tiles, the geometry needs %lld", path, d.offsets.size(), (long long)(across * down)); return MHS_ERR_INVALID; }
+    for (size_t k = 0; k < d.offsets.size(); ++k)
+        if (d.offsets[k] > t.size || d.counts[k] > t.size - d.offsets[k]) { set_error("%s: strip/tile %zu lies outside the file", path, k); return MHS_ERR_INVALID; }
     return MHS_OK;
 }
 
@@ -309,6 +343,7 @@ static int decode_rows(TiffFile &t, const Ifd &d, int64_t r0, int64_t r1, uint8_
     std::atomic<int64_t> next(0);
     std::atomic<int> bad(0);
     auto work = [&]() {
+      try {   // an exception leaving a std::thread calls std::terminate -- and would take the R process with it
         std::vector<uint8_t> raw, buf;
         for (int64_t j = next++; j < nchunks; j = next++) {
             const int64_t kr = k0 + j / across, kc = j % across;
@@ -324,6 +359,7 @@ static int decode_rows(TiffFile &t, const Ifd &d, int64_t r0, int64_t r1, uint8_
                        (size_t)ncopy * bps);
             }
         }
+      } catch (...) { bad = 1; }
     };
     nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, nchunks));
     std::vector<std::thread> pool;
@@ -370,6 +406,7 @@ static int write_f32_tiff(const char *path, const mhs_grid &g, const float *data
     std::atomic<int64_t> next(0);
     std::atomic<int> bad(0);
     auto work = [&]() {
+      try {
         for (int64_t s = next++; s < nstrips; s = next++) {
             const int64_t r0 = s * rps, nr = std::min(rps, H - r0);
             const uint8_t *src = (const uint8_t *)(data + r0 * W);
@@ -382,6 +419,7 @@ static int write_f32_tiff(const char *path, const mhs_grid &g, const float *data
                 strips[(size_t)s].resize(cap);
             }
         }
+      } catch (...) { bad = 1; }
     };
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(decode_threads(), nstrips));
     std::vector<std::thread> pool;
@@ -474,15 +512,23 @@ static int write_f32_tiff(const char *path, const mhs_grid &g, const float *data
 
 using namespace mhs;
 
-extern "C" {
+// No exception crosses the C ABI (the R shim would longjmp over live C++ frames): the bodies below run inside
+// guard(), which maps std::bad_alloc to MHS_ERR_ALLOC and anything else to MHS_ERR_INVALID.
+template <typename F>
+static int guard(const char *what, F &&body) {
+    try { return body(); }
+    catch (const std::bad_alloc &) { set_error("%s: out of memory", what); return MHS_ERR_ALLOC; }
+    catch (const std::exception &e) { set_error("%s: %s", what, e.what()); return MHS_ERR_INVALID; }
+    catch (...) { set_error("%s: unexpected exception", what); return MHS_ERR_INVALID; }
+}
 
-int mhs_tiff_info_read(const char *path, int ifd, mhs_tiff_info *out) {
+static int mhs_tiff_info_read_impl(const char *path, int ifd, mhs_tiff_info *out) {
     MHS_REQUIRE(path && out && ifd >= 0, "bad arguments");
     TiffFile t;
     if (int rc = open_tiff(path, &t)) return rc;
     if ((size_t)ifd >= t.ifds.size()) { set_error("%s has %zu image directories", path, t.ifds.size()); return MHS_ERR_INVALID; }
     const Ifd &d = t.ifds[(size_t)ifd];
-    if (int rc = check_ifd(path, d)) return rc;
+    if (int rc = check_layout(path, t, d)) return rc;
     out->width = d.width; out->height = d.height; out->bits = d.bits; out->sample_format = d.fmt;
     out->compression = d.comp; out->n_ifd = (int32_t)t.ifds.size(); out->nodata = d.nodata;
     out->dtype = dtype_of(d);
@@ -494,25 +540,25 @@ int mhs_tiff_info_read(const char *path, int ifd, mhs_tiff_info *out) {
     return MHS_OK;
 }
 
-int mhs_tiff_read_host(const char *path, int ifd, void *out, int64_t out_bytes) {
+static int mhs_tiff_read_host_impl(const char *path, int ifd, void *out, int64_t out_bytes) {
     MHS_REQUIRE(path && out && ifd >= 0, "bad arguments");
     TiffFile t;
     if (int rc = open_tiff(path, &t)) return rc;
     if ((size_t)ifd >= t.ifds.size()) { set_error("%s has %zu image directories", path, t.ifds.size()); return MHS_ERR_INVALID; }
     const Ifd &d = t.ifds[(size_t)ifd];
-    if (int rc = check_ifd(path, d)) return rc;
+    if (int rc = check_layout(path, t, d)) return rc;
     MHS_REQUIRE(out_bytes >= d.width * d.height * (d.bits / 8), "output buffer too small");
     return decode_rows(t, d, 0, d.height, (uint8_t *)out, decode_threads());
 }
 
-int mhs_tiff_read_dev(const char *path, int ifd, void *out_dev, int64_t ld_elems, void *stream) {
+static int mhs_tiff_read_dev_impl(const char *path, int ifd, void *out_dev, int64_t ld_elems, void *stream) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(path && out_dev && ifd >= 0, "bad arguments");
     TiffFile t;
     if (int rc = open_tiff(path, &t)) return rc;
     if ((size_t)ifd >= t.ifds.size()) { set_error("%s has %zu image directories", path, t.ifds.size()); return MHS_ERR_INVALID; }
     const Ifd &d = t.ifds[(size_t)ifd];
-    if (int rc = check_ifd(path, d)) return rc;
+    if (int rc = check_layout(path, t, d)) return rc;
     MHS_REQUIRE(dtype_of(d) >= 0, "sample type has no device plane type (need int16, float32 or float64)");
     MHS_REQUIRE(ld_elems >= d.width, "ld smaller than the image width");
     hipStream_t s = pick_stream(stream);
@@ -544,13 +590,13 @@ int mhs_tiff_read_dev(const char *path, int ifd, void *out_dev, int64_t ld_elems
     return rc;
 }
 
-int mhs_tiff_write_f32_host(const char *path, const mhs_grid *g, const float *data, double nodata, int compression) {
+static int mhs_tiff_write_f32_host_impl(const char *path, const mhs_grid *g, const float *data, double nodata, int compression) {
     MHS_REQUIRE(path && g && data && g->nrow > 0 && g->ncol > 0, "bad arguments");
     MHS_REQUIRE(compression == 1 || compression == 8, "compression must be 1 (none) or 8 (deflate)");
     return write_f32_tiff(path, *g, data, nodata, compression);
 }
 
-int mhs_tiff_write_f32_dev(const char *path, const mhs_grid *g, const double *plane_dev, int64_t ld, double nodata,
+static int mhs_tiff_write_f32_dev_impl(const char *path, const mhs_grid *g, const double *plane_dev, int64_t ld, double nodata,
                            int compression, void *stream) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(path && g && plane_dev && g->nrow > 0 && g->ncol > 0 && ld >= g->ncol, "bad arguments");
@@ -572,7 +618,7 @@ int mhs_tiff_write_f32_dev(const char *path, const mhs_grid *g, const double *pl
     return rc;
 }
 
-int mhs_tfw_read(const char *path, double *six) {
+static int mhs_tfw_read_impl(const char *path, double *six) {
     MHS_REQUIRE(path && six, "bad arguments");
     FILE *f = fopen(path, "r");
     if (!f) { set_error("cannot open %s", path); return MHS_ERR_INVALID; }
@@ -581,6 +627,28 @@ int mhs_tfw_read(const char *path, double *six) {
     fclose(f);
     if (n != 6) { set_error("%s: a world file needs six numbers", path); return MHS_ERR_INVALID; }
     return MHS_OK;
+}
+
+extern "C" {
+
+int mhs_tiff_info_read(const char *path, int ifd, mhs_tiff_info *out) {
+    return guard("mhs_tiff_info_read", [&] { return mhs_tiff_info_read_impl(path, ifd, out); });
+}
+int mhs_tiff_read_host(const char *path, int ifd, void *out, int64_t out_bytes) {
+    return guard("mhs_tiff_read_host", [&] { return mhs_tiff_read_host_impl(path, ifd, out, out_bytes); });
+}
+int mhs_tiff_read_dev(const char *path, int ifd, void *out_dev, int64_t ld_elems, void *stream) {
+    return guard("mhs_tiff_read_dev", [&] { return mhs_tiff_read_dev_impl(path, ifd, out_dev, ld_elems, stream); });
+}
+int mhs_tiff_write_f32_host(const char *path, const mhs_grid *g, const float *data, double nodata, int compression) {
+    return guard("mhs_tiff_write_f32_host", [&] { return mhs_tiff_write_f32_host_impl(path, g, data, nodata, compression); });
+}
+int mhs_tiff_write_f32_dev(const char *path, const mhs_grid *g, const double *plane_dev, int64_t ld, double nodata,
+                           int compression, void *stream) {
+    return guard("mhs_tiff_write_f32_dev", [&] { return mhs_tiff_write_f32_dev_impl(path, g, plane_dev, ld, nodata, compression, stream); });
+}
+int mhs_tfw_read(const char *path, double *six) {
+    return guard("mhs_tfw_read", [&] { return mhs_tfw_read_impl(path, six); });
 }
 
 }  // extern "C"

@@ -87,13 +87,18 @@ extern "C" int mhs_lm_fit(const double *X, const double *y, int64_t n, int p, do
     MHS_HIP(hipStreamSynchronize(s));
     // R[r + q c]: the leading (p+1) x (p+1) triangle and, in column q-1, the first p+1 entries of Q'y
     const int k = p + 1;
-    double rmax = 0.0;
-    for (int j = 0; j < k; ++j) rmax = std::max(rmax, fabs(R[(size_t)j + (size_t)q * j]));
-    for (int j = 0; j < k; ++j)
-        if (!(fabs(R[(size_t)j + (size_t)q * j]) > 1e-7 * rmax)) {   // lm's rank tolerance
+    // lm's rank test (dqrdc2, tol = 1e-7): a column is dropped when what is left of it after the earlier columns
+    // have been projected out, |R_jj|, falls below tol x the column's ORIGINAL norm -- a per-column, unit-free test
+    // (elevation in metres beside a narrow-range covariate must not read as rank deficiency).
+    for (int j = 0; j < k; ++j) {
+        double cn = 0.0;
+        for (int64_t i = 0; i < n; ++i) cn += M[(size_t)j * n + i] * M[(size_t)j * n + i];
+        cn = sqrt(cn);
+        if (!(fabs(R[(size_t)j + (size_t)q * j]) > 1e-7 * cn)) {
             set_error("mhs_lm_fit: rank-deficient design (column %d)", j);
             return MHS_ERR_NUMERIC;
         }
+    }
     for (int j = k - 1; j >= 0; --j) {
         double sum = R[(size_t)j + (size_t)q * (q - 1)];
         for (int c = j + 1; c < k; ++c) sum -= R[(size_t)j + (size_t)q * c] * coef[c];

@@ -148,7 +148,6 @@ extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const do
     rc = mhs_mosaic_feather_dev(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s);
     if (timing) { (void)hipStreamSynchronize(s); lap("mosaic + feather"); }
     return rc;
-    return mhs_mosaic_feather_dev(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s);
 }
 
 extern "C" int mhs_tps_surface(const mhs_grid *g, const double *xy, const double *resid, int64_t n,

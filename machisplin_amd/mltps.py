@@ -116,18 +116,32 @@ def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None,
     return tiles.mosaic_feather(geom, nRx, nCx, keep_win, bufs, merge_mode=False, out=out)
 
 
+def complete_cases(stack: RasterStack, int_values):
+    """``Mydata[complete.cases(Mydata),]`` (V73:154): the reference filters ONCE over every column of the
+    joined table -- long, lat, every response layer and every extracted covariate -- so a station with an NA
+    in any response layer is dropped from ALL layers.  Returns the boolean keep mask over the rows of
+    `int_values` (columns long, lat, response layers)."""
+    int_values = np.asarray(int_values, dtype=np.float64)
+    X, _, _ = station_predictors(stack, int_values[:, :2])
+    return ~np.isnan(X).any(axis=1) & ~np.isnan(int_values).any(axis=1)
+
+
 def mltps_predict(stack: RasterStack, int_xy, resp, models, weights, wt_total, tps: bool = True,
-                  tile_edge: int = 1500, lambda_=None, gcv_mode: str = "fields", tps_info: bool = False):
+                  tile_edge: int = 1500, lambda_=None, gcv_mode: str = "fields", tps_info: bool = False,
+                  keep=None):
     """machisplin.mltps Steps 2-5 for ONE response layer, given the fitted ensemble members.
 
     Returns a dict mirroring ``omega[[i]]`` (V73:914-930, 946-955): ``final`` (device tensor),
     ``residuals`` (n x 3: residual, long, lat), ``summary`` (r2 ensemble / r2 final) plus the
     intermediate ``pred_elev`` and ``final_tps`` planes.  ``tps_info=True`` composes Step 3 tile by tile and
-    reports the per-tile station counts and lambdas in ``tps_info`` (same surface, slower)."""
+    reports the per-tile station counts and lambdas in ``tps_info`` (same surface, slower).  ``keep`` is the
+    table-wide complete.cases mask (:func:`complete_cases`, what :func:`mltps` passes); without it the mask is
+    taken over this layer's columns only -- the caller then owns the reference's table-wide filter."""
     import torch
     g = stack.geom
     X, rows, cols = station_predictors(stack, int_xy)
-    keep = ~np.isnan(X).any(axis=1) & ~np.isnan(np.asarray(resp, dtype=np.float64))  # complete.cases, V73:154
+    own = ~np.isnan(X).any(axis=1) & ~np.isnan(np.asarray(resp, dtype=np.float64))  # complete.cases, V73:154
+    keep = own if keep is None else (np.asarray(keep, dtype=bool) & own)
     X, rows, cols = X[keep], rows[keep], cols[keep]
     y = np.asarray(resp, dtype=np.float64)[keep]
     # Step 2 (V73:447-620)
@@ -170,10 +184,11 @@ def mltps(stack: RasterStack, int_values, fitted, tps: bool = True, tile_edge: i
     n_layers = int_values.shape[1] - 2
     if n_layers != len(fitted):
         raise ValueError("fitted must hold one entry per response column of int_values")
+    keep = complete_cases(stack, int_values)   # once, over every column of the table (V73:154)
     omega = []
     for i, f in enumerate(fitted):
         out = mltps_predict(stack, int_values[:, :2], int_values[:, 2 + i], f["models"], f["weights"], f["wt_total"],
-                            tps=tps, tile_edge=tile_edge, lambda_=lambda_, gcv_mode=gcv_mode)
+                            tps=tps, tile_edge=tile_edge, lambda_=lambda_, gcv_mode=gcv_mode, keep=keep)
         out["n_layers"] = n_layers
         omega.append(out)
     return omega

@@ -49,18 +49,34 @@ def balanced_rank0_share(world: int, cells_ms: float, fit_ms: float) -> float:
     return min(max(s0, 0.0), 1.0 / world)
 
 
-def pack_tps(knots, c, d, center, scale, lambda_):
-    """Flat float64 message for the coefficient broadcast: u[n], v[n], c[n], d[3], center[2],
-    scale[2], lambda."""
+def tps_msg_len(n_stations: int) -> int:
+    """Doubles in the coefficient broadcast for a fit on at most `n_stations` station rows."""
+    return 3 * int(n_stations) + 9
+
+
+def pack_tps(knots, c, d, center, scale, lambda_, n_stations: int | None = None):
+    """Flat float64 message for the coefficient broadcast: n, u[n], v[n], c[n], d[3], center[2],
+    scale[2], lambda -- zero-padded to tps_msg_len(n_stations).  n is the number of UNIQUE knots of
+    the fit: fields::Tps collapses replicated locations (two stations in one cell, V73:127-154 make
+    knots cell centres), so n <= the number of station rows and travels in the message."""
     knots = np.asarray(knots, dtype=np.float64)
-    return np.concatenate([knots[:, 0], knots[:, 1], np.asarray(c, dtype=np.float64), np.asarray(d, dtype=np.float64),
-                           np.asarray(center, dtype=np.float64), np.asarray(scale, dtype=np.float64), [float(lambda_)]])
+    n = knots.shape[0]
+    msg = np.concatenate([[float(n)], knots[:, 0], knots[:, 1], np.asarray(c, dtype=np.float64),
+                          np.asarray(d, dtype=np.float64), np.asarray(center, dtype=np.float64),
+                          np.asarray(scale, dtype=np.float64), [float(lambda_)]])
+    if n_stations is not None:
+        if n > n_stations:
+            raise ValueError("fit has more knots than station rows")
+        msg = np.concatenate([msg, np.zeros(tps_msg_len(n_stations) - msg.size)])
+    return msg
 
 
-def unpack_tps(buf, n):
+def unpack_tps(buf):
     buf = np.asarray(buf, dtype=np.float64)
-    return {"knots": np.column_stack([buf[:n], buf[n:2 * n]]), "c": buf[2 * n:3 * n], "d": buf[3 * n:3 * n + 3],
-            "center": buf[3 * n + 3:3 * n + 5], "scale": buf[3 * n + 5:3 * n + 7], "lambda": float(buf[3 * n + 7])}
+    n = int(buf[0])
+    b = buf[1:]
+    return {"knots": np.column_stack([b[:n], b[n:2 * n]]), "c": b[2 * n:3 * n], "d": b[3 * n:3 * n + 3],
+            "center": b[3 * n + 3:3 * n + 5], "scale": b[3 * n + 5:3 * n + 7], "lambda": float(b[3 * n + 7]), "n": n}
 
 
 class ShardedMltps:
@@ -70,7 +86,7 @@ class ShardedMltps:
       ensemble_band(r0, r1, out)      pred.elev rows [r0, r1) written into `out`         (Step 2)
       station_residuals() -> (knots n x 2, res.FINAL n, resp n, rows n, cols n)          (Step 2)
       tps_fit(knots, resid) -> packed coefficients (pack_tps)                            (Step 3, rank 0)
-      tps_band(packed, n, r0, r1, out)  final.TPS rows [r0, r1)                          (Step 3)
+      tps_band(packed, r0, r1, out)   final.TPS rows [r0, r1)                            (Step 3)
       add(a, b, out)                  out = a + b, NA if either is NA                    (Step 5)
       gather(plane, rows, cols) -> np.ndarray                                            (Step 5)
     """
@@ -114,9 +130,10 @@ class ShardedMltps:
         work = None
         if self.world > 1:
             work = self.dist.all_gather_into_tensor(self.full, self.pred, async_op=True)
-        msg = torch.zeros(3 * n + 8, dtype=torch.float64, device=ops.device)
+        msg = torch.zeros(tps_msg_len(n), dtype=torch.float64, device=ops.device)
         if self.rank == 0:
-            msg.copy_(torch.from_numpy(np.ascontiguousarray(ops.tps_fit(knots, resid))))
+            packed0 = np.ascontiguousarray(ops.tps_fit(knots, resid))
+            msg[:packed0.size].copy_(torch.from_numpy(packed0))   # replicates collapsed: fewer knots than rows
         if self.world > 1:
             self.dist.broadcast(msg, src=0)
         packed = msg.cpu().numpy()
@@ -126,7 +143,7 @@ class ShardedMltps:
         else:
             pred_full = self.pred[:self.nrow]
         # Step 3 on the whole grid on every rank, Step 5's sum
-        ops.tps_band(packed, n, 0, self.nrow, self.tps)
+        ops.tps_band(packed, 0, self.nrow, self.tps)
         ops.add(pred_full, self.tps, self.total)
         # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
         f_actual = ops.gather(self.total, rows, cols)
@@ -134,7 +151,7 @@ class ShardedMltps:
         rsq_model = 1.0 - float(np.sum(resid ** 2)) / tss
         rsq_final = 1.0 - float(np.sum((resp - f_actual) ** 2)) / tss
         final = self.total if rsq_final > rsq_model else pred_full   # V73:925-930
-        return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": float(packed[3 * n + 7])}
+        return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": unpack_tps(packed)["lambda"]}
 
 
 class HipOps:
@@ -143,7 +160,7 @@ class HipOps:
     of the device phases on the launch stream."""
 
     def __init__(self, stack, int_xy, resp, models, weights, wt_total, lambda_=None, gcv_mode="fields",
-                 timed: bool = False):
+                 timed: bool = False, keep=None):
         import torch
         from . import _lib, mltps
         self.torch, self._lib = torch, _lib
@@ -152,7 +169,8 @@ class HipOps:
         self.device = stack.planes.device
         X, rows, cols = mltps.station_predictors(stack, int_xy)
         y = np.asarray(resp, dtype=np.float64)
-        keep = ~np.isnan(X).any(axis=1) & ~np.isnan(y)  # complete.cases (V73:154)
+        own = ~np.isnan(X).any(axis=1) & ~np.isnan(y)  # complete.cases (V73:154)
+        keep = own if keep is None else (np.asarray(keep, dtype=bool) & own)   # table-wide mask: mltps.complete_cases
         self.X, self.rows, self.cols, self.y = X[keep], rows[keep], cols[keep], y[keep]
         self.timed = timed
         self.timings = {"ensemble_ms": [], "tps_eval_ms": [], "tps_fit_ms": [], "residuals_ms": []}
@@ -201,9 +219,9 @@ class HipOps:
         self.last_fit = fit
         return pack_tps(fit.knots, fit.c, fit.d, fit.center, fit.scale, fit.lambda_)
 
-    def tps_band(self, packed, n, r0, r1, out):
+    def tps_band(self, packed, r0, r1, out):
         from .tps import Tps, interpolate
-        d = unpack_tps(packed, n)
+        d = unpack_tps(packed)
         fit = Tps.from_coef(d["knots"], d["c"], d["d"], d["lambda"], d["center"], d["scale"])
         g = self.stack.geom
         self._timed("tps_eval_ms", lambda: interpolate(g, fit, window=(r0, r1, 0, g.ncol), out=out))

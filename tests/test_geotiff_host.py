@@ -97,3 +97,58 @@ def test_errors(tmp_path):
     Image.fromarray(np.zeros((4, 4, 3), dtype=np.uint8)).save(rgb)
     with pytest.raises(mhs.MhsError):  # three samples per pixel
         mio.tiff_info(rgb)
+
+
+def _patch_tag(raw: bytearray, tag: int, value: int):
+    """overwrite the inline value of a classic little-endian TIFF directory entry"""
+    import struct
+    ifd = struct.unpack_from("<I", raw, 4)[0]
+    n = struct.unpack_from("<H", raw, ifd)[0]
+    for e in range(n):
+        p = ifd + 2 + 12 * e
+        t, typ = struct.unpack_from("<HH", raw, p)
+        if t == tag:
+            if typ == 3:
+                struct.pack_into("<H", raw, p + 8, value & 0xFFFF)
+            else:
+                struct.pack_into("<I", raw, p + 8, value & 0xFFFFFFFF)
+            return
+    raise KeyError(tag)
+
+
+@pytest.mark.parametrize("tag,value", [(256, 0x7FFFFFF0), (257, 0x7FFFFFF0), (279, 0x7FFFFFFF), (273, 0x7FFFFF00),
+                                       (278, 0)])
+def test_crafted_header_fields_are_rejected_not_trusted(tmp_path, tag, value):
+    """width / height / StripByteCounts / StripOffsets that do not fit the file: an error code, never an
+    over-read, an attacker-sized allocation or an exception out of the C ABI (geotiff.hip)."""
+    a = np.arange(64 * 48, dtype=np.int16).reshape(48, 64)
+    p = str(tmp_path / "ok.tif")
+    Image.fromarray(a.view(np.uint16)).save(p, compression="raw", tiffinfo={339: 2, 278: 48})
+    raw = bytearray(open(p, "rb").read())
+    assert np.array_equal(mio.read_host(p), a)
+    _patch_tag(raw, tag, value)
+    q = str(tmp_path / "bad.tif")
+    open(q, "wb").write(bytes(raw))
+    if tag == 278:   # RowsPerStrip = 0 means "one strip" and stays readable
+        assert np.array_equal(mio.read_host(q), a)
+        return
+    with pytest.raises(mhs.MhsError):
+        mio.read_host(q)
+
+
+def test_truncated_file_and_huge_tag_count(tmp_path):
+    import struct
+    a = np.arange(64 * 48, dtype=np.int16).reshape(48, 64)
+    p = str(tmp_path / "ok.tif")
+    Image.fromarray(a.view(np.uint16)).save(p, compression="tiff_lzw", tiffinfo={339: 2})
+    raw = bytearray(open(p, "rb").read())
+    q = str(tmp_path / "cut.tif")
+    open(q, "wb").write(bytes(raw[: len(raw) // 2]))
+    with pytest.raises(mhs.MhsError):
+        mio.read_host(q)
+    # a directory entry whose count field claims 4e9 values
+    ifd = struct.unpack_from("<I", raw, 4)[0]
+    struct.pack_into("<I", raw, ifd + 2 + 4, 0xF0000000)
+    open(q, "wb").write(bytes(raw))
+    with pytest.raises(mhs.MhsError):
+        mio.tiff_info(q)

@@ -49,3 +49,16 @@ def test_lm_fit_rejects_bad_designs(hip):
     assert e.value.code == _lib.ERR_INVALID
     with pytest.raises(_lib.MhsError):
         Gam.fit(X[:5], y[:5])                            # fewer rows than coefficients
+
+
+def test_lm_fit_rank_test_is_per_column_like_dqrdc2(hip):
+    """lm's tolerance compares |R_jj| with the column's own original norm: a covariate in tiny units beside
+    elevation in metres is NOT rank deficiency (lm_fit.hip)."""
+    from machisplin_amd.models import Gam
+    rng = np.random.default_rng(9)
+    n = 400
+    X = np.column_stack([rng.normal(1500.0, 400.0, n), 1e-5 * rng.standard_normal(n), rng.uniform(-78, -76, n)])
+    y = 3.0 + 0.01 * X[:, 0] + 2e4 * X[:, 1] + 0.5 * X[:, 2] + 0.1 * rng.standard_normal(n)
+    m = Gam.fit(X, y)
+    ref = oe.lm_fit(X, y)
+    assert np.abs((m.coefficients - ref) / ref).max() < 1e-7

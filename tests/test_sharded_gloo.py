@@ -21,12 +21,14 @@ NROW, NCOL, N = 37, 29, 120  # 37 rows over 2 ranks: bands of 19 and 18 (uneven 
 class OracleOps:
     device = torch.device("cpu")
 
-    def __init__(self, w=1.0):
+    def __init__(self, w=1.0, dup=False):
         rng = np.random.default_rng(0)
         self.x, self.y = otps.cell_centres(-78.0, -5.0, 0.01, 0.01, NROW, NCOL)
         cov = rng.uniform(0, 100, (2, NROW, NCOL))
         self.Xgrid = oe.stack_predictors(cov, (self.x, self.y))
         cells = rng.choice(NROW * NCOL, N, replace=False)
+        if dup:   # two stations in one cell: fields::Tps collapses them, the fit has fewer knots than rows
+            cells[-7:] = cells[:7]
         self.rows, self.cols = np.divmod(cells, NCOL)
         self.Xs = self.Xgrid[cells]
         self.resp = 3 + 0.05 * self.Xs[:, 0] + np.sin(40 * self.Xs[:, 2]) + 0.1 * rng.standard_normal(N)
@@ -46,8 +48,8 @@ class OracleOps:
         m = otps.fit(knots, resid)
         return sharded.pack_tps(m["knots"], m["c"], m["d"], m["center"], m["scale"], m["lambda"])
 
-    def tps_band(self, packed, n, r0, r1, out):
-        m = sharded.unpack_tps(packed, n)
+    def tps_band(self, packed, r0, r1, out):
+        m = sharded.unpack_tps(packed)
         out.copy_(torch.from_numpy(otps.predict_grid(m, -78.0, -5.0, 0.01, 0.01, NROW, NCOL, r0, r1)))
 
     def add(self, a, b, out):
@@ -57,12 +59,12 @@ class OracleOps:
         return plane[torch.from_numpy(rows), torch.from_numpy(cols)].numpy()
 
 
-def _worker(rank, world, port, q, w, share=None):
+def _worker(rank, world, port, q, w, share=None, dup=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = sharded.ShardedMltps(OracleOps(w), dist, rank, world, NROW, NCOL, rank0_share=share)
+        run = sharded.ShardedMltps(OracleOps(w, dup), dist, rank, world, NROW, NCOL, rank0_share=share)
         out = run.step()
         q.put((rank, out["final"].numpy().copy(), out["rsq_model"], out["rsq_final"], out["lambda"]))
         dist.barrier()
@@ -89,20 +91,24 @@ def test_row_bands_and_packing():
     assert sharded.row_bands(2, 4)[1] == [(0, 1), (1, 2), (2, 2), (2, 2)]  # more ranks than rows
     kn = np.arange(10.0).reshape(5, 2)
     msg = sharded.pack_tps(kn, np.arange(5.0), [1, 2, 3], [4, 5], [6, 7], 0.5)
-    d = sharded.unpack_tps(msg, 5)
-    assert msg.size == 3 * 5 + 8
+    d = sharded.unpack_tps(msg)
+    assert msg.size == sharded.tps_msg_len(5) == 3 * 5 + 9 and d["n"] == 5
+    padded = sharded.pack_tps(kn, np.arange(5.0), [1, 2, 3], [4, 5], [6, 7], 0.5, n_stations=7)   # 2 replicated rows
+    assert padded.size == sharded.tps_msg_len(7) and sharded.unpack_tps(padded)["lambda"] == 0.5
+    assert np.array_equal(sharded.unpack_tps(padded)["knots"], kn)
     assert np.array_equal(d["knots"], kn) and list(d["d"]) == [1, 2, 3] and d["lambda"] == 0.5
     assert list(d["center"]) == [4, 5] and list(d["scale"]) == [6, 7]
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("w,share", [(1.0, None), (0.8, None), (1.0, 0.2), (1.0, 0.0)])
-def test_two_ranks_equal_one_rank(w, share):
-    single = sharded.ShardedMltps(OracleOps(w), None, 0, 1, NROW, NCOL).step()
+@pytest.mark.parametrize("w,share,dup", [(1.0, None, False), (0.8, None, False), (1.0, 0.2, False), (1.0, 0.0, False),
+                                         (1.0, None, True)])
+def test_two_ranks_equal_one_rank(w, share, dup):
+    single = sharded.ShardedMltps(OracleOps(w, dup), None, 0, 1, NROW, NCOL).step()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, w, share)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, w, share, dup)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]
