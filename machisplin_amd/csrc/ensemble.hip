@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "devmath.h"
@@ -71,13 +72,20 @@ struct mhs_model {
     int lut_S = 0;                       // splits per tree after padding (0 = path unavailable)
     double *lut = nullptr;               // device, n_trees_padded << lut_S leaf values
     int *lut_meta = nullptr;             // device, 12 dwords per tree: c[6] (float bits), key offset[6]
-    float *lut_sorted = nullptr;         // device, sorted distinct key-space thresholds, predictor after predictor
+    void *lut_sorted = nullptr;          // device, sorted distinct key-space thresholds, predictor after predictor
+                                         // (float keys for float32 / int16 planes, double keys for float64 planes)
     int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
     int n_trees_padded = 0;
     mhs_grid meta_grid = {0, 0, 0, 0, 0, 0};  // geometry lut_meta / rf_nodes were built for
     int meta_C = -1;
+    int meta_key64 = -1;                 // key type lut_meta / rf_nodes were built for (1 = double keys)
+    // The geometry-dependent tables above are IMMUTABLE once built: a rebuild (another grid, another plane type)
+    // allocates fresh buffers and retires the old ones until mhs_model_free, so kernels already enqueued on any
+    // stream keep reading what they were launched with; `mu` serialises rebuilds from several host threads.
+    std::vector<void *> retired;
+    std::mutex mu;
     // randomForest level-synchronous walk (rf_walk_kernel): available when every split node has
     // rightDaughter == leftDaughter + 1 (how randomForest numbers its nodes)
     bool rf_fast = false;
@@ -430,25 +438,29 @@ __device__ __forceinline__ void pred_bits(float2v &b01, float2v &b23, const floa
 // rank[c] = #{sorted distinct tkeys of predictor j that are <= key[c]} for the lane's LUT_R cells: a
 // binary search of a coarse table (every stride-th tkey, staged in LDS by the whole block) and a
 // short fine search in global memory.  Must be called by every thread of the block.
-template <int LUT_R, int NT>
-__device__ __forceinline__ void lut_ranks(const int j, const float *__restrict__ sorted,
-                                          const int *__restrict__ sorted_off, float *coarse,
-                                          const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
-                                          const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
+// KT = float: planes whose values are exactly float-representable (float32 / int16); KT = double: float64 planes
+// (what terra holds in RAM and the R shim hands over, V73:468-606) -- the search is 1 % of a tree kernel, so doing
+// it in double costs nothing and the ranks that come out are the same small integers either way.
+template <int LUT_R, int NT, typename KT>
+__device__ __forceinline__ void lut_ranks_t(const int j, const KT *__restrict__ sorted,
+                                            const int *__restrict__ sorted_off, KT *coarse,
+                                            const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
+                                            const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
+    constexpr int COARSE_N = LUT_COARSE * (int)sizeof(float) / (int)sizeof(KT);   // the scratch is LUT_COARSE floats
     const int o = sorted_off[j], n = sorted_off[j + 1] - o;
-    const float *T = sorted + o;
-    const int stride = (n + LUT_COARSE - 1) / LUT_COARSE;
+    const KT *T = sorted + o;
+    const int stride = (n + COARSE_N - 1) / COARSE_N;
     const int nc = stride ? (n + stride - 1) / stride : 0;
     __syncthreads();
     for (int e = threadIdx.x; e < nc; e += NT) coarse[e] = T[(int64_t)e * stride];
     __syncthreads();
-    float k[LUT_R];
+    KT k[LUT_R];
     int lo[LUT_R], cnt[LUT_R];
 #pragma unroll
     for (int c = 0; c < LUT_R; ++c) {
-        if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k[c] = (float)xv; }
-        else if (j == s.C) k[c] = (float)(g.c0 + col[c]);
-        else k[c] = -(float)(g.r0 + row[c]);
+        if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k[c] = (KT)xv; }
+        else if (j == s.C) k[c] = (KT)(g.c0 + col[c]);
+        else k[c] = -(KT)(g.r0 + row[c]);
         lo[c] = 0; cnt[c] = 0;
     }
     int top = 1;
@@ -473,11 +485,19 @@ __device__ __forceinline__ void lut_ranks(const int j, const float *__restrict__
 #pragma unroll
     for (int c = 0; c < LUT_R; ++c) rank[c] = (float)(lo[c] > 0 ? (lo[c] - 1) * stride + 1 + cnt[c] : 0);
 }
+template <int LUT_R, int NT>
+__device__ __forceinline__ void lut_ranks(const int j, const void *__restrict__ sorted, const int key64,
+                                          const int *__restrict__ sorted_off, float *coarse,
+                                          const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
+                                          const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
+    if (key64) lut_ranks_t<LUT_R, NT, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, rank);
+    else lut_ranks_t<LUT_R, NT, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, rank);
+}
 
 template <int S>
 __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__ lut,
                                                       const int *__restrict__ meta,
-                                                      const float *__restrict__ sorted,
+                                                      const void *__restrict__ sorted, int key64,
                                                       const int *__restrict__ sorted_off, int n_trees_padded,
                                                       double init_f, int p, StackDev s, PredGeom g,
                                                       double weight, int accumulate,
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__
     // keys -> ranks among the predictor's sorted distinct tkeys
     for (int j = 0; j < p; ++j) {
         float r[LUT_R];
-        lut_ranks<LUT_R, 256>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        lut_ranks<LUT_R, 256>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < LUT_R; ++c) keys[(j * 256 + threadIdx.x) * LUT_R + c] = -r[c];
     }
@@ -612,9 +632,9 @@ __device__ __forceinline__ void lut_tree_reg(float2v &a01, float2v &a23, const f
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void gbm_lutreg_kernel(const double *__restrict__ lut,
+__global__ __launch_bounds__(256, 5) void gbm_lutreg_kernel(const double *__restrict__ lut,
                                                          const int *__restrict__ meta,
-                                                         const float *__restrict__ sorted,
+                                                         const void *__restrict__ sorted, int key64,
                                                          const int *__restrict__ sorted_off, int n_trees_padded,
                                                          double init_f, int p, StackDev s, PredGeom g,
                                                          double weight, int accumulate,
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(256) void gbm_lutreg_kernel(const double *__restric
 #pragma unroll
     for (int j = 0; j < LUT_REG_P; ++j) {
         float r[LUT_R] = {0.f, 0.f, 0.f, 0.f};
-        if (j < p) lut_ranks<LUT_R, 256>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        if (j < p) lut_ranks<LUT_R, 256>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < LUT_R; ++c) keys[j * LUT_R + c] = -r[c];
     }
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
                                                        const double *__restrict__ glval,
                                                        const int *__restrict__ tree_off,
                                                        const int *__restrict__ depth,
-                                                       const float *__restrict__ sorted,
+                                                       const void *__restrict__ sorted, int key64,
                                                        const int *__restrict__ sorted_off, int n_trees,
                                                        int max_nodes, int p, StackDev s, PredGeom g,
                                                        double weight, int accumulate,
@@ -730,7 +750,7 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
     }
     for (int j = 0; j < p; ++j) {
         float r[R];
-        lut_ranks<R, 1024>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        lut_ranks<R, 1024>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
@@ -775,7 +795,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
                                                           const int *__restrict__ depth,
-                                                          const float *__restrict__ sorted,
+                                                          const void *__restrict__ sorted, int key64,
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int max_nodes, int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     }
     for (int j = 0; j < p; ++j) {
         float r[R];
-        lut_ranks<R, 1024>(j, sorted, sorted_off, coarse, s, g, row, col, na, r);
+        lut_ranks<R, 1024>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
@@ -1030,56 +1050,97 @@ static float ceil_to_float(double thr) {  // smallest float >= thr
     if ((double)f < thr) f = nextafterf(f, INFINITY);
     return f;
 }
+static float floor_to_float(double thr) {  // largest float <= thr
+    float f = (float)thr;
+    if ((double)f > thr) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+// Key-space threshold of a split for this grid:  x < thr (gbm, LE = false)  or  x <= thr (randomForest, LE = true)
+// <=>  key < tkey  EXACTLY, with key = the plane value as KT (float for float32 / int16 planes, which hold nothing
+// but float-representable values; double for float64 planes), the column index for LONG, minus the row index for
+// LAT (thresholds converted with the same double formula the kernels use for the cell centres).
+template <typename KT, bool LE>
+static KT split_tkey(int v, int C, double thr, const mhs_grid &grid) {
+    KT tk;
+    if (v < C) {
+        if constexpr (sizeof(KT) == 4) tk = LE ? nextafterf(floor_to_float(thr), INFINITY) : ceil_to_float(thr);
+        else tk = LE ? nextafter(thr, (double)INFINITY) : thr;
+    } else if (v == C) {  // LONG: columns whose centre is < (<=) thr form a prefix [0, c*)
+        int64_t lo = 0, hi = grid.ncol;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
+            if (LE ? x <= thr : x < thr) lo = mid + 1; else hi = mid;
+        }
+        tk = (KT)lo;
+    } else {              // LAT: rows whose centre is < (<=) thr form a suffix [r*, nrow)
+        int64_t lo = 0, hi = grid.nrow;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
+            if (LE ? y <= thr : y < thr) hi = mid; else lo = mid + 1;
+        }
+        tk = (KT)0.5 - (KT)lo;
+    }
+    if (tk != tk) tk = (KT)INFINITY;   // a NaN split value never sends a cell left or right by "<"
+    return tk;
+}
+
+static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64) {
+    const mhs_grid &o = m->meta_grid;
+    return m->meta_C == C && m->meta_key64 == key64 && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
+           o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol;
+}
+
+// what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
+struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; };
+
+// fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
+template <typename T>
+static int publish(mhs_model *m, const std::vector<T> &h, T **slot) {
+    T *d = nullptr;
+    if (int rc = to_device(h.data(), h.size(), &d)) return rc;
+    if (*slot) m->retired.push_back((void *)*slot);
+    *slot = d;
+    return MHS_OK;
+}
+
+// sorted distinct key-space thresholds per predictor, flattened; returns the per-predictor lists for the rank lookup
+template <typename KT>
+static void sort_unique(std::vector<std::vector<KT>> &sorted, std::vector<int> &off, std::vector<KT> &flat) {
+    off.assign(sorted.size() + 1, 0);
+    for (size_t v = 0; v < sorted.size(); ++v) {
+        std::vector<KT> &sv = sorted[v];
+        std::sort(sv.begin(), sv.end());
+        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
+        off[v + 1] = off[v] + (int)sv.size();
+        flat.insert(flat.end(), sv.begin(), sv.end());
+    }
+    if (flat.empty()) flat.push_back((KT)0);
+}
 
 // key-space thresholds of every split for this grid, the sorted distinct thresholds of each
-// predictor and every split's rank among them (see gbm_lut_kernel); cached per geometry
-static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C) {
-    const mhs_grid &o = m->meta_grid;
-    if (m->lut_meta && m->meta_C == C && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
-        o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
+// predictor and every split's rank among them (see gbm_lut_kernel); cached per geometry and key type
+template <typename KT>
+static int build_lut_meta_t(mhs_model *m, const mhs_grid &grid, int C) {
     const int S = m->lut_S;
-    std::vector<float> tkey((size_t)m->n_trees * S, 0.f);
-    std::vector<std::vector<float>> sorted((size_t)m->p);
+    std::vector<KT> tkey((size_t)m->n_trees * S, (KT)0);
+    std::vector<std::vector<KT>> sorted((size_t)m->p);
     for (int t = 0; t < m->n_trees; ++t) {
         for (int q = 0; q < S; ++q) {
             const int v = m->lut_var[(size_t)t * S + q];
             if (v < 0) continue;
-            const double thr = m->lut_thr[(size_t)t * S + q];
-            float tk;
-            if (v < C) {
-                tk = ceil_to_float(thr);
-            } else if (v == C) {  // LONG: columns whose centre is < thr form a prefix [0, c*)
-                int64_t lo = 0, hi = grid.ncol;
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) / 2;
-                    const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
-                    if (x < thr) lo = mid + 1; else hi = mid;
-                }
-                tk = (float)lo;
-            } else {              // LAT: rows whose centre is < thr form a suffix [r*, nrow)
-                int64_t lo = 0, hi = grid.nrow;
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) / 2;
-                    const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
-                    if (y < thr) hi = mid; else lo = mid + 1;
-                }
-                tk = 0.5f - (float)lo;
-            }
-            if (tk != tk) tk = INFINITY;   // a NaN split value never sends a cell left or right by "<"
+            const KT tk = split_tkey<KT, false>(v, C, m->lut_thr[(size_t)t * S + q], grid);
             tkey[(size_t)t * S + q] = tk;
             sorted[(size_t)v].push_back(tk);
         }
     }
-    std::vector<int> off((size_t)m->p + 1, 0);
-    std::vector<float> flat;
-    for (int v = 0; v < m->p; ++v) {
-        std::vector<float> &sv = sorted[(size_t)v];
-        std::sort(sv.begin(), sv.end());
-        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
-        off[(size_t)v + 1] = off[(size_t)v] + (int)sv.size();
-        flat.insert(flat.end(), sv.begin(), sv.end());
-    }
-    if (flat.empty()) flat.push_back(0.f);
+    std::vector<int> off;
+    std::vector<KT> flat;
+    sort_unique(sorted, off, flat);
+    for (int v = 0; v < m->p; ++v)
+        if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("gbm: too many distinct split values"); return MHS_ERR_INVALID; }
     std::vector<int> meta((size_t)m->n_trees_padded * LUT_META_DW, 0);
     const float never = -33554432.f;   // c - rank <= 0 for every rank: the padded predicates read 0
     for (int t = 0; t < m->n_trees_padded; ++t) {
@@ -1089,27 +1150,33 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C) {
         for (int q = 0; q < S; ++q) {
             const int v = m->lut_var[(size_t)t * S + q];
             if (v < 0) continue;
-            const std::vector<float> &sv = sorted[(size_t)v];
-            const float tk = tkey[(size_t)t * S + q];
+            const std::vector<KT> &sv = sorted[(size_t)v];
+            const KT tk = tkey[(size_t)t * S + q];
             const float c = (float)((std::lower_bound(sv.begin(), sv.end(), tk) - sv.begin()) + 1);
             memcpy(&mt[q], &c, 4);
             mt[6 + q] = v * 256 * LUT_R * (int)sizeof(float);
         }
     }
-    if (m->lut_sorted) { (void)hipFree(m->lut_sorted); m->lut_sorted = nullptr; }
-    if (int rc = to_device(flat.data(), flat.size(), &m->lut_sorted)) return rc;
-    if (!m->lut_sorted_off) MHS_HIP(hipMalloc((void **)&m->lut_sorted_off, off.size() * sizeof(int)));
-    MHS_HIP(hipMemcpy(m->lut_sorted_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (!m->lut_meta) MHS_HIP(hipMalloc((void **)&m->lut_meta, meta.size() * sizeof(int)));
-    MHS_HIP(hipMemcpy(m->lut_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
-    m->meta_grid = grid;
-    m->meta_C = C;
+    if (int rc = publish(m, flat, (KT **)&m->lut_sorted)) return rc;
+    if (int rc = publish(m, off, &m->lut_sorted_off)) return rc;
+    return publish(m, meta, &m->lut_meta);
+}
+
+static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, TreeTables *tt) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!(m->lut_meta && same_meta(m, grid, C, key64))) {
+        if (int rc = key64 ? build_lut_meta_t<double>(m, grid, C) : build_lut_meta_t<float>(m, grid, C)) return rc;
+        m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
+    }
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr};
     return MHS_OK;
 }
 
 static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
                           double w, int acc, double *out, hipStream_t st, int64_t total) {
-    if (int rc = build_lut_meta(const_cast<mhs_model *>(m), grid, s.C)) return rc;
+    const int key64 = s.dtype == MHS_F64;
+    TreeTables tt;
+    if (int rc = build_lut_meta(const_cast<mhs_model *>(m), grid, s.C, key64, &tt)) return rc;
     const int64_t quarter = (total + LUT_R - 1) / LUT_R;
     const unsigned blocks = (unsigned)((quarter + 255) / 256);
     const size_t lut_bytes = ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
@@ -1118,18 +1185,12 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     auto kern = in_regs ? (m->lut_S == 5 ? gbm_lutreg_kernel<5> : gbm_lutreg_kernel<6>)
                         : (m->lut_S == 5 ? gbm_lut_kernel<5> : gbm_lut_kernel<6>);
     MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, m->lut_meta, m->lut_sorted, m->lut_sorted_off,
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, tt.lut_meta, tt.sorted, key64, tt.sorted_off,
                        m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
     // cells with an NA covariate: walked through their MissingNode children
     return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
 }
 
-
-static float floor_to_float(double thr) {  // largest float <= thr
-    float f = (float)thr;
-    if ((double)f > thr) f = nextafterf(f, -INFINITY);
-    return f;
-}
 
 // LDS bytes of rf_walk_kernel for R = 2^log2r walks per lane
 static size_t rf_walk_lds(const mhs_model *m, int log2r, bool big) {
@@ -1165,52 +1226,25 @@ static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
     return false;
 }
 
-// key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry
-static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big) {
-    const mhs_grid &o = m->meta_grid;
-    if (m->rf_nodes && m->meta_C == C && m->rf_log2r == log2r && m->rf_big == big && o.xmin == grid.xmin && o.ymax == grid.ymax &&
-        o.xres == grid.xres && o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol) return MHS_OK;
+// key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry and key type
+template <typename KT>
+static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big) {
     const size_t nn = m->rf_thr.size();
-    std::vector<float> tkey(nn, 0.f);
-    std::vector<std::vector<float>> sorted((size_t)m->p);
+    std::vector<KT> tkey(nn, (KT)0);
+    std::vector<std::vector<KT>> sorted((size_t)m->p);
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
         if (v == 0xFFFFu) continue;
-        float tk;
-        if ((int)v < C) tk = nextafterf(floor_to_float(m->rf_thr[k]), INFINITY);
-        else if ((int)v == C) {   // LONG: columns with centre <= thr form a prefix [0, c*)
-            int64_t lo = 0, hi = grid.ncol;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) / 2;
-                const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
-                if (x <= m->rf_thr[k]) lo = mid + 1; else hi = mid;
-            }
-            tk = (float)lo;
-        } else {                  // LAT: rows with centre <= thr form a suffix [r*, nrow)
-            int64_t lo = 0, hi = grid.nrow;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) / 2;
-                const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
-                if (y <= m->rf_thr[k]) hi = mid; else lo = mid + 1;
-            }
-            tk = 0.5f - (float)lo;
-        }
-        if (tk != tk) tk = INFINITY;
+        const KT tk = split_tkey<KT, true>((int)v, C, m->rf_thr[k], grid);
         tkey[k] = tk;
         sorted[(size_t)v].push_back(tk);
     }
-    std::vector<int> off((size_t)m->p + 1, 0);
-    std::vector<float> flat;
-    for (int v = 0; v < m->p; ++v) {
-        std::vector<float> &sv = sorted[(size_t)v];
-        std::sort(sv.begin(), sv.end());
-        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
-        if (sv.size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
-        off[(size_t)v + 1] = off[(size_t)v] + (int)sv.size();
-        flat.insert(flat.end(), sv.begin(), sv.end());
-    }
-    if (flat.empty()) flat.push_back(0.f);
-    std::vector<unsigned long long> rec(nn);
+    std::vector<int> off;
+    std::vector<KT> flat;
+    sort_unique(sorted, off, flat);
+    for (int v = 0; v < m->p; ++v)
+        if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
+    std::vector<unsigned long long> rec(nn ? nn : 1, 0ull);
     const unsigned R = 1u << log2r;
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
@@ -1219,29 +1253,34 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, 
         unsigned node0 = 0, children;
         if (v == 0xFFFFu) children = (left * unit) | ((left * unit) << 16);
         else {
-            const std::vector<float> &sv = sorted[(size_t)v];
+            const std::vector<KT> &sv = sorted[(size_t)v];
             const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[k]) - sv.begin());
             node0 = (j << 8) | (v * R * 4u);
             children = (left * unit) | (((left + 1u) * unit) << 16);
         }
         rec[k] = ((unsigned long long)children << 32) | node0;
     }
-    if (m->lut_sorted) { (void)hipFree(m->lut_sorted); m->lut_sorted = nullptr; }
-    if (int rc = to_device(flat.data(), flat.size(), &m->lut_sorted)) return rc;
-    if (!m->lut_sorted_off) MHS_HIP(hipMalloc((void **)&m->lut_sorted_off, off.size() * sizeof(int)));
-    MHS_HIP(hipMemcpy(m->lut_sorted_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (!m->rf_nodes) MHS_HIP(hipMalloc((void **)&m->rf_nodes, (nn ? nn : 1) * sizeof(unsigned long long)));
-    MHS_HIP(hipMemcpy(m->rf_nodes, rec.data(), nn * sizeof(unsigned long long), hipMemcpyHostToDevice));
-    m->meta_grid = grid;
-    m->meta_C = C;
-    m->rf_log2r = log2r;
-    m->rf_big = big;
+    if (int rc = publish(m, flat, (KT **)&m->lut_sorted)) return rc;
+    if (int rc = publish(m, off, &m->lut_sorted_off)) return rc;
+    return publish(m, rec, &m->rf_nodes);
+}
+
+static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big, int key64, TreeTables *tt) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!(m->rf_nodes && m->rf_log2r == log2r && m->rf_big == big && same_meta(m, grid, C, key64))) {
+        if (int rc = key64 ? build_rf_nodes_t<double>(m, grid, C, log2r, big) : build_rf_nodes_t<float>(m, grid, C, log2r, big)) return rc;
+        m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
+        m->rf_log2r = log2r; m->rf_big = big;
+    }
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes};
     return MHS_OK;
 }
 
 static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
                           double w, int acc, double *out, hipStream_t st, int64_t total, int log2r, bool big) {
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big)) return rc;
+    const int key64 = s.dtype == MHS_F64;
+    TreeTables tt;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big, key64, &tt)) return rc;
     const int R = 1 << log2r;
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
@@ -1249,16 +1288,16 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         const size_t dbytes = rf_walk_db_lds(m, log2r);
         auto dk = log2r == 2 ? rf_walk_db_kernel<2> : rf_walk_db_kernel<1>;
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
-        hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)m->rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, m->lut_sorted, m->lut_sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+        hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
+                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
         return MHS_OK;
     }
     const size_t bytes = rf_walk_lds(m, log2r, big);
     auto kern = big ? (log2r == 2 ? rf_walk_kernel<2, true> : rf_walk_kernel<1, true>)
                     : (log2r == 2 ? rf_walk_kernel<2, false> : rf_walk_kernel<1, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)m->rf_nodes, m->rf_lval, m->tree_off,
-                       m->rf_depth, m->lut_sorted, m->lut_sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
+                       m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
     return MHS_OK;
 }
 
@@ -1289,13 +1328,13 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             break;
         }
         case K_GBM:
-            // fast path: grid mode, planes whose values are exactly float-representable
-            if (grid && m->lut_S > 0 && !s.all_from_planes && s.dtype != MHS_F64 && (size_t)m->p * 256 * LUT_R * 4 + ((size_t)LUT_CHUNK << m->lut_S) * 8 <= LDS_LIMIT) {
+            // fast path: grid mode (rank search in float for float32 / int16 planes, in double for float64 planes)
+            if (grid && m->lut_S > 0 && !s.all_from_planes && !getenv("MHS_TREES_GENERIC") && (size_t)m->p * 256 * LUT_R * 4 + ((size_t)LUT_CHUNK << m->lut_S) * 8 <= LDS_LIMIT) {
                 if (int rc = launch_gbm_lut(m, s, g, *grid, weight, accumulate, out, st, total)) return rc;
             } else if (int rc = launch_trees<true, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
             break;
         case K_RF:
-            if (grid && m->rf_fast && !s.all_from_planes && s.dtype != MHS_F64) {
+            if (grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC")) {
                 int log2r = 0;
                 bool big = false;
                 if (rf_walk_config(m, &log2r, &big)) {
@@ -1354,6 +1393,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
     if (m->rf_lval) (void)hipFree(m->rf_lval);
     if (m->rf_depth) (void)hipFree(m->rf_depth);
+    for (void *q : m->retired) (void)hipFree(q);
     delete m;
     return MHS_OK;
 }

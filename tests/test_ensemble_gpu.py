@@ -38,13 +38,44 @@ def _tol(ref):
 
 @pytest.mark.parametrize("dtype", ["f32", "f64", "i16"])
 def test_each_member_matches_oracle(hip, dtype):
-    g, stack, X, Xs, ys, params = _setup(hip, dtype=dtype, nodata_frac=0.01 if dtype != "f64" else 0.0)
+    g, stack, X, Xs, ys, params = _setup(hip, dtype=dtype, nodata_frac=0.01)
     for prm in params:
         m = hip.models.from_param_dict(prm)
         got = hip.predict(stack, m).cpu().numpy().ravel()
         want = oe.predict(prm, X)
         assert np.array_equal(np.isnan(got), np.isnan(want)), prm["kind"]
         assert np.nanmax(np.abs(got - want)) <= _tol(want), (prm["kind"], np.nanmax(np.abs(got - want)))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i16"])
+def test_tree_fast_paths_equal_the_generic_walk_bit_for_bit(hip, dtype, monkeypatch):
+    """float64 planes -- what terra holds in RAM and the R shim hands over (V73:468-606, MHS_F64) -- take the
+    predicate-LUT / level-synchronous kernels with the rank search done in double against double thresholds;
+    float32 / int16 planes search in float.  Either way the trees are summed in the same order as the node walk
+    (MHS_TREES_GENERIC=1 forces it), so the planes must be identical, NA cells included."""
+    import torch
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=150, ncol=211, dtype=dtype, nodata_frac=0.01, n=1500, gbm_trees=700,
+                                         rf_trees=30)
+    for prm in (params[0], params[4]):
+        assert prm["kind"] in ("gbm", "rf")
+        m = hip.models.from_param_dict(prm)
+        fast = hip.predict(stack, m)
+        monkeypatch.setenv("MHS_TREES_GENERIC", "1")
+        slow = hip.predict(stack, m)
+        monkeypatch.delenv("MHS_TREES_GENERIC")
+        assert torch.equal(torch.isnan(fast), torch.isnan(slow)), prm["kind"]
+        assert torch.equal(torch.nan_to_num(fast), torch.nan_to_num(slow)), prm["kind"]
+        # the same model on another plane type right after: the geometry tables are rebuilt for the other key type
+        other = hip.RasterStack(g, stack.planes.to(torch.float64 if dtype != "f64" else torch.float32),
+                                float("nan") if dtype != "i16" else -32768.0)
+        again = hip.predict(other, m).cpu().numpy().ravel()
+        host = other.planes.cpu().numpy().astype(np.float64)
+        if dtype == "i16":
+            host[host == -32768.0] = np.nan
+        x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol)
+        want = oe.predict(prm, oe.stack_predictors(host, (x, y)))
+        assert np.array_equal(np.isnan(again), np.isnan(want))
+        assert np.nanmax(np.abs(again - want)) <= _tol(want), prm["kind"]
 
 
 def test_gbm_routes_na_through_missing_nodes(hip):

@@ -17,10 +17,11 @@ def _cfg3_stack(hip, side, dtype="f32"):
     return g, hip.RasterStack(g, planes, nodata), planes
 
 
-def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip):
+def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip, monkeypatch):
     """gbm: predicate-LUT kernel vs node walk; randomForest: level-synchronous LDS walk vs node walk.
-    float32 planes take the fast kernels, the same values as float64 planes take the generic walk;
-    both sum the trees in the same order, so the 10 000 x 10 000 planes must be IDENTICAL."""
+    float32 planes take the fast kernels with float keys, the same values as float64 planes (what the R shim
+    hands over) take them with double keys, and MHS_TREES_GENERIC=1 forces the node walk; all three sum the
+    trees in the same order, so the 10 000 x 10 000 planes must be IDENTICAL."""
     import torch
     from machisplin_amd import synth
     side = 10000
@@ -29,14 +30,18 @@ def test_cfg3_tree_members_fast_path_equals_generic_walk_on_1e8_cells(hip):
     cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
     X = np.column_stack([np.nan_to_num(cov), xy])
     y = synth.response(X, uv, 1)
-    stack64 = hip.RasterStack(g, planes.to(torch.float64), float("nan"))  # same values, generic-walk kernels
+    stack64 = hip.RasterStack(g, planes.to(torch.float64), float("nan"))  # same values as doubles
     for prm in (synth.gbm_params(X, y, 3, n_trees=10000), synth.rf_params(X, y, 3, n_trees=500)):
         m = hip.models.from_param_dict(prm)
         a = hip.predict(stack32, m)
         b = hip.predict(stack64, m)
-        assert torch.equal(torch.isnan(a), torch.isnan(b)), prm["kind"]
-        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), prm["kind"]
-        del a, b
+        monkeypatch.setenv("MHS_TREES_GENERIC", "1")
+        c = hip.predict(stack64, m)
+        monkeypatch.delenv("MHS_TREES_GENERIC")
+        for other in (b, c):
+            assert torch.equal(torch.isnan(a), torch.isnan(other)), prm["kind"]
+            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(other)), prm["kind"]
+        del a, b, c
     del stack64
     # sampled rows against the C oracle (gbm NA routing included)
     host = planes[:, 4321:4323].cpu().numpy().astype(np.float64)
@@ -122,3 +127,93 @@ def test_cfg3_ensemble_linearity_on_the_full_grid(hip):
     got = fused.cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     assert np.allclose(got, ref, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def test_cfg5_gcv_fit_of_20000_stations(hip):
+    """BASELINE configs[4]: the GCV route at n = 20 000 (band reduction of the 3.2 GB projected Gram matrix, host
+    search on the band, back-transform).  Properties: the normal equations hold at the chosen lambda, the
+    coefficients agree with the Cholesky route run at that same lambda, T'c = 0, and the criterion value the fit
+    reports is not above its neighbours' (fixed-lambda fits a factor 2 either side have a larger GCV -- computed
+    from their own residuals and the trace identity is not available there, so the check is on the surface: the
+    GCV fit's residual sum of squares lies between theirs)."""
+    from machisplin_amd import synth
+    n = 20000
+    g = synth.grid(20000, 20000)
+    xy, rows, cols, uv = synth.stations(g, n, synth.BASE_SEED + 5)
+    y = synth.tps_residual(uv, synth.BASE_SEED + 5)
+    fg = hip.Tps(xy, y)
+    lam = fg.lambda_
+    assert lam > 0 and 3.0 < fg.eff_df < n and np.isfinite(fg.gcv)
+    f = fg.predict(xy)
+    assert np.abs(f - (y - lam * fg.c)).max() < 1e-7 * np.abs(y).max()
+    T = np.column_stack([np.ones(n), fg.knots])
+    assert np.abs(T.T @ fg.c).max() < 1e-7 * np.abs(fg.c).max() * n ** 0.5
+    fc = hip.Tps(xy, y, lambda_=lam)                      # MFMA Cholesky at the same lambda
+    assert np.abs(fg.c - fc.c).max() < 1e-7 * np.abs(fc.c).max()
+    assert np.abs(fg.d - fc.d).max() < 1e-7 * np.abs(fc.d).max()
+    rss = lambda fit: float(np.sum((y - fit.predict(xy)) ** 2))
+    lo, hi = hip.Tps(xy, y, lambda_=lam / 2), hip.Tps(xy, y, lambda_=lam * 2)
+    assert rss(lo) < rss(fg) < rss(hi)                    # RSS is monotone in lambda
+    # GCV(lambda) = (RSS / n) / (1 - trA / n)^2 with the reported effective degrees of freedom
+    assert abs(rss(fg) / n / (1.0 - fg.eff_df / n) ** 2 - fg.gcv) < 1e-4 * fg.gcv
+
+
+def test_cfg5_grid_evaluation_20000_squared(hip):
+    """20 000 knots over 4e8 cells: the far-field-interpolated evaluation of the whole grid against the direct sum
+    on sampled row bands (both HIP) and against the C oracle's direct sum on sampled rows."""
+    import torch
+    from machisplin_amd import synth
+    n, side = 20000, 20000
+    g = synth.grid(side, side)
+    xy, rows, cols, uv = synth.stations(g, n, synth.BASE_SEED + 5)
+    fit = hip.Tps(xy, synth.tps_residual(uv, synth.BASE_SEED + 5), lambda_=1e-4)
+    full = hip.interpolate(g, fit)
+    assert fit.eval_plan()[0] > 0                          # the far-field path was taken
+    scale = full.abs().max().item()
+    hip.eval_mode(hip.EVAL_DIRECT)
+    try:
+        for r0 in (0, 7777, side - 32):
+            band = hip.interpolate(g, fit, window=(r0, r0 + 32, 0, side))
+            assert (band - full[r0:r0 + 32]).abs().max().item() < 1e-10 * scale
+            del band
+    finally:
+        hip.eval_mode(hip.EVAL_AUTO)
+    m = {"knots": fit.knots, "c": fit.c, "d": fit.d, "center": fit.center, "scale": fit.scale}
+    for r0 in (3, 12345):
+        want = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, r0, r0 + 1, 0, side, threads=16)
+        assert np.abs(full[r0:r0 + 1].cpu().numpy() - want).max() < 1e-10 * scale
+    del full
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_five_covariate_ensemble_rows(hip):
+    """cfg5's Step 2: 5 covariate planes (p = 7) over 20 000 x 20 000 cells with a 20 000-station forest (trees of
+    ~12 000 nodes: the BIG form of the level-synchronous walk).  A row band of the fused ensemble against the C
+    oracle, and band vs full-grid window consistency of the tree members (same cells, same bits)."""
+    import torch
+    from machisplin_amd import synth
+    side, n = 20000, 20000
+    g = synth.grid(side, side)
+    planes, nodata = synth.covariates(g, 5, synth.BASE_SEED + 5, dtype="f32", nodata_frac=0.001)
+    stack = hip.RasterStack(g, planes, nodata)
+    xy, rows, cols, uv = synth.stations(g, n, synth.BASE_SEED + 5)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([np.nan_to_num(cov), xy])
+    y = synth.response(X, uv, 5)
+    params = synth.ensemble_params(X, y, 5, n_gbm_trees=600, n_rf_trees=12)
+    assert np.diff(params[4]["tree_offsets"]).max() > 8191
+    mods = [hip.models.from_param_dict(p) for p in params]
+    _, wts, tot = hip.models.select_weights(synth.OPTX_WEIGHTS)
+    r0, r1 = 9990, 10022
+    band = hip.ensemble_predict(stack, mods, wts, tot, window=(r0, r1, 0, side)).cpu().numpy()
+    host = planes[:, r0:r0 + 2].cpu().numpy().astype(np.float64)
+    xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, side, side, r0, r0 + 2)
+    Xg = oe.stack_predictors(host, (xs, ys))
+    want = cbind.ensemble(params, wts, tot, Xg, threads=16).reshape(2, side)
+    assert np.array_equal(np.isnan(band[:2]), np.isnan(want))
+    assert np.nanmax(np.abs(band[:2] - want)) < 1e-10 * np.nanmax(np.abs(want))
+    # a tree member over a larger window holds the same bits on the shared rows (window origin independence)
+    for k in (0, 4):
+        a = hip.predict(stack, mods[k], window=(r0, r1, 0, side))
+        b = hip.predict(stack, mods[k], window=(r0 - 1000, r1 + 24, 0, side))
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b[1000:1000 + (r1 - r0)]))
