@@ -535,7 +535,11 @@ static void band_eig_multi(const BandGcv &B, const int64_t *k, int nk, Pool &poo
     gershgorin(B, &glo, &ghi);
     std::vector<double> lo((size_t)nk, glo), hi((size_t)nk, ghi);
     std::vector<char> done((size_t)nk, 0);
-    const int P = std::max(1, (pool.size() + nk - 1) / nk);   // points per bracket per round
+    // Points per bracket per round: a CONSTANT, not a function of the pool size -- the sequence of brackets, hence
+    // the last bits of the eigenvalue, the ends of the lambda grid and finally lambda itself must not depend on how
+    // many host threads happen to serve the search (the same fit on a lane of mhs_tps_surface, on another box or
+    // under another CPU quota has to give the same bits).
+    const int P = 16;
     std::vector<double> xs((size_t)(P * nk));
     std::vector<int> cnt((size_t)(P * nk));
     for (int it = 0; it < 400; ++it) {

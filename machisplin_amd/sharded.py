@@ -21,8 +21,10 @@ def row_bands(nrow: int, world: int, rank0_share: float | None = None):
     """Contiguous row bands, one per rank.  With rank0_share = None the bands are equal
     (ceil(nrow / world) rows, the last ones may be short or empty).  Otherwise rank 0 -- which
     also carries the spline fit -- gets round(rank0_share * nrow) rows (possibly none) and the
-    other ranks split the rest evenly.  Returns (rows of the largest band, [(r0, r1)] per rank);
-    the all-gather moves equal chunks of that height and the stitch drops the padding."""
+    other ranks take ceil(rest / (world - 1)) rows each (the last ones may be short or empty).
+    Returns (rows of the largest band, [(r0, r1)] per rank).  Every band but rank 0's and the trailing
+    ones is exactly `band` rows high, so with rank 0's rows parked at the END of its chunk the all-gather
+    of equal chunks lands the whole grid in place (ShardedMltps: no stitching copy)."""
     if world == 1:
         return nrow, [(0, nrow)]
     if rank0_share is None:
@@ -30,13 +32,12 @@ def row_bands(nrow: int, world: int, rank0_share: float | None = None):
         return band, [(min(r * band, nrow), min((r + 1) * band, nrow)) for r in range(world)]
     n0 = int(round(min(max(rank0_share, 0.0), 1.0) * nrow))
     rest, others = nrow - n0, world - 1
-    base, extra = divmod(rest, others)
-    bands, r = [(0, n0)], n0
-    for k in range(others):
-        h = base + (1 if k < extra else 0)
-        bands.append((r, r + h))
-        r += h
-    return max(b[1] - b[0] for b in bands), bands
+    h = -(-rest // others)
+    if n0 > h:     # rank 0 must not be the tallest band (its rows sit at the end of its chunk)
+        n0 = h = -(-nrow // world)
+        return h, [(min(r * h, nrow), min((r + 1) * h, nrow)) for r in range(world)]
+    bands = [(0, n0)] + [(min(n0 + k * h, nrow), min(n0 + (k + 1) * h, nrow)) for k in range(others)]
+    return max(h, n0), bands
 
 
 def balanced_rank0_share(world: int, cells_ms: float, fit_ms: float) -> float:
@@ -97,33 +98,26 @@ class ShardedMltps:
         self.nrow, self.ncol = nrow, ncol
         self.band, self.bands = row_bands(nrow, world, rank0_share)
         self.r0, self.r1 = self.bands[rank]
-        self.even = all(b[1] - b[0] == self.band for b in self.bands[:-1]) and rank0_share is None
+        # Per-rank memory: the gather target (grid + at most one band of padding), the final plane, and -- for
+        # N > 1 -- this rank's band as the gather's source.  Rank 0's rows sit at the END of its chunk and every
+        # other band is `band` rows high, so the gathered chunks ARE the grid, in place, from row `self.lead` on.
+        self.lead = self.band - (self.bands[0][1] - self.bands[0][0]) if world > 1 else 0
         kw = {"dtype": torch.float64, "device": ops.device}
-        self.pred = torch.zeros((self.band, ncol), **kw)              # this rank's ensemble band (padded)
-        self.full = torch.zeros((self.band * world, ncol), **kw)      # all-gather target (padded bands)
-        self.stitched = None if self.even else torch.zeros((nrow, ncol), **kw)
-        self.tps = torch.zeros((nrow, ncol), **kw)                    # final.TPS, whole grid, on every rank
-        self.total = torch.zeros((nrow, ncol), **kw)
+        self.full = torch.zeros((self.band * world, ncol), **kw)      # all-gather target
+        self.pred = torch.zeros((self.band, ncol), **kw) if world > 1 else self.full   # this rank's chunk
+        self.total = torch.zeros((nrow, ncol), **kw)                  # final.TPS, then pred.elev + final.TPS
         self.torch = torch
-
-    def _stitch(self):
-        """The gathered buffer holds `world` chunks of `band` rows; with uneven bands drop the padding."""
-        if self.even:
-            return self.full[:self.nrow]
-        for r, (a, b) in enumerate(self.bands):
-            if b > a:
-                self.stitched[a:b].copy_(self.full[r * self.band:r * self.band + (b - a)])
-        return self.stitched
 
     def step(self):
         ops, torch = self.ops, self.torch
         nb = self.r1 - self.r0
+        off = self.lead if self.rank == 0 else 0          # rank 0's rows at the end of its chunk
         # The band kernels are only enqueued here (VALU / LDS bound, ~0.5 s at N = 1).  Step 2 at the stations (a
         # few thousand points, all the fit needs) follows on the library's own high-priority stream: a
         # prioritised small grid gets its slots within a millisecond or two of its launch, so the residuals cost
         # nothing on the critical path, and rank 0 fits the spline while every rank's band is still running
         if nb > 0:
-            ops.ensemble_band(self.r0, self.r1, self.pred[:nb])
+            ops.ensemble_band(self.r0, self.r1, self.pred[off:off + nb])
         knots, resid, resp, rows, cols = ops.station_residuals()
         n = knots.shape[0]
         # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
@@ -137,14 +131,12 @@ class ShardedMltps:
         if self.world > 1:
             self.dist.broadcast(msg, src=0)
         packed = msg.cpu().numpy()
+        # Step 3 on the whole grid on every rank, straight into the plane that becomes the sum (while the gather runs)
+        ops.tps_band(packed, 0, self.nrow, self.total)
         if work is not None:
             work.wait()
-            pred_full = self._stitch()
-        else:
-            pred_full = self.pred[:self.nrow]
-        # Step 3 on the whole grid on every rank, Step 5's sum
-        ops.tps_band(packed, 0, self.nrow, self.tps)
-        ops.add(pred_full, self.tps, self.total)
+        pred_full = self.full[self.lead:self.lead + self.nrow]
+        ops.add(pred_full, self.total, self.total)       # Step 5's sum, in place
         # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
         f_actual = ops.gather(self.total, rows, cols)
         tss = float(np.sum((resp - resp.mean()) ** 2))
@@ -235,3 +227,128 @@ class HipOps:
     def gather(self, plane, rows, cols):
         from . import tiles
         return tiles.extract(plane, rows, cols)
+
+
+# ======================================================================================================
+# machisplin.tiles.* sharding (BASELINE.json configs[3]; README.md:157-215): machisplin.tiles.create cuts the
+# study area into out.nrow x out.ncol user tiles (V73:1165-1256), every tile is an INDEPENDENT machisplin.mltps
+# run per response layer (its own stations, its own Step-3 tiles and spline fits, its own R^2 selection), and
+# machisplin.tiles.merge feathers the per-tile finals back together (V73:1392-1548).  The shard unit is one
+# (tile, layer) run -- no halo, no exchange while it runs.  ONE all-gather moves every unit's final plane (and its
+# two R^2 values) to every rank; the merge of layer l then runs on rank l mod N (or on every rank).
+# ======================================================================================================
+def unit_owner(tile: int, layer: int, n_tiles: int, world: int):
+    """(rank, slot) of the (tile, layer) unit: units are numbered layer-major, u = layer * n_tiles + tile, and
+    dealt round-robin -- u mod N is the rank, u div N its slot in that rank's chunk of the gather.  With as many
+    ranks as tiles every rank keeps ONE tile's covariates resident (tile t -> GPU t mod N, all layers); with more
+    ranks than tiles the layers of a tile are shared out as well."""
+    u = layer * n_tiles + tile
+    return u % world, u // world
+
+
+class TileShardedMltps:
+    """Every response layer of a tiled run over `world` ranks.
+
+    ops must provide (tensors live on ops.device):
+      tile_shapes -> [(rows, cols)] of the user tiles, in machisplin.tiles.create order (row-major from the SW)
+      n_layers
+      tile_layer(tile, layer, out) -> (rsq_model, rsq_final)   the whole mltps run of one tile and layer, final
+                                                               plane written into `out` (rows x cols, contiguous)
+      merge(layer, planes) -> tensor                           machisplin.tiles.merge of one layer's tile planes
+    `merge_on`: "owner" = layer l is merged on rank l mod N only (the rank that would write its GeoTIFF, V73:998);
+    "all" = every rank merges every layer.
+    """
+
+    def __init__(self, ops, dist, rank: int, world: int, merge_on: str = "owner"):
+        import torch
+        if merge_on not in ("owner", "all"):
+            raise ValueError("merge_on must be 'owner' or 'all'")
+        self.ops, self.dist, self.rank, self.world, self.merge_on = ops, dist, rank, world, merge_on
+        self.shapes = [(int(h), int(w)) for h, w in ops.tile_shapes]
+        self.n_tiles, self.n_layers = len(self.shapes), int(ops.n_layers)
+        n_units = self.n_tiles * self.n_layers
+        self.slots = -(-n_units // world)
+        self.slot_len = max(h * w for h, w in self.shapes) + 2      # the plane + (rsq_model, rsq_final)
+        kw = {"dtype": torch.float64, "device": ops.device}
+        self.full = torch.zeros((world * self.slots, self.slot_len), **kw)     # gather target: every unit
+        self.mine = self.full[rank * self.slots:(rank + 1) * self.slots] if world == 1 else \
+            torch.zeros((self.slots, self.slot_len), **kw)
+        self.torch = torch
+
+    def my_units(self):
+        return [(t, l) for l in range(self.n_layers) for t in range(self.n_tiles)
+                if unit_owner(t, l, self.n_tiles, self.world)[0] == self.rank]
+
+    def _plane(self, buf, slot, tile):
+        h, w = self.shapes[tile]
+        return buf[slot, :h * w].view(h, w)
+
+    def step(self):
+        torch = self.torch
+        for t, l in self.my_units():
+            _, slot = unit_owner(t, l, self.n_tiles, self.world)
+            rsq = self.ops.tile_layer(t, l, self._plane(self.mine, slot, t))
+            self.mine[slot, -2:] = torch.tensor([float(rsq[0]), float(rsq[1])], dtype=torch.float64).to(self.mine.device)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.full, self.mine)      # the one exchange of the path
+        stats = self.full[:, -2:].cpu().numpy()
+        out = {"layers": {}, "rsq_model": np.full((self.n_layers, self.n_tiles), np.nan),
+               "rsq_final": np.full((self.n_layers, self.n_tiles), np.nan)}
+        for l in range(self.n_layers):
+            rows = []
+            for t in range(self.n_tiles):
+                r, slot = unit_owner(t, l, self.n_tiles, self.world)
+                rows.append(r * self.slots + slot)
+                out["rsq_model"][l, t], out["rsq_final"][l, t] = stats[rows[-1]]
+            if self.merge_on == "all" or l % self.world == self.rank:
+                out["layers"][l] = self.ops.merge(l, [self._plane(self.full, rows[t], t) for t in range(self.n_tiles)])
+        return out
+
+
+class HipTileOps:
+    """TileShardedMltps' per-unit arithmetic on one MI355X through the C ABI: `tiles` is
+    machisplin_amd.tiles.tiles_create's result for the study area, `stack_for_tile(t)` returns the RasterStack of
+    tile t's window (cropped covariates -- each rank only ever asks for the tiles it owns), `int_values` the
+    station table (long, lat, one response column per layer) and `fitted[t][l]` the members / weights / wt_total
+    of tile t, layer l (model fitting is out of scope: V73:176-436 stays in R)."""
+
+    def __init__(self, geom, tiles, stack_for_tile, int_values, fitted, tile_edge=1500, lambda_=None, gcv_mode="fields",
+                 tps: bool = True):
+        import torch
+        from . import _lib
+        self.torch = torch
+        self.device = torch.device("cuda", _lib.init())
+        self.geom, self.tiles, self.stack_for_tile = geom, tiles, stack_for_tile
+        self.int_values = np.asarray(int_values, dtype=np.float64)
+        self.fitted, self.tile_edge, self.lambda_, self.gcv_mode, self.tps = fitted, tile_edge, lambda_, gcv_mode, tps
+        self.tile_shapes = [(int(w[1] - w[0]), int(w[3] - w[2])) for w in tiles["win"]]
+        self.n_layers = self.int_values.shape[1] - 2
+        self._stacks, self._keep = {}, {}
+        self.unit_ms = {}
+
+    def _stack(self, t):
+        if t not in self._stacks:
+            from .mltps import complete_cases
+            self._stacks[t] = self.stack_for_tile(t)
+            sel = self.tiles["dat"][t]
+            self._keep[t] = complete_cases(self._stacks[t], self.int_values[sel])   # once per tile, over every column
+        return self._stacks[t]
+
+    def tile_layer(self, t, l, out):
+        import time
+        from .mltps import mltps_predict
+        stack = self._stack(t)
+        sel = self.tiles["dat"][t]
+        f = self.fitted[t][l]
+        t0 = time.perf_counter()
+        res = mltps_predict(stack, self.int_values[sel, :2], self.int_values[sel, 2 + l], f["models"], f["weights"],
+                            f["wt_total"], tps=self.tps, tile_edge=self.tile_edge, lambda_=self.lambda_,
+                            gcv_mode=self.gcv_mode, keep=self._keep[t])
+        out.copy_(res["final"])
+        self.unit_ms[(t, l)] = (time.perf_counter() - t0) * 1e3
+        return res["rsq_model"], res.get("rsq_final", float("nan"))
+
+    def merge(self, l, planes):
+        from . import tiles as tl
+        return tl.tiles_merge(self.geom, self.tiles["win"], [p.contiguous() for p in planes], in_ncol=self.tiles["nC"],
+                              in_nrow=self.tiles["nR"])

@@ -169,19 +169,22 @@ def test_cfg5_grid_evaluation_20000_squared(hip):
     fit = hip.Tps(xy, synth.tps_residual(uv, synth.BASE_SEED + 5), lambda_=1e-4)
     full = hip.interpolate(g, fit)
     assert fit.eval_plan()[0] > 0                          # the far-field path was taken
+    # 20 000 terms of either sign cancel by orders of magnitude in a fitted spline (sum |c phi| ~ 1e4 max|f| at
+    # lambda = 1e-4), and both GPU sums carry the table log's 2e-14 of that: 1e-8 of max|f| here, two orders inside
+    # the north star's 1e-6
     scale = full.abs().max().item()
     hip.eval_mode(hip.EVAL_DIRECT)
     try:
         for r0 in (0, 7777, side - 32):
             band = hip.interpolate(g, fit, window=(r0, r0 + 32, 0, side))
-            assert (band - full[r0:r0 + 32]).abs().max().item() < 1e-10 * scale
+            assert (band - full[r0:r0 + 32]).abs().max().item() < 1e-8 * scale
             del band
     finally:
         hip.eval_mode(hip.EVAL_AUTO)
     m = {"knots": fit.knots, "c": fit.c, "d": fit.d, "center": fit.center, "scale": fit.scale}
     for r0 in (3, 12345):
         want = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, r0, r0 + 1, 0, side, threads=16)
-        assert np.abs(full[r0:r0 + 1].cpu().numpy() - want).max() < 1e-10 * scale
+        assert np.abs(full[r0:r0 + 1].cpu().numpy() - want).max() < 1e-8 * scale
     del full
     torch.cuda.empty_cache()
 
