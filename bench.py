@@ -42,6 +42,14 @@ WORKLOADS = {
     # BASELINE.json configs[4] (its 8-GPU shape; also runs on one GPU: 3.2 GB Gram matrix, 8e12 TPS pairs)
     "cfg5": dict(stations=20000, side=20000, layers=5, gbm_trees=10000, rf_trees=500, ensemble=True,
                  name="cfg5: 20000 stations, 5 covariates, 20000x20000 grid, 6-model ensemble + TPS residual correction"),
+    # BASELINE.json configs[3]: 12 response layers, smooth members only (g, n, m, v -- V73:366-392), the study area cut
+    # into 2 x 2 user tiles by machisplin.tiles.create(feather.d = 50); every (tile, layer) is an independent mltps run
+    # (reference-tiled Step 3 inside: 4 x 4 TPS tiles per user tile), merged by machisplin.tiles.merge
+    "cfg4": dict(stations=5000, side=10000, layers=3, resp_layers=12, tiles=(2, 2), feather_d=50, ensemble=True, tiled=True,
+                 name="cfg4: 5000 stations, 12 response layers, 10000x10000 grid, smooth.outputs.only, 2x2 machisplin.tiles.* "
+                      "tiles (feather.d 50), tiles.merge"),
+    "cfg4-mini": dict(stations=1200, side=1200, layers=3, resp_layers=3, tiles=(2, 2), feather_d=20, ensemble=True, tiled=True,
+                      tile_edge=400, name="cfg4-mini (debug only)"),
     # a small version of cfg3 for quick checks (NOT a bench line)
     "cfg3-mini": dict(stations=1000, side=1500, layers=3, gbm_trees=500, rf_trees=50, ensemble=True,
                       name="cfg3-mini (debug only)"),
@@ -203,6 +211,69 @@ class Workload:
             r["traffic"] = sum(parts) * band_cells if all(x is not None for x in parts) else None
         return rows
 
+    def f64_boundary(self):
+        """The ensemble pass with float64 planes: (a) resident in HBM through the _dev entry point, (b) through the
+        host-pointer entry point the R shim binds (covariates and result cross PCIe inside the call)."""
+        import ctypes as C
+        from machisplin_amd import _lib
+        torch, mhs = self.torch, self.mhs
+        g = self.geom
+        t32 = []
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            a = mhs.ensemble_predict(self.stack, self.models, self.weights, self.wt_total)
+            torch.cuda.synchronize(); t32.append((time.perf_counter() - t0) * 1e3)
+        stack64 = mhs.RasterStack(g, self.stack.planes.to(torch.float64), self.stack.nodata)
+        t64 = []
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            b = mhs.ensemble_predict(stack64, self.models, self.weights, self.wt_total)
+            torch.cuda.synchronize(); t64.append((time.perf_counter() - t0) * 1e3)
+        same = bool(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)))
+        host = np.ascontiguousarray(stack64.planes.cpu().numpy())
+        del stack64, b
+        out = np.empty((g.nrow, g.ncol))
+        hs = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        ws = (C.c_double * len(self.models))(*[float(w) for w in self.weights])
+        st = _lib.Stack(host.ctypes.data, host.shape[0], _lib.F64, g.nrow * g.ncol, g.ncol, float("nan"))
+        gs = g.c_struct()
+        th = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, len(self.models), float(self.wt_total), C.byref(gs), C.byref(st),
+                                                       0, g.nrow, 0, g.ncol, out.ctypes.data))
+            th.append((time.perf_counter() - t0) * 1e3)
+        same_host = bool(np.array_equal(np.nan_to_num(out), np.nan_to_num(a.cpu().numpy())))
+        nbytes = host.nbytes + out.nbytes
+        return {"f32_resident_ensemble_ms": min(t32), "f64_resident_ensemble_ms": min(t64),
+                "f64_over_f32": min(t64) / min(t32), "f64_planes_equal_f32_planes_bitwise": same,
+                "host_abi_f64_ms": min(th), "host_abi_bytes_over_pcie": nbytes,
+                "host_abi_equals_resident_bitwise": same_host,
+                "note": "f64 planes = the f32 planes widened (same values), what terra holds in RAM; host ABI = "
+                        "mhs_ensemble_predict with pageable host buffers, as mhsr_ensemble_predict calls it"}
+
+    def model_check(self, fit_ms, step_ms):
+        """Per-rank phase times gathered on rank 0: predicted step = max over ranks of (band + rank 0's fit) + gather +
+        whole-grid spline + Step 5, against the observed step."""
+        import torch.distributed as dist
+        torch = self.torch
+        tm = self.ops.timings
+        mean = lambda v: float(np.mean(v[-max(1, len(v) // 2):])) if v else 0.0
+        band_ms = sum(mean(v) for k, v in tm.items() if k.startswith("model_"))
+        mine = torch.tensor([band_ms, mean(tm.get("tps_eval_ms", [])), mean(tm.get("tps_fit_ms", [])),
+                             mean(tm.get("residuals_ms", [])), float(self.run.r1 - self.run.r0)], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine)
+        allv = torch.stack(allv).cpu().numpy()
+        gather_bytes = self.run.band * self.geom.ncol * 8 * (self.world - 1)
+        gather_ms = gather_bytes / 153e9 * 1e3 / max(1, min(7, self.world - 1))   # direct mesh: one xGMI link per peer
+        pred0 = allv[0, 0] + fit_ms
+        pred = max(pred0, float(allv[1:, 0].max()) + gather_ms) + float(allv[:, 1].max()) + 3.0
+        return {"band_ms_per_rank": allv[:, 0].tolist(), "rows_per_rank": allv[:, 4].astype(int).tolist(),
+                "tps_eval_ms_per_rank": allv[:, 1].tolist(), "fit_ms_in_step_rank0": float(allv[0, 2]),
+                "fit_ms_standalone": fit_ms, "rank0_share": self.rank0_share,
+                "gather_ms_model": gather_ms, "predicted_step_ms": pred, "observed_step_ms": step_ms}
+
     def rf_level_sum(self):
         """sum over the forest's trees of the tree depth (levels every lane descends in rf_walk_kernel)."""
         if getattr(self, "_rf_levels", None) is None:
@@ -226,11 +297,17 @@ class Workload:
             if prm["kind"] in ("gbm", "rf"):
                 self.mean_visits[prm["kind"]] = synth.mean_tree_visits(prm, self.X[:256])
 
-    def cpu_baseline(self):
-        """kind 'port': the oracle's C restatement (OpenMP over cells, one socket's worth of threads) on a
-        row band sized for ~15 s, plus the numpy QR+eigen+GCV fit; extrapolated linearly to the grid."""
-        from oracle import cbind, ensemble as oe, tps as otps
-        threads = min(64, os.cpu_count() or 1)
+    def cpu_baseline(self, ms_per_step=None, direct_sum_ms=None, farfield_ms=None):
+        """kind 'port' (no R on the box -- probed below): the oracle's C restatement
+        of the six predict methods and of predict.Krig's direct radial sum, OpenMP over cells, plus the numpy
+        QR + eigen + GCV fit, on a bounded row band extrapolated linearly to the grid.  Threads = what one socket
+        offers, capped by the cgroup CPU quota; the same band on ONE core (how the reference itself runs,
+        V73:117) and the reference-tiled Step 3 (V73:656-753: ceil(n/1500)^2 tile fits + evaluations) beside it."""
+        import shutil
+        import subprocess
+        from oracle import cbind, ensemble as oe, tiles as ot, tps as otps
+        host = host_info()
+        threads = host["threads_used"]
         g = self.geom
         X, y = self.ops.X, self.ops.y
         res = None
@@ -241,32 +318,137 @@ class Workload:
         t0 = time.perf_counter()
         m = otps.fit(X[:, -2:], res)
         t_fit = time.perf_counter() - t0
-        host = None
+        hostp = None
 
-        def band(rows):
-            nonlocal host
+        def band(rows, nthreads, keep=False):
+            nonlocal hostp
             cov = self.stack.planes[:, :rows].cpu().numpy().astype(np.float64)
             xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol, 0, rows)
             Xg = oe.stack_predictors(cov, (xs, ys))
             t0 = time.perf_counter()
-            pred = cbind.ensemble(self.params, self.weights, self.wt_total, Xg, threads)
-            tps = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, 0, rows, 0, g.ncol, threads=threads)
-            host = pred.reshape(rows, g.ncol) + tps
-            return time.perf_counter() - t0
+            pred = cbind.ensemble(self.params, self.weights, self.wt_total, Xg, nthreads)
+            t_ens = time.perf_counter() - t0
+            tps = cbind.tps_eval_grid(m, g.xmin, g.ymax, g.xres, g.yres, 0, rows, 0, g.ncol, threads=nthreads)
+            t_all = time.perf_counter() - t0
+            if keep:
+                hostp = pred.reshape(rows, g.ncol) + tps
+            return t_all, t_ens
 
         probe = max(1, min(g.nrow, 64 * 10000 // g.ncol // 8))
-        t_probe = band(probe)
-        rows = int(min(g.nrow, max(probe, probe * 15.0 / max(t_probe, 1e-3))))
-        t_band = band(rows)
+        t_probe, _ = band(probe, threads)
+        rows = int(min(g.nrow, max(probe, probe * 10.0 / max(t_probe, 1e-3))))
+        t_band, t_band_ens = band(rows, threads, keep=True)
         t_cells = t_band * (g.nrow / rows)
         # the CPU sample doubles as a full-size spot check of the GPU result
         gpu = self.last["final"][:rows].cpu().numpy()
-        err = float(np.nanmax(np.abs(gpu - host)) / np.nanmax(np.abs(host)))
-        return {"value": self.cells / (t_fit + t_cells) / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "port",
-                "sample": f"C restatement (OpenMP, {threads} threads) of ensemble + TPS evaluation on {rows} of {g.nrow} rows "
-                          f"({t_band:.1f} s, extrapolated linearly to the grid: {t_cells:.0f} s) + numpy QR/eigen/GCV fit of "
-                          f"{X.shape[0]} stations ({t_fit:.1f} s)",
-                "fit_s": t_fit, "cells_s_full_grid": t_cells, "gpu_vs_cpu_sample_max_rel_err": err}
+        err = float(np.nanmax(np.abs(gpu - hostp)) / np.nanmax(np.abs(hostp)))
+        # one core: the reference's own mode (n.cores is forced to 1, V73:117)
+        rows1 = max(1, int(rows * 6.0 / max(t_band * threads, 1e-3)))
+        t_band1, _ = band(rows1, 1)
+        t_cells1 = t_band1 * (g.nrow / rows1)
+        out = {"value": self.cells / (t_fit + t_cells) / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "port",
+               "sample": f"C restatement (OpenMP, {threads} threads) of the 6-member ensemble + direct-sum TPS evaluation on {rows} of "
+                         f"{g.nrow} rows ({t_band:.1f} s, extrapolated linearly to the grid: {t_cells:.0f} s) + numpy QR/eigen/GCV fit of "
+                         f"{X.shape[0]} stations ({t_fit:.1f} s); global TPS mode, as the GPU step",
+               "host": host,
+               "fit_s": t_fit, "cells_s_full_grid": t_cells, "gpu_vs_cpu_sample_max_rel_err": err,
+               "one_core": {"value": self.cells / (t_fit + t_cells1) / 1e6, "unit": "Mcells/s", "cores": 1,
+                            "sample": f"{rows1} rows in {t_band1:.1f} s on one thread, extrapolated: {t_cells1:.0f} s (+ the same fit)"}}
+        # reference-tiled Step 3 (what V73 really does above 1500 px): every tile's fit, and the evaluation of one
+        # row of tiles extrapolated to all rows of tiles; Step 2 is the band figure above
+        og = ot.Geom(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol)
+        nRx, nCx, fw, kw = ot.step3_windows(og, 1500)
+        if nRx * nCx > 1:
+            cov1 = np.zeros((1, 1))   # stations_in_window only needs "not NA": the synthetic planes have no NA at stations
+            knots = X[:, -2:]
+            rowsS = np.array([og.row_from_y(v) for v in knots[:, 1]])
+            colsS = np.array([og.col_from_x(v) for v in knots[:, 0]])
+            t0 = time.perf_counter()
+            fits = []
+            for h in range(nRx * nCx):
+                r0, r1, c0, c1 = fw[h]
+                sel = np.flatnonzero((rowsS >= r0) & (rowsS < r1) & (colsS >= c0) & (colsS < c1))
+                fits.append(otps.fit(knots[sel], res[sel]) if sel.size >= 10 else None)
+            t_tfit = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for h in range(nCx):       # the southern row of tiles
+                if fits[h] is None:
+                    continue
+                gf = ot.window_geom(og, fw[h])
+                wk = (kw[h][0] - fw[h][0], kw[h][1] - fw[h][0], kw[h][2] - fw[h][2], kw[h][3] - fw[h][2])
+                cbind.tps_eval_grid(fits[h], gf.xmin, gf.ymax, gf.xres, gf.yres, *wk, threads=threads)
+            t_teval = (time.perf_counter() - t0) * nRx
+            t_ens_full = t_band_ens * (g.nrow / rows)
+            out["reference_tiled"] = {"value": self.cells / (t_tfit + t_teval + t_ens_full) / 1e6, "unit": "Mcells/s", "cores": threads,
+                                      "tiles": [int(nRx), int(nCx)],
+                                      "sample": f"{nRx * nCx} tile fits in full ({t_tfit:.1f} s) + evaluation of one row of {nCx} tiles x {nRx} "
+                                                f"({t_teval:.1f} s) + the ensemble band above ({t_ens_full:.0f} s); mosaic / feather not timed"}
+        # the reference itself, if the box had R
+        rs = shutil.which("Rscript")
+        if rs:
+            try:
+                pr = subprocess.run([rs, "-e", "library(fields);library(terra);cat(as.character(packageVersion('fields')))"],
+                                    capture_output=True, text=True, timeout=60)
+                out["rscript"] = {"path": rs, "rc": pr.returncode, "out": (pr.stdout + pr.stderr)[-200:]}
+            except Exception as e:  # noqa: BLE001
+                out["rscript"] = {"path": rs, "error": str(e)}
+        else:
+            out["rscript"] = "not installed (which Rscript: empty): the reference itself cannot be timed on this box"
+        if ms_per_step and direct_sum_ms and farfield_ms:
+            like = ms_per_step - farfield_ms + direct_sum_ms    # the GPU step with predict.Krig's own direct sum
+            out["gpu_step_ms_with_direct_sum_tps"] = like
+            out["gpu_over_cpu_like_for_like"] = (t_fit + t_cells) * 1e3 / like
+        if ms_per_step:
+            out["gpu_over_cpu"] = (t_fit + t_cells) * 1e3 / ms_per_step
+            out["gpu_over_one_core"] = (t_fit + t_cells1) * 1e3 / ms_per_step
+        return out
+
+
+def host_info():
+    """CPU model, sockets, cores per socket, visible CPUs, cgroup CPU quota, and the thread count the CPU baseline
+    uses: min(cores of ONE socket, quota) -- the 'single-socket CPU wall-clock' of the north-star target."""
+    info = {"model": None, "sockets": None, "cores_per_socket": None, "nproc": os.cpu_count(), "cgroup_cpu_quota": None}
+    try:
+        phys, cores, model = set(), {}, None
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [t.strip() for t in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                phys.add(cur.get("physical id", "0")); cores[cur.get("physical id", "0")] = int(cur.get("cpu cores", "1"))
+                model = cur.get("model name", model); cur = {}
+        if cur:
+            phys.add(cur.get("physical id", "0")); cores[cur.get("physical id", "0")] = int(cur.get("cpu cores", "1"))
+            model = cur.get("model name", model)
+        info.update({"model": model, "sockets": len(phys), "cores_per_socket": max(cores.values()) if cores else None})
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_cpu_quota"] = quota
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["sched_affinity"] = None
+    t = info["cores_per_socket"] or info["nproc"] or 1
+    if quota:
+        t = min(t, max(1, int(quota)))
+    if info["sched_affinity"]:
+        t = min(t, info["sched_affinity"])
+    info["threads_used"] = int(max(1, t))
+    return info
 
 
 class PerModelOps:
@@ -293,6 +475,58 @@ class PerModelOps:
         o._lib.check(o._lib.lib().mhs_scale_add_dev(out.data_ptr(), o.wt_total, None, out.data_ptr(), out.numel(), st))
 
 
+class TileWorkload:
+    """BASELINE.json configs[3]: one step = every (tile, layer) unit of a machisplin.tiles.* run -- the whole mltps
+    Steps 2-5 of the tile for that response layer, smooth members only, reference-tiled Step 3 inside -- plus ONE
+    all-gather of the units' final planes and machisplin.tiles.merge of every layer on its owner rank."""
+
+    def __init__(self, cfg, mhs, torch, dist, rank, world):
+        from machisplin_amd import sharded, synth
+        self.cfg, self.mhs, self.torch, self.rank, self.world = cfg, mhs, torch, rank, world
+        side, n, L = cfg["side"], cfg["stations"], cfg["resp_layers"]
+        self.geom = g = synth.grid(side, side)
+        seed = synth.BASE_SEED + 4
+        xy, rows, cols, uv = synth.stations(g, n, seed)
+        self.tiles = mhs.tiles.tiles_create(g, xy, out_ncol=cfg["tiles"][1], out_nrow=cfg["tiles"][0], feather_d=cfg["feather_d"])
+        nt = len(self.tiles["dat"])
+        mine = sorted({t for t in range(nt) for l in range(L) if sharded.unit_owner(t, l, nt, world)[0] == rank})
+        # every rank generates only the windows of the tiles it owns (the generator is a function of the absolute
+        # cell indices: synth.covariates(window=...)), i.e. it "reads" only its tiles' crops of the rasters
+        self._stacks = {}
+        for t in mine:
+            r0, r1, c0, c1 = (int(v) for v in self.tiles["win"][t])
+            planes, nodata = synth.covariates(g, cfg["layers"], seed, dtype="f32", window=(r0, r1, c0, c1))
+            self._stacks[t] = mhs.RasterStack(self.tiles["geom"][t], planes, nodata)
+        # the station table: 12 BIO-like response layers = the cfg3 response, shifted / rescaled / re-noised per layer
+        full_cov = synth.covariates_at(g, cfg["layers"], seed, rows, cols)
+        X = np.column_stack([full_cov, xy])
+        base = synth.response(X, uv, seed)
+        rng = np.random.default_rng(seed + 99)
+        resp = np.column_stack([(1.0 + 0.1 * l) * base + 3.0 * np.sin((2 + l) * uv[:, 0]) + 0.5 * rng.standard_normal(n) for l in range(L)])
+        self.int_values = np.column_stack([xy, resp])
+        _, wts, tot = mhs.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")      # smooth.outputs.only (V73:366-392)
+        fitted = {}
+        for t in mine:
+            sel = self.tiles["dat"][t]
+            fitted[t] = {}
+            for l in range(L):
+                if sharded.unit_owner(t, l, nt, world)[0] != rank:
+                    continue
+                params = synth.ensemble_params(X[sel], resp[sel, l], seed + 7 * l + t, which="gnmv")
+                fitted[t][l] = {"models": [mhs.models.from_param_dict(p) for p in params], "weights": wts, "wt_total": tot}
+        self.ops = sharded.HipTileOps(g, self.tiles, lambda t: self._stacks[t], self.int_values, fitted,
+                                      tile_edge=cfg.get("tile_edge", 1500))
+        self.run = sharded.TileShardedMltps(self.ops, dist, rank, world, merge_on="owner")
+        self.cells = side * side * L
+        self.last = None
+
+    def step(self):
+        self.last = self.run.step()
+
+    def collect(self):
+        self.torch.cuda.synchronize()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -316,7 +550,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     cfg = WORKLOADS[args.workload]
-    wl = Workload(cfg, mhs, torch, dist, rank, world)
+    wl = (TileWorkload if cfg.get("tiled") else Workload)(cfg, mhs, torch, dist, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -338,6 +572,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if cfg.get("tiled"):
+        if rank == 0:
+            out = wl.last
+            unit = wl.ops.unit_ms
+            res = {
+                "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
+                "value": wl.cells * args.steps / dt / 1e6, "unit": "Mcells/s (cells x response layers)",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": cfg["name"], "stations": cfg["stations"], "grid": [cfg["side"], cfg["side"]],
+                           "response_layers": cfg["resp_layers"], "members": ["lm", "nnet", "earth", "svr"],
+                           "user_tiles": list(cfg["tiles"]), "feather_d": cfg["feather_d"],
+                           "tile_shapes": [list(sh) for sh in wl.run.shapes],
+                           "stations_per_tile": [int(len(d)) for d in wl.tiles["dat"]],
+                           "tps_mode": "reference-tiled inside every user tile (tile edge %d, V73:656-753), GCV lambda" % cfg.get("tile_edge", 1500),
+                           "parallelism": "(tile, layer) units round-robin over %d rank(s) + 1 all-gather + tiles.merge on the layer's owner" % world},
+                "units_on_rank0": len(unit), "unit_ms_mean_rank0": float(np.mean(list(unit.values()))) if unit else None,
+                "unit_ms_max_rank0": float(np.max(list(unit.values()))) if unit else None,
+                "rsq_model_mean": float(np.nanmean(out["rsq_model"])), "rsq_final_mean": float(np.nanmean(out["rsq_final"])),
+                "roofline": None, "cpu_baseline": None,
+            }
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         wl.measure_mean_visits()
@@ -398,7 +659,21 @@ def main():
                           "max_abs_diff_over_max_abs": diff / float(direct.abs().max()),
                           "max_abs_diff_over_sum_abs_terms": diff / float(S.max())}
             del far, direct
+        # for the record (outside the timed region): the boundary as the R shim reaches it -- float64 planes (terra holds
+        # doubles in RAM, integration/r/src/machisplin_shim.c passes MHS_F64) resident in HBM, and the host-pointer entry
+        # point mhs_ensemble_predict exactly as mhsr_ensemble_predict calls it (PCIe included)
+        f64_boundary = None
+        if world == 1 and cfg["ensemble"] and wl.cells <= 2 * 10 ** 8 and not os.environ.get("MHS_BENCH_SKIP_F64"):
+            f64_boundary = wl.f64_boundary()
+        # N > 1: what the step should cost from its parts (this rank's band, the stand-alone fit, the gather) against
+        # what it did cost -- so that an 8-GPU line can be read without a profiler
+        model_check = None
+        if world > 1:
+            model_check = wl.model_check(fit_ms, dt / args.steps * 1e3)
         m = wl.ops.X.shape[0] - 3
+        if cfg["ensemble"] and wl.cfg["stations"] >= 2000:
+            # the synthetic members are fitted, not random: the ensemble explains the response and the spline improves on it
+            assert 0.5 < wl.last["rsq_model"] < wl.last["rsq_final"], (wl.last["rsq_model"], wl.last["rsq_final"])
         res = {
             "metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s",
             "value": wl.cells * args.steps / dt / 1e6,
@@ -424,10 +699,12 @@ def main():
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "tps_eval_check": eval_check,
+            "f64_boundary": f64_boundary, "model_check": model_check,
             "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
-            res["cpu_baseline"] = wl.cpu_baseline()
+            ff = next((r["launch_ms"] for r in table if r["kernel"].startswith("tps_ff")), None)
+            res["cpu_baseline"] = wl.cpu_baseline(res["ms_per_step"], eval_check["direct_sum_ms"] if eval_check else None, ff)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

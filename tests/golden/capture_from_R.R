@@ -1,0 +1,71 @@
+# capture_from_R.R -- run on ANY box with R (> 4.3), fields and terra installed:
+#
+#     Rscript tests/golden/capture_from_R.R          (from the repository root)
+#
+# It writes tests/golden/r_capture/*.csv; tests/test_r_capture.py picks them up (and is skipped while they are absent).
+# This is the one route by which this repository's parity claim can be pinned against the reference's own arithmetic
+# (SURVEY.md section 8c, last row): the build container and the GPU box have no R, so the files cannot be made there.
+#
+# What is captured, for the three station sets of tests/golden/r_inputs/ (the same data as tests/golden/tps_*.npz):
+#   * fields::Tps(x, Y) with GCV lambda (the call of V73:722 / V73:751) and with the fixture's fixed lambda:
+#     $c, $d, $lambda, $eff.df, $transform$x.center / $x.scale, the GCV grid end points gcv.Krig used;
+#   * predict() of both fits on the fixture's 48 x 64 grid of cell centres (what terra::interpolate evaluates,
+#     V73:726 / V73:753);
+#   * terra::crop windows of the Step-3 tile boxes (V73:656-681, 695-699, 728) for the grids of SURVEY.md G6, as
+#     1-based (row0, row1, col0, col1) of the cropped raster inside the parent -- the integer bookkeeping the library
+#     reproduces bit for bit.
+# sessionInfo() is stored next to the numbers.
+suppressPackageStartupMessages({ library(fields); library(terra) })
+inp <- file.path("tests", "golden", "r_inputs")
+out <- file.path("tests", "golden", "r_capture")
+dir.create(out, showWarnings = FALSE, recursive = TRUE)
+w <- function(x, name) write.table(format(x, digits = 17), file.path(out, name), sep = ",", quote = FALSE,
+                                   row.names = FALSE, col.names = FALSE)
+
+for (name in c("tps_synth12", "tps_synth200", "tps_sampling813")) {
+  hdr <- readLines(file.path(inp, paste0(name, ".csv")), n = 1)
+  kv <- regmatches(hdr, gregexpr("[a-z]+=[-0-9.e+]+", hdr))[[1]]
+  par <- setNames(as.numeric(sub(".*=", "", kv)), sub("=.*", "", kv))
+  tab <- read.csv(file.path(inp, paste0(name, ".csv")), comment.char = "#")
+  x <- as.matrix(tab[, c("x", "y")]); Y <- tab$resid
+  xs <- par["xmin"] + (seq_len(par["ncol"]) - 0.5) * par["res"]        # xFromCol
+  ys <- par["ymax"] - (seq_len(par["nrow"]) - 0.5) * par["res"]        # yFromRow
+  grid <- as.matrix(expand.grid(x = xs, y = ys))                          # terra cell order: row-major from the NW cell
+  for (mode in c("gcv", "fixed")) {
+    fit <- if (mode == "gcv") fields::Tps(x, Y) else fields::Tps(x, Y, lambda = par["lam"])
+    tag <- paste0(name, "_", mode)
+    w(fit$c, paste0(tag, "_c.csv")); w(fit$d, paste0(tag, "_d.csv"))
+    w(c(lambda = fit$lambda, eff.df = fit$eff.df, n = nrow(fit$knots), N = length(Y)), paste0(tag, "_scalars.csv"))
+    w(rbind(fit$transform$x.center, fit$transform$x.scale), paste0(tag, "_transform.csv"))
+    if (!is.null(fit$gcv.grid)) w(as.matrix(fit$gcv.grid[, c("lambda", "trA", "GCV")]), paste0(tag, "_gcvgrid.csv"))
+    if (!is.null(fit$lambda.est)) w(as.matrix(fit$lambda.est), paste0(tag, "_lambdaest.csv"))
+    w(matrix(predict(fit, grid), nrow = par["nrow"], ncol = par["ncol"], byrow = TRUE), paste0(tag, "_surface.csv"))
+  }
+}
+
+# ---- Step-3 tile windows (V73:649-681 tile boxes; V73:699 fit crop, V73:728 keep crop) -------------------------------
+tile_windows <- function(nrow, ncol, xmin = -78, ymax = -5, res = 1 / 1200) {
+  r <- terra::rast(nrows = nrow, ncols = ncol, xmin = xmin, xmax = xmin + ncol * res, ymin = ymax - nrow * res, ymax = ymax)
+  nRx <- ceiling(nrow / 1500); nCx <- ceiling(ncol / 1500)
+  e <- terra::ext(r)
+  longDist <- (e[2] - e[1]) / nCx; latDist <- (e[4] - e[3]) / nRx
+  rows <- NULL
+  for (j in seq_len(nRx)) for (h in seq_len(nCx)) {                       # row-major from the south-west, V73:664-681
+    cell <- c(e[1] + longDist * (h - 1), e[1] + longDist * h, e[3] + latDist * (j - 1), e[3] + latDist * j)
+    for (ov in c(0.2, 0.025)) {                                           # fit box, keep box
+      b <- terra::ext(cell[1] - ov * longDist, cell[2] + ov * longDist, cell[3] - ov * latDist, cell[4] + ov * latDist)
+      cr <- terra::crop(r, b)                                             # for the keep box the reference crops the FIT raster:
+      ce <- terra::ext(cr)                                                # the library intersects the two windows
+      rows <- rbind(rows, c(nrow, ncol, j, h, ov,
+                            terra::rowFromY(r, ce[4] - 0.5 * res), terra::rowFromY(r, ce[3] + 0.5 * res),
+                            terra::colFromX(r, ce[1] + 0.5 * res), terra::colFromX(r, ce[2] - 0.5 * res)))
+    }
+  }
+  rows
+}
+g6 <- rbind(tile_windows(1500, 1500), tile_windows(1501, 1501), tile_windows(2476, 3264), tile_windows(2000, 2000),
+            tile_windows(10000, 10000))
+colnames(g6) <- c("nrow", "ncol", "tile_row", "tile_col", "overlap", "row0", "row1", "col0", "col1")
+write.csv(g6, file.path(out, "step3_tile_windows.csv"), row.names = FALSE, quote = FALSE)
+writeLines(capture.output(sessionInfo()), file.path(out, "sessionInfo.txt"))
+cat("wrote", length(list.files(out)), "files to", out, "\n")

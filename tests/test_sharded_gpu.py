@@ -76,3 +76,109 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(hip, share):
         assert final.shape == (NROW, NCOL)
         assert np.array_equal(final, want, equal_nan=True), rank      # every rank holds the whole grid
         assert lam == single["lambda"] and rsq_m == single["rsq_model"] and rsq_f == single["rsq_final"]
+
+
+# ---------------------------------------------------------------- machisplin.tiles.* sharding (BASELINE config 4) --
+T_NROW, T_NCOL, T_N, T_LAYERS = 300, 380, 900, 3
+
+
+def _build_tiles(hip, rank=0, world=1):
+    import torch
+    from machisplin_amd import sharded, synth
+    g = synth.grid(T_NROW, T_NCOL)
+    xy, rows, cols, uv = synth.stations(g, T_N, 21)
+    tiles = hip.tiles.tiles_create(g, xy, out_ncol=2, out_nrow=2, feather_d=24)
+    cov = synth.covariates_at(g, 3, 21, rows, cols)
+    X = np.column_stack([cov, xy])
+    base = synth.response(X, uv, 21)
+    resp = np.column_stack([base + l + np.sin((2 + l) * uv[:, 0]) for l in range(T_LAYERS)])
+    iv = np.column_stack([xy, resp])
+    iv[17, 3] = np.nan                                    # an NA in layer 1 drops the station from every layer of its tiles
+    _, wts, tot = hip.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")
+    fitted = {}
+    for t in range(4):
+        sel = tiles["dat"][t]
+        ok = ~np.isnan(iv[sel]).any(axis=1)
+        fitted[t] = {}
+        for l in range(T_LAYERS):
+            if sharded.unit_owner(t, l, 4, world)[0] != rank:
+                continue
+            params = synth.ensemble_params(X[sel][ok], resp[sel, l][ok], 50 + 7 * l + t, which="gnmv")
+            fitted[t][l] = {"models": [hip.models.from_param_dict(p) for p in params], "weights": wts, "wt_total": tot}
+
+    def stack_for_tile(t):
+        r0, r1, c0, c1 = (int(v) for v in tiles["win"][t])
+        planes, nodata = synth.covariates(g, 3, 21, dtype="f32", window=(r0, r1, c0, c1))
+        return hip.RasterStack(tiles["geom"][t], planes, nodata)
+
+    ops = sharded.HipTileOps(g, tiles, stack_for_tile, iv, fitted, tile_edge=100, lambda_=None)
+    return g, tiles, iv, fitted, ops
+
+
+def _tile_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import machisplin_amd as hip
+    from machisplin_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    hip.init(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, tiles, iv, fitted, ops = _build_tiles(hip, rank, world)
+        out = sharded.TileShardedMltps(ops, dist, rank, world).step()
+        torch.cuda.synchronize()
+        q.put((rank, {l: v.cpu().numpy() for l, v in out["layers"].items()}, out["rsq_model"], out["rsq_final"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_tile_sharded_two_ranks_equal_the_single_process_chain(hip):
+    """TileShardedMltps with the HIP ops: (tile, layer) units over two ranks (sharing GPU 0, gloo) == one rank ==
+    the chain written out by hand (tiles.create -> mltps per tile and layer -> tiles.merge), bit for bit; the
+    synthetic covariate crops equal slices of the whole-grid planes."""
+    import torch
+    import torch.multiprocessing as mp
+    from machisplin_amd import sharded, synth
+    g, tiles, iv, fitted, ops = _build_tiles(hip)
+    single = sharded.TileShardedMltps(ops, None, 0, 1).step()
+    torch.cuda.synchronize()
+    full, nodata = synth.covariates(g, 3, 21, dtype="f32")
+    keep_all = None
+    for l in range(T_LAYERS):
+        planes = []
+        for t in range(4):
+            r0, r1, c0, c1 = (int(v) for v in tiles["win"][t])
+            sub = hip.RasterStack(tiles["geom"][t], full[:, r0:r1, c0:c1].contiguous(), nodata)
+            assert torch.equal(sub.planes, ops._stack(t).planes)
+            sel = tiles["dat"][t]
+            keep = hip.mltps.complete_cases(sub, iv[sel])
+            f = fitted[t][l]
+            res = hip.mltps_predict(sub, iv[sel, :2], iv[sel, 2 + l], f["models"], f["weights"], f["wt_total"], tile_edge=100, keep=keep)
+            planes.append(res["final"].contiguous())
+            assert res["rsq_model"] == single["rsq_model"][l, t]
+        want = hip.tiles.tiles_merge(g, tiles["win"], planes, in_ncol=2, in_nrow=2)
+        assert torch.equal(torch.nan_to_num(want), torch.nan_to_num(single["layers"][l]))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=800) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    seen = set()
+    for rank, layers, rsq_m, rsq_f in results:
+        assert np.array_equal(rsq_m, single["rsq_model"]) and np.array_equal(rsq_f, single["rsq_final"], equal_nan=True)
+        for l, plane in layers.items():
+            assert l % 2 == rank
+            assert np.array_equal(plane, single["layers"][l].cpu().numpy(), equal_nan=True)
+            seen.add(l)
+    assert seen == set(range(T_LAYERS))
