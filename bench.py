@@ -252,9 +252,9 @@ class Workload:
                 "note": "f64 planes = the f32 planes widened (same values), what terra holds in RAM; host ABI = "
                         "mhs_ensemble_predict with pageable host buffers, as mhsr_ensemble_predict calls it"}
 
-    def model_check(self, fit_ms, step_ms):
-        """Per-rank phase times gathered on rank 0: predicted step = max over ranks of (band + rank 0's fit) + gather +
-        whole-grid spline + Step 5, against the observed step."""
+    def phase_table(self):
+        """COLLECTIVE (every rank calls it): per-rank phase times [band, spline evaluation, fit inside the step,
+        station residuals, rows] gathered on every rank."""
         import torch.distributed as dist
         torch = self.torch
         tm = self.ops.timings
@@ -264,7 +264,11 @@ class Workload:
                              mean(tm.get("residuals_ms", [])), float(self.run.r1 - self.run.r0)], dtype=torch.float64, device="cuda")
         allv = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allv, mine)
-        allv = torch.stack(allv).cpu().numpy()
+        return torch.stack(allv).cpu().numpy()
+
+    def model_check(self, allv, fit_ms, step_ms):
+        """Predicted step = max over ranks of (band [+ rank 0's fit]) + gather + whole-grid spline + Step 5, against
+        the observed step."""
         gather_bytes = self.run.band * self.geom.ncol * 8 * (self.world - 1)
         gather_ms = gather_bytes / 153e9 * 1e3 / max(1, min(7, self.world - 1))   # direct mesh: one xGMI link per peer
         pred0 = allv[0, 0] + fit_ms
@@ -600,6 +604,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    phase_table = wl.phase_table() if world > 1 else None     # collective: outside the rank-0 block
     if rank == 0:
         wl.measure_mean_visits()
         table = wl.kernel_table()
@@ -669,7 +674,7 @@ def main():
         # what it did cost -- so that an 8-GPU line can be read without a profiler
         model_check = None
         if world > 1:
-            model_check = wl.model_check(fit_ms, dt / args.steps * 1e3)
+            model_check = wl.model_check(phase_table, fit_ms, dt / args.steps * 1e3)
         m = wl.ops.X.shape[0] - 3
         if cfg["ensemble"] and wl.cfg["stations"] >= 2000:
             # the synthetic members are fitted, not random: the ensemble explains the response and the spline improves on it

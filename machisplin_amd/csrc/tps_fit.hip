@@ -22,6 +22,7 @@
 #include "common.h"
 #include "devmath.h"
 #include "tps_host.h"
+#include "tps_chol.h"
 
 namespace mhs {
 
@@ -1332,21 +1333,27 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    const int64_t ld = (n + 15) & ~(int64_t)15;
+    // The matrix is allocated with room for the Cholesky's identity padding (up to one panel of rows and columns) and
+    // shifted by one double, so that row 3 -- where B = Q2'KQ2 starts -- sits on a 16-byte boundary in every column.
+    const int m_pad = chol_padded(m);
+    const int64_t ld = ((int64_t)(3 + m_pad) + 15) & ~(int64_t)15;
     const int64_t vs = n;
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
-    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd;
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw;
+    const bool fixed = !std::isnan(lambda);
     int *info_dev = nullptr;
     auto layout = [&](ArenaCarver &ar) {
-        A.p = ar.take<double>((size_t)(ld * n));
+        A.p = ar.take<double>((size_t)(ld * (3 + m_pad)) + 2);
+        if (A.p) A.p += 1;
         duv.p = ar.take<double>((size_t)(2 * n));
         dsw.p = ar.take<double>((size_t)n);
         vbuf.p = ar.take<double>((size_t)n);
         pbuf.p = ar.take<double>((size_t)n);
         wbuf.p = ar.take<double>((size_t)n);
-        gbuf.p = ar.take<double>((size_t)n);
+        gbuf.p = ar.take<double>((size_t)m_pad + 8);
+        chw.p = ar.take<double>(fixed ? chol_work_doubles(m) : 1);
         tau.p = ar.take<double>((size_t)n + 3);
         Vd.p = ar.take<double>((size_t)BW * vs);
         Vd2.p = ar.take<double>((size_t)BW * vs);
@@ -1400,7 +1407,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         // fixed lambda: Cholesky of B + lambda I, solve for c2 = (B + lambda I)^-1 w2
         hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, s, A.p, ld, 3, m, lam);
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
-        if (int rc = cholesky_solve(A.p, ld, 3, m, gbuf.p, info_dev, s)) return rc;
+        if (int rc = cholesky_solve_mfma(L, A.p, ld, 3, m, gbuf.p, chw.p, info_dev)) return rc;
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
     } else if (m <= TRI_SMALL_CUT && m >= 3) {

@@ -182,3 +182,48 @@ def test_tile_sharded_two_ranks_equal_the_single_process_chain(hip):
             assert np.array_equal(plane, single["layers"][l].cpu().numpy(), equal_nan=True)
             seen.add(l)
     assert seen == set(range(T_LAYERS))
+
+
+# ------------------------------------------------------------------------------- bench.py's N > 1 path, end to end --
+def _run_bench(world, workload, port):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MHS_BENCH_BACKEND="gloo", MHS_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--workload", workload,
+           "--steps", "2", "--warmup", "1"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=root)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_n_ranks_row_bands_plumbing(hip, world):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with the ranks
+    sharing GPU 0 over gloo: calibration pass, weighted row bands (rank 0 carries the fit), coefficient broadcast,
+    the in-place all-gather, the per-rank phase table and the predicted-vs-observed step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _run_bench(world, "cfg3-mini", port)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0
+    mc = d["model_check"]
+    assert len(mc["band_ms_per_rank"]) == world and sum(mc["rows_per_rank"]) == 1500
+    assert mc["rows_per_rank"][0] <= max(mc["rows_per_rank"][1:])          # rank 0 also fits the spline
+    assert mc["predicted_step_ms"] > 0 and mc["observed_step_ms"] > 0
+    assert d["rsq_final"] > d["rsq_model"] > 0.5
+
+
+@pytest.mark.timeout(900)
+def test_bench_cfg4_two_ranks_plumbing(hip):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _run_bench(2, "cfg4-mini", port)
+    assert d["n_gpus"] == 2 and d["units_on_rank0"] == 6 and d["value"] > 0      # 4 tiles x 3 layers over 2 ranks
+    assert 0.5 < d["rsq_model_mean"] <= d["rsq_final_mean"]
