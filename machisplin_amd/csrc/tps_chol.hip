@@ -196,7 +196,8 @@ __global__ __launch_bounds__(DG_THREADS) void chol_diag_kernel(double *__restric
     }
     for (int e = tid; e < CH_NB * CH_NB; e += DG_THREADS) {
         const int i = e & (CH_NB - 1), j = e >> 7;
-        Tinv[e] = SS(S, i, j);          // zeros above the diagonal
+        Tinv[e] = SS(S, i, j);                          // L11^-1, zeros above the diagonal
+        Tinv[CH_NB * CH_NB + e] = SS(S, j, i);          // and its transpose (read by the back substitution)
     }
     if (tid < CH_NB) {                  // y_j = L11^-1 b_j
         double s = 0.0;
@@ -206,59 +207,81 @@ __global__ __launch_bounds__(DG_THREADS) void chol_diag_kernel(double *__restric
 }
 
 // X = A21 L11^-T for the t rows below the diagonal block of the panel at `off` (in place), and b[below] -= X y_j.
-// Block = 64 rows; wave w owns rows 16 w .. 16 w + 15 and all 128 columns (8 accumulator tiles).
-constexpr int TR_ROWS = 64, TR_KC = 16, TR_SA = TR_ROWS + 16, TR_ST = CH_NB + 16;
+// Block = 32 rows (t / 32 blocks: the kernel sits on the factorisation's critical path, so it wants every CU even at
+// small t); wave w owns rows 16 (w & 1) .. + 15 and the column half (w >> 1) (4 accumulator tiles).  K = 128 is
+// streamed in chunks of 16 through two LDS buffers (the next chunk travels global -> registers while this one is
+// multiplied).  L11^-1 is lower triangular: products with k > j are skipped.
+constexpr int TR_ROWS = 32, TR_KC = 16, TR_SA = TR_ROWS + 16, TR_ST = CH_NB + 16;
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ A, int64_t ld, int off,
                                                         const double *__restrict__ Tinv, double *__restrict__ rhs) {
-    __shared__ __attribute__((aligned(16))) double sT[TR_KC * TR_ST];   // [k][j]
-    __shared__ __attribute__((aligned(16))) double sA[TR_KC * TR_SA];   // [k][i]
+    __shared__ __attribute__((aligned(16))) double sT[2][TR_KC * TR_ST];   // [k][j]
+    __shared__ __attribute__((aligned(16))) double sA[2][TR_KC * TR_SA];   // [k][i]
     __shared__ double ys[CH_NB];
+    __shared__ double part[2][TR_ROWS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int rh = wave & 1, ch = wave >> 1;
     double *a21 = A + (int64_t)off * ld + off + CH_NB + (int64_t)blockIdx.x * TR_ROWS;   // rows of this block, column 0 of the panel
     if (tid < CH_NB) ys[tid] = rhs[tid];   // the caller passes rhs + j: y_j at [0, NB), the entries below the panel after it
-    d4 acc[8];
+    d4 acc[4];
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[mb] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < CH_NB; k0 += TR_KC) {
-        __syncthreads();
-        // Tinv chunk: 16 columns k of 128 entries j; 2048 doubles = 8 per thread, as 4 x double2
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = (d4){0.0, 0.0, 0.0, 0.0};
+    // chunk loads: Tinv 16 columns k x 128 entries j = 1024 double2 (4 per thread: column k = wave + 4 q, rows 2 lane);
+    // A21 16 columns k x 32 rows = 256 double2 (one per thread: column tid >> 4, rows 2 (tid & 15))
+    const int tk = tid >> 6, tj = (tid & 63) * 2, ak = tid >> 4, ai = (tid & 15) * 2;
+    double2 gT0, gT1, gT2, gT3, gA;
+#define TR_GLOAD(K0)                                                                      \
+    do {                                                                                  \
+        const double *q = Tinv + (int64_t)((K0) + tk) * CH_NB + tj;                       \
+        gT0 = *(const double2 *)q; gT1 = *(const double2 *)(q + 4 * CH_NB);               \
+        gT2 = *(const double2 *)(q + 8 * CH_NB); gT3 = *(const double2 *)(q + 12 * CH_NB); \
+        gA = *(const double2 *)&a21[(int64_t)((K0) + ak) * ld + ai];                      \
+    } while (0)
+#define TR_SSTORE(BUF)                                                                    \
+    do {                                                                                  \
+        double *d = &sT[BUF][tk * TR_ST + tj];                                            \
+        *(double2 *)d = gT0; *(double2 *)(d + 4 * TR_ST) = gT1;                           \
+        *(double2 *)(d + 8 * TR_ST) = gT2; *(double2 *)(d + 12 * TR_ST) = gT3;            \
+        *(double2 *)&sA[BUF][ak * TR_SA + ai] = gA;                                       \
+    } while (0)
+    TR_GLOAD(0);
+    TR_SSTORE(0);
+    __syncthreads();
+    for (int c = 0; c < CH_NB / TR_KC; ++c) {
+        const int buf = c & 1, k0 = c * TR_KC;
+        if (c + 1 < CH_NB / TR_KC) TR_GLOAD(k0 + TR_KC);
+        if (k0 <= ch * 64 + 63) {                      // this wave's columns all have j < k0: nothing left to add
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e2 = tid + 256 * q;                 // double2 index: 1024 of them
-            const int k = e2 >> 6, j2 = (e2 & 63) * 2;
-            *(double2 *)&sT[k * TR_ST + j2] = *(const double2 *)&Tinv[(k0 + k) * CH_NB + j2];
-        }
-        // A21 chunk: 16 columns k of 64 rows; 1024 doubles = 4 per thread, as 2 x double2
+            for (int kk = 0; kk < TR_KC; kk += 4) {
+                const double b = sA[buf][(kk + l4) * TR_SA + rh * 16 + l15];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e2 = tid + 256 * q;                 // 512 double2
-            const int k = e2 >> 5, i2 = (e2 & 31) * 2;
-            *(double2 *)&sA[k * TR_SA + i2] = *(const double2 *)&a21[(int64_t)(k0 + k) * ld + i2];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < TR_KC; kk += 4) {
-            const double b = sA[(kk + l4) * TR_SA + wave * 16 + l15];
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                if (k0 + kk > mb * 16 + 15) continue;     // L11^-1 is lower triangular: (j, k) with k > j vanish
-                acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(kk + l4) * TR_ST + mb * 16 + l15], b, acc[mb], 0, 0, 0);
+                for (int mb = 0; mb < 4; ++mb) {
+                    if (k0 + kk > (ch * 4 + mb) * 16 + 15) continue;
+                    acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[buf][(kk + l4) * TR_ST + (ch * 4 + mb) * 16 + l15], b, acc[mb], 0, 0, 0);
+                }
             }
         }
+        if (c + 1 < CH_NB / TR_KC) {
+            TR_SSTORE(buf ^ 1);
+            __syncthreads();
+        }
     }
-    // acc[mb][r] = X[i = 16 wave + l15][j = 16 mb + l4 + 4 r]
+#undef TR_GLOAD
+#undef TR_SSTORE
+    // acc[mb][r] = X[i = 16 rh + l15][j = 64 ch + 16 mb + l4 + 4 r]
     double s = 0.0;
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = mb * 16 + l4 + 4 * r;
-            a21[(int64_t)j * ld + wave * 16 + l15] = acc[mb][r];
+            const int j = ch * 64 + mb * 16 + l4 + 4 * r;
+            a21[(int64_t)j * ld + rh * 16 + l15] = acc[mb][r];
             s = fma(acc[mb][r], ys[j], s);
         }
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (l4 == 0) rhs[CH_NB + (int64_t)blockIdx.x * TR_ROWS + wave * 16 + l15] -= s;
+    if (l4 == 0) part[ch][rh * 16 + l15] = s;
+    __syncthreads();
+    if (tid < TR_ROWS) rhs[CH_NB + (int64_t)blockIdx.x * TR_ROWS + tid] -= part[0][tid] + part[1][tid];
 }
 
 // C -= X X' on 128 x 128 tiles of the lower triangle of the trailing matrix.  X = the panel just solved (t x 128,
@@ -287,11 +310,20 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
     const double *X = A + (int64_t)off * ld + off + CH_NB;       // X[row][k] at X[row + k * ld]
     const double *xI = X + (int64_t)bi * SY_T, *xJ = X + (int64_t)bj * SY_T;
+    // The accumulators START as the C tile (its loads are in flight while the first chunk of X is staged) and the
+    // X_J operand is negated, so the MFMA chain itself computes C - X_I X_J' and the epilogue is stores only -- no
+    // read-modify-write latency at the end of a tile.
+    // acc[a][b][r] <-> C[i = bi T + wi + 16 b + l15][j = bj T + wj + 16 a + l4 + 4 r]
+    double *C = A + (int64_t)(off + CH_NB) * ld + off + CH_NB;
     d4 acc[4][4];   // [a: j sub-block][b: i sub-block]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 4; ++r) {
+            const double *cj = C + (int64_t)(bj * SY_T + wj + a * 16 + l4 + 4 * r) * ld + bi * SY_T + wi + l15;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b][r] = cj[b * 16];
+        }
     // chunk = 16 columns k of 128 rows for each of X_I, X_J: 1024 double2 each, 4 + 4 per thread
     // (thread -> column k = wave + 4 q, rows 2 lane, 2 lane + 1: one wave reads one whole 1 KB column)
     const int gk = tid >> 6, gr = (tid & 63) * 2;
@@ -325,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
             double fi[4], fj[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                fj[a] = sJ[buf][(kk + l4) * SY_S + wj + a * 16 + l15];
+                fj[a] = -sJ[buf][(kk + l4) * SY_S + wj + a * 16 + l15];
                 fi[a] = sI[buf][(kk + l4) * SY_S + wi + a * 16 + l15];
             }
 #pragma unroll
@@ -340,28 +372,28 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
     }
 #undef SY_GLOAD
 #undef SY_SSTORE
-    // acc[a][b][r] = sum_k X_J[wj + 16 a + l4 + 4 r][k] X_I[wi + 16 b + l15][k]  ->  C[i][j] -= it
-    double *C = A + (int64_t)(off + CH_NB) * ld + off + CH_NB;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = bj * SY_T + wj + a * 16 + l4 + 4 * r;
-            double *cj = C + (int64_t)j * ld + bi * SY_T + wi + l15;
+            double *cj = C + (int64_t)(bj * SY_T + wj + a * 16 + l4 + 4 * r) * ld + bi * SY_T + wi + l15;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) cj[b * 16] -= acc[a][b][r];
+            for (int b = 0; b < 4; ++b) cj[b * 16] = acc[a][b][r];
         }
 }
 
 // ---- back substitution x = L^-T y, panel by panel from the last ------------------------------------------------------
 // x_j = L_jj^-T y_j : one block, Tinv_j = L_jj^-1 (lower, column-major): x[i] = sum_{k >= i} Tinv[k][i] y[k]
-__global__ __launch_bounds__(128) void chol_bsolve_diag_kernel(const double *__restrict__ Tinv, double *__restrict__ y) {
+__global__ __launch_bounds__(128) void chol_bsolve_diag_kernel(const double *__restrict__ TinvT, double *__restrict__ y) {
     __shared__ double ys[CH_NB];
     ys[threadIdx.x] = y[threadIdx.x];
     __syncthreads();
-    const double *col = Tinv + (int64_t)threadIdx.x * CH_NB;     // column i of Tinv: rows k
+    // TinvT[i + NB k] = Tinv[k][i]: thread i walks row i of the transpose, consecutive threads read consecutive
+    // addresses, every load independent of the running sum (entries with k < i are zero)
+    const double *row = TinvT + threadIdx.x;
     double s = 0.0;
-    for (int k = threadIdx.x; k < CH_NB; ++k) s = fma(col[k], ys[k], s);
+#pragma unroll 16
+    for (int k = 0; k < CH_NB; ++k) s = fma(row[(int64_t)k * CH_NB], ys[k], s);
     y[threadIdx.x] = s;
 }
 // y[c] -= sum_r L[j0 + r][c] x_j[r] for every column c < j0: one wave per column (128 rows = 2 per lane)
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(256) void chol_bsolve_update_kernel(const double *_
 // work: chol_work_doubles(m) doubles.  Launches on L.s / L.s2; returns after the solve has been ENQUEUED and the
 // pivot flag read back (one stream synchronisation).
 int chol_padded(int m) { return (m + CH_NB - 1) / CH_NB * CH_NB; }
-size_t chol_work_doubles(int m) { return (size_t)(chol_padded(m) / CH_NB) * CH_NB * CH_NB; }
+size_t chol_work_doubles(int m) { return (size_t)(chol_padded(m) / CH_NB) * 2 * CH_NB * CH_NB; }
 
 int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, double *rhs_dev, double *work, int *info_dev) {
     hipStream_t s = L.s, s2 = L.s2;
@@ -410,7 +442,7 @@ int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, doubl
     }
     for (int p = 0; p < np; ++p) {
         const int j = p * CH_NB, t = m_pad - j - CH_NB, nt = t / CH_NB;
-        double *Tp = work + (size_t)p * CH_NB * CH_NB;
+        double *Tp = work + (size_t)p * 2 * CH_NB * CH_NB;
         // look-ahead: the diagonal block and the panel solve only touch this panel's columns, which the previous
         // panel's first update launch (same stream) finished; the REST of that update (stream 2) must be complete
         // only before this panel's own update reads and writes the trailing tiles
@@ -431,7 +463,7 @@ int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, doubl
     // back substitution
     for (int p = np - 1; p >= 0; --p) {
         const int j = p * CH_NB;
-        hipLaunchKernelGGL(chol_bsolve_diag_kernel, dim3(1), dim3(128), 0, s, work + (size_t)p * CH_NB * CH_NB, rhs_dev + j);
+        hipLaunchKernelGGL(chol_bsolve_diag_kernel, dim3(1), dim3(128), 0, s, work + (size_t)p * 2 * CH_NB * CH_NB + CH_NB * CH_NB, rhs_dev + j);
         if (j > 0) hipLaunchKernelGGL(chol_bsolve_update_kernel, dim3((unsigned)((j + 3) / 4)), dim3(256), 0, s, A, ld, off, j, rhs_dev);
     }
     MHS_HIP(hipGetLastError());
