@@ -539,7 +539,7 @@ static void band_eig_multi(const BandGcv &B, const int64_t *k, int nk, Pool &poo
     // the last bits of the eigenvalue, the ends of the lambda grid and finally lambda itself must not depend on how
     // many host threads happen to serve the search (the same fit on a lane of mhs_tps_surface, on another box or
     // under another CPU quota has to give the same bits).
-    const int P = 16;
+    const int P = 8;
     std::vector<double> xs((size_t)(P * nk));
     std::vector<int> cnt((size_t)(P * nk));
     for (int it = 0; it < 400; ++it) {
