@@ -254,6 +254,218 @@ __global__ __launch_bounds__(1024) void band_panel_kernel(double *__restrict__ A
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TALL panels (t > PANEL_THREADS * PANEL_RPT rows: the first panels of a fit with more than ~5 000 unknowns, e.g. the
+// 20 000-station fit of BASELINE config 5).  The single-block streaming kernel above moves the panel at what ONE block
+// can stream (~35 GB/s: 0.77 ms per panel at t = 15 000, and there are 1 900 of them at n = 20 000); here a panel is
+// factorised by a short chain of MANY-block launches instead -- one per Householder step, each a single pass over the
+// panel that applies reflector J and, in the same pass, forms the partial dot products reflector J + 1 needs:
+//   tall_dots0_kernel            S_p = sum_{i > 0} x[i][0] x[i][p] per row block; row 0 published
+//   tall_step_kernel (x BW)      totals of step J's partials -> beta, tau, v = scal x[:, J], w_p = x[J][p] + scal S_p;
+//                                x[:, p] -= tau w_p v; dense V column J; partials and pivot row of step J + 1
+//   tall_gram_kernel             partials of G = V'V (upper triangle) and V'g
+//   tall_finish_kernel           every block: T = larft(tau, G), z = T'(V'g), its rows of g -= V z; block 0 stores T
+// Every block re-derives the step's scalars from the same partials in the same order (no single-block launch in the
+// chain).  11 launches per panel, ~6 us each.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TALL_RPB = 256;                   // rows per block: one row per thread -- 60-80 blocks for a 15-20 000-row panel
+constexpr int TALL_MAXBLK = 256;                // up to 65 536 rows
+struct TallScratch {                            // device scratch of one fit lane
+    double part[2][TALL_MAXBLK][BW];            // partial dot products, ping-pong between steps
+    double rowj[BW + 1][BW];                    // pivot row J as it is when step J starts (entries p >= J)
+    double taus[BW];
+    double gpart[TALL_MAXBLK][44];              // partials of G (36) and V'g (8)
+};
+
+// sum BW per-thread values over a 256-thread block (fixed order), result in every thread
+__device__ __forceinline__ void block_sum8(double (&v)[BW], double (*lds)[BW]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < BW; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < BW; ++k) lds[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BW; ++k) v[k] = (lds[0][k] + lds[1][k]) + (lds[2][k] + lds[3][k]);
+}
+
+__global__ __launch_bounds__(256) void tall_dots0_kernel(const double *__restrict__ A, int64_t ld, int c0, int r0, int t,
+                                                         TallScratch *__restrict__ sc) {
+    __shared__ double lds[4][BW];
+    const double *P = A + (int64_t)c0 * ld + r0;
+    double acc[BW];
+#pragma unroll
+    for (int p = 0; p < BW; ++p) acc[p] = 0.0;
+#pragma unroll
+    for (int r = 0; r < TALL_RPB / 256; ++r) {
+        const int i = blockIdx.x * TALL_RPB + r * 256 + threadIdx.x;
+        if (i < t && i > 0) {
+            const double x0 = P[i];
+#pragma unroll
+            for (int p = 0; p < BW; ++p) acc[p] = fma(x0, P[(int64_t)p * ld + i], acc[p]);
+        }
+    }
+    block_sum8(acc, lds);
+    if (threadIdx.x < BW) sc->part[0][blockIdx.x][threadIdx.x] = acc[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < BW) sc->rowj[0][threadIdx.x] = P[(int64_t)threadIdx.x * ld];
+}
+
+__global__ __launch_bounds__(256) void tall_step_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t, int J,
+                                                        double *__restrict__ Vd, int64_t vs, TallScratch *__restrict__ sc) {
+    __shared__ double lds[4][BW];
+    const int nblk = gridDim.x, ph = J & 1;
+    // totals of this step's dot products: thread b takes row block b's partials, then a block sum (every block, same order)
+    double S[BW];
+#pragma unroll
+    for (int p = 0; p < BW; ++p) S[p] = (int)threadIdx.x < nblk ? sc->part[ph][threadIdx.x][p] : 0.0;
+    block_sum8(S, lds);
+    __syncthreads();
+    double xj[BW];
+#pragma unroll
+    for (int p = 0; p < BW; ++p) xj[p] = sc->rowj[J][p];
+    double alpha = 0.0, ss = 0.0;
+#pragma unroll
+    for (int p = 0; p < BW; ++p) if (p == J) { alpha = xj[p]; ss = S[p]; }
+    double beta = alpha, tau = 0.0, scal = 0.0;
+    if (ss != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+    double tw[BW];      // tau w_p for the columns still to be updated (p > J), 0 otherwise
+#pragma unroll
+    for (int p = 0; p < BW; ++p) tw[p] = p > J ? tau * fma(scal, S[p], xj[p]) : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->taus[J] = tau;
+    double *P = A + (int64_t)c0 * ld + r0;
+    double acc[BW];
+#pragma unroll
+    for (int p = 0; p < BW; ++p) acc[p] = 0.0;
+#pragma unroll
+    for (int r = 0; r < TALL_RPB / 256; ++r) {
+        const int i = blockIdx.x * TALL_RPB + r * 256 + threadIdx.x;
+        if (i >= t) continue;
+        double x[BW];
+#pragma unroll
+        for (int p = 0; p < BW; ++p) x[p] = P[(int64_t)p * ld + i];
+        double v = 0.0;
+        if (i == J) {
+            v = 1.0;
+#pragma unroll
+            for (int p = 0; p < BW; ++p) { if (p == J) x[p] = beta; else if (p > J) x[p] -= tw[p]; }
+        } else if (i > J) {
+#pragma unroll
+            for (int p = 0; p < BW; ++p) if (p == J) v = x[p] * scal;
+#pragma unroll
+            for (int p = 0; p < BW; ++p) { if (p == J) x[p] = v; else if (p > J) x[p] -= tw[p] * v; }
+        }
+        if (i >= J) {
+#pragma unroll
+            for (int p = 0; p < BW; ++p) if (p >= J) P[(int64_t)p * ld + i] = x[p];
+        }
+        Vd[(int64_t)J * vs + i] = v;
+        if (J + 1 < BW) {
+            if (i == J + 1) {
+#pragma unroll
+                for (int p = 0; p < BW; ++p) sc->rowj[J + 1][p] = x[p];
+            }
+            if (i > J + 1) {
+                double xn = 0.0;
+#pragma unroll
+                for (int p = 0; p < BW; ++p) if (p == J + 1) xn = x[p];
+#pragma unroll
+                for (int p = 0; p < BW; ++p) if (p > J) acc[p] = fma(xn, x[p], acc[p]);
+            }
+        }
+    }
+    if (J + 1 < BW) {
+        block_sum8(acc, lds);
+        if (threadIdx.x < BW) sc->part[ph ^ 1][blockIdx.x][threadIdx.x] = acc[threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void tall_gram_kernel(const double *__restrict__ Vd, int64_t vs, int t,
+                                                        const double *__restrict__ g, TallScratch *__restrict__ sc) {
+    __shared__ double lds[4][44];
+    double acc[44];
+#pragma unroll
+    for (int k = 0; k < 44; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < TALL_RPB / 256; ++r) {
+        const int i = blockIdx.x * TALL_RPB + r * 256 + threadIdx.x;
+        if (i >= t) continue;
+        double v[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) v[a] = Vd[(int64_t)a * vs + i];
+        const double gi = g[i];
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < BW; ++a)
+#pragma unroll
+            for (int b = a; b < BW; ++b) { acc[k] = fma(v[a], v[b], acc[k]); ++k; }
+#pragma unroll
+        for (int a = 0; a < BW; ++a) acc[36 + a] = fma(v[a], gi, acc[36 + a]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 44; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 44; ++k) lds[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 44) sc->gpart[blockIdx.x][threadIdx.x] = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void tall_finish_kernel(const double *__restrict__ Vd, int64_t vs, int t, double *__restrict__ g,
+                                                          double *__restrict__ Tm, const TallScratch *__restrict__ sc) {
+    __shared__ double tot[44], Ts[BW * BW], zs[BW], grp[5][44];
+    const int nblk = gridDim.x;
+    if (threadIdx.x < 220) {      // five groups of 44 threads stride over the row blocks, then the groups are added in order
+        const int k = threadIdx.x % 44, gq = threadIdx.x / 44;
+        double s = 0.0;
+        for (int b = gq; b < nblk; b += 5) s += sc->gpart[b][k];
+        grp[gq][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 44) tot[threadIdx.x] = ((grp[0][threadIdx.x] + grp[1][threadIdx.x]) + (grp[2][threadIdx.x] + grp[3][threadIdx.x])) + grp[4][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double G[BW][BW];
+        int k = 0;
+        for (int a = 0; a < BW; ++a)
+            for (int b = a; b < BW; ++b) { G[a][b] = tot[k]; G[b][a] = tot[k]; ++k; }
+        for (int e = 0; e < BW * BW; ++e) Ts[e] = 0.0;
+        for (int j = 0; j < BW; ++j) {          // larft: T upper triangular, T[r + BW c]
+            const double tj = sc->taus[j];
+            Ts[j + BW * j] = tj;
+            for (int i = 0; i < j; ++i) {
+                double sum = 0.0;
+                for (int l = i; l < j; ++l) sum += Ts[i + BW * l] * G[l][j];
+                Ts[i + BW * j] = -tj * sum;
+            }
+        }
+        for (int a = 0; a < BW; ++a) {          // z = T' (V'g)
+            double sum = 0.0;
+            for (int b = 0; b <= a; ++b) sum += Ts[b + BW * a] * tot[36 + b];
+            zs[a] = sum;
+        }
+        if (blockIdx.x == 0) for (int e = 0; e < BW * BW; ++e) Tm[e] = Ts[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TALL_RPB / 256; ++r) {
+        const int i = blockIdx.x * TALL_RPB + r * 256 + threadIdx.x;
+        if (i >= t) continue;
+        double gi = g[i];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) gi -= Vd[(int64_t)a * vs + i] * zs[a];
+        g[i] = gi;
+    }
+}
+
 // Register-resident variant for t <= PANEL_THREADS * PANEL_RPT rows: the whole t x BW panel (320 KB at
 // t = 5000) lives in the register file of ONE CU -- each thread owns PANEL_RPT rows of all BW
 // columns -- so the BW Householder steps touch global memory only to load and store the panel.
@@ -826,6 +1038,276 @@ __global__ __launch_bounds__(256) void band_update_kernel(double *__restrict__ A
     }
 }
 
+// =============================================================================================
+// DELAYED trailing update (large trailing matrices; LAPACK dsytrd's idea carried to the band reduction).  The eager
+// scheme above rewrites the whole trailing matrix after every panel of 8 columns: 24 bytes of HBM traffic per matrix
+// element and panel (symmetric product 8, rank-16 update 16), which is what a fit of 10 000+ unknowns waits for.
+// Here the updates of DG = 8 consecutive panels are ACCUMULATED -- Z = [V_0 .. V_7 | W_0 .. W_7], 128 columns -- and
+// applied once per group as one rank-128 product on v_mfma_f64_16x16x4f64 (band_rankk_kernel), while inside the group
+// the matrix stays stale and what the next panel needs is corrected on the fly:
+//   panel columns   A[:, next 8] -= sum_{q <= j} V_q W_q[next]' + W_q V_q[next]'          (band_wfix_kernel)
+//   Y = A_true V    = A_stale V - sum_{q < j} V_q (W_q'V) + W_q (V_q'V)                    (band_gram_kernel + band_wfix_kernel)
+//   M = V'Y         = M_stale - sum_{q < j} G1_q'G2_q + G2_q'G1_q,   G1_q = V_q'V, G2_q = W_q'V
+// Traffic per element and panel: 8 (symmetric product) + 16/8 (group update) = 10 bytes, and the group update is a
+// K = 128 contraction -- MFMA-shaped -- instead of eight memory-bound rank-16 passes.  Rows are indexed from the
+// group's first trailing row; slot j of Z holds panel j's V (columns 8 j ..) and W (columns 64 + 8 j ..), valid from
+// row 8 j on (nothing ever reads a slot above its first row).
+// =============================================================================================
+constexpr int DG = 8;                       // panels per group
+constexpr int DG_K = 2 * DG * BW;           // columns of Z
+constexpr int GRAM_RPB = 4096;              // rows per block of the Gram kernel (256 threads x 16)
+constexpr int GRAM_MAXBLK = 16;             // up to 65 536 rows
+
+// G[y][a][b] partial over a row range, y = 0 .. 2 j - 1: (y < j ? V_y : W_{y-j})' V_p.  Grid (row blocks, 2 j).
+__global__ __launch_bounds__(256) void band_gram_kernel(const double *__restrict__ Z, int64_t vs, int goff, int t, int j,
+                                                        double *__restrict__ Gpart /* [rowblk][2 j][64] */) {
+    __shared__ double red[4][BW * BW];
+    const int y = blockIdx.y, q = y < j ? y : y - j;
+    const double *U = Z + (int64_t)((y < j ? 0 : DG * BW) + q * BW) * vs + goff;     // V_q or W_q, local row 0 of this panel
+    const double *V = Z + (int64_t)(j * BW) * vs + goff;                              // V_p
+    double acc[BW * BW];   // acc[a * BW + b]
+#pragma unroll
+    for (int e = 0; e < BW * BW; ++e) acc[e] = 0.0;
+    for (int r = 0; r < GRAM_RPB / 256; ++r) {
+        const int i = blockIdx.x * GRAM_RPB + r * 256 + threadIdx.x;
+        const bool ok = i < t;
+        const unsigned ii = ok ? (unsigned)i : 0u;
+        double u[BW], v[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) { u[a] = ok ? U[(int64_t)a * vs + ii] : 0.0; v[a] = V[(int64_t)a * vs + ii]; }
+#pragma unroll
+        for (int a = 0; a < BW; ++a)
+#pragma unroll
+            for (int b = 0; b < BW; ++b) acc[a * BW + b] = fma(u[a], v[b], acc[a * BW + b]);
+    }
+    double w[16];
+    wave_sum64(acc, w);      // row r of the wave holds value 4 i + rho(r) in w[i]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4;
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][wave_sum64_slot(row, i)] = w[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < BW * BW)
+        Gpart[((int64_t)blockIdx.x * gridDim.y + y) * (BW * BW) + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// W_p for 64 rows per block (stored into slot j of Z) and the fix-up of the next panel's 8 columns; see above.
+__global__ __launch_bounds__(256) void band_wfix_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                        double *__restrict__ Z, int64_t vs, int goff, int j,
+                                                        const double *__restrict__ Ypart, int nsplit,
+                                                        const double *__restrict__ Tm, const double *__restrict__ Mpart, int nparts,
+                                                        const double *__restrict__ Gpart, int ngblk) {
+    __shared__ double Ts[BW * BW], Ss[BW * BW], Mm[BW * BW], MT[BW * BW], red[16][BW * BW];
+    __shared__ double G1[DG * BW * BW], G2[DG * BW * BW];          // [q][a][b]
+    __shared__ double Yh[72][BW + 1], Wh[72][BW + 1], Vh[72][BW + 1];   // rows 0..63: the block's rows; 64..71: head rows 0..7
+    __shared__ double Vhead[DG][BW][BW + 1], Whead[DG][BW][BW + 1];     // V_q / W_q at the head rows, q < j: [q][n][a]
+    const int tid = threadIdx.x, i0 = blockIdx.x * 64;
+    // ---- totals: M (as band_update_kernel<true>) and the Gram blocks
+    double4 msum = {0.0, 0.0, 0.0, 0.0};
+    {
+        const int e4 = (tid & 15) * 4, grp = tid >> 4;
+#pragma unroll 4
+        for (int p = grp; p < nparts; p += 16) {
+            const double4 m4 = *(const double4 *)(Mpart + (int64_t)p * (BW * BW) + e4);
+            msum.x += m4.x; msum.y += m4.y; msum.z += m4.z; msum.w += m4.w;
+        }
+        red[grp][e4] = msum.x; red[grp][e4 + 1] = msum.y; red[grp][e4 + 2] = msum.z; red[grp][e4 + 3] = msum.w;
+    }
+    for (int e = tid; e < 2 * j * BW * BW; e += 256) {
+        double g = 0.0;
+        for (int b = 0; b < ngblk; ++b) g += Gpart[(int64_t)b * (2 * j * BW * BW) + e];
+        if (e < j * BW * BW) G1[e] = g; else G2[e - j * BW * BW] = g;
+    }
+    if (tid < BW * BW) Ts[tid] = Tm[tid];
+    __syncthreads();
+    if (tid < BW * BW) {
+        double m = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m += red[q][tid];
+        // M[b][b'] -= sum_q sum_a G1[q][a][b] G2[q][a][b'] + G2[q][a][b] G1[q][a][b']     (M stored as Mm[b + BW b'])
+        const int b = tid % BW, b2 = tid / BW;
+        for (int qa = 0; qa < j * BW; ++qa) m -= G1[qa * BW + b] * G2[qa * BW + b2] + G2[qa * BW + b] * G1[qa * BW + b2];
+        Mm[tid] = m;
+    }
+    __syncthreads();
+    if (tid < BW * BW) {  // MT = M T
+        const int a2 = tid % BW, c = tid / BW;
+        double m = 0.0;
+        for (int b2 = 0; b2 <= c; ++b2) m += Mm[a2 + BW * b2] * Ts[b2 + BW * c];
+        MT[a2 + BW * c] = m;
+    }
+    __syncthreads();
+    if (tid < BW * BW) {  // S = T' MT, symmetrised
+        const int a2 = tid % BW, c = tid / BW;
+        double s1 = 0.0, s2 = 0.0;
+        for (int d = 0; d <= a2; ++d) s1 += Ts[d + BW * a2] * MT[d + BW * c];
+        for (int d = 0; d <= c; ++d) s2 += Ts[d + BW * c] * MT[d + BW * a2];
+        Ss[a2 + BW * c] = 0.5 * (s1 + s2);
+    }
+    // ---- head rows of the earlier panels' V and W
+    for (int e = tid; e < j * BW * BW; e += 256) {
+        const int q = e / (BW * BW), n = (e / BW) % BW, a = e % BW;
+        Vhead[q][n][a] = Z[(int64_t)(q * BW + a) * vs + goff + n];
+        Whead[q][n][a] = Z[(int64_t)(DG * BW + q * BW + a) * vs + goff + n];
+    }
+    // ---- corrected Y for the block's 64 rows and the 8 head rows: thread (slot, bq) owns b = 2 bq, 2 bq + 1
+    const double *Vp = Z + (int64_t)(j * BW) * vs + goff;
+    double *Wp = Z + (int64_t)(DG * BW + j * BW) * vs + goff;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int slot = pass == 0 ? (tid & 63) : 64 + (tid & 7);
+        const int bq = pass == 0 ? (tid >> 6) : ((tid >> 3) & 3);
+        const bool active = pass == 0 || tid < 32;
+        const int i = pass == 0 ? i0 + (tid & 63) : (tid & 7);
+        if (active) {
+            const bool ok = i < t;
+            const unsigned ii = ok ? (unsigned)i : 0u;
+            double y0 = 0.0, y1 = 0.0;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                y0 += Ypart[(int64_t)sp * BW * vs + (int64_t)(2 * bq) * vs + ii];
+                y1 += Ypart[(int64_t)sp * BW * vs + (int64_t)(2 * bq + 1) * vs + ii];
+            }
+            for (int qa = 0; qa < j * BW; ++qa) {
+                const double vq = Z[(int64_t)qa * vs + goff + ii], wq = Z[(int64_t)(DG * BW + qa) * vs + goff + ii];
+                y0 -= vq * G2[qa * BW + 2 * bq] + wq * G1[qa * BW + 2 * bq];
+                y1 -= vq * G2[qa * BW + 2 * bq + 1] + wq * G1[qa * BW + 2 * bq + 1];
+            }
+            Yh[slot][2 * bq] = ok ? y0 : 0.0; Yh[slot][2 * bq + 1] = ok ? y1 : 0.0;
+            Vh[slot][2 * bq] = ok ? Vp[(int64_t)(2 * bq) * vs + ii] : 0.0;
+            Vh[slot][2 * bq + 1] = ok ? Vp[(int64_t)(2 * bq + 1) * vs + ii] : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- W = Y T - 1/2 V S
+    for (int pass = 0; pass < 2; ++pass) {
+        const int slot = pass == 0 ? (tid & 63) : 64 + (tid & 7);
+        const int bq = pass == 0 ? (tid >> 6) : ((tid >> 3) & 3);
+        const bool active = pass == 0 || tid < 32;
+        const int i = pass == 0 ? i0 + (tid & 63) : (tid & 7);
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int a2 = 2 * bq + h;
+                double x = 0.0, vsum = 0.0;
+                for (int b = 0; b <= a2; ++b) x = fma(Yh[slot][b], Ts[b + BW * a2], x);
+                for (int c = 0; c < BW; ++c) vsum = fma(Vh[slot][c], Ss[c + BW * a2], vsum);
+                const double wv = x - 0.5 * vsum;
+                Wh[slot][a2] = wv;
+                if (pass == 0 && i < t) Wp[(int64_t)a2 * vs + i] = wv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- fix-up of the next panel's columns n = 0 .. 7 (local) for the block's rows: thread (row, bq) owns n = 2 bq, 2 bq + 1
+    {
+        const int rr = tid & 63, bq = tid >> 6, i = i0 + rr;
+        if (i < t) {
+            double s0 = 0.0, s1 = 0.0;
+            const int n0 = 2 * bq, n1 = 2 * bq + 1;
+            for (int qa = 0; qa < j * BW; ++qa) {
+                const int q = qa / BW, a = qa % BW;
+                const double vq = Z[(int64_t)qa * vs + goff + i], wq = Z[(int64_t)(DG * BW + qa) * vs + goff + i];
+                s0 += vq * Whead[q][n0][a] + wq * Vhead[q][n0][a];
+                s1 += vq * Whead[q][n1][a] + wq * Vhead[q][n1][a];
+            }
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                s0 += Vh[rr][a] * Wh[64 + n0][a] + Wh[rr][a] * Vh[64 + n0][a];
+                s1 += Vh[rr][a] * Wh[64 + n1][a] + Wh[rr][a] * Vh[64 + n1][a];
+            }
+            double *a0 = A + (int64_t)(r0 + n0) * ld + r0 + i;
+            if (n0 < t) a0[0] -= s0;
+            if (n1 < t) a0[ld] -= s1;
+        }
+    }
+}
+
+// A22 -= P Q' with P = [V | W] = Z, Q = [W | V] (K = 128) on 128 x 128 tiles, ALL tiles of the t x t block (the
+// symmetric product reads both triangles); rows of Z and A22 from `zoff` / r0.  Same MFMA tile loop as the
+// Cholesky's trailing update (tps_chol.hip): 4 waves x 64 x 64, K streamed through two LDS buffers in chunks of
+// 16, the C tile preloaded into the accumulators.  col0_only: the first block column only (look-ahead).
+typedef double d4r __attribute__((ext_vector_type(4)));
+constexpr int RK_T = 128, RK_KC = 16, RK_S = RK_T + 16;
+__global__ __launch_bounds__(256, 2) void band_rankk_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                            const double *__restrict__ Z, int64_t vs, int zoff, int nt, int col0_only) {
+    __shared__ __attribute__((aligned(16))) double sI[2][RK_KC * RK_S];
+    __shared__ __attribute__((aligned(16))) double sJ[2][RK_KC * RK_S];
+    int bi, bj;
+    if (col0_only) { bi = blockIdx.x; bj = 0; }
+    else { bi = blockIdx.x % nt; bj = 1 + blockIdx.x / nt; }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    double *C = A + (int64_t)r0 * ld + r0;
+    d4r acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = bj * RK_T + wj + a * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = bi * RK_T + wi + b * 16 + l15;
+                acc[a][b][r] = (i < t && l < t) ? C[(int64_t)l * ld + i] : 0.0;
+            }
+        }
+    // staging: thread -> column k = wave + 4 q of the chunk, row gr = lane (and lane + 64): scalar 8-byte loads (the rows
+    // of Z start at an arbitrary offset, no 16-byte alignment), rows past the end read as zero
+    const int gk = tid >> 6, gr = tid & 63;
+    const int rI0 = bi * RK_T + gr, rI1 = rI0 + 64, rJ0 = bj * RK_T + gr, rJ1 = rJ0 + 64;
+    double gI[4][2], gJ[4][2];
+    auto zcol = [&](int kappa) { return Z + (int64_t)kappa * vs + zoff; };
+#define RK_GLOAD(K0)                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+        const int kp = (K0) + gk + 4 * q;                                                              \
+        const double *cp = zcol(kp), *cq = zcol((kp + DG * BW) & (DG_K - 1));                          \
+        gI[q][0] = rI0 < t ? cp[rI0] : 0.0; gI[q][1] = rI1 < t ? cp[rI1] : 0.0;                        \
+        gJ[q][0] = rJ0 < t ? cq[rJ0] : 0.0; gJ[q][1] = rJ1 < t ? cq[rJ1] : 0.0;                        \
+    }
+#define RK_SSTORE(BUF)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+        sI[BUF][(gk + 4 * q) * RK_S + gr] = gI[q][0]; sI[BUF][(gk + 4 * q) * RK_S + gr + 64] = gI[q][1]; \
+        sJ[BUF][(gk + 4 * q) * RK_S + gr] = gJ[q][0]; sJ[BUF][(gk + 4 * q) * RK_S + gr + 64] = gJ[q][1]; \
+    }
+    RK_GLOAD(0)
+    RK_SSTORE(0)
+    __syncthreads();
+    for (int c = 0; c < DG_K / RK_KC; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < DG_K / RK_KC) { RK_GLOAD((c + 1) * RK_KC) }
+#pragma unroll
+        for (int kk = 0; kk < RK_KC; kk += 4) {
+            double fi[4], fj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                fj[a] = -sJ[buf][(kk + l4) * RK_S + wj + a * 16 + l15];
+                fi[a] = sI[buf][(kk + l4) * RK_S + wi + a * 16 + l15];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[a], fi[b], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < DG_K / RK_KC) {
+            RK_SSTORE(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef RK_GLOAD
+#undef RK_SSTORE
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = bj * RK_T + wj + a * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = bi * RK_T + wi + b * 16 + l15;
+                if (i < t && l < t) C[(int64_t)l * ld + i] = acc[a][b][r];
+            }
+        }
+}
+
 // lower band of B -> ab[d + (BW+1) j]
 __global__ void band_extract_kernel(const double *__restrict__ A, int64_t ld, int off0, int m,
                                     double *__restrict__ ab) {
@@ -903,6 +1385,57 @@ __global__ __launch_bounds__(BT_THREADS) void band_backtransform_reg_kernel(cons
     for (int k = 0; k < BT_RPT; ++k) {
         const int q = threadIdx.x + BT_THREADS * k;
         if (q < m) r[q] = rr[k];
+    }
+}
+
+// Tall form (m beyond the register-resident kernel): one MANY-block launch per panel.  Launch p applies panel p's block
+// reflector, r -= V_p (T_p s_p) with s_p = V_p'r summed from the previous launch's partials, and in the same pass over
+// its rows forms the partials of s_{p-1} = V_{p-1}'r for the next launch (panel p-1's rows contain panel p's).
+constexpr int BTM_RPB = 256, BTM_MAXBLK = 256;
+__global__ __launch_bounds__(256) void band_backtransform_step_kernel(const double *__restrict__ A, int64_t ld, int off0, int m,
+                                                                      int p /* panel to apply, npanels = none yet */, int npanels,
+                                                                      const double *__restrict__ Tall, double *__restrict__ r,
+                                                                      double *__restrict__ part /* [2][BTM_MAXBLK][BW] */) {
+    __shared__ double lds[4][BW];
+    const int i = blockIdx.x * BTM_RPB + threadIdx.x;       // row of B (0 .. m-1)
+    double ri = i < m ? r[i] : 0.0;
+    if (p < npanels) {      // apply panel p: rows q >= base_p = 8 p + 8
+        const int base = p * BW + BW;
+        double sv[BW];      // thread b takes row block b's partials (blocks above the panel wrote zeros), then a block sum
+#pragma unroll
+        for (int a = 0; a < BW; ++a) sv[a] = threadIdx.x < gridDim.x ? part[(size_t)((p & 1) * BTM_MAXBLK + threadIdx.x) * BW + a] : 0.0;
+        block_sum8(sv, lds);
+        __syncthreads();
+        const double *T = Tall + (int64_t)p * BW * BW;
+        const int il = i - base;
+        if (il >= 0 && i < m) {
+            const double *P = A + (int64_t)(off0 + p * BW) * ld + off0 + base;
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                double z = 0.0;
+#pragma unroll
+                for (int b = a; b < BW; ++b) z += T[a + BW * b] * sv[b];
+                const double v = il < a ? 0.0 : (il == a ? 1.0 : P[(int64_t)a * ld + il]);
+                ri -= v * z;
+            }
+            r[i] = ri;
+        }
+    }
+    if (p > 0) {            // partials of s_{p-1} = V_{p-1}' r (updated r)
+        const int q = p - 1, base = q * BW + BW, il = i - base;
+        double acc[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) acc[a] = 0.0;
+        if (il >= 0 && i < m) {
+            const double *P = A + (int64_t)(off0 + q * BW) * ld + off0 + base;
+#pragma unroll
+            for (int a = 0; a < BW; ++a) {
+                const double v = il < a ? 0.0 : (il == a ? 1.0 : P[(int64_t)a * ld + il]);
+                acc[a] = v * ri;
+            }
+        }
+        block_sum8(acc, lds);
+        if (threadIdx.x < BW) part[(size_t)((q & 1) * BTM_MAXBLK + blockIdx.x) * BW + threadIdx.x] = acc[threadIdx.x];
     }
 }
 
@@ -1341,9 +1874,13 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
-    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw;
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp;
     const bool fixed = !std::isnan(lambda);
+    int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme (MHS_DELAY_T overrides)
+    if (const char *e = getenv("MHS_DELAY_T")) t_delay = std::max(BW, atoi(e));
     int *info_dev = nullptr;
+    TallScratch *tall_sc = nullptr;
+    static const bool tall_multi = getenv("MHS_TALL_PANEL_ONE_BLOCK") == nullptr;
     auto layout = [&](ArenaCarver &ar) {
         A.p = ar.take<double>((size_t)(ld * (3 + m_pad)) + 2);
         if (A.p) A.p += 1;
@@ -1362,8 +1899,13 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         Yp.p = ar.take<double>((size_t)SYMM_MAX_SPLITS * BW * vs);
         Mp.p = ar.take<double>((size_t)((m + SYMM_COLS - 1) / SYMM_COLS + 1) * SYMM_MAX_SPLITS * BW * BW);
         Tall.p = ar.take<double>((size_t)std::max(npanels, 1) * BW * BW);
+        const bool big = !fixed && m - BW > t_delay;   // the delayed scheme's group buffers (large fits only)
+        Zb.p = ar.take<double>(big ? (size_t)DG_K * vs + 16 : 1);
+        Zb2.p = ar.take<double>(big ? (size_t)DG_K * vs + 16 : 1);
+        Gp.p = ar.take<double>((size_t)GRAM_MAXBLK * 2 * DG * BW * BW);
         abd.p = ar.take<double>((size_t)m * (BW + 1));
         info_dev = ar.take<int>(1);
+        tall_sc = ar.take<TallScratch>(1);
     };
     {
         ArenaCarver dry{nullptr};
@@ -1450,10 +1992,19 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             pool.push_back(e);
         }
+        // Panels 0 .. p_sw-1 run the DELAYED scheme (groups of DG panels, one MFMA rank-128 update per group) while the
+        // trailing matrix is large -- there the eager scheme waits for HBM -- the rest the eager one (latency-optimal).
+        int p_sw = 0;
+        while (p_sw + DG <= npanels && m - p_sw * BW - BW > t_delay && m - p_sw * BW - BW <= GRAM_RPB * GRAM_MAXBLK) p_sw += DG;
+        hipEvent_t pending_rest = nullptr;      // the update launch the next symmetric product has to wait for
         for (int p = 0; p < npanels; ++p) {
             const int c = p * BW, t = m - c - BW, c0 = 3 + c, r0 = 3 + c + BW;
             double *Tp = Tall.p + (size_t)p * BW * BW;
-            double *Vp = (p & 1) ? Vd2.p : Vd.p, *Wp = (p & 1) ? Wd2.p : Wd.p;
+            const bool delayed = p < p_sw;
+            const int jg = p % DG;                                          // position in its group (delayed panels)
+            double *Zg = ((p / DG) & 1) ? Zb2.p : Zb.p;                     // the group's [V | W] columns, double-buffered
+            double *Vp = delayed ? Zg + (int64_t)(jg * BW) * vs + jg * BW : ((p & 1) ? Vd2.p : Vd.p);
+            double *Wp = (p & 1) ? Wd2.p : Wd.p;
             hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
             if (t <= PANEL_THREADS * PANEL_RPT) {
                 // 640 rows per wave up to one wave per SIMD; beyond that all 8 (5 .. 7 waves load the SIMDs unevenly:
@@ -1463,21 +2014,52 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 switch (nw) { MHS_PANEL(1) MHS_PANEL(2) MHS_PANEL(3) MHS_PANEL(4) default: MHS_PANEL(8) }
 #undef MHS_PANEL
             }
-            else
+            else if (!tall_multi || t > TALL_RPB * TALL_MAXBLK)
                 hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
+            else {      // tall panel: one many-block launch per Householder step
+                const unsigned nblk = (unsigned)((t + TALL_RPB - 1) / TALL_RPB);
+                hipLaunchKernelGGL(tall_dots0_kernel, dim3(nblk), dim3(256), 0, s, A.p, ld, c0, r0, t, tall_sc);
+                for (int J = 0; J < BW; ++J)
+                    hipLaunchKernelGGL(tall_step_kernel, dim3(nblk), dim3(256), 0, s, A.p, ld, c0, r0, t, J, Vp, vs, tall_sc);
+                hipLaunchKernelGGL(tall_gram_kernel, dim3(nblk), dim3(256), 0, s, Vp, vs, t, gbuf.p + c + BW, tall_sc);
+                hipLaunchKernelGGL(tall_finish_kernel, dim3(nblk), dim3(256), 0, s, Vp, vs, t, gbuf.p + c + BW, Tp, tall_sc);
+            }
             if (p == std::max(0, npanels - 12)) MHS_HIP(hipEventRecord(pool[2 * npanels], s));   // ~1 ms before the end
-            if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));     // rest of step p-1's update
             const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS, nsplit = symm_splits(t);
-            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
             const unsigned nb = (unsigned)((t + 63) / 64);
+            if (delayed) {
+                int ngblk = 0;
+                if (jg > 0) {      // G1 = V_q'V, G2 = W_q'V for the group's earlier panels (reads the panel's output only)
+                    ngblk = (t + GRAM_RPB - 1) / GRAM_RPB;
+                    hipLaunchKernelGGL(band_gram_kernel, dim3((unsigned)ngblk, (unsigned)(2 * jg)), dim3(256), 0, s, Zg, vs, jg * BW, t, jg, Gp.p);
+                }
+                if (pending_rest) { MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0)); pending_rest = nullptr; }
+                hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
+                hipLaunchKernelGGL(band_wfix_kernel, dim3(nb), dim3(256), 0, s, A.p, ld, r0, t, Zg, vs, jg * BW, jg, Yp.p, nsplit, Tp, Mp.p,
+                                   ncg * nsplit, Gp.p, ngblk);
+                if (jg == DG - 1 && t > BW) {      // group complete: A22 of the NEXT panel -= [V | W] [W | V]'
+                    const int t2 = t - BW, r2 = r0 + BW, nt = (t2 + RK_T - 1) / RK_T;
+                    hipLaunchKernelGGL(band_rankk_kernel, dim3((unsigned)nt), dim3(256), 0, s, A.p, ld, r2, t2, Zg, vs, DG * BW, nt, 1);
+                    MHS_HIP(hipEventRecord(ev_block, s));
+                    MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
+                    if (nt > 1)
+                        hipLaunchKernelGGL(band_rankk_kernel, dim3((unsigned)(nt * (nt - 1))), dim3(256), 0, s2, A.p, ld, r2, t2, Zg, vs, DG * BW, nt, 0);
+                    MHS_HIP(hipEventRecord(ev_rest, s2));
+                    pending_rest = ev_rest;
+                }
+                continue;
+            }
+            if (pending_rest) { MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0)); pending_rest = nullptr; }     // rest of the previous update
+            hipLaunchKernelGGL(band_symm_kernel, dim3((unsigned)ncg, (unsigned)nsplit), dim3(256), 0, s, A.p, ld, r0, t, Vp, vs, Yp.p, Mp.p);
             hipLaunchKernelGGL(band_update_kernel<true>, dim3(nb, 1), dim3(256), 0, s, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Mp.p, ncg * nsplit, Wp);
             MHS_HIP(hipEventRecord(ev_block, s));
             MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
             if (nb > 1)
                 hipLaunchKernelGGL(band_update_kernel<false>, dim3(nb, nb - 1), dim3(256), 0, s2, A.p, ld, r0, t, Vp, Yp.p, nsplit, vs, Tp, Mp.p, ncg * nsplit, Wp);
             MHS_HIP(hipEventRecord(ev_rest, s2));
+            pending_rest = ev_rest;
         }
-        if (npanels > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (npanels - 1) + 1], 0));
+        if (pending_rest) MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0));
         hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)((m * (BW + 1) + 255) / 256)), dim3(256), 0, s, A.p, ld, 3, m, abd.p);
         MHS_HIP(hipGetLastError());
         std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
@@ -1501,7 +2083,11 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (npanels > 0) {
             if (m <= BT_THREADS * BT_RPT)
                 hipLaunchKernelGGL(band_backtransform_reg_kernel, dim3(1), dim3(BT_THREADS), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
-            else
+            else if (m <= BTM_RPB * BTM_MAXBLK) {
+                const unsigned nblk = (unsigned)((m + BTM_RPB - 1) / BTM_RPB);
+                for (int p = npanels; p >= 0; --p)      // launch p applies panel p (none for p = npanels) and prepares panel p - 1
+                    hipLaunchKernelGGL(band_backtransform_step_kernel, dim3(nblk), dim3(256), 0, s, A.p, ld, 3, m, p, npanels, Tall.p, gbuf.p, Gp.p);
+            } else
                 hipLaunchKernelGGL(band_backtransform_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
         }
         MHS_HIP(hipGetLastError());

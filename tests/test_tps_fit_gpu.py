@@ -108,3 +108,22 @@ def test_large_fit_uses_streaming_panel_path(hip):
     assert _rel(got.c, ref["c"]) < 1e-7 and _rel(got.d, ref["d"]) < 1e-7
     fixed = hip.Tps(xy, y, lambda_=got.lambda_)  # Cholesky route agrees with the band route
     assert _rel(fixed.c, got.c) < 1e-8
+
+
+@pytest.mark.parametrize("n", [300, 813, 1500])
+def test_delayed_update_scheme_equals_the_eager_one(hip, n, monkeypatch):
+    """Large trailing matrices take the DELAYED update scheme of the band reduction (groups of 8 panels, one MFMA
+    rank-128 update per group, the symmetric products corrected on the fly); MHS_DELAY_T lowers its threshold so
+    that small fits exercise it: every group position, the group update's ragged edge tiles, the switch to the eager
+    scheme.  Same lambda, same coefficients (to rounding) as the eager scheme and as the oracle."""
+    xy, y = synth_stations(n, 300 + n)
+    eager = hip.Tps(xy, y)
+    monkeypatch.setenv("MHS_DELAY_T", "40")
+    delayed = hip.Tps(xy, y)
+    monkeypatch.delenv("MHS_DELAY_T")
+    assert abs(delayed.lambda_ - eager.lambda_) < 1e-8 * eager.lambda_
+    assert abs(delayed.gcv - eager.gcv) < 1e-9 * eager.gcv
+    ref = otps.fit(xy, y, lam=delayed.lambda_)
+    assert _rel(delayed.c, ref["c"]) < 1e-8 and _rel(delayed.d, ref["d"]) < 1e-8
+    want = otps.fit(xy, y)
+    assert abs(delayed.lambda_ - want["lambda"]) < 1e-8 * want["lambda"]
