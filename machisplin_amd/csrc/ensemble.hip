@@ -631,7 +631,9 @@ __device__ __forceinline__ void lut_tree_reg(float2v &a01, float2v &a23, const f
     }
 }
 
-template <int S>
+// K64: float64 planes (rank search in double).  A separate instantiation, so that the float-key kernel -- the one the
+// resident-float32 bench runs -- keeps its 96 registers without the double search's temporaries.
+template <int S, bool K64>
 __global__ __launch_bounds__(256, 5) void gbm_lutreg_kernel(const double *__restrict__ lut,
                                                          const int *__restrict__ meta,
                                                          const void *__restrict__ sorted, int key64,
@@ -660,7 +662,10 @@ __global__ __launch_bounds__(256, 5) void gbm_lutreg_kernel(const double *__rest
 #pragma unroll
     for (int j = 0; j < LUT_REG_P; ++j) {
         float r[LUT_R] = {0.f, 0.f, 0.f, 0.f};
-        if (j < p) lut_ranks<LUT_R, 256>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
+        if (j < p) {
+            if constexpr (K64) lut_ranks_t<LUT_R, 256, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+            else lut_ranks_t<LUT_R, 256, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+        }
 #pragma unroll
         for (int c = 0; c < LUT_R; ++c) keys[j * LUT_R + c] = -r[c];
     }
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
 // tree costs one barrier.  In the single-buffer form a third of the kernel was staging: every wave idle while
 // 48 KB are copied between two barriers, 500 times per block.
-template <int LOG2R>
+template <int LOG2R, bool K64>
 __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restrict__ gnodes,
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
@@ -825,7 +830,8 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     }
     for (int j = 0; j < p; ++j) {
         float r[R];
-        lut_ranks<R, 1024>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
+        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
@@ -1182,7 +1188,8 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     const size_t lut_bytes = ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
     const bool in_regs = m->p <= LUT_REG_P;
     const size_t bytes = in_regs ? lut_bytes : (size_t)m->p * 256 * LUT_R * sizeof(float) + lut_bytes;
-    auto kern = in_regs ? (m->lut_S == 5 ? gbm_lutreg_kernel<5> : gbm_lutreg_kernel<6>)
+    auto kern = in_regs ? (m->lut_S == 5 ? (key64 ? gbm_lutreg_kernel<5, true> : gbm_lutreg_kernel<5, false>)
+                                         : (key64 ? gbm_lutreg_kernel<6, true> : gbm_lutreg_kernel<6, false>))
                         : (m->lut_S == 5 ? gbm_lut_kernel<5> : gbm_lut_kernel<6>);
     MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, tt.lut_meta, tt.sorted, key64, tt.sorted_off,
@@ -1286,7 +1293,8 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
     if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
         const size_t dbytes = rf_walk_db_lds(m, log2r);
-        auto dk = log2r == 2 ? rf_walk_db_kernel<2> : rf_walk_db_kernel<1>;
+        auto dk = log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
+                             : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
         hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
                            m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
