@@ -63,14 +63,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tps-mode", default="global", choices=["global", "tiled"],
+                    help="Step 3 of the row-band workloads: one global fit (the north-star primitive, default) or the reference's "
+                         "own ceil(n/1500)^2 overlapping tiles dealt over the ranks (no serial fit)")
     return ap.parse_args()
 
 
 class Workload:
-    def __init__(self, cfg, mhs, torch, dist, rank, world):
+    def __init__(self, cfg, mhs, torch, dist, rank, world, tps_mode="global"):
         from machisplin_amd import sharded, synth
         self.cfg, self.mhs, self.torch = cfg, mhs, torch
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.tps_mode = rank, world, tps_mode
         side, n = cfg["side"], cfg["stations"]
         self.geom = synth.grid(side, side)
         seed = synth.BASE_SEED + 3
@@ -90,11 +93,14 @@ class Workload:
         self.models = [mhs.models.from_param_dict(p) for p in self.params]
         self.X = X
         self.ops = sharded.HipOps(self.stack, self.xy, self.resp, self.models, self.weights, self.wt_total, timed=True)
-        self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side)
+        if tps_mode == "tiled":
+            self.run = sharded.TiledTpsShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side, tile_edge=1500)
+        else:
+            self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side)
         self.cells = side * side
         self.last = None
         self.rank0_share = None
-        if world > 1:
+        if world > 1 and tps_mode == "global":
             # Load balance (setup, untimed): rank 0 also carries the spline fit, so it gets fewer rows.  One
             # calibration pass with equal bands gives this GPU's time for all cells and the stand-alone fit time;
             # rank 0 decides the share and broadcasts it so that every rank builds the same bands.
@@ -155,6 +161,14 @@ class Workload:
                              "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
         if mean_ms("tps_eval_ms"):
             band_cells = ens_band_cells
+        fused = [kk for kk in ops.timings if kk.startswith("model_") and "+" in kk]
+        for fk in fused:
+            ms = mean_ms(fk)
+            if ms:
+                by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
+                rows.append({"kernel": "small_members_kernel (%s)" % fk[6:-3], "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "work": "gam + nnet + earth in one pass: read C fp32 planes once + read-modify-write the fp64 plane once"})
         for prm in self.params:
             k = prm["kind"]
             ms = mean_ms("model_%s_ms" % k)
@@ -469,12 +483,23 @@ class PerModelOps:
     def ensemble_band(self, r0, r1, out):
         o = self.o
         g = o.stack.geom
-        from machisplin_amd.models import predict
+        from machisplin_amd.models import members_predict
         kinds = {"Gbm": "gbm", "Gam": "lm", "Nnet": "nnet", "Earth": "earth", "RandomForest": "rf", "Ksvm": "svr"}
-        for k, (m, w) in enumerate(zip(o.models, o.weights)):
-            key = "model_%s_ms" % kinds[type(m).__name__]
+        small = ("lm", "nnet", "earth")
+        k, n = 0, len(o.models)
+        while k < n:    # the library's own grouping: a run of gam / nnet / earth members is ONE fused launch
+            e = k + 1
+            name = kinds[type(o.models[k]).__name__]
+            if name in small:
+                want = list(small[small.index(name) + 1:])
+                while e < n and kinds[type(o.models[e]).__name__] in want:
+                    want = want[want.index(kinds[type(o.models[e]).__name__]) + 1:]
+                    e += 1
+            key = "model_%s_ms" % ("+".join(kinds[type(m).__name__] for m in o.models[k:e]))
             o.timings.setdefault(key, [])
-            o._timed(key, lambda: predict(o.stack, m, window=(r0, r1, 0, g.ncol), weight=w, accumulate=k > 0, out=out))
+            ms, ws, first = o.models[k:e], o.weights[k:e], k == 0
+            o._timed(key, lambda: members_predict(o.stack, ms, ws, window=(r0, r1, 0, g.ncol), accumulate=not first, out=out))
+            k = e
         st = o.torch.cuda.current_stream(o.device).cuda_stream
         o._lib.check(o._lib.lib().mhs_scale_add_dev(out.data_ptr(), o.wt_total, None, out.data_ptr(), out.numel(), st))
 
@@ -554,7 +579,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     cfg = WORKLOADS[args.workload]
-    wl = (TileWorkload if cfg.get("tiled") else Workload)(cfg, mhs, torch, dist, rank, world)
+    wl = TileWorkload(cfg, mhs, torch, dist, rank, world) if cfg.get("tiled") else Workload(cfg, mhs, torch, dist, rank, world, args.tps_mode)
 
     def fence():
         torch.cuda.synchronize()
@@ -610,7 +635,7 @@ def main():
         table = wl.kernel_table()
         dom = max(table, key=lambda r: r["launch_ms"]) if table else None
         tm = wl.ops.timings
-        fit_overlapped_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):]))
+        fit_overlapped_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):])) if tm["tps_fit_ms"] else None
         # inside a step the fit runs BESIDE the ensemble kernels (it is starved by them and its wall time
         # is not a kernel property), so the TPS-solve rate is taken from a stand-alone fit after the run
         knots, resid = wl.ops.X[:, -2:], wl.run.ops.station_residuals()[1]
@@ -693,8 +718,10 @@ def main():
             "config": {"workload": cfg["name"], "stations": cfg["stations"], "grid": [cfg["side"], cfg["side"]],
                        "covariates": "%d x float32 planes resident in HBM" % cfg["layers"],
                        "members": [p["kind"] for p in wl.params], "gbm_trees": cfg["gbm_trees"], "rf_trees": cfg["rf_trees"],
-                       "tps_mode": "global (one fit on all stations, GCV lambda, V73:748-753)",
-                       "parallelism": "rowband%d + bcast(coef) + 1 all-gather" % world,
+                       "tps_mode": ("global (one fit on all stations, GCV lambda, V73:748-753)" if args.tps_mode == "global" else
+                                    "reference-tiled (ceil(n/1500)^2 overlapping tiles with their own GCV fits, mosaic, feathering, V73:636-897), tiles dealt over the ranks"),
+                       "parallelism": ("rowband%d + bcast(coef) + 1 all-gather" if args.tps_mode == "global" else
+                                       "rowband%d + Step-3 tiles dealt over the ranks + 1 all-gather") % world,
                        "rank0_row_share": wl.rank0_share},
             "roofline": ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")}
                          if dom else None),  # None only if rank 0 was given no rows at all
@@ -705,7 +732,7 @@ def main():
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "tps_eval_check": eval_check,
             "f64_boundary": f64_boundary, "model_check": model_check,
-            "lambda": wl.last["lambda"], "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
+            "lambda": wl.last.get("lambda"), "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
             ff = next((r["launch_ms"] for r in table if r["kernel"].startswith("tps_ff")), None)

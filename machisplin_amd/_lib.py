@@ -82,6 +82,8 @@ SIGNATURES = {
     "mhs_model_free": (C.c_int, [_vp]),
     "mhs_predict_dev": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Stack), _i64, _i64, _i64, _i64,
                                   C.c_double, C.c_int, _vp, _i64, _vp]),
+    "mhs_members_predict_dev": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.POINTER(Grid), C.POINTER(Stack), C.c_int64, C.c_int64,
+                                          C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mhs_ensemble_predict_dev": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),
                                            C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "mhs_ensemble_predict": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),

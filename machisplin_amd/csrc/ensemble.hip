@@ -196,6 +196,65 @@ __global__ __launch_bounds__(256) void earth_kernel(const double *__restrict__ c
     emit(out, (int64_t)row * g.ld_out + col, na ? NAN : acc, weight, accumulate);
 }
 
+// ------------------------------------------------- lm + nnet + earth in ONE pass --
+// The three HBM-bound members are consecutive in the reference's model order (g, n, m -- V73:340-362): evaluated in
+// one kernel the planes are read once and the output plane is read and written once (28 B per cell instead of 3 x
+// 28), with exactly the arithmetic and accumulation order of the three separate kernels (bit-identical planes).
+struct SmallArgs {
+    const double *lm_coef;                                             // NULL: member absent
+    const double *nn_w; int nn_H; double nn_scale, nn_shift;           // nn_w NULL: absent
+    const double *ea_coef; const double *ea_cut; const int *ea_tstart, *ea_fvar, *ea_fdir; int ea_nterms;   // ea_coef NULL: absent
+    double w_lm, w_nn, w_ea;
+};
+template <int P>
+__global__ __launch_bounds__(256) void small_members_kernel(SmallArgs a, StackDev s, PredGeom g, int accumulate,
+                                                            double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)g.nr * g.nc) return;
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    double x[P];
+    bool na = false;
+#pragma unroll
+    for (int j = 0; j < P; ++j) { x[j] = predictor(s, g, j, row, col); na |= isnan(x[j]); }
+    const int64_t o = (int64_t)row * g.ld_out + col;
+    double v = accumulate ? out[o] : 0.0;
+    bool first = !accumulate;
+    auto add = [&](double pred, double w) { const double t = pred * w; v = first ? t : v + t; first = false; };
+    if (a.lm_coef) {
+        double acc = a.lm_coef[0];
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc = acc + a.lm_coef[j + 1] * x[j];
+        add(acc, a.w_lm);
+    }
+    if (a.nn_w) {
+        double acc = a.nn_w[(P + 1) * a.nn_H];
+        for (int h = 0; h < a.nn_H; ++h) {
+            const double *wh = a.nn_w + h * (P + 1);
+            double z = wh[0];
+#pragma unroll
+            for (int j = 0; j < P; ++j) z = z + wh[1 + j] * x[j];
+            acc = acc + a.nn_w[(P + 1) * a.nn_H + 1 + h] * nnet_sigmoid(z);
+        }
+        acc = acc * a.nn_scale + a.nn_shift;
+        add(na ? NAN : acc, a.w_nn);
+    }
+    if (a.ea_coef) {
+        double acc = 0.0;
+        for (int k = 0; k < a.ea_nterms; ++k) {
+            double term = 1.0;
+            for (int f = a.ea_tstart[k]; f < a.ea_tstart[k + 1]; ++f) {
+                const double xv = predictor(s, g, a.ea_fvar[f], row, col);
+                const int d = a.ea_fdir[f];
+                const double fac = d == 2 ? xv : (d == 1 ? fmax(0.0, xv - a.ea_cut[f]) : fmax(0.0, a.ea_cut[f] - xv));
+                term = term * fac;
+            }
+            acc = acc + a.ea_coef[k] * term;
+        }
+        add(na ? NAN : acc, a.w_ea);
+    }
+    out[o] = v;
+}
+
 // ------------------------------------------------------------------------ svr --
 // exp(-700 u) for u in [0, 1] (u = -x / 700: the factor is folded into the per-support-vector coefficients, and
 // the range check is the free `clamp` output modifier of the fma that produces u).  In units of ln2/4096,
@@ -1360,6 +1419,51 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
     return MHS_OK;
 }
 
+template <int P>
+static void launch_small(const SmallArgs &a, const StackDev &s, const PredGeom &g, int acc, double *out, hipStream_t st, unsigned blocks) {
+    hipLaunchKernelGGL((small_members_kernel<P>), dim3(blocks), dim3(256), 0, st, a, s, g, acc, out);
+}
+
+// out (+)= sum_k w_k pred_k for the members in order (V73:471 ... 606); a run of two or three of (lm, nnet, earth) --
+// consecutive in the reference's model order -- goes through one fused pass.  MHS_NO_FUSE=1 launches them one by one.
+static int launch_members(const mhs_model *const *models, const double *weights, int n_models, const StackDev &s,
+                          const PredGeom &g, int accumulate_first, double *out, hipStream_t st, const mhs_grid *grid) {
+    static const bool fuse = getenv("MHS_NO_FUSE") == nullptr;
+    const int64_t total = (int64_t)g.nr * g.nc;
+    int k = 0;
+    while (k < n_models) {
+        const int acc = (k > 0 || accumulate_first) ? 1 : 0;
+        // the longest run lm? nnet? earth? starting at k (each at most once, in that order)
+        int e = k;
+        const mhs_model *lm = nullptr, *nn = nullptr, *ea = nullptr;
+        if (fuse && total > 0 && models[k]->p <= PMAX) {
+            if (e < n_models && models[e]->kind == K_LM) lm = models[e++];
+            if (e < n_models && models[e]->kind == K_NNET && models[e]->p == models[k]->p) nn = models[e++];
+            if (e < n_models && models[e]->kind == K_EARTH && models[e]->p == models[k]->p) ea = models[e++];
+        }
+        if (e - k >= 2) {
+            SmallArgs a{};
+            if (lm) { a.lm_coef = lm->dpar; a.w_lm = weights[k]; }
+            if (nn) { a.nn_w = nn->dpar; a.nn_H = nn->n0; a.nn_scale = nn->s0; a.nn_shift = nn->s1; a.w_nn = weights[k + (lm ? 1 : 0)]; }
+            if (ea) {
+                a.ea_coef = ea->dpar; a.ea_cut = ea->dpar + ea->n0; a.ea_tstart = ea->ipar; a.ea_fvar = ea->ipar + ea->n0 + 1;
+                a.ea_fdir = ea->ipar + ea->n0 + 1 + ea->n1; a.ea_nterms = ea->n0; a.w_ea = weights[e - 1];
+            }
+            const unsigned blocks = (unsigned)((total + 255) / 256);
+            const int P_ = models[k]->p;
+#define CALL_SMALL(P) launch_small<P>(a, s, g, acc, out, st, blocks)
+            MHS_DISPATCH_P(P_, CALL_SMALL)
+#undef CALL_SMALL
+            MHS_HIP(hipGetLastError());
+            k = e;
+            continue;
+        }
+        if (int rc = launch_model(models[k], s, g, weights[k], acc, out, st, grid)) return rc;
+        ++k;
+    }
+    return MHS_OK;
+}
+
 static int make_stack(const mhs_model *m, const mhs_grid *g, const mhs_stack *c, StackDev *s) {
     MHS_REQUIRE(c && c->data, "covariate stack is NULL");
     MHS_REQUIRE(c->n_layers == m->p - 2, "stack has the wrong number of layers for this model (p = layers + 2)");
@@ -1658,14 +1762,28 @@ int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_stack *cova
     return launch_model(m, s, pg, weight, accumulate, out_dev, pick_stream(stream), g);
 }
 
+int mhs_members_predict_dev(const mhs_model *const *models, const double *weights, int n_models, const mhs_grid *g,
+                            const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0, int64_t c1, int accumulate,
+                            double *out_dev, int64_t ld, void *stream) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(models && weights && n_models >= 1 && out_dev, "bad arguments");
+    PredGeom pg;
+    StackDev s;
+    if (int rc = make_geom(g, r0, r1, c0, c1, ld, &pg)) return rc;
+    for (int k = 0; k < n_models; ++k) {
+        MHS_REQUIRE(models[k] != nullptr, "NULL model");
+        if (int rc = make_stack(models[k], g, covars, &s)) return rc;     // every member must fit the stack
+    }
+    return launch_members(models, weights, n_models, s, pg, accumulate, out_dev, pick_stream(stream), g);
+}
+
 int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weights, int n_models,
                              double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
                              int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(models && weights && n_models >= 1 && out_dev, "bad ensemble arguments");
     MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
-    for (int k = 0; k < n_models; ++k)
-        if (int rc = mhs_predict_dev(models[k], g, covars, r0, r1, c0, c1, weights[k], k > 0, out_dev, ld, stream)) return rc;
+    if (int rc = mhs_members_predict_dev(models, weights, n_models, g, covars, r0, r1, c0, c1, 0, out_dev, ld, stream)) return rc;
     const int64_t total = (r1 - r0) * (c1 - c0);
     if (total > 0) {
         hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -1701,14 +1819,15 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     mhs_stack ds = *covars;
     ds.data = dcov.p - (size_t)r0 * covars->ld * esz;
     ds.plane_stride = (int64_t)nr * covars->ld;
-    for (int k = 0; k < n_models; ++k) {
+    {
         PredGeom pg;
         StackDev sd;
         if (int rc = make_geom(g, r0, r1, c0, c1, nc, &pg)) return rc;
-        MHS_REQUIRE(covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
+        for (int k = 0; k < n_models; ++k)
+            MHS_REQUIRE(models[k] && covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
         sd.data = ds.data; sd.C = ds.n_layers; sd.dtype = ds.dtype; sd.plane_stride = ds.plane_stride;
         sd.ld = ds.ld; sd.nodata = ds.nodata; sd.has_nodata = !std::isnan(ds.nodata); sd.all_from_planes = 0;
-        if (int rc = launch_model(models[k], sd, pg, weights[k], k > 0, dout.p, s, g)) return rc;
+        if (int rc = launch_members(models, weights, n_models, sd, pg, 0, dout.p, s, g)) return rc;
     }
     hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((nr * nc + 255) / 256)), dim3(256), 0, s,
                        dout.p, (int)nr, (int)nc, nc, wt_total);

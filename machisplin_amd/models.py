@@ -221,6 +221,25 @@ def ensemble_predict(stack: RasterStack, models, weights, wt_total: float, windo
     return out
 
 
+def members_predict(stack: RasterStack, models, weights, window=None, accumulate: bool = False, out=None, stream=None):
+    """``out (+)= sum_k w_k pred_k`` over the window, members in order: the accumulation lines of the Step-2 loop
+    (V73:471 ... 605) without the final division.  Consecutive gam / nnet / earth members share one pass over the planes
+    (bit-identical to calling :func:`predict` member by member)."""
+    import torch
+    window = _window(stack, window)
+    out = _out(stack, window, out)
+    n = len(models)
+    if n == 0 or n != len(weights):
+        raise ValueError("need one weight per model")
+    hs = (C.c_void_p * n)(*[m._h for m in models])
+    ws = (C.c_double * n)(*[float(w) for w in weights])
+    g, s = stack.geom.c_struct(), stack.c_struct()
+    st = stream if stream is not None else torch.cuda.current_stream(out.device).cuda_stream
+    _lib.check(_lib.lib().mhs_members_predict_dev(hs, ws, n, C.byref(g), C.byref(s), *window, int(bool(accumulate)),
+                                                  out.data_ptr(), out.stride(0), st))
+    return out
+
+
 def select_weights(p_opt, labels="bgnmrv"):
     """V73:336-362 / 375-392: keep model k iff round(p_k, 2) > 0.05 * sum(p); the kept
     weight is round(p_k, 2); the divisor stays the unrounded sum over ALL candidates."""

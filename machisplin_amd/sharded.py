@@ -146,6 +146,98 @@ class ShardedMltps:
         return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": unpack_tps(packed)["lambda"]}
 
 
+def assign_tiles(costs, world: int):
+    """Owner rank of every Step-3 tile: longest-processing-time greedy on the tile costs (stations x cells of the
+    keep window) -- heaviest tile first onto the least loaded rank, ties to the lower rank.
+    Deterministic, so every rank computes the same table."""
+    order = sorted(range(len(costs)), key=lambda h: (-float(costs[h]), h))
+    load, owner = [0.0] * world, [0] * len(costs)
+    for h in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[h] = r
+        load[r] += float(costs[h])
+    return owner
+
+
+class TiledTpsShardedMltps:
+    """Steps 2-5 over `world` ranks with Step 3 the way the REFERENCE computes it above 1500 px (V73:636-897):
+    ceil(nrow/1500) x ceil(ncol/1500) overlapping tiles, each with its own spline fit, mean mosaic, seam feathering.
+    The tiles are independent given res.FINAL, so they are dealt to the ranks (assign_tiles) and there is no serial
+    fit: every rank predicts its row band of the ensemble AND fits + evaluates its tiles, ONE all-gather moves both
+    (chunk = band rows followed by the rank's tile slots), and every rank mosaics, feathers and sums.
+
+    ops: ensemble_band, station_residuals, add, gather as for ShardedMltps, plus
+      tps_tiles(tile_edge) -> dict(nRx, nCx, keep = [(r0, r1, c0, c1)], cost = [stations x cells])   (same on every rank)
+      tps_tile(h, knots, resid, out)   tile h's keep-window plane (its own fit; zeros below 10 stations, V73:710-721)
+      tps_mosaic(nRx, nCx, keep, tiles, out)   mean mosaic + feathering of the tile planes into the grid plane `out`
+    """
+
+    def __init__(self, ops, dist, rank: int, world: int, nrow: int, ncol: int, tile_edge: int = 1500):
+        import torch
+        self.ops, self.dist, self.rank, self.world = ops, dist, rank, world
+        self.nrow, self.ncol = nrow, ncol
+        self.band, self.bands = row_bands(nrow, world)
+        self.r0, self.r1 = self.bands[rank]
+        self.layout = ops.tps_tiles(tile_edge)
+        keep = [tuple(int(v) for v in w) for w in self.layout["keep"]]
+        self.keep = keep
+        self.cells = [(w[1] - w[0]) * (w[3] - w[2]) for w in keep]
+        self.owner = assign_tiles(self.layout["cost"], world)
+        self.offset, fill = [0] * len(keep), [0] * world          # tile h's offset inside its owner's tile area
+        for h in range(len(keep)):
+            self.offset[h] = fill[self.owner[h]]
+            fill[self.owner[h]] += self.cells[h]
+        self.band_len = self.band * ncol
+        self.chunk = self.band_len + max(fill + [1])
+        kw = {"dtype": torch.float64, "device": ops.device}
+        self.full = torch.zeros(world * self.chunk, **kw)
+        self.mine = self.full[:self.chunk] if world == 1 else torch.zeros(self.chunk, **kw)
+        self.total = torch.zeros((nrow, ncol), **kw)
+        self.pred_full = None
+        self.torch = torch
+
+    def _tile_view(self, buf, base, h):
+        r0, r1, c0, c1 = self.keep[h]
+        o = base + self.band_len + self.offset[h]
+        return buf[o:o + self.cells[h]].view(r1 - r0, c1 - c0)
+
+    def step(self):
+        ops = self.ops
+        nb = self.r1 - self.r0
+        if nb > 0:
+            ops.ensemble_band(self.r0, self.r1, self.mine[:nb * self.ncol].view(nb, self.ncol))
+        knots, resid, resp, rows, cols = ops.station_residuals()
+        for h in range(len(self.keep)):
+            if self.owner[h] == self.rank:
+                ops.tps_tile(h, knots, resid, self._tile_view(self.mine, 0, h))
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.full, self.mine)      # the one exchange: bands + tile planes
+        tiles = [self._tile_view(self.full, self.owner[h] * self.chunk, h) for h in range(len(self.keep))]
+        ops.tps_mosaic(self.layout["nRx"], self.layout["nCx"], self.keep, tiles, self.total)     # final.TPS
+        bands = []
+        for r, (a, b) in enumerate(self.bands):
+            if b > a:
+                pb = self.full[r * self.chunk:r * self.chunk + (b - a) * self.ncol].view(b - a, self.ncol)
+                bands.append((a, b, pb))
+        f_tps = ops.gather(self.total, rows, cols)          # final.TPS at the stations, before the sum goes in place
+        for a, b, pb in bands:
+            ops.add(pb, self.total[a:b], self.total[a:b])    # Step 5's sum, band by band, in place
+        f_actual = ops.gather(self.total, rows, cols)
+        tss = float(np.sum((resp - resp.mean()) ** 2))
+        rsq_model = 1.0 - float(np.sum(resid ** 2)) / tss
+        rsq_final = 1.0 - float(np.sum((resp - f_actual) ** 2)) / tss
+        if rsq_final > rsq_model:
+            final = self.total
+        else:      # V73:925-930: the ensemble alone (assembled from the gathered bands; the rare branch)
+            if self.pred_full is None:
+                self.pred_full = self.torch.zeros_like(self.total)
+            for a, b, pb in bands:
+                self.pred_full[a:b].copy_(pb)
+            final = self.pred_full
+        return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "tps_at_stations": f_tps,
+                "tile_owner": list(self.owner)}
+
+
 class HipOps:
     """The per-band arithmetic of ShardedMltps on one MI355X, through the C ABI (global-TPS
     mode: one fit on all stations, V73:748-753).  `timings` collects HIP-event durations (ms)
@@ -218,6 +310,38 @@ class HipOps:
         g = self.stack.geom
         self._timed("tps_eval_ms", lambda: interpolate(g, fit, window=(r0, r1, 0, g.ncol), out=out))
         self.last_eval_plan = fit.eval_plan()
+
+    # ---- reference-tiled Step 3 (TiledTpsShardedMltps) --------------------------------------------------------------
+    def tps_tiles(self, tile_edge):
+        from . import tiles
+        g = self.stack.geom
+        nRx, nCx, fit, keep = tiles.step3_tile_windows(g, tile_edge)
+        ok = ~np.isnan(self.X[:, 0])                       # stations on an NA cell of covariate 1 are dropped (V73:701-706)
+        self._tile_sel, cost = [], []
+        for h in range(nRx * nCx):
+            fr0, fr1, fc0, fc1 = (int(v) for v in fit[h])
+            sel = np.flatnonzero(ok & (self.rows >= fr0) & (self.rows < fr1) & (self.cols >= fc0) & (self.cols < fc1))
+            self._tile_sel.append(sel)
+            kr0, kr1, kc0, kc1 = (int(v) for v in keep[h])
+            cost.append(float(sel.size) * (kr1 - kr0) * (kc1 - kc0) + float(sel.size) ** 3)
+        self._tile_fit, self._tile_keep = fit, keep
+        return {"nRx": int(nRx), "nCx": int(nCx), "keep": [tuple(int(v) for v in w) for w in keep], "cost": cost}
+
+    def tps_tile(self, h, knots, resid, out):
+        from .tps import Tps, interpolate
+        sel = self._tile_sel[h]
+        if sel.size < 10:                                  # V73:710-721: the tile is all zeros
+            out.zero_()
+            return
+        fr0, fr1, fc0, fc1 = (int(v) for v in self._tile_fit[h])
+        kr0, kr1, kc0, kc1 = (int(v) for v in self._tile_keep[h])
+        fit = Tps(knots[sel], resid[sel], lambda_=self.lambda_, gcv_mode=self.gcv_mode)
+        gf = self.stack.geom.window(fr0, fr1, fc0, fc1)     # terra::rast(rb): geometry of the fit raster
+        interpolate(gf, fit, window=(kr0 - fr0, kr1 - fr0, kc0 - fc0, kc1 - fc0), out=out)
+
+    def tps_mosaic(self, nRx, nCx, keep, tiles_, out):
+        from . import tiles
+        tiles.mosaic_feather(self.stack.geom, nRx, nCx, np.asarray(keep, dtype=np.int64), list(tiles_), merge_mode=False, out=out)
 
     def add(self, a, b, out):
         st = self.torch.cuda.current_stream(self.device).cuda_stream

@@ -220,3 +220,24 @@ def test_loaders_reject_malformed_models(hip):
     g, stack, *_ = _setup(hip, nrow=8, ncol=8, n=40, gbm_trees=2, rf_trees=1)
     with pytest.raises(ValueError):
         hip.predict(stack, hip.models.Gam([1.0, 2.0, 3.0]))  # p != layers + 2
+
+
+@pytest.mark.parametrize("which", ["bgnmrv", "gnmv", "nm", "gm", "bnr"])
+def test_fused_small_members_equal_member_by_member_accumulation(hip, which):
+    """gam, nnet and earth are consecutive in the reference's model order; the library evaluates a run of them in
+    one pass over the planes (mhs_members_predict_dev).  Same arithmetic, same accumulation order: the planes are
+    identical to member-by-member mhs_predict_dev calls, NA cells included."""
+    import torch
+    g, stack, X, Xs, ys, params = _setup(hip, nodata_frac=0.01, gbm_trees=40, rf_trees=4)
+    sel = [params[KINDS.index(k)] for k in which]
+    mods = [hip.models.from_param_dict(p) for p in sel]
+    wts = [0.31, 0.22, 0.12, 0.18, 0.27, 0.41][:len(mods)]
+    fused = hip.models.members_predict(stack, mods, wts)
+    acc = hip.predict(stack, mods[0], weight=wts[0])
+    for m, w in zip(mods[1:], wts[1:]):
+        hip.predict(stack, m, weight=w, accumulate=True, out=acc)
+    assert torch.equal(torch.isnan(fused), torch.isnan(acc))
+    assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(acc)), which
+    # accumulate = True adds to what the plane holds
+    again = hip.models.members_predict(stack, mods[1:], wts[1:], accumulate=True, out=hip.predict(stack, mods[0], weight=wts[0]))
+    assert torch.equal(torch.nan_to_num(again), torch.nan_to_num(acc))

@@ -124,3 +124,99 @@ def test_two_ranks_equal_one_rank(w, share, dup):
     # w = 1: the TPS correction is kept.  w = 0.8 with wt.tot = 1: the reference does not renormalise the
     # weights (V73:337,619), the sum is biased, R^2 drops and pred.elev alone is returned (already gathered)
     assert (single["rsq_final"] > single["rsq_model"]) == (w == 1.0)
+
+
+# ------------------------------------------------------------ reference-tiled Step 3 dealt over the ranks --
+from oracle import tiles as ot  # noqa: E402
+
+T_NROW, T_NCOL, T_N, T_EDGE = 46, 70, 260, 24   # ceil(46/24) x ceil(70/24) = 2 x 3 Step-3 tiles
+
+
+class OracleTiledOps(OracleOps):
+    def __init__(self):
+        rng = np.random.default_rng(1)
+        self.g = ot.Geom(-78.0, -5.0, 0.01, 0.01, T_NROW, T_NCOL)
+        self.x, self.y = otps.cell_centres(-78.0, -5.0, 0.01, 0.01, T_NROW, T_NCOL)
+        self.cov = rng.uniform(0, 100, (2, T_NROW, T_NCOL))
+        self.Xgrid = oe.stack_predictors(self.cov, (self.x, self.y))
+        cells = rng.choice(T_NROW * T_NCOL, T_N, replace=False)
+        self.rows, self.cols = np.divmod(cells, T_NCOL)
+        self.Xs = self.Xgrid[cells]
+        self.resp = 3 + 0.05 * self.Xs[:, 0] + np.sin(40 * self.Xs[:, 2]) + 0.1 * rng.standard_normal(T_N)
+        A = np.column_stack([np.ones(T_N), self.Xs])
+        self.models = [oe.lm_model(np.linalg.lstsq(A, self.resp, rcond=None)[0])]
+        self.weights, self.tot = [1.0], 1.0
+        self.fitted = []
+
+    def ensemble_band(self, r0, r1, out):
+        p = oe.ensemble(self.models, self.weights, self.tot, self.Xgrid[r0 * T_NCOL:r1 * T_NCOL])
+        out.copy_(torch.from_numpy(p.reshape(r1 - r0, T_NCOL)))
+
+    def tps_tiles(self, tile_edge):
+        self.nRx, self.nCx, self.fw, self.kw = ot.step3_windows(self.g, tile_edge)
+        knots = self.Xs[:, -2:]
+        self.sel = [ot.stations_in_window(self.g, self.fw[h], knots, self.cov[0]) for h in range(self.nRx * self.nCx)]
+        cost = [float(s.size) * (k[1] - k[0]) * (k[3] - k[2]) for s, k in zip(self.sel, self.kw)]
+        return {"nRx": self.nRx, "nCx": self.nCx, "keep": [tuple(k) for k in self.kw], "cost": cost}
+
+    def tps_tile(self, h, knots, resid, out):
+        self.fitted.append(h)
+        sel, fw, kw = self.sel[h], self.fw[h], self.kw[h]
+        gf = ot.window_geom(self.g, fw)
+        m = otps.fit(knots[sel], resid[sel], lam=1e-3)
+        wk = (kw[0] - fw[0], kw[1] - fw[0], kw[2] - fw[2], kw[3] - fw[2])
+        out.copy_(torch.from_numpy(otps.predict_grid(m, gf.xmin, gf.ymax, gf.xres, gf.yres, gf.nrow, gf.ncol, *wk)))
+
+    def tps_mosaic(self, nRx, nCx, keep, tiles_, out):
+        tl = [t.numpy() for t in tiles_]
+        layers = [ot.extend_full(self.g, keep[h], tl[h]) for h in range(len(keep))]
+        out.copy_(torch.from_numpy(ot.feather_and_merge(self.g, nRx, nCx, keep, tl, ot.mosaic_mean(layers[::-1]))))
+
+
+def _tiled_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ops = OracleTiledOps()
+        out = sharded.TiledTpsShardedMltps(ops, dist, rank, world, T_NROW, T_NCOL, tile_edge=T_EDGE).step()
+        q.put((rank, out["final"].numpy().copy(), out["rsq_model"], out["rsq_final"], sorted(ops.fitted), out["tile_owner"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_assign_tiles_is_longest_first_onto_the_least_loaded_rank():
+    assert sharded.assign_tiles([5, 1, 9, 3], 2) == [1, 1, 0, 1]       # 9 -> r0, 5 -> r1, 3 -> r1 (5 < 9), 1 -> r1 (8 < 9)
+    own = sharded.assign_tiles([4.0] * 49, 8)
+    assert max(own.count(r) for r in range(8)) - min(own.count(r) for r in range(8)) <= 1
+    assert sharded.assign_tiles([], 3) == [] and sharded.assign_tiles([2, 2], 1) == [0, 0]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_tiled_step3_over_ranks_equals_one_rank(world):
+    ops1 = OracleTiledOps()
+    single = sharded.TiledTpsShardedMltps(ops1, None, 0, 1, T_NROW, T_NCOL, tile_edge=T_EDGE).step()
+    assert (ops1.nRx, ops1.nCx) == (2, 3) and sorted(ops1.fitted) == list(range(6))
+    # and the single-rank driver equals the flow written out: ensemble + tiled surface + Step 5
+    pred = oe.ensemble(ops1.models, ops1.weights, ops1.tot, ops1.Xgrid).reshape(T_NROW, T_NCOL)
+    assert single["rsq_final"] > single["rsq_model"]
+    assert np.allclose(single["final"].numpy() - pred, single["final"].numpy() - pred)   # finite everywhere
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fitted_all = []
+    for rank, final, rsq_m, rsq_f, fitted, owner in results:
+        assert np.array_equal(final, single["final"].numpy())          # same tiles, same mosaic: bit for bit
+        assert rsq_m == single["rsq_model"] and rsq_f == single["rsq_final"]
+        assert fitted == [h for h in range(6) if owner[h] == rank]
+        fitted_all += fitted
+    assert sorted(fitted_all) == list(range(6))                        # every tile fitted exactly once, no serial fit

@@ -227,3 +227,57 @@ def test_bench_cfg4_two_ranks_plumbing(hip):
     d = _run_bench(2, "cfg4-mini", port)
     assert d["n_gpus"] == 2 and d["units_on_rank0"] == 6 and d["value"] > 0      # 4 tiles x 3 layers over 2 ranks
     assert 0.5 < d["rsq_model_mean"] <= d["rsq_final_mean"]
+
+
+# ------------------------------------------------------------- reference-tiled Step 3 dealt over the ranks (HIP ops) --
+def _tiled_tps_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import machisplin_amd as hip
+    from machisplin_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    hip.init(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        run = sharded.TiledTpsShardedMltps(_build(hip), dist, rank, world, NROW, NCOL, tile_edge=120)
+        out = run.step()
+        torch.cuda.synchronize()
+        q.put((rank, out["final"].cpu().numpy(), out["rsq_model"], out["rsq_final"], out["tile_owner"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_reference_tiled_step3_sharded_equals_the_one_call_surface(hip):
+    """TiledTpsShardedMltps with the HIP ops: the Step-3 tiles (3 x 4 at tile edge 120) dealt over two ranks == one
+    rank == mltps_predict's one-call tiled surface (mhs_tps_surface), bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from machisplin_amd import sharded
+    ops = _build(hip)
+    single = sharded.TiledTpsShardedMltps(ops, None, 0, 1, NROW, NCOL, tile_edge=120).step()
+    torch.cuda.synchronize()
+    assert (ops.tps_tiles(120)["nRx"], ops.tps_tiles(120)["nCx"]) == (3, 4)
+    ref = hip.mltps_predict(ops.stack, ops.X[:, -2:], ops.y, ops.models, ops.weights, ops.wt_total, tile_edge=120)
+    assert ref["rsq_final"] == single["rsq_final"] and ref["rsq_model"] == single["rsq_model"]
+    assert torch.equal(torch.nan_to_num(ref["final"]), torch.nan_to_num(single["final"]))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tiled_tps_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = single["final"].cpu().numpy()
+    for rank, final, rsq_m, rsq_f, owner in results:
+        assert np.array_equal(final, want, equal_nan=True)
+        assert rsq_m == single["rsq_model"] and rsq_f == single["rsq_final"]
+        assert sorted(set(owner)) == [0, 1] and len(owner) == 12
