@@ -295,6 +295,14 @@ MHS_API int mhs_gather_cells_dev(const double *plane_dev, int64_t ld, const int6
 MHS_API int mhs_tps_surface(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
                             const double *cov1_at_stations, int64_t tile_edge, double lambda,
                             int gcv_mode, double *out_host, int64_t *tiles_out);
+/* A SUBSET of the Step-3 tiles (V73:690-731), for a driver that deals the tiles over several GPUs (SURVEY.md section 8e,
+ * reference-tiled mode): tile tile_ids[k] (numbering of mhs_step3_tile_windows, row-major from the south-west) is fitted
+ * on the stations of its fit box and evaluated on its keep window into out_dev_ptrs[k] (device, rows x cols of the keep
+ * window, contiguous; all zeros below 10 stations, V73:710-721).  The tiles are fitted side by side on the library's
+ * lanes; blocks until they are done.  Same arithmetic as mhs_tps_surface (bit-identical planes). */
+MHS_API int mhs_tps_tiles_dev(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
+                      const double *cov1_at_stations, int64_t tile_edge, double lambda, int gcv_mode,
+                      const int64_t *tile_ids, int64_t n_ids, double *const *out_dev_ptrs);
 MHS_API int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const double *resid, int64_t n,
                                 const double *cov1_at_stations, int64_t tile_edge, double lambda,
                                 int gcv_mode, double *out_dev, int64_t ld, int64_t *tiles_out,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mhs_tiff_write_f32_dev": (C.c_int, [C.c_char_p, C.POINTER(Grid), _vp, _i64, C.c_double, C.c_int, _vp]),
     "mhs_tfw_read": (C.c_int, [C.c_char_p, _dp]),
     "mhs_tps_surface": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _vp]),
+    "mhs_tps_tiles_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64, _vp]),
     "mhs_tps_surface_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64,
                                       _vp, _vp]),
 }

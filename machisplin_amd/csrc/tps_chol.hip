@@ -289,32 +289,42 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ A, 
 // are numbered block column after block column... (bi, bj), bj <= bi: id = bi (bi + 1) / 2 + bj in row-major order of
 // the triangle; col0_only launches the first block column only (bj = 0, id -> bi).
 constexpr int SY_T = 128, SY_KC = 16, SY_S = SY_T + 16;
-__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ A, int64_t ld, int off, int nt, int col0_only) {
+// General form: the trailing block C starts at row/column `coff` (absolute), X = the K columns from column `xcol` on,
+// rows from `coff` (K = 128: one panel; K = 256: a pair of panels applied in one pass over the tiles -- half the HBM
+// traffic per flop, which is what holds the K = 128 update at 57 % MFMA-busy at n = 20 000).  Tiles (bi, bj),
+// bj <= bi < nt: head = 1 selects block columns [0, ncol) (the look-ahead launch), head = 0 the columns from ncol on.
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ A, int64_t ld, int coff, int xcol, int K,
+                                                           int nt, int ncol, int head) {
     __shared__ __attribute__((aligned(16))) double sI[2][SY_KC * SY_S];
     __shared__ __attribute__((aligned(16))) double sJ[2][SY_KC * SY_S];
     int bi, bj;
-    if (col0_only) { bi = blockIdx.x; bj = 0; }
-    else {
-        // tiles with 1 <= bj <= bi < nt, numbered row-major in that triangle; blocks are dealt to the XCDs round-robin
+    if (head) {      // block columns 0 .. ncol-1, column after column
+        int id = blockIdx.x;
+        bj = 0;
+        while (bj < ncol && id >= nt - bj) { id -= nt - bj; ++bj; }
+        if (bj >= ncol) return;
+        bi = bj + id;
+    } else {
+        // tiles with ncol <= bj <= bi < nt, numbered row-major in that triangle; blocks are dealt to the XCDs round-robin
         // (block b runs on XCD b % 8), so give every XCD a contiguous range of tile rows: its X_I stays in its L2
-        const int total = (nt - 1) * nt / 2;
+        const int nr = nt - ncol, total = nr * (nr + 1) / 2;
         const int per = (total + 7) / 8;
         const int id = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
         if (id >= total) return;
         int r = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
         while ((r + 1) * (r + 2) / 2 <= id) ++r;
         while (r * (r + 1) / 2 > id) --r;
-        bi = r + 1; bj = id - r * (r + 1) / 2 + 1;
+        bi = r + ncol; bj = id - r * (r + 1) / 2 + ncol;
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
-    const double *X = A + (int64_t)off * ld + off + CH_NB;       // X[row][k] at X[row + k * ld]
+    const double *X = A + (int64_t)xcol * ld + coff;             // X[row][k] at X[row + k * ld]
     const double *xI = X + (int64_t)bi * SY_T, *xJ = X + (int64_t)bj * SY_T;
     // The accumulators START as the C tile (its loads are in flight while the first chunk of X is staged) and the
     // X_J operand is negated, so the MFMA chain itself computes C - X_I X_J' and the epilogue is stores only -- no
     // read-modify-write latency at the end of a tile.
     // acc[a][b][r] <-> C[i = bi T + wi + 16 b + l15][j = bj T + wj + 16 a + l4 + 4 r]
-    double *C = A + (int64_t)(off + CH_NB) * ld + off + CH_NB;
+    double *C = A + (int64_t)coff * ld + coff;
     d4 acc[4][4];   // [a: j sub-block][b: i sub-block]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -349,9 +359,10 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
     SY_GLOAD(0);
     SY_SSTORE(0);
     __syncthreads();
-    for (int c = 0; c < CH_NB / SY_KC; ++c) {
+    const int nchunk = K / SY_KC;
+    for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < CH_NB / SY_KC) SY_GLOAD((c + 1) * SY_KC);
+        if (c + 1 < nchunk) SY_GLOAD((c + 1) * SY_KC);
 #pragma unroll
         for (int kk = 0; kk < SY_KC; kk += 4) {
             double fi[4], fj[4];
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[a], fi[b], acc[a][b], 0, 0, 0);
         }
-        if (c + 1 < CH_NB / SY_KC) {
+        if (c + 1 < nchunk) {
             SY_SSTORE(buf ^ 1);
             __syncthreads();
         }
@@ -435,30 +446,67 @@ int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, doubl
         attr_done = true;
     }
     std::vector<hipEvent_t> &pool = L.pool;
-    while ((int)pool.size() < 2 * np + 2) {
+    while ((int)pool.size() < 2 * np + 4) {
         hipEvent_t e;
         MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pool.push_back(e);
     }
-    for (int p = 0; p < np; ++p) {
-        const int j = p * CH_NB, t = m_pad - j - CH_NB, nt = t / CH_NB;
-        double *Tp = work + (size_t)p * 2 * CH_NB * CH_NB;
-        // look-ahead: the diagonal block and the panel solve only touch this panel's columns, which the previous
-        // panel's first update launch (same stream) finished; the REST of that update (stream 2) must be complete
-        // only before this panel's own update reads and writes the trailing tiles
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(DG_THREADS), diag_lds, s, A, ld, off + j, Tp, rhs_dev + j, info_dev);
-        if (t > 0) {
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3((unsigned)(t / TR_ROWS)), dim3(256), 0, s, A, ld, off + j, Tp, rhs_dev + j);
-            if (p > 0) MHS_HIP(hipStreamWaitEvent(s, pool[2 * (p - 1) + 1], 0));
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)nt), dim3(256), 0, s, A, ld, off + j, nt, 1);
-            MHS_HIP(hipEventRecord(pool[2 * p], s));
-            if (nt > 1) {
-                MHS_HIP(hipStreamWaitEvent(s2, pool[2 * p], 0));
-                const int total = (nt - 1) * nt / 2, per = (total + 7) / 8;
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, s2, A, ld, off + j, nt, 0);
-            }
-            MHS_HIP(hipEventRecord(pool[2 * p + 1], s2));
+    // Panels are processed in PAIRS (A, B): A is factorised and solved, its update goes to B's block column only
+    // (K = 128, one column of tiles), B is factorised and solved, and the rest of the trailing matrix receives both
+    // panels in ONE pass over its tiles (K = 256).  Look-ahead as before: the first two block columns of that pass
+    // -- the next pair's own columns -- are launched first on the main stream, the rest on the second stream, and the
+    // next pair's factorisation runs beside it.  MHS_CHOL_K128=1: every panel on its own (K = 128 everywhere).
+    static const bool pairs = getenv("MHS_CHOL_K128") == nullptr;
+    hipEvent_t pending = nullptr;     // the second-stream update the next trailing pass has to wait for
+    auto syrk = [&](int coff, int xcol, int K, int nt, int ncol) -> int {      // trailing block at coff, nt tiles a side
+        if (nt <= 0) return MHS_OK;
+        if (pending) { MHS_HIP(hipStreamWaitEvent(s, pending, 0)); pending = nullptr; }
+        const int nc = std::min(ncol, nt);
+        int head_tiles = 0;
+        for (int c = 0; c < nc; ++c) head_tiles += nt - c;
+        hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)head_tiles), dim3(256), 0, s, A, ld, coff, xcol, K, nt, nc, 1);
+        return MHS_OK;
+    };
+    int nev = 0;
+    auto syrk_rest = [&](int coff, int xcol, int K, int nt, int ncol) -> int {
+        const int nr = nt - ncol;
+        MHS_HIP(hipEventRecord(pool[nev], s));
+        MHS_HIP(hipStreamWaitEvent(s2, pool[nev], 0));
+        ++nev;
+        if (nr > 0) {
+            const int total = nr * (nr + 1) / 2, per = (total + 7) / 8;
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, s2, A, ld, coff, xcol, K, nt, ncol, 0);
         }
+        MHS_HIP(hipEventRecord(pool[nev], s2));
+        pending = pool[nev];
+        ++nev;
+        return MHS_OK;
+    };
+    for (int p = 0; p < np;) {
+        const int jA = p * CH_NB, tA = m_pad - jA - CH_NB;
+        double *TA = work + (size_t)p * 2 * CH_NB * CH_NB;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(DG_THREADS), diag_lds, s, A, ld, off + jA, TA, rhs_dev + jA, info_dev);
+        if (tA <= 0) { ++p; break; }
+        hipLaunchKernelGGL(chol_trsm_kernel, dim3((unsigned)(tA / TR_ROWS)), dim3(256), 0, s, A, ld, off + jA, TA, rhs_dev + jA);
+        const int ntA = tA / CH_NB;
+        if (!pairs || p + 1 >= np) {      // single panel: its own K = 128 pass (head = the next panel's column)
+            if (int rc = syrk(off + jA + CH_NB, off + jA, CH_NB, ntA, 1)) return rc;
+            if (int rc = syrk_rest(off + jA + CH_NB, off + jA, CH_NB, ntA, 1)) return rc;
+            ++p;
+            continue;
+        }
+        // A's update of B's block column only
+        if (int rc = syrk(off + jA + CH_NB, off + jA, CH_NB, ntA, 1)) return rc;
+        const int jB = jA + CH_NB, tB = tA - CH_NB;
+        double *TB = work + (size_t)(p + 1) * 2 * CH_NB * CH_NB;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(DG_THREADS), diag_lds, s, A, ld, off + jB, TB, rhs_dev + jB, info_dev);
+        if (tB > 0) {
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((unsigned)(tB / TR_ROWS)), dim3(256), 0, s, A, ld, off + jB, TB, rhs_dev + jB);
+            const int ntB = tB / CH_NB;
+            if (int rc = syrk(off + jB + CH_NB, off + jA, 2 * CH_NB, ntB, 2)) return rc;
+            if (int rc = syrk_rest(off + jB + CH_NB, off + jA, 2 * CH_NB, ntB, 2)) return rc;
+        }
+        p += 2;
     }
     // back substitution
     for (int p = np - 1; p >= 0; --p) {

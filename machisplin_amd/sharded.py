@@ -207,8 +207,11 @@ class TiledTpsShardedMltps:
         if nb > 0:
             ops.ensemble_band(self.r0, self.r1, self.mine[:nb * self.ncol].view(nb, self.ncol))
         knots, resid, resp, rows, cols = ops.station_residuals()
-        for h in range(len(self.keep)):
-            if self.owner[h] == self.rank:
+        mine = [h for h in range(len(self.keep)) if self.owner[h] == self.rank]
+        if hasattr(ops, "tps_tiles_batch"):      # the library fits a rank's tiles side by side on its lanes
+            ops.tps_tiles_batch(mine, knots, resid, [self._tile_view(self.mine, 0, h) for h in mine])
+        else:
+            for h in mine:
                 ops.tps_tile(h, knots, resid, self._tile_view(self.mine, 0, h))
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.full, self.mine)      # the one exchange: bands + tile planes
@@ -324,7 +327,7 @@ class HipOps:
             self._tile_sel.append(sel)
             kr0, kr1, kc0, kc1 = (int(v) for v in keep[h])
             cost.append(float(sel.size) * (kr1 - kr0) * (kc1 - kc0) + float(sel.size) ** 3)
-        self._tile_fit, self._tile_keep = fit, keep
+        self._tile_fit, self._tile_keep, self._tile_edge = fit, keep, tile_edge
         return {"nRx": int(nRx), "nCx": int(nCx), "keep": [tuple(int(v) for v in w) for w in keep], "cost": cost}
 
     def tps_tile(self, h, knots, resid, out):
@@ -338,6 +341,25 @@ class HipOps:
         fit = Tps(knots[sel], resid[sel], lambda_=self.lambda_, gcv_mode=self.gcv_mode)
         gf = self.stack.geom.window(fr0, fr1, fc0, fc1)     # terra::rast(rb): geometry of the fit raster
         interpolate(gf, fit, window=(kr0 - fr0, kr1 - fr0, kc0 - fc0, kc1 - fc0), out=out)
+
+    def tps_tiles_batch(self, hs, knots, resid, outs):
+        """This rank's tiles in ONE library call (mhs_tps_tiles_dev: up to 8 fits side by side)."""
+        import ctypes as C
+        import time
+        if not hs:
+            return
+        t0 = time.perf_counter()
+        g = self.stack.geom.c_struct()
+        xyf = np.asfortranarray(np.asarray(knots, dtype=np.float64))
+        res = np.ascontiguousarray(resid, dtype=np.float64)
+        cov = np.ascontiguousarray(self.X[:, 0], dtype=np.float64)
+        ids = np.ascontiguousarray(hs, dtype=np.int64)
+        ptrs = (C.c_void_p * len(hs))(*[o.data_ptr() for o in outs])
+        mode = {"fields": self._lib.GCV_FIELDS, "converged": self._lib.GCV_CONVERGED}[self.gcv_mode]
+        self._lib.check(self._lib.lib().mhs_tps_tiles_dev(C.byref(g), xyf.ctypes.data, res.ctypes.data, res.shape[0], cov.ctypes.data,
+                                                          int(self._tile_edge), float("nan") if self.lambda_ is None else float(self.lambda_),
+                                                          mode, ids.ctypes.data, len(hs), ptrs))
+        self.timings.setdefault("tps_tiles_ms", []).append((time.perf_counter() - t0) * 1e3)
 
     def tps_mosaic(self, nRx, nCx, keep, tiles_, out):
         from . import tiles
