@@ -289,6 +289,10 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ A, 
 // are numbered block column after block column... (bi, bj), bj <= bi: id = bi (bi + 1) / 2 + bj in row-major order of
 // the triangle; col0_only launches the first block column only (bj = 0, id -> bi).
 constexpr int SY_T = 128, SY_KC = 16, SY_S = SY_T + 16;
+#ifndef SY_BAND_V
+#define SY_BAND_V 16
+#endif
+constexpr int SY_BAND = SY_BAND_V;   // tile rows per band of the update's tile order
 // General form: the trailing block C starts at row/column `coff` (absolute), X = the K columns from column `xcol` on,
 // rows from `coff` (K = 128: one panel; K = 256: a pair of panels applied in one pass over the tiles -- half the HBM
 // traffic per flop, which is what holds the K = 128 update at 57 % MFMA-busy at n = 20 000).  Tiles (bi, bj),
@@ -307,14 +311,30 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
     } else {
         // tiles with ncol <= bj <= bi < nt, numbered row-major in that triangle; blocks are dealt to the XCDs round-robin
         // (block b runs on XCD b % 8), so give every XCD a contiguous range of tile rows: its X_I stays in its L2
+        // Order within the triangle: BANDS of SY_BAND tile rows, inside a band column after column, inside a column
+        // the band's rows.  The blocks of one XCD (a contiguous range of this order) then work on ~SY_BAND tiles that
+        // share one X_J chunk while the band's X_I chunks stay in the XCD's L2 -- in plain row-major order every tile
+        // row streamed all of X_J again (one 128 KB chunk per tile: as many bytes as the C tiles themselves).
         const int nr = nt - ncol, total = nr * (nr + 1) / 2;
         const int per = (total + 7) / 8;
-        const int id = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+        int id = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
         if (id >= total) return;
-        int r = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= id) ++r;
-        while (r * (r + 1) / 2 > id) --r;
-        bi = r + ncol; bj = id - r * (r + 1) / 2 + ncol;
+        int a0 = 0, h = 0;
+        for (;; a0 += SY_BAND) {
+            h = min(SY_BAND, nr - a0);
+            const int cnt = a0 * h + h * (h + 1) / 2;
+            if (id < cnt) break;
+            id -= cnt;
+        }
+        int r, c;
+        if (id < a0 * h) { c = id / h; r = a0 + id % h; }
+        else {
+            id -= a0 * h;
+            int q = 0;
+            while (id >= h - q) { id -= h - q; ++q; }
+            c = a0 + q; r = c + id;
+        }
+        bi = r + ncol; bj = c + ncol;
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
