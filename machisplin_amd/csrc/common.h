@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "machisplin_hip.h"
@@ -111,6 +112,9 @@ struct mhs_tps {
         double *lx_dev = nullptr, *ly_dev = nullptr;  // interpolation matrices, tx x 16 and ty x 16
         size_t nodes_cap = 0, bins_cap = 0, lx_cap = 0, ly_cap = 0;
         bool last_used = false;                 // the last grid evaluation took this path
+        hipStream_t last_stream = nullptr;      // stream of the last far-field evaluation (its kernels read the buffers above)
+        bool in_flight = false;                 // ... which may still be running
         int64_t node_pairs = 0, cell_pairs = 0; // (node, far knot) and (cell, near knot) kernel evaluations
     } far;
+    std::mutex mu;   // grid evaluations of one handle from several host threads: the plan is rebuilt under it
 };

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ A, 
     } while (0)
     TR_GLOAD(0);
     TR_SSTORE(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see chol_syrk_kernel
     __syncthreads();
     for (int c = 0; c < CH_NB / TR_KC; ++c) {
         const int buf = c & 1, k0 = c * TR_KC;
@@ -378,6 +379,10 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double *__restrict__ 
     } while (0)
     SY_GLOAD(0);
     SY_SSTORE(0);
+    // every prologue load (the C tile in the accumulators) retired BEFORE the loop: otherwise the compiler carries
+    // "accumulator load pending" into the loop and plants s_waitcnt vmcnt(3..0) beside the first MFMAs of every
+    // iteration -- where, in steady state, they wait for the chunk loads issued a moment earlier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
     const int nchunk = K / SY_KC;
     for (int c = 0; c < nchunk; ++c) {

@@ -331,6 +331,9 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
     const bool same = P.sorted_dev && P.xmin == e.xmin && P.ymax == e.ymax && P.xres == e.xres && P.yres == e.yres &&
                       P.r0 == e.r0 && P.r1 == r1 && P.c0 == e.c0 && P.c1 == c1 && P.tx == btx && P.ty == bty;
     if (same) return MHS_OK;
+    // The plan's device buffers are about to be rewritten (blocking copies on the null stream): kernels of the previous
+    // evaluation, enqueued on a caller's non-blocking stream, may still be reading them.
+    if (P.in_flight) { MHS_HIP(hipStreamSynchronize(P.last_stream)); P.in_flight = false; }
     // counting sort of the knots by bin; bins beyond FF_PAD tiles outside the window collapse onto the rim
     const int nbx = f->ntx + 2 * FF_PAD, nby = f->nty + 2 * FF_PAD;
     std::vector<int> bin((size_t)N), start((size_t)nbx * nby + 1, 0);
@@ -465,9 +468,16 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
     const EvalGeom e = make_geom(t, g, r0, r1, c0, c1, ld);
     FarGeom f;
     bool far = false;
-    if (int rc = plan_far(const_cast<mhs_tps *>(t), g, e, r1, c1, &f, &far)) return rc;
-    const_cast<mhs_tps *>(t)->far.last_used = far;
+    mhs_tps *tm = const_cast<mhs_tps *>(t);
+    std::lock_guard<std::mutex> lk(tm->mu);
+    if (int rc = plan_far(tm, g, e, r1, c1, &f, &far)) return rc;
+    tm->far.last_used = far;
     if (far) {
+        mhs_tps::FarPlan &Pm = tm->far;
+        // the node values are scratch of ONE evaluation: another stream must not start on them before the last one is done
+        if (Pm.in_flight && Pm.last_stream != pick_stream(stream)) MHS_HIP(hipStreamSynchronize(Pm.last_stream));
+        Pm.last_stream = pick_stream(stream);
+        Pm.in_flight = true;
         const mhs_tps::FarPlan &P = t->far;
         const int ntiles = f.ntx * f.nty;
         dim3 cgrid((unsigned)(f.ntx * (f.tx / 64)), (unsigned)(f.nty * (f.ty / EVAL_TILE_ROWS)));

@@ -1271,6 +1271,7 @@ __global__ __launch_bounds__(256, 2) void band_rankk_kernel(double *__restrict__
     }
     RK_GLOAD(0)
     RK_SSTORE(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prologue load (the C tile) pending into the loop, see chol_syrk_kernel
     __syncthreads();
     for (int c = 0; c < DG_K / RK_KC; ++c) {
         const int buf = c & 1;
