@@ -45,6 +45,64 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ u,
     }
 }
 
+// The null-space projection A <- Q'KQ, Q = H1 H2 H3 = I - V T V' (the three reflectors of the QR of [1 u v]), WITHOUT
+// ever storing K: Q'KQ = K - W V' - V W' with W = Y T - 1/2 V S, Y = K V, S = T'(V'Y)T.  Pass 1 forms Y from kernel
+// entries computed on the fly (row blocks x column splits, partial sums); the host turns Y into W (3 columns); pass 2
+// computes the entries again and writes the projected matrix directly.  Two passes of n^2 logs and ONE write of the
+// matrix instead of a write and three read-modify-write passes (memory-bound: 7.8 -> 2.5 ms at n = 20 000).
+constexpr int GY_MAXSPLIT = 16;
+__global__ __launch_bounds__(256) void gram_y_kernel(const double *__restrict__ u, const double *__restrict__ v,
+                                                     const double *__restrict__ sw, int n, const double *__restrict__ V3,
+                                                     const double2 *__restrict__ gtab, double *__restrict__ Ypart /* [split][3][n] */) {
+    __shared__ double2 tab[LOG_TAB_N];
+    __shared__ double red[4][3][64];
+    stage_log_table(tab, gtab);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int per = ((n + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3;
+    const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+    const bool ok = i < n;
+    const int ii = ok ? i : 0;
+    const double ui = u[ii], vi = v[ii], si = sw[ii] * (0.5 / (8.0 * M_PI));
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    for (int j = j0 + wave; j < j1; j += 4) {
+        const double dx = ui - u[j], dy = vi - v[j];
+        const double d2 = fma(dy, dy, dx * dx);
+        const double k = si * sw[j] * r2logr2(d2, tab);
+        y0 = fma(k, V3[j], y0); y1 = fma(k, V3[n + j], y1); y2 = fma(k, V3[2 * (int64_t)n + j], y2);
+    }
+    red[wave][0][lane] = y0; red[wave][1][lane] = y1; red[wave][2][lane] = y2;
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int a = threadIdx.x >> 6;
+        const double t = (red[0][a][lane] + red[1][a][lane]) + (red[2][a][lane] + red[3][a][lane]);
+        if (ok) Ypart[((int64_t)blockIdx.y * 3 + a) * n + i] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_proj_kernel(const double *__restrict__ u, const double *__restrict__ v,
+                                                        const double *__restrict__ sw, int n, int64_t ld,
+                                                        const double2 *__restrict__ gtab, const double *__restrict__ V3,
+                                                        const double *__restrict__ W3, double *__restrict__ A) {
+    __shared__ double2 tab[LOG_TAB_N];
+    stage_log_table(tab, gtab);
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+    if (i >= n) return;
+    const double ui = u[i], vi = v[i], si = sw[i] * (0.5 / (8.0 * M_PI));
+    const double v0 = V3[i], v1 = V3[n + i], v2 = V3[2 * (int64_t)n + i];
+    const double w0 = W3[i], w1 = W3[n + i], w2 = W3[2 * (int64_t)n + i];
+    for (int j = j0; j < j0 + 16 && j < n; ++j) {
+        const double dx = ui - u[j], dy = vi - v[j];
+        const double d2 = fma(dy, dy, dx * dx);
+        double a = si * sw[j] * r2logr2(d2, tab);
+        a -= w0 * V3[j] + v0 * W3[j];
+        a -= w1 * V3[n + j] + v1 * W3[n + j];
+        a -= w2 * V3[2 * (int64_t)n + j] + v2 * W3[2 * (int64_t)n + j];
+        A[i + (int64_t)j * ld] = a;
+    }
+}
+
 // --------------------------------------------- two-sided Householder machinery --
 // p = A_sub v  (A_sub = A[off:off+t, off:off+t], symmetric full storage): one wave per row
 __global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ A, int64_t ld, int off,
@@ -1875,7 +1933,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
-    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp;
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp, v3buf, w3buf, ypbuf;
     const bool fixed = !std::isnan(lambda);
     int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme (MHS_DELAY_T overrides)
     if (const char *e = getenv("MHS_DELAY_T")) t_delay = std::max(BW, atoi(e));
@@ -1887,6 +1945,9 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (A.p) A.p += 1;
         duv.p = ar.take<double>((size_t)(2 * n));
         dsw.p = ar.take<double>((size_t)n);
+        v3buf.p = ar.take<double>(3 * (size_t)n);
+        w3buf.p = ar.take<double>(3 * (size_t)n);
+        ypbuf.p = ar.take<double>((size_t)GY_MAXSPLIT * 3 * n);
         vbuf.p = ar.take<double>((size_t)n);
         pbuf.p = ar.take<double>((size_t)n);
         wbuf.p = ar.take<double>((size_t)n);
@@ -1923,19 +1984,62 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     MHS_HIP(hipMemcpyAsync(duv.p, uv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(dsw.p, sw.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
 
-    {
+    static const bool fused_proj = getenv("MHS_PROJ_PASSES") == nullptr;
+    if (fused_proj) {
+        // A = Q'KQ = K - W V' - V W' in two passes over kernel entries computed on the fly (see gram_y_kernel)
+        for (int k = 0; k < 3; ++k)
+            MHS_HIP(hipMemcpyAsync(v3buf.p + (size_t)k * n, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        const unsigned rb = (unsigned)((n + 63) / 64);
+        const unsigned nsp = (unsigned)std::min<int64_t>(GY_MAXSPLIT, std::max<int64_t>(1, (1024 + rb - 1) / rb));
+        hipLaunchKernelGGL(gram_y_kernel, dim3(rb, nsp), dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, v3buf.p, ctx().log_tab, ypbuf.p);
+        MHS_HIP(hipGetLastError());
+        std::vector<double> Yp((size_t)nsp * 3 * n), Y(3 * (size_t)n, 0.0), W(3 * (size_t)n);
+        MHS_HIP(hipMemcpyAsync(Yp.data(), ypbuf.p, sizeof(double) * Yp.size(), hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipStreamSynchronize(s));
+        for (unsigned sp = 0; sp < nsp; ++sp)
+            for (size_t e = 0; e < 3 * (size_t)n; ++e) Y[e] += Yp[(size_t)sp * 3 * n + e];
+        double G[3][3], Tm3[3][3] = {{0}}, M3[3][3], S3[3][3], TM[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double g = 0.0, mm = 0.0;
+                for (int64_t i = 0; i < n; ++i) { g += hv[a][i] * hv[b][i]; mm += hv[a][i] * Y[(size_t)b * n + i]; }
+                G[a][b] = g; M3[a][b] = mm;
+            }
+        for (int j = 0; j < 3; ++j) {      // larft (forward, columnwise): Q = H1 H2 H3 = I - V T V'
+            Tm3[j][j] = htau[j];
+            for (int i = 0; i < j; ++i) {
+                double sum = 0.0;
+                for (int l = i; l < j; ++l) sum += Tm3[i][l] * G[l][j];
+                Tm3[i][j] = -htau[j] * sum;
+            }
+        }
+        for (int a = 0; a < 3; ++a)        // S = T' (1/2 (M + M')) T
+            for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += 0.5 * (M3[a][c] + M3[c][a]) * Tm3[c][b]; TM[a][b] = t; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += Tm3[c][a] * TM[c][b]; S3[a][b] = t; }
+        for (int64_t i = 0; i < n; ++i)
+            for (int b = 0; b < 3; ++b) {
+                double t = 0.0;
+                for (int c = 0; c < 3; ++c) t += Y[(size_t)c * n + i] * Tm3[c][b] - 0.5 * hv[c][i] * 0.5 * (S3[c][b] + S3[b][c]);
+                W[(size_t)b * n + i] = t;
+            }
+        MHS_HIP(hipMemcpyAsync(w3buf.p, W.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+        hipLaunchKernelGGL(gram_proj_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld, ctx().log_tab, v3buf.p, w3buf.p, A.p);
+        MHS_HIP(hipGetLastError());
+        MHS_HIP(hipStreamSynchronize(s));      // W (host vector) is read by the copy above
+    } else {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
         hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld,
                            ctx().log_tab, A.p);
-    }
-    // A <- H3 H2 H1 A H1 H2 H3 (full-length reflectors, leading zeros)
-    MHS_HIP(hipMemcpyAsync(tau.p + n, htau, sizeof(double) * 3, hipMemcpyHostToDevice, s));
-    for (int k = 0; k < 3; ++k) {
-        MHS_HIP(hipMemcpyAsync(vbuf.p, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, pbuf.p);
-        hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
-        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
-        hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
+        // A <- H3 H2 H1 A H1 H2 H3 (full-length reflectors, leading zeros)
+        MHS_HIP(hipMemcpyAsync(tau.p + n, htau, sizeof(double) * 3, hipMemcpyHostToDevice, s));
+        for (int k = 0; k < 3; ++k) {
+            MHS_HIP(hipMemcpyAsync(vbuf.p, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, pbuf.p);
+            hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
+            hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
+        }
     }
     MHS_HIP(hipGetLastError());
     lap("gram + projection");
