@@ -197,7 +197,10 @@ class Workload:
                 # each tree's full depth (terminals self-loop); the HBM view is what the JSON contract can express
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
                 lds_bytes = band_cells * float(self.rf_level_sum()) * 12.0
-                rows.append({"kernel": "rf_walk_db_kernel", "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                prm = next(p for p in self.params if p["kind"] == "rf")
+                big = int(np.diff(prm["tree_offsets"]).max()) > 4095      # launch_model's choice (ensemble.hip, case K_RF)
+                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_db_kernel", "bound": "hbm", "launch_ms": ms,
+                             "achieved": by / ms / 1e6,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view; the walk itself is LDS-bound: "
                                      "%.0f node visits/cell, %.3g visits/s)" % (self.cfg["layers"], self.mean_visits[k],

@@ -96,7 +96,12 @@ struct mhs_model {
     std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
     int rf_max_nodes = 0;
     int rf_log2r = -1;                       // walks per lane rf_nodes were built for
-    bool rf_big = false;                     // ... and whether in the BIG form (node indices, predictions in global memory)
+    int rf_form = 0;                         // ... and in which form: RF_SMALL (16-bit byte addresses, predictions in LDS),
+                                             // RF_BIG (node indices, predictions in global memory), RF_COMPACT (split nodes only)
+    std::vector<int> rf_off;                 // host, n_trees + 1 node offsets
+    int *rf_coff = nullptr;                  // device, n_trees + 1 record offsets of the COMPACT form
+    int rf_cmax = 0;                         // COMPACT: most records in a tree (its split nodes + 1)
+    int rf_compact_ok = 0;                   // every tree's leaf codes fit 16 bits (8 * splits + nodes <= 65535)
 };
 
 namespace mhs {
@@ -511,7 +516,7 @@ __device__ __forceinline__ void lut_ranks_t(const int j, const KT *__restrict__ 
     const int stride = (n + COARSE_N - 1) / COARSE_N;
     const int nc = stride ? (n + stride - 1) / stride : 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < nc; e += NT) coarse[e] = T[(int64_t)e * stride];
+    for (int e = threadIdx.x; e < nc; e += (NT ? NT : (int)blockDim.x)) coarse[e] = T[(int64_t)e * stride];
     __syncthreads();
     KT k[LUT_R];
     int lo[LUT_R], cnt[LUT_R];
@@ -849,6 +854,103 @@ __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__
     }
 }
 
+// TREE-MAJOR form for BIG trees (a 20 000-station forest: ~12 000 nodes = 96 KB per tree).  In rf_walk_kernel<BIG> every
+// block stages every tree for ONE batch of 2 048 cells -- all 16 waves idle while 96 KB travel global -> LDS between two
+// barriers, 500 times per block -- and staging is as long as the walk.  Here a block keeps a staged tree for NB batches
+// of cells: the -rank keys of every batch live in REGISTERS (the walk needs them in LDS, indexed by the node's
+// predictor, so the lane copies the batch's P * R keys into its private LDS slots before walking it -- 28 writes
+// against ~140 reads of the walk), 512 threads x R = 4 independent walks x NB = 4 batches = 8 192 cells per block and
+// staging, and the node predictions (global memory) are requested after each batch's walk and added after the last.
+template <int NB, int P, bool K64>
+__global__ __launch_bounds__(512) void rf_walk_tm_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
+                                                         const int *__restrict__ tree_off, const int *__restrict__ depth,
+                                                         const void *__restrict__ sorted, const int *__restrict__ sorted_off,
+                                                         int n_trees, int max_nodes, StackDev s, PredGeom g, double weight,
+                                                         int accumulate, double *__restrict__ out) {
+    constexpr int R = 4, KPB = P * R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2 *lnodes = (uint2 *)smem;                                 // [max_nodes], node index -> record
+    const unsigned tree_bytes = max((unsigned)max_nodes * 8u, (unsigned)RF_COARSE_BYTES);
+    float *coarse = (float *)smem;
+    const unsigned stride = (unsigned)KPB | 1u;
+    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t base = (int64_t)blockIdx.x * (512 * R * NB);
+    unsigned kreg[NB][KPB];
+    double acc[NB][R];
+    bool na[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int row[R], col[R];
+        bool nab[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            int64_t i = base + (int64_t)(b * R + c) * 512 + threadIdx.x;
+            if (i >= total) i = total - 1;
+            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+            nab[c] = false; acc[b][c] = 0.0;
+        }
+        // the rank code is instantiated once per batch (not once per batch and predictor): the ranks pass through the
+        // lane's private LDS slots, which take a run-time predictor index, on their way to the statically indexed kreg
+#pragma unroll 1
+        for (int j = 0; j < P; ++j) {
+            float r[R];
+            if constexpr (K64) lut_ranks_t<R, 512, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, nab, r);
+            else lut_ranks_t<R, 512, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, nab, r);
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+                *(__attribute__((address_space(3))) unsigned *)(uintptr_t)(lane_base + 4u * (unsigned)(j * R + c)) = (unsigned)r[c] << 8;
+        }
+#pragma unroll
+        for (int k = 0; k < KPB; ++k) kreg[b][k] = lds_u32(lane_base + 4u * k);
+#pragma unroll
+        for (int c = 0; c < R; ++c) na[b][c] = nab[c];
+    }
+    for (int t = 0; t < n_trees; ++t) {
+        const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += 512) lnodes[e] = gnodes[o + e];
+        __syncthreads();
+        double pend[NB][R];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int k = 0; k < KPB; ++k) *(__attribute__((address_space(3))) unsigned *)(uintptr_t)(lane_base + 4u * k) = kreg[b][k];
+            unsigned node[R];
+#pragma unroll
+            for (int c = 0; c < R; ++c) node[c] = 0u;
+            for (int l = 0; l < levels; ++l) {
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const uint2v nd = lds_u2(node[c] << 3);
+                    const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                    asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                        : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < R; ++c) pend[b][c] = glval[o + (int)node[c]];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int c = 0; c < R; ++c) acc[b][c] = acc[b][c] + pend[b][c];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int64_t i = base + (int64_t)(b * R + c) * 512 + threadIdx.x;
+            if (i < total) {
+                const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+                emit(out, (int64_t)row * g.ld_out + col, na[b][c] ? NAN : acc[b][c] / (double)n_trees, weight, accumulate);
+            }
+        }
+}
+
 // Double-buffered form for trees of up to 4095 nodes (two buffers stay within the 16-bit child addresses): the
 // next tree travels global -> registers -> the other LDS buffer WHILE this one is walked, the node predictions are
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
@@ -943,6 +1045,116 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         }
         __syncthreads();
         o = o1; o1 = o2; o2 = o3;
+        levels = levels1; levels1 = levels2;
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        const int64_t i = i0 + c * part;
+        if (i0 < part && i < total)
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+
+// COMPACT form for trees beyond the double-buffered kernel's 4 095 nodes (a 20 000-station forest: ~12 000 nodes per
+// tree).  Half of a tree's nodes are terminals, which the walk never needs to READ -- it only has to remember which one
+// it reached.  LDS holds the records of the split nodes alone plus one all-zero record at byte address D = 8 * splits
+// (build_rf_nodes_t, RF_COMPACT): ~49 KB instead of 97 KB for such a tree, which leaves room for the keys of
+// 4 cells x 960 lanes (15 waves; the BIG form fits 2 x 1024 or 4 x 512 -- half the walks in flight, and this loop
+// is bound by the latency of its two dependent LDS reads).  A lane's state is the byte address of a split node's
+// record or, once it has reached a terminal, D + that node's index:
+//       rec = LDS[min(state, D)];  child = key > rec.rank ? rec.right : rec.left;  state = max(child, state)
+// (children follow their parent in randomForest's numbering and every terminal code is >= D, so max() leaves a split
+// node's state to its child and a terminal's state alone: the all-zero record's children are 0).  The next tree's
+// records travel global -> registers during the walk (PF x 8 bytes per thread) and registers -> LDS between two
+// barriers after it, so staging costs the block one LDS write pass per tree instead of a round trip to L2.
+template <int PF, bool K64>
+__global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
+                                                               const int *__restrict__ tree_off, const int *__restrict__ coff,
+                                                               const int *__restrict__ depth, const void *__restrict__ sorted,
+                                                               const int *__restrict__ sorted_off, int n_trees, int cmax, int p,
+                                                               StackDev s, PredGeom g, double weight, int accumulate,
+                                                               double *__restrict__ out) {
+    constexpr int R = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned nt = blockDim.x;
+    const unsigned tree_bytes = max((unsigned)cmax * 8u, (unsigned)RF_COARSE_BYTES);
+    float *coarse = (float *)smem;
+    const unsigned stride = (unsigned)(p * R) | 1u;
+    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * nt + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R], pending[R];
+    unsigned node[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * part;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
+    }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        if constexpr (K64) lut_ranks_t<R, 0, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 0, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    __syncthreads();                                               // coarse table no longer needed
+    {
+        const int o = coff[0], cnt = coff[1] - o;
+        for (int e = threadIdx.x; e < cnt; e += (int)nt) ((uint2 *)smem)[e] = gnodes[o + e];
+    }
+    __syncthreads();
+    // scalars of the trees ahead are fetched early, as in rf_walk_db_kernel
+    int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
+    int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
+    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+    for (int t = 0; t < n_trees; ++t) {
+        const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
+        const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
+        const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
+        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+        const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
+        uint2 pn[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = (int)threadIdx.x + q * (int)nt;
+            if (e < cnt1) pn[q] = gnodes[c1 + e];
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = 0u;
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const uint2v nd = lds_u2(min(node[c], D));
+                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                unsigned child;
+                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                    : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                node[c] = max(child, node[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            pending[c] = glval[o + (int)(node[c] - D)];
+        }
+        __syncthreads();                                           // every wave has left this tree
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = (int)threadIdx.x + q * (int)nt;
+            if (e < cnt1) *(uint2 *)(smem + (unsigned)e * 8u) = pn[q];
+        }
+        __syncthreads();
+        o = o1; o1 = o2;
+        c0 = c1; c1 = c2; c2 = c3;
         levels = levels1; levels1 = levels2;
     }
 #pragma unroll
@@ -1158,8 +1370,10 @@ static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64
            o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol;
 }
 
+enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomForest node records (build_rf_nodes_t)
+
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
-struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; };
+struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff; };
 
 // fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
 template <typename T>
@@ -1294,7 +1508,8 @@ static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
 
 // key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry and key type
 template <typename KT>
-static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big) {
+static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r, int form) {
+    const bool big = form == RF_BIG;
     const size_t nn = m->rf_thr.size();
     std::vector<KT> tkey(nn, (KT)0);
     std::vector<std::vector<KT>> sorted((size_t)m->p);
@@ -1312,6 +1527,34 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
     std::vector<unsigned long long> rec(nn ? nn : 1, 0ull);
     const unsigned R = 1u << log2r;
+    if (form == RF_COMPACT) {
+        // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
+        // A child field holds the LDS byte address of a split child's record or, for a terminal child, D + its node
+        // index: the walk reads record min(state, D), picks the child field and keeps max(child, state) -- a split
+        // node's children come after it and every terminal code is >= D, so a terminal state stays what it is.
+        rec.clear();
+        std::vector<int> coff(1, 0), newid;
+        for (int t = 0; t < m->n_trees; ++t) {
+            const int o = m->rf_off[(size_t)t], cnt = m->rf_off[(size_t)t + 1] - o;
+            newid.assign((size_t)cnt, 0);
+            unsigned splits = 0;
+            for (int k = 0; k < cnt; ++k) if (m->rf_var[(size_t)(o + k)] != 0xFFFFu) newid[(size_t)k] = (int)splits++;
+            const unsigned D = 8u * splits;
+            auto code = [&](unsigned k) { return m->rf_var[(size_t)o + k] != 0xFFFFu ? 8u * (unsigned)newid[k] : D + k; };
+            for (int k = 0; k < cnt; ++k) {
+                const unsigned v = m->rf_var[(size_t)(o + k)];
+                if (v == 0xFFFFu) continue;
+                const std::vector<KT> &sv = sorted[(size_t)v];
+                const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[(size_t)(o + k)]) - sv.begin());
+                const unsigned left = m->rf_left[(size_t)(o + k)];
+                const unsigned children = code(left) | (code(left + 1u) << 16);
+                rec.push_back(((unsigned long long)children << 32) | ((j << 8) | (v * R * 4u)));
+            }
+            rec.push_back(0ull);
+            coff.push_back((int)rec.size());
+        }
+        if (int rc = publish(m, coff, &m->rf_coff)) return rc;
+    } else
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
         const unsigned left = m->rf_left[k];   // node index within the tree (terminal: its own index)
@@ -1331,22 +1574,38 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     return publish(m, rec, &m->rf_nodes);
 }
 
-static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, bool big, int key64, TreeTables *tt) {
+static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, int form, int key64, TreeTables *tt) {
     std::lock_guard<std::mutex> lk(m->mu);
-    if (!(m->rf_nodes && m->rf_log2r == log2r && m->rf_big == big && same_meta(m, grid, C, key64))) {
-        if (int rc = key64 ? build_rf_nodes_t<double>(m, grid, C, log2r, big) : build_rf_nodes_t<float>(m, grid, C, log2r, big)) return rc;
+    if (!(m->rf_nodes && m->rf_log2r == log2r && m->rf_form == form && same_meta(m, grid, C, key64))) {
+        if (int rc = key64 ? build_rf_nodes_t<double>(m, grid, C, log2r, form) : build_rf_nodes_t<float>(m, grid, C, log2r, form)) return rc;
         m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
-        m->rf_log2r = log2r; m->rf_big = big;
+        m->rf_log2r = log2r; m->rf_form = form;
     }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes};
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes, form == RF_COMPACT ? m->rf_coff : nullptr};
     return MHS_OK;
 }
 
 static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
                           double w, int acc, double *out, hipStream_t st, int64_t total, int log2r, bool big) {
     const int key64 = s.dtype == MHS_F64;
+    if (big && m->p >= 5 && m->p <= 8 && !getenv("MHS_RF_BIG_PER_BATCH")) {      // tree-major form (keys in registers, R = 4)
+        constexpr int NB = 4;
+        const size_t tbytes = std::max((size_t)m->rf_max_nodes * 8, (size_t)RF_COARSE_BYTES) + (size_t)512 * (((size_t)m->p * 4) | 1) * 4;
+        if (tbytes <= LDS_MAX && m->rf_max_nodes <= 65535) {
+            TreeTables t2;
+            if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_BIG, key64, &t2)) return rc;
+            const unsigned nblk = (unsigned)((total + 512 * 4 * NB - 1) / (512 * 4 * NB));
+#define MHS_TM(P_) case P_: { auto k = key64 ? rf_walk_tm_kernel<NB, P_, true> : rf_walk_tm_kernel<NB, P_, false>; \
+            MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes)); \
+            hipLaunchKernelGGL(k, dim3(nblk), dim3(512), tbytes, st, (const uint2 *)t2.rf_nodes, m->rf_lval, m->tree_off, m->rf_depth, \
+                               t2.sorted, t2.sorted_off, m->n_trees, m->rf_max_nodes, s, g, w, acc, out); } break;
+            switch (m->p) { MHS_TM(5) MHS_TM(6) MHS_TM(7) MHS_TM(8) }
+#undef MHS_TM
+            return MHS_OK;
+        }
+    }
     TreeTables tt;
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big, key64, &tt)) return rc;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big ? RF_BIG : RF_SMALL, key64, &tt)) return rc;
     const int R = 1 << log2r;
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
@@ -1365,6 +1624,35 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
                        m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+    return MHS_OK;
+}
+
+// rf_walk_compact_kernel: the most threads (whole waves, at least 8) whose keys fit beside one tree's split records,
+// 0 = the form does not apply (terminal codes beyond 16 bits, too many predictors, no room)
+static int rf_compact_threads(const mhs_model *m) {
+    if (!m->rf_compact_ok || m->p * 16 > 255) return 0;
+    const size_t tree_bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES);
+    if (tree_bytes >= LDS_MAX) return 0;
+    const size_t per_lane = (((size_t)m->p * 4) | 1) * 4;
+    int nt = (int)std::min<size_t>(1024, (LDS_MAX - tree_bytes) / per_lane) / 64 * 64;
+    if (nt < 512 || (size_t)nt * 8 < (size_t)m->rf_cmax) return 0;     // PF <= 8 records per thread
+    return nt;
+}
+
+static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
+                             double w, int acc, double *out, hipStream_t st, int64_t total, int nt) {
+    const int key64 = s.dtype == MHS_F64;
+    TreeTables tt;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_COMPACT, key64, &tt)) return rc;
+    const size_t bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES) + (size_t)nt * (((size_t)m->p * 4) | 1) * 4;
+    const int64_t part = (total + 3) / 4;
+    const unsigned blocks = (unsigned)((part + nt - 1) / nt);
+    const bool pf4 = (size_t)nt * 4 >= (size_t)m->rf_cmax;
+    auto k = pf4 ? (key64 ? rf_walk_compact_kernel<4, true> : rf_walk_compact_kernel<4, false>)
+                 : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
+    MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
+                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out);
     return MHS_OK;
 }
 
@@ -1404,6 +1692,13 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             if (grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC")) {
                 int log2r = 0;
                 bool big = false;
+                if (rf_walk_db_log2r(m) < 0 && !getenv("MHS_RF_NO_COMPACT")) {
+                    const int nt = rf_compact_threads(m);
+                    if (nt > 0) {
+                        if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
+                        break;
+                    }
+                }
                 if (rf_walk_config(m, &log2r, &big)) {
                     if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r, big)) return rc;
                     break;
@@ -1505,6 +1800,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
     if (m->rf_lval) (void)hipFree(m->rf_lval);
     if (m->rf_depth) (void)hipFree(m->rf_depth);
+    if (m->rf_coff) (void)hipFree(m->rf_coff);
     for (void *q : m->retired) (void)hipFree(q);
     delete m;
     return MHS_OK;
@@ -1717,6 +2013,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
             const int o = off[t], cnt = off[t + 1] - off[t];
             if (cnt > 65535) { paired = false; break; }   // node indices within a tree are 16-bit in the walk kernels
             max_nodes = std::max(max_nodes, cnt);
+            m->rf_off.push_back(o);
             lev.assign((size_t)cnt, -1);
             lev[0] = 0;
             int dmax = 0;
@@ -1739,6 +2036,14 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
             depth[(size_t)t] = dmax;
         }
         if (paired) {
+            m->rf_off.push_back((int)nodes.size());
+            m->rf_compact_ok = 1;
+            for (int64_t t = 0; t < n_trees; ++t) {
+                int splits = 0;
+                for (int k = m->rf_off[(size_t)t]; k < m->rf_off[(size_t)t + 1]; ++k) splits += m->rf_var[(size_t)k] != 0xFFFFu;
+                m->rf_cmax = std::max(m->rf_cmax, splits + 1);
+                if (8 * splits + (m->rf_off[(size_t)t + 1] - m->rf_off[(size_t)t]) > 65535) m->rf_compact_ok = 0;
+            }
             m->rf_fast = true;
             m->rf_max_nodes = max_nodes;
             int rc = to_device(lval.data(), lval.size(), &m->rf_lval);

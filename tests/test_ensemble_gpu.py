@@ -1,5 +1,7 @@
 """GPU parity: the six HIP predictors + weighted ensemble (through the C ABI) vs the oracle's
 restatement of the CRAN predict methods on the same covariate planes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -208,6 +210,39 @@ def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     want = oe.predict(prm, X)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    # p = 5: the walk above was the tree-major form (a staged tree serves four batches of cells whose keys wait in
+    # registers); the one-batch-per-staging form adds the same leaves in the same order
+    os.environ["MHS_RF_BIG_PER_BATCH"] = "1"
+    try:
+        per_batch = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
+    finally:
+        del os.environ["MHS_RF_BIG_PER_BATCH"]
+    assert np.array_equal(got, per_batch, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_forest_in_the_compact_form_equals_the_big_forms(hip, dtype):
+    """Trees of ~7 000 nodes (12 000 stations): beyond the double-buffered kernel's 4 095, within the COMPACT form
+    (split nodes only in LDS, terminals as codes).  Same leaves in the same order as the BIG forms and the oracle."""
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=200, ncol=300, C=5, n=12000, gbm_trees=2, rf_trees=1, nodata_frac=0.01, dtype=dtype)
+    prm = synth.rf_params(Xs, ys, 6, n_trees=5)
+    nodes = np.diff(prm["tree_offsets"]).max()
+    assert 4095 < nodes and 8 * (nodes // 2) + nodes <= 65535
+    model = hip.models.from_param_dict(prm)
+    got = hip.predict(stack, model).cpu().numpy().ravel()
+    want = oe.predict(prm, X)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    for envs in (("MHS_RF_NO_COMPACT",), ("MHS_RF_NO_COMPACT", "MHS_RF_BIG_PER_BATCH"), ("MHS_TREES_GENERIC",)):
+        for e in envs:
+            os.environ[e] = "1"
+        try:
+            other = hip.predict(stack, model).cpu().numpy().ravel()
+        finally:
+            for e in envs:
+                del os.environ[e]
+        assert np.array_equal(got, other, equal_nan=True), envs
 
 
 def test_loaders_reject_malformed_models(hip):

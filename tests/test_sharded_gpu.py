@@ -185,7 +185,7 @@ def test_tile_sharded_two_ranks_equal_the_single_process_chain(hip):
 
 
 # ------------------------------------------------------------------------------- bench.py's N > 1 path, end to end --
-def _run_bench(world, workload, port):
+def _run_bench(world, workload, port, extra=()):
     import json
     import subprocess
     import sys
@@ -193,7 +193,7 @@ def _run_bench(world, workload, port):
     env = dict(os.environ, MHS_BENCH_BACKEND="gloo", MHS_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--workload", workload,
-           "--steps", "2", "--warmup", "1"]
+           "--steps", "2", "--warmup", "1", *extra]
     pr = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=root)
     assert pr.returncode == 0, pr.stderr[-3000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -281,3 +281,14 @@ def test_reference_tiled_step3_sharded_equals_the_one_call_surface(hip):
         assert np.array_equal(final, want, equal_nan=True)
         assert rsq_m == single["rsq_model"] and rsq_f == single["rsq_final"]
         assert sorted(set(owner)) == [0, 1] and len(owner) == 12
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_reference_tiled_step3(hip):
+    """`bench.py --gpus 2 --tps-mode tiled`: the Step-3 tiles dealt over the ranks, no serial fit, one all-gather."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _run_bench(2, "cfg3-mini", port, extra=("--tps-mode", "tiled"))
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "reference-tiled" in d["config"]["tps_mode"]
+    assert d["rsq_final"] > d["rsq_model"] > 0.5

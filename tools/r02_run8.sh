@@ -1,7 +1,4 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests -m gpu -q -x -k "tps_fit or cfg5_gcv or golden" > gpurun_out/r02_gputest10.log 2>&1
-tail -8 gpurun_out/r02_gputest10.log | cut -c1-200
-timeout 600 python tools/fit_speed.py 5000 5400 10000 20000 2>&1 | grep -v "^/opt" > gpurun_out/r02_fit_speed_e.txt
-cat gpurun_out/r02_fit_speed_e.txt
-MHS_FIT_TIMING=1 python tools/fit_pmc.py gcv 20000 1 2>&1 | grep "mhs_tps_fit\|gcv m"
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_ensemble_gpu.py tests/test_full_size_gpu.py tests/test_sharded_gpu.py -m gpu -q -x 2>&1 | tail -5
+timeout 900 python bench.py --workload cfg5 --steps 2 --warmup 1 2>&1 | tail -30 | cut -c1-2500
