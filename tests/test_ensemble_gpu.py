@@ -245,6 +245,24 @@ def test_forest_in_the_compact_form_equals_the_big_forms(hip, dtype):
         assert np.array_equal(got, other, equal_nan=True), envs
 
 
+@pytest.mark.parametrize("C,dtype", [(1, "f32"), (3, "f64"), (5, "f32"), (9, "i16")])
+def test_ksvm_window_and_point_paths_match_the_oracle(hip, C, dtype):
+    """ksvm with p = 3, 5, 7, 11 predictors, NA cells, positive and negative alphas: the whole grid, a window of it
+    (a cell's value must not depend on the launch geometry) and the stations' point path, against the oracle."""
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=61, ncol=83, C=C, n=333, dtype=dtype, nodata_frac=0.02, gbm_trees=2, rf_trees=1)
+    prm = params[KINDS.index("v")]
+    assert (np.asarray(prm["alpha"]) > 0).any() and (np.asarray(prm["alpha"]) < 0).any()
+    model = hip.models.from_param_dict(prm)
+    want = oe.predict(prm, X)
+    got = hip.predict(stack, model).cpu().numpy().ravel()
+    win = hip.predict(stack, model, window=(7, 40, 11, 70)).cpu().numpy()
+    pts = model.predict_points(Xs[:100])
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    assert np.array_equal(win, got.reshape(61, 83)[7:40, 11:70], equal_nan=True)
+    assert np.abs(pts - oe.predict(prm, Xs[:100])).max() <= _tol(want)
+
+
 def test_loaders_reject_malformed_models(hip):
     with pytest.raises(hip.MhsError):
         hip.models.Gbm(0.0, [0, 2], [0, -1], [1.0, 2.0], [5, 0], [1, 0], [1, 0], p=5)  # child out of range
