@@ -1,10 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_ensemble_gpu.py -m gpu -q -x -k "ksvm or each_member" 2>&1 | tail -4
-timeout 900 python bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3 | python -c "
-import sys, json
-for line in sys.stdin:
-    if line.startswith('{'):
-        d = json.loads(line); print(d['value'], d['ms_per_step']); print(d['roofline']['kernel'], d['roofline']['launch_ms'])
-        for k in d.get('kernels', []): print(' ', k['kernel'], round(k['launch_ms'], 1), k.get('frac'))
-"
+for q in 4 16; do for r in 0 16; do
+echo "HWQ $q RESERVE $r"
+GPU_MAX_HW_QUEUES=$q MHS_FIT_TIMING=1 MHS_FIT_RESERVE_CUS=$r timeout 900 python bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "n=5000\] band\|^{" | cut -c1-220 | tail -6
+done; done
