@@ -153,6 +153,26 @@ MHS_API int mhs_lm_load(const double *coef, int p, mhs_model **out);
  * coef[p+1], intercept first; MHS_ERR_NUMERIC for a rank-deficient design.
  * replaces mgcv::gam(mod.form, data = train) V73:252 (CV folds) and V73:600 (final fit)      */
 MHS_API int mhs_lm_fit(const double *X, const double *y, int64_t n, int p, double *coef);
+/* kernlab::ksvm(mod.form, data) for a numeric response -- type eps-svr, kernel rbfdot, scaled = TRUE, C = 1,
+ * epsilon = 0.1, tol = 0.001 are kernlab's defaults and the reference passes none (V73:251 in the CV loop, V73:560 for
+ * the final model).  X: n x p column-major, y: n responses, no NA rows.  The columns and the response are scaled to
+ * zero mean / unit sd (n - 1), the dual is solved by the libsvm SMO kernlab uses (second-order working-set
+ * selection, stop when the maximal KKT violation < tol) in one resident kernel over a Gram matrix kept in HBM.
+ * sigma = kpar$sigma (kernlab's "automatic" value comes from sigest() on a RANDOM half of the rows: pass it in).
+ * Outputs: beta[n] = alpha_i - alpha*_i (0 for rows that are not support vectors; the non-zero ones with their scaled
+ * rows are mhs_svr_load's alpha / sv), b, scaling.  max_iter <= 0: libsvm's max(10^7, 100 n).  MHS_ERR_NUMERIC if the
+ * iteration limit is hit.  replaces kernlab::ksvm V73:251, V73:560                                              */
+MHS_API int mhs_svr_fit(const double *X, const double *y, int64_t n, int p, double sigma, double C, double epsilon,
+                        double tol, int64_t max_iter, double *beta, double *b, double *x_center, double *x_scale,
+                        double *y_center, double *y_scale, int64_t *n_iter);
+/* nnet::nnet(mod.form, data = trainNN, size = 10, linout = TRUE, maxit = 10000) (V73:249, V73:463): least squares
+ * (sum over rows of (y - yhat)^2, decay 0) by R's optim "BFGS" (vmmin; abstol = 1e-4, reltol = 1e-8 are nnet's
+ * defaults) in one resident kernel.  wts: IN the initial weights (nnet draws runif(-0.7, 0.7): RNG-dependent, so
+ * they are the caller's), OUT the fitted ones, nnet order (mhs_nnet_load).  X: n x p column-major, y as the caller
+ * scaled it (V73:455-459).  value: final objective; counts[2]: function / gradient evaluations; fail: 1 = maxit
+ * reached.  size must be 10.  replaces nnet::nnet V73:249, V73:463                                              */
+MHS_API int mhs_nnet_fit(const double *X, const double *y, int64_t n, int p, int size, double *wts, int maxit,
+                         double abstol, double reltol, double *value, int *counts, int *fail);
 /* nnet::nnet(size, linout=TRUE) (V73:463): wts in nnet order -- per hidden unit its bias
  * then p input weights, then output bias and `size` hidden->output weights.  The
  * response un-scaling pred*max2.resp.f + min.resp.f (V73:469-470) is y_scale/y_shift.
@@ -227,6 +247,11 @@ MHS_API int mhs_ensemble_predict(const mhs_model *const *models, const double *w
 /* predict(model, data.frame): X is n x p COLUMN-major (all p predictors given, LONG and
  * LAT included), out[n].  Station residuals V73:477-482,501-505,...                     */
 MHS_API int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *out_host);
+/* gbm::predict.gbm(model, newdata, n.trees = step, 2 step, ...) for a table of points in ONE walk over the trees:
+ * out_host[(k - 1) * n + i] = prediction of row i with the first k * step trees, k = 1 .. n_trees / step.  This is
+ * what machisplin.gbm.step evaluates on every fold's hold-out rows after each gbm.more (V73:1843, 1919) to build
+ * the hold-out deviance curve its tree-count search runs on (V73:1884-1981).  X: n x p column-major.             */
+MHS_API int mhs_gbm_staged_points(const mhs_model *m, const double *X, int64_t n, int step, double *out_host);
 /* res.FINAL in one call (V73:477-482, 501-505, 525-528, 547-549, 586-589, 608-611, 620): the kept members at the
  * n station rows X (as above), out[i] = ((resp_i - pred_1) w_1 + (resp_i - pred_2) w_2 + ...) / wt_total, accumulated
  * member after member; weights = the rounded kept weights, wt_total the unrounded total (at most 8 members). */

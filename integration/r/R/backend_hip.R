@@ -75,3 +75,27 @@ mhs_interpolate <- function(r, object) {
   v <- .Call("mhsr_tps_predict_grid", object$handle, .mhs_geom(r), c(0L, nrow(r), 0L, ncol(r)))
   terra::setValues(terra::rast(r), v)
 }
+
+
+# ---- learner fits on the device (SURVEY.md 8f rank 4); every one keeps the CRAN call as its fallback -----------------
+# kernlab::ksvm(mod.form, data = dat) (V73:251, V73:560).  sigma: kernlab draws it with sigest() from a random half
+# of the rows -- do the same here so that the two backends see the same kernel width.
+.mhs_ksvm <- function(dat, sigma = mean(kernlab::sigest(as.matrix(dat[, -1]), scaled = TRUE)[c(1, 3)])) {
+  X <- as.matrix(dat[, -1]); p <- ncol(X)
+  f <- .Call("mhsr_svr_fit", X, as.numeric(dat[, 1]), sigma, 1.0, 0.1, 0.001)
+  sv <- which(f[[1]] != 0)
+  Z <- sweep(sweep(X[sv, , drop = FALSE], 2, f[[3]]), 2, f[[4]], "/")
+  list(handle = .Call("mhsr_svr_load", as.numeric(f[[1]][sv]), as.numeric(t(Z)), p, f[[2]], sigma, f[[3]], f[[4]], f[[5]], f[[6]]),
+       beta = f[[1]], b = f[[2]], sigma = sigma, iterations = f[[7]])
+}
+# nnet::nnet(mod.form, data = trainNN, size = 10, linout = TRUE, maxit = 10000) (V73:249, V73:463); trainNN$resp is
+# already (resp - min) / max (V73:455-459)
+.mhs_nnet <- function(trainNN, max2.resp.f, min.resp.f, maxit = 10000L) {
+  X <- as.matrix(trainNN[, -1]); p <- ncol(X)
+  f <- .Call("mhsr_nnet_fit", X, as.numeric(trainNN[, 1]), runif((p + 1) * 10 + 11, -0.7, 0.7), as.integer(maxit))
+  list(handle = .Call("mhsr_nnet_load", f[[1]], p, 10L, max2.resp.f, min.resp.f), wts = f[[1]], value = f[[2]], convergence = f[[4]])
+}
+# inside machisplin.gbm.step's loop (V73:1843, 1919): the hold-out predictions of fold model i for every stage at once,
+# instead of one predict.gbm per gbm.more
+.mhs_gbm_holdout_stages <- function(handle, x.holdout, step.size, n.fitted)
+  .Call("mhsr_gbm_staged_points", handle, as.matrix(x.holdout), as.integer(step.size), as.integer(n.fitted))

@@ -150,6 +150,57 @@ SEXP mhsr_lm_fit(SEXP X, SEXP y) {
     return out;
 }
 
+/* kernlab::ksvm(mod.form, data) (V73:251, V73:560) with kpar = list(sigma = sigma): returns list(beta[n], b,
+ * x.center[p], x.scale[p], y.center, y.scale, iterations); the support vectors are the rows with beta != 0 */
+SEXP mhsr_svr_fit(SEXP X, SEXP y, SEXP sigma, SEXP C, SEXP epsilon, SEXP tol) {
+    int n = Rf_nrows(X), p = Rf_ncols(X);
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 7));
+    SEXP beta = PROTECT(Rf_allocVector(REALSXP, n)), xc = PROTECT(Rf_allocVector(REALSXP, p)), xs = PROTECT(Rf_allocVector(REALSXP, p));
+    double b = 0, yc = 0, ys = 0;
+    int64_t it = 0;
+    int rc = mhs_svr_fit(REAL(X), REAL(y), (int64_t)n, p, Rf_asReal(sigma), Rf_asReal(C), Rf_asReal(epsilon), Rf_asReal(tol), 0,
+                         REAL(beta), &b, REAL(xc), REAL(xs), &yc, &ys, &it);
+    if (rc == 0) {
+        SET_VECTOR_ELT(out, 0, beta); SET_VECTOR_ELT(out, 1, Rf_ScalarReal(b)); SET_VECTOR_ELT(out, 2, xc); SET_VECTOR_ELT(out, 3, xs);
+        SET_VECTOR_ELT(out, 4, Rf_ScalarReal(yc)); SET_VECTOR_ELT(out, 5, Rf_ScalarReal(ys)); SET_VECTOR_ELT(out, 6, Rf_ScalarReal((double)it));
+    }
+    UNPROTECT(4);
+    chk(rc);
+    return out;
+}
+
+/* nnet::nnet(mod.form, data = trainNN, size = 10, linout = TRUE, maxit = maxit) (V73:249, V73:463) from the initial
+ * weights wts0 (nnet's own: runif(length, -0.7, 0.7)); y already scaled as V73:455-459.
+ * returns list(wts, value, counts[2], fail) */
+SEXP mhsr_nnet_fit(SEXP X, SEXP y, SEXP wts0, SEXP maxit) {
+    int nw = Rf_length(wts0);
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 4));
+    SEXP w = PROTECT(Rf_allocVector(REALSXP, nw)), counts = PROTECT(Rf_allocVector(INTSXP, 2));
+    for (int i = 0; i < nw; ++i) REAL(w)[i] = REAL(wts0)[i];
+    double value = 0;
+    int fail = 0;
+    int rc = mhs_nnet_fit(REAL(X), REAL(y), (int64_t)Rf_nrows(X), Rf_ncols(X), 10, REAL(w), Rf_asInteger(maxit), 1e-4, 1e-8,
+                          &value, INTEGER(counts), &fail);
+    if (rc == 0) {
+        SET_VECTOR_ELT(out, 0, w); SET_VECTOR_ELT(out, 1, Rf_ScalarReal(value)); SET_VECTOR_ELT(out, 2, counts);
+        SET_VECTOR_ELT(out, 3, Rf_ScalarInteger(fail));
+    }
+    UNPROTECT(3);
+    chk(rc);
+    return out;
+}
+
+/* gbm::predict.gbm(model, x.data[pred.mask, ], n.trees = k * step) for k = 1 .. in one pass (V73:1843, 1919): returns the
+ * n x stages matrix machisplin.gbm.step's hold-out deviance curve is computed from */
+SEXP mhsr_gbm_staged_points(SEXP model, SEXP X, SEXP step, SEXP n_trees) {
+    int n = Rf_nrows(X), stages = Rf_asInteger(n_trees) / Rf_asInteger(step);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, n, stages));
+    int rc = mhs_gbm_staged_points((const mhs_model *)R_ExternalPtrAddr(model), REAL(X), (int64_t)n, Rf_asInteger(step), REAL(out));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
 /* machisplin.tiles.merge (V73:1392-1546): tiles = list of numeric vectors (terra::values of each
  * rast.in[[h]] in cell order), win = integer matrix 4 x n (r0, r1, c0, c1 per tile, 0-based) */
 SEXP mhsr_tiles_merge(SEXP geom, SEXP tiles, SEXP win, SEXP in_ncol, SEXP in_nrow) {

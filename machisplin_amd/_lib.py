@@ -73,6 +73,9 @@ SIGNATURES = {
     "mhs_tps_eval_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "mhs_lm_load": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "mhs_lm_fit": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "mhs_svr_fit": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp]),
+    "mhs_nnet_fit": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "mhs_nnet_load": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(_vp)]),
     "mhs_earth_load": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "mhs_svr_load": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_double, C.c_double, _vp, _vp, C.c_double,
@@ -89,6 +92,7 @@ SIGNATURES = {
     "mhs_ensemble_predict": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid),
                                        C.POINTER(Stack), _i64, _i64, _i64, _i64, _vp]),
     "mhs_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mhs_gbm_staged_points": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "mhs_residual_points": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_scale_add_dev": (C.c_int, [_vp, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_crop_window": (C.c_int, [C.POINTER(Grid), _vp, _vp]),

@@ -1166,6 +1166,28 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
     }
 }
 
+// predict.gbm(model, newdata, n.trees = step, 2 step, ...) at a table of points: what machisplin.gbm.step evaluates on
+// every fold's hold-out rows after every gbm.more (V73:1843, 1919) -- here in one walk over the trees, the running sum
+// written out every `step` trees (same additions in the same order as a model cut at that tree count)
+__global__ __launch_bounds__(256) void gbm_staged_points_kernel(const Node *__restrict__ nodes, const int *__restrict__ tree_off,
+                                                                int n_trees, double init_f, const double *__restrict__ X,
+                                                                int64_t n, int step, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int t = 0; t < n_trees; ++t) {
+        const int tb = tree_off[t];
+        Node nd = nodes[tb];
+        while (nd.var >= 0) {
+            const double xv = X[(int64_t)nd.var * n + i];
+            const unsigned nxt = isnan(xv) ? nd.missing : (xv < nd.val ? nd.left : nd.right);
+            nd = nodes[tb + nxt];
+        }
+        acc = acc + nd.val;
+        if ((t + 1) % step == 0) out[(int64_t)((t + 1) / step - 1) * n + i] = init_f + acc;
+    }
+}
+
 // res.FINAL at the stations (V73:477-482 ... 608-611, 620): ((resp - pred_1) w_1 + (resp - pred_2) w_2 + ...) / wt.tot,
 // member after member as the reference accumulates it
 struct ResidualArgs { double w[8]; };
@@ -2158,6 +2180,25 @@ int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *o
     sd.has_nodata = 0; sd.all_from_planes = 1;
     if (int rc = launch_model(m, sd, pg, 1.0, 0, dout.p, s)) return rc;
     MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+int mhs_gbm_staged_points(const mhs_model *m, const double *X, int64_t n, int step, double *out_host) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(m && X && out_host && n >= 1 && n < (1LL << 31) && step >= 1, "bad arguments");
+    MHS_REQUIRE(m->kind == K_GBM, "not a gbm model");
+    const int stages = m->n_trees / step;
+    if (stages == 0) return MHS_OK;
+    hipStream_t s = ctx().stream;
+    DevBuf<double> dx, dout;
+    MHS_HIP(dx.alloc((size_t)n * m->p));
+    MHS_HIP(dout.alloc((size_t)n * stages));
+    MHS_HIP(hipMemcpyAsync(dx.p, X, sizeof(double) * (size_t)n * m->p, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gbm_staged_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->nodes, m->tree_off,
+                       m->n_trees, m->init_f, dx.p, n, step, dout.p);
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)n * stages, hipMemcpyDeviceToHost, s));
     MHS_HIP(hipStreamSynchronize(s));
     return MHS_OK;
 }

@@ -1,6 +1,6 @@
 """Step 1's data-parallel part: hold-out predictions of the six learners for the
 k-fold cross-validation (V73:225-319) on the GPU, and the ensemble weight search that consumes them
-(V73:326-393).
+(V73:326-393); rank 4: the tree-count search of machisplin.gbm.step over grown fold models (gbm_step_search).
 
 Fitting the fold models stays in the CRAN packages (R); what runs here is what R does with
 ``terra::predict(model, test)`` inside the fold loop: every fold's models evaluated at that fold's hold-out
@@ -90,3 +90,51 @@ def optx_weights(residuals, smooth_only: bool = False):
                    bounds=[(0.0, 1.0)] * len(labels))
     kept, wts, tot = select_weights(res.x, labels)
     return res.x, kept, wts, tot
+
+
+def gbm_step_search(fold_models, X, y, selector, step: int = 50, tolerance: float = 0.001, max_trees: int = 10000,
+                    site_weights=None):
+    """The tree-count search of ``machisplin.gbm.step`` (V73:1765-1981) over fold models that gbm has grown far enough
+    (growing them -- gbm::gbm / gbm.more with bag.fraction = 0.5 -- is RNG-dependent and stays in the package):
+
+    * fold i's model predicts its hold-out rows (``selector == i``) at n.trees = step, 2 step, ... in ONE device walk
+      (:meth:`models.Gbm.staged_predict_points`; R calls predict.gbm once per stage, V73:1843, 1919);
+    * ``cv.loss.values[j]`` = mean over the folds of the hold-out deviance, gaussian = mean squared error
+      (machisplin.calc.deviance, V73:2250-2285; V73:1866, 1942-1946);
+    * stages are added while ``delta.deviance > tolerance.test`` and ``n.fitted < max.trees`` (V73:1884); from the
+      20th stage on ``delta.deviance = mean(cv[j-19 .. j-9]) - mean(cv[j-9 .. j])`` (V73:1957-1961);
+      ``tolerance.test`` = tolerance x the mean total deviance (tolerance.method = "auto", V73:1786-1794);
+    * a loss that rises within the first four stages aborts (V73:1948-1955: returns None, R prints "restart model
+      with a smaller learning rate");
+    * the tree count is the first stage with the smallest loss (V73:1976-1981).
+
+    Returns ``(target_trees, cv_loss_values, trees_fitted)``."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    selector = np.asarray(selector)
+    w = np.ones_like(y) if site_weights is None else np.asarray(site_weights, dtype=np.float64)
+    u = np.sum(y * w) / np.sum(w)
+    tolerance_test = float(np.sum((y - u) * (y - u))) / y.size * tolerance
+    staged = []
+    for i, m in enumerate(fold_models):
+        mask = selector == i + 1
+        P = m.staged_predict_points(X[mask], step)
+        d = y[mask][None, :] - P
+        staged.append(np.sum(d * d, axis=1) / int(mask.sum()))
+    n_fitted = step
+    trees = [n_fitted]
+    cv = [float(np.mean([s[0] for s in staged]))]
+    delta, j = 1.0, 1
+    while delta > tolerance_test and n_fitted < max_trees:
+        n_fitted += step
+        trees.append(n_fitted)
+        j += 1
+        if j > len(staged[0]):
+            raise ValueError("fold models have fewer trees than the search needs")
+        cv.append(float(np.mean([s[j - 1] for s in staged])))
+        if j < 5 and cv[j - 1] > cv[j - 2]:
+            return None
+        if j >= 20:
+            delta = float(np.mean(cv[j - 20:j - 9]) - np.mean(cv[j - 10:j]))
+    cv = np.array(cv)
+    return trees[int(np.argmax(cv == cv.min()))], cv, np.array(trees)

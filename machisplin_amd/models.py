@@ -89,6 +89,30 @@ class Nnet(Model):
         _lib.check(_lib.lib().mhs_nnet_load(w.ctypes.data, p, size, float(max2_resp), float(min_resp), C.byref(h)))
         super().__init__(h, p)
 
+    @classmethod
+    def fit(cls, X, y, wts0, size=10, maxit=10000, abstol=1e-4, reltol=1e-8) -> "Nnet":
+        """nnet::nnet(mod.form, data = trainNN, size = 10, linout = TRUE, maxit = 10000) with the response scaling of
+        V73:455-459 (resp - min, / max) around it, on the device (R's vmmin in one resident kernel).  wts0: the
+        initial weights, nnet order (nnet draws runif(-0.7, 0.7)).  The object carries .wts, .value, .counts, .fail."""
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        y = _f64(y)
+        if X.ndim != 2 or X.shape[0] != y.size:
+            raise ValueError("X must be n x p with one response per row")
+        n, p = X.shape
+        w = _f64(wts0).copy()
+        if w.size != (p + 1) * size + size + 1:
+            raise ValueError("wts0 has the wrong length for (p, size)")
+        mn = float(y.min())
+        mx = float((y - mn).max())
+        ys = np.ascontiguousarray((y - mn) / mx)
+        val, counts, fail = C.c_double(), (C.c_int * 2)(), C.c_int()
+        _lib.init()
+        _lib.check(_lib.lib().mhs_nnet_fit(X.ctypes.data, ys.ctypes.data, n, p, int(size), w.ctypes.data, int(maxit), float(abstol),
+                                           float(reltol), C.byref(val), counts, C.byref(fail)))
+        m = cls(w, p, size, mx, mn)
+        m.wts, m.value, m.counts, m.fail = w, val.value, (counts[0], counts[1]), fail.value
+        return m
+
 
 class Earth(Model):
     """earth::earth (V73:539): coefficients, dirs and cuts of the SELECTED terms."""
@@ -118,6 +142,30 @@ class Ksvm(Model):
                                            float(y_scale), C.byref(h)))
         super().__init__(h, sv.shape[1])
 
+    @classmethod
+    def fit(cls, X, y, sigma, C_=1.0, epsilon=0.1, tol=1e-3, max_iter=0) -> "Ksvm":
+        """kernlab::ksvm(mod.form, data) (V73:251, V73:560) on the device: eps-svr, rbfdot, scaled = TRUE, kernlab's
+        defaults for C / epsilon / tol.  sigma is kpar$sigma (kernlab's automatic value is drawn by sigest() from a
+        random half of the rows).  The fitted object carries .beta (n), .n_iter and the support-vector bundle."""
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        y = _f64(y)
+        if X.ndim != 2 or X.shape[0] != y.size:
+            raise ValueError("X must be n x p with one response per row")
+        n, p = X.shape
+        beta, xc, xs = np.empty(n), np.empty(p), np.empty(p)
+        b, yc, ys, it = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        _lib.init()
+        _lib.check(_lib.lib().mhs_svr_fit(X.ctypes.data, y.ctypes.data, n, p, float(sigma), float(C_), float(epsilon), float(tol),
+                                          int(max_iter), beta.ctypes.data, C.byref(b), xc.ctypes.data, xs.ctypes.data,
+                                          C.byref(yc), C.byref(ys), C.byref(it)))
+        sv = np.flatnonzero(beta != 0.0)
+        Z = (np.ascontiguousarray(X)[sv] - xc) / xs
+        m = cls(beta[sv], Z, b.value, sigma, xc, xs, yc.value, ys.value)
+        m.beta, m.n_iter, m.sv_index = beta, int(it.value), sv
+        m.params = {"kind": "svr", "alpha": beta[sv], "sv": Z, "b": b.value, "sigma": float(sigma), "x_center": xc, "x_scale": xs,
+                    "y_center": yc.value, "y_scale": ys.value}
+        return m
+
 
 class Gbm(Model):
     """gbm object evaluated at n.trees = best.trees, type="response" (V73:497)."""
@@ -132,6 +180,18 @@ class Gbm(Model):
         _lib.check(_lib.lib().mhs_gbm_load(float(init_f), off.size - 1, off.ctypes.data, sv.ctypes.data,
                                            val.ctypes.data, l.ctypes.data, r.ctypes.data, m.ctypes.data, p, C.byref(h)))
         super().__init__(h, p)
+        self.n_trees = int(off.size - 1)
+
+    def staged_predict_points(self, X, step: int) -> np.ndarray:
+        """predict.gbm(model, X, n.trees = step, 2 step, ...) in one walk (mhs_gbm_staged_points): (n_trees // step, n);
+        the hold-out predictions machisplin.gbm.step's tree-count search is run on (V73:1843, 1919)."""
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        if X.ndim != 2 or X.shape[1] != self.p:
+            raise ValueError("X must be n x p")
+        out = np.empty((self.n_trees // int(step), X.shape[0]))
+        if out.size:
+            _lib.check(_lib.lib().mhs_gbm_staged_points(self._h, X.ctypes.data, X.shape[0], int(step), out.ctypes.data))
+        return out
 
 
 class RandomForest(Model):
