@@ -14,6 +14,8 @@
 #   * terra::crop windows of the Step-3 tile boxes (V73:656-681, 695-699, 728) for the grids of SURVEY.md G6, as
 #     1-based (row0, row1, col0, col1) of the cropped raster inside the parent -- the integer bookkeeping the library
 #     reproduces bit for bit.
+#   * (where kernlab / nnet are installed) kernlab::ksvm and nnet::nnet fits of tests/golden/r_inputs/learn_fit.csv with
+#     the RNG-dependent inputs fixed (sigma; initial weights), and their predict() values.
 # sessionInfo() is stored next to the numbers.
 suppressPackageStartupMessages({ library(fields); library(terra) })
 inp <- file.path("tests", "golden", "r_inputs")
@@ -67,5 +69,33 @@ g6 <- rbind(tile_windows(1500, 1500), tile_windows(1501, 1501), tile_windows(247
             tile_windows(10000, 10000))
 colnames(g6) <- c("nrow", "ncol", "tile_row", "tile_col", "overlap", "row0", "row1", "col0", "col1")
 write.csv(g6, file.path(out, "step3_tile_windows.csv"), row.names = FALSE, quote = FALSE)
+# ---- learner fits (SURVEY.md 8f rank 4), only where kernlab / nnet are installed ---------------------------------------
+# tests/golden/r_inputs/learn_fit.csv: resp + 4 predictors; sigma is fixed (ksvm's automatic value is drawn by sigest()),
+# the initial nnet weights are given (nnet would draw runif(-0.7, 0.7)).  Captured: what mhs_svr_fit / mhs_nnet_fit and
+# the two predict() evaluators must reproduce.
+lf <- read.csv(file.path(inp, "learn_fit.csv"), comment.char = "#", header = FALSE, skip = 2,
+               col.names = c("resp", "a", "b", "LONG", "LAT"))
+sigma <- 0.25
+if (requireNamespace("kernlab", quietly = TRUE)) {
+  sv <- kernlab::ksvm(resp ~ a + b + LONG + LAT, data = lf, kpar = list(sigma = sigma))       # V73:560 + fixed sigma
+  beta <- numeric(nrow(lf)); beta[kernlab::alphaindex(sv)] <- unlist(kernlab::coef(sv))
+  w(beta, "learn_ksvm_beta.csv")
+  w(c(b = kernlab::b(sv), sigma = sigma, nSV = kernlab::nSV(sv)), "learn_ksvm_scalars.csv")
+  sc <- kernlab::scaling(sv)
+  w(rbind(sc$x.scale$`scaled:center`, sc$x.scale$`scaled:scale`), "learn_ksvm_xscale.csv")
+  w(c(sc$y.scale$`scaled:center`, sc$y.scale$`scaled:scale`), "learn_ksvm_yscale.csv")
+  w(as.numeric(kernlab::predict(sv, lf)), "learn_ksvm_predict.csv")
+}
+if (requireNamespace("nnet", quietly = TRUE)) {
+  nn.in <- lf
+  mn <- min(nn.in$resp); nn.in$resp <- nn.in$resp - mn; mx <- max(nn.in$resp); nn.in$resp <- nn.in$resp / mx     # V73:455-459
+  w0 <- scan(file.path(inp, "learn_fit_wts0.csv"), quiet = TRUE)
+  nn <- nnet::nnet(resp ~ a + b + LONG + LAT, data = nn.in, size = 10, linout = TRUE, maxit = 10000, Wts = w0, trace = FALSE)
+  w(nn$wts, "learn_nnet_wts.csv")
+  w(c(value = nn$value, convergence = nn$convergence, min.resp = mn, max2.resp = mx), "learn_nnet_scalars.csv")
+  w(as.numeric(predict(nn, nn.in)) * mx + mn, "learn_nnet_predict.csv")                       # V73:468-470
+  nn25 <- nnet::nnet(resp ~ a + b + LONG + LAT, data = nn.in, size = 10, linout = TRUE, maxit = 25, Wts = w0, trace = FALSE)
+  w(nn25$wts, "learn_nnet_wts_maxit25.csv")
+}
 writeLines(capture.output(sessionInfo()), file.path(out, "sessionInfo.txt"))
 cat("wrote", length(list.files(out)), "files to", out, "\n")

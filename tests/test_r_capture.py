@@ -81,3 +81,74 @@ def test_tile_windows_match_terra_crop():
             win = fit[h] if abs(float(r["overlap"]) - 0.2) < 1e-9 else None
             if win is not None:   # 1-based inclusive rows/cols of the crop -> half-open 0-based window
                 assert tuple(int(v) for v in win) == (int(r["row0"]) - 1, int(r["row1"]), int(r["col0"]) - 1, int(r["col1"]))
+
+
+# ---- learner fits (kernlab::ksvm, nnet::nnet): captured only where those packages are installed ----------------------
+have_ksvm = os.path.exists(os.path.join(CAP, "learn_ksvm_beta.csv"))
+have_nnet = os.path.exists(os.path.join(CAP, "learn_nnet_wts.csv"))
+
+
+def _learn_inputs():
+    tab = np.loadtxt(os.path.join(GOLD, "r_inputs", "learn_fit.csv"), delimiter=",", skiprows=2)
+    w0 = np.loadtxt(os.path.join(GOLD, "r_inputs", "learn_fit_wts0.csv"))
+    return tab[:, 1:], tab[:, 0], w0
+
+
+def test_learn_inputs_are_reproducible():
+    X, y, w0 = _learn_inputs()
+    assert X.shape == (200, 4) and y.shape == (200,) and w0.size == 61 and np.abs(w0).max() <= 0.7
+
+
+@pytest.mark.skipif(not have_ksvm, reason="no kernlab capture")
+def test_oracle_svr_fit_matches_kernlab():
+    from oracle import ensemble as oe, fit as of
+    X, y, _ = _learn_inputs()
+    b_r, sigma, nsv = _csv("learn_ksvm_scalars.csv")
+    m, _ = of.svr_fit(X, y, sigma)
+    xs, ys = _csv("learn_ksvm_xscale.csv"), _csv("learn_ksvm_yscale.csv")
+    np.testing.assert_allclose(m["x_center"], xs[0], rtol=1e-12)
+    np.testing.assert_allclose(m["x_scale"], xs[1], rtol=1e-12)
+    np.testing.assert_allclose([m["y_center"], m["y_scale"]], ys, rtol=1e-12)
+    Z = (X - xs[0]) / xs[1]
+    K = of.rbf_gram(Z, sigma)
+    mine = np.zeros(y.size)
+    sv_rows = [int(np.flatnonzero((Z == r).all(1))[0]) for r in m["sv"]]
+    mine[sv_rows] = m["alpha"]
+    assert np.abs(K @ (mine - _csv("learn_ksvm_beta.csv"))).max() < 5e-3 and abs(m["b"] - b_r) < 5e-3    # solver tolerance 1e-3
+    assert abs(m["alpha"].size - nsv) <= 3
+    # the evaluator on kernlab's own coefficients: predict.ksvm to rounding
+    r = _csv("learn_ksvm_beta.csv")
+    keep = np.flatnonzero(r != 0)
+    mk = oe.svr_model(r[keep], Z[keep], b_r, sigma, xs[0], xs[1], ys[0], ys[1])
+    assert np.abs(oe.predict(mk, X) - _csv("learn_ksvm_predict.csv")).max() < 1e-10 * np.abs(y).max()
+
+
+@pytest.mark.skipif(not have_nnet, reason="no nnet capture")
+def test_oracle_nnet_fit_matches_nnet():
+    from oracle import ensemble as oe, fit as of
+    X, y, w0 = _learn_inputs()
+    value, conv, mn, mx = _csv("learn_nnet_scalars.csv")
+    t = (y - mn) / mx
+    w25, *_ = of.nnet_fit(X, t, w0, maxit=25)
+    r25 = _csv("learn_nnet_wts_maxit25.csv")
+    assert np.abs(w25 - r25).max() < 1e-6 * np.abs(r25).max()           # the same iterates
+    w, val, nf, ng, fail = of.nnet_fit(X, t, w0)
+    assert abs(val - value) < 1e-3 * value and fail == int(conv)
+    rw = _csv("learn_nnet_wts.csv")
+    assert np.abs(oe.predict_nnet(oe.nnet_model(rw, 4, 10, mx, mn), X) - _csv("learn_nnet_predict.csv")).max() < 1e-10 * np.abs(y).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (have_ksvm and have_nnet), reason="no kernlab / nnet capture")
+def test_hip_learner_fits_match_r(hip):
+    X, y, w0 = _learn_inputs()
+    b_r, sigma, nsv = _csv("learn_ksvm_scalars.csv")
+    m = hip.models.Ksvm.fit(X, y, sigma)
+    xs = _csv("learn_ksvm_xscale.csv")
+    from oracle import fit as of
+    K = of.rbf_gram((X - xs[0]) / xs[1], sigma)
+    assert np.abs(K @ (m.beta - _csv("learn_ksvm_beta.csv"))).max() < 5e-3 and abs(m.params["b"] - b_r) < 5e-3
+    assert np.abs(m.predict_points(X) - _csv("learn_ksvm_predict.csv")).max() < 5e-3 * y.std()
+    r25 = _csv("learn_nnet_wts_maxit25.csv")
+    nn = hip.models.Nnet.fit(X, y, w0, maxit=25)
+    assert np.abs(nn.wts - r25).max() < 1e-6 * np.abs(r25).max()
