@@ -490,6 +490,10 @@ class PerModelOps:
         kinds = {"Gbm": "gbm", "Gam": "lm", "Nnet": "nnet", "Earth": "earth", "RandomForest": "rf", "Ksvm": "svr"}
         small = ("lm", "nnet", "earth")
         k, n = 0, len(o.models)
+        # mhs_fit_reserve_cus as ONE ensemble call applies it: only the forest (else ksvm, else gbm) is masked
+        names = [kinds[type(m).__name__] for m in o.models]
+        masked = next((w for w in ("rf", "svr", "gbm") if w in names), None)
+        reserve_cus = o.reserve(0)
         while k < n:    # the library's own grouping: a run of gam / nnet / earth members is ONE fused launch
             e = k + 1
             name = kinds[type(o.models[k]).__name__]
@@ -501,8 +505,10 @@ class PerModelOps:
             key = "model_%s_ms" % ("+".join(kinds[type(m).__name__] for m in o.models[k:e]))
             o.timings.setdefault(key, [])
             ms, ws, first = o.models[k:e], o.weights[k:e], k == 0
+            o.reserve(reserve_cus if name == masked else 0)
             o._timed(key, lambda: members_predict(o.stack, ms, ws, window=(r0, r1, 0, g.ncol), accumulate=not first, out=out))
             k = e
+        o.reserve(reserve_cus)
         st = o.torch.cuda.current_stream(o.device).cuda_stream
         o._lib.check(o._lib.lib().mhs_scale_add_dev(out.data_ptr(), o.wt_total, None, out.data_ptr(), out.numel(), st))
 

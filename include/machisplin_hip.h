@@ -81,6 +81,19 @@ MHS_API int mhs_init(int device);
 MHS_API int mhs_shutdown(void);
 MHS_API int mhs_device_count(int *count);
 MHS_API int mhs_sync(void *stream);
+/* Scheduling knob for a fit that runs beside an ensemble evaluation (the reference computes Step 2's rasters and
+ * Step 3's fields::Tps fit one after the other, V73:468-620 then 722-753; here the fit only needs the members'
+ * predictions at the stations, so it can run while the grid is still being evaluated -- but grid-filling kernels leave
+ * the fit's chain of small dependent kernels no workgroup slots).  While n_cus > 0 (a multiple of 8: n_cus / 8
+ * compute units of every XCD):
+ *   - ONE long member of every mhs_ensemble_predict(_dev) / mhs_members_predict_dev call on a window of >= 2^22 cells
+ *     (randomForest if present, else ksvm, else gbm) is launched on a stream whose CU mask leaves those compute units
+ *     out, fenced by events so that it keeps its place in the caller's stream order (results are unchanged);
+ *   - mhs_tps_fit's GCV route runs on streams confined to exactly those compute units.
+ * CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): they synchronise with the NULL
+ * stream, so the ensemble call must be given a non-NULL, non-blocking stream or the fit waits for it after all.
+ * 0 switches it off (the default).  *previous may be NULL. */
+MHS_API int mhs_fit_reserve_cus(int n_cus, int *previous);
 /* HIP-event timing on the stream work is launched on (bench.py's roofline leg):
  * t0 = mhs_timer_start(stream) ... launches ... mhs_timer_stop(stream,&ms). */
 MHS_API int mhs_timer_start(void *stream);

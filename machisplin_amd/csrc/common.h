@@ -34,6 +34,7 @@ constexpr int LOG_TAB_N = 1 << LOG_TAB_BITS;
 // from host threads.
 struct FitLane {
     hipStream_t s = nullptr, s2 = nullptr;
+    hipStream_t ms = nullptr, ms2 = nullptr;   // the same pair confined to the compute units mhs_fit_reserve_cus keeps free
     std::vector<hipEvent_t> pool;
     char *arena = nullptr;
     size_t arena_cap = 0;
@@ -52,7 +53,14 @@ struct Context {
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 0;
+    // mhs_fit_reserve_cus: a stream whose CU mask leaves compute units out, and the two events that order a kernel
+    // launched on it between its neighbours on the caller's stream
+    int reserved_cus = 0;                 // active setting (0 = off)
+    int masked_cus = 0;                   // what masked_stream was created for
+    hipStream_t masked_stream = nullptr;
+    hipEvent_t mask_ev0 = nullptr, mask_ev1 = nullptr;
 };
+std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences
 Context &ctx();
 int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)
 // mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
@@ -26,6 +27,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 Context &ctx() {
     static Context c;
     return c;
+}
+
+std::mutex &mask_mutex() {
+    static std::mutex m;
+    return m;
 }
 
 int fit_lane(int i, FitLane **out) {
@@ -136,14 +142,51 @@ int mhs_shutdown(void) {
     if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); }
+    if (c.mask_ev0) (void)hipEventDestroy(c.mask_ev0);
+    if (c.mask_ev1) (void)hipEventDestroy(c.mask_ev1);
     for (FitLane *L : c.lanes) {
         (void)hipStreamSynchronize(L->s); (void)hipStreamSynchronize(L->s2);
         for (hipEvent_t e : L->pool) (void)hipEventDestroy(e);
+        if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); }
         if (L->arena) (void)hipFree(L->arena);
         (void)hipStreamDestroy(L->s2); (void)hipStreamDestroy(L->s);
         delete L;
     }
     c = Context();
+    return MHS_OK;
+}
+
+int mhs_fit_reserve_cus(int n_cus, int *previous) {
+    if (int rc = require_ready()) return rc;
+    Context &c = ctx();
+    MHS_REQUIRE(n_cus >= 0 && n_cus <= c.n_cu / 2 && n_cus % 8 == 0, "n_cus must be a multiple of 8 between 0 and half of the device's compute units");
+    std::lock_guard<std::mutex> lk(mask_mutex());
+    if (previous) *previous = c.reserved_cus;
+    if (n_cus == 0 || n_cus == c.masked_cus) { c.reserved_cus = n_cus; return MHS_OK; }   // the stream is kept for the next time
+    if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); c.masked_stream = nullptr; }
+    c.reserved_cus = c.masked_cus = 0;
+    std::vector<uint32_t> mask((size_t)(c.n_cu + 31) / 32, 0u), comp(mask.size(), 0u);
+    for (int i = 0; i < c.n_cu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    // Index i of the mask is compute unit i / 8 of XCD i % 8 (measured, tools/fit_beside_member.py: clearing every
+    // 8th index -- one whole XCD -- is silently ignored, clearing the first n indices slows a masked kernel as n / 256
+    // of the chip and more): the first n_cus indices = the same n_cus / 8 compute units of every XCD, so a grid's
+    // blocks, which are dealt round-robin over the XCDs, find room in each of them.
+    for (int i = 0; i < n_cus; ++i) {
+        mask[(size_t)i / 32] &= ~(1u << (i % 32));
+        comp[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    MHS_HIP(hipExtStreamCreateWithCUMask(&c.masked_stream, (uint32_t)mask.size(), mask.data()));
+    for (FitLane *L : c.lanes) {
+        if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); L->ms = L->ms2 = nullptr; }
+        MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)comp.size(), comp.data()));
+        MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)comp.size(), comp.data()));
+    }
+    if (!c.mask_ev0) {
+        MHS_HIP(hipEventCreateWithFlags(&c.mask_ev0, hipEventDisableTiming));
+        MHS_HIP(hipEventCreateWithFlags(&c.mask_ev1, hipEventDisableTiming));
+    }
+    c.reserved_cus = c.masked_cus = n_cus;
     return MHS_OK;
 }
 

@@ -1914,7 +1914,10 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     for (int64_t i = 0; i < n; ++i) wv[i] = sw[i] * ym[i];
     for (int k = 0; k < 3; ++k) apply_reflector(hv[k], htau[k], wv.data(), n);
 
-    hipStream_t s = L.s;
+    // mhs_fit_reserve_cus active: the fit stays on the compute units the ensemble's masked member leaves free
+    // (the GCV route only: the Cholesky route takes its two streams from the lane itself)
+    const bool confined = std::isnan(lambda) && ctx().reserved_cus > 0 && L.ms != nullptr && !getenv("MHS_FIT_UNCONFINED");
+    hipStream_t s = confined ? L.ms : L.s;
     const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -2090,7 +2093,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         // on stream2 behind an event.  The panel block needs a whole CU's registers: it must reach the
         // dispatcher before the flood of update blocks, which the event's latency ensures.  Per step the
         // critical path is panel + symm + s + one column block instead of panel + symm + s + the whole update.
-        hipStream_t s2 = L.s2;
+        hipStream_t s2 = confined ? L.ms2 : L.s2;
         std::vector<hipEvent_t> &pool = L.pool;
         while ((int)pool.size() < 2 * npanels + 1) {
             hipEvent_t e;

@@ -300,6 +300,15 @@ def members_predict(stack: RasterStack, models, weights, window=None, accumulate
     return out
 
 
+def fit_reserve_cus(n_cus: int) -> int:
+    """mhs_fit_reserve_cus: while n_cus > 0 the first tree / ksvm member of every ensemble call on a large window
+    leaves n_cus compute units free for a concurrent Tps fit (results unchanged).  Returns the previous setting."""
+    _lib.init()
+    prev = C.c_int(0)
+    _lib.check(_lib.lib().mhs_fit_reserve_cus(int(n_cus), C.byref(prev)))
+    return int(prev.value)
+
+
 def select_weights(p_opt, labels="bgnmrv"):
     """V73:336-362 / 375-392: keep model k iff round(p_k, 2) > 0.05 * sum(p); the kept
     weight is round(p_k, 2); the divisor stays the unrounded sum over ALL candidates."""

@@ -14,7 +14,17 @@ CPU tests pass a numpy stand-in so the collective plumbing is exercised under gl
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import numpy as np
+
+# Compute units the fitting rank keeps free of one long ensemble kernel (the forest) so that the spline can be fitted
+# beside the grid kernels (mhs_fit_reserve_cus; 0 = off; a multiple of 8).  Measured on cfg3: DESIGN.md section 9.
+FIT_RESERVE_CUS = 32
+# ... only while the fit is a latency-bound chain (62 ms alone at 5 000 stations, 143 ms on 32 units): at 20 000
+# stations it is compute-bound (1.2 s on the whole chip) and confining it to an eighth of the chip costs seconds
+FIT_RESERVE_MAX_STATIONS = 6000
 
 
 def row_bands(nrow: int, world: int, rank0_share: float | None = None):
@@ -107,8 +117,22 @@ class ShardedMltps:
         self.pred = torch.zeros((self.band, ncol), **kw) if world > 1 else self.full   # this rank's chunk
         self.total = torch.zeros((nrow, ncol), **kw)                  # final.TPS, then pred.elev + final.TPS
         self.torch = torch
+        self.fit_reserve_cus = int(os.environ.get("MHS_FIT_RESERVE_CUS", FIT_RESERVE_CUS))
 
     def step(self):
+        # The whole step is enqueued on a stream of its own (ops.side_stream, non-blocking), never on the NULL stream:
+        # the CU-masked streams of mhs_fit_reserve_cus are blocking streams, and ANY operation that reaches the NULL
+        # stream between the forest's launch and the end of the fit (a torch.zeros is enough) becomes a barrier
+        # between the two.  The caller's current stream takes over at the end.
+        side = getattr(self.ops, "side_stream", None) or contextlib.nullcontext
+        with side():
+            out = self._step()
+        join = getattr(self.ops, "join_side_stream", None)
+        if join:
+            join()
+        return out
+
+    def _step(self):
         ops, torch = self.ops, self.torch
         nb = self.r1 - self.r0
         off = self.lead if self.rank == 0 else 0          # rank 0's rows at the end of its chunk
@@ -116,18 +140,27 @@ class ShardedMltps:
         # few thousand points, all the fit needs) follows on the library's own high-priority stream: a
         # prioritised small grid gets its slots within a millisecond or two of its launch, so the residuals cost
         # nothing on the critical path, and rank 0 fits the spline while every rank's band is still running
-        if nb > 0:
-            ops.ensemble_band(self.r0, self.r1, self.pred[off:off + nb])
-        knots, resid, resp, rows, cols = ops.station_residuals()
-        n = knots.shape[0]
-        # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
-        work = None
-        if self.world > 1:
-            work = self.dist.all_gather_into_tensor(self.full, self.pred, async_op=True)
-        msg = torch.zeros(tps_msg_len(n), dtype=torch.float64, device=ops.device)
-        if self.rank == 0:
-            packed0 = np.ascontiguousarray(ops.tps_fit(knots, resid))
-            msg[:packed0.size].copy_(torch.from_numpy(packed0))   # replicates collapsed: fewer knots than rows
+        # ... provided its small dependent kernels find workgroup slots beside grid-filling kernels: the fitting rank
+        # launches the forest with FIT_RESERVE_CUS compute units masked out and confines the fit to them.
+        small_fit = getattr(ops, "n_stations", FIT_RESERVE_MAX_STATIONS + 1) <= FIT_RESERVE_MAX_STATIONS
+        reserve = getattr(ops, "reserve", None) if (self.rank == 0 and self.fit_reserve_cus > 0 and small_fit) else None
+        prev = reserve(self.fit_reserve_cus) if reserve else None
+        try:
+            if nb > 0:
+                ops.ensemble_band(self.r0, self.r1, self.pred[off:off + nb])
+            knots, resid, resp, rows, cols = ops.station_residuals()
+            n = knots.shape[0]
+            # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
+            work = None
+            if self.world > 1:
+                work = self.dist.all_gather_into_tensor(self.full, self.pred, async_op=True)
+            msg = torch.zeros(tps_msg_len(n), dtype=torch.float64, device=ops.device)
+            if self.rank == 0:
+                packed0 = np.ascontiguousarray(ops.tps_fit(knots, resid))
+                msg[:packed0.size].copy_(torch.from_numpy(packed0))   # replicates collapsed: fewer knots than rows
+        finally:
+            if prev is not None:
+                reserve(prev)
         if self.world > 1:
             self.dist.broadcast(msg, src=0)
         packed = msg.cpu().numpy()
@@ -259,6 +292,7 @@ class HipOps:
         own = ~np.isnan(X).any(axis=1) & ~np.isnan(y)  # complete.cases (V73:154)
         keep = own if keep is None else (np.asarray(keep, dtype=bool) & own)   # table-wide mask: mltps.complete_cases
         self.X, self.rows, self.cols, self.y = X[keep], rows[keep], cols[keep], y[keep]
+        self.n_stations = int(self.X.shape[0])
         self.timed = timed
         self.timings = {"ensemble_ms": [], "tps_eval_ms": [], "tps_fit_ms": [], "residuals_ms": []}
         self.last_fit = None
@@ -282,6 +316,33 @@ class HipOps:
         for key, e0, e1 in self._pending:
             self.timings.setdefault(key, []).append(e0.elapsed_time(e1))
         self._pending = []
+
+    def reserve(self, n_cus):
+        """mhs_fit_reserve_cus; returns the previous setting, or None where the device refuses CU masks (the step then
+        runs without the reservation)."""
+        from . import _lib
+        from .models import fit_reserve_cus
+        if getattr(self, "_no_cu_mask", False):
+            return None
+        try:
+            return fit_reserve_cus(n_cus)
+        except _lib.MhsError:
+            self._no_cu_mask = True
+            return None
+
+    @contextlib.contextmanager
+    def side_stream(self):
+        """The band kernels' own (non-blocking) stream, ordered after what the current stream holds."""
+        torch = self.torch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            yield
+
+    def join_side_stream(self):
+        if getattr(self, "_side", None) is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def ensemble_band(self, r0, r1, out):
         from .models import ensemble_predict

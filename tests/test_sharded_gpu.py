@@ -292,3 +292,37 @@ def test_bench_two_ranks_reference_tiled_step3(hip):
     d = _run_bench(2, "cfg3-mini", port, extra=("--tps-mode", "tiled"))
     assert d["n_gpus"] == 2 and d["value"] > 0 and "reference-tiled" in d["config"]["tps_mode"]
     assert d["rsq_final"] > d["rsq_model"] > 0.5
+
+
+def test_fit_beside_the_forest_changes_no_number(hip):
+    """mhs_fit_reserve_cus (the forest launched with 32 compute units masked out, the GCV fit confined to them, the
+    whole step on a stream of its own): the planes, lambda and both R^2 are those of the plain step, bit for bit."""
+    import torch
+    from machisplin_amd import models, sharded, synth
+    side, n = 2304, 1200                     # 5.3e6 cells: above the 2^22-cell threshold of the masked launch
+    geom = synth.grid(side, side)
+    seed = synth.BASE_SEED + 9
+    planes, nodata = synth.covariates(geom, 3, seed, dtype="f32")
+    stack = hip.RasterStack(geom, planes, nodata)
+    xy, rows, cols, uv = synth.stations(geom, n, seed)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([cov, xy])
+    resp = synth.response(X, uv, seed)
+    params = synth.ensemble_params(X, resp, seed, n_gbm_trees=300, n_rf_trees=40)
+    mods = [hip.models.from_param_dict(p) for p in params]
+    _, weights, wt_total = hip.models.select_weights(synth.OPTX_WEIGHTS)
+    outs = []
+    for reserve in (0, 32):
+        ops = sharded.HipOps(stack, xy, resp, mods, weights, wt_total)
+        run = sharded.ShardedMltps(ops, None, 0, 1, side, side)
+        run.fit_reserve_cus = reserve
+        o = run.step()
+        torch.cuda.synchronize()
+        outs.append((o["final"].clone(), o["lambda"], o["rsq_model"], o["rsq_final"]))
+        assert models.fit_reserve_cus(0) == 0                      # the step leaves the setting as it found it
+    assert torch.equal(torch.nan_to_num(outs[0][0]), torch.nan_to_num(outs[1][0]))
+    assert outs[0][1:] == outs[1][1:]
+    with pytest.raises(hip.MhsError):
+        models.fit_reserve_cus(12)                                 # not a multiple of 8
+    with pytest.raises(hip.MhsError):
+        models.fit_reserve_cus(200)                                # more than half of the device
