@@ -25,6 +25,10 @@ FIT_RESERVE_CUS = 32
 # ... only while the fit is a latency-bound chain (62 ms alone at 5 000 stations, 143 ms on 32 units): at 20 000
 # stations it is compute-bound (1.2 s on the whole chip) and confining it to an eighth of the chip costs seconds
 FIT_RESERVE_MAX_STATIONS = 6000
+# ... and while the fitting rank's band is large enough for its forest to run as long as the confined fit (143 ms at
+# 5 000 stations; the forest takes ~2.1 ns per cell with 500 trees): with a shorter band the fit would be left
+# confined AND starved once the forest is done
+FIT_RESERVE_MIN_CELLS = 60_000_000
 
 
 def row_bands(nrow: int, world: int, rank0_share: float | None = None):
@@ -118,6 +122,7 @@ class ShardedMltps:
         self.total = torch.zeros((nrow, ncol), **kw)                  # final.TPS, then pred.elev + final.TPS
         self.torch = torch
         self.fit_reserve_cus = int(os.environ.get("MHS_FIT_RESERVE_CUS", FIT_RESERVE_CUS))
+        self.fit_reserve_min_cells = FIT_RESERVE_MIN_CELLS
 
     def step(self):
         # The whole step is enqueued on a stream of its own (ops.side_stream, non-blocking), never on the NULL stream:
@@ -143,7 +148,8 @@ class ShardedMltps:
         # ... provided its small dependent kernels find workgroup slots beside grid-filling kernels: the fitting rank
         # launches the forest with FIT_RESERVE_CUS compute units masked out and confines the fit to them.
         small_fit = getattr(ops, "n_stations", FIT_RESERVE_MAX_STATIONS + 1) <= FIT_RESERVE_MAX_STATIONS
-        reserve = getattr(ops, "reserve", None) if (self.rank == 0 and self.fit_reserve_cus > 0 and small_fit) else None
+        long_band = nb * self.ncol >= self.fit_reserve_min_cells
+        reserve = getattr(ops, "reserve", None) if (self.rank == 0 and self.fit_reserve_cus > 0 and small_fit and long_band) else None
         prev = reserve(self.fit_reserve_cus) if reserve else None
         try:
             if nb > 0:

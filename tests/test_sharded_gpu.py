@@ -315,7 +315,7 @@ def test_fit_beside_the_forest_changes_no_number(hip):
     for reserve in (0, 32):
         ops = sharded.HipOps(stack, xy, resp, mods, weights, wt_total)
         run = sharded.ShardedMltps(ops, None, 0, 1, side, side)
-        run.fit_reserve_cus = reserve
+        run.fit_reserve_cus, run.fit_reserve_min_cells = reserve, 0      # (the band-length rule would switch it off at this size)
         o = run.step()
         torch.cuda.synchronize()
         outs.append((o["final"].clone(), o["lambda"], o["rsq_model"], o["rsq_final"]))

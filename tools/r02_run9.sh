@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py --workload cfg5 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
-timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
 timeout 900 python -m pytest tests/test_sharded_gpu.py -m gpu -q -x 2>&1 | tail -3
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-230
