@@ -52,12 +52,14 @@ struct Context {
     double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t upload = nullptr;         // non-blocking stream of the small blocking host -> device copies (h2d_sync)
     int n_cu = 0;
     // mhs_fit_reserve_cus: a stream whose CU mask leaves compute units out, and the two events that order a kernel
     // launched on it between its neighbours on the caller's stream
     int reserved_cus = 0;                 // active setting (0 = off)
     int masked_cus = 0;                   // what masked_stream was created for
     hipStream_t masked_stream = nullptr;
+    std::vector<uint32_t> comp_mask;      // the reserved units' mask (for lanes created later)
     hipEvent_t mask_ev0 = nullptr, mask_ev1 = nullptr;
 };
 std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences
@@ -67,6 +69,9 @@ int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                  int gcv_threads, mhs_tps **out);
 int require_ready();
+// Blocking host -> device copy that does NOT go through the NULL stream: a plain hipMemcpy synchronises with every
+// blocking stream -- the CU-masked streams of mhs_fit_reserve_cus are blocking ones, so it would wait for the forest.
+int h2d_sync(void *dst, const void *src, size_t bytes);
 // _dev entry points launch on exactly the stream they are given; NULL is HIP's default
 // (null) stream, which is also torch's default stream.
 inline hipStream_t pick_stream(void *s) { return (hipStream_t)s; }

@@ -42,9 +42,21 @@ int fit_lane(int i, FitLane **out) {
         MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         MHS_HIP(hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi));
         MHS_HIP(hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio_hi));
+        if (c.masked_cus > 0 && !c.comp_mask.empty()) {
+            MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data()));
+            MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)c.comp_mask.size(), c.comp_mask.data()));
+        }
         c.lanes.push_back(L);
     }
     *out = c.lanes[(size_t)i];
+    return MHS_OK;
+}
+
+int h2d_sync(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return MHS_OK;
+    hipStream_t up = ctx().upload;
+    MHS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
+    MHS_HIP(hipStreamSynchronize(up));
     return MHS_OK;
 }
 
@@ -115,6 +127,7 @@ int mhs_init(int device) {
         if (int rc = fit_lane(0, &L0)) return rc;
         c.stream = L0->s;
     }
+    MHS_HIP(hipStreamCreateWithFlags(&c.upload, hipStreamNonBlocking));
     MHS_HIP(hipEventCreate(&c.ev0));
     MHS_HIP(hipEventCreate(&c.ev1));
     std::vector<double2> tab;
@@ -140,6 +153,7 @@ int mhs_shutdown(void) {
     if (c.surface_arena) (void)hipFree(c.surface_arena);
     if (c.points_arena) (void)hipFree(c.points_arena);
     if (c.exp_tab) (void)hipFree(c.exp_tab);
+    if (c.upload) { (void)hipStreamSynchronize(c.upload); (void)hipStreamDestroy(c.upload); }
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); }
@@ -177,6 +191,7 @@ int mhs_fit_reserve_cus(int n_cus, int *previous) {
         comp[(size_t)i / 32] |= 1u << (i % 32);
     }
     MHS_HIP(hipExtStreamCreateWithCUMask(&c.masked_stream, (uint32_t)mask.size(), mask.data()));
+    c.comp_mask = comp;
     for (FitLane *L : c.lanes) {
         if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); L->ms = L->ms2 = nullptr; }
         MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)comp.size(), comp.data()));

@@ -240,8 +240,7 @@ int upload_knots(mhs_tps *t) {
     t->far.r0 = -1;   // coefficients changed: the far-field plan's sorted knots are stale
     if (t->knots_dev) { (void)hipFree(t->knots_dev); t->knots_dev = nullptr; }
     MHS_HIP(hipMalloc((void **)&t->knots_dev, sizeof(Knot) * (size_t)(t->n ? t->n : 1)));
-    MHS_HIP(hipMemcpy(t->knots_dev, h.data(), sizeof(Knot) * (size_t)t->n, hipMemcpyHostToDevice));
-    return MHS_OK;
+    return h2d_sync(t->knots_dev, h.data(), sizeof(Knot) * (size_t)t->n);
 }
 
 static EvalGeom make_geom(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0,
@@ -372,10 +371,10 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
     if (int rc = grow(&P.nodes_dev, &P.nodes_cap, (size_t)f->ntx * f->nty * FF_NODES)) return rc;
     if (int rc = grow(&P.lx_dev, &P.lx_cap, lx.size())) return rc;
     if (int rc = grow(&P.ly_dev, &P.ly_cap, ly.size())) return rc;
-    MHS_HIP(hipMemcpy(P.sorted_dev, sorted.data(), sizeof(Knot) * (size_t)N, hipMemcpyHostToDevice));
-    MHS_HIP(hipMemcpy(P.bin_start_dev, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
-    MHS_HIP(hipMemcpy(P.lx_dev, lx.data(), sizeof(double) * lx.size(), hipMemcpyHostToDevice));
-    MHS_HIP(hipMemcpy(P.ly_dev, ly.data(), sizeof(double) * ly.size(), hipMemcpyHostToDevice));
+    if (int rc = h2d_sync(P.sorted_dev, sorted.data(), sizeof(Knot) * (size_t)N)) return rc;
+    if (int rc = h2d_sync(P.bin_start_dev, start.data(), sizeof(int) * start.size())) return rc;
+    if (int rc = h2d_sync(P.lx_dev, lx.data(), sizeof(double) * lx.size())) return rc;
+    if (int rc = h2d_sync(P.ly_dev, ly.data(), sizeof(double) * ly.size())) return rc;
     P.xmin = e.xmin; P.ymax = e.ymax; P.xres = e.xres; P.yres = e.yres;
     P.r0 = e.r0; P.r1 = r1; P.c0 = e.c0; P.c1 = c1; P.tx = btx; P.ty = bty; P.ntx = f->ntx; P.nty = f->nty;
     return MHS_OK;

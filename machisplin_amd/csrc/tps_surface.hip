@@ -41,6 +41,8 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     auto worker = [&](int lane_id) {
         FitLane &L = *lanes[(size_t)lane_id];
         (void)hipSetDevice(ctx().device);   // the current device is per host thread
+        // mhs_fit_reserve_cus active: the tiles' evaluations stay, like their fits, on the reserved compute units
+        const hipStream_t ls = (ctx().reserved_cus > 0 && L.ms) ? L.ms : L.s;
         std::vector<double> sx, sy, sr, txy;
         for (;;) {
             const int64_t job = next.fetch_add(1);
@@ -59,7 +61,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
             const int64_t m = (int64_t)sr.size();
             int rc = MHS_OK;
             if (m < 10) {  // V73:710-721: the tile is all zeros
-                if (hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(kr * kc), L.s) != hipSuccess) rc = MHS_ERR_HIP;
+                if (hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(kr * kc), ls) != hipSuccess) rc = MHS_ERR_HIP;
             } else {
                 txy.resize((size_t)2 * m);
                 for (int64_t i = 0; i < m; ++i) { txy[i] = sx[i]; txy[m + i] = sy[i]; }
@@ -72,7 +74,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
                     gf.xmin = g->xmin + (double)f[2] * g->xres;
                     gf.ymax = g->ymax - (double)f[0] * g->yres;
                     gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
-                    rc = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], dst, kc, L.s);
+                    rc = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], dst, kc, ls);
                 }
             }
             if (rc) {
@@ -92,8 +94,10 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
         for (std::thread &th : threads) th.join();
     }
     int rc = first_rc.load();
-    for (FitLane *L : lanes)
+    for (FitLane *L : lanes) {
         if (hipStreamSynchronize(L->s) != hipSuccess && !rc) rc = MHS_ERR_HIP;
+        if (L->ms && hipStreamSynchronize(L->ms) != hipSuccess && !rc) rc = MHS_ERR_HIP;
+    }
     for (mhs_tps *t : handles) mhs_tps_free(t);
     if (rc && !err_msg.empty()) set_error("%s", err_msg.c_str());
     return rc;

@@ -234,6 +234,10 @@ class TiledTpsShardedMltps:
         self.total = torch.zeros((nrow, ncol), **kw)
         self.pred_full = None
         self.torch = torch
+        # no reservation here by default: the tiles' evaluations are real work (773 ms per cfg3 step when confined to 32
+        # units); off the NULL stream the small fits and evaluations find their slots beside the band (546 ms)
+        self.fit_reserve_cus = int(os.environ.get("MHS_TILED_FIT_RESERVE_CUS", 0))
+        self.fit_reserve_min_cells = FIT_RESERVE_MIN_CELLS
 
     def _tile_view(self, buf, base, h):
         r0, r1, c0, c1 = self.keep[h]
@@ -241,17 +245,35 @@ class TiledTpsShardedMltps:
         return buf[o:o + self.cells[h]].view(r1 - r0, c1 - c0)
 
     def step(self):
+        # as ShardedMltps.step: the whole step on a stream of its own, never on the NULL stream
+        side = getattr(self.ops, "side_stream", None) or contextlib.nullcontext
+        with side():
+            out = self._step()
+        join = getattr(self.ops, "join_side_stream", None)
+        if join:
+            join()
+        return out
+
+    def _step(self):
         ops = self.ops
         nb = self.r1 - self.r0
-        if nb > 0:
-            ops.ensemble_band(self.r0, self.r1, self.mine[:nb * self.ncol].view(nb, self.ncol))
-        knots, resid, resp, rows, cols = ops.station_residuals()
-        mine = [h for h in range(len(self.keep)) if self.owner[h] == self.rank]
-        if hasattr(ops, "tps_tiles_batch"):      # the library fits a rank's tiles side by side on its lanes
-            ops.tps_tiles_batch(mine, knots, resid, [self._tile_view(self.mine, 0, h) for h in mine])
-        else:
-            for h in mine:
-                ops.tps_tile(h, knots, resid, self._tile_view(self.mine, 0, h))
+        # this rank's tiles (small fits + their evaluations) run beside its band on the compute units the forest is
+        # launched without (mhs_fit_reserve_cus), when the band is long enough for that to pay
+        reserve = getattr(ops, "reserve", None) if (self.fit_reserve_cus > 0 and nb * self.ncol >= self.fit_reserve_min_cells) else None
+        prev = reserve(self.fit_reserve_cus) if reserve else None
+        try:
+            if nb > 0:
+                ops.ensemble_band(self.r0, self.r1, self.mine[:nb * self.ncol].view(nb, self.ncol))
+            knots, resid, resp, rows, cols = ops.station_residuals()
+            mine = [h for h in range(len(self.keep)) if self.owner[h] == self.rank]
+            if hasattr(ops, "tps_tiles_batch"):      # the library fits a rank's tiles side by side on its lanes
+                ops.tps_tiles_batch(mine, knots, resid, [self._tile_view(self.mine, 0, h) for h in mine])
+            else:
+                for h in mine:
+                    ops.tps_tile(h, knots, resid, self._tile_view(self.mine, 0, h))
+        finally:
+            if prev is not None:
+                reserve(prev)
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.full, self.mine)      # the one exchange: bands + tile planes
         tiles = [self._tile_view(self.full, self.owner[h] * self.chunk, h) for h in range(len(self.keep))]
