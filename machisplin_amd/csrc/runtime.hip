@@ -54,6 +54,8 @@ int fit_lane(int i, FitLane **out) {
 
 int h2d_sync(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return MHS_OK;
+    static const bool plain = getenv("MHS_NULL_STREAM_COPIES") != nullptr;      // diagnostic: the old behaviour
+    if (plain) { MHS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MHS_OK; }
     hipStream_t up = ctx().upload;
     MHS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
     MHS_HIP(hipStreamSynchronize(up));
