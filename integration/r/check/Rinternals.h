@@ -49,4 +49,5 @@ void *R_ExternalPtrAddr(SEXP s);
 void R_ClearExternalPtr(SEXP s);
 void R_RegisterCFinalizerEx(SEXP s, R_CFinalizer_t fun, Rboolean onexit);
 void R_CheckUserInterrupt(void);
+typedef struct _DllInfo DllInfo;     /* R_ext/Rdynload.h */
 #endif

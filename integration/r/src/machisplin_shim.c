@@ -216,3 +216,10 @@ SEXP mhsr_tiles_merge(SEXP geom, SEXP tiles, SEXP win, SEXP in_ncol, SEXP in_nro
     chk(rc);
     return out;
 }
+
+/* library.dynam.unload / R exit: the library's streams go while the HIP runtime is still whole (mhs_init also registers
+ * an atexit handler, so this is belt and braces) */
+void R_unload_machisplin_hip(DllInfo *info) {
+    (void)info;
+    (void)mhs_shutdown();
+}

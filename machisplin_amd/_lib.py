@@ -5,6 +5,7 @@ visible when a compute entry point is reached, the call raises.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
@@ -176,8 +177,19 @@ def init(device: int | None = None) -> int:
     if _inited_device == device:
         return device
     check(lib.mhs_init(int(device)))
+    if _inited_device is None:
+        # the library's streams (the CU-masked ones of mhs_fit_reserve_cus among them) are destroyed while the HIP
+        # runtime is still whole: left to process teardown they crash rocprofv3's finalisation
+        atexit.register(_shutdown)
     _inited_device = device
     return device
+
+
+def _shutdown() -> None:
+    global _inited_device
+    if _lib is not None and _inited_device is not None:
+        _lib.mhs_shutdown()
+        _inited_device = None
 
 
 def lib() -> C.CDLL:

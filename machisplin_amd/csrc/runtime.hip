@@ -144,6 +144,10 @@ int mhs_init(int device) {
     }
     c.device = device;
     c.ready = true;
+    // streams (CU-masked ones among them) are destroyed while the HIP runtime is still whole, whatever the host forgets:
+    // handlers run in reverse order of registration, so this one runs before the runtime's own
+    static bool registered = false;
+    if (!registered) { registered = true; std::atexit([] { (void)mhs_shutdown(); }); }
     return MHS_OK;
 }
 

@@ -16,6 +16,9 @@ find /tmp/kst -name "*domain_stats.csv" -exec cp {} $O/cfg3_rocprofv3_domain_sta
 head -8 $O/cfg3_rocprofv3_kernel_stats.csv | cut -c1-150
 timeout 600 python tools/fit_speed.py 500 2000 5000 10000 20000 2>&1 | grep -v "^/opt" > $O/fit_speed.txt; cat $O/fit_speed.txt
 bash tools/fit_chain_gaps.sh > $O/fit_chain_gaps.txt 2>&1
+timeout 600 python tools/fit_beside_member.py 2>&1 | grep "reserve\|alone" > $O/fit_beside_member.txt
+timeout 600 python tools/learn_fit_speed.py 5000 20000 2>&1 | grep -v "^/opt" > $O/learn_fit_speed.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/cu_mask_probe.hip -o /tmp/cu_mask_probe 2>/dev/null && /tmp/cu_mask_probe > $O/cu_mask_probe.txt 2>&1
 bash tools/r02_chol_timeline.sh 20000 > $O/chol_timeline_n20000.txt 2>&1
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys
