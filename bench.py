@@ -217,10 +217,12 @@ class Workload:
         pmc = {}
         try:  # bytes per cell measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled as
             # the gfx950 guide prescribes) on tools/pmc_probe; committed under profiles/
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc_file = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"))
+                            if os.path.exists(p))
+            with open(pmc_file) as f:
                 for kn, d in json.load(f)["kernels"].items():
                     pmc[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         for r in rows:
             r["frac"] = r["achieved"] / r["peak"]
