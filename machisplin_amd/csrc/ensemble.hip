@@ -784,6 +784,10 @@ __device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((
 // BIG: trees of more than 8191 nodes (or whose predictions do not fit beside the keys): the children words hold
 // node INDICES (one extra shift per level) and the node predictions stay in global memory -- one read per tree
 // and walk -- so that a 12 000-node tree of a 20 000-station forest (96 KB of nodes) still walks in LDS.
+// walks per lane for the "log2r" code the forest tables are built with: 1 -> 2, 2 -> 4, 3 -> 5 (the double-buffered
+// kernel only: five walks' keys still fit beside two tree buffers when the trees are small)
+__host__ __device__ constexpr int rf_walks(int code) { return code == 3 ? 5 : (1 << code); }
+
 template <int LOG2R, bool BIG>
 __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__ gnodes,
                                                        const double *__restrict__ glval,
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                                                           int max_nodes, int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
                                                           double *__restrict__ out) {
-    constexpr int R = 1 << LOG2R;
+    constexpr int R = rf_walks(LOG2R);
     constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned buf_bytes = (unsigned)max_nodes * 8u;           // one tree's nodes; the two buffers sit at 0 and buf_bytes
@@ -1507,12 +1511,13 @@ static size_t rf_walk_lds(const mhs_model *m, int log2r, bool big) {
 // the double-buffered kernel: two node buffers within 16-bit byte addresses, predictions in global memory
 static size_t rf_walk_db_lds(const mhs_model *m, int log2r) {
     const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
-    return tree_bytes + (size_t)1024 * (((size_t)m->p << log2r) | 1) * 4;
+    return tree_bytes + (size_t)1024 * (((size_t)m->p * rf_walks(log2r)) | 1) * 4;
 }
 static int rf_walk_db_log2r(const mhs_model *m) {
     if (m->rf_max_nodes > 4095) return -1;
-    for (int l2 = 2; l2 >= 1; --l2)
-        if (((m->p << l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
+    static const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
+    for (int l2 = five ? 3 : 2; l2 >= 1; --l2)
+        if ((m->p * rf_walks(l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
     return -1;
 }
 
@@ -1549,7 +1554,7 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     for (int v = 0; v < m->p; ++v)
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
     std::vector<unsigned long long> rec(nn ? nn : 1, 0ull);
-    const unsigned R = 1u << log2r;
+    const unsigned R = (unsigned)rf_walks(log2r);
     if (form == RF_COMPACT) {
         // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
         // A child field holds the LDS byte address of a split child's record or, for a terminal child, D + its node
@@ -1627,14 +1632,19 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
             return MHS_OK;
         }
     }
+    if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane
+        const int dl = rf_walk_db_log2r(m);
+        if (dl > 0) log2r = dl;
+    }
     TreeTables tt;
     if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big ? RF_BIG : RF_SMALL, key64, &tt)) return rc;
-    const int R = 1 << log2r;
+    const int R = rf_walks(log2r);
     const int64_t part = (total + R - 1) / R;
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
     if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
         const size_t dbytes = rf_walk_db_lds(m, log2r);
-        auto dk = log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
+        auto dk = log2r == 3 ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
+                : log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
                              : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
         hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
