@@ -49,6 +49,8 @@ struct Context {
     double *exp_tab = nullptr;   // device, 4096 entries 2^(j/4096) (svr_kernel)
     double *points_arena = nullptr;       // grow-only device scratch of mhs_residual_points
     size_t points_arena_cap = 0;          // in doubles
+    char *mosaic_arena = nullptr;         // grow-only device scratch of mhs_mosaic_feather_dev (sums, counts, seam boxes)
+    size_t mosaic_arena_cap = 0;          // in bytes
     double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

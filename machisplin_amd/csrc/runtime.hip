@@ -157,6 +157,7 @@ int mhs_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
+    if (c.mosaic_arena) (void)hipFree(c.mosaic_arena);
     if (c.points_arena) (void)hipFree(c.points_arena);
     if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.upload) { (void)hipStreamSynchronize(c.upload); (void)hipStreamDestroy(c.upload); }

@@ -9,6 +9,7 @@
 // (V73:740-746, 783-806, 853-895, 1419-1546) and the Step-5 station gather (V73:910).
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -285,11 +286,33 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
         MHS_REQUIRE(0 <= tw[h].r0 && tw[h].r0 < tw[h].r1 && tw[h].r1 <= g->nrow && 0 <= tw[h].c0 &&
                     tw[h].c0 < tw[h].c1 && tw[h].c1 <= g->ncol && tile_dev[h], "bad tile window");
     }
-    DevBuf<double> bsum, ssum;
-    DevBuf<unsigned char> bcnt, scnt;
-    DevBuf<int> box;
-    MHS_HIP(bsum.alloc((size_t)cells)); MHS_HIP(ssum.alloc((size_t)cells));
-    MHS_HIP(bcnt.alloc((size_t)cells)); MHS_HIP(scnt.alloc((size_t)cells));
+    // 18 bytes per cell of scratch (two sums, two counts) + the seams' boxes, from a grow-only arena: a hipMalloc /
+    // hipFree pair of 1.8 GB per call cost 40-60 ms per merged layer at 10 000^2 cells (and the free synchronises the
+    // device).  One call at a time uses it; the call ends with a stream synchronisation.
+    static std::mutex arena_mu;
+    std::lock_guard<std::mutex> arena_lock(arena_mu);
+    struct Span { double *p; };
+    struct SpanB { unsigned char *p; };
+    struct SpanI { int *p; };
+    Span bsum, ssum;
+    SpanB bcnt, scnt;
+    SpanI box;
+    {
+        Context &c = ctx();
+        const size_t ns_max = (size_t)seam_list(nRx, nCx).size();
+        const size_t need = (size_t)cells * 18 + 16 * (ns_max + 1) + 64;
+        if (need > c.mosaic_arena_cap) {
+            if (c.mosaic_arena) { (void)hipStreamSynchronize(s); (void)hipFree(c.mosaic_arena); c.mosaic_arena = nullptr; c.mosaic_arena_cap = 0; }
+            MHS_HIP(hipMalloc((void **)&c.mosaic_arena, need));
+            c.mosaic_arena_cap = need;
+        }
+        char *a = c.mosaic_arena;
+        bsum.p = (double *)a; a += sizeof(double) * (size_t)cells;
+        ssum.p = (double *)a; a += sizeof(double) * (size_t)cells;
+        box.p = (int *)a; a += 16 * (ns_max + 1);
+        bcnt.p = (unsigned char *)a; a += (size_t)cells;
+        scnt.p = (unsigned char *)a;
+    }
     MHS_HIP(hipMemsetAsync(bsum.p, 0, sizeof(double) * cells, s));
     MHS_HIP(hipMemsetAsync(ssum.p, 0, sizeof(double) * cells, s));
     MHS_HIP(hipMemsetAsync(bcnt.p, 0, (size_t)cells, s));
@@ -304,7 +327,6 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
     std::vector<Seam> seams = seam_list(nRx, nCx);
     const size_t ns = seams.size();
     if (n > 1 && ns > 0) {
-        MHS_HIP(box.alloc(4 * ns));
         std::vector<int> hbox(4 * ns);
         std::vector<Win> inter(ns);
         std::vector<char> has(ns, 0);
@@ -357,7 +379,7 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
     hipLaunchKernelGGL(compose_kernel, dim3(nblk(cells)), dim3(256), 0, s, ssum.p, scnt.p, bsum.p, bcnt.p,
                        g->nrow, g->ncol, out_dev, ld);
     MHS_HIP(hipGetLastError());
-    MHS_HIP(hipStreamSynchronize(s));  // the temporaries are freed on return
+    MHS_HIP(hipStreamSynchronize(s));  // the arena is free for the next call on return
     return MHS_OK;
 }
 
