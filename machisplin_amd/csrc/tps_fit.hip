@@ -1758,12 +1758,22 @@ __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__rest
     __shared__ double pbuf[2][16][BW];
     const double *B = A + (int64_t)off * ld + off;
     int ph = 0;
+    // the next reflector's element and tau are requested a step ahead: a step is two barriers, not a trip to L2 as well
+    double xn = 0.0, tn = 0.0;
+    if (m >= 3) {
+        const int k0 = m - 3;
+        if (threadIdx.x >= 1 && (int)threadIdx.x < m - k0 - 1) xn = B[(int64_t)k0 * ld + (k0 + 1) + threadIdx.x];
+        tn = tau[k0];
+    }
     for (int k = m - 3; k >= 0; --k) {
         const int t = m - k - 1;
-        const double tk = tau[k];
-        const double *x = B + (int64_t)k * ld + (k + 1);
+        const double tk = tn, xk = xn;
+        if (k > 0) {
+            if (threadIdx.x >= 1 && (int)threadIdx.x < t + 1) xn = B[(int64_t)(k - 1) * ld + k + threadIdx.x];
+            tn = tau[k - 1];
+        }
         double vi = 0.0, qi = 0.0;
-        if (threadIdx.x < t) { vi = threadIdx.x == 0 ? 1.0 : x[threadIdx.x]; qi = q[k + 1 + threadIdx.x]; }
+        if (threadIdx.x < t) { vi = threadIdx.x == 0 ? 1.0 : xk; qi = q[k + 1 + threadIdx.x]; }
         double red[1] = {vi * qi};
         wave_publish<1>(red, pbuf[ph]);
         __syncthreads();
