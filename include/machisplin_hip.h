@@ -109,6 +109,14 @@ MHS_API int mhs_timer_stop(void *stream, double *elapsed_ms);
  * GCV search run on the host.                                                   */
 MHS_API int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda,
                 int gcv_mode, mhs_tps **out);
+/* Several response layers on one station table (the layer loop of machisplin.mltps, V73:176-957: BIO 1..12 on the same
+ * stations; V73:154 keeps the same rows for every layer): B = Q2'KQ2 and its reduction depend on the coordinates only,
+ * yet every fields::Tps call reduces it again.  Between mhs_tps_reduction_cache(1) and mhs_tps_reduction_cache(0),
+ * GCV fits on the small route (<= 259 stations after replicate collapse: the reference-tiled mode's tiles) keep the
+ * reduction of each station set (reflectors, tridiagonal, projected rows) and later fits of the SAME coordinates and
+ * replicate weights send only their right-hand side through it -- bit for bit the result of a full fit.  (0) frees
+ * everything that was kept.  Scope it to one multi-layer call: nothing is reused across calls of the host's loop.    */
+MHS_API int mhs_tps_reduction_cache(int enable);
 /* Host-only helper of the fit (no GPU needed; exported so the host logic is testable on
  * a CPU box): given the tridiagonal form T = P'(Q2'KQ2)P (diag[m], offdiag[m-1]) and
  * g = P'Q2'y, evaluate fields' GCV criterion / choose lambda (NaN => search, gcv_mode)

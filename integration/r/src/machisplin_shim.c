@@ -217,6 +217,12 @@ SEXP mhsr_tiles_merge(SEXP geom, SEXP tiles, SEXP win, SEXP in_ncol, SEXP in_nro
     return out;
 }
 
+/* bracket of the layer loop of machisplin.mltps (V73:176-957): fits of later layers reuse the tiles' reductions */
+SEXP mhsr_tps_reduction_cache(SEXP enable) {
+    chk(mhs_tps_reduction_cache(Rf_asInteger(enable)));
+    return enable;
+}
+
 /* library.dynam.unload / R exit: the library's streams go while the HIP runtime is still whole (mhs_init also registers
  * an atexit handler, so this is belt and braces) */
 void R_unload_machisplin_hip(DllInfo *info) {

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mhs_shutdown": (C.c_int, []),
     "mhs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mhs_sync": (C.c_int, [_vp]),
+    "mhs_tps_reduction_cache": (C.c_int, [C.c_int]),
     "mhs_fit_reserve_cus": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "mhs_timer_start": (C.c_int, [_vp]),
     "mhs_timer_stop": (C.c_int, [_vp, _dp]),

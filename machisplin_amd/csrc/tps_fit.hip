@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "devmath.h"
@@ -1784,6 +1786,59 @@ __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__rest
     }
 }
 
+// g <- Q' g = H_{m-3} ... H_0 g with the reflectors tridiag_small_kernel left: the updates that kernel applies to g while it
+// reduces the matrix, in the same order and through the same reduction tree (the second slot of its two-value
+// reduction), so a right-hand side sent through here equals bit for bit one that was carried through the reduction.
+// Used when the reduction of a station set is reused for another response layer (mhs_tps_reduction_cache).
+__global__ __launch_bounds__(1024) void tridiag_qt_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
+                                                          const double *__restrict__ tau, double *__restrict__ g) {
+    __shared__ double pbuf[2][16][BW];
+    const double *B = A + (int64_t)off * ld + off;
+    int ph = 0;
+    double xn = 0.0, tn = 0.0;
+    if (m >= 3) {
+        if (threadIdx.x >= 1 && (int)threadIdx.x < m - 1) xn = B[1 + threadIdx.x];
+        tn = tau[0];
+    }
+    for (int k = 0; k < m - 2; ++k) {
+        const int t = m - k - 1;
+        const double tk = tn, xk = xn;
+        if (k + 1 < m - 2) {
+            if (threadIdx.x >= 1 && (int)threadIdx.x < t - 1) xn = B[(int64_t)(k + 1) * ld + (k + 2) + threadIdx.x];
+            tn = tau[k + 1];
+        }
+        double vi = 0.0, gi = 0.0;
+        if ((int)threadIdx.x < t) { vi = threadIdx.x == 0 ? 1.0 : xk; gi = g[k + 1 + threadIdx.x]; }
+        double red2[2] = {0.0, vi * gi};
+        wave_publish<2>(red2, pbuf[ph]);
+        __syncthreads();
+        const double vg = lane_value(block_total<2, 16>(pbuf[ph]), 1);
+        ph ^= 1;
+        if ((int)threadIdx.x < t) g[k + 1 + threadIdx.x] = gi - tk * vg * vi;
+        __syncthreads();
+    }
+}
+
+// The reduction of one station set (small route), kept for the other response layers of the same table:
+// reflectors + tau on the device, the tridiagonal and the three projected rows on the host.
+struct ReductionEntry {
+    int64_t n = 0;
+    int m = 0;
+    std::vector<double> uv, sw, td, te, Atop;
+    double *refl = nullptr, *tau = nullptr;      // device: m x m (ld = m), m
+};
+struct ReductionCache {
+    std::mutex mu;
+    bool enabled = false;
+    std::unordered_multimap<uint64_t, ReductionEntry *> map;
+};
+static ReductionCache g_rcache;
+static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h) {
+    const unsigned char *c = (const unsigned char *)p;
+    for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 // single block: solve L L' x = b in place (L = lower triangle of A[off:off+m, off:off+m])
 __global__ __launch_bounds__(1024) void potrs_kernel(const double *__restrict__ A, int64_t ld, int off,
                                                      int m, double *__restrict__ x) {
@@ -1994,11 +2049,30 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         ArenaCarver real{L.arena};
         layout(real);
     }
+    // mhs_tps_reduction_cache: the reduction of this station set may already be there (another response layer)
+    const bool small_route = !fixed && m <= TRI_SMALL_CUT && m >= 3;
+    const ReductionEntry *hit = nullptr;
+    uint64_t rkey = 0;
+    bool rcache_on = false;
+    if (small_route) {
+        std::lock_guard<std::mutex> lk(g_rcache.mu);
+        rcache_on = g_rcache.enabled;
+        if (rcache_on) {
+            rkey = fnv1a(sw.data(), sizeof(double) * sw.size(), fnv1a(uv.data(), sizeof(double) * uv.size(), 1469598103934665603ull ^ (uint64_t)n));
+            auto range = g_rcache.map.equal_range(rkey);
+            for (auto it = range.first; it != range.second && !hit; ++it)
+                if (it->second->n == n && it->second->uv == uv && it->second->sw == sw) hit = it->second;
+        }
+    }
+    if (!hit) {
     MHS_HIP(hipMemcpyAsync(duv.p, uv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(dsw.p, sw.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+    }
 
     static const bool fused_proj = getenv("MHS_PROJ_PASSES") == nullptr;
-    if (fused_proj) {
+    if (hit) {
+        // nothing to build: the reflectors, the tridiagonal and the projected rows come from the cache
+    } else if (fused_proj) {
         // A = Q'KQ = K - W V' - V W' in two passes over kernel entries computed on the fly (see gram_y_kernel)
         for (int k = 0; k < 3; ++k)
             MHS_HIP(hipMemcpyAsync(v3buf.p + (size_t)k * n, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -2058,8 +2132,10 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     lap("gram + projection");
     // rows 0..2 of the projected matrix, columns 3..n-1 (by symmetry: columns 0..2, rows 3..)
     std::vector<double> Atop(3 * (size_t)m);
-    for (int k = 0; k < 3; ++k)
-        MHS_HIP(hipMemcpyAsync(&Atop[(size_t)k * m], A.p + (int64_t)k * ld + 3, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+    if (hit) Atop = hit->Atop;
+    else
+        for (int k = 0; k < 3; ++k)
+            MHS_HIP(hipMemcpyAsync(&Atop[(size_t)k * m], A.p + (int64_t)k * ld + 3, sizeof(double) * m, hipMemcpyDeviceToHost, s));
 
     std::vector<double> c2((size_t)m);
     double lam = lambda, gcv = NAN, eff_df = NAN;
@@ -2070,18 +2146,44 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (int rc = cholesky_solve_mfma(L, A.p, ld, 3, m, gbuf.p, chw.p, info_dev)) return rc;
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
-    } else if (m <= TRI_SMALL_CUT && m >= 3) {
+    } else if (small_route) {
         // small matrix: single-block tridiagonalisation + tridiagonal GCV on the host + single-block back-transform
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
         double *dd_dev = pbuf.p, *ee_dev = wbuf.p;
-        hipLaunchKernelGGL(tridiag_small_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, dd_dev, ee_dev, tau.p, gbuf.p);
-        MHS_HIP(hipGetLastError());
         std::vector<double> td((size_t)m), te((size_t)m), g((size_t)m), q((size_t)m);
-        MHS_HIP(hipMemcpyAsync(td.data(), dd_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
-        MHS_HIP(hipMemcpyAsync(te.data(), ee_dev, sizeof(double) * (m - 1), hipMemcpyDeviceToHost, s));
+        const double *refl = A.p;
+        const double *tau_dev = tau.p;
+        int64_t refl_ld = ld;
+        int refl_off = 3;
+        if (hit) {
+            refl = hit->refl; tau_dev = hit->tau; refl_ld = m; refl_off = 0;
+            td = hit->td; te = hit->te;
+            hipLaunchKernelGGL(tridiag_qt_kernel, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
+            MHS_HIP(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(tridiag_small_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, dd_dev, ee_dev, tau.p, gbuf.p);
+            MHS_HIP(hipGetLastError());
+            MHS_HIP(hipMemcpyAsync(td.data(), dd_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipMemcpyAsync(te.data(), ee_dev, sizeof(double) * (m - 1), hipMemcpyDeviceToHost, s));
+        }
         MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
-        lap("tridiagonalisation (GPU, one block)");
+        lap(hit ? "Q'g with the cached reflectors" : "tridiagonalisation (GPU, one block)");
+        if (!hit && rcache_on) {      // keep the reduction for the next response layer on these stations
+            ReductionEntry *e = new ReductionEntry();
+            e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->td = td; e->te = te; e->Atop = Atop;
+            bool ok = hipMalloc((void **)&e->refl, sizeof(double) * (size_t)m * m) == hipSuccess &&
+                      hipMalloc((void **)&e->tau, sizeof(double) * (size_t)m) == hipSuccess;
+            ok = ok && hipMemcpy2DAsync(e->refl, sizeof(double) * m, A.p + (int64_t)3 * ld + 3, sizeof(double) * ld, sizeof(double) * m,
+                                        (size_t)m, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(e->tau, tau.p, sizeof(double) * m, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipStreamSynchronize(s) == hipSuccess;
+            if (ok) {
+                std::lock_guard<std::mutex> lk(g_rcache.mu);
+                if (g_rcache.enabled) { g_rcache.map.emplace(rkey, e); e = nullptr; }
+            }
+            if (e) { if (e->refl) (void)hipFree(e->refl); if (e->tau) (void)hipFree(e->tau); delete e; (void)hipGetLastError(); }
+        }
         TridiagGcv tg;
         tg.a = td.data(); tg.b = te.data(); tg.g = g.data(); tg.m = m; tg.n = n; tg.N = N; tg.pure_ss = pure_ss;
         lam = tg.find_lambda(gcv_mode);
@@ -2089,7 +2191,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         tg.eval(lam, &gcv, &eff_df, q.data());
         lap("GCV search (host, tridiagonal)");
         MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(tridiag_back_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, tau.p, gbuf.p);
+        hipLaunchKernelGGL(tridiag_back_kernel, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
         MHS_HIP(hipGetLastError());
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
@@ -2243,6 +2345,20 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     return MHS_OK;
 }
 }  // namespace mhs
+
+extern "C" int mhs_tps_reduction_cache(int enable) {
+    if (int rc = require_ready()) return rc;
+    std::vector<ReductionEntry *> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_rcache.mu);
+        if (enable) { g_rcache.enabled = true; return MHS_OK; }
+        g_rcache.enabled = false;
+        for (auto &kv : g_rcache.map) dead.push_back(kv.second);
+        g_rcache.map.clear();
+    }
+    for (ReductionEntry *e : dead) { (void)hipFree(e->refl); (void)hipFree(e->tau); delete e; }
+    return MHS_OK;
+}
 
 extern "C" int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                            mhs_tps **out) {

@@ -186,9 +186,11 @@ def mltps(stack: RasterStack, int_values, fitted, tps: bool = True, tile_edge: i
         raise ValueError("fitted must hold one entry per response column of int_values")
     keep = complete_cases(stack, int_values)   # once, over every column of the table (V73:154)
     omega = []
-    for i, f in enumerate(fitted):
-        out = mltps_predict(stack, int_values[:, :2], int_values[:, 2 + i], f["models"], f["weights"], f["wt_total"],
-                            tps=tps, tile_edge=tile_edge, lambda_=lambda_, gcv_mode=gcv_mode, keep=keep)
-        out["n_layers"] = n_layers
-        omega.append(out)
+    from .tps import reduction_cache
+    with reduction_cache():      # every layer fits the same stations: the tiles' reductions are built once (bit-identical fits)
+        for i, f in enumerate(fitted):
+            out = mltps_predict(stack, int_values[:, :2], int_values[:, 2 + i], f["models"], f["weights"], f["wt_total"],
+                                tps=tps, tile_edge=tile_edge, lambda_=lambda_, gcv_mode=gcv_mode, keep=keep)
+            out["n_layers"] = n_layers
+            omega.append(out)
     return omega

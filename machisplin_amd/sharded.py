@@ -520,10 +520,15 @@ class TileShardedMltps:
 
     def step(self):
         torch = self.torch
-        for t, l in self.my_units():
-            _, slot = unit_owner(t, l, self.n_tiles, self.world)
-            rsq = self.ops.tile_layer(t, l, self._plane(self.mine, slot, t))
-            self.mine[slot, -2:] = torch.tensor([float(rsq[0]), float(rsq[1])], dtype=torch.float64).to(self.mine.device)
+        # one scope per step: a tile's response layers share its stations, so the Step-3 tiles' reductions are built by
+        # the first layer this rank runs on the tile and reused by its other layers (ops.reduction_cache; bit-identical
+        # fits) -- and nothing is carried from one step to the next
+        scope = getattr(self.ops, "reduction_cache", None) or contextlib.nullcontext
+        with scope():
+            for t, l in self.my_units():
+                _, slot = unit_owner(t, l, self.n_tiles, self.world)
+                rsq = self.ops.tile_layer(t, l, self._plane(self.mine, slot, t))
+                self.mine[slot, -2:] = torch.tensor([float(rsq[0]), float(rsq[1])], dtype=torch.float64).to(self.mine.device)
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.full, self.mine)      # the one exchange of the path
         stats = self.full[:, -2:].cpu().numpy()
@@ -582,6 +587,10 @@ class HipTileOps:
         out.copy_(res["final"])
         self.unit_ms[(t, l)] = (time.perf_counter() - t0) * 1e3
         return res["rsq_model"], res.get("rsq_final", float("nan"))
+
+    def reduction_cache(self):
+        from .tps import reduction_cache
+        return reduction_cache()
 
     def merge(self, l, planes):
         from . import tiles as tl

@@ -9,6 +9,7 @@ arguments.  There is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -121,6 +122,19 @@ def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None):
 
 
 EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD = 0, 1, 2
+
+
+@contextlib.contextmanager
+def reduction_cache():
+    """Scope of mhs_tps_reduction_cache: inside it, small GCV fits (the reference-tiled mode's tiles) of a station set
+    that has been fitted before -- another response layer of the same table -- reuse its reduction and send only
+    their right-hand side through it; same coefficients bit for bit.  Everything kept is freed on exit."""
+    _lib.init()
+    _lib.check(_lib.lib().mhs_tps_reduction_cache(1))
+    try:
+        yield
+    finally:
+        _lib.check(_lib.lib().mhs_tps_reduction_cache(0))
 
 
 def eval_mode(mode: int) -> None:

@@ -127,3 +127,29 @@ def test_delayed_update_scheme_equals_the_eager_one(hip, n, monkeypatch):
     assert _rel(delayed.c, ref["c"]) < 1e-8 and _rel(delayed.d, ref["d"]) < 1e-8
     want = otps.fit(xy, y)
     assert abs(delayed.lambda_ - want["lambda"]) < 1e-8 * want["lambda"]
+
+
+@pytest.mark.parametrize("n", [12, 131, 250])
+def test_reduction_cache_refits_are_bit_identical(hip, n):
+    """mhs_tps_reduction_cache: a second response on the same stations reuses the reduction (reflectors, tridiagonal,
+    projected rows) and sends only its right-hand side through it -- the coefficients, lambda, GCV and effective
+    degrees of freedom are those of a full fit, bit for bit; other stations or replicate weights do not hit."""
+    from machisplin_amd import tps
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 1, (n, 2))
+    ys = [np.sin(6 * xy[:, 0]) * np.cos(5 * xy[:, 1]) + 0.1 * rng.standard_normal(n) for _ in range(3)]
+    full = [hip.Tps(xy, y) for y in ys]
+    with tps.reduction_cache():
+        cached = [hip.Tps(xy, y) for y in ys]                      # the first builds the entry, the others hit it
+        other = hip.Tps(xy[::-1].copy(), ys[0][::-1].copy())        # other order of the stations: another entry
+        dup_xy = np.vstack([xy, xy[:3]]); dup_y = np.concatenate([ys[1], ys[1][:3] + 0.2])
+        dup = hip.Tps(dup_xy, dup_y)                                # replicates: other weights, no hit
+    for a, b in zip(full, cached):
+        assert a.lambda_ == b.lambda_ and a.gcv == b.gcv and a.eff_df == b.eff_df
+        assert np.array_equal(a.c, b.c) and np.array_equal(a.d, b.d)
+    ref = hip.Tps(xy[::-1].copy(), ys[0][::-1].copy())
+    assert np.array_equal(other.c, ref.c) and other.lambda_ == ref.lambda_
+    ref_dup = hip.Tps(dup_xy, dup_y)
+    assert np.array_equal(dup.c, ref_dup.c) and dup.lambda_ == ref_dup.lambda_
+    again = hip.Tps(xy, ys[2])                                      # after the scope: a plain fit again
+    assert np.array_equal(again.c, full[2].c)
