@@ -1755,9 +1755,13 @@ __global__ __launch_bounds__(1024) void tridiag_small_kernel(double *__restrict_
 }
 
 // q <- Q q = H_0 H_1 ... H_{m-3} q with the reflectors tridiag_small_kernel left below the subdiagonal
-__global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
-                                                            const double *__restrict__ tau, double *__restrict__ q) {
-    __shared__ double pbuf[2][16][BW];
+// NW waves: 16, or 4 when m <= 256 (a row per thread is all the kernel uses; the waves beyond the rows contribute exact
+// zeros to every sum, so both sizes give the same bits) -- a 256-thread block finds a slot beside grid-filling kernels
+// as soon as ONE of their blocks retires, a 1024-thread block needs a whole CU to drain
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void tridiag_back_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
+                                                               const double *__restrict__ tau, double *__restrict__ q) {
+    __shared__ double pbuf[2][NW][BW];
     const double *B = A + (int64_t)off * ld + off;
     int ph = 0;
     // the next reflector's element and tau are requested a step ahead: a step is two barriers, not a trip to L2 as well
@@ -1779,7 +1783,7 @@ __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__rest
         double red[1] = {vi * qi};
         wave_publish<1>(red, pbuf[ph]);
         __syncthreads();
-        const double vq = lane_value(block_total<1, 16>(pbuf[ph]), 0);
+        const double vq = lane_value(block_total<1, NW>(pbuf[ph]), 0);
         ph ^= 1;
         if (threadIdx.x < t) q[k + 1 + threadIdx.x] = qi - tk * vq * vi;
         __syncthreads();
@@ -1790,9 +1794,10 @@ __global__ __launch_bounds__(1024) void tridiag_back_kernel(const double *__rest
 // reduces the matrix, in the same order and through the same reduction tree (the second slot of its two-value
 // reduction), so a right-hand side sent through here equals bit for bit one that was carried through the reduction.
 // Used when the reduction of a station set is reused for another response layer (mhs_tps_reduction_cache).
-__global__ __launch_bounds__(1024) void tridiag_qt_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
-                                                          const double *__restrict__ tau, double *__restrict__ g) {
-    __shared__ double pbuf[2][16][BW];
+template <int NW>      // 16 waves, or 4 when m <= 256: see tridiag_back_kernel
+__global__ __launch_bounds__(NW * 64) void tridiag_qt_kernel(const double *__restrict__ A, int64_t ld, int off, int m,
+                                                             const double *__restrict__ tau, double *__restrict__ g) {
+    __shared__ double pbuf[2][NW][BW];
     const double *B = A + (int64_t)off * ld + off;
     int ph = 0;
     double xn = 0.0, tn = 0.0;
@@ -1812,7 +1817,7 @@ __global__ __launch_bounds__(1024) void tridiag_qt_kernel(const double *__restri
         double red2[2] = {0.0, vi * gi};
         wave_publish<2>(red2, pbuf[ph]);
         __syncthreads();
-        const double vg = lane_value(block_total<2, 16>(pbuf[ph]), 1);
+        const double vg = lane_value(block_total<2, NW>(pbuf[ph]), 1);
         ph ^= 1;
         if ((int)threadIdx.x < t) g[k + 1 + threadIdx.x] = gi - tk * vg * vi;
         __syncthreads();
@@ -2158,7 +2163,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (hit) {
             refl = hit->refl; tau_dev = hit->tau; refl_ld = m; refl_off = 0;
             td = hit->td; te = hit->te;
-            hipLaunchKernelGGL(tridiag_qt_kernel, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
+            if (m <= 256) hipLaunchKernelGGL(tridiag_qt_kernel<4>, dim3(1), dim3(256), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
+            else hipLaunchKernelGGL(tridiag_qt_kernel<16>, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
             MHS_HIP(hipGetLastError());
         } else {
             hipLaunchKernelGGL(tridiag_small_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, 3, m, dd_dev, ee_dev, tau.p, gbuf.p);
@@ -2191,7 +2197,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         tg.eval(lam, &gcv, &eff_df, q.data());
         lap("GCV search (host, tridiagonal)");
         MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(tridiag_back_kernel, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
+        if (m <= 256) hipLaunchKernelGGL(tridiag_back_kernel<4>, dim3(1), dim3(256), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
+        else hipLaunchKernelGGL(tridiag_back_kernel<16>, dim3(1), dim3(1024), 0, s, refl, refl_ld, refl_off, m, tau_dev, gbuf.p);
         MHS_HIP(hipGetLastError());
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
