@@ -54,6 +54,13 @@ struct Context {
     double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Pipelined host-pointer entry points (what the R shim calls: rasters live in host RAM, V73:468-606): persistent,
+    // grow-only device arena + copy streams + events, so that a call makes no hipMalloc / hipFree (a device-wide
+    // synchronisation each) and row band k + 1 travels host -> device, band k - 1 device -> host, under band k's kernels
+    char *pipe_arena = nullptr;
+    size_t pipe_arena_cap = 0;
+    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_comp = nullptr;
+    hipEvent_t pipe_in[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_out[2] = {nullptr, nullptr};
     hipStream_t upload = nullptr;         // non-blocking stream of the small blocking host -> device copies (h2d_sync)
     int n_cu = 0;
     // mhs_fit_reserve_cus: a stream whose CU mask leaves compute units out, and the two events that order a kernel
@@ -64,6 +71,8 @@ struct Context {
     std::vector<uint32_t> comp_mask;      // the reserved units' mask (for lanes created later)
     hipEvent_t mask_ev0 = nullptr, mask_ev1 = nullptr;
 };
+std::mutex &pipe_mutex();             // one pipelined host-pointer call at a time
+int host_pipe(size_t arena_bytes);    // streams / events on first use; grows the arena (grow-only) to at least arena_bytes
 std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences
 Context &ctx();
 int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)

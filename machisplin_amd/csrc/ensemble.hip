@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "common.h"
 #include "devmath.h"
@@ -76,6 +77,9 @@ struct mhs_model {
     void *lut_sorted = nullptr;          // device, sorted distinct key-space thresholds, predictor after predictor
                                          // (float keys for float32 / int16 planes, double keys for float64 planes)
     int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
+    double *lut_rt = nullptr;            // device, the same leaf values with every tree's levels ordered uniform-first
+    int *lut_rt_meta = nullptr;          // device, LUT_RT_DW dwords per tree (gbm_lutreg_rt_kernel)
+    std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
     int n_trees_padded = 0;
@@ -759,6 +763,89 @@ __global__ __launch_bounds__(256, 5) void gbm_lutreg_kernel(const double *__rest
     }
 }
 
+// ROW-TILE form of the register kernel (round 3; S = 5, the reference's interaction depth, V73:493).  A wave owns 256
+// consecutive cells of ONE raster row (lane l: columns tile + l + 64 c, c = 0..3), so every split on LAT -- a
+// predictor of every model, V73:127-138 -- is WAVE-UNIFORM for all four cells of all 64 lanes, and so is every
+// padding level of a tree with fewer than 5 splits (its predicate is 0).  The geometry-dependent tables order each
+// tree's levels uniform-first (up to two of them; the leaf LUT is permuted to match, per tree): the K uniform
+// predicates are evaluated on the SCALAR unit (compare + select on the row's LAT rank, which sits in an SGPR) and
+// folded into the accumulator's start value, and only the NV = 5 - K per-cell levels run as packed vector
+// instructions -- 4 NV + 8 VALU per tree and 4 cells instead of 28.  The tree loop branches on NV (wave-uniform, scalar
+// branches); the 64-byte record of the next tree is fetched into SGPRs while this one is evaluated.  Same leaf values
+// added in the same tree order as gbm_lutreg_kernel and the generic walk: bit-identical results.
+// Record (16 dwords): c[5] float rank thresholds of the vector levels | NV | idx[5] VGPR offsets of their predictors |
+// uthr[5] int rank thresholds of the uniform levels (0 = never: a padding level).
+constexpr int LUT_RT_DW = 16;
+constexpr int LUT_RT_MAXK = 2;          // more uniform levels than this run as vector levels (their keys exist too)
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));   // one record
+
+template <bool K64>
+__global__ __launch_bounds__(256, 5) void gbm_lutreg_rt_kernel(const double *__restrict__ lut,
+                                                            const u64x8 *__restrict__ meta,
+                                                            const void *__restrict__ sorted,
+                                                            const int *__restrict__ sorted_off, int n_trees_padded,
+                                                            double init_f, int p, StackDev s, PredGeom g, int tiles_per_row,
+                                                            double weight, int accumulate,
+                                                            double *__restrict__ out) {
+    constexpr int S = 5;
+    static_assert((LUT_CHUNK << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *slut = (double *)smem;                                            // [LUT_CHUNK << S]
+    float *coarse = (float *)smem;
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (int64_t)g.nr * tiles_per_row;
+    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = tile < ntiles;
+    if (!live) tile = ntiles - 1;
+    const int trow = (int)(tile / tiles_per_row), tcol = (int)(tile - (int64_t)trow * tiles_per_row) * (64 * LUT_R);
+    int row[LUT_R], col[LUT_R];
+    bool na[LUT_R], ok[LUT_R];
+    double acc[LUT_R];
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c) {
+        const int cc = tcol + c * 64 + lane;
+        ok[c] = live && cc < g.nc;
+        row[c] = trow; col[c] = min(cc, g.nc - 1);
+        na[c] = false; acc[c] = 0.0;
+    }
+    float32v keys;
+    int latv = 0;
+#pragma unroll
+    for (int j = 0; j < LUT_REG_P; ++j) {
+        float r[LUT_R] = {0.f, 0.f, 0.f, 0.f};
+        if (j < p) {
+            if constexpr (K64) lut_ranks_t<LUT_R, 256, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+            else lut_ranks_t<LUT_R, 256, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+            if (j == s.C + 1) latv = (int)r[0];
+        }
+#pragma unroll
+        for (int c = 0; c < LUT_R; ++c) keys[j * LUT_R + c] = -r[c];
+    }
+    const int latrank = __builtin_amdgcn_readfirstlane(latv);      // the wave's row: one rank for all its cells
+    unsigned lut_base = 0u - 0x58000000u;                          // see gbm_lut_kernel
+    asm volatile("" : "+s"(lut_base));
+    for (int t0 = 0; t0 < n_trees_padded; t0 += LUT_CHUNK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < (LUT_CHUNK << S); e += 256) slut[e] = lut[((int64_t)t0 << S) + e];
+        __syncthreads();
+        // the chunk's 64 trees: hand-scheduled loop (tools/gen_gbm_rt_asm.py; the table carries one record past the end)
+        const u64x8 *mp = meta + t0;
+        asm volatile(
+#include "gbm_rt_loop.inc"
+            : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3])
+            : "{v[64:95]}"(keys), [mp] "s"(mp), [lat] "s"(latrank), [lb] "s"(lut_base)
+            : "memory", "scc",
+              "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+              "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+              "s68", "s69", "s70", "s71", "s72", "s73", "s74",
+              "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+              "v56", "v57", "v58", "v59");
+    }
+#pragma unroll
+    for (int c = 0; c < LUT_R; ++c)
+        if (ok[c] && !na[c]) emit(out, (int64_t)row[c] * g.ld_out + col[c], init_f + acc[c], weight, accumulate);
+}
+
 // ------------------------------------------------- randomForest: level-synchronous walk --
 // One tree at a time lives in LDS (from byte 0) as 8-byte node records plus the node predictions.
 // Terminals point at themselves, so every lane descends a fixed, wave-uniform number of levels (the
@@ -786,7 +873,7 @@ __device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((
 // and walk -- so that a 12 000-node tree of a 20 000-station forest (96 KB of nodes) still walks in LDS.
 // walks per lane for the "log2r" code the forest tables are built with: 1 -> 2, 2 -> 4, 3 -> 5 (the double-buffered
 // kernel only: five walks' keys still fit beside two tree buffers when the trees are small)
-__host__ __device__ constexpr int rf_walks(int code) { return code == 3 ? 5 : (1 << code); }
+__host__ __device__ constexpr int rf_walks(int code) { return code >= 3 ? code + 2 : (1 << code); }   // 1 2 4 | 5 6 7 8
 
 template <int LOG2R, bool BIG>
 __global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__ gnodes,
@@ -1051,6 +1138,246 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         __syncthreads();
         o = o1; o1 = o2; o2 = o3;
         levels = levels1; levels1 = levels2;
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        const int64_t i = i0 + c * part;
+        if (i0 < part && i < total)
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+
+// COMPACT records in TWO buffers (round 3) -- the form for trees whose split nodes fit twice beside the keys (a 5 000-
+// station forest: ~1 500 split records = 12 KB per tree).  Measured on cfg3, the double-buffered walk above sits at 7.4
+// LDS cycles per wave, level and walk against 4 conflict-free (ds_read_b64 + ds_read_b32, 2 cycles each): the rest is
+// bank conflicts of the random node reads, and a third of all reads are lanes parked on a terminal's self-loop, each
+// at its own random address.  With the split nodes alone in LDS every such lane reads the SAME all-zero record at D
+// (rf_walk_compact_kernel's state machine) -- identical addresses broadcast, they conflict with nobody -- and a tree is
+// half the bytes, so two of them leave room for the keys of more walks per lane (R = 6 at p = 5).  Buffers at 0 and
+// STRIDE (compile-time: the buffer rides in the ds_read's immediate offset, the records stay buffer-relative and need
+// no relocation; the tree loop is unrolled by two), the next tree global -> registers during the walk and registers ->
+// the other buffer after it, one barrier per tree, predictions one tree behind: rf_walk_db_kernel's pipeline.
+template <int RCODE, bool K64, int STRIDE>
+__global__ __launch_bounds__(1024) void rf_walk_cdb_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
+                                                           const int *__restrict__ tree_off, const int *__restrict__ coff,
+                                                           const int *__restrict__ depth, const void *__restrict__ sorted,
+                                                           const int *__restrict__ sorted_off, int n_trees, int p,
+                                                           StackDev s, PredGeom g, double weight, int accumulate,
+                                                           double *__restrict__ out) {
+    constexpr int R = rf_walks(RCODE);
+    constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // records per thread in flight
+    constexpr unsigned TREE_BYTES = 2u * STRIDE;
+    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && STRIDE <= 65535, "two buffers, the second inside the immediate offset");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *coarse = (float *)smem;
+    const unsigned stride = (unsigned)(p * R) | 1u;
+    const unsigned lane_base = TREE_BYTES + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R], pending[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * part;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
+    }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    __syncthreads();                                               // coarse table no longer needed
+    {
+        const int o = coff[0], cnt = coff[1] - o;
+        for (int e = threadIdx.x; e < cnt; e += 1024) ((uint2 *)smem)[e] = gnodes[o + e];
+    }
+    __syncthreads();
+    // scalars of the trees ahead are fetched early, as in rf_walk_db_kernel
+    int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
+    int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
+    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+    auto step = [&](auto slot_tag, const int t) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
+        const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
+        const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
+        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+        const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
+        uint2 pn[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = (int)threadIdx.x + q * 1024;
+            if (e < cnt1) pn[q] = gnodes[c1 + e];
+        }
+        unsigned node[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = 0u;
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const uint2v nd = *((__attribute__((address_space(3))) const uint2v *)(uintptr_t)min(node[c], D) + SLOT * (STRIDE / 8));
+                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                unsigned child;
+                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                    : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                node[c] = max(child, node[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            pending[c] = glval[o + (int)(node[c] - D)];
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = (int)threadIdx.x + q * 1024;
+            if (e < cnt1) *(uint2 *)(smem + (unsigned)(1 - SLOT) * STRIDE + (unsigned)e * 8u) = pn[q];
+        }
+        __syncthreads();
+        o = o1; o1 = o2;
+        c0 = c1; c1 = c2; c2 = c3;
+        levels = levels1; levels1 = levels2;
+    };
+    for (int t = 0; t < n_trees; t += 2) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        const int64_t i = i0 + c * part;
+        if (i0 < part && i < total)
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+
+// TRIPLE-buffered form (round 3): the double-buffered kernel above still meets at one s_barrier per tree, and the 16 waves
+// of a block do not finish a tree together (their random node reads conflict differently): measured, a quarter of that
+// kernel was waves waiting at the barrier for the slowest one while the LDS pipe -- the bound of the walk -- ran dry.
+// Here there is NO barrier in the tree loop.  Three node buffers at a compile-time STRIDE (the walk's ds_read_b64 carries
+// the buffer in its immediate offset, so the records hold buffer-relative child addresses and need no relocation; the
+// tree loop is unrolled by three); a wave that has walked tree t (buffer t % 3) parks its share of tree t + 2 in buffer
+// (t + 2) % 3 -- which held tree t - 1 -- and goes on to tree t + 1, which was parked during tree t - 1.  Two monotonic
+// LDS counters per buffer order this: walked[b] (+1 per wave and tree walked in b) guards the overwrite, staged[b] (+1
+// per wave and tree parked in b) guards the walk.  The LDS unit executes a wave's operations in order, so "parked,
+// then ds_add" and "last node read, then ds_add" need no fence; the polls are ds_read + s_waitcnt, normally satisfied at
+// the first read.  A wave may run up to a whole tree ahead of the slowest one.
+__device__ __forceinline__ void lds_wait_ge(unsigned addr, unsigned target) {
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ void lds_signal(unsigned addr) {      // the wave's first lane adds 1
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory");
+    else asm volatile("" ::: "memory");
+}
+
+template <int LOG2R, bool K64, int STRIDE>
+__global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restrict__ gnodes,
+                                                          const double *__restrict__ glval,
+                                                          const int *__restrict__ tree_off,
+                                                          const int *__restrict__ depth,
+                                                          const void *__restrict__ sorted,
+                                                          const int *__restrict__ sorted_off, int n_trees,
+                                                          int p, StackDev s, PredGeom g,
+                                                          double weight, int accumulate,
+                                                          double *__restrict__ out) {
+    constexpr int R = rf_walks(LOG2R);
+    constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // node records per thread in flight
+    constexpr unsigned TREE_BYTES = 3u * STRIDE;
+    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
+    constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
+    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
+    const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int row[R], col[R];
+    bool na[R];
+    double acc[R], pending[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        int64_t i = i0 + c * part;
+        if (i >= total) i = total - 1;
+        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
+    }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    __syncthreads();                                               // coarse table no longer needed
+    for (int t = 0; t < 2 && t < n_trees; ++t) {
+        const int o = tree_off[t], cnt = tree_off[t + 1] - o;
+        for (int e = threadIdx.x; e < cnt; e += 1024) *(uint2 *)(smem + (unsigned)t * STRIDE + (unsigned)e * 8u) = gnodes[o + e];
+    }
+    if (threadIdx.x < 8) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = threadIdx.x < 2 ? 16u : 0u;
+    __syncthreads();
+    auto step = [&](auto slot_tag, const int t) {
+        constexpr int SLOT = decltype(slot_tag)::value, SLOT2 = (SLOT + 2) % 3;
+        const int o = tree_off[t], levels = depth[t];
+        const bool more = t + 2 < n_trees;
+        const int o2 = more ? tree_off[t + 2] : 0, cnt2 = more ? tree_off[t + 3] - o2 : 0;
+        uint2 pn[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = threadIdx.x + q * 1024;
+            if (e < cnt2) pn[q] = gnodes[o2 + e];
+        }
+        lds_wait_ge(CNT + 4u * SLOT, 16u * (unsigned)(t / 3 + 1));      // tree t is parked
+        unsigned node[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = 0u;
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const uint2v nd = *((__attribute__((address_space(3))) const uint2v *)(uintptr_t)node[c] + SLOT * (STRIDE / 8));
+                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+            }
+        }
+        lds_signal(CNT + 16u + 4u * SLOT);                               // this wave has left tree t
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            pending[c] = glval[o + (int)(node[c] >> 3)];
+        }
+        if (more) {                                                      // uniform
+            lds_wait_ge(CNT + 16u + 4u * SLOT2, 16u * (unsigned)((t + 2) / 3));   // every wave has left tree t - 1
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = threadIdx.x + q * 1024;
+                if (e < cnt2) *(uint2 *)(smem + (unsigned)SLOT2 * STRIDE + (unsigned)e * 8u) = pn[q];
+            }
+            lds_signal(CNT + 4u * SLOT2);
+        }
+    };
+    for (int t = 0; t < n_trees; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, t + 2);
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
@@ -1400,7 +1727,8 @@ static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64
 enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomForest node records (build_rf_nodes_t)
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
-struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff; };
+struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
+                    const double *lut_rt; const int *lut_rt_meta; };
 
 // fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
 template <typename T>
@@ -1463,6 +1791,43 @@ static int build_lut_meta_t(mhs_model *m, const mhs_grid &grid, int C) {
             mt[6 + q] = v * 256 * LUT_R * (int)sizeof(float);
         }
     }
+    // row-tile tables (gbm_lutreg_rt_kernel, S = 5): per tree, up to LUT_RT_MAXK of the levels that are uniform along
+    // a raster row -- splits on LAT (predictor C + 1) and padding levels -- first, the other levels after them, the leaf
+    // LUT permuted to that order; one all-padding record past the last tree (the kernel fetches a tree ahead)
+    if (m->p <= LUT_REG_P && S == 5 && !m->lut_host.empty()) {
+        const int lat = C + 1 < m->p ? C + 1 : -2;
+        std::vector<int> rmeta(((size_t)m->n_trees_padded + 1) * LUT_RT_DW, 0);
+        std::vector<double> rlut(m->lut_host.size(), 0.0);
+        for (int t = 0; t <= m->n_trees_padded; ++t) {
+            int *mt = &rmeta[(size_t)t * LUT_RT_DW];
+            for (int q = 0; q < 5; ++q) { memcpy(&mt[q], &never, 4); mt[6 + q] = 0; mt[11 + q] = 0; }
+            mt[5] = S - LUT_RT_MAXK;            // padded trees: two uniform padding levels, three vector ones that read 0
+            if (t >= m->n_trees) continue;
+            int perm[6], K = 0, n = 0;
+            bool first[6] = {false, false, false, false, false, false};
+            for (int q = 0; q < S && K < LUT_RT_MAXK; ++q) {
+                const int v = m->lut_var[(size_t)t * S + q];
+                if (v < 0 || v == lat) { perm[n++] = q; first[q] = true; ++K; }
+            }
+            for (int q = 0; q < S; ++q) if (!first[q]) perm[n++] = q;
+            for (int i = 0; i < S; ++i) {
+                const int q = perm[i], v = m->lut_var[(size_t)t * S + q];
+                if (v < 0) continue;            // padding: uthr 0 / c = never
+                const std::vector<KT> &sv = sorted[(size_t)v];
+                const int c = (int)(std::lower_bound(sv.begin(), sv.end(), tkey[(size_t)t * S + q]) - sv.begin()) + 1;
+                if (i < K) mt[11 + i] = c;
+                else { const float cf = (float)c; memcpy(&mt[i - K], &cf, 4); mt[6 + i - K] = v * LUT_R; }
+            }
+            mt[5] = S - K;
+            for (int b = 0; b < (1 << S); ++b) {        // b: slot in the new order (level i <-> bit S-1-i)
+                int bo = 0;
+                for (int i = 0; i < S; ++i) bo |= ((b >> (S - 1 - i)) & 1) << (S - 1 - perm[i]);
+                rlut[((size_t)t << S) + b] = m->lut_host[((size_t)t << S) + bo];
+            }
+        }
+        if (int rc = publish(m, rlut, &m->lut_rt)) return rc;
+        if (int rc = publish(m, rmeta, &m->lut_rt_meta)) return rc;
+    }
     if (int rc = publish(m, flat, (KT **)&m->lut_sorted)) return rc;
     if (int rc = publish(m, off, &m->lut_sorted_off)) return rc;
     return publish(m, meta, &m->lut_meta);
@@ -1474,7 +1839,7 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, 
         if (int rc = key64 ? build_lut_meta_t<double>(m, grid, C) : build_lut_meta_t<float>(m, grid, C)) return rc;
         m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
     }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr};
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr, nullptr, m->lut_rt, m->lut_rt_meta};
     return MHS_OK;
 }
 
@@ -1487,6 +1852,19 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     const unsigned blocks = (unsigned)((quarter + 255) / 256);
     const size_t lut_bytes = ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
     const bool in_regs = m->p <= LUT_REG_P;
+    // row-tile form: a wave = 256 consecutive cells of one row (LAT splits and padding levels on the scalar unit); taken
+    // when the rows are long enough that the ragged last tile of a row wastes little (MHS_GBM_NO_ROWTILE: never)
+    const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
+    const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
+    if (in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R)) {
+        const int64_t ntiles = (int64_t)g.nr * tpr;
+        const unsigned rblocks = (unsigned)((ntiles + 3) / 4);
+        auto rk = key64 ? gbm_lutreg_rt_kernel<true> : gbm_lutreg_rt_kernel<false>;
+        MHS_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_bytes));
+        hipLaunchKernelGGL(rk, dim3(rblocks), dim3(256), lut_bytes, st, tt.lut_rt, (const u64x8 *)tt.lut_rt_meta, tt.sorted, tt.sorted_off,
+                           m->n_trees_padded, m->init_f, m->p, s, g, tpr, w, acc, out);
+        return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+    }
     const size_t bytes = in_regs ? lut_bytes : (size_t)m->p * 256 * LUT_R * sizeof(float) + lut_bytes;
     auto kern = in_regs ? (m->lut_S == 5 ? (key64 ? gbm_lutreg_kernel<5, true> : gbm_lutreg_kernel<5, false>)
                                          : (key64 ? gbm_lutreg_kernel<6, true> : gbm_lutreg_kernel<6, false>))
@@ -1515,10 +1893,46 @@ static size_t rf_walk_db_lds(const mhs_model *m, int log2r) {
 }
 static int rf_walk_db_log2r(const mhs_model *m) {
     if (m->rf_max_nodes > 4095) return -1;
-    static const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
+    const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
     for (int l2 = five ? 3 : 2; l2 >= 1; --l2)
         if ((m->p * rf_walks(l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
     return -1;
+}
+
+// COMPACT records in two buffers (rf_walk_cdb_kernel): walks-per-lane code and buffer stride, false = does not apply
+static bool rf_walk_cdb_config(const mhs_model *m, int *rcode, int *stride) {
+    // measured on cfg3 (tools/r03_tree_variants.py): 213-229 ms per 1e8 cells against the double-buffered kernel's 176 -- the two
+    // extra VALU per level (min / max) cost more than the broadcast reads of parked lanes save.  Opt-in: MHS_RF_CDB.
+    if (!getenv("MHS_RF_CDB") || getenv("MHS_RF_DOUBLE_BUFFER") || getenv("MHS_RF_SINGLE_BUFFER") || getenv("MHS_RF_TRIPLE_BUFFER")) return false;
+    if (!m->rf_compact_ok) return false;
+    int want = 4;                                   // most walks per lane tried first (code 4 = 6 walks); MHS_RF_CDB_WALKS = 4..8
+    if (const char *e = getenv("MHS_RF_CDB_WALKS")) want = std::max(2, std::min(6, atoi(e) == 4 ? 2 : atoi(e) - 2));
+    for (int st : {16384, 32768}) {
+        if ((size_t)m->rf_cmax * 8 > (size_t)st) continue;
+        for (int rc = want; rc >= 2; --rc)
+            if ((m->p * rf_walks(rc) * 4) <= 255 &&
+                (size_t)2 * st + (size_t)1024 * (((size_t)m->p * rf_walks(rc)) | 1) * 4 <= LDS_MAX) {
+                *rcode = rc; *stride = st;
+                return true;
+            }
+    }
+    return false;
+}
+
+// triple-buffered kernel: buffer stride (bytes, a template parameter) and walks per lane, false = does not apply
+static bool rf_walk_tb_config(const mhs_model *m, int *log2r, int *stride) {
+    if (!getenv("MHS_RF_TRIPLE_BUFFER")) return false;      // measured no faster than two buffers and a barrier: kept as evidence
+    const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
+    for (int st : {16384, 24576}) {
+        if ((size_t)m->rf_max_nodes * 8 > (size_t)st) continue;
+        for (int l2 = five ? 3 : 2; l2 >= 2; --l2)
+            if ((m->p * rf_walks(l2) * 4) <= 255 &&
+                (size_t)3 * st + 32 + (size_t)1024 * (((size_t)m->p * rf_walks(l2)) | 1) * 4 <= LDS_MAX) {
+                *log2r = l2; *stride = st;
+                return true;
+            }
+    }
+    return false;
 }
 
 static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
@@ -1632,6 +2046,45 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
             return MHS_OK;
         }
     }
+    int cd_rc = 0, cd_stride = 0;
+    if (!big && rf_walk_cdb_config(m, &cd_rc, &cd_stride)) {     // split-node records, two buffers
+        TreeTables tt;
+        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, cd_rc, RF_COMPACT, key64, &tt)) return rc;
+        const int R = rf_walks(cd_rc);
+        const int64_t part = (total + R - 1) / R;
+        const unsigned blocks = (unsigned)((part + 1023) / 1024);
+        const size_t cbytes = (size_t)2 * cd_stride + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
+        typedef void (*CdbKernel)(const uint2 *, const double *, const int *, const int *, const int *, const void *, const int *, int, int,
+                                  StackDev, PredGeom, double, int, double *);
+        CdbKernel ck = nullptr;
+#define MHS_CDB(RC, ST) (key64 ? (CdbKernel)rf_walk_cdb_kernel<RC, true, ST> : (CdbKernel)rf_walk_cdb_kernel<RC, false, ST>)
+#define MHS_CDB_ST(ST) switch (cd_rc) { case 2: ck = MHS_CDB(2, ST); break; case 3: ck = MHS_CDB(3, ST); break; case 4: ck = MHS_CDB(4, ST); break; \
+                                        case 5: ck = MHS_CDB(5, ST); break; default: ck = MHS_CDB(6, ST); break; }
+        if (cd_stride == 16384) { MHS_CDB_ST(16384) } else { MHS_CDB_ST(32768) }
+#undef MHS_CDB_ST
+#undef MHS_CDB
+        MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes));
+        hipLaunchKernelGGL(ck, dim3(blocks), dim3(1024), cbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out);
+        return MHS_OK;
+    }
+    int tb_l2 = 0, tb_stride = 0;
+    if (!big && rf_walk_tb_config(m, &tb_l2, &tb_stride)) {      // triple-buffered, barrier-free tree loop
+        TreeTables tt;
+        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
+        const int R = rf_walks(tb_l2);
+        const int64_t part = (total + R - 1) / R;
+        const unsigned blocks = (unsigned)((part + 1023) / 1024);
+        const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
+#define MHS_TB(L2, ST) (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>)
+        auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
+                                     : (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576));
+#undef MHS_TB
+        MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
+        hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out);
+        return MHS_OK;
+    }
     if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane
         const int dl = rf_walk_db_log2r(m);
         if (dl > 0) log2r = dl;
@@ -1725,7 +2178,7 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             if (grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC")) {
                 int log2r = 0;
                 bool big = false;
-                if (rf_walk_db_log2r(m) < 0 && !getenv("MHS_RF_NO_COMPACT")) {
+                if ((rf_walk_db_log2r(m) < 0 || getenv("MHS_RF_FORCE_COMPACT")) && !getenv("MHS_RF_NO_COMPACT")) {
                     const int nt = rf_compact_threads(m);
                     if (nt > 0) {
                         if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
@@ -1853,6 +2306,8 @@ int mhs_model_free(mhs_model *m) {
     if (m->split_scratch) (void)hipFree(m->split_scratch);
     if (m->lut) (void)hipFree(m->lut);
     if (m->lut_meta) (void)hipFree(m->lut_meta);
+    if (m->lut_rt) (void)hipFree(m->lut_rt);
+    if (m->lut_rt_meta) (void)hipFree(m->lut_rt_meta);
     if (m->lut_sorted) (void)hipFree(m->lut_sorted);
     if (m->lut_sorted_off) (void)hipFree(m->lut_sorted_off);
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
@@ -2020,6 +2475,7 @@ int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets, co
             }
         }
         if (int rc = to_device(lut.data(), lut.size(), &m->lut)) { mhs_model_free(m); return rc; }
+        m->lut_host = std::move(lut);
     }
     *out = m;
     return MHS_OK;
@@ -2156,6 +2612,14 @@ int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weigh
     return MHS_OK;
 }
 
+// The host-pointer form -- what the R shim calls with terra's in-memory rasters (V73:468-606 reads, predicts and writes
+// block by block) -- as a three-stream pipeline over ROW BANDS: while band k is predicted, band k + 1's covariate rows
+// travel host -> device and band k - 1's result device -> host.  Buffers come from the library's persistent arena (two
+// covariate bands + two result bands; no hipMalloc / hipFree per call).  The host side issues, in this order, "kernels of
+// band k, upload of band k + 1, download of band k - 1": copies from / to pageable memory block the CALLING THREAD until
+// they are staged, so the kernels must already be in the queue when the thread goes into them.  Cells are independent
+// and a band is described with the parent grid's affine, so the plane equals the one-piece evaluation bit for bit.
+// MHS_HOST_BANDS overrides the band count (1 = the serial round-2 behaviour, minus the allocations).
 int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, int n_models,
                          double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
                          int64_t r1, int64_t c0, int64_t c1, double *out_host) {
@@ -2164,39 +2628,73 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     MHS_REQUIRE(0 <= r0 && r0 <= r1 && r1 <= g->nrow && 0 <= c0 && c0 <= c1 && c1 <= g->ncol, "window outside the grid");
     const int64_t nr = r1 - r0, nc = c1 - c0;
     if (nr == 0 || nc == 0) return MHS_OK;
+    for (int k = 0; k < n_models; ++k)
+        MHS_REQUIRE(models[k] && covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
     const size_t esz = covars->dtype == MHS_F64 ? 8 : covars->dtype == MHS_F32 ? 4 : 2;
-    hipStream_t s = ctx().stream;
-    // ship rows [r0, r1) of every layer; the device copy is described as a grid of nr rows
-    DevBuf<char> dcov;
-    DevBuf<double> dout;
-    const size_t plane_bytes = (size_t)nr * covars->ld * esz;
-    MHS_HIP(dcov.alloc(plane_bytes * (size_t)covars->n_layers));
-    MHS_HIP(dout.alloc((size_t)(nr * nc)));
-    for (int k = 0; k < covars->n_layers; ++k)
-        MHS_HIP(hipMemcpyAsync(dcov.p + plane_bytes * k,
-                               (const char *)covars->data + ((size_t)k * covars->plane_stride + (size_t)r0 * covars->ld) * esz,
-                               plane_bytes, hipMemcpyHostToDevice, s));
-    // Describe the device copy with the PARENT grid's affine (cell centres stay bit-identical):
-    // plane k, absolute row r lives at base + (k*plane_stride + r*ld)*esz, so shift the base
-    // back by r0 rows once and let plane_stride skip the nr rows that were shipped.
-    mhs_stack ds = *covars;
-    ds.data = dcov.p - (size_t)r0 * covars->ld * esz;
-    ds.plane_stride = (int64_t)nr * covars->ld;
-    {
+    // bands of ~12 M cells (8 for the 10 000 x 10 000 grid): the first upload and the last download are all that is not
+    // hidden, and a band is still ~10 rounds of the forest's 5 000-cell blocks over the device
+    int64_t nb = std::max<int64_t>(1, std::min<int64_t>(nr, (nr * nc + 6250000) / 12500000));
+    if (const char *e = getenv("MHS_HOST_BANDS")) nb = std::max<int64_t>(1, std::min<int64_t>(nr, atoll(e)));
+    const int64_t rows_per = (nr + nb - 1) / nb;
+    nb = (nr + rows_per - 1) / rows_per;
+    const size_t in_bytes = ((size_t)rows_per * covars->ld * esz * (size_t)covars->n_layers + 255) & ~(size_t)255;
+    const size_t out_bytes = ((size_t)rows_per * nc * sizeof(double) + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lk(pipe_mutex());
+    if (int rc = host_pipe(2 * (in_bytes + out_bytes))) return rc;
+    Context &c = ctx();
+    char *in[2] = {c.pipe_arena, c.pipe_arena + in_bytes};
+    double *outb[2] = {(double *)(c.pipe_arena + 2 * in_bytes), (double *)(c.pipe_arena + 2 * in_bytes + out_bytes)};
+    auto band_rows = [&](int64_t b, int64_t *b0, int64_t *b1) { *b0 = r0 + b * rows_per; *b1 = std::min(r1, *b0 + rows_per); };
+    auto upload = [&](int64_t b) -> int {
+        const int sl = (int)(b & 1);
+        int64_t b0, b1;
+        band_rows(b, &b0, &b1);
+        if (b >= 2) MHS_HIP(hipStreamWaitEvent(c.pipe_h2d, c.pipe_done[sl], 0));      // band b - 2's kernels read this buffer
+        const size_t plane_bytes = (size_t)(b1 - b0) * covars->ld * esz;
+        for (int k = 0; k < covars->n_layers; ++k)
+            MHS_HIP(hipMemcpyAsync(in[sl] + plane_bytes * k,
+                                   (const char *)covars->data + ((size_t)k * covars->plane_stride + (size_t)b0 * covars->ld) * esz,
+                                   plane_bytes, hipMemcpyHostToDevice, c.pipe_h2d));
+        MHS_HIP(hipEventRecord(c.pipe_in[sl], c.pipe_h2d));
+        return MHS_OK;
+    };
+    auto download = [&](int64_t b) -> int {
+        const int sl = (int)(b & 1);
+        int64_t b0, b1;
+        band_rows(b, &b0, &b1);
+        MHS_HIP(hipStreamWaitEvent(c.pipe_d2h, c.pipe_done[sl], 0));
+        MHS_HIP(hipMemcpyAsync(out_host + (size_t)(b0 - r0) * nc, outb[sl], sizeof(double) * (size_t)((b1 - b0) * nc), hipMemcpyDeviceToHost,
+                               c.pipe_d2h));
+        MHS_HIP(hipEventRecord(c.pipe_out[sl], c.pipe_d2h));
+        return MHS_OK;
+    };
+    if (int rc = upload(0)) return rc;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int sl = (int)(b & 1);
+        int64_t b0, b1;
+        band_rows(b, &b0, &b1);
+        MHS_HIP(hipStreamWaitEvent(c.pipe_comp, c.pipe_in[sl], 0));
+        if (b >= 2) MHS_HIP(hipStreamWaitEvent(c.pipe_comp, c.pipe_out[sl], 0));       // band b - 2's result has left this buffer
+        // The device copy is described with the PARENT grid's affine (cell centres stay bit-identical): plane k, absolute
+        // row r lives at base + (k * plane_stride + r * ld) * esz, so the base is shifted back by b0 rows and plane_stride
+        // skips the rows that were shipped.
         PredGeom pg;
         StackDev sd;
-        if (int rc = make_geom(g, r0, r1, c0, c1, nc, &pg)) return rc;
-        for (int k = 0; k < n_models; ++k)
-            MHS_REQUIRE(models[k] && covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
-        sd.data = ds.data; sd.C = ds.n_layers; sd.dtype = ds.dtype; sd.plane_stride = ds.plane_stride;
-        sd.ld = ds.ld; sd.nodata = ds.nodata; sd.has_nodata = !std::isnan(ds.nodata); sd.all_from_planes = 0;
-        if (int rc = launch_members(models, weights, n_models, sd, pg, 0, dout.p, s, g)) return rc;
+        if (int rc = make_geom(g, b0, b1, c0, c1, nc, &pg)) return rc;
+        sd.data = in[sl] - (size_t)b0 * covars->ld * esz; sd.C = covars->n_layers; sd.dtype = covars->dtype;
+        sd.plane_stride = (b1 - b0) * covars->ld; sd.ld = covars->ld; sd.nodata = covars->nodata;
+        sd.has_nodata = !std::isnan(covars->nodata); sd.all_from_planes = 0;
+        if (int rc = launch_members(models, weights, n_models, sd, pg, 0, outb[sl], c.pipe_comp, g)) return rc;
+        hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)(((b1 - b0) * nc + 255) / 256)), dim3(256), 0, c.pipe_comp,
+                           outb[sl], (int)(b1 - b0), (int)nc, nc, wt_total);
+        MHS_HIP(hipGetLastError());
+        MHS_HIP(hipEventRecord(c.pipe_done[sl], c.pipe_comp));
+        if (b + 1 < nb) if (int rc = upload(b + 1)) return rc;
+        if (b >= 1) if (int rc = download(b - 1)) return rc;
     }
-    hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((nr * nc + 255) / 256)), dim3(256), 0, s,
-                       dout.p, (int)nr, (int)nc, nc, wt_total);
-    MHS_HIP(hipGetLastError());
-    MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost, s));
-    MHS_HIP(hipStreamSynchronize(s));
+    if (int rc = download(nb - 1)) return rc;
+    MHS_HIP(hipStreamSynchronize(c.pipe_d2h));
+    MHS_HIP(hipStreamSynchronize(c.pipe_comp));
     return MHS_OK;
 }
 

@@ -34,6 +34,35 @@ std::mutex &mask_mutex() {
     return m;
 }
 
+std::mutex &pipe_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int host_pipe(size_t arena_bytes) {
+    Context &c = ctx();
+    if (!c.pipe_h2d) {
+        MHS_HIP(hipStreamCreateWithFlags(&c.pipe_h2d, hipStreamNonBlocking));
+        MHS_HIP(hipStreamCreateWithFlags(&c.pipe_d2h, hipStreamNonBlocking));
+        MHS_HIP(hipStreamCreateWithFlags(&c.pipe_comp, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            MHS_HIP(hipEventCreateWithFlags(&c.pipe_in[i], hipEventDisableTiming));
+            MHS_HIP(hipEventCreateWithFlags(&c.pipe_done[i], hipEventDisableTiming));
+            MHS_HIP(hipEventCreateWithFlags(&c.pipe_out[i], hipEventDisableTiming));
+        }
+    }
+    if (arena_bytes > c.pipe_arena_cap) {      // grow-only; growing synchronises the device, the first calls only
+        if (c.pipe_arena) {
+            (void)hipStreamSynchronize(c.pipe_h2d); (void)hipStreamSynchronize(c.pipe_comp); (void)hipStreamSynchronize(c.pipe_d2h);
+            (void)hipFree(c.pipe_arena); c.pipe_arena = nullptr; c.pipe_arena_cap = 0;
+        }
+        const size_t cap = arena_bytes + arena_bytes / 16;
+        MHS_HIP(hipMalloc((void **)&c.pipe_arena, cap));
+        c.pipe_arena_cap = cap;
+    }
+    return MHS_OK;
+}
+
 int fit_lane(int i, FitLane **out) {
     Context &c = ctx();
     while ((int)c.lanes.size() <= i) {
@@ -161,6 +190,12 @@ int mhs_shutdown(void) {
     if (c.points_arena) (void)hipFree(c.points_arena);
     if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.upload) { (void)hipStreamSynchronize(c.upload); (void)hipStreamDestroy(c.upload); }
+    for (hipStream_t ps : {c.pipe_h2d, c.pipe_comp, c.pipe_d2h})
+        if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+    for (int i = 0; i < 2; ++i)
+        for (hipEvent_t pe : {c.pipe_in[i], c.pipe_done[i], c.pipe_out[i]})
+            if (pe) (void)hipEventDestroy(pe);
+    if (c.pipe_arena) (void)hipFree(c.pipe_arena);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); }

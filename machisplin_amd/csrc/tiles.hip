@@ -389,20 +389,28 @@ int mhs_mosaic_feather(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_
     if (int rc = check_grid(g)) return rc;
     MHS_REQUIRE(nRx >= 1 && nCx >= 1 && tile_win && tile_host && out_host, "bad arguments");
     const int64_t n = nRx * nCx;
-    hipStream_t s = ctx().stream;
-    std::vector<DevBuf<double>> bufs((size_t)n);
-    std::vector<const double *> ptrs((size_t)n);
+    // tiles and the merged plane live in the library's persistent arena (no hipMalloc / hipFree per call)
+    std::vector<size_t> off((size_t)n + 1, 0);
     for (int64_t h = 0; h < n; ++h) {
         const int64_t cells = (tile_win[4 * h + 1] - tile_win[4 * h]) * (tile_win[4 * h + 3] - tile_win[4 * h + 2]);
         MHS_REQUIRE(cells > 0 && tile_host[h], "bad tile");
-        MHS_HIP(bufs[h].alloc((size_t)cells));
-        MHS_HIP(hipMemcpyAsync(bufs[h].p, tile_host[h], sizeof(double) * (size_t)cells, hipMemcpyHostToDevice, s));
-        ptrs[h] = bufs[h].p;
+        off[(size_t)h + 1] = off[(size_t)h] + (((size_t)cells * sizeof(double) + 255) & ~(size_t)255);
     }
-    DevBuf<double> out;
-    MHS_HIP(out.alloc((size_t)(g->nrow * g->ncol)));
-    if (int rc = mhs_mosaic_feather_dev(g, nRx, nCx, tile_win, ptrs.data(), merge_mode, out.p, g->ncol, nullptr, s)) return rc;
-    MHS_HIP(hipMemcpy(out_host, out.p, sizeof(double) * (size_t)(g->nrow * g->ncol), hipMemcpyDeviceToHost));
+    const size_t out_bytes = sizeof(double) * (size_t)(g->nrow * g->ncol);
+    std::lock_guard<std::mutex> lk(pipe_mutex());
+    if (int rc = host_pipe(off[(size_t)n] + out_bytes)) return rc;
+    hipStream_t s = ctx().pipe_comp;
+    char *base = ctx().pipe_arena;
+    std::vector<const double *> ptrs((size_t)n);
+    for (int64_t h = 0; h < n; ++h) {
+        const int64_t cells = (tile_win[4 * h + 1] - tile_win[4 * h]) * (tile_win[4 * h + 3] - tile_win[4 * h + 2]);
+        MHS_HIP(hipMemcpyAsync(base + off[(size_t)h], tile_host[h], sizeof(double) * (size_t)cells, hipMemcpyHostToDevice, s));
+        ptrs[(size_t)h] = (const double *)(base + off[(size_t)h]);
+    }
+    double *out = (double *)(base + off[(size_t)n]);
+    if (int rc = mhs_mosaic_feather_dev(g, nRx, nCx, tile_win, ptrs.data(), merge_mode, out, g->ncol, nullptr, s)) return rc;
+    MHS_HIP(hipMemcpyAsync(out_host, out, out_bytes, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
     return MHS_OK;
 }
 

@@ -504,12 +504,15 @@ int mhs_tps_predict_grid(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_
     MHS_REQUIRE(0 <= r0 && r0 <= r1 && 0 <= c0 && c0 <= c1, "bad window");
     const int64_t nr = r1 - r0, nc = c1 - c0;
     if (nr == 0 || nc == 0) return MHS_OK;
-    DevBuf<double> buf;
-    MHS_HIP(buf.alloc((size_t)(nr * nc)));
-    if (int rc = mhs_tps_predict_grid_dev(t, g, r0, r1, c0, c1, buf.p, nc, nullptr)) return rc;
-    MHS_HIP(hipMemcpyAsync(out_host, buf.p, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost,
-                           ctx().stream));
-    MHS_HIP(hipStreamSynchronize(ctx().stream));
+    // the plane comes from the library's persistent arena (no hipMalloc / hipFree -- a device-wide synchronisation each --
+    // per call) and is evaluated on the library's own stream, the one the copy back is ordered on
+    std::lock_guard<std::mutex> lk(pipe_mutex());
+    if (int rc = host_pipe(sizeof(double) * (size_t)(nr * nc))) return rc;
+    double *buf = (double *)ctx().pipe_arena;
+    hipStream_t s = ctx().pipe_comp;
+    if (int rc = mhs_tps_predict_grid_dev(t, g, r0, r1, c0, c1, buf, nc, s)) return rc;
+    MHS_HIP(hipMemcpyAsync(out_host, buf, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
     return MHS_OK;
 }
 

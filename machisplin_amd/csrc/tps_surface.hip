@@ -174,11 +174,15 @@ extern "C" int mhs_tps_surface(const mhs_grid *g, const double *xy, const double
                                double *out_host, int64_t *tiles_out) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(g && out_host && g->nrow > 0 && g->ncol > 0, "bad arguments");
-    DevBuf<double> out;
-    MHS_HIP(out.alloc((size_t)(g->nrow * g->ncol)));
-    if (int rc = mhs_tps_surface_dev(g, xy, resid, n, cov1_at_stations, tile_edge, lambda, gcv_mode, out.p, g->ncol,
-                                     tiles_out, ctx().stream)) return rc;
-    MHS_HIP(hipMemcpy(out_host, out.p, sizeof(double) * (size_t)(g->nrow * g->ncol), hipMemcpyDeviceToHost));
+    // the plane comes from the library's persistent arena (no hipMalloc / hipFree per call)
+    std::lock_guard<std::mutex> lk(pipe_mutex());
+    if (int rc = host_pipe(sizeof(double) * (size_t)(g->nrow * g->ncol))) return rc;
+    double *out = (double *)ctx().pipe_arena;
+    hipStream_t s = ctx().pipe_comp;
+    if (int rc = mhs_tps_surface_dev(g, xy, resid, n, cov1_at_stations, tile_edge, lambda, gcv_mode, out, g->ncol,
+                                     tiles_out, s)) return rc;
+    MHS_HIP(hipMemcpyAsync(out_host, out, sizeof(double) * (size_t)(g->nrow * g->ncol), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
     return MHS_OK;
 }
 

@@ -199,6 +199,75 @@ def test_gbm_rank_lut_variants(hip, C, trees, n):
     assert np.abs(got - want).max() <= _tol(want)   # one wrong leaf would be ~1e-3 * sd(y)
 
 
+@pytest.mark.parametrize("dtype,n_splits,window", [("f32", 5, None), ("f64", 5, (3, 37, 40, 1040)), ("i16", 3, None),
+                                                   ("f32", 1, (0, 40, 0, 1000))])
+def test_gbm_row_tile_kernel_equals_the_other_paths_bit_for_bit(hip, dtype, n_splits, window, monkeypatch):
+    """Rows of >= ~240 cells take gbm_lutreg_rt_kernel (round 3): a wave = 256 consecutive cells of one row, the
+    tree's splits on LAT and its padding levels evaluated on the scalar unit, the leaf LUT permuted per tree.  Same
+    leaf values in the same tree order as the lane-per-cell register kernel (MHS_GBM_NO_ROWTILE is read once per
+    process, so that one is reached through a narrow window here) and as the node walk: identical planes, NA cells,
+    ragged last tile, windows, trees with fewer than five splits (n_splits < 5: up to two padding levels go to the
+    scalar unit, the rest read as never-true vector levels) included."""
+    import torch
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=40, ncol=1100, dtype=dtype, nodata_frac=0.01, n=1500, gbm_trees=2, rf_trees=1)
+    prm = synth.gbm_params(Xs, ys, 3, n_trees=900, n_splits=n_splits)
+    assert (prm["split_var"] == prm["p"] - 1).any()          # some splits on LAT
+    m = hip.models.from_param_dict(prm)
+    win = window or (0, g.nrow, 0, 1000)
+    fast = hip.predict(stack, m, window=win)
+    monkeypatch.setenv("MHS_TREES_GENERIC", "1")
+    slow = hip.predict(stack, m, window=win)
+    monkeypatch.delenv("MHS_TREES_GENERIC")
+    assert torch.equal(torch.isnan(fast), torch.isnan(slow))
+    assert torch.equal(torch.nan_to_num(fast), torch.nan_to_num(slow))
+    assert not torch.isnan(fast).any()          # gbm routes NA covariates through its MissingNode children
+    # the lane-per-cell register kernel on 100-column pieces of the same window (too narrow for the row tiles)
+    r0, r1, c0, c1 = win
+    for cc in range(c0, c1, 100):
+        piece = hip.predict(stack, m, window=(r0, r1, cc, min(cc + 100, c1)))
+        ref = fast[:, cc - c0:min(cc + 100, c1) - c0]
+        assert torch.equal(torch.nan_to_num(piece), torch.nan_to_num(ref)), cc
+    want = oe.predict(prm, X).reshape(g.nrow, g.ncol)[r0:r1, c0:c1]
+    got = fast.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
+@pytest.mark.parametrize("n,dtype", [(1400, "f32"), (4600, "f64"), (4600, "i16")])
+def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, monkeypatch):
+    """Round 3's two experiments on the forest walk -- rf_walk_cdb_kernel (MHS_RF_CDB: split-node records in two LDS
+    buffers, lanes parked on a terminal all read one dummy record, 4..8 walks per lane) and rf_walk_tb_kernel
+    (MHS_RF_TRIPLE_BUFFER: three buffers, no barrier in the tree loop, LDS counters between the waves); neither beat
+    round 2's double-buffered kernel (the default), both are kept opt-in -- against that kernel, the single-buffer forms
+    and the node walk: bit-identical planes.  1 400 stations give trees of
+    ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).  Seven trees: a count that is a
+    multiple neither of the two nor of the three buffers."""
+    import torch
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=120, ncol=257, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
+    prm = synth.rf_params(Xs, ys, 9, n_trees=7)
+    nodes = np.diff(prm["tree_offsets"]).max()
+    assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
+    m = hip.models.from_param_dict(prm)
+    fast = hip.predict(stack, m)
+    for envs in ({"MHS_RF_CDB": "1"}, {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "4"}, {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "5"},
+                 {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "8"}, {"MHS_RF_TRIPLE_BUFFER": "1"},
+                 {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
+                 {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
+        for e, v in envs.items():
+            monkeypatch.setenv(e, v)
+        other = hip.predict(stack, m)
+        for e in envs:
+            monkeypatch.delenv(e)
+        assert torch.equal(torch.isnan(fast), torch.isnan(other)), envs
+        assert torch.equal(torch.nan_to_num(fast), torch.nan_to_num(other)), envs
+    want = oe.predict(prm, X)
+    got = fast.cpu().numpy().ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
 def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     """Trees of ~18 000 nodes (30 000 stations): too many for 16-bit byte addresses and for nodes + predictions in
     LDS, so the walk takes its BIG form (node indices, predictions read from global memory).  Same results."""

@@ -1,0 +1,47 @@
+"""Round 3: stand-alone times of the gbm and randomForest kernel variants on a cfg3-shaped model set (5 000 stations,
+10 000 gbm trees, 500 forest trees) over side x side cells.  Variants are selected with the library's environment
+switches; every variant's plane is compared bit for bit with the first one's.
+    python tools/r03_tree_variants.py [side=8000] [reps=3]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import machisplin_amd as m
+from machisplin_amd import synth
+
+m.init()
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+g = synth.grid(side, side)
+seed = synth.BASE_SEED + 3
+planes, nodata = synth.covariates(g, 3, seed, dtype="f32")
+stack = m.RasterStack(g, planes, nodata)
+xy, rows, cols, uv = synth.stations(g, 5000, seed)
+cov_at = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+X = np.column_stack([cov_at, xy])
+y = synth.response(X, uv, seed)
+params = {p["kind"]: p for p in synth.ensemble_params(X, y, seed, which="br")}
+out = torch.empty((side, side), dtype=torch.float64, device="cuda")
+
+def run(kind, env):
+    for k, v in env.items(): os.environ[k] = v
+    mod = m.models.from_param_dict(params[kind])
+    m.predict(stack, mod, out=out); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.time(); m.predict(stack, mod, out=out); torch.cuda.synchronize(); best = min(best, time.time() - t0)
+    for k in env: del os.environ[k]
+    return best, out.clone()
+
+for kind, variants in (("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
+                       ("rf", [("double-buffered, 5 walks (round 2, default)", {}),
+                               ("split-node records, two buffers, 6 walks", {"MHS_RF_CDB": "1"}),
+                               ("same, 5 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "5"}), ("same, 4 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "4"}),
+                               ("triple-buffered, no barrier", {"MHS_RF_TRIPLE_BUFFER": "1"}),
+                               ("double-buffered, 4 walks", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}),
+                               ("split-node records, one buffer, 4 walks", {"MHS_RF_FORCE_COMPACT": "1"})])):
+    ref = None
+    for name, env in variants:
+        dt, plane = run(kind, env)
+        same = "" if ref is None else ("  == first" if torch.equal(torch.nan_to_num(plane), torch.nan_to_num(ref)) else "  DIFFERS from first")
+        if ref is None: ref = plane
+        print(f"{kind:4s} {name:52s} {dt*1e3:9.2f} ms  -> 1e8 cells: {dt*1e8/(side*side)*1e3:8.1f} ms{same}", flush=True)
