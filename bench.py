@@ -17,6 +17,7 @@ launch from SURVEY.md section 8d divided by its HIP-event duration on the launch
 sample of the same workload.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -30,7 +31,20 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64: vector == MFMA peak (v_mfma_f64_16x16x4 measured 75.3 TF)
 HBM_PEAK_GBS = 8000.0
 FP32_PEAK_TFLOPS = 157.3  # FP32 vector == FP32 MFMA peak
-LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk x 2.4 GHz (ds_read_b64 / b32 rate)
+LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk x 2.4 GHz (round-1/2 view of the LDS rate; kept for comparison)
+VALU_ISSUE_PEAK_G = 1024 * 2.4 / 4.0   # G wave-instructions/s: 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+LDS_CYCLE_PEAK_G = 256 * 2.4           # G LDS-array cycles/s: 256 CUs at 2.4 GHz (MI355X guide: ds_read_b64 = ds_read_b32 = 2 cycles)
+
+
+def pmc_derived():
+    """profiles/r03_members_pmc_derived.json (tools/r03_members_pmc.sh + tools/r03_pmc_derive.py): per-unit instruction
+    counts and pipe utilisations of the three heavy member kernels from rocprofv3 --pmc passes on a torch-free driver."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_members_pmc_derived.json")) as f:
+            d = json.load(f)
+        return {("gbm" if "gbm" in k else "rf" if "rf_" in k else "svr"): v for k, v in d.items() if isinstance(v, dict)}
+    except (OSError, ValueError):
+        return {}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the north-star target is quoted on
@@ -136,6 +150,7 @@ class Workload:
         band_cells = (self.run.r1 - self.run.r0) * self.geom.ncol
         n = ops.X.shape[0]
         rows = []
+        pmc = pmc_derived()
 
         def mean_ms(key):
             v = ops.timings.get(key, [])
@@ -148,7 +163,7 @@ class Workload:
             tc, tr, node_pairs, cell_pairs = getattr(ops, "last_eval_plan", (0, 0, 0, 0))
             if tc:   # far-field-interpolated path: kernel evaluations actually performed + 32 FMA/cell of interpolation
                 fl = 8.0 * (node_pairs + cell_pairs) + band_cells * 70.0
-                rows.append({"kernel": "tps_ff_nodes_kernel+tps_ff_cells_kernel", "bound": "mfma", "launch_ms": ms,
+                rows.append({"kernel": "tps_ff_nodes_kernel+tps_ff_cells_kernel", "bound": "fp64-valu", "launch_ms": ms,
                              "achieved": fl / ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "work": "far-field-interpolated sum, tiles %d x %d cells: 8 flop per evaluated (point, knot) pair "
                                      "(%.3g pairs at tile nodes + %.3g at cells, vs %.3g for the direct sum) + 70 flop/cell of "
@@ -156,7 +171,7 @@ class Workload:
                              "direct_sum_equivalent_tflops": band_cells * (8.0 * n + 6.0) / ms / 1e9})
             else:
                 fl = band_cells * (8.0 * n + 6.0)
-                rows.append({"kernel": "tps_eval_grid_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                rows.append({"kernel": "tps_eval_grid_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "8N+6 flop/cell, log = 1 flop; FP64 VALU/"
                              "transcendental-bound (FP64 MFMA shares the DP pipe, same peak)"})
         if mean_ms("tps_eval_ms"):
@@ -177,56 +192,78 @@ class Workload:
             if k == "svr":
                 nsv, p = prm["sv"].shape
                 fl = band_cells * nsv * (3.0 * p + 2.0)
-                rows.append({"kernel": "svr_kernel", "bound": "mfma", "launch_ms": ms, "achieved": fl / ms / 1e9,
-                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop"})
+                pm = pmc.get("svr", {})
+                ipp = pm.get("valu_per_cell_unit", 15.07)
+                rows.append({"kernel": "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop",
+                             "issue_view": {"achieved": band_cells * nsv / 64.0 * ipp / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
+                                            "frac": band_cells * nsv / 64.0 * ipp / ms / 1e6 / VALU_ISSUE_PEAK_G,
+                                            "work": "%.2f VALU wave-instructions per (cell, SV) / 64 lanes (SQ_INSTS_VALU, profiles/r03_members_pmc_*), "
+                                                    "12 of them FP64" % ipp},
+                             "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "lds_array_busy") if kk in pm}})
             elif k == "gbm":
-                # compute view (the kernel is VALU-issue bound, PMC traffic = the 28 B/cell it must move): per
-                # (cell, tree) the predicate-LUT form needs S threshold compares + 1 fp64 add, against the FP32
-                # vector/matrix peak the compares issue at
+                # The kernel evaluates a tree as S wave-wide predicates + one LUT read + one fp64 add and is bound by the rate at
+                # which a SIMD issues VALU instructions (one wave64 instruction per 4 cycles); HBM traffic = the planes and the
+                # plane it accumulates into.  achieved = VALU wave-instructions per second, the count per (cell, tree) taken
+                # from the SQ_INSTS_VALU pass on the torch-free driver (row tiles: ~6.4; lane per cell: 7.1).
                 nt = len(prm["tree_offsets"]) - 1
+                rowtile = self.geom.ncol >= 0.93 * (-(-self.geom.ncol // 256) * 256) and prm["p"] <= 8
+                pm = pmc.get("gbm", {}) if rowtile else {}
+                ipt = pm.get("valu_per_cell_unit", 6.4 if rowtile else 7.1)
+                inst = band_cells * nt / 64.0 * ipt
                 ops_ = band_cells * nt * 6.0
-                rows.append({"kernel": "gbm_lutreg_kernel", "bound": "mfma", "launch_ms": ms, "achieved": ops_ / ms / 1e9,
-                             "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "work": "6 ops per (cell, tree): 5 split predicates + 1 fp64 add (predicate-LUT form of gbm_pred; the kernel issues "
-                                     "7 VALU lane-instructions per (cell, tree) at ~90 %% of the VALU issue rate); "
-                                     "reference walk = %.0f node visits/cell, %.3g visits/s" % (
-                                         self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
-                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3)})
+                rows.append({"kernel": "gbm_lutreg_rt_kernel" if rowtile else "gbm_lutreg_kernel", "bound": "valu-issue", "launch_ms": ms,
+                             "achieved": inst / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
+                             "work": "%.2f VALU wave-instructions per (cell, tree) / 64 lanes (SQ_INSTS_VALU pass, profiles/r03_members_pmc_*): "
+                                     "4 packed-FP32 predicate instructions per per-cell level and 4 cells, 4 shift-adds, 4 fp64 adds; row-uniform "
+                                     "levels (LAT splits, padding) on the scalar unit; reference walk = %.0f node visits/cell, %.3g visits/s" % (
+                                         ipt, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
+                             "ops_view": {"achieved": ops_ / ms / 1e9, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ops_ / ms / 1e9 / FP32_PEAK_TFLOPS,
+                                          "work": "6 algorithmic ops per (cell, tree) -- 5 split predicates + 1 fp64 add -- against the packed-FP32 peak "
+                                                  "(rounds 1-2 reported this view as the roofline)"},
+                             "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "salu_per_valu", "lds_array_busy") if kk in pm}})
             elif k == "rf":
-                # LDS-bandwidth bound walk: every lane reads an 8-byte node and a 4-byte key per level and descends
-                # each tree's full depth (terminals self-loop); the HBM view is what the JSON contract can express
+                # LDS-bound walk: per lane, tree and level one ds_read_b64 (node) + one ds_read_b32 (rank key), 2 LDS-array
+                # cycles each per wave when conflict-free (MI355X guide, LDS table); every lane descends each tree's full depth
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
-                lds_bytes = band_cells * float(self.rf_level_sum()) * 12.0
+                levels = float(self.rf_level_sum())
+                cyc = band_cells * levels / 64.0 * 4.0
                 prm = next(p for p in self.params if p["kind"] == "rf")
                 big = int(np.diff(prm["tree_offsets"]).max()) > 4095      # launch_model's choice (ensemble.hip, case K_RF)
-                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_db_kernel", "bound": "hbm", "launch_ms": ms,
-                             "achieved": by / ms / 1e6,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "work": "read %d fp32 planes + RMW fp64 out per cell (HBM view; the walk itself is LDS-bound: "
-                                     "%.0f node visits/cell, %.3g visits/s)" % (self.cfg["layers"], self.mean_visits[k],
-                                                                              self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                pm = pmc.get("rf", {}) if not big else {}
+                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
+                             "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
+                             "work": "4 conflict-free LDS-array cycles per wave, tree level and walk (ds_read_b64 node + ds_read_b32 key), sum of "
+                                     "tree depths = %d levels/cell; %.0f node visits/cell on the reference's walk, %.3g visits/s" % (
+                                         levels, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
-                             "lds_view": {"achieved": lds_bytes / ms / 1e6, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                                          "frac": lds_bytes / ms / 1e6 / LDS_PEAK_GBS,
-                                          "work": "12 B of LDS reads per lane and level, sum of tree depths = %d levels/cell"
-                                                  % self.rf_level_sum()}})
+                             "pmc": {kk: pm[kk] for kk in ("lds_array_busy", "lds_bank_conflict_share_of_lds_cycles", "lds_cycles_per_lds_instruction",
+                                                           "lds_cmd_fifo_full_share", "valu_issue_utilisation") if kk in pm},
+                             "hbm_view": {"achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS},
+                             "lds_bytes_view": {"achieved": band_cells * levels * 12.0 / ms / 1e6, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                                "frac": band_cells * levels * 12.0 / ms / 1e6 / LDS_PEAK_GBS,
+                                                "work": "rounds 1-2: 12 B of LDS reads per lane and level against 128 B/clk/CU"}})
             else:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
                 rows.append({"kernel": "%s_kernel" % k, "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "work": "read C fp32 planes + read-modify-write fp64 out"})
-        pmc = {}
+        pmc_t = {}
         try:  # bytes per cell measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled as
             # the gfx950 guide prescribes) on tools/pmc_probe; committed under profiles/
             pmc_file = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"))
                             if os.path.exists(p))
             with open(pmc_file) as f:
                 for kn, d in json.load(f)["kernels"].items():
-                    pmc[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
+                    pmc_t[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass
+        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("rf", "rf_walk_db_kernel"), ("svr", "svr_kernel")):
+            if "hbm_bytes_per_cell_fetch_x2_plus_write" in pmc.get(kind, {}):      # round 3's passes (fresh output plane: no RMW read)
+                pmc_t[kn] = pmc[kind]["hbm_bytes_per_cell_fetch_x2_plus_write"]
         for r in rows:
             r["frac"] = r["achieved"] / r["peak"]
-            parts = [pmc.get(kn.split("<")[0]) for kn in r["kernel"].split("+")]
+            parts = [pmc_t.get(kn.split("<")[0]) for kn in r["kernel"].split("+")]
             r["traffic"] = sum(parts) * band_cells if all(x is not None for x in parts) else None
         return rows
 
@@ -237,6 +274,18 @@ class Workload:
         from machisplin_amd import _lib
         torch, mhs = self.torch, self.mhs
         g = self.geom
+        # without mhs_fit_reserve_cus (a setting of the Python drivers, not of the R shim): its CU-masked stream is a
+        # BLOCKING stream, and the runtime's pageable copies then wait for the forest instead of running under it
+        reserved = self.ops.reserve(0)
+        try:
+            return self._f64_boundary(torch, mhs, g)
+        finally:
+            if reserved:
+                self.ops.reserve(reserved)
+
+    def _f64_boundary(self, torch, mhs, g):
+        import ctypes as C
+        from machisplin_amd import _lib
         t32 = []
         for _ in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -546,6 +595,7 @@ class TileWorkload:
         self.int_values = np.column_stack([xy, resp])
         _, wts, tot = mhs.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")      # smooth.outputs.only (V73:366-392)
         fitted = {}
+        self.unit_params = {}
         for t in mine:
             sel = self.tiles["dat"][t]
             fitted[t] = {}
@@ -554,6 +604,9 @@ class TileWorkload:
                     continue
                 params = synth.ensemble_params(X[sel], resp[sel, l], seed + 7 * l + t, which="gnmv")
                 fitted[t][l] = {"models": [mhs.models.from_param_dict(p) for p in params], "weights": wts, "wt_total": tot}
+                if not self.unit_params:      # the first unit's host-side parameters: unit_profile / cpu_baseline
+                    sv = next(p for p in params if p["kind"] == "svr")
+                    self.unit_params[(t, l)] = {"params": params, "weights": wts, "wt_total": tot, "svr_shape": tuple(sv["sv"].shape)}
         self.ops = sharded.HipTileOps(g, self.tiles, lambda t: self._stacks[t], self.int_values, fitted,
                                       tile_edge=cfg.get("tile_edge", 1500))
         self.run = sharded.TileShardedMltps(self.ops, dist, rank, world, merge_on="owner")
@@ -565,6 +618,131 @@ class TileWorkload:
 
     def collect(self):
         self.torch.cuda.synchronize()
+
+    # ---- outside the timed region: what ONE (tile, layer) unit is made of, its dominant kernel and the CPU figure ----
+    def unit_profile(self):
+        """Phases of the unit (tile t, layer l) this rank owns first, each one fenced by device synchronisations: the
+        Step-2 member launches (the library's own grouping: gam + nnet + earth fused, ksvm), the station residuals,
+        Step 3 + 4 as the reference computes them (its own tiles, fits at their GCV lambdas, mosaic, feathering), Step 5."""
+        import torch
+        from machisplin_amd import mltps as ml, models as mm, tiles as tl
+        mhs = self.mhs
+        t, l = self.run.my_units()[0]
+        ops = self.ops
+        stack = ops._stack(t)
+        g = stack.geom
+        sel = self.tiles["dat"][t]
+        f = ops.fitted[t][l]
+        cells = g.nrow * g.ncol
+        X, rows, cols = ml.station_predictors(stack, self.int_values[sel, :2])
+        keep = ops._keep[t] & ~np.isnan(X).any(axis=1)
+        X, rows, cols = X[keep], rows[keep], cols[keep]
+        y = self.int_values[sel, 2 + l][keep]
+
+        def timed(fn, reps=2):
+            best, out = 1e30, None
+            for _ in range(reps):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                out = fn()
+                torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) * 1e3)
+            return best, out
+
+        out = torch.empty((g.nrow, g.ncol), dtype=torch.float64, device="cuda")
+        kinds = [type(m).__name__ for m in f["models"]]
+        small = [i for i, k in enumerate(kinds) if k in ("Gam", "Nnet", "Earth")]
+        sv = [i for i, k in enumerate(kinds) if k == "Ksvm"]
+        rows_tab = []
+        if small:
+            ms, _ = timed(lambda: mm.members_predict(stack, [f["models"][i] for i in small], [f["weights"][i] for i in small], out=out))
+            by = cells * (4.0 * self.cfg["layers"] + 8.0)
+            rows_tab.append({"kernel": "small_members_kernel (gam+nnet+earth)", "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
+                             "work": "read C fp32 planes once + write the fp64 plane once"})
+        if sv:
+            m = f["models"][sv[0]]
+            ms, _ = timed(lambda: mm.members_predict(stack, [m], [f["weights"][sv[0]]], accumulate=True, out=out))
+            nsv, p = self.unit_params[(t, l)]["svr_shape"]
+            fl = cells * nsv * (3.0 * p + 2.0)
+            pm = pmc_derived().get("svr", {})
+            ipp = pm.get("valu_per_cell_unit", 15.07)
+            rows_tab.append({"kernel": "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9, "peak": FP64_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": fl / ms / 1e9 / FP64_PEAK_TFLOPS,
+                             "work": "(3p+2) flop per (cell, SV), exp = 1 flop; %d support vectors, %d cells" % (nsv, cells),
+                             "issue_view": {"achieved": cells * nsv / 64.0 * ipp / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
+                                            "frac": cells * nsv / 64.0 * ipp / ms / 1e6 / VALU_ISSUE_PEAK_G},
+                             "traffic": pm.get("hbm_bytes_per_cell_fetch_x2_plus_write", 0) * cells or None})
+        ms_res, res = timed(lambda: ml.ensemble_residuals(f["models"], f["weights"], f["wt_total"], X, y))
+        from machisplin_amd.tps import reduction_cache
+        with reduction_cache():
+            ms_tps, _ = timed(lambda: mhs.tps_residual_surface(g, X[:, -2:], res, cov1_at_stations=X[:, 0], tile_edge=self.cfg.get("tile_edge", 1500)), reps=1)
+            ms_tps2, _ = timed(lambda: mhs.tps_residual_surface(g, X[:, -2:], res, cov1_at_stations=X[:, 0], tile_edge=self.cfg.get("tile_edge", 1500)), reps=1)
+        nRx, nCx = tl.step3_tile_windows(g, self.cfg.get("tile_edge", 1500))[:2]
+        ms_unit, _ = timed(lambda: ops.tile_layer(t, l, out), reps=1)
+        return {"unit": [int(t), int(l)], "tile_cells": int(cells), "stations": int(y.size), "kernels": rows_tab,
+                "station_residuals_ms": ms_res, "step3_4_ms_first_layer_of_the_tile": ms_tps, "step3_4_ms_later_layers_reductions_cached": ms_tps2,
+                "step3_tiles": [int(nRx), int(nCx)], "whole_unit_ms_alone": ms_unit}
+
+    def cpu_baseline(self, ms_per_step):
+        """kind 'port': one (tile, layer) unit on the host -- the oracle's C restatement (OpenMP) of the four smooth members
+        over a bounded band of the tile's rows, extrapolated to the tile, + the unit's Step-3 tile fits (numpy QR / eigen /
+        GCV) in full + the direct-sum evaluation of one row of its Step-3 tiles, extrapolated -- times the number of units."""
+        from oracle import cbind, ensemble as oe, tiles as ot, tps as otps
+        from machisplin_amd import mltps as ml
+        host = host_info()
+        threads = host["threads_used"]
+        t, l = self.run.my_units()[0]
+        stack = self.ops._stack(t)
+        g = stack.geom
+        sel = self.tiles["dat"][t]
+        params, wts, tot = self.unit_params[(t, l)]["params"], self.unit_params[(t, l)]["weights"], self.unit_params[(t, l)]["wt_total"]
+        X, rows, cols = ml.station_predictors(stack, self.int_values[sel, :2])
+        keep = self.ops._keep[t] & ~np.isnan(X).any(axis=1)
+        X, y = X[keep], self.int_values[sel, 2 + l][keep]
+        res = None
+        for p, w in zip(params, wts):
+            rk = (y - cbind.predict(p, X, threads)) * w
+            res = rk if res is None else res + rk
+        res = res / tot
+
+        def band(nrows):
+            cov = stack.planes[:, :nrows].cpu().numpy().astype(np.float64)
+            xs, ys = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol, 0, nrows)
+            Xg = oe.stack_predictors(cov, (xs, ys))
+            t0 = time.perf_counter()
+            cbind.ensemble(params, wts, tot, Xg, threads)
+            return time.perf_counter() - t0
+
+        probe = max(1, min(g.nrow, 32))
+        tp = band(probe)
+        nrows = int(min(g.nrow, max(probe, probe * 8.0 / max(tp, 1e-3))))
+        t_ens = band(nrows) * (g.nrow / nrows)
+        og = ot.Geom(g.xmin, g.ymax, g.xres, g.yres, g.nrow, g.ncol)
+        nRx, nCx, fw, kw = ot.step3_windows(og, self.cfg.get("tile_edge", 1500))
+        knots = X[:, -2:]
+        rS = np.array([og.row_from_y(v) for v in knots[:, 1]]); cS = np.array([og.col_from_x(v) for v in knots[:, 0]])
+        t0 = time.perf_counter()
+        fits = []
+        for h in range(nRx * nCx):
+            r0, r1, c0, c1 = fw[h]
+            s_ = np.flatnonzero((rS >= r0) & (rS < r1) & (cS >= c0) & (cS < c1))
+            fits.append(otps.fit(knots[s_], res[s_]) if s_.size >= 10 else None)
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for h in range(nCx):
+            if fits[h] is None:
+                continue
+            gf = ot.window_geom(og, fw[h])
+            wk = (kw[h][0] - fw[h][0], kw[h][1] - fw[h][0], kw[h][2] - fw[h][2], kw[h][3] - fw[h][2])
+            cbind.tps_eval_grid(fits[h], gf.xmin, gf.ymax, gf.xres, gf.yres, *wk, threads=threads)
+        t_eval = (time.perf_counter() - t0) * nRx
+        n_units = self.run.n_tiles * self.run.n_layers
+        t_unit = t_ens + t_fit + t_eval
+        return {"value": self.cells / (t_unit * n_units) / 1e6, "unit": "Mcells/s (cells x response layers)", "cores": threads, "kind": "port",
+                "sample": f"one (tile, layer) unit of {n_units}: C restatement (OpenMP, {threads} threads) of the gam/nnet/earth/ksvm ensemble on "
+                          f"{nrows} of {g.nrow} rows of the tile (extrapolated: {t_ens:.0f} s) + its {nRx * nCx} Step-3 tile fits in full, numpy "
+                          f"({t_fit:.1f} s) + direct-sum evaluation of one row of {nCx} Step-3 tiles x {nRx} ({t_eval:.0f} s); mosaic, feathering and "
+                          f"tiles.merge not timed; all units assumed alike",
+                "host": host, "unit_s": t_unit, "gpu_over_cpu": t_unit * n_units * 1e3 / ms_per_step}
 
 
 def main():
@@ -634,6 +812,15 @@ def main():
                 "rsq_model_mean": float(np.nanmean(out["rsq_model"])), "rsq_final_mean": float(np.nanmean(out["rsq_final"])),
                 "roofline": None, "cpu_baseline": None,
             }
+            prof = wl.unit_profile()
+            dom = max(prof["kernels"], key=lambda r: r["launch_ms"]) if prof["kernels"] else None
+            res["unit_profile"] = prof
+            res["roofline"] = ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work", "issue_view")
+                                if k in dom} if dom else None)
+            if res["roofline"] is not None:
+                res["roofline"].setdefault("traffic", None)
+            if not args.no_cpu_baseline and world == 1:
+                res["cpu_baseline"] = wl.cpu_baseline(res["ms_per_step"])
             print(json.dumps(res), flush=True)
         if world > 1:
             dist.barrier()
@@ -734,8 +921,8 @@ def main():
                        "parallelism": ("rowband%d + bcast(coef) + 1 all-gather" if args.tps_mode == "global" else
                                        "rowband%d + Step-3 tiles dealt over the ranks + 1 all-gather") % world,
                        "rank0_row_share": wl.rank0_share},
-            "roofline": ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work")}
-                         if dom else None),  # None only if rank 0 was given no rows at all
+            "roofline": ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work", "pmc",
+                                               "ops_view", "issue_view") if k in dom} if dom else None),  # None only if rank 0 was given no rows at all
             "kernels": table,
             "tps_fit_ms": fit_ms, "tps_fit_ms_overlapped_with_ensemble": fit_overlapped_ms,
             "tps_solve_gflops": 4.0 * m ** 3 / 3.0 / (fit_ms * 1e-3) / 1e9,

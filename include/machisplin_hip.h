@@ -273,6 +273,10 @@ MHS_API int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, d
  * what machisplin.gbm.step evaluates on every fold's hold-out rows after each gbm.more (V73:1843, 1919) to build
  * the hold-out deviance curve its tree-count search runs on (V73:1884-1981).  X: n x p column-major.             */
 MHS_API int mhs_gbm_staged_points(const mhs_model *m, const double *X, int64_t n, int step, double *out_host);
+/* What a loaded model is: kind (0 lm, 1 nnet, 2 earth, 3 ksvm, 4 gbm, 5 randomForest), its number of predictors p and,
+ * for the tree ensembles, its tree count (0 otherwise).  Callers size their outputs from it -- mhs_gbm_staged_points
+ * writes n * (n_trees / step) values whatever n.trees the R side believes the model has.  Any output pointer may be NULL. */
+MHS_API int mhs_model_info(const mhs_model *m, int *kind, int *p, int64_t *n_trees);
 /* res.FINAL in one call (V73:477-482, 501-505, 525-528, 547-549, 586-589, 608-611, 620): the kept members at the
  * n station rows X (as above), out[i] = ((resp_i - pred_1) w_1 + (resp_i - pred_2) w_2 + ...) / wt_total, accumulated
  * member after member; weights = the rounded kept weights, wt_total the unrounded total (at most 8 members). */

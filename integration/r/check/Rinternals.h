@@ -37,6 +37,10 @@ R_xlen_t Rf_xlength(SEXP);
 int Rf_nrows(SEXP);
 int Rf_ncols(SEXP);
 Rboolean Rf_isNull(SEXP);
+Rboolean Rf_isReal(SEXP);
+Rboolean Rf_isMatrix(SEXP);
+extern int R_NaInt;
+#define NA_INTEGER R_NaInt
 SEXP Rf_ScalarInteger(int);
 SEXP Rf_ScalarReal(double);
 SEXP Rf_mkString(const char *);

@@ -153,7 +153,10 @@ SEXP mhsr_lm_fit(SEXP X, SEXP y) {
 /* kernlab::ksvm(mod.form, data) (V73:251, V73:560) with kpar = list(sigma = sigma): returns list(beta[n], b,
  * x.center[p], x.scale[p], y.center, y.scale, iterations); the support vectors are the rows with beta != 0 */
 SEXP mhsr_svr_fit(SEXP X, SEXP y, SEXP sigma, SEXP C, SEXP epsilon, SEXP tol) {
+    if (!Rf_isReal(X) || !Rf_isMatrix(X) || !Rf_isReal(y)) Rf_error("mhsr_svr_fit: X must be a double matrix and y a double vector");
     int n = Rf_nrows(X), p = Rf_ncols(X);
+    if (Rf_length(y) != n) Rf_error("mhsr_svr_fit: length(y) = %d but X has %d rows", Rf_length(y), n);
+    if (p < 1 || p > 12) Rf_error("mhsr_svr_fit: 1..12 predictors supported, got %d", p);
     SEXP out = PROTECT(Rf_allocVector(VECSXP, 7));
     SEXP beta = PROTECT(Rf_allocVector(REALSXP, n)), xc = PROTECT(Rf_allocVector(REALSXP, p)), xs = PROTECT(Rf_allocVector(REALSXP, p));
     double b = 0, yc = 0, ys = 0;
@@ -173,7 +176,11 @@ SEXP mhsr_svr_fit(SEXP X, SEXP y, SEXP sigma, SEXP C, SEXP epsilon, SEXP tol) {
  * weights wts0 (nnet's own: runif(length, -0.7, 0.7)); y already scaled as V73:455-459.
  * returns list(wts, value, counts[2], fail) */
 SEXP mhsr_nnet_fit(SEXP X, SEXP y, SEXP wts0, SEXP maxit) {
+    if (!Rf_isReal(X) || !Rf_isMatrix(X) || !Rf_isReal(y) || !Rf_isReal(wts0)) Rf_error("mhsr_nnet_fit: X must be a double matrix, y and wts0 double vectors");
     int nw = Rf_length(wts0);
+    if (Rf_ncols(X) < 1 || Rf_ncols(X) > 12) Rf_error("mhsr_nnet_fit: 1..12 predictors supported, got %d", Rf_ncols(X));
+    if (Rf_length(y) != Rf_nrows(X)) Rf_error("mhsr_nnet_fit: length(y) = %d but X has %d rows", Rf_length(y), Rf_nrows(X));
+    if (nw != (Rf_ncols(X) + 1) * 10 + 11) Rf_error("mhsr_nnet_fit: wts0 must hold (ncol(X) + 1) * 10 + 11 = %d weights, got %d", (Rf_ncols(X) + 1) * 10 + 11, nw);
     SEXP out = PROTECT(Rf_allocVector(VECSXP, 4));
     SEXP w = PROTECT(Rf_allocVector(REALSXP, nw)), counts = PROTECT(Rf_allocVector(INTSXP, 2));
     for (int i = 0; i < nw; ++i) REAL(w)[i] = REAL(wts0)[i];
@@ -193,9 +200,20 @@ SEXP mhsr_nnet_fit(SEXP X, SEXP y, SEXP wts0, SEXP maxit) {
 /* gbm::predict.gbm(model, x.data[pred.mask, ], n.trees = k * step) for k = 1 .. in one pass (V73:1843, 1919): returns the
  * n x stages matrix machisplin.gbm.step's hold-out deviance curve is computed from */
 SEXP mhsr_gbm_staged_points(SEXP model, SEXP X, SEXP step, SEXP n_trees) {
-    int n = Rf_nrows(X), stages = Rf_asInteger(n_trees) / Rf_asInteger(step);
+    const mhs_model *m = (const mhs_model *)R_ExternalPtrAddr(model);
+    int kind = -1, p = 0, st = Rf_asInteger(step);
+    int64_t trees = 0;
+    chk(mhs_model_info(m, &kind, &p, &trees));
+    if (kind != 4) Rf_error("mhsr_gbm_staged_points: the handle is not a gbm model");
+    if (st == NA_INTEGER || st < 1) Rf_error("mhsr_gbm_staged_points: step must be >= 1");
+    if (!Rf_isReal(X) || !Rf_isMatrix(X) || Rf_ncols(X) != p) Rf_error("mhsr_gbm_staged_points: X must be a double matrix with %d columns", p);
+    /* the library walks the trees the HANDLE holds and writes n x (trees / step) values: the matrix is sized from the
+     * handle, and a caller whose n.trees disagrees with it is told so instead of being overrun */
+    if (Rf_asInteger(n_trees) != NA_INTEGER && (int64_t)Rf_asInteger(n_trees) != trees)
+        Rf_error("mhsr_gbm_staged_points: n.trees = %d but the loaded model has %lld trees", Rf_asInteger(n_trees), (long long)trees);
+    int n = Rf_nrows(X), stages = (int)(trees / st);
     SEXP out = PROTECT(Rf_allocMatrix(REALSXP, n, stages));
-    int rc = mhs_gbm_staged_points((const mhs_model *)R_ExternalPtrAddr(model), REAL(X), (int64_t)n, Rf_asInteger(step), REAL(out));
+    int rc = stages > 0 && n > 0 ? mhs_gbm_staged_points(m, REAL(X), (int64_t)n, st, REAL(out)) : 0;
     UNPROTECT(1);
     chk(rc);
     return out;

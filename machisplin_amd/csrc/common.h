@@ -80,6 +80,7 @@ int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                  int gcv_threads, mhs_tps **out);
 int require_ready();
+void reduction_cache_clear();           // tps_fit.hip: drop every cached reduction (mhs_shutdown)
 // Blocking host -> device copy that does NOT go through the NULL stream: a plain hipMemcpy synchronises with every
 // blocking stream -- the CU-masked streams of mhs_fit_reserve_cus are blocking ones, so it would wait for the forest.
 int h2d_sync(void *dst, const void *src, size_t bytes);

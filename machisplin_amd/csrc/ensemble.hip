@@ -9,6 +9,7 @@
 // bound tree walks (node records staged chunk-wise in LDS, predictors parked in LDS so a
 // lane can index them by the node's split variable).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2619,7 +2620,7 @@ int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weigh
 // band k, upload of band k + 1, download of band k - 1": copies from / to pageable memory block the CALLING THREAD until
 // they are staged, so the kernels must already be in the queue when the thread goes into them.  Cells are independent
 // and a band is described with the parent grid's affine, so the plane equals the one-piece evaluation bit for bit.
-// MHS_HOST_BANDS overrides the band count (1 = the serial round-2 behaviour, minus the allocations).
+// MHS_HOST_BANDS = n forces n equal bands (1 = the serial round-2 behaviour, minus the allocations).
 int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, int n_models,
                          double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0,
                          int64_t r1, int64_t c0, int64_t c1, double *out_host) {
@@ -2631,12 +2632,27 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     for (int k = 0; k < n_models; ++k)
         MHS_REQUIRE(models[k] && covars->n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
     const size_t esz = covars->dtype == MHS_F64 ? 8 : covars->dtype == MHS_F32 ? 4 : 2;
-    // bands of ~12 M cells (8 for the 10 000 x 10 000 grid): the first upload and the last download are all that is not
-    // hidden, and a band is still ~10 rounds of the forest's 5 000-cell blocks over the device
-    int64_t nb = std::max<int64_t>(1, std::min<int64_t>(nr, (nr * nc + 6250000) / 12500000));
-    if (const char *e = getenv("MHS_HOST_BANDS")) nb = std::max<int64_t>(1, std::min<int64_t>(nr, atoll(e)));
-    const int64_t rows_per = (nr + nb - 1) / nb;
-    nb = (nr + rows_per - 1) / rows_per;
+    // Band plan.  Measured on cfg3 (tools/r03_host_abi.py): the copies do hide behind the kernels, what a band costs is the
+    // partly filled last round of each member kernel, ~3-5 ms per band -- so FEW bands; and all that stays exposed is the
+    // first band's upload and the last band's download -- so those two bands are SHORT (8 % of the rows each, at least one
+    // round of blocks over the device) and the rows between them go in bands of at most ~100 M cells (they bound the
+    // arena: two covariate bands + two result bands).  Small windows go in one piece.  MHS_HOST_BANDS = n: n equal bands.
+    std::vector<int64_t> edge;       // band b = rows [edge[b], edge[b + 1])
+    edge.push_back(r0);
+    const int64_t cells = nr * nc;
+    if (const char *e = getenv("MHS_HOST_BANDS")) {
+        const int64_t n = std::max<int64_t>(1, std::min<int64_t>(nr, atoll(e))), rp = (nr + n - 1) / n;
+        for (int64_t r = r0 + rp; r < r1; r += rp) edge.push_back(r);
+    } else if (cells >= 16000000 && nr >= 8) {
+        const int64_t ends = std::min<int64_t>(nr / 4, std::max<int64_t>((nr * 8 + 99) / 100, (1500000 + nc - 1) / nc));
+        const int64_t mid = nr - 2 * ends, nmid = std::max<int64_t>(1, (mid * nc + 99999999) / 100000000), rp = (mid + nmid - 1) / nmid;
+        for (int64_t r = r0 + ends; r < r1 - ends; r += rp) edge.push_back(r);
+        edge.push_back(r1 - ends);
+    }
+    edge.push_back(r1);
+    const int64_t nb = (int64_t)edge.size() - 1;
+    int64_t rows_per = 0;
+    for (int64_t b = 0; b < nb; ++b) rows_per = std::max(rows_per, edge[(size_t)b + 1] - edge[(size_t)b]);
     const size_t in_bytes = ((size_t)rows_per * covars->ld * esz * (size_t)covars->n_layers + 255) & ~(size_t)255;
     const size_t out_bytes = ((size_t)rows_per * nc * sizeof(double) + 255) & ~(size_t)255;
     std::lock_guard<std::mutex> lk(pipe_mutex());
@@ -2644,17 +2660,20 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     Context &c = ctx();
     char *in[2] = {c.pipe_arena, c.pipe_arena + in_bytes};
     double *outb[2] = {(double *)(c.pipe_arena + 2 * in_bytes), (double *)(c.pipe_arena + 2 * in_bytes + out_bytes)};
-    auto band_rows = [&](int64_t b, int64_t *b0, int64_t *b1) { *b0 = r0 + b * rows_per; *b1 = std::min(r1, *b0 + rows_per); };
+    const bool timing = getenv("MHS_HOST_TIMING") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now_ms();
+    auto band_rows = [&](int64_t b, int64_t *b0, int64_t *b1) { *b0 = edge[(size_t)b]; *b1 = edge[(size_t)b + 1]; };
     auto upload = [&](int64_t b) -> int {
         const int sl = (int)(b & 1);
         int64_t b0, b1;
         band_rows(b, &b0, &b1);
         if (b >= 2) MHS_HIP(hipStreamWaitEvent(c.pipe_h2d, c.pipe_done[sl], 0));      // band b - 2's kernels read this buffer
         const size_t plane_bytes = (size_t)(b1 - b0) * covars->ld * esz;
-        for (int k = 0; k < covars->n_layers; ++k)
-            MHS_HIP(hipMemcpyAsync(in[sl] + plane_bytes * k,
-                                   (const char *)covars->data + ((size_t)k * covars->plane_stride + (size_t)b0 * covars->ld) * esz,
-                                   plane_bytes, hipMemcpyHostToDevice, c.pipe_h2d));
+        for (int k = 0; k < covars->n_layers; ++k) {
+            const char *src = (const char *)covars->data + ((size_t)k * covars->plane_stride + (size_t)b0 * covars->ld) * esz;
+            MHS_HIP(hipMemcpyAsync(in[sl] + plane_bytes * k, src, plane_bytes, hipMemcpyHostToDevice, c.pipe_h2d));
+        }
         MHS_HIP(hipEventRecord(c.pipe_in[sl], c.pipe_h2d));
         return MHS_OK;
     };
@@ -2673,8 +2692,9 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         const int sl = (int)(b & 1);
         int64_t b0, b1;
         band_rows(b, &b0, &b1);
-        MHS_HIP(hipStreamWaitEvent(c.pipe_comp, c.pipe_in[sl], 0));
-        if (b >= 2) MHS_HIP(hipStreamWaitEvent(c.pipe_comp, c.pipe_out[sl], 0));       // band b - 2's result has left this buffer
+        hipStream_t cs = c.pipe_comp;
+        MHS_HIP(hipStreamWaitEvent(cs, c.pipe_in[sl], 0));
+        if (b >= 2) MHS_HIP(hipStreamWaitEvent(cs, c.pipe_out[sl], 0));       // band b - 2's result has left this buffer
         // The device copy is described with the PARENT grid's affine (cell centres stay bit-identical): plane k, absolute
         // row r lives at base + (k * plane_stride + r * ld) * esz, so the base is shifted back by b0 rows and plane_stride
         // skips the rows that were shipped.
@@ -2684,13 +2704,17 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         sd.data = in[sl] - (size_t)b0 * covars->ld * esz; sd.C = covars->n_layers; sd.dtype = covars->dtype;
         sd.plane_stride = (b1 - b0) * covars->ld; sd.ld = covars->ld; sd.nodata = covars->nodata;
         sd.has_nodata = !std::isnan(covars->nodata); sd.all_from_planes = 0;
-        if (int rc = launch_members(models, weights, n_models, sd, pg, 0, outb[sl], c.pipe_comp, g)) return rc;
-        hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)(((b1 - b0) * nc + 255) / 256)), dim3(256), 0, c.pipe_comp,
+        if (int rc = launch_members(models, weights, n_models, sd, pg, 0, outb[sl], cs, g)) return rc;
+        hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)(((b1 - b0) * nc + 255) / 256)), dim3(256), 0, cs,
                            outb[sl], (int)(b1 - b0), (int)nc, nc, wt_total);
         MHS_HIP(hipGetLastError());
-        MHS_HIP(hipEventRecord(c.pipe_done[sl], c.pipe_comp));
+        MHS_HIP(hipEventRecord(c.pipe_done[sl], cs));
+        const double t0 = now_ms();
         if (b + 1 < nb) if (int rc = upload(b + 1)) return rc;
+        const double t1 = now_ms();
         if (b >= 1) if (int rc = download(b - 1)) return rc;
+        if (timing) fprintf(stderr, "[mhs_ensemble_predict] band %lld launched at %.1f ms: upload of the next %.1f ms, download of the previous %.1f ms\n",
+                            (long long)b, t0 - t_start, t1 - t0, now_ms() - t1);
     }
     if (int rc = download(nb - 1)) return rc;
     MHS_HIP(hipStreamSynchronize(c.pipe_d2h));
@@ -2715,6 +2739,14 @@ int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *o
     if (int rc = launch_model(m, sd, pg, 1.0, 0, dout.p, s)) return rc;
     MHS_HIP(hipMemcpyAsync(out_host, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
     MHS_HIP(hipStreamSynchronize(s));
+    return MHS_OK;
+}
+
+int mhs_model_info(const mhs_model *m, int *kind, int *p, int64_t *n_trees) {
+    MHS_REQUIRE(m != nullptr, "NULL model");
+    if (kind) *kind = m->kind;
+    if (p) *p = m->p;
+    if (n_trees) *n_trees = (m->kind == K_GBM || m->kind == K_RF) ? m->n_trees : 0;
     return MHS_OK;
 }
 

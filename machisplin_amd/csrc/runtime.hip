@@ -1,5 +1,6 @@
 // Runtime of libmachisplin_hip.so: device selection, the library stream, error
 // reporting, constant tables and HIP-event timers.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -184,6 +185,7 @@ int mhs_shutdown(void) {
     Context &c = ctx();
     if (!c.ready) return MHS_OK;
     (void)hipStreamSynchronize(c.stream);
+    reduction_cache_clear();              // device pointers of this device must not outlive it
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
     if (c.mosaic_arena) (void)hipFree(c.mosaic_arena);

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <unordered_map>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -763,7 +764,7 @@ template <int PANEL_WAVES>
 __global__ __launch_bounds__(64 * PANEL_WAVES) void band_panel_reg_kernel(double *__restrict__ A, int64_t ld, int c0,
                                                                           int r0, int t, double *__restrict__ Vd,
                                                                           int64_t vs, double *__restrict__ Tm,
-                                                                          double *__restrict__ g) {
+                                                                          double *__restrict__ g, double *__restrict__ aux) {
     constexpr int PANEL_THREADS = 64 * PANEL_WAVES;   // shadows the largest form's constant
     __shared__ PanelShared<PANEL_WAVES> sh;
 #ifdef MHS_PANEL_TRACE
@@ -847,6 +848,9 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void band_panel_reg_kernel(double
             g[(unsigned)i] = gi;
         }
     }
+    // what "Q' onto another right-hand side" needs to repeat this panel's update of g bit for bit (band_qt_kernel; the
+    // reduction cache of the band route): tau_0..7 and G = (v_l'v_j)
+    if (aux) for (int e = threadIdx.x; e < BW + BW * BW; e += PANEL_THREADS) aux[e] = e < BW ? sh.taus[e] : sh.Gs[(e - BW) / BW][(e - BW) % BW];
     if (wave == 0) {
         // larft, after the stores so that the panel's registers are free: lane i < BW forms row i of T
         // (T[i][j] = -tau_j sum_{l=i}^{j-1} T[i][l] G[l][j], a recurrence along the row only)
@@ -872,6 +876,94 @@ extern "C" __attribute__((visibility("default"))) int mhs_debug_panel_trace(unsi
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_trace), sizeof(unsigned long long) * 64);
 }
 #endif
+
+// g <- Q'g for ANOTHER right-hand side with the reflectors of a finished band reduction (mhs_tps_reduction_cache, band
+// route: the other response layers of a station table, V73:203 -- B = Q2'KQ2 depends on the coordinates only).  One block
+// walks the panels in order and repeats, per panel, exactly what band_panel_reg_kernel did to g: the same rows per
+// thread (i = tid + 64 NW r with the panel's own wave count NW), the same fma chain for V'g, the same lane-swap / DPP
+// reduction tree, the same recurrence for z = T'(V'g) from tau and G = (v_l'v_j) (stored by the panel kernel: aux), the
+// same multiply-subtract order -- so the rotated g, hence lambda, c and d, equal the full fit's bit for bit.
+constexpr int PANEL_AUX = BW + BW * BW;
+template <int NW>
+__device__ __forceinline__ void qt_panel(const double *__restrict__ P, int64_t ld, int t, const double *__restrict__ aux,
+                                         double *__restrict__ g, double (*part)[BW]) {
+    constexpr int PT = 64 * NW;
+    const int nref = min(BW, t - 1);
+    const int lane = threadIdx.x & 63;
+    const bool on = (int)threadIdx.x < PT;
+    double v[PANEL_RPT][BW], gi[PANEL_RPT];
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < PANEL_RPT; ++r) {
+            const int i = threadIdx.x + PT * r;
+            const unsigned ii = i < t ? (unsigned)i : 0u;
+#pragma unroll
+            for (int j = 0; j < BW; ++j) v[r][j] = P[(int64_t)j * ld + ii];
+            gi[r] = i < t ? g[ii] : 0.0;
+        }
+        double sg[BW];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) sg[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < PANEL_RPT; ++r) {
+            const int i = threadIdx.x + PT * r;
+#pragma unroll
+            for (int j = 0; j < BW; ++j) {
+                const double vj = i >= t ? 0.0 : (r > 0 ? v[r][j] : ((j >= nref || i < j) ? 0.0 : (i == j ? 1.0 : v[r][j])));
+                v[r][j] = vj;
+                sg[j] = fma(vj, gi[r], sg[j]);
+            }
+        }
+        wave_publish<BW>(sg, part);
+    }
+    __syncthreads();
+    if (on) {
+        const int b = lane < BW ? lane : BW - 1;
+        const double sgb = block_total<BW, NW>(part), taub = aux[b];
+        double zb = 0.0;
+#pragma unroll
+        for (int a = 0; a < BW; ++a) {
+            double c = b < a ? aux[BW + b * BW + a] * zb : 0.0;
+            c += dpp_fetch<0xB1, 0xf>(c);
+            c += dpp_fetch<0x4E, 0xf>(c);
+            c += dpp_fetch<0x141, 0xf>(c);
+            if (b == a) zb = taub * (sgb - c);
+        }
+        double z[BW];
+#pragma unroll
+        for (int a = 0; a < BW; ++a) z[a] = lane_value(zb, a);
+#pragma unroll
+        for (int r = 0; r < PANEL_RPT; ++r) {
+            const int i = threadIdx.x + PT * r;
+            if (i < t) {
+                double x = gi[r];
+#pragma unroll
+                for (int j = 0; j < BW; ++j) x -= v[r][j] * z[j];
+                g[(unsigned)i] = x;
+            }
+        }
+    }
+    __syncthreads();      // g of the next panel's rows is in place, the partial buffer may be reused
+}
+
+__global__ __launch_bounds__(PANEL_THREADS) void band_qt_kernel(const double *__restrict__ A, int64_t ld, int off0, int m, int npanels,
+                                                                const double *__restrict__ aux, double *__restrict__ g) {
+    __shared__ double part[PANEL_THREADS / 64][BW];
+    for (int p = 0; p < npanels; ++p) {
+        const int c = p * BW, t = m - c - BW;
+        const double *P = A + (int64_t)(off0 + c) * ld + off0 + c + BW;
+        const int nw = t <= 256 * PANEL_RPT ? (t + 64 * PANEL_RPT - 1) / (64 * PANEL_RPT) : PANEL_THREADS / 64;   // tps_fit_lane's choice
+        const double *ax = aux + (int64_t)p * PANEL_AUX;
+        double *gp = g + c + BW;
+        switch (nw) {
+            case 1: qt_panel<1>(P, ld, t, ax, gp, part); break;
+            case 2: qt_panel<2>(P, ld, t, ax, gp, part); break;
+            case 3: qt_panel<3>(P, ld, t, ax, gp, part); break;
+            case 4: qt_panel<4>(P, ld, t, ax, gp, part); break;
+            default: qt_panel<PANEL_THREADS / 64>(P, ld, t, ax, gp, part); break;
+        }
+    }
+}
 
 // Sum 64 per-lane values over the wave: two halving stages with the gfx950 lane-swap instructions
 // (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd and even rows between two registers, so
@@ -1824,20 +1916,42 @@ __global__ __launch_bounds__(NW * 64) void tridiag_qt_kernel(const double *__res
     }
 }
 
-// The reduction of one station set (small route), kept for the other response layers of the same table:
-// reflectors + tau on the device, the tridiagonal and the three projected rows on the host.
+// The reduction of one station set, kept for the other response layers of the same table.  Small route: reflectors + tau
+// on the device, the tridiagonal and the three projected rows on the host.  Band route (round 3): the reduced matrix
+// (band + reflectors, n x ld), the panels' T factors and (tau, G) records on the device, the band and the projected rows
+// on the host.  Entries are shared_ptr-owned: a fit keeps its hit alive while mhs_tps_reduction_cache(0) -- or
+// mhs_shutdown -- empties the map from another thread.
 struct ReductionEntry {
     int64_t n = 0;
     int m = 0;
     std::vector<double> uv, sw, td, te, Atop;
     double *refl = nullptr, *tau = nullptr;      // device: m x m (ld = m), m
+    // band route
+    bool band = false;
+    int64_t ld = 0;
+    int npanels = 0;
+    double *Ared = nullptr, *Tall = nullptr, *aux = nullptr;   // device
+    std::vector<double> ab;                                    // host: m x (BW + 1)
+    ~ReductionEntry() {
+        for (double *q : {refl, tau, Ared, Tall, aux}) if (q) (void)hipFree(q);
+        (void)hipGetLastError();
+    }
 };
 struct ReductionCache {
     std::mutex mu;
     bool enabled = false;
-    std::unordered_multimap<uint64_t, ReductionEntry *> map;
+    std::unordered_multimap<uint64_t, std::shared_ptr<ReductionEntry>> map;
 };
 static ReductionCache g_rcache;
+void reduction_cache_clear() {      // mhs_shutdown / mhs_init on another device: nothing of the old device survives
+    std::vector<std::shared_ptr<ReductionEntry>> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_rcache.mu);
+        g_rcache.enabled = false;
+        for (auto &kv : g_rcache.map) dead.push_back(std::move(kv.second));
+        g_rcache.map.clear();
+    }
+}
 static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h) {
     const unsigned char *c = (const unsigned char *)p;
     for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
@@ -2006,7 +2120,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     int npanels = 0;
     for (int c = 0; m - c - BW >= 2; c += BW) ++npanels;
     struct P { double *p; };
-    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp, v3buf, w3buf, ypbuf;
+    P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp, v3buf, w3buf, ypbuf, auxb;
     const bool fixed = !std::isnan(lambda);
     int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme (MHS_DELAY_T overrides)
     if (const char *e = getenv("MHS_DELAY_T")) t_delay = std::max(BW, atoi(e));
@@ -2034,6 +2148,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         Yp.p = ar.take<double>((size_t)SYMM_MAX_SPLITS * BW * vs);
         Mp.p = ar.take<double>((size_t)((m + SYMM_COLS - 1) / SYMM_COLS + 1) * SYMM_MAX_SPLITS * BW * BW);
         Tall.p = ar.take<double>((size_t)std::max(npanels, 1) * BW * BW);
+        auxb.p = ar.take<double>((size_t)std::max(npanels, 1) * PANEL_AUX);
         const bool big = !fixed && m - BW > t_delay;   // the delayed scheme's group buffers (large fits only)
         Zb.p = ar.take<double>(big ? (size_t)DG_K * vs + 16 : 1);
         Zb2.p = ar.take<double>(big ? (size_t)DG_K * vs + 16 : 1);
@@ -2056,19 +2171,22 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     }
     // mhs_tps_reduction_cache: the reduction of this station set may already be there (another response layer)
     const bool small_route = !fixed && m <= TRI_SMALL_CUT && m >= 3;
-    const ReductionEntry *hit = nullptr;
+    // band route: cacheable while every panel is a register-resident one (band_qt_kernel mirrors that kernel's update of g)
+    const bool band_cacheable = !fixed && !small_route && npanels > 0 && m - BW <= PANEL_THREADS * PANEL_RPT;
+    std::shared_ptr<ReductionEntry> hit_sp;
     uint64_t rkey = 0;
     bool rcache_on = false;
-    if (small_route) {
+    if (small_route || band_cacheable) {
         std::lock_guard<std::mutex> lk(g_rcache.mu);
         rcache_on = g_rcache.enabled;
         if (rcache_on) {
             rkey = fnv1a(sw.data(), sizeof(double) * sw.size(), fnv1a(uv.data(), sizeof(double) * uv.size(), 1469598103934665603ull ^ (uint64_t)n));
             auto range = g_rcache.map.equal_range(rkey);
-            for (auto it = range.first; it != range.second && !hit; ++it)
-                if (it->second->n == n && it->second->uv == uv && it->second->sw == sw) hit = it->second;
+            for (auto it = range.first; it != range.second && !hit_sp; ++it)
+                if (it->second->n == n && it->second->band == band_cacheable && it->second->uv == uv && it->second->sw == sw) hit_sp = it->second;
         }
     }
+    const ReductionEntry *hit = hit_sp.get();      // kept alive by hit_sp whatever another thread does to the map
     if (!hit) {
     MHS_HIP(hipMemcpyAsync(duv.p, uv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(dsw.p, sw.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -2176,7 +2294,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         MHS_HIP(hipStreamSynchronize(s));
         lap(hit ? "Q'g with the cached reflectors" : "tridiagonalisation (GPU, one block)");
         if (!hit && rcache_on) {      // keep the reduction for the next response layer on these stations
-            ReductionEntry *e = new ReductionEntry();
+            auto e = std::make_shared<ReductionEntry>();
             e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->td = td; e->te = te; e->Atop = Atop;
             bool ok = hipMalloc((void **)&e->refl, sizeof(double) * (size_t)m * m) == hipSuccess &&
                       hipMalloc((void **)&e->tau, sizeof(double) * (size_t)m) == hipSuccess;
@@ -2186,9 +2304,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             ok = ok && hipStreamSynchronize(s) == hipSuccess;
             if (ok) {
                 std::lock_guard<std::mutex> lk(g_rcache.mu);
-                if (g_rcache.enabled) { g_rcache.map.emplace(rkey, e); e = nullptr; }
-            }
-            if (e) { if (e->refl) (void)hipFree(e->refl); if (e->tau) (void)hipFree(e->tau); delete e; (void)hipGetLastError(); }
+                if (g_rcache.enabled) g_rcache.map.emplace(rkey, e);
+            } else (void)hipGetLastError();
         }
         TridiagGcv tg;
         tg.a = td.data(); tg.b = te.data(); tg.g = g.data(); tg.m = m; tg.n = n; tg.N = N; tg.pure_ss = pure_ss;
@@ -2206,6 +2323,22 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     } else {
         // reduce B to bandwidth BW in place (blocked), rotating g = Q' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        const bool store_aux = band_cacheable && rcache_on && !hit;
+        const double *redA = A.p, *redT = Tall.p;      // what the back-transform reads: this fit's reduction, or the cached one
+        int64_t red_ld = ld;
+        std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
+        struct Lease { GcvPool *p = nullptr; ~Lease() { gcv_pool_release(p); } } lease;
+        if (hit) {
+            // another response layer on a station set reduced before: only the right-hand side goes through the panels
+            redA = hit->Ared; redT = hit->Tall; red_ld = hit->ld;
+            ab = hit->ab;
+            hipLaunchKernelGGL(band_qt_kernel, dim3(1), dim3(PANEL_THREADS), 0, s, hit->Ared, hit->ld, 3, m, npanels, hit->aux, gbuf.p);
+            MHS_HIP(hipGetLastError());
+            MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            lease.p = gcv_pool_lease(gcv_threads);
+            MHS_HIP(hipStreamSynchronize(s));
+            lap("Q'g with the cached band reduction");
+        } else {
         // Two streams: the panel factorisation of step p+1 needs only the first column block of the trailing
         // matrix as updated by step p.  That block is updated first, on the main stream, which goes straight on
         // to the (single-block, latency-bound) panel kernel of step p+1, while the rest of step p's update runs
@@ -2237,7 +2370,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 // 640 rows per wave up to one wave per SIMD; beyond that all 8 (5 .. 7 waves load the SIMDs unevenly:
                 // t = 4197 took 44 us with 7 against 38.5 with 8)
                 const int nw = t <= 256 * PANEL_RPT ? (t + 64 * PANEL_RPT - 1) / (64 * PANEL_RPT) : PANEL_THREADS / 64;
-#define MHS_PANEL(NW) case NW: hipLaunchKernelGGL(band_panel_reg_kernel<NW>, dim3(1), dim3(64 * NW), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW); break;
+#define MHS_PANEL(NW) case NW: hipLaunchKernelGGL(band_panel_reg_kernel<NW>, dim3(1), dim3(64 * NW), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW, store_aux ? auxb.p + (size_t)p * PANEL_AUX : nullptr); break;
                 switch (nw) { MHS_PANEL(1) MHS_PANEL(2) MHS_PANEL(3) MHS_PANEL(4) default: MHS_PANEL(8) }
 #undef MHS_PANEL
             }
@@ -2289,15 +2422,32 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (pending_rest) MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0));
         hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)((m * (BW + 1) + 255) / 256)), dim3(256), 0, s, A.p, ld, 3, m, abd.p);
         MHS_HIP(hipGetLastError());
-        std::vector<double> ab((size_t)m * (BW + 1)), g((size_t)m), q((size_t)m);
         MHS_HIP(hipMemcpyAsync(ab.data(), abd.p, sizeof(double) * ab.size(), hipMemcpyDeviceToHost, s));
         MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         // wake the GCV workers while the last panels are still running
-        struct Lease { GcvPool *p = nullptr; ~Lease() { gcv_pool_release(p); } } lease;
         if (npanels > 0) MHS_HIP(hipEventSynchronize(pool[2 * npanels]));
         lease.p = gcv_pool_lease(gcv_threads);
         MHS_HIP(hipStreamSynchronize(s));
         lap("band reduction (GPU)");
+        if (store_aux) {      // keep the reduction for the next response layer on these stations (200 MB at n = 5 000)
+            auto e = std::make_shared<ReductionEntry>();
+            e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->Atop = Atop; e->band = true; e->ld = ld; e->npanels = npanels; e->ab = ab;
+            const size_t abytes = sizeof(double) * (size_t)ld * (size_t)(3 + m);
+            double *raw = nullptr;
+            bool ok = hipMalloc((void **)&raw, abytes) == hipSuccess;
+            if (ok) e->Ared = raw;      // no 16-byte row alignment needed: only band_qt_kernel and the back-transform read it
+            ok = ok && hipMalloc((void **)&e->Tall, sizeof(double) * (size_t)npanels * BW * BW) == hipSuccess &&
+                 hipMalloc((void **)&e->aux, sizeof(double) * (size_t)npanels * PANEL_AUX) == hipSuccess;
+            ok = ok && hipMemcpyAsync(e->Ared, A.p, abytes, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(e->Tall, Tall.p, sizeof(double) * (size_t)npanels * BW * BW, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(e->aux, auxb.p, sizeof(double) * (size_t)npanels * PANEL_AUX, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+            if (ok) {
+                std::lock_guard<std::mutex> lk(g_rcache.mu);
+                if (g_rcache.enabled) g_rcache.map.emplace(rkey, e);
+            } else (void)hipGetLastError();
+        }
+        }
         BandGcv bg;
         bg.ab = ab.data(); bg.g = g.data(); bg.m = m; bg.n = n; bg.N = N; bg.bw = BW; bg.pure_ss = pure_ss; bg.threads = gcv_threads;
         bg.pool = lease.p;
@@ -2309,7 +2459,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
         if (npanels > 0) {
             if (m <= BT_THREADS * BT_RPT)
-                hipLaunchKernelGGL(band_backtransform_reg_kernel, dim3(1), dim3(BT_THREADS), 0, s, A.p, ld, 3, m, npanels, Tall.p, gbuf.p);
+                hipLaunchKernelGGL(band_backtransform_reg_kernel, dim3(1), dim3(BT_THREADS), 0, s, redA, red_ld, 3, m, npanels, redT, gbuf.p);
             else if (m <= BTM_RPB * BTM_MAXBLK) {
                 const unsigned nblk = (unsigned)((m + BTM_RPB - 1) / BTM_RPB);
                 for (int p = npanels; p >= 0; --p)      // launch p applies panel p (none for p = npanels) and prepares panel p - 1
@@ -2355,15 +2505,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
 
 extern "C" int mhs_tps_reduction_cache(int enable) {
     if (int rc = require_ready()) return rc;
-    std::vector<ReductionEntry *> dead;
-    {
+    if (enable) {
         std::lock_guard<std::mutex> lk(g_rcache.mu);
-        if (enable) { g_rcache.enabled = true; return MHS_OK; }
-        g_rcache.enabled = false;
-        for (auto &kv : g_rcache.map) dead.push_back(kv.second);
-        g_rcache.map.clear();
+        g_rcache.enabled = true;
+        return MHS_OK;
     }
-    for (ReductionEntry *e : dead) { (void)hipFree(e->refl); (void)hipFree(e->tau); delete e; }
+    reduction_cache_clear();      // entries still used by a running fit live until that fit lets go of them
     return MHS_OK;
 }
 

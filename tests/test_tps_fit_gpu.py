@@ -153,3 +153,30 @@ def test_reduction_cache_refits_are_bit_identical(hip, n):
     assert np.array_equal(dup.c, ref_dup.c) and dup.lambda_ == ref_dup.lambda_
     again = hip.Tps(xy, ys[2])                                      # after the scope: a plain fit again
     assert np.array_equal(again.c, full[2].c)
+
+
+@pytest.mark.parametrize("n", [700, 2211, 4100])
+def test_reduction_cache_band_route_refits_are_bit_identical(hip, n):
+    """The same for fits beyond the small route (round 3): the band reduction of Q2'KQ2 -- reduced matrix with its
+    reflectors, the panels' T factors and (tau, G) records, the band, the projected rows -- is kept, and another response
+    layer on the same stations (V73:203: machisplin.mltps loops over the layers of ONE station table) sends only its
+    right-hand side through band_qt_kernel, which repeats every panel's update of g exactly: lambda, GCV, effective
+    degrees of freedom, c and d equal the full fit's bit for bit.  n = 700: one to two waves per panel; 2 211: the 1-4
+    wave forms and the 8-wave form; 4 100: the delayed scheme's first panels as well."""
+    import time
+    from machisplin_amd import tps
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 1, (n, 2))
+    ys = [np.sin(6 * xy[:, 0]) * np.cos(5 * xy[:, 1]) + 0.1 * rng.standard_normal(n) + k * xy[:, 0] for k in range(3)]
+    full = [hip.Tps(xy, y) for y in ys]
+    with tps.reduction_cache():
+        t0 = time.perf_counter(); first = hip.Tps(xy, ys[0]); t1 = time.perf_counter()
+        rest = [hip.Tps(xy, y, gcv_mode=mode) for y, mode in ((ys[1], "fields"), (ys[2], "fields"), (ys[1], "converged"))]
+        t2 = time.perf_counter()
+        fixed = hip.Tps(xy, ys[1], lambda_=1e-3)                     # the Cholesky route never touches the cache
+    conv = hip.Tps(xy, ys[1], gcv_mode="converged")
+    for a, b in zip(full + [conv], [first] + rest):
+        assert a.lambda_ == b.lambda_ and a.gcv == b.gcv and a.eff_df == b.eff_df
+        assert np.array_equal(a.c, b.c) and np.array_equal(a.d, b.d)
+    assert np.array_equal(fixed.c, hip.Tps(xy, ys[1], lambda_=1e-3).c)
+    print("n = %d: first fit (builds the entry) %.1f ms, later layers %.1f ms each" % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3 / 3))
