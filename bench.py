@@ -286,17 +286,20 @@ class Workload:
     def _f64_boundary(self, torch, mhs, g):
         import ctypes as C
         from machisplin_amd import _lib
-        t32 = []
-        for _ in range(2):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            a = mhs.ensemble_predict(self.stack, self.models, self.weights, self.wt_total)
-            torch.cuda.synchronize(); t32.append((time.perf_counter() - t0) * 1e3)
-        stack64 = mhs.RasterStack(g, self.stack.planes.to(torch.float64), self.stack.nodata)
-        t64 = []
-        for _ in range(2):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            b = mhs.ensemble_predict(stack64, self.models, self.weights, self.wt_total)
-            torch.cuda.synchronize(); t64.append((time.perf_counter() - t0) * 1e3)
+        # on a stream of its own, as the timed steps run: launches on the NULL stream synchronise with every blocking stream
+        # (the CU-masked streams of the reservation are blocking ones, whether the reservation is in use or not)
+        t32, t64 = [], []
+        with self.ops.side_stream():
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                a = mhs.ensemble_predict(self.stack, self.models, self.weights, self.wt_total)
+                torch.cuda.synchronize(); t32.append((time.perf_counter() - t0) * 1e3)
+            stack64 = mhs.RasterStack(g, self.stack.planes.to(torch.float64), self.stack.nodata)
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                b = mhs.ensemble_predict(stack64, self.models, self.weights, self.wt_total)
+                torch.cuda.synchronize(); t64.append((time.perf_counter() - t0) * 1e3)
+        self.ops.join_side_stream()
         same = bool(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)))
         host = np.ascontiguousarray(stack64.planes.cpu().numpy())
         del stack64, b
@@ -898,6 +901,25 @@ def main():
         model_check = None
         if world > 1:
             model_check = wl.model_check(phase_table, fit_ms, dt / args.steps * 1e3)
+        # N = 1: what the row-band driver should do on 2 / 4 / 8 GPUs, from this run's parts and model_check's own formula --
+        # a prediction for the first real SCALE run to be held against (8-GPU boxes are the driver's, not the builder's)
+        projected = None
+        if world == 1 and table:
+            ens = sum(r["launch_ms"] for r in table if not r["kernel"].startswith("tps_"))
+            spl = sum(r["launch_ms"] for r in table if r["kernel"].startswith("tps_"))
+            step1 = dt / args.steps * 1e3
+            projected = {"model": "rank 0: band x + the serial fit; ranks 1..N-1: band (ens - x) / (N - 1) then its all-gather share "
+                                  "(band bytes over one 153 GB/s xGMI link per peer); x = max(0, (ens - (N - 1) fit) / N); every rank then "
+                                  "evaluates the whole-grid spline and Step 5 (~3 ms); fit unconfined (no CU reservation at N > 1)",
+                         "ensemble_ms_n1": ens, "fit_ms": fit_ms, "spline_eval_ms": spl, "step_ms_n1": step1}
+            for N in (2, 4, 8):
+                x = max(0.0, (ens - (N - 1) * fit_ms) / N)
+                others = (ens - x) / (N - 1)
+                band_bytes = wl.cells * 8.0 * (others / ens)
+                gather = band_bytes / 153e9 * 1e3
+                step = max(x + fit_ms, others + gather) + spl + 3.0
+                projected["n%d" % N] = {"rank0_band_ms": x, "other_band_ms": others, "gather_ms": gather, "step_ms": step,
+                                        "mcells_per_s": wl.cells / step / 1e3, "speedup_over_n1": step1 / step}
         m = wl.ops.X.shape[0] - 3
         if cfg["ensemble"] and wl.cfg["stations"] >= 2000:
             # the synthetic members are fitted, not random: the ensemble explains the response and the spline improves on it
@@ -929,7 +951,7 @@ def main():
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "tps_eval_check": eval_check,
-            "f64_boundary": f64_boundary, "model_check": model_check,
+            "f64_boundary": f64_boundary, "model_check": model_check, "projected": projected,
             "lambda": wl.last.get("lambda"), "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only

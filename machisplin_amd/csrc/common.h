@@ -60,7 +60,7 @@ struct Context {
     char *pipe_arena = nullptr;
     size_t pipe_arena_cap = 0;
     hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_comp = nullptr;
-    hipEvent_t pipe_in[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_out[2] = {nullptr, nullptr};
+    hipEvent_t pipe_in[8] = {}, pipe_done[8] = {}, pipe_out[8] = {};
     hipStream_t upload = nullptr;         // non-blocking stream of the small blocking host -> device copies (h2d_sync)
     int n_cu = 0;
     // mhs_fit_reserve_cus: a stream whose CU mask leaves compute units out, and the two events that order a kernel

@@ -46,7 +46,7 @@ int host_pipe(size_t arena_bytes) {
         MHS_HIP(hipStreamCreateWithFlags(&c.pipe_h2d, hipStreamNonBlocking));
         MHS_HIP(hipStreamCreateWithFlags(&c.pipe_d2h, hipStreamNonBlocking));
         MHS_HIP(hipStreamCreateWithFlags(&c.pipe_comp, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 8; ++i) {
             MHS_HIP(hipEventCreateWithFlags(&c.pipe_in[i], hipEventDisableTiming));
             MHS_HIP(hipEventCreateWithFlags(&c.pipe_done[i], hipEventDisableTiming));
             MHS_HIP(hipEventCreateWithFlags(&c.pipe_out[i], hipEventDisableTiming));
@@ -194,7 +194,7 @@ int mhs_shutdown(void) {
     if (c.upload) { (void)hipStreamSynchronize(c.upload); (void)hipStreamDestroy(c.upload); }
     for (hipStream_t ps : {c.pipe_h2d, c.pipe_comp, c.pipe_d2h})
         if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 8; ++i)
         for (hipEvent_t pe : {c.pipe_in[i], c.pipe_done[i], c.pipe_out[i]})
             if (pe) (void)hipEventDestroy(pe);
     if (c.pipe_arena) (void)hipFree(c.pipe_arena);

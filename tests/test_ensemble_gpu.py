@@ -182,6 +182,50 @@ def test_seven_predictors_and_host_entry_point(hip):
     assert np.array_equal(out, got[10:35], equal_nan=True)
 
 
+@pytest.mark.parametrize("which,dtype", [("bgnmrv", "f64"), ("gnmv", "f32"), ("rv", "i16"), ("b", "f32")])
+def test_host_pointer_ensemble_pipeline_equals_the_resident_call_bitwise(hip, which, dtype, monkeypatch):
+    """mhs_ensemble_predict (what the R shim calls, V73:468-606) on a window of >= 16 M cells: the first member launch is
+    banded behind the arriving covariate rows, the last one ahead of the departing result rows, the members between run
+    once over the window (host_window_pipeline); a single member, or MHS_HOST_BANDS, takes the all-members band pipeline.
+    Whatever the route, the plane is the resident one-call plane bit for bit (NA cells included)."""
+    import ctypes as C
+    import torch
+    from machisplin_amd import _lib, synth
+    nrow, ncol = 4100, 4000
+    g = synth.grid(nrow, ncol)
+    planes, nodata = synth.covariates(g, 3, 5, dtype=dtype, nodata_frac=0.001)
+    stack = hip.RasterStack(g, planes, nodata)
+    xy, rows, cols, uv = synth.stations(g, 500, 5)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([cov, xy])
+    ok = ~(cov == nodata).any(axis=1) if not np.isnan(nodata) else ~np.isnan(cov).any(axis=1)
+    X, uv = X[ok], uv[ok]
+    params = synth.ensemble_params(X, synth.response(X, uv, 5), 5, n_gbm_trees=64, n_rf_trees=4, which=which)
+    models = [hip.models.from_param_dict(p) for p in params]
+    wts = [0.1 + 0.07 * k for k in range(len(models))]
+    want = hip.ensemble_predict(stack, models, wts, 1.3).cpu().numpy()
+    host = np.ascontiguousarray(planes.cpu().numpy())
+    out = np.empty((nrow, ncol))
+    hs = (C.c_void_p * len(models))(*[m._h for m in models])
+    ws = (C.c_double * len(models))(*wts)
+    st = _lib.Stack(host.ctypes.data, 3, {"f64": _lib.F64, "f32": _lib.F32, "i16": _lib.I16}[dtype], nrow * ncol, ncol, float(nodata))
+    gs = g.c_struct()
+    for bands in (None, "3"):
+        if bands:
+            monkeypatch.setenv("MHS_HOST_BANDS", bands)
+        out[:] = -1.0
+        _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, len(models), 1.3, C.byref(gs), C.byref(st), 0, nrow, 0, ncol, out.ctypes.data))
+        if bands:
+            monkeypatch.delenv("MHS_HOST_BANDS")
+        assert np.array_equal(np.isnan(out), np.isnan(want)), bands
+        assert np.array_equal(np.nan_to_num(out), np.nan_to_num(want)), bands
+    # a window that does not start at the grid's first row or column
+    win = (37, 4090, 11, 3990)
+    sub = np.empty((win[1] - win[0], win[3] - win[2]))
+    _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, len(models), 1.3, C.byref(gs), C.byref(st), *win, sub.ctypes.data))
+    assert np.array_equal(np.nan_to_num(sub), np.nan_to_num(want[win[0]:win[1], win[2]:win[3]]))
+
+
 @pytest.mark.parametrize("C,trees,n", [(7, 120, 600), (3, 8000, 7000)])
 def test_gbm_rank_lut_variants(hip, C, trees, n):
     """The gbm predicate-LUT path works on RANKS of the keys among the model's sorted distinct split values.

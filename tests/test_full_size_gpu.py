@@ -220,3 +220,78 @@ def test_cfg5_five_covariate_ensemble_rows(hip):
         a = hip.predict(stack, mods[k], window=(r0, r1, 0, side))
         b = hip.predict(stack, mods[k], window=(r0 - 1000, r1 + 24, 0, side))
         assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b[1000:1000 + (r1 - r0)]))
+
+
+def test_cfg4_one_unit_full_size(hip):
+    """BASELINE configs[3] at full size, ONE (tile, layer) unit: the south-west user tile of machisplin.tiles.create
+    (10 000 x 10 000 grid, 2 x 2 tiles, feather.d = 50: 5 025 x 5 025 cells, ~1 260 of the 5 000 stations), smooth
+    members (gam, nnet, earth, ksvm), the reference's own 4 x 4 Step-3 tiles inside.  (a) The sharded driver's unit
+    (HipTileOps.tile_layer, what TileShardedMltps runs on a rank) equals the hand-written chain mltps_predict bit for bit,
+    in the one-call form and in the tile-by-tile form that reports the tiles' lambdas; (b) sampled rows of the ensemble
+    plane match the C oracle; (c) inside Step-3 tile (1, 1), clear of every overlap strip, the residual surface is that
+    tile's own spline: the oracle's fit of the tile's stations at the GPU's lambda, evaluated on the fit raster's cells."""
+    import torch
+    from machisplin_amd import sharded, synth
+    from oracle import tiles as ot
+    side, n, seed = 10000, 5000, synth.BASE_SEED + 4
+    g = synth.grid(side, side)
+    xy, rows, cols, uv = synth.stations(g, n, seed)
+    tiles = hip.tiles.tiles_create(g, xy, out_ncol=2, out_nrow=2, feather_d=50)
+    t = 0
+    r0, r1, c0, c1 = (int(v) for v in tiles["win"][t])
+    assert (r1 - r0, c1 - c0) == (5025, 5025)
+    planes, nodata = synth.covariates(g, 3, seed, dtype="f32", window=(r0, r1, c0, c1))
+    tg = tiles["geom"][t]
+    stack = hip.RasterStack(tg, planes, nodata)
+    X = np.column_stack([synth.covariates_at(g, 3, seed, rows, cols), xy])
+    resp = synth.response(X, uv, seed) + 3.0 * np.sin(2 * uv[:, 0])
+    iv = np.column_stack([xy, resp])
+    sel = tiles["dat"][t]
+    assert 1000 < len(sel) < 1600
+    _, wts, tot = hip.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")
+    params = synth.ensemble_params(X[sel], resp[sel], seed + t, which="gnmv")
+    models = [hip.models.from_param_dict(p) for p in params]
+    fitted = {t: {0: {"models": models, "weights": wts, "wt_total": tot}}}
+    ops = sharded.HipTileOps(g, tiles, lambda tt: stack, iv, fitted, tile_edge=1500)
+    unit = torch.empty((r1 - r0, c1 - c0), dtype=torch.float64, device="cuda")
+    rsq_m, rsq_f = ops.tile_layer(t, 0, unit)
+    keep = hip.mltps.complete_cases(stack, iv[sel])
+    hand = hip.mltps_predict(stack, iv[sel, :2], iv[sel, 2], models, wts, tot, tile_edge=1500, keep=keep)
+    assert torch.equal(unit, hand["final"]) and rsq_m == hand["rsq_model"] and rsq_f == hand["rsq_final"]
+    assert 0.5 < rsq_m < rsq_f
+    byt = hip.mltps_predict(stack, iv[sel, :2], iv[sel, 2], models, wts, tot, tile_edge=1500, keep=keep, tps_info=True)
+    assert torch.equal(byt["final_tps"], hand["final_tps"])
+    info = byt["tps_info"]
+    assert (info["nRx"], info["nCx"]) == (4, 4)
+    # (b) ensemble rows vs the C oracle
+    rr = 2500
+    host = planes[:, rr:rr + 2].cpu().numpy().astype(np.float64)
+    xs, ys = otps.cell_centres(tg.xmin, tg.ymax, tg.xres, tg.yres, tg.nrow, tg.ncol, rr, rr + 2)
+    want = cbind.ensemble(params, wts, tot, oe.stack_predictors(host, (xs, ys)), 8).reshape(2, -1)
+    got = hand["pred_elev"][rr:rr + 2].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-11 * np.abs(want).max()
+    # (c) the interior of Step-3 tile (row 1, column 1) of the 4 x 4 layout
+    og = ot.Geom(tg.xmin, tg.ymax, tg.xres, tg.yres, tg.nrow, tg.ncol)
+    nRx, nCx, fw, kw = ot.step3_windows(og, 1500)
+    h = 1 * nCx + 1
+    kr0, kr1, kc0, kc1 = kw[h]
+    # keep windows overlap their neighbours by 2 x 2.5 % of a tile (~63 cells) and Step 4 feathers inside those strips:
+    # 200 cells in from every edge the plane is this tile's spline alone
+    ir0, ir1, ic0, ic1 = kr0 + 200, kr1 - 200, kc0 + 200, kc1 - 200
+    for k in range(nRx * nCx):
+        if k != h:
+            o = kw[k]
+            assert o[1] <= ir0 or o[0] >= ir1 or o[3] <= ic0 or o[2] >= ic1
+    assert ir1 - ir0 > 700 and ic1 - ic0 > 700
+    knots, res = hand["residuals"][:, 1:], None
+    Xs, _, _ = hip.mltps.station_predictors(stack, iv[sel, :2])
+    res = hip.mltps.ensemble_residuals(models, wts, tot, Xs[keep], iv[sel, 2][keep])
+    ssel = ot.stations_in_window(og, fw[h], knots, None)
+    assert len(ssel) == info["tile_n"][h]
+    m = otps.fit(knots[ssel], res[ssel], lam=info["lambda"][h])
+    gf = ot.window_geom(og, fw[h])
+    rows_o = (ir0 + 7, (ir0 + ir1) // 2, ir1 - 9)
+    for ro in rows_o:
+        ref = cbind.tps_eval_grid(m, gf.xmin, gf.ymax, gf.xres, gf.yres, ro - fw[h][0], ro - fw[h][0] + 1, ic0 - fw[h][2], ic1 - fw[h][2], threads=8)
+        got = hand["final_tps"][ro, ic0:ic1].cpu().numpy()
+        assert np.abs(got - ref.ravel()).max() < 1e-9 * np.abs(ref).max(), ro

@@ -202,7 +202,7 @@ def _run_bench(world, workload, port, extra=()):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_n_ranks_row_bands_plumbing(hip, world):
     """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with the ranks
     sharing GPU 0 over gloo: calibration pass, weighted row bands (rank 0 carries the fit), coefficient broadcast,
@@ -220,13 +220,15 @@ def test_bench_n_ranks_row_bands_plumbing(hip, world):
 
 
 @pytest.mark.timeout(900)
-def test_bench_cfg4_two_ranks_plumbing(hip):
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_cfg4_n_ranks_plumbing(hip, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    d = _run_bench(2, "cfg4-mini", port)
-    assert d["n_gpus"] == 2 and d["units_on_rank0"] == 6 and d["value"] > 0      # 4 tiles x 3 layers over 2 ranks
+    d = _run_bench(world, "cfg4-mini", port)
+    assert d["n_gpus"] == world and d["units_on_rank0"] == 12 // world and d["value"] > 0      # 4 tiles x 3 layers
     assert 0.5 < d["rsq_model_mean"] <= d["rsq_final_mean"]
+    assert d["roofline"] is not None and d["unit_profile"]["whole_unit_ms_alone"] > 0
 
 
 # ------------------------------------------------------------- reference-tiled Step 3 dealt over the ranks (HIP ops) --

@@ -29,6 +29,23 @@ for _ in range(3):
     res = m.ensemble_predict(stack64, models, wts, 1.0)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
 print(f"resident f64: {dt:.1f} ms", flush=True)
+# does a pageable host -> device copy running beside the kernels slow them down?  (the copy goes to a scratch buffer)
+import threading
+scratch = torch.empty_like(stack64.planes)
+src_cpu = stack64.planes.cpu()
+def _bg():
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        scratch.copy_(src_cpu, non_blocking=True)
+    st.synchronize()
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    th = threading.Thread(target=_bg); th.start()
+    res2 = m.ensemble_predict(stack64, models, wts, 1.0)
+    torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) * 1e3
+    th.join()
+print(f"resident f64 with a 2.4 GB pageable upload running beside it: {dt2:.1f} ms (+{dt2 - dt:.1f})", flush=True)
+del scratch, src_cpu, res2
 host = np.ascontiguousarray(stack64.planes.cpu().numpy())
 ref = res.cpu().numpy()
 del stack64, res
