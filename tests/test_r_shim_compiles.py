@@ -2,14 +2,14 @@
 check uses integration/r/check/{R.h,Rinternals.h} -- declarations of the documented R C API subset the shim uses, not
 R's headers -- and `gcc -fsyntax-only` with the prototype errors switched on: every mhs_* call in the shim must match
 include/machisplin_hip.h, every R API call its documented signature.  And every `.Call("mhsr_...")` in
-integration/r/R/backend_hip.R must name a function the shim defines with that many SEXP arguments."""
+integration/r/R/{backend_hip,multi_gpu}.R must name a function the shim defines with that many SEXP arguments."""
 import os
 import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "integration", "r", "src", "machisplin_shim.c")
-RFILE = os.path.join(ROOT, "integration", "r", "R", "backend_hip.R")
+RFILES = [os.path.join(ROOT, "integration", "r", "R", n) for n in ("backend_hip.R", "multi_gpu.R")]
 
 
 def test_shim_passes_the_c_compiler():
@@ -29,7 +29,7 @@ def test_every_dot_call_names_a_shim_function_with_that_arity():
         assert all(a.strip().startswith("SEXP") for a in args), m.group(0)
         defs[m.group(1)] = len(args)
     assert len(defs) >= 8
-    r = open(RFILE).read()
+    r = "\n".join(open(f).read() for f in RFILES)
     calls = re.findall(r'\.Call\(\s*"(mhsr_\w+)"((?:[^()]|\([^()]*\))*)\)', r)
     assert calls
     for name, rest in calls:
