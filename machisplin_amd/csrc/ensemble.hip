@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(512) void rf_walk_tm_kernel(const uint2 *__restrict
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
 // tree costs one barrier.  In the single-buffer form a third of the kernel was staging: every wave idle while
 // 48 KB are copied between two barriers, 500 times per block.
-template <int LOG2R, bool K64>
+template <int LOG2R, bool K64, bool HAND = true>
 __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restrict__ gnodes,
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
@@ -1112,6 +1112,18 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         }
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = boff;
+        if constexpr (R == 5 && HAND) {
+            // five walks: the level loop by hand (tools/gen_rf_walk_asm.py) -- the walks rotated so that the two wait states an
+            // SDWA select needs after v_cmp's write of VCC are the previous walk's next node read and the next walk's key wait
+            int cnt = levels;
+            if (cnt > 0)
+                asm volatile(
+#include "rf_walk_loop5.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt)
+                    : [lb] "v"(lane_base)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+        } else
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -2254,7 +2266,9 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     const unsigned blocks = (unsigned)((part + 1023) / 1024);
     if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
         const size_t dbytes = rf_walk_db_lds(m, log2r);
-        auto dk = log2r == 3 ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
+        const bool hand = getenv("MHS_RF_COMPILER_LOOP") == nullptr;      // five walks: hand-scheduled level loop (default)
+        auto dk = log2r == 3 ? (hand ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
+                                     : (key64 ? rf_walk_db_kernel<3, true, false> : rf_walk_db_kernel<3, false, false>))
                 : log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
                              : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));

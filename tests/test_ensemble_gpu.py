@@ -297,7 +297,7 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, monkeypatch):
     fast = hip.predict(stack, m)
     for envs in ({"MHS_RF_CDB": "1"}, {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "4"}, {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "5"},
                  {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "8"}, {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_MIXED": "1"}, {"MHS_RF_MIXED": "2"},
-                 {"MHS_RF_MIXED": "3"},
+                 {"MHS_RF_MIXED": "3"}, {"MHS_RF_COMPILER_LOOP": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
                  {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():

@@ -33,7 +33,8 @@ def run(kind, env):
     return best, out.clone()
 
 for kind, variants in (("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
-                       ("rf", [("double-buffered, 5 walks (round 2, default)", {}),
+                       ("rf", [("double-buffered, 5 walks, hand-scheduled level loop (default)", {}),
+                               ("double-buffered, 5 walks, the compiler's loop (round 2)", {"MHS_RF_COMPILER_LOOP": "1"}),
                                ("split-node records, two buffers, 6 walks", {"MHS_RF_CDB": "1"}),
                                ("same, 5 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "5"}), ("same, 4 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "4"}),
                                ("triple-buffered, no barrier", {"MHS_RF_TRIPLE_BUFFER": "1"}),
@@ -46,4 +47,4 @@ for kind, variants in (("gbm", [("row tiles (round 3)", {}), ("lane per cell (ro
         dt, plane = run(kind, env)
         same = "" if ref is None else ("  == first" if torch.equal(torch.nan_to_num(plane), torch.nan_to_num(ref)) else "  DIFFERS from first")
         if ref is None: ref = plane
-        print(f"{kind:4s} {name:52s} {dt*1e3:9.2f} ms  -> 1e8 cells: {dt*1e8/(side*side)*1e3:8.1f} ms{same}", flush=True)
+        print(f"{kind:4s} {name:60s} {dt*1e3:9.2f} ms  -> 1e8 cells: {dt*1e8/(side*side)*1e3:8.1f} ms{same}", flush=True)
