@@ -839,6 +839,14 @@ def main():
         fit_overlapped_ms = float(np.mean(tm["tps_fit_ms"][-max(1, len(tm["tps_fit_ms"]) // 2):])) if tm["tps_fit_ms"] else None
         # inside a step the fit runs BESIDE the ensemble kernels (it is starved by them and its wall time
         # is not a kernel property), so the TPS-solve rate is taken from a stand-alone fit after the run
+        # for the record (outside the timed region), FIRST among the records -- the later ones (direct-sum spline evaluation,
+        # stand-alone fits) leave the device clocked lower for a while, which a profiled run showed as +25 % on every member
+        # kernel of this leg: the boundary as the R shim reaches it -- float64 planes (terra holds doubles in RAM,
+        # integration/r/src/machisplin_shim.c passes MHS_F64) resident in HBM, and the host-pointer entry point
+        # mhs_ensemble_predict exactly as mhsr_ensemble_predict calls it (PCIe included)
+        f64_boundary = None
+        if world == 1 and cfg["ensemble"] and wl.cells <= 2 * 10 ** 8 and not os.environ.get("MHS_BENCH_SKIP_F64"):
+            f64_boundary = wl.f64_boundary()
         knots, resid = wl.ops.X[:, -2:], wl.run.ops.station_residuals()[1]
         fit_ms = 1e30
         for _ in range(2):
@@ -890,12 +898,6 @@ def main():
                           "max_abs_diff_over_max_abs": diff / float(direct.abs().max()),
                           "max_abs_diff_over_sum_abs_terms": diff / float(S.max())}
             del far, direct
-        # for the record (outside the timed region): the boundary as the R shim reaches it -- float64 planes (terra holds
-        # doubles in RAM, integration/r/src/machisplin_shim.c passes MHS_F64) resident in HBM, and the host-pointer entry
-        # point mhs_ensemble_predict exactly as mhsr_ensemble_predict calls it (PCIe included)
-        f64_boundary = None
-        if world == 1 and cfg["ensemble"] and wl.cells <= 2 * 10 ** 8 and not os.environ.get("MHS_BENCH_SKIP_F64"):
-            f64_boundary = wl.f64_boundary()
         # N > 1: what the step should cost from its parts (this rank's band, the stand-alone fit, the gather) against
         # what it did cost -- so that an 8-GPU line can be read without a profiler
         model_check = None

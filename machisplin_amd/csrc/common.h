@@ -79,6 +79,13 @@ int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from
 // mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                  int gcv_threads, mhs_tps **out);
+// Small device blocks (a spline's knots, its far-field plan) from a pool instead of hipMalloc / hipFree: the reference-tiled
+// Step 3 builds and drops a spline per tile -- 16 per (tile, layer) unit at cfg4, ~6 buffers each -- and every hipFree is a
+// device-wide synchronisation.  Power-of-two size classes, blocks never return to the driver before mhs_shutdown.
+// pool_release does NOT synchronise: the caller guarantees that nothing in flight still reads the block.
+void *pool_alloc(size_t bytes);
+void pool_release(void *p);
+void pool_clear();
 int require_ready();
 void reduction_cache_clear();           // tps_fit.hip: drop every cached reduction (mhs_shutdown)
 // Blocking host -> device copy that does NOT go through the NULL stream: a plain hipMemcpy synchronises with every
@@ -115,6 +122,7 @@ struct Knot { double u, v, cw, pad; };
 struct mhs_tps;
 namespace mhs {
 int upload_knots(mhs_tps *t);  // (re)build t->knots_dev from t->c / t->knots_uv
+int tps_free_quiet(mhs_tps *t);   // mhs_tps_free without its device-wide wait (the caller has synchronised)
 }
 
 // fitted spline handle (opaque to callers)

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
+#include <vector>
 #include "common.h"
 
 namespace mhs {
@@ -33,6 +35,56 @@ Context &ctx() {
 std::mutex &mask_mutex() {
     static std::mutex m;
     return m;
+}
+
+namespace {
+struct BlockPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> cls;                 // every block handed out or parked -> its class (0 = direct)
+    std::unordered_map<size_t, std::vector<void *>> parked;
+};
+BlockPool &block_pool() { static BlockPool p; return p; }
+constexpr size_t POOL_MAX_CLASS = (size_t)64 << 20;
+}  // namespace
+
+void *pool_alloc(size_t bytes) {
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    BlockPool &bp = block_pool();
+    if (c <= POOL_MAX_CLASS) {
+        std::lock_guard<std::mutex> lk(bp.mu);
+        auto it = bp.parked.find(c);
+        if (it != bp.parked.end() && !it->second.empty()) { void *q = it->second.back(); it->second.pop_back(); return q; }
+    }
+    void *q = nullptr;
+    const size_t want = c <= POOL_MAX_CLASS ? c : bytes;
+    if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); set_error("out of device memory (%zu bytes)", want); return nullptr; }
+    std::lock_guard<std::mutex> lk(bp.mu);
+    bp.cls[q] = c <= POOL_MAX_CLASS ? c : 0;
+    return q;
+}
+
+void pool_release(void *p) {
+    if (!p) return;
+    BlockPool &bp = block_pool();
+    size_t c = 0;
+    {
+        std::lock_guard<std::mutex> lk(bp.mu);
+        auto it = bp.cls.find(p);
+        if (it == bp.cls.end()) return;                    // not ours (or the pool was cleared): leave it
+        c = it->second;
+        if (c) { bp.parked[c].push_back(p); return; }
+        bp.cls.erase(it);
+    }
+    (void)hipFree(p);
+}
+
+void pool_clear() {
+    BlockPool &bp = block_pool();
+    std::lock_guard<std::mutex> lk(bp.mu);
+    for (auto &kv : bp.cls) (void)hipFree(kv.first);
+    bp.cls.clear();
+    bp.parked.clear();
 }
 
 std::mutex &pipe_mutex() {
@@ -186,6 +238,7 @@ int mhs_shutdown(void) {
     if (!c.ready) return MHS_OK;
     (void)hipStreamSynchronize(c.stream);
     reduction_cache_clear();              // device pointers of this device must not outlive it
+    pool_clear();                         // (handles that outlive the shutdown release into an empty pool: ignored)
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
     if (c.mosaic_arena) (void)hipFree(c.mosaic_arena);

@@ -238,8 +238,9 @@ int upload_knots(mhs_tps *t) {
         h[j].pad = 0.0;
     }
     t->far.r0 = -1;   // coefficients changed: the far-field plan's sorted knots are stale
-    if (t->knots_dev) { (void)hipFree(t->knots_dev); t->knots_dev = nullptr; }
-    MHS_HIP(hipMalloc((void **)&t->knots_dev, sizeof(Knot) * (size_t)(t->n ? t->n : 1)));
+    if (t->knots_dev) { (void)hipDeviceSynchronize(); pool_release(t->knots_dev); t->knots_dev = nullptr; }   // re-fitted handle: rare
+    t->knots_dev = (Knot *)pool_alloc(sizeof(Knot) * (size_t)(t->n ? t->n : 1));
+    if (!t->knots_dev) return MHS_ERR_ALLOC;
     return h2d_sync(t->knots_dev, h.data(), sizeof(Knot) * (size_t)t->n);
 }
 
@@ -259,8 +260,9 @@ static int g_eval_mode = 0;   // 0 auto, 1 direct, 2 far-field-interpolated
 template <typename T>
 static int grow(T **p, size_t *cap, size_t need) {
     if (*cap >= need && *p) return MHS_OK;
-    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-    MHS_HIP(hipMalloc((void **)p, (need ? need : 1) * sizeof(T)));
+    if (*p) { (void)hipDeviceSynchronize(); pool_release(*p); *p = nullptr; *cap = 0; }      // a plan for another window: rare
+    *p = (T *)pool_alloc((need ? need : 1) * sizeof(T));
+    if (!*p) return MHS_ERR_ALLOC;
     *cap = need;
     return MHS_OK;
 }
@@ -366,7 +368,7 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
     std::vector<double> lx, ly;
     cheb_matrix(btx, false, f->t, lx);
     cheb_matrix(bty, true, f->t, ly);
-    if (!P.sorted_dev) MHS_HIP(hipMalloc((void **)&P.sorted_dev, sizeof(Knot) * (size_t)N));
+    if (!P.sorted_dev) { P.sorted_dev = (Knot *)pool_alloc(sizeof(Knot) * (size_t)N); if (!P.sorted_dev) return MHS_ERR_ALLOC; }
     if (int rc = grow(&P.bin_start_dev, &P.bins_cap, start.size())) return rc;
     if (int rc = grow(&P.nodes_dev, &P.nodes_cap, (size_t)f->ntx * f->nty * FF_NODES)) return rc;
     if (int rc = grow(&P.lx_dev, &P.lx_cap, lx.size())) return rc;
@@ -426,16 +428,22 @@ int mhs_tps_get(const mhs_tps *t, double *c, double *d3, double *knots_uv, doubl
     return MHS_OK;
 }
 
-int mhs_tps_free(mhs_tps *t) {
+// drop a handle whose device buffers nothing in flight reads any more (the caller has synchronised): no device-wide wait
+}  // extern "C"
+int mhs::tps_free_quiet(mhs_tps *t) {
     if (!t) return MHS_OK;
-    if (t->knots_dev) (void)hipFree(t->knots_dev);
-    if (t->far.sorted_dev) (void)hipFree(t->far.sorted_dev);
-    if (t->far.bin_start_dev) (void)hipFree(t->far.bin_start_dev);
-    if (t->far.nodes_dev) (void)hipFree(t->far.nodes_dev);
-    if (t->far.lx_dev) (void)hipFree(t->far.lx_dev);
-    if (t->far.ly_dev) (void)hipFree(t->far.ly_dev);
+    for (void *q : {(void *)t->knots_dev, (void *)t->far.sorted_dev, (void *)t->far.bin_start_dev, (void *)t->far.nodes_dev,
+                    (void *)t->far.lx_dev, (void *)t->far.ly_dev}) pool_release(q);
     delete t;
     return MHS_OK;
+}
+extern "C" {
+
+int mhs_tps_free(mhs_tps *t) {
+    if (!t) return MHS_OK;
+    // evaluations are asynchronous on the caller's streams: ONE device-wide wait (hipFree made six) before the blocks go back
+    if (t->knots_dev && ctx().ready) (void)hipDeviceSynchronize();
+    return tps_free_quiet(t);
 }
 
 int mhs_tps_eval_mode(int mode) {

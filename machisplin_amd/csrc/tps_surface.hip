@@ -98,7 +98,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
         if (hipStreamSynchronize(L->s) != hipSuccess && !rc) rc = MHS_ERR_HIP;
         if (L->ms && hipStreamSynchronize(L->ms) != hipSuccess && !rc) rc = MHS_ERR_HIP;
     }
-    for (mhs_tps *t : handles) mhs_tps_free(t);
+    for (mhs_tps *t : handles) tps_free_quiet(t);      // every lane is idle: no wait, the blocks go back to the pool
     if (rc && !err_msg.empty()) set_error("%s", err_msg.c_str());
     return rc;
 }
