@@ -1123,6 +1123,15 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                     : [lb] "v"(lane_base)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+        } else if constexpr (R == 4 && HAND) {
+            int cnt = levels;
+            if (cnt > 0)
+                asm volatile(
+#include "rf_walk_loop4.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt)
+                    : [lb] "v"(lane_base)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
+                      "v115", "v116", "v117", "v118");
         } else
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
@@ -1495,6 +1504,25 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
         unsigned node[R];
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = 0u;
+        if constexpr (R == 4) {
+            int cnt = levels;
+            if (cnt > 0)
+                asm volatile(
+#include "rf_walk_loop4o.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
+                      "v115", "v116", "v117", "v118");
+        } else if constexpr (R == 5) {
+            int cnt = levels;
+            if (cnt > 0)
+                asm volatile(
+#include "rf_walk_loop5o.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+        } else
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -2269,7 +2297,8 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         const bool hand = getenv("MHS_RF_COMPILER_LOOP") == nullptr;      // five walks: hand-scheduled level loop (default)
         auto dk = log2r == 3 ? (hand ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
                                      : (key64 ? rf_walk_db_kernel<3, true, false> : rf_walk_db_kernel<3, false, false>))
-                : log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
+                : log2r == 2 ? (hand ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
+                                     : (key64 ? rf_walk_db_kernel<2, true, false> : rf_walk_db_kernel<2, false, false>))
                              : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
         hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
