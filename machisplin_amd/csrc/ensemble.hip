@@ -344,9 +344,11 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             const double *sp = svp + (int64_t)v * stride;
 #pragma unroll
             for (int c = 0; c < R; ++c) {
-                double arg = q[c] + sp[P];
+                // the LAST predictor first: in grid mode it is LAT, constant along a raster row -- svr_rt_kernel forms this
+                // term once per row and support vector with the same fma, so the two kernels agree bit for bit
+                double arg = q[c] + fma(sp[P - 1], x[c][P - 1], sp[P]);
 #pragma unroll
-                for (int j = 0; j < P; ++j) arg = fma(sp[j], x[c][j], arg);
+                for (int j = 0; j < P - 1; ++j) arg = fma(sp[j], x[c][j], arg);
                 arg = fmin(fmax(arg, 0.0), 1.0);   // folds into the clamp modifier of the last fma
                 a[c] = table_exp_neg_acc(arg, etab, a[c]);
             }
@@ -362,6 +364,82 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : pred, weight, accumulate);
         }
     }
+}
+
+// ROW-TILE form of the ksvm kernel (round 3): a wave = 64 R consecutive cells of ONE raster row.  LAT is the last
+// predictor of every model (V73:127-138) and the same for all of the wave's cells, so its term b_LAT x_LAT + a of the
+// exponent is formed ONCE per wave and support vector -- 128 vectors at a time, two per lane, parked in a wave-private
+// 1 KB of LDS and read back as a broadcast -- instead of once per cell: 14 VALU instructions per (cell, SV) instead of
+// 15.  Same fma, same order as svr_kernel: identical planes.
+template <int P, int R>
+__global__ __launch_bounds__(256) void svr_rt_kernel(const double *__restrict__ svp, int nsv, int stride,
+                                                     int npos, const double *__restrict__ xcs,
+                                                     const double *__restrict__ gtab, double sigma, double b,
+                                                     double amax, double y_center, double y_scale, StackDev s, PredGeom g,
+                                                     int tiles_per_row, double weight, int accumulate, double *__restrict__ out) {
+    constexpr int CH = 128;
+    __shared__ double etab[EXP_TAB_N];
+    __shared__ double aw[4][CH];
+    for (int i = threadIdx.x; i < EXP_TAB_N; i += 256) {   // mantissa bits of 2^(j/4096)
+        const double e = gtab[i];
+        etab[i] = __hiloint2double(__double2hiint(e) & 0x000fffff, __double2loint(e));
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t ntiles = (int64_t)g.nr * tiles_per_row;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const int row = (int)(tile / tiles_per_row), tcol = (int)(tile - (int64_t)row * tiles_per_row) * (64 * R);
+    double x[R][P], q[R], acc[R], accn[R];
+    bool na[R], ok[R];
+    int col[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        const int cc = tcol + c * 64 + lane;
+        ok[c] = cc < g.nc;
+        col[c] = min(cc, g.nc - 1);
+        na[c] = false; q[c] = 0.0; acc[c] = 0.0; accn[c] = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double xv = predictor(s, g, j, row, col[c]);
+            na[c] |= isnan(xv);
+            x[c][j] = (xv - xcs[j]) / xcs[P + j];
+            q[c] = fma(x[c][j], x[c][j], q[c]);
+        }
+        q[c] = (sigma / EXP_RANGE) * q[c];
+    }
+    const double xlat = x[0][P - 1];                       // the row's scaled LAT: the same value in every lane and cell
+    auto sum_range = [&](int v0, int v1, double (&a)[R]) {
+        for (int vb = v0; vb < v1; vb += CH) {
+            const int n = min(CH, v1 - vb);
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < n; e += 64) {
+                const double *sp = svp + (int64_t)(vb + e) * stride;
+                aw[wave][e] = fma(sp[P - 1], xlat, sp[P]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < n; ++e) {
+                const double *sp = svp + (int64_t)(vb + e) * stride;
+                const double ap = aw[wave][e];
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    double arg = q[c] + ap;
+#pragma unroll
+                    for (int j = 0; j < P - 1; ++j) arg = fma(sp[j], x[c][j], arg);
+                    arg = fmin(fmax(arg, 0.0), 1.0);
+                    a[c] = table_exp_neg_acc(arg, etab, a[c]);
+                }
+            }
+        }
+    };
+    sum_range(0, npos, acc);
+    sum_range(npos, nsv, accn);
+#pragma unroll
+    for (int c = 0; c < R; ++c)
+        if (ok[c]) {
+            const double pred = ((acc[c] - accn[c]) * amax - b) * y_scale + y_center;
+            emit(out, (int64_t)row * g.ld_out + col[c], na[c] ? NAN : pred, weight, accumulate);
+        }
 }
 
 // ---------------------------------------------------------------------- trees --
@@ -1786,6 +1864,15 @@ template <int P>
 static void launch_svr(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc,
                        double *out, hipStream_t st, int64_t total) {
     constexpr int R = 3;      // cells per lane (2: 83.5, 3: 81.0, 4: 82.4 ms on 8000^2 cells x 3000 SVs)
+    // grid mode with long rows: a wave = 192 cells of one row, the LAT term of the exponent once per wave (svr_rt_kernel)
+    const int tpr = (g.nc + 64 * R - 1) / (64 * R);
+    if (!s.all_from_planes && P == s.C + 2 && P >= 3 && !getenv("MHS_SVR_NO_ROWTILE") && (double)g.nc >= 0.93 * (double)tpr * (64 * R)) {
+        const int64_t ntiles = (int64_t)g.nr * tpr;
+        hipLaunchKernelGGL((svr_rt_kernel<P, R>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st,
+                           m->dpar, m->n0, m->n1, m->n2, m->dpar + (size_t)m->n0 * m->n1, ctx().exp_tab, m->s1, m->s0, m->s4,
+                           m->s2, m->s3, s, g, tpr, w, acc, out);
+        return;
+    }
     const int64_t half = (total + R - 1) / R;
     hipLaunchKernelGGL((svr_kernel<P, R>), dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st,
                        m->dpar, m->n0, m->n1, m->n2, m->dpar + (size_t)m->n0 * m->n1, ctx().exp_tab, m->s1, m->s0, m->s4,

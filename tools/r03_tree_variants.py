@@ -1,4 +1,4 @@
-"""Round 3: stand-alone times of the gbm and randomForest kernel variants on a cfg3-shaped model set (5 000 stations,
+"""Round 3: stand-alone times of the ksvm, gbm and randomForest kernel variants on a cfg3-shaped model set (5 000 stations,
 10 000 gbm trees, 500 forest trees) over side x side cells.  Variants are selected with the library's environment
 switches; every variant's plane is compared bit for bit with the first one's.
     python tools/r03_tree_variants.py [side=8000] [reps=3]"""
@@ -19,7 +19,7 @@ xy, rows, cols, uv = synth.stations(g, 5000, seed)
 cov_at = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
 X = np.column_stack([cov_at, xy])
 y = synth.response(X, uv, seed)
-params = {p["kind"]: p for p in synth.ensemble_params(X, y, seed, which="br")}
+params = {p["kind"]: p for p in synth.ensemble_params(X, y, seed, which="brv")}
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 
 def run(kind, env):
@@ -32,7 +32,9 @@ def run(kind, env):
     for k in env: del os.environ[k]
     return best, out.clone()
 
-for kind, variants in (("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
+for kind, variants in (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
+                                ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
+                       ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
                        ("rf", [("double-buffered, 5 walks, hand-scheduled level loop (default)", {}),
                                ("double-buffered, 5 walks, the compiler's loop (round 2)", {"MHS_RF_COMPILER_LOOP": "1"}),
                                ("split-node records, two buffers, 6 walks", {"MHS_RF_CDB": "1"}),
