@@ -246,9 +246,6 @@ typedef struct mhs_stack {
 MHS_API int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_stack *covars,
                             int64_t r0, int64_t r1, int64_t c0, int64_t c1, double weight,
                             int accumulate, double *out_dev, int64_t ld, void *stream);
-/* the whole Step-2 raster loop V73:447-619: out = (((p1 w1) + p2 w2) + ...) / wt_total,
- * models in mods.run order, weights = the rounded kept weights, wt_total = the
- * unrounded OptX.mfit.wt.tot (V73:337).                                                  */
 /* out (+)= sum_k weights[k] * pred_k over the window, members in order -- the accumulation lines of the Step-2 loop
  * (pred.elev <- pred.elev + pred * wt, V73:471,498,522,544,583,605) without the final division; `accumulate` = 0 starts
  * from the first member's plane, 1 adds to what `out_dev` holds.  A run of the consecutive members gam, nnet, earth
@@ -256,6 +253,9 @@ MHS_API int mhs_predict_dev(const mhs_model *m, const mhs_grid *g, const mhs_sta
 MHS_API int mhs_members_predict_dev(const mhs_model *const *models, const double *weights, int n_models,
                             const mhs_grid *g, const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0,
                             int64_t c1, int accumulate, double *out_dev, int64_t ld, void *stream);
+/* the whole Step-2 raster loop V73:447-619: out = (((p1 w1) + p2 w2) + ...) / wt_total,
+ * models in mods.run order, weights = the rounded kept weights, wt_total = the
+ * unrounded OptX.mfit.wt.tot (V73:337).                                                  */
 MHS_API int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weights,
                                      int n_models, double wt_total, const mhs_grid *g,
                                      const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0,

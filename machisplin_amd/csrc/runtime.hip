@@ -118,6 +118,8 @@ int host_pipe(size_t arena_bytes) {
 
 int fit_lane(int i, FitLane **out) {
     Context &c = ctx();
+    // mhs_fit_reserve_cus walks c.lanes and rebuilds their masked streams under this mutex
+    std::lock_guard<std::mutex> lk(mask_mutex());
     while ((int)c.lanes.size() <= i) {
         FitLane *L = new FitLane();
         int prio_lo = 0, prio_hi = 0;
