@@ -1248,254 +1248,6 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     }
 }
 
-// MIXED walks (round 3).  The PMC passes on rf_walk_db_kernel show an LDS array 65 % busy and a VALU 47 % busy: the walk
-// is bound by how many dependent LDS reads a wave keeps in flight, and the keys' LDS footprint caps the walks per lane.
-// Here a lane runs RL = 4 walks as before (node read + key read, both LDS) and RV more whose keys stay in REGISTERS:
-// their level is ONE LDS read (the node) and the key is picked from the P registers with bit-field selects on the
-// node's predictor bits (byte 0 of the record is var * 16 for four LDS walks: bits 4..6 are var) -- 3 v_bfe_i32 masks +
-// 4 v_bfi_b32 for P <= 5, the VALU has the room.  Same records, same double-buffered pipeline, same tree order.
-__device__ __forceinline__ unsigned bfe_mask(unsigned x, int bit) {      // all ones if the bit is set
-    unsigned m;
-    if (bit == 4) asm("v_bfe_i32 %0, %1, 4, 1" : "=v"(m) : "v"(x));
-    else if (bit == 5) asm("v_bfe_i32 %0, %1, 5, 1" : "=v"(m) : "v"(x));
-    else asm("v_bfe_i32 %0, %1, 6, 1" : "=v"(m) : "v"(x));
-    return m;
-}
-__device__ __forceinline__ unsigned bfi_sel(unsigned m, unsigned a, unsigned b) {      // (m & a) | (~m & b)
-    unsigned d;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
-    return d;
-}
-template <int P>
-__device__ __forceinline__ unsigned pick_key(const unsigned (&k)[P], unsigned ndx) {
-    static_assert(P >= 5 && P <= 8, "5..8 predictors");
-    const unsigned m0 = bfe_mask(ndx, 4), m1 = bfe_mask(ndx, 5), m2 = bfe_mask(ndx, 6);
-    const unsigned t01 = bfi_sel(m0, k[1], k[0]), t23 = bfi_sel(m0, k[3], k[2]), t03 = bfi_sel(m1, t23, t01);
-    unsigned t47 = k[4];
-    if constexpr (P >= 6) t47 = bfi_sel(m0, k[P >= 6 ? 5 : 0], k[4]);
-    if constexpr (P >= 7) {
-        const unsigned t67 = P >= 8 ? bfi_sel(m0, k[P >= 8 ? 7 : 0], k[P >= 7 ? 6 : 0]) : k[P >= 7 ? 6 : 0];
-        t47 = bfi_sel(m1, t67, t47);
-    }
-    return bfi_sel(m2, t47, t03);
-}
-
-template <int P, int RV, bool K64>
-__global__ __launch_bounds__(1024) void rf_walk_mx_kernel(const uint2 *__restrict__ gnodes,
-                                                          const double *__restrict__ glval,
-                                                          const int *__restrict__ tree_off,
-                                                          const int *__restrict__ depth,
-                                                          const void *__restrict__ sorted,
-                                                          const int *__restrict__ sorted_off, int n_trees,
-                                                          int max_nodes, StackDev s, PredGeom g,
-                                                          double weight, int accumulate,
-                                                          double *__restrict__ out) {
-    constexpr int RL = 4, R = RL + RV;
-    constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned buf_bytes = (unsigned)max_nodes * 8u;
-    const unsigned tree_bytes = max(2u * buf_bytes, (unsigned)RF_COARSE_BYTES);
-    float *coarse = (float *)smem;
-    constexpr unsigned stride = (unsigned)(P * RL) | 1u;
-    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
-    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int row[R], col[R];
-    bool na[R];
-    double acc[R], pending[R];
-    unsigned node[R], kv[RV][P], key[R];
-    uint2v nd[R];
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        float r[R];
-        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < RL; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * RL + c) * 4u) = (unsigned)r[c] << 8;
-#pragma unroll
-        for (int c = 0; c < RV; ++c) kv[c][j] = (unsigned)r[RL + c] << 8;
-    }
-    __syncthreads();
-    {
-        const int o = tree_off[0], cnt = tree_off[1] - o;
-        for (int e = threadIdx.x; e < cnt; e += 1024) ((uint2 *)smem)[e] = gnodes[o + e];
-    }
-    __syncthreads();
-    int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1;
-    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
-    for (int t = 0; t < n_trees; ++t) {
-        const unsigned boff = (t & 1) ? buf_bytes : 0u, noff = (t & 1) ? 0u : buf_bytes;
-        const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0;
-        const int o3 = t + 3 <= n_trees ? tree_off[t + 3] : o2;
-        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
-        uint2 pn[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            if (e < cnt1) pn[q] = gnodes[o1 + e];
-        }
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = boff;
-        for (int l = 0; l < levels; ++l) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) nd[c] = lds_u2(node[c]);
-#pragma unroll
-            for (int c = 0; c < RL; ++c) key[c] = lds_u32(lane_base + (nd[c].x & 0xFFu) + c * 4);
-#pragma unroll
-            for (int c = RL; c < R; ++c) key[c] = pick_key<P>(kv[c - RL], nd[c].x);
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(node[c]) : "v"(key[c]), "v"(nd[c].x), "v"(nd[c].y) : "vcc");
-        }
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = glval[o + (int)((node[c] - boff) >> 3)];
-        }
-        const unsigned reloc = noff * 0x10001u;
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            if (e < cnt1) { uint2 nd = pn[q]; nd.y += reloc; *(uint2 *)(smem + noff + (unsigned)e * 8u) = nd; }
-        }
-        __syncthreads();
-        o = o1; o1 = o2; o2 = o3;
-        levels = levels1; levels1 = levels2;
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
-// COMPACT records in TWO buffers (round 3) -- the form for trees whose split nodes fit twice beside the keys (a 5 000-
-// station forest: ~1 500 split records = 12 KB per tree).  Measured on cfg3, the double-buffered walk above sits at 7.4
-// LDS cycles per wave, level and walk against 4 conflict-free (ds_read_b64 + ds_read_b32, 2 cycles each): the rest is
-// bank conflicts of the random node reads, and a third of all reads are lanes parked on a terminal's self-loop, each
-// at its own random address.  With the split nodes alone in LDS every such lane reads the SAME all-zero record at D
-// (rf_walk_compact_kernel's state machine) -- identical addresses broadcast, they conflict with nobody -- and a tree is
-// half the bytes, so two of them leave room for the keys of more walks per lane (R = 6 at p = 5).  Buffers at 0 and
-// STRIDE (compile-time: the buffer rides in the ds_read's immediate offset, the records stay buffer-relative and need
-// no relocation; the tree loop is unrolled by two), the next tree global -> registers during the walk and registers ->
-// the other buffer after it, one barrier per tree, predictions one tree behind: rf_walk_db_kernel's pipeline.
-template <int RCODE, bool K64, int STRIDE>
-__global__ __launch_bounds__(1024) void rf_walk_cdb_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
-                                                           const int *__restrict__ tree_off, const int *__restrict__ coff,
-                                                           const int *__restrict__ depth, const void *__restrict__ sorted,
-                                                           const int *__restrict__ sorted_off, int n_trees, int p,
-                                                           StackDev s, PredGeom g, double weight, int accumulate,
-                                                           double *__restrict__ out) {
-    constexpr int R = rf_walks(RCODE);
-    constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // records per thread in flight
-    constexpr unsigned TREE_BYTES = 2u * STRIDE;
-    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && STRIDE <= 65535, "two buffers, the second inside the immediate offset");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *coarse = (float *)smem;
-    const unsigned stride = (unsigned)(p * R) | 1u;
-    const unsigned lane_base = TREE_BYTES + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
-    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int row[R], col[R];
-    bool na[R];
-    double acc[R], pending[R];
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
-    }
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    __syncthreads();                                               // coarse table no longer needed
-    {
-        const int o = coff[0], cnt = coff[1] - o;
-        for (int e = threadIdx.x; e < cnt; e += 1024) ((uint2 *)smem)[e] = gnodes[o + e];
-    }
-    __syncthreads();
-    // scalars of the trees ahead are fetched early, as in rf_walk_db_kernel
-    int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
-    int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
-    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
-    auto step = [&](auto slot_tag, const int t) {
-        constexpr int SLOT = decltype(slot_tag)::value;
-        const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
-        const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
-        const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
-        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
-        const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
-        uint2 pn[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = (int)threadIdx.x + q * 1024;
-            if (e < cnt1) pn[q] = gnodes[c1 + e];
-        }
-        unsigned node[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = 0u;
-        for (int l = 0; l < levels; ++l) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const uint2v nd = *((__attribute__((address_space(3))) const uint2v *)(uintptr_t)min(node[c], D) + SLOT * (STRIDE / 8));
-                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                unsigned child;
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-                node[c] = max(child, node[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = glval[o + (int)(node[c] - D)];
-        }
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = (int)threadIdx.x + q * 1024;
-            if (e < cnt1) *(uint2 *)(smem + (unsigned)(1 - SLOT) * STRIDE + (unsigned)e * 8u) = pn[q];
-        }
-        __syncthreads();
-        o = o1; o1 = o2;
-        c0 = c1; c1 = c2; c2 = c3;
-        levels = levels1; levels1 = levels2;
-    };
-    for (int t = 0; t < n_trees; t += 2) {
-        step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
 // TRIPLE-buffered form (round 3): the double-buffered kernel above still meets at one s_barrier per tree, and the 16 waves
 // of a block do not finish a tree together (their random node reads conflict differently): measured, a quarter of that
 // kernel was waves waiting at the barrier for the slowest one while the LDS pipe -- the bound of the walk -- ran dry.
@@ -2162,29 +1914,9 @@ static int rf_walk_db_log2r(const mhs_model *m) {
     return -1;
 }
 
-// COMPACT records in two buffers (rf_walk_cdb_kernel): walks-per-lane code and buffer stride, false = does not apply
-static bool rf_walk_cdb_config(const mhs_model *m, int *rcode, int *stride) {
-    // measured on cfg3 (tools/r03_tree_variants.py): 213-229 ms per 1e8 cells against the double-buffered kernel's 176 -- the two
-    // extra VALU per level (min / max) cost more than the broadcast reads of parked lanes save.  Opt-in: MHS_RF_CDB.
-    if (!getenv("MHS_RF_CDB") || getenv("MHS_RF_DOUBLE_BUFFER") || getenv("MHS_RF_SINGLE_BUFFER") || getenv("MHS_RF_TRIPLE_BUFFER")) return false;
-    if (!m->rf_compact_ok) return false;
-    int want = 4;                                   // most walks per lane tried first (code 4 = 6 walks); MHS_RF_CDB_WALKS = 4..8
-    if (const char *e = getenv("MHS_RF_CDB_WALKS")) want = std::max(2, std::min(6, atoi(e) == 4 ? 2 : atoi(e) - 2));
-    for (int st : {16384, 32768}) {
-        if ((size_t)m->rf_cmax * 8 > (size_t)st) continue;
-        for (int rc = want; rc >= 2; --rc)
-            if ((m->p * rf_walks(rc) * 4) <= 255 &&
-                (size_t)2 * st + (size_t)1024 * (((size_t)m->p * rf_walks(rc)) | 1) * 4 <= LDS_MAX) {
-                *rcode = rc; *stride = st;
-                return true;
-            }
-    }
-    return false;
-}
-
 // triple-buffered kernel: buffer stride (bytes, a template parameter) and walks per lane, false = does not apply
 static bool rf_walk_tb_config(const mhs_model *m, int *log2r, int *stride) {
-    if (!getenv("MHS_RF_TRIPLE_BUFFER")) return false;      // measured no faster than two buffers and a barrier: kept as evidence
+    if (!getenv("MHS_RF_TRIPLE_BUFFER")) return false;      // opt-in: as fast as two buffers + five walks (169 ms), no faster
     const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
     for (int st : {16384, 24576}) {
         if ((size_t)m->rf_max_nodes * 8 > (size_t)st) continue;
@@ -2308,50 +2040,6 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
 #undef MHS_TM
             return MHS_OK;
         }
-    }
-    if (!big && getenv("MHS_RF_MIXED") && m->p >= 5 && m->p <= 8 && m->rf_max_nodes <= 4095 &&
-        std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES) + (size_t)1024 * (((size_t)m->p * 4) | 1) * 4 <= LDS_LIMIT) {
-        TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_SMALL, key64, &tt)) return rc;
-        const int rv = std::max(1, std::min(3, atoi(getenv("MHS_RF_MIXED"))));
-        const int R = 4 + rv;
-        const int64_t part = (total + R - 1) / R;
-        const unsigned blocks = (unsigned)((part + 1023) / 1024);
-        const size_t mbytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES) + (size_t)1024 * (((size_t)m->p * 4) | 1) * 4;
-        typedef void (*MxKernel)(const uint2 *, const double *, const int *, const int *, const void *, const int *, int, int, StackDev, PredGeom,
-                                 double, int, double *);
-        MxKernel mk = nullptr;
-#define MHS_MX(P_, RV_) (key64 ? (MxKernel)rf_walk_mx_kernel<P_, RV_, true> : (MxKernel)rf_walk_mx_kernel<P_, RV_, false>)
-#define MHS_MX_P(P_) case P_: mk = rv == 1 ? MHS_MX(P_, 1) : rv == 2 ? MHS_MX(P_, 2) : MHS_MX(P_, 3); break;
-        switch (m->p) { MHS_MX_P(5) MHS_MX_P(6) MHS_MX_P(7) MHS_MX_P(8) }
-#undef MHS_MX_P
-#undef MHS_MX
-        MHS_HIP(hipFuncSetAttribute((const void *)mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mbytes));
-        hipLaunchKernelGGL(mk, dim3(blocks), dim3(1024), mbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, m->rf_depth,
-                           tt.sorted, tt.sorted_off, m->n_trees, m->rf_max_nodes, s, g, w, acc, out);
-        return MHS_OK;
-    }
-    int cd_rc = 0, cd_stride = 0;
-    if (!big && rf_walk_cdb_config(m, &cd_rc, &cd_stride)) {     // split-node records, two buffers
-        TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, cd_rc, RF_COMPACT, key64, &tt)) return rc;
-        const int R = rf_walks(cd_rc);
-        const int64_t part = (total + R - 1) / R;
-        const unsigned blocks = (unsigned)((part + 1023) / 1024);
-        const size_t cbytes = (size_t)2 * cd_stride + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-        typedef void (*CdbKernel)(const uint2 *, const double *, const int *, const int *, const int *, const void *, const int *, int, int,
-                                  StackDev, PredGeom, double, int, double *);
-        CdbKernel ck = nullptr;
-#define MHS_CDB(RC, ST) (key64 ? (CdbKernel)rf_walk_cdb_kernel<RC, true, ST> : (CdbKernel)rf_walk_cdb_kernel<RC, false, ST>)
-#define MHS_CDB_ST(ST) switch (cd_rc) { case 2: ck = MHS_CDB(2, ST); break; case 3: ck = MHS_CDB(3, ST); break; case 4: ck = MHS_CDB(4, ST); break; \
-                                        case 5: ck = MHS_CDB(5, ST); break; default: ck = MHS_CDB(6, ST); break; }
-        if (cd_stride == 16384) { MHS_CDB_ST(16384) } else { MHS_CDB_ST(32768) }
-#undef MHS_CDB_ST
-#undef MHS_CDB
-        MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes));
-        hipLaunchKernelGGL(ck, dim3(blocks), dim3(1024), cbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out);
-        return MHS_OK;
     }
     int tb_l2 = 0, tb_stride = 0;
     if (!big && rf_walk_tb_config(m, &tb_l2, &tb_stride)) {      // triple-buffered, barrier-free tree loop

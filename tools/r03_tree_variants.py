@@ -37,11 +37,7 @@ for kind, variants in (("svr", [("row tiles: the LAT term once per wave and supp
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
                        ("rf", [("double-buffered, 5 walks, hand-scheduled level loop (default)", {}),
                                ("double-buffered, 5 walks, the compiler's loop (round 2)", {"MHS_RF_COMPILER_LOOP": "1"}),
-                               ("split-node records, two buffers, 6 walks", {"MHS_RF_CDB": "1"}),
-                               ("same, 5 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "5"}), ("same, 4 walks", {"MHS_RF_CDB": "1", "MHS_RF_CDB_WALKS": "4"}),
                                ("triple-buffered, no barrier", {"MHS_RF_TRIPLE_BUFFER": "1"}),
-                               ("mixed: 4 LDS-key walks + 1 register-key walk", {"MHS_RF_MIXED": "1"}),
-                               ("mixed: 4 + 2", {"MHS_RF_MIXED": "2"}), ("mixed: 4 + 3", {"MHS_RF_MIXED": "3"}),
                                ("double-buffered, 4 walks", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}),
                                ("split-node records, one buffer, 4 walks", {"MHS_RF_FORCE_COMPACT": "1"})])):
     ref = None
