@@ -194,7 +194,10 @@ class Workload:
                 fl = band_cells * nsv * (3.0 * p + 2.0)
                 pm = pmc.get("svr", {})
                 ipp = pm.get("valu_per_cell_unit", 15.07)
-                rows.append({"kernel": "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
+                rowtile = self.geom.ncol >= 0.93 * (-(-self.geom.ncol // 192) * 192)      # launch_svr's choice (ensemble.hip)
+                if rowtile:
+                    ipp = min(ipp, 14.07)      # the LAT term once per wave: one fma less per (cell, SV) than the PMC pass's kernel
+                rows.append({"kernel": "svr_rt_kernel" if rowtile else "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop",
                              "issue_view": {"achieved": band_cells * nsv / 64.0 * ipp / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
                                             "frac": band_cells * nsv / 64.0 * ipp / ms / 1e6 / VALU_ISSUE_PEAK_G,
@@ -258,7 +261,7 @@ class Workload:
                     pmc_t[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass
-        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("rf", "rf_walk_db_kernel"), ("svr", "svr_kernel")):
+        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("rf", "rf_walk_db_kernel"), ("svr", "svr_kernel"), ("svr", "svr_rt_kernel")):
             if "hbm_bytes_per_cell_fetch_x2_plus_write" in pmc.get(kind, {}):      # round 3's passes (fresh output plane: no RMW read)
                 pmc_t[kn] = pmc[kind]["hbm_bytes_per_cell_fetch_x2_plus_write"]
         for r in rows:
