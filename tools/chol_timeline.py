@@ -3,7 +3,7 @@ time has an update kernel running, how much only chain kernels (diagonal block, 
 import csv, glob, sys
 f = glob.glob('/tmp/ct/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-start = [i for i, r in enumerate(rows) if 'gram_kernel' in r['Kernel_Name']][-1]
+start = [i for i, r in enumerate(rows) if 'gram_' in r['Kernel_Name']][-1]      # the last fit's Gram / projection launch (gram_kernel or the fused gram_proj_kernel)
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].split('::')[-1]) for r in rows[start:]]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 print("kernels", len(ev), "span %.2f ms" % ((t1 - t0) / 1e6))
