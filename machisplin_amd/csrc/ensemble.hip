@@ -98,6 +98,7 @@ struct mhs_model {
     unsigned long long *rf_nodes = nullptr;  // device, 8-byte records {(rank << 8) | key offset; left | right << 16}
     double *rf_lval = nullptr;               // device, node prediction by node id
     int *rf_depth = nullptr;                 // device, levels to descend per tree
+    int *rf_dmin = nullptr;                  // device, depth of every tree's shallowest terminal node
     std::vector<double> rf_thr;              // host, split value per node
     std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
     int rf_max_nodes = 0;
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int max_nodes, int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips) {
     constexpr int R = rf_walks(LOG2R);
     constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1150,14 +1151,27 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     const int64_t part = (total + R - 1) / R;
     const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     int row[R], col[R];
-    bool na[R];
+    bool na[R], live[R];
     double acc[R], pending[R];
     unsigned node[R];
+    // A lane's R cells.  STRIPS (grids): the same column of R adjacent rows -- the rows are cut into strips of R, a lane
+    // index runs along a strip and on into the next one -- so that a wave's 64 R cells are neighbours, end in neighbouring
+    // leaves and the wave can leave a tree at its cells' deepest leaf instead of the tree's (rf_walk_loop5x.inc).
+    // Otherwise (few rows, e.g. the stations' point list): cell i0 + c * ceil(total / R), as the other walk kernels.
 #pragma unroll
     for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        if (strips) {
+            const int64_t sr = i0 / g.nc;
+            col[c] = (int)(i0 - sr * g.nc);
+            const int64_t r = sr * R + c;
+            live[c] = r < g.nr;
+            row[c] = (int)(live[c] ? r : g.nr - 1);
+        } else {
+            int64_t i = i0 + c * part;
+            live[c] = i0 < part && i < total;
+            if (i >= total) i = total - 1;
+            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        }
         na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
     }
     for (int j = 0; j < p; ++j) {
@@ -1177,11 +1191,13 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     // would stall all 16 waves for its latency, 500 times
     int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1;
     int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+    int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
     for (int t = 0; t < n_trees; ++t) {
         const unsigned boff = (t & 1) ? buf_bytes : 0u, noff = (t & 1) ? 0u : buf_bytes;
         const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0;
         const int o3 = t + 3 <= n_trees ? tree_off[t + 3] : o2;        // consumed two iterations from now
         const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+        const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
         uint2 pn[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
@@ -1193,23 +1209,26 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         if constexpr (R == 5 && HAND) {
             // five walks: the level loop by hand (tools/gen_rf_walk_asm.py) -- the walks rotated so that the two wait states an
             // SDWA select needs after v_cmp's write of VCC are the previous walk's next node read and the next walk's key wait
-            int cnt = levels;
-            if (cnt > 0)
+            // levels - 1 of them with a next level: the first min(shallowest leaf, levels - 1) untested, the others leave the
+            // loop when every walk of the wave has reached a terminal node; then the last level
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
                 asm volatile(
-#include "rf_walk_loop5.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt)
+#include "rf_walk_loop5x.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
+                      [c0] "+s"(c0)
                     : [lb] "v"(lane_base)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
         } else if constexpr (R == 4 && HAND) {
-            int cnt = levels;
-            if (cnt > 0)
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
                 asm volatile(
-#include "rf_walk_loop4.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt)
+#include "rf_walk_loop4x.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
                     : [lb] "v"(lane_base)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118");
+                      "v115", "v116", "v117", "v118", "v120");
         } else
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
@@ -1238,12 +1257,12 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         __syncthreads();
         o = o1; o1 = o2; o2 = o3;
         levels = levels1; levels1 = levels2;
+        shallow = shallow1; shallow1 = shallow2;
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
         acc[c] = acc[c] + pending[c];
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
+        if (live[c])
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }
 }
@@ -1740,6 +1759,7 @@ static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64
 }
 
 enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomForest node records (build_rf_nodes_t)
+constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a terminal node's record (rf_walk_loop5x.inc tests for it)
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
 struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
@@ -1997,8 +2017,10 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
         const unsigned left = m->rf_left[k];   // node index within the tree (terminal: its own index)
         const unsigned unit = big ? 1u : 8u;   // children as node indices or as LDS byte addresses
         unsigned node0 = 0, children;
-        if (v == 0xFFFFu) children = (left * unit) | ((left * unit) << 16);
-        else {
+        if (v == 0xFFFFu) {
+            children = (left * unit) | ((left * unit) << 16);
+            if (!big) node0 = RF_LEAF_WORD;      // above every key: the compare is false, both children are the node itself
+        } else {
             const std::vector<KT> &sv = sorted[(size_t)v];
             const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[k]) - sv.begin());
             node0 = (j << 8) | (v * R * 4u);
@@ -2066,9 +2088,14 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big ? RF_BIG : RF_SMALL, key64, &tt)) return rc;
     const int R = rf_walks(log2r);
     const int64_t part = (total + R - 1) / R;
-    const unsigned blocks = (unsigned)((part + 1023) / 1024);
+    unsigned blocks = (unsigned)((part + 1023) / 1024);
     if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
         const size_t dbytes = rf_walk_db_lds(m, log2r);
+        // grids: a lane's walks on R adjacent rows and the early exit per wave (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: the
+        // round-2 cell order / every tree to its full depth -- the equality tests' switches)
+        const int strips = g.nr >= 4 * R && !getenv("MHS_RF_FAR_WALKS");
+        if (strips) blocks = (unsigned)((((int64_t)(g.nr + R - 1) / R) * g.nc + 1023) / 1024);
+        const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
         const bool hand = getenv("MHS_RF_COMPILER_LOOP") == nullptr;      // five walks: hand-scheduled level loop (default)
         auto dk = log2r == 3 ? (hand ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
                                      : (key64 ? rf_walk_db_kernel<3, true, false> : rf_walk_db_kernel<3, false, false>))
@@ -2077,7 +2104,7 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
                              : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
         hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips);
         return MHS_OK;
     }
     const size_t bytes = rf_walk_lds(m, log2r, big);
@@ -2289,6 +2316,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
     if (m->rf_lval) (void)hipFree(m->rf_lval);
     if (m->rf_depth) (void)hipFree(m->rf_depth);
+    if (m->rf_dmin) (void)hipFree(m->rf_dmin);
     if (m->rf_coff) (void)hipFree(m->rf_coff);
     for (void *q : m->retired) (void)hipFree(q);
     delete m;
@@ -2497,7 +2525,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
         m->rf_left.resize(nodes.size());
         m->rf_var.resize(nodes.size());
         std::vector<double> lval(nodes.size());
-        std::vector<int> depth((size_t)n_trees, 0), lev;
+        std::vector<int> depth((size_t)n_trees, 0), shallow((size_t)n_trees, 0), lev;
         int max_nodes = 0;
         for (int64_t t = 0; t < n_trees && paired; ++t) {
             const int o = off[t], cnt = off[t + 1] - off[t];
@@ -2506,7 +2534,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
             m->rf_off.push_back(o);
             lev.assign((size_t)cnt, -1);
             lev[0] = 0;
-            int dmax = 0;
+            int dmax = 0, dlow = 1 << 30;
             for (int k = 0; k < cnt; ++k) {  // randomForest numbers children after their parent
                 const Node &nd = nodes[(size_t)(o + k)];
                 if (lev[k] < 0) { paired = false; break; }  // unreachable or out-of-order node
@@ -2521,9 +2549,11 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
                 } else {
                     m->rf_left[(size_t)(o + k)] = (unsigned short)k;  // self loop
                     m->rf_var[(size_t)(o + k)] = 0xFFFFu;
+                    dlow = std::min(dlow, lev[k]);
                 }
             }
             depth[(size_t)t] = dmax;
+            shallow[(size_t)t] = std::min(dlow, dmax);
         }
         if (paired) {
             m->rf_off.push_back((int)nodes.size());
@@ -2538,6 +2568,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
             m->rf_max_nodes = max_nodes;
             int rc = to_device(lval.data(), lval.size(), &m->rf_lval);
             if (!rc) rc = to_device(depth.data(), depth.size(), &m->rf_depth);
+            if (!rc) rc = to_device(shallow.data(), shallow.size(), &m->rf_dmin);
             if (rc) { mhs_model_free(m); return rc; }
         }
     }

@@ -284,17 +284,21 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, monkeypatch):
     compiler's loop, the four-walk forms, the barrier-free triple-buffered kernel (MHS_RF_TRIPLE_BUFFER: three buffers, LDS
     counters between the waves, hand-scheduled loops too), round 2's single-buffer forms and the node walk: bit-identical
     planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).
-    Seven trees: a count that is a multiple neither of the two nor of the three buffers.  (Two more restructurings were
+    The default also walks a lane's five cells on five ADJACENT rows (123 rows: a ragged last strip) and lets a wave leave a
+    tree once all its walks sit at terminal nodes (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: round 2's cell order / every tree
+    to its full depth).  Seven trees: a count that is a multiple neither of the two nor of the three buffers.  (Two more restructurings were
     measured in round 3 and removed again, see DESIGN.md section 4 and profiles/r03_tree_variants.txt.)"""
     import torch
     from machisplin_amd import synth
-    g, stack, X, Xs, ys, params = _setup(hip, nrow=120, ncol=257, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=257, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
     prm = synth.rf_params(Xs, ys, 9, n_trees=7)
     nodes = np.diff(prm["tree_offsets"]).max()
     assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
     m = hip.models.from_param_dict(prm)
     fast = hip.predict(stack, m)
     for envs in ({"MHS_RF_COMPILER_LOOP": "1"}, {"MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_COMPILER_LOOP": "1"},
+                 {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
+                 {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
                  {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):

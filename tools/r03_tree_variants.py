@@ -35,7 +35,11 @@ def run(kind, env):
 for kind, variants in (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
-                       ("rf", [("double-buffered, 5 walks, hand-scheduled level loop (default)", {}),
+                       ("rf", [("5 walks on adjacent rows, a wave leaves a tree at its deepest leaf (default)", {}),
+                               ("5 walks on adjacent rows, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
+                               ("5 walks a fifth of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
+                               ("5 walks a fifth of the grid apart, full depth (round 3 before the early exit)", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}),
+                               ("4 walks on adjacent rows, early exit", {"MHS_RF_FOUR_WALKS": "1"}),
                                ("double-buffered, 5 walks, the compiler's loop (round 2)", {"MHS_RF_COMPILER_LOOP": "1"}),
                                ("triple-buffered, no barrier", {"MHS_RF_TRIPLE_BUFFER": "1"}),
                                ("double-buffered, 4 walks", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}),
