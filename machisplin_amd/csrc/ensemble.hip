@@ -1123,6 +1123,36 @@ __global__ __launch_bounds__(512) void rf_walk_tm_kernel(const uint2 *__restrict
         }
 }
 
+// A lane's R cells in the forest walk kernels.  STRIPS (grids): the same column of R adjacent rows -- the rows are cut
+// into strips of R, a lane index runs along a strip and on into the next one -- so that a wave's 64 R cells are
+// neighbours, end in neighbouring leaves, and the wave can leave a tree at its cells' deepest leaf instead of the tree's.
+// Otherwise (few rows, e.g. the stations' point list): cell i0 + c * ceil(total / R).
+template <int R>
+__device__ __forceinline__ void rf_lane_cells(const PredGeom &g, int64_t i0, int strips, int (&row)[R], int (&col)[R], bool (&live)[R]) {
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t part = (total + R - 1) / R;
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        if (strips) {
+            const int64_t sr = i0 / g.nc;
+            col[c] = (int)(i0 - sr * g.nc);
+            const int64_t r = sr * R + c;
+            live[c] = r < g.nr;
+            row[c] = (int)(live[c] ? r : g.nr - 1);
+        } else {
+            int64_t i = i0 + c * part;
+            live[c] = i0 < part && i < total;
+            if (i >= total) i = total - 1;
+            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
+        }
+    }
+}
+static int64_t rf_lane_count(const PredGeom &g, int R, int strips) {      // lanes a launch needs
+    const int64_t total = (int64_t)g.nr * g.nc;
+    return strips ? (((int64_t)g.nr + R - 1) / R) * g.nc : (total + R - 1) / R;
+}
+static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R && !getenv("MHS_RF_FAR_WALKS"); }
+
 // Double-buffered form for trees of up to 4095 nodes (two buffers stay within the 16-bit child addresses): the
 // next tree travels global -> registers -> the other LDS buffer WHILE this one is walked, the node predictions are
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
@@ -1147,33 +1177,14 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
     const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
     const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     int row[R], col[R];
     bool na[R], live[R];
     double acc[R], pending[R];
     unsigned node[R];
-    // A lane's R cells.  STRIPS (grids): the same column of R adjacent rows -- the rows are cut into strips of R, a lane
-    // index runs along a strip and on into the next one -- so that a wave's 64 R cells are neighbours, end in neighbouring
-    // leaves and the wave can leave a tree at its cells' deepest leaf instead of the tree's (rf_walk_loop5x.inc).
-    // Otherwise (few rows, e.g. the stations' point list): cell i0 + c * ceil(total / R), as the other walk kernels.
+    rf_lane_cells<R>(g, i0, strips, row, col, live);
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-        if (strips) {
-            const int64_t sr = i0 / g.nc;
-            col[c] = (int)(i0 - sr * g.nc);
-            const int64_t r = sr * R + c;
-            live[c] = r < g.nr;
-            row[c] = (int)(live[c] ? r : g.nr - 1);
-        } else {
-            int64_t i = i0 + c * part;
-            live[c] = i0 < part && i < total;
-            if (i >= total) i = total - 1;
-            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        }
-        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
-    }
+    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
     for (int j = 0; j < p; ++j) {
         float r[R];
         if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
@@ -1300,7 +1311,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips) {
     constexpr int R = rf_walks(LOG2R);
     constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // node records per thread in flight
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
@@ -1311,19 +1322,13 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
     const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
     const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
     const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     int row[R], col[R];
-    bool na[R];
+    bool na[R], live[R];
     double acc[R], pending[R];
+    rf_lane_cells<R>(g, i0, strips, row, col, live);
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
-    }
+    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
     for (int j = 0; j < p; ++j) {
         float r[R];
         if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
@@ -1340,7 +1345,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
     __syncthreads();
     auto step = [&](auto slot_tag, const int t) {
         constexpr int SLOT = decltype(slot_tag)::value, SLOT2 = (SLOT + 2) % 3;
-        const int o = tree_off[t], levels = depth[t];
+        const int o = tree_off[t], levels = depth[t], shallow = dmin ? dmin[t] : levels;
         const bool more = t + 2 < n_trees;
         const int o2 = more ? tree_off[t + 2] : 0, cnt2 = more ? tree_off[t + 3] - o2 : 0;
         uint2 pn[PF];
@@ -1354,23 +1359,24 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = 0u;
         if constexpr (R == 4) {
-            int cnt = levels;
-            if (cnt > 0)
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
                 asm volatile(
-#include "rf_walk_loop4o.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt)
+#include "rf_walk_loop4xo.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
                     : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118");
+                      "v115", "v116", "v117", "v118", "v120");
         } else if constexpr (R == 5) {
-            int cnt = levels;
-            if (cnt > 0)
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
                 asm volatile(
-#include "rf_walk_loop5o.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt)
+#include "rf_walk_loop5xo.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
+                      [c0] "+s"(c0)
                     : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
         } else
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
@@ -1407,8 +1413,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 #pragma unroll
     for (int c = 0; c < R; ++c) {
         acc[c] = acc[c] + pending[c];
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
+        if (live[c])
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }
 }
@@ -1431,7 +1436,7 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
                                                                const int *__restrict__ depth, const void *__restrict__ sorted,
                                                                const int *__restrict__ sorted_off, int n_trees, int cmax, int p,
                                                                StackDev s, PredGeom g, double weight, int accumulate,
-                                                               double *__restrict__ out) {
+                                                               double *__restrict__ out, const int *__restrict__ dmin, int strips) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned nt = blockDim.x;
@@ -1440,20 +1445,14 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
     const unsigned stride = (unsigned)(p * R) | 1u;
     const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
     const int64_t i0 = (int64_t)blockIdx.x * nt + threadIdx.x;
     int row[R], col[R];
-    bool na[R];
+    bool na[R], live[R];
     double acc[R], pending[R];
     unsigned node[R];
+    rf_lane_cells<R>(g, i0, strips, row, col, live);
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        na[c] = false; acc[c] = 0.0; pending[c] = 0.0;
-    }
+    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
     for (int j = 0; j < p; ++j) {
         float r[R];
         if constexpr (K64) lut_ranks_t<R, 0, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
@@ -1471,11 +1470,13 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
     int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
     int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
     int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+    int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
     for (int t = 0; t < n_trees; ++t) {
         const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
         const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
         const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
         const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+        const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
         const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
         uint2 pn[PF];
 #pragma unroll
@@ -1485,7 +1486,7 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
         }
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = 0u;
-        for (int l = 0; l < levels; ++l) {
+        auto level = [&]() {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 const uint2v nd = lds_u2(min(node[c], D));
@@ -1497,6 +1498,14 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
                     : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
                 node[c] = max(child, node[c]);
             }
+        };
+        // no state is terminal above the tree's shallowest leaf; from there on the wave leaves the tree as soon as every
+        // state of every lane is a terminal code (>= D)
+        for (int l = 0; l < shallow; ++l) level();
+        for (int l = shallow; l < levels; ++l) {
+            const unsigned lowest = min(min(node[0], node[1]), min(node[2], node[3]));
+            if (!__builtin_amdgcn_ballot_w64(lowest < D)) break;
+            level();
         }
 #pragma unroll
         for (int c = 0; c < R; ++c) {
@@ -1513,12 +1522,12 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
         o = o1; o1 = o2;
         c0 = c1; c1 = c2; c2 = c3;
         levels = levels1; levels1 = levels2;
+        shallow = shallow1; shallow1 = shallow2;
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
         acc[c] = acc[c] + pending[c];
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
+        if (live[c])
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }
 }
@@ -2068,8 +2077,9 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         TreeTables tt;
         if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
         const int R = rf_walks(tb_l2);
-        const int64_t part = (total + R - 1) / R;
-        const unsigned blocks = (unsigned)((part + 1023) / 1024);
+        const int strips = rf_strips(g, R);
+        const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
+        const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
         const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
 #define MHS_TB(L2, ST) (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>)
         auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
@@ -2077,7 +2087,7 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
 #undef MHS_TB
         MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
         hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out);
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips);
         return MHS_OK;
     }
     if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane
@@ -2093,8 +2103,8 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         const size_t dbytes = rf_walk_db_lds(m, log2r);
         // grids: a lane's walks on R adjacent rows and the early exit per wave (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: the
         // round-2 cell order / every tree to its full depth -- the equality tests' switches)
-        const int strips = g.nr >= 4 * R && !getenv("MHS_RF_FAR_WALKS");
-        if (strips) blocks = (unsigned)((((int64_t)(g.nr + R - 1) / R) * g.nc + 1023) / 1024);
+        const int strips = rf_strips(g, R);
+        blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
         const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
         const bool hand = getenv("MHS_RF_COMPILER_LOOP") == nullptr;      // five walks: hand-scheduled level loop (default)
         auto dk = log2r == 3 ? (hand ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
@@ -2134,14 +2144,15 @@ static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGe
     TreeTables tt;
     if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_COMPACT, key64, &tt)) return rc;
     const size_t bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES) + (size_t)nt * (((size_t)m->p * 4) | 1) * 4;
-    const int64_t part = (total + 3) / 4;
-    const unsigned blocks = (unsigned)((part + nt - 1) / nt);
+    const int strips = rf_strips(g, 4);
+    const unsigned blocks = (unsigned)((rf_lane_count(g, 4, strips) + nt - 1) / nt);
+    const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
     const bool pf4 = (size_t)nt * 4 >= (size_t)m->rf_cmax;
     auto k = pf4 ? (key64 ? rf_walk_compact_kernel<4, true> : rf_walk_compact_kernel<4, false>)
                  : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
-                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out);
+                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips);
     return MHS_OK;
 }
 

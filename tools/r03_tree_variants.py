@@ -11,15 +11,17 @@ from machisplin_amd import synth
 m.init()
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+shape = sys.argv[3] if len(sys.argv) > 3 else "cfg3"          # cfg5: 20 000 stations, 5 covariates (the forest's COMPACT form)
+ncov, nst = (5, 20000) if shape == "cfg5" else (3, 5000)
 g = synth.grid(side, side)
 seed = synth.BASE_SEED + 3
-planes, nodata = synth.covariates(g, 3, seed, dtype="f32")
+planes, nodata = synth.covariates(g, ncov, seed, dtype="f32")
 stack = m.RasterStack(g, planes, nodata)
-xy, rows, cols, uv = synth.stations(g, 5000, seed)
+xy, rows, cols, uv = synth.stations(g, nst, seed)
 cov_at = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
 X = np.column_stack([cov_at, xy])
 y = synth.response(X, uv, seed)
-params = {p["kind"]: p for p in synth.ensemble_params(X, y, seed, which="brv")}
+params = {p["kind"]: p for p in synth.ensemble_params(X, y, seed, which="r" if shape == "cfg5" else "brv")}
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 
 def run(kind, env):
@@ -32,7 +34,11 @@ def run(kind, env):
     for k in env: del os.environ[k]
     return best, out.clone()
 
-for kind, variants in (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
+cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, early exit (default)", {}),
+                         ("same, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
+                         ("same, 4 walks a quarter of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
+                         ("round 3 before the early exit", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"})]),)
+for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
                        ("rf", [("5 walks on adjacent rows, a wave leaves a tree at its deepest leaf (default)", {}),
