@@ -80,6 +80,7 @@ struct mhs_model {
     int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
     double *lut_rt = nullptr;            // device, the same leaf values with every tree's levels ordered uniform-first
     int *lut_rt_meta = nullptr;          // device, LUT_RT_DW dwords per tree (gbm_lutreg_rt_kernel)
+    unsigned *lut_cls = nullptr;         // device, 5 class words per tree (rank threshold << 3 | predictor; gbm_coherent_kernel)
     std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
@@ -924,6 +925,226 @@ __global__ __launch_bounds__(256, 5) void gbm_lutreg_rt_kernel(const double *__r
 #pragma unroll
     for (int c = 0; c < LUT_R; ++c)
         if (ok[c] && !na[c]) emit(out, (int64_t)row[c] * g.ld_out + col[c], init_f + acc[c], weight, accumulate);
+}
+
+
+// COHERENT form of the gbm evaluation (round 3; S = 5).  Neighbouring cells have neighbouring covariates, and a split is a
+// threshold: over the 64 x 4 cells of a wave's tile most splits of most trees have the SAME outcome for
+// every cell (cfg3's synthetic rasters: 67 % of the trees have no split at all whose threshold lies inside the wave's range
+// of that predictor, and the others 1.2 such splits on average).  So, per wave and chunk of 64 trees, with LANE = TREE:
+//   * from the wave's [min, max] rank of every predictor (one reduction at the start) each lane classifies the five splits
+//     of its tree: all cells left, all cells right, or straddling;
+//   * no straddling split: the tree's leaf is the same for all the wave's cells -- the lane adds it to ITS sum of such
+//     leaves (the 64 sums are added at the very end and go to every cell);
+//   * one straddling split (predictor v, rank threshold c): the cells take one of two leaves, B (bit 0) or A (bit 1); the
+//     lane adds B to its sum and queues (v, c, A - B) in a wave-private list; then the wave runs down the list with
+//     LANE = CELL: acc += rank_v < c ? A - B : 0 -- one compare, two selects and one fp64 add per cell;
+//   * two or more: the tree is queued for the full five-level evaluation (lane = cell, class words broadcast from LDS).
+// The same leaves reach every cell's sum; their ORDER differs from the other gbm kernels' (tree order), and A enters as
+// B + (A - B): planes agree to ~1e-15 of the prediction, not bitwise.  Incoherent rasters (every tree straddling several
+// times) fall to the last case for every tree, which is slower than gbm_lutreg_rt_kernel: launch_gbm_lut samples the
+// grid first and takes this kernel only where it pays.
+// Block = 16 waves; the chunk's leaf LUT (16 KB) and class words (1.25 KB) are staged in LDS for all of them, double-buffered.
+constexpr int GBC_WAVES = 16;
+__device__ __forceinline__ double gbc_lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
+typedef float float4v __attribute__((ext_vector_type(4)));
+template <bool K64>
+__global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__restrict__ lut, const unsigned *__restrict__ cls,
+                                                            const void *__restrict__ sorted, const int *__restrict__ sorted_off,
+                                                            int n_trees_padded, double init_f, int p, StackDev s, PredGeom g,
+                                                            int tiles_per_row, double weight, int accumulate,
+                                                            double *__restrict__ out) {
+    constexpr int S = 5, CH = LUT_CHUNK, CLS_STRIDE = 384, R = LUT_R;
+    static_assert(R == 4, "four cells per lane: two packed predicate instructions");
+    static_assert((CH << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *slut = (double *)smem;                                             // 2 x [CH << S], from LDS address 0
+    unsigned *scls = (unsigned *)(smem + 2 * (CH << S) * sizeof(double));      // 2 x CLS_STRIDE
+    int2 *srange = (int2 *)(scls + 2 * CLS_STRIDE);                            // [waves][8] (min, max) rank
+    float *coarse = (float *)smem;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // a wave = 64 columns x R adjacent rows (lane = column, a lane's R cells one below the other): the most compact
+    // footprint a wave can have, hence the narrowest rank ranges
+    const int64_t ntiles = (int64_t)((g.nr + R - 1) / R) * tiles_per_row;
+    int64_t tile = (int64_t)blockIdx.x * GBC_WAVES + wave;
+    const bool live = tile < ntiles;
+    if (!live) tile = ntiles - 1;
+    const int trow = (int)(tile / tiles_per_row) * R, tcol = (int)(tile % tiles_per_row) * 64;
+    int row[R], col[R];
+    bool na[R], ok[R];
+    double acc[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        ok[c] = live && tcol + lane < g.nc && trow + c < g.nr;
+        row[c] = min(trow + c, g.nr - 1); col[c] = min(tcol + lane, g.nc - 1);
+        na[c] = false; acc[c] = 0.0;
+    }
+    // MINUS the ranks (the packed predicate adds them to c), [predictor][cell] in 32 registers that the several-splits
+    // loop addresses through the VGPR index mode, as gbm_lutreg_kernel does
+    float32v keys;
+#pragma unroll
+    for (int j = 0; j < LUT_REG_P; ++j) {
+        float r[R] = {0.f, 0.f, 0.f, 0.f};
+        if (j < p) {
+            if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+            else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) keys[j * R + c] = -r[c];
+        // the wave's rank range of predictor j, NA cells left out (they are walked separately)
+        int mn = 0x7fffffff, mx = -1;
+#pragma unroll
+        for (int c = 0; c < R; ++c)
+            if (!na[c]) { mn = min(mn, (int)r[c]); mx = max(mx, (int)r[c]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
+        if (lane == 0) srange[wave * 8 + j] = make_int2(mn, mx);
+    }
+    __syncthreads();                                               // the coarse table (it aliases the LUT buffers) is done with
+    for (int e = tid; e < (CH << S); e += 1024) slut[e] = lut[e];
+    if (tid < CH * S) scls[tid] = cls[tid];
+    __syncthreads();
+    double usum = 0.0;
+    for (int t0 = 0, buf = 0; t0 < n_trees_padded; t0 += CH, buf ^= 1) {
+        const bool more = t0 + CH < n_trees_padded;
+        double pre0 = 0.0, pre1 = 0.0;
+        unsigned prec = 0u;
+        if (more) {
+            const double *ln = lut + ((int64_t)(t0 + CH) << S);
+            pre0 = ln[tid]; pre1 = ln[tid + 1024];
+            if (tid < CH * S) prec = cls[(int64_t)(t0 + CH) * S + tid];
+        }
+        // ---- lane = tree: classify the five splits against the wave's rank ranges
+        const unsigned *cw = scls + buf * CLS_STRIDE + lane * S;
+        const double *L = slut + buf * (CH << S) + (lane << S);
+        unsigned w[S];
+        int2 mm[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) w[q] = cw[q];
+#pragma unroll
+        for (int q = 0; q < S; ++q) mm[q] = srange[wave * 8 + (int)(w[q] & 7u)];
+        unsigned known = 0u, nstr = 0u;
+        unsigned cl[S], vl[S];     // the straddling levels in level order: c as a float's bits; 4 * predictor | bit position << 8
+#pragma unroll
+        for (int q = 0; q < S; ++q) { cl[q] = 0u; vl[q] = 0u; }
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const int c = (int)(w[q] >> 3);
+            const bool all1 = mm[q].y < c, all0 = mm[q].x >= c;
+            if (all1) known |= 16u >> q;
+            if (!(all1 || all0)) {
+                const unsigned cb = __float_as_uint((float)c), vb = ((w[q] & 7u) << 2) | ((unsigned)(S - 1 - q) << 8);
+#pragma unroll
+                for (int l = 0; l < S; ++l) if (nstr == (unsigned)l) { cl[l] = cb; vl[l] = vb; }
+                ++nstr;
+            }
+        }
+        const double B = L[known];
+        const bool single = nstr == 1u, pair = nstr == 2u, multi = nstr >= 3u;
+        if (!multi) usum = usum + B;
+        // One or two straddling splits: with b1, b2 their predicates the leaf is
+        //     B + b1 (A1 - B) + b2 ((A2 - B) + b1 (A12 - A1 - A2 + B)),     A1, A2, A12 = the leaves with bit 1 / bit 2 / both set.
+        // The cell loops below form a predicate as the float clamp(c - rank) written into the HIGH word of a register pair
+        // whose low word is 0: read as a double that is 0 or 2^-7, so the differences are scaled by 2^7 (2^14) here -- exact.
+        double d1 = 0.0, d2 = 0.0, d12 = 0.0;
+        if (single || pair) {
+            const unsigned p1 = 1u << (vl[0] >> 8), p2 = 1u << (vl[1] >> 8);
+            const double A1 = L[known + p1];
+            d1 = (A1 - B) * 128.0;
+            if (pair) {
+                const double A2 = L[known + p2], A12 = L[known + p1 + p2];
+                d2 = (A2 - B) * 128.0;
+                d12 = (((A12 - A1) - A2) + B) * 16384.0;
+            }
+        }
+        // ---- lane = cell.  What a tree needs sits in the registers of the lane that classified it and is fetched from
+        // there with v_readlane (no list in LDS, no wait); the predictor's ranks are picked with the VGPR index mode.
+#define MHS_GBC_RL(x) __builtin_amdgcn_readlane((int)(x), t)
+#define MHS_GBC_RLD(x) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), t), __builtin_amdgcn_readlane(__double2loint(x), t))
+#define MHS_GBC_BITS(h0, h1, h2, h3, vo, cc)                                                                 \
+        asm volatile("s_set_gpr_idx_on %[v], 0x1\n\t"                                                        \
+                     "v_add_f32_e64 %[a], v64, %[c] clamp\n\t"                                               \
+                     "v_add_f32_e64 %[b], v65, %[c] clamp\n\t"                                               \
+                     "v_add_f32_e64 %[d], v66, %[c] clamp\n\t"                                               \
+                     "v_add_f32_e64 %[e], v67, %[c] clamp\n\t"                                               \
+                     "s_set_gpr_idx_off"                                                                     \
+                     : [a] "=&v"(h0), [b] "=&v"(h1), [d] "=&v"(h2), [e] "=&v"(h3)                            \
+                     : "{v[64:95]}"(keys), [v] "s"(vo), [c] "s"(cc));
+        for (unsigned long long m1 = __builtin_amdgcn_ballot_w64(single); m1; m1 &= m1 - 1ull) {
+            const int t = (int)__builtin_ctzll(m1);
+            const int cc = MHS_GBC_RL(cl[0]), vo = MHS_GBC_RL(vl[0]) & 0xFF;
+            const double e1 = MHS_GBC_RLD(d1);
+            int h[R];
+            MHS_GBC_BITS(h[0], h[1], h[2], h[3], vo, cc)
+#pragma unroll
+            for (int c = 0; c < R; ++c) acc[c] = fma(__hiloint2double(h[c], 0), e1, acc[c]);
+        }
+        for (unsigned long long mp = __builtin_amdgcn_ballot_w64(pair); mp; mp &= mp - 1ull) {
+            const int t = (int)__builtin_ctzll(mp);
+            const int c1 = MHS_GBC_RL(cl[0]), v1 = MHS_GBC_RL(vl[0]) & 0xFF, c2 = MHS_GBC_RL(cl[1]), v2 = MHS_GBC_RL(vl[1]) & 0xFF;
+            const double e1 = MHS_GBC_RLD(d1), e2 = MHS_GBC_RLD(d2), e12 = MHS_GBC_RLD(d12);
+            int h[R], k[R];
+            MHS_GBC_BITS(h[0], h[1], h[2], h[3], v1, c1)
+            MHS_GBC_BITS(k[0], k[1], k[2], k[3], v2, c2)
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const double b1 = __hiloint2double(h[c], 0), b2 = __hiloint2double(k[c], 0);
+                acc[c] = fma(b1, e1, acc[c]);
+                acc[c] = fma(b2, fma(b1, e12, e2), acc[c]);
+            }
+        }
+#undef MHS_GBC_BITS
+#undef MHS_GBC_RLD
+#undef MHS_GBC_RL
+        // Three or more: their straddling levels only (the others' bits are in `known`), each a packed predicate and a packed
+        // multiply-add that drops the bit into the slot, which is kept as a float 2^23 + slot (its bit pattern is the LUT's
+        // dword index plus a constant)
+        const unsigned abase = (unsigned)buf * (unsigned)((CH << S) * sizeof(double)) - 0x58000000u;
+        for (unsigned long long m2 = __builtin_amdgcn_ballot_w64(multi); m2; m2 &= m2 - 1ull) {
+            const int t = (int)__builtin_ctzll(m2);
+            const int n = __builtin_amdgcn_readlane((int)nstr, t);
+            const float a0 = __uint_as_float(0x4B000000u + ((unsigned)t << S) + (unsigned)__builtin_amdgcn_readlane((int)known, t));
+            float2v s01 = {a0, a0}, s23 = {a0, a0};
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                if (l < n) {
+                    const unsigned long long cc = (unsigned)__builtin_amdgcn_readlane((int)cl[l], t);
+                    const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)vl[l], t);
+                    const int vo = (int)(vw & 0xFFu);
+                    const unsigned long long wb = (127u + (vw >> 8)) << 23;
+                    float2v b01, b23;
+                    asm volatile("s_set_gpr_idx_on %[vo], 0x1\n\t"
+                                 "v_pk_add_f32 %[b01], v[64:65], %[cc] op_sel_hi:[1,0] clamp\n\t"
+                                 "v_pk_add_f32 %[b23], v[66:67], %[cc] op_sel_hi:[1,0] clamp\n\t"
+                                 "s_set_gpr_idx_off\n\t"
+                                 "v_pk_fma_f32 %[s01], %[b01], %[wb], %[s01] op_sel_hi:[1,0,1]\n\t"
+                                 "v_pk_fma_f32 %[s23], %[b23], %[wb], %[s23] op_sel_hi:[1,0,1]"
+                                 : [s01] "+v"(s01), [s23] "+v"(s23), [b01] "=&v"(b01), [b23] "=&v"(b23)
+                                 : "{v[64:95]}"(keys), [vo] "s"(vo), [cc] "s"(cc), [wb] "s"(wb));
+                }
+            }
+            acc[0] = acc[0] + gbc_lds_f64(__float_as_uint(s01.x) * 8u + abase);
+            acc[1] = acc[1] + gbc_lds_f64(__float_as_uint(s01.y) * 8u + abase);
+            acc[2] = acc[2] + gbc_lds_f64(__float_as_uint(s23.x) * 8u + abase);
+            acc[3] = acc[3] + gbc_lds_f64(__float_as_uint(s23.y) * 8u + abase);
+        }
+        // ---- the next chunk into the other buffer
+        if (more) {
+            double *ld = slut + (buf ^ 1) * (CH << S);
+            ld[tid] = pre0; ld[tid + 1024] = pre1;
+            if (tid < CH * S) scls[(buf ^ 1) * CLS_STRIDE + tid] = prec;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) usum = usum + __shfl_xor(usum, o);
+#pragma unroll
+    for (int c = 0; c < R; ++c)
+        if (ok[c] && !na[c]) emit(out, (int64_t)row[c] * g.ld_out + col[c], init_f + (acc[c] + usum), weight, accumulate);
+}
+static size_t gbc_lds_bytes() {
+    return 2 * ((size_t)LUT_CHUNK << 5) * sizeof(double) + 2 * 384 * sizeof(unsigned) + GBC_WAVES * 8 * sizeof(int2);
 }
 
 // ------------------------------------------------- randomForest: level-synchronous walk --
@@ -1772,7 +1993,7 @@ constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a term
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
 struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
-                    const double *lut_rt; const int *lut_rt_meta; };
+                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; };
 
 // fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
 template <typename T>
@@ -1871,6 +2092,17 @@ static int build_lut_meta_t(mhs_model *m, const mhs_grid &grid, int C) {
         }
         if (int rc = publish(m, rlut, &m->lut_rt)) return rc;
         if (int rc = publish(m, rmeta, &m->lut_rt_meta)) return rc;
+        // class words (gbm_coherent_kernel): level q of tree t = rank threshold << 3 | predictor, 0 for a padding level
+        std::vector<unsigned> cw((size_t)m->n_trees_padded * 5, 0u);
+        for (int t = 0; t < m->n_trees; ++t)
+            for (int q = 0; q < S; ++q) {
+                const int v = m->lut_var[(size_t)t * S + q];
+                if (v < 0) continue;
+                const std::vector<KT> &sv = sorted[(size_t)v];
+                const unsigned c = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[(size_t)t * S + q]) - sv.begin()) + 1u;
+                cw[(size_t)t * 5 + q] = (c << 3) | (unsigned)v;
+            }
+        if (int rc = publish(m, cw, &m->lut_cls)) return rc;
     }
     if (int rc = publish(m, flat, (KT **)&m->lut_sorted)) return rc;
     if (int rc = publish(m, off, &m->lut_sorted_off)) return rc;
@@ -1883,7 +2115,7 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, 
         if (int rc = key64 ? build_lut_meta_t<double>(m, grid, C) : build_lut_meta_t<float>(m, grid, C)) return rc;
         m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
     }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr, nullptr, m->lut_rt, m->lut_rt_meta};
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr, nullptr, m->lut_rt, m->lut_rt_meta, m->lut_cls};
     return MHS_OK;
 }
 
@@ -1900,6 +2132,17 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     // when the rows are long enough that the ragged last tile of a row wastes little (MHS_GBM_NO_ROWTILE: never)
     const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
     const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
+    const int ctpr = (g.nc + 63) / 64;
+    if (in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.93 * (double)ctpr * 64 &&
+        !getenv("MHS_GBM_NO_COHERENT")) {
+        const int64_t ntiles = (int64_t)((g.nr + LUT_R - 1) / LUT_R) * ctpr;
+        const unsigned cblocks = (unsigned)((ntiles + GBC_WAVES - 1) / GBC_WAVES);
+        auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
+        MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
+        hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
+                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out);
+        return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+    }
     if (in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R)) {
         const int64_t ntiles = (int64_t)g.nr * tpr;
         const unsigned rblocks = (unsigned)((ntiles + 3) / 4);
@@ -2322,6 +2565,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->lut_meta) (void)hipFree(m->lut_meta);
     if (m->lut_rt) (void)hipFree(m->lut_rt);
     if (m->lut_rt_meta) (void)hipFree(m->lut_rt_meta);
+    if (m->lut_cls) (void)hipFree(m->lut_cls);
     if (m->lut_sorted) (void)hipFree(m->lut_sorted);
     if (m->lut_sorted_off) (void)hipFree(m->lut_sorted_off);
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);

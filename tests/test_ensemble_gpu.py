@@ -259,6 +259,7 @@ def test_gbm_row_tile_kernel_equals_the_other_paths_bit_for_bit(hip, dtype, n_sp
     assert (prm["split_var"] == prm["p"] - 1).any()          # some splits on LAT
     m = hip.models.from_param_dict(prm)
     win = window or (0, g.nrow, 0, 1000)
+    monkeypatch.setenv("MHS_GBM_NO_COHERENT", "1")          # the default for such rows, gbm_coherent_kernel: next test
     fast = hip.predict(stack, m, window=win)
     monkeypatch.setenv("MHS_TREES_GENERIC", "1")
     slow = hip.predict(stack, m, window=win)
@@ -274,6 +275,51 @@ def test_gbm_row_tile_kernel_equals_the_other_paths_bit_for_bit(hip, dtype, n_sp
         assert torch.equal(torch.nan_to_num(piece), torch.nan_to_num(ref)), cc
     want = oe.predict(prm, X).reshape(g.nrow, g.ncol)[r0:r1, c0:c1]
     got = fast.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
+@pytest.mark.parametrize("dtype,n_splits,window,smooth", [("f32", 5, None, False), ("f64", 5, (3, 37, 40, 1040), False), ("i16", 3, None, False),
+                                                          ("f32", 1, (0, 40, 0, 1000), False), ("f32", 5, None, True), ("f64", 4, (1, 39, 7, 1100), True)])
+def test_gbm_coherent_kernel_matches_the_tree_order_kernels_and_the_oracle(hip, dtype, n_splits, window, smooth, monkeypatch):
+    """The default for long rows (round 3), gbm_coherent_kernel: per wave of 256 consecutive cells a tree whose splits all fall
+    the same way for every cell is summed once per wave, a tree with one split inside the wave's range costs a compare and
+    a select per cell, the others the full evaluation.  Same leaves, another order of the sum: equal to the tree-order
+    kernels (MHS_GBM_NO_COHERENT=1) to rounding, NA cells (walked through MissingNode) and ragged tiles included.  The
+    standard test rasters vary fast (most trees take the full evaluation); `smooth` stretches them so that most trees
+    are wave-uniform or single -- all three branches carry weight in one case or the other."""
+    import torch
+    from machisplin_amd import synth
+    if smooth:
+        g = synth.grid(40 * 50, 1100 * 9)                     # the test grid is a corner of a grid 50 x 9 times larger
+        planes, nodata = synth.covariates(g, 3, 5, dtype=dtype, window=(0, 40, 0, 1100))
+        gs = synth.grid(40, 1100)                             # same origin and cell size: the large grid's NW corner
+        stack = hip.RasterStack(gs, planes, nodata)
+        host = planes.cpu().numpy().astype(np.float64)
+        x, y = otps.cell_centres(gs.xmin, gs.ymax, gs.xres, gs.yres, 40, 1100)
+        X = oe.stack_predictors(host, (x, y))
+        rng = np.random.default_rng(5)
+        idx = rng.choice(X.shape[0], 1500, replace=False)
+        Xs = X[idx]
+        ys = synth.response(Xs, np.column_stack([(idx % 1100 + 0.5) / 1100, (idx // 1100 + 0.5) / 40]), 5)
+        g = gs
+    else:
+        g, stack, X, Xs, ys, params = _setup(hip, nrow=40, ncol=1100, dtype=dtype, nodata_frac=0.01, n=1500, gbm_trees=2, rf_trees=1)
+    prm = synth.gbm_params(Xs, ys, 3, n_trees=900, n_splits=n_splits)
+    m = hip.models.from_param_dict(prm)
+    win = window or (0, g.nrow, 0, 1000)
+    r0, r1, c0, c1 = win
+    coh = hip.predict(stack, m, window=win)
+    monkeypatch.setenv("MHS_GBM_NO_COHERENT", "1")
+    ordered = hip.predict(stack, m, window=win)
+    monkeypatch.delenv("MHS_GBM_NO_COHERENT")
+    assert not torch.isnan(coh).any()                         # gbm routes NA covariates through its MissingNode children
+    assert torch.equal(torch.isnan(coh), torch.isnan(ordered))
+    scale = float(ordered.abs().max())
+    assert float((coh - ordered).abs().max()) <= 1e-13 * scale
+    assert smooth or not torch.equal(coh, ordered)            # i.e. the switch did select another kernel
+    want = oe.predict(prm, X).reshape(g.nrow, g.ncol)[r0:r1, c0:c1]
+    got = coh.cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
