@@ -946,6 +946,7 @@ __global__ __launch_bounds__(256, 5) void gbm_lutreg_rt_kernel(const double *__r
 // grid first and takes this kernel only where it pays.
 // Block = 16 waves; the chunk's leaf LUT (16 KB) and class words (1.25 KB) are staged in LDS for all of them, double-buffered.
 constexpr int GBC_WAVES = 16;
+constexpr int BAND_ALIGN = 4 * LUT_R;   // row bands of a window are cut at multiples of this many grid rows (a multiple of LUT_R)
 __device__ __forceinline__ double gbc_lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
 typedef float float4v __attribute__((ext_vector_type(4)));
 template <bool K64>
@@ -965,19 +966,23 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // a wave = 64 columns x R adjacent rows (lane = column, a lane's R cells one below the other): the most compact
-    // footprint a wave can have, hence the narrowest rank ranges
-    const int64_t ntiles = (int64_t)((g.nr + R - 1) / R) * tiles_per_row;
+    // footprint a wave can have, hence the narrowest rank ranges.  The tiles are anchored to the GRID (rows at multiples of
+    // R, columns at multiples of 64 of the grid, clipped by the window), so that a cell meets the same companions -- and
+    // its sum the same order -- whether the window is evaluated whole or in row bands cut at multiples of R
+    const int roff = (int)(g.r0 % R), coff = (int)(g.c0 % 64);
+    const int64_t ntiles = (int64_t)((g.nr + roff + R - 1) / R) * tiles_per_row;
     int64_t tile = (int64_t)blockIdx.x * GBC_WAVES + wave;
     const bool live = tile < ntiles;
     if (!live) tile = ntiles - 1;
-    const int trow = (int)(tile / tiles_per_row) * R, tcol = (int)(tile % tiles_per_row) * 64;
+    const int trow = (int)(tile / tiles_per_row) * R - roff, tcol = (int)(tile % tiles_per_row) * 64 - coff;
     int row[R], col[R];
     bool na[R], ok[R];
     double acc[R];
 #pragma unroll
     for (int c = 0; c < R; ++c) {
-        ok[c] = live && tcol + lane < g.nc && trow + c < g.nr;
-        row[c] = min(trow + c, g.nr - 1); col[c] = min(tcol + lane, g.nc - 1);
+        const int rr = trow + c, cc = tcol + lane;
+        ok[c] = live && cc >= 0 && cc < g.nc && rr >= 0 && rr < g.nr;
+        row[c] = min(max(rr, 0), g.nr - 1); col[c] = min(max(cc, 0), g.nc - 1);
         na[c] = false; acc[c] = 0.0;
     }
     // MINUS the ranks (the packed predicate adds them to c), [predictor][cell] in 32 registers that the several-splits
@@ -2132,10 +2137,10 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     // when the rows are long enough that the ragged last tile of a row wastes little (MHS_GBM_NO_ROWTILE: never)
     const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
     const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
-    const int ctpr = (g.nc + 63) / 64;
-    if (in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.93 * (double)ctpr * 64 &&
+    const int ctpr = (int)((g.nc + g.c0 % 64 + 63) / 64);
+    if (in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * 64 &&
         !getenv("MHS_GBM_NO_COHERENT")) {
-        const int64_t ntiles = (int64_t)((g.nr + LUT_R - 1) / LUT_R) * ctpr;
+        const int64_t ntiles = (int64_t)((g.nr + g.r0 % LUT_R + LUT_R - 1) / LUT_R) * ctpr;
         const unsigned cblocks = (unsigned)((ntiles + GBC_WAVES - 1) / GBC_WAVES);
         auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
@@ -2906,8 +2911,9 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
     up[0] = down[0] = r0;
     for (int b = 0, a = 0, d = 0; b < 4; ++b) {
         a += pct[b]; d += pct[3 - b];
-        up[b + 1] = b == 3 ? r1 : r0 + nr * a / 100;
-        down[b + 1] = b == 3 ? r1 : r0 + nr * d / 100;
+        // cut at multiples of BAND_ALIGN grid rows (gbm_coherent_kernel's tiles are anchored to the grid: a band sees whole tiles)
+        up[b + 1] = b == 3 ? r1 : std::min(r1, std::max(r0, (r0 + nr * a / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
+        down[b + 1] = b == 3 ? r1 : std::min(r1, std::max(r0, (r0 + nr * d / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
     }
     StackDev sd;
     sd.data = in - (size_t)r0 * covars->ld * esz; sd.C = covars->n_layers; sd.dtype = covars->dtype;
@@ -2997,6 +3003,10 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         edge.push_back(r1 - ends);
     }
     edge.push_back(r1);
+    // cuts at multiples of BAND_ALIGN grid rows: gbm_coherent_kernel's tiles are anchored there, so a band sees whole tiles
+    // and its cells the same sums as in a resident call
+    for (size_t b = 1; b + 1 < edge.size(); ++b) edge[b] = std::min(r1, std::max(r0, (edge[b] + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
+    edge.erase(std::unique(edge.begin(), edge.end()), edge.end());
     const int64_t nb = (int64_t)edge.size() - 1;
     int64_t rows_per = 0;
     for (int64_t b = 0; b < nb; ++b) rows_per = std::max(rows_per, edge[(size_t)b + 1] - edge[(size_t)b]);

@@ -31,24 +31,33 @@ FIT_RESERVE_MAX_STATIONS = 6000
 FIT_RESERVE_MIN_CELLS = 60_000_000
 
 
+# Bands are cut at multiples of this many grid rows: the coherent gbm kernel sums a cell's trees in an order that depends on
+# the 4-row tile the cell sits in (tiles anchored to the grid), so bands of whole tiles reproduce the one-GPU planes bit for bit.
+BAND_ALIGN = 16
+
+
 def row_bands(nrow: int, world: int, rank0_share: float | None = None):
     """Contiguous row bands, one per rank.  With rank0_share = None the bands are equal
     (ceil(nrow / world) rows, the last ones may be short or empty).  Otherwise rank 0 -- which
     also carries the spline fit -- gets round(rank0_share * nrow) rows (possibly none) and the
-    other ranks take ceil(rest / (world - 1)) rows each (the last ones may be short or empty).
+    other ranks take ceil(rest / (world - 1)) rows each (the last ones may be short or empty); every cut is a multiple
+    of BAND_ALIGN rows.
     Returns (rows of the largest band, [(r0, r1)] per rank).  Every band but rank 0's and the trailing
     ones is exactly `band` rows high, so with rank 0's rows parked at the END of its chunk the all-gather
     of equal chunks lands the whole grid in place (ShardedMltps: no stitching copy)."""
     if world == 1:
         return nrow, [(0, nrow)]
+    even = -(-nrow // world)
+    align = BAND_ALIGN if even >= 4 * BAND_ALIGN else (4 if even >= 8 else 1)     # toy grids: whole 4-row tiles, or no rule
+    up = lambda n: -(-n // align) * align
     if rank0_share is None:
-        band = -(-nrow // world)
+        band = up(even)
         return band, [(min(r * band, nrow), min((r + 1) * band, nrow)) for r in range(world)]
-    n0 = int(round(min(max(rank0_share, 0.0), 1.0) * nrow))
+    n0 = min(nrow, int(round(min(max(rank0_share, 0.0), 1.0) * nrow / align)) * align)
     rest, others = nrow - n0, world - 1
-    h = -(-rest // others)
+    h = up(-(-rest // others))
     if n0 > h:     # rank 0 must not be the tallest band (its rows sit at the end of its chunk)
-        n0 = h = -(-nrow // world)
+        n0 = h = up(-(-nrow // world))
         return h, [(min(r * h, nrow), min((r + 1) * h, nrow)) for r in range(world)]
     bands = [(0, n0)] + [(min(n0 + k * h, nrow), min(n0 + (k + 1) * h, nrow)) for k in range(others)]
     return max(h, n0), bands

@@ -61,7 +61,9 @@ def test_tree_fast_paths_equal_the_generic_walk_bit_for_bit(hip, dtype, monkeypa
     for prm in (params[0], params[4]):
         assert prm["kind"] in ("gbm", "rf")
         m = hip.models.from_param_dict(prm)
+        monkeypatch.setenv("MHS_GBM_NO_COHERENT", "1")          # gbm's default on grids sums in another order: its own test
         fast = hip.predict(stack, m)
+        monkeypatch.delenv("MHS_GBM_NO_COHERENT")
         monkeypatch.setenv("MHS_TREES_GENERIC", "1")
         slow = hip.predict(stack, m)
         monkeypatch.delenv("MHS_TREES_GENERIC")
@@ -127,7 +129,9 @@ def test_weighted_ensemble_window_and_accumulate(hip):
     big = torch.full((g.nrow, 128), -7.0, dtype=torch.float64, device="cuda")
     hip.ensemble_predict(stack, mods, wts, tot, window=win, out=big[11:57, 20:81])
     b = big.cpu().numpy()
-    assert np.array_equal(b[11:57, 20:81], got[11:57, 20:81], equal_nan=True)
+    # (to rounding: gbm sums a cell's trees in an order that depends on which cells share its wave, i.e. on the window)
+    assert np.array_equal(np.isnan(b[11:57, 20:81]), np.isnan(got[11:57, 20:81]))
+    assert np.nanmax(np.abs(b[11:57, 20:81] - got[11:57, 20:81])) <= 1e-13 * np.nanmax(np.abs(got))
     b[11:57, 20:81] = -7.0
     assert (b == -7.0).all()
     # step-by-step accumulate == the fused loop (V73:471/475 order)
@@ -223,7 +227,11 @@ def test_host_pointer_ensemble_pipeline_equals_the_resident_call_bitwise(hip, wh
     win = (37, 4090, 11, 3990)
     sub = np.empty((win[1] - win[0], win[3] - win[2]))
     _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, len(models), 1.3, C.byref(gs), C.byref(st), *win, sub.ctypes.data))
-    assert np.array_equal(np.nan_to_num(sub), np.nan_to_num(want[win[0]:win[1], win[2]:win[3]]))
+    res = hip.ensemble_predict(stack, models, wts, 1.3, window=win).cpu().numpy()
+    assert np.array_equal(np.nan_to_num(sub), np.nan_to_num(res))
+    # against the full plane: the window's clipped edge tiles give gbm another order of its sum -- to rounding
+    cut = want[win[0]:win[1], win[2]:win[3]]
+    assert np.array_equal(np.isnan(sub), np.isnan(cut)) and np.nanmax(np.abs(sub - cut)) <= 1e-13 * np.nanmax(np.abs(cut))
 
 
 @pytest.mark.parametrize("C,trees,n", [(7, 120, 600), (3, 8000, 7000)])

@@ -80,9 +80,10 @@ def _free_port():
 
 def test_row_bands_and_packing():
     band, bands = sharded.row_bands(37, 2)
-    assert band == 19 and bands == [(0, 19), (19, 37)]
+    assert band == 20 and bands == [(0, 20), (20, 37)]          # cuts at multiples of 4 rows (whole gbm tiles per band)
     # rank 0 also carries the fit: it can be given fewer rows, or none
-    assert sharded.row_bands(100, 4, rank0_share=0.1) == (30, [(0, 10), (10, 40), (40, 70), (70, 100)])
+    assert sharded.row_bands(100, 4, rank0_share=0.1) == (32, [(0, 8), (8, 40), (40, 72), (72, 100)])
+    assert sharded.row_bands(10000, 8)[1][1] == (1264, 2528) and sharded.row_bands(10000, 8, rank0_share=0.04)[1][0] == (0, 400)
     assert sharded.row_bands(10, 3, rank0_share=0.0) == (5, [(0, 0), (0, 5), (5, 10)])
     assert sharded.row_bands(10, 1, rank0_share=0.3) == (10, [(0, 10)])
     assert sharded.balanced_rank0_share(8, 1050.0, 130.0) == pytest.approx(0.125 - 130 * 7 / (8 * 1050))

@@ -22,7 +22,7 @@ prm = synth.ensemble_params(X, y, seed, which="b")[0]
 mod = m.models.from_param_dict(prm)
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
-for noise in (0.0, 0.001, 0.01, 0.1):
+for noise in (0.0, 0.01, 0.1, 1.0):
     pl = planes
     if noise > 0:
         pl = planes.clone()
