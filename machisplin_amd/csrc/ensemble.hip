@@ -9,6 +9,7 @@
 // bound tree walks (node records staged chunk-wise in LDS, predictors parked in LDS so a
 // lane can index them by the node's split variable).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -81,6 +82,8 @@ struct mhs_model {
     double *lut_rt = nullptr;            // device, the same leaf values with every tree's levels ordered uniform-first
     int *lut_rt_meta = nullptr;          // device, LUT_RT_DW dwords per tree (gbm_lutreg_rt_kernel)
     unsigned *lut_cls = nullptr;         // device, 5 class words per tree (rank threshold << 3 | predictor; gbm_coherent_kernel)
+    int *gbm_probe = nullptr;            // device, GBC_PROBE_SLOTS x 8 ints: per launch, what the probe blocks summed
+    std::atomic<unsigned> gbm_probe_next{0};
     std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
@@ -860,6 +863,18 @@ constexpr int LUT_RT_DW = 16;
 constexpr int LUT_RT_MAXK = 2;          // more uniform levels than this run as vector levels (their keys exist too)
 typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));   // one record
 
+// Which kernel for this window: PROBE instantiation of gbm_coherent_kernel (below) = its classification alone, on 64 tiles spread
+// over the window and the first 256 trees, summing what the cell loops would cost (in hundredths of what the tree-order
+// kernel spends per tree and wave; measured, profiles/r03_gbm_coherent.txt: 12 fixed, 85 + 26 n for a tree with n >= 1
+// straddling splits).  Both product kernels are then launched and read the four blocks' sums: the one that loses returns
+// at once.  No host synchronisation; smooth rasters run the coherent kernel (4x faster), white noise the tree-order one.
+constexpr int GBC_PROBE_BLOCKS = 4, GBC_PROBE_CHUNKS = 4, GBC_PROBE_SLOTS = 1024;
+__device__ __forceinline__ bool gbc_coherent_pays(const int *__restrict__ probe) {
+    long long cost = 0, cnt = 0;
+#pragma unroll
+    for (int b = 0; b < GBC_PROBE_BLOCKS; ++b) { cost += probe[2 * b]; cnt += probe[2 * b + 1]; }
+    return cost < 83 * cnt;
+}
 template <bool K64>
 __global__ __launch_bounds__(256, 5) void gbm_lutreg_rt_kernel(const double *__restrict__ lut,
                                                             const u64x8 *__restrict__ meta,
@@ -867,10 +882,11 @@ __global__ __launch_bounds__(256, 5) void gbm_lutreg_rt_kernel(const double *__r
                                                             const int *__restrict__ sorted_off, int n_trees_padded,
                                                             double init_f, int p, StackDev s, PredGeom g, int tiles_per_row,
                                                             double weight, int accumulate,
-                                                            double *__restrict__ out) {
+                                                            double *__restrict__ out, const int *__restrict__ probe) {
     constexpr int S = 5;
     static_assert((LUT_CHUNK << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (probe && gbc_coherent_pays(probe)) return;                            // gbm_coherent_kernel takes this window
     double *slut = (double *)smem;                                            // [LUT_CHUNK << S]
     float *coarse = (float *)smem;
     const int lane = threadIdx.x & 63;
@@ -949,13 +965,15 @@ constexpr int GBC_WAVES = 16;
 constexpr int BAND_ALIGN = 4 * LUT_R;   // row bands of a window are cut at multiples of this many grid rows (a multiple of LUT_R)
 __device__ __forceinline__ double gbc_lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
 typedef float float4v __attribute__((ext_vector_type(4)));
-template <bool K64>
+template <bool K64, bool PROBE = false>
 __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__restrict__ lut, const unsigned *__restrict__ cls,
                                                             const void *__restrict__ sorted, const int *__restrict__ sorted_off,
                                                             int n_trees_padded, double init_f, int p, StackDev s, PredGeom g,
                                                             int tiles_per_row, double weight, int accumulate,
-                                                            double *__restrict__ out) {
+                                                            double *__restrict__ out, int *__restrict__ probe) {
     constexpr int S = 5, CH = LUT_CHUNK, CLS_STRIDE = 384, R = LUT_R;
+    if (!PROBE && probe && !gbc_coherent_pays(probe)) return;
+    if (PROBE) n_trees_padded = min(n_trees_padded, GBC_PROBE_CHUNKS * CH);
     static_assert(R == 4, "four cells per lane: two packed predicate instructions");
     static_assert((CH << S) * sizeof(double) >= LUT_COARSE * sizeof(float), "coarse table must fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -972,6 +990,7 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
     const int roff = (int)(g.r0 % R), coff = (int)(g.c0 % 64);
     const int64_t ntiles = (int64_t)((g.nr + roff + R - 1) / R) * tiles_per_row;
     int64_t tile = (int64_t)blockIdx.x * GBC_WAVES + wave;
+    if (PROBE) tile = ntiles >= GBC_PROBE_BLOCKS * GBC_WAVES ? tile * (ntiles / (GBC_PROBE_BLOCKS * GBC_WAVES)) : tile % ntiles;
     const bool live = tile < ntiles;
     if (!live) tile = ntiles - 1;
     const int trow = (int)(tile / tiles_per_row) * R - roff, tcol = (int)(tile % tiles_per_row) * 64 - coff;
@@ -1011,6 +1030,7 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
     if (tid < CH * S) scls[tid] = cls[tid];
     __syncthreads();
     double usum = 0.0;
+    int pcost = 0;
     for (int t0 = 0, buf = 0; t0 < n_trees_padded; t0 += CH, buf ^= 1) {
         const bool more = t0 + CH < n_trees_padded;
         double pre0 = 0.0, pre1 = 0.0;
@@ -1044,6 +1064,16 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
                 for (int l = 0; l < S; ++l) if (nstr == (unsigned)l) { cl[l] = cb; vl[l] = vb; }
                 ++nstr;
             }
+        }
+        if (PROBE) {
+            if (nstr) pcost += 85 + 26 * (int)nstr;
+            if (more) {
+                double *ld = slut + (buf ^ 1) * (CH << S);
+                ld[tid] = pre0; ld[tid + 1024] = pre1;
+                if (tid < CH * S) scls[(buf ^ 1) * CLS_STRIDE + tid] = prec;
+            }
+            __syncthreads();
+            continue;
         }
         const double B = L[known];
         const bool single = nstr == 1u, pair = nstr == 2u, multi = nstr >= 3u;
@@ -1141,6 +1171,18 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
             if (tid < CH * S) scls[(buf ^ 1) * CLS_STRIDE + tid] = prec;
         }
         __syncthreads();
+    }
+    if (PROBE) {
+        int *tot = (int *)srange;                                   // the ranges are done with
+        __syncthreads();
+        if (tid == 0) tot[0] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pcost += __shfl_xor(pcost, o);
+        if (lane == 0) atomicAdd(tot, pcost);
+        __syncthreads();
+        if (tid == 0) { probe[2 * blockIdx.x] = tot[0]; probe[2 * blockIdx.x + 1] = GBC_WAVES * n_trees_padded; }
+        return;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) usum = usum + __shfl_xor(usum, o);
@@ -2138,23 +2180,43 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
     const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
     const int ctpr = (int)((g.nc + g.c0 % 64 + 63) / 64);
-    if (in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * 64 &&
-        !getenv("MHS_GBM_NO_COHERENT")) {
+    const bool rt_ok = in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R);
+    const bool coh_ok = in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * 64 &&
+                        !getenv("MHS_GBM_NO_COHERENT");
+    // Grids: the coherent kernel where neighbouring cells share their trees' outcomes, the tree-order row-tile kernel where
+    // they do not (white-noise rasters) -- decided on the device by a probe of 64 tiles (large windows; small ones are not
+    // worth two more launches and take the coherent kernel; MHS_GBM_FORCE_COHERENT: no probe)
+    int *probe = nullptr;
+    if (coh_ok && rt_ok && total >= (1 << 20) && !getenv("MHS_GBM_FORCE_COHERENT")) {
+        mhs_model *mm = const_cast<mhs_model *>(m);
+        {
+            std::lock_guard<std::mutex> lk(mm->mu);
+            if (!mm->gbm_probe) MHS_HIP(hipMalloc(&mm->gbm_probe, sizeof(int) * 2 * GBC_PROBE_BLOCKS * GBC_PROBE_SLOTS));
+        }
+        probe = mm->gbm_probe + (size_t)(mm->gbm_probe_next.fetch_add(1) % GBC_PROBE_SLOTS) * 2 * GBC_PROBE_BLOCKS;
+    }
+    if (coh_ok) {
         const int64_t ntiles = (int64_t)((g.nr + g.r0 % LUT_R + LUT_R - 1) / LUT_R) * ctpr;
         const unsigned cblocks = (unsigned)((ntiles + GBC_WAVES - 1) / GBC_WAVES);
+        if (probe) {
+            auto pk = key64 ? gbm_coherent_kernel<true, true> : gbm_coherent_kernel<false, true>;
+            MHS_HIP(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
+            hipLaunchKernelGGL(pk, dim3(GBC_PROBE_BLOCKS), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
+                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe);
+        }
         auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
         hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out);
-        return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe);
+        if (!probe) return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
     }
-    if (in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R)) {
+    if (rt_ok) {
         const int64_t ntiles = (int64_t)g.nr * tpr;
         const unsigned rblocks = (unsigned)((ntiles + 3) / 4);
         auto rk = key64 ? gbm_lutreg_rt_kernel<true> : gbm_lutreg_rt_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_bytes));
         hipLaunchKernelGGL(rk, dim3(rblocks), dim3(256), lut_bytes, st, tt.lut_rt, (const u64x8 *)tt.lut_rt_meta, tt.sorted, tt.sorted_off,
-                           m->n_trees_padded, m->init_f, m->p, s, g, tpr, w, acc, out);
+                           m->n_trees_padded, m->init_f, m->p, s, g, tpr, w, acc, out, (const int *)probe);
         return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
     }
     const size_t bytes = in_regs ? lut_bytes : (size_t)m->p * 256 * LUT_R * sizeof(float) + lut_bytes;
@@ -2571,6 +2633,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->lut_rt) (void)hipFree(m->lut_rt);
     if (m->lut_rt_meta) (void)hipFree(m->lut_rt_meta);
     if (m->lut_cls) (void)hipFree(m->lut_cls);
+    if (m->gbm_probe) (void)hipFree(m->gbm_probe);
     if (m->lut_sorted) (void)hipFree(m->lut_sorted);
     if (m->lut_sorted_off) (void)hipFree(m->lut_sorted_off);
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);

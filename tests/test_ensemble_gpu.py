@@ -332,6 +332,38 @@ def test_gbm_coherent_kernel_matches_the_tree_order_kernels_and_the_oracle(hip, 
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
+def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_order_kernel_on_noise(hip, monkeypatch):
+    """Windows of 2^20 cells and more: a probe (the coherent kernel's classification on 64 tiles and 256 trees) prices the
+    coherent kernel against the tree-order row-tile kernel on the device, both are launched and the loser returns at once.
+    Smooth rasters (the BASELINE generator) must come out with the coherent kernel's bits (MHS_GBM_FORCE_COHERENT=1),
+    white noise with the tree-order kernel's (MHS_GBM_NO_COHERENT=1) -- whose plane is the node walk's."""
+    import torch
+    from machisplin_amd import synth
+    g = synth.grid(4000, 4096)        # a 64-column tile spans 1.6 % of the rasters' extent (cfg3: 0.6 %)
+    planes, nodata = synth.covariates(g, 3, 5, dtype="f32")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    noise = planes.clone()
+    for k in range(3):
+        lo, hi = float(planes[k].min()), float(planes[k].max())
+        noise[k] = lo + (hi - lo) * torch.rand(planes[k].shape, device="cuda", generator=gen)
+    xy, rows, cols, uv = synth.stations(g, 1500, 5)
+    cov = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
+    X = np.column_stack([cov, xy])
+    prm = synth.gbm_params(X, synth.response(X, uv, 5), 3, n_trees=300)
+    m = hip.models.from_param_dict(prm)
+    for pl, picked, other in ((planes, "MHS_GBM_FORCE_COHERENT", "MHS_GBM_NO_COHERENT"), (noise, "MHS_GBM_NO_COHERENT", "MHS_GBM_FORCE_COHERENT")):
+        stack = hip.RasterStack(g, pl, nodata)
+        auto = hip.predict(stack, m)
+        monkeypatch.setenv(picked, "1")
+        a = hip.predict(stack, m)
+        monkeypatch.delenv(picked)
+        monkeypatch.setenv(other, "1")
+        b = hip.predict(stack, m)
+        monkeypatch.delenv(other)
+        assert torch.equal(auto, a), (picked, float((auto - a).abs().max()), float((auto - b).abs().max()))
+        assert not torch.equal(auto, b) and float((auto - b).abs().max()) <= 1e-13 * float(b.abs().max())
+
+
 @pytest.mark.parametrize("n,dtype", [(1400, "f32"), (4600, "f64"), (4600, "i16")])
 def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, monkeypatch):
     """The default forest walk (round 3: double-buffered, five walks per lane, hand-scheduled level loop) against the
