@@ -205,41 +205,57 @@ class Workload:
                                                     "12 of them FP64" % ipp},
                              "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "lds_array_busy") if kk in pm}})
             elif k == "gbm":
-                # The kernel evaluates a tree as S wave-wide predicates + one LUT read + one fp64 add and is bound by the rate at
-                # which a SIMD issues VALU instructions (one wave64 instruction per 4 cycles); HBM traffic = the planes and the
-                # plane it accumulates into.  achieved = VALU wave-instructions per second, the count per (cell, tree) taken
-                # from the SQ_INSTS_VALU pass on the torch-free driver (row tiles: ~6.4; lane per cell: 7.1).
+                # Grids: gbm_coherent_kernel (a probe on the device prices it against the tree-order row-tile kernel).  Both are
+                # bound by the rate at which a SIMD issues VALU instructions (one wave64 instruction per 4 cycles); achieved =
+                # VALU wave-instructions per second, the count per (cell, tree) from the SQ_INSTS_VALU pass on the torch-free
+                # driver over the same rasters (tree-order kernel: 6.4; coherent: ~1 on cfg3's rasters -- it depends on them).
                 nt = len(prm["tree_offsets"]) - 1
-                rowtile = self.geom.ncol >= 0.93 * (-(-self.geom.ncol // 256) * 256) and prm["p"] <= 8
-                pm = pmc.get("gbm", {}) if rowtile else {}
-                ipt = pm.get("valu_per_cell_unit", 6.4 if rowtile else 7.1)
+                grid_ok = prm["p"] <= 8 and self.geom.nrow >= 8
+                pm = pmc.get("gbm", {}) if grid_ok else {}
+                probe = None
+                try:
+                    import ctypes as C
+                    from machisplin_amd import _lib
+                    cst, cnt = C.c_int64(0), C.c_int64(0)
+                    mod = self.models[[q["kind"] for q in self.params].index("gbm")]
+                    _lib.check(_lib.lib().mhs_gbm_probe_last(mod._h, C.byref(cst), C.byref(cnt)))
+                    if cnt.value:
+                        probe = {"estimated_cost_vs_tree_order_kernel": 0.12 + cst.value / (100.0 * cnt.value), "coherent_kernel_ran": cst.value < 83 * cnt.value,
+                                 "sample": "%d (tile, tree) pairs of the window classified on the device before the launch" % cnt.value}
+                except Exception:
+                    pass
+                coherent = grid_ok and (probe is None or probe["coherent_kernel_ran"])
+                ipt = pm.get("valu_per_cell_unit", 1.0 if coherent else 6.4)
                 inst = band_cells * nt / 64.0 * ipt
-                ops_ = band_cells * nt * 6.0
-                rows.append({"kernel": "gbm_lutreg_rt_kernel" if rowtile else "gbm_lutreg_kernel", "bound": "valu-issue", "launch_ms": ms,
+                rows.append({"kernel": "gbm_coherent_kernel" if coherent else "gbm_lutreg_rt_kernel", "bound": "valu-issue", "launch_ms": ms,
                              "achieved": inst / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
-                             "work": "%.2f VALU wave-instructions per (cell, tree) / 64 lanes (SQ_INSTS_VALU pass, profiles/r03_members_pmc_*): "
-                                     "4 packed-FP32 predicate instructions per per-cell level and 4 cells, 4 shift-adds, 4 fp64 adds; row-uniform "
-                                     "levels (LAT splits, padding) on the scalar unit; reference walk = %.0f node visits/cell, %.3g visits/s" % (
+                             "work": "%.2f VALU wave-instructions per (cell, tree) / 64 lanes (SQ_INSTS_VALU pass on the same rasters, "
+                                     "profiles/r03_members_pmc_*): per wave of 64 x 4 cells a tree whose splits fall the same way for every cell is "
+                                     "summed once (lane = tree), one or two straddling splits cost a clamp-add and a multiply-add per cell; "
+                                     "reference walk = %.0f node visits/cell, %.3g visits/s" % (
                                          ipt, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
-                             "ops_view": {"achieved": ops_ / ms / 1e9, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ops_ / ms / 1e9 / FP32_PEAK_TFLOPS,
-                                          "work": "6 algorithmic ops per (cell, tree) -- 5 split predicates + 1 fp64 add -- against the packed-FP32 peak "
-                                                  "(rounds 1-2 reported this view as the roofline)"},
+                             "probe": probe,
                              "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "salu_per_valu", "lds_array_busy") if kk in pm}})
             elif k == "rf":
                 # LDS-bound walk: per lane, tree and level one ds_read_b64 (node) + one ds_read_b32 (rank key), 2 LDS-array
                 # cycles each per wave when conflict-free (MI355X guide, LDS table); every lane descends each tree's full depth
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
-                levels = float(self.rf_level_sum())
-                cyc = band_cells * levels / 64.0 * 4.0
+                full = float(self.rf_level_sum())
                 prm = next(p for p in self.params if p["kind"] == "rf")
                 big = int(np.diff(prm["tree_offsets"]).max()) > 4095      # launch_model's choice (ensemble.hip, case K_RF)
                 pm = pmc.get("rf", {}) if not big else {}
+                # a wave leaves a tree when all its walks sit at terminal nodes: the levels really walked come from the
+                # SQ_INSTS_LDS pass on the same rasters (two LDS instructions per walk and level), scaled to this forest's depth
+                walked_share = pm["levels_walked_per_cell"] / pm["levels_full_depth_per_cell"] if "levels_walked_per_cell" in pm else 1.0
+                levels = full * min(1.0, walked_share)
+                cyc = band_cells * levels / 64.0 * 4.0
                 rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
                              "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
-                             "work": "4 conflict-free LDS-array cycles per wave, tree level and walk (ds_read_b64 node + ds_read_b32 key), sum of "
-                                     "tree depths = %d levels/cell; %.0f node visits/cell on the reference's walk, %.3g visits/s" % (
-                                         levels, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "work": "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "
+                                     "%.0f levels/cell walked (a wave of 64 x 5 neighbouring cells leaves a tree at its deepest leaf; SQ_INSTS_LDS pass) "
+                                     "of %d levels/cell of full tree depth; %.0f node visits/cell on the reference's walk, %.3g visits/s" % (
+                                         levels, full, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
                              "pmc": {kk: pm[kk] for kk in ("lds_array_busy", "lds_bank_conflict_share_of_lds_cycles", "lds_cycles_per_lds_instruction",
                                                            "lds_cmd_fifo_full_share", "valu_issue_utilisation") if kk in pm},
@@ -261,7 +277,7 @@ class Workload:
                     pmc_t[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass
-        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("rf", "rf_walk_db_kernel"), ("svr", "svr_kernel"), ("svr", "svr_rt_kernel")):
+        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("gbm", "gbm_coherent_kernel"), ("rf", "rf_walk_db_kernel"), ("svr", "svr_kernel"), ("svr", "svr_rt_kernel")):
             if "hbm_bytes_per_cell_fetch_x2_plus_write" in pmc.get(kind, {}):      # round 3's passes (fresh output plane: no RMW read)
                 pmc_t[kn] = pmc[kind]["hbm_bytes_per_cell_fetch_x2_plus_write"]
         for r in rows:

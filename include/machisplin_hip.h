@@ -277,6 +277,12 @@ MHS_API int mhs_gbm_staged_points(const mhs_model *m, const double *X, int64_t n
  * for the tree ensembles, its tree count (0 otherwise).  Callers size their outputs from it -- mhs_gbm_staged_points
  * writes n * (n_trees / step) values whatever n.trees the R side believes the model has.  Any output pointer may be NULL. */
 MHS_API int mhs_model_info(const mhs_model *m, int *kind, int *p, int64_t *n_trees);
+
+/* Diagnostic: what the most recent gbm evaluation of a window of >= 2^20 cells measured before choosing its kernel (the
+ * probe of gbm_coherent_kernel: 64 tiles x 256 trees classified).  cost / count = the coherent kernel's estimated time per
+ * tree and wave in hundredths of the tree-order kernel's, without its fixed 12; below 83 the coherent kernel ran.  count = 0:
+ * no probe has run (small windows, non-grid calls, or a model that is not gbm).  Synchronises the device. */
+MHS_API int mhs_gbm_probe_last(const mhs_model *m, int64_t *cost, int64_t *count);
 /* res.FINAL in one call (V73:477-482, 501-505, 525-528, 547-549, 586-589, 608-611, 620): the kept members at the
  * n station rows X (as above), out[i] = ((resp_i - pred_1) w_1 + (resp_i - pred_2) w_2 + ...) / wt_total, accumulated
  * member after member; weights = the rounded kept weights, wt_total the unrounded total (at most 8 members). */

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mhs_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mhs_gbm_staged_points": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "mhs_model_info": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mhs_gbm_probe_last": (C.c_int, [_vp, _vp, _vp]),
     "mhs_residual_points": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_scale_add_dev": (C.c_int, [_vp, C.c_double, _vp, _vp, _i64, _vp]),
     "mhs_crop_window": (C.c_int, [C.POINTER(Grid), _vp, _vp]),

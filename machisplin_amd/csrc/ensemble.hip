@@ -3162,6 +3162,19 @@ int mhs_predict_points(const mhs_model *m, const double *X, int64_t n, double *o
     return MHS_OK;
 }
 
+int mhs_gbm_probe_last(const mhs_model *m, int64_t *cost, int64_t *count) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(m && cost && count, "NULL argument");
+    *cost = 0; *count = 0;
+    if (m->kind != K_GBM || !m->gbm_probe || m->gbm_probe_next.load() == 0) return MHS_OK;
+    int h[2 * GBC_PROBE_BLOCKS];
+    MHS_HIP(hipDeviceSynchronize());
+    MHS_HIP(hipMemcpy(h, m->gbm_probe + (size_t)((m->gbm_probe_next.load() - 1) % GBC_PROBE_SLOTS) * 2 * GBC_PROBE_BLOCKS, sizeof(h),
+                      hipMemcpyDeviceToHost));
+    for (int b = 0; b < GBC_PROBE_BLOCKS; ++b) { *cost += h[2 * b]; *count += h[2 * b + 1]; }
+    return MHS_OK;
+}
+
 int mhs_model_info(const mhs_model *m, int *kind, int *p, int64_t *n_trees) {
     MHS_REQUIRE(m != nullptr, "NULL model");
     if (kind) *kind = m->kind;

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3/pmc
 mkdir -p $O
-SIDE=${1:-4000}
+SIDE=${1:-10000}
 i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
          "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -20,8 +20,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in sorted(glob.glob(O + "/pass*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].split("::")[-1]
-        if not any(s in k for s in ("gbm_lutreg", "rf_walk", "svr_kernel")): continue
+        k = row["Kernel_Name"].split("(")[0].split("::")[-1].replace("void ", "")
+        if not any(s in k for s in ("gbm_lutreg", "gbm_coherent", "rf_walk", "svr_kernel", "svr_rt_kernel")): continue
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 res = {k: {c: {"sum": v, "dispatches": cnt[k][c]} for c, v in d.items()} for k, d in agg.items()}

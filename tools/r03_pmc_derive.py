@@ -1,16 +1,22 @@
 """profiles/r03_members_pmc_summary.json (tools/r03_members_pmc.sh: counters summed over the 2 dispatches of each member
 kernel on a side x side grid) -> profiles/r03_members_pmc_derived.json: per-unit instruction counts and pipe utilisations.
-    python tools/r03_pmc_derive.py [side=4000] [gbm_trees=10000] [rf_levels=...] [nsv=...]
+    python tools/r03_pmc_derive.py      (reads profiles/r03_members_pmc_summary.json and r03_members_pmc_units.json)
 Unit conventions (rocprofiler-sdk counter_defs.yaml): SQ_INSTS_* count wave-instructions; a wave64 VALU instruction
 occupies its SIMD for 4 cycles (16 lanes / clk); GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_LDS_IDX_ACTIVE counts
 LDS-array cycles summed over the CUs; FETCH_SIZE / WRITE_SIZE are KB (FETCH_SIZE doubled for gfx950, MI355X guide)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-side = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-units = {"gbm": float(sys.argv[2]) if len(sys.argv) > 2 else 10000.0,       # trees
-         "rf": float(sys.argv[3]) if len(sys.argv) > 3 else None,            # sum of tree depths (levels per cell)
-         "svr": float(sys.argv[4]) if len(sys.argv) > 4 else None}           # support vectors
+U = json.load(open(os.path.join(ROOT, "profiles", "r03_members_pmc_units.json")))      # written by tools/r03_members_pmc.py
+side = int(U["side"])
+units = {"gbm": U.get("gbm"), "rf": U.get("rf"), "svr": U.get("svr")}      # trees; sum of tree depths (levels per cell); support vectors
 S = json.load(open(os.path.join(ROOT, "profiles", "r03_members_pmc_summary.json")))
+# per member the kernel that did the work (gbm launches a probe and two kernels of which one returns at once)
+best = {}
+for k, d in S.items():
+    kind = "gbm" if "gbm" in k else "rf" if "rf_" in k else "svr"
+    t = d["GRBM_GUI_ACTIVE"]["sum"] / d["GRBM_GUI_ACTIVE"]["dispatches"]
+    if kind not in best or t > best[kind][1]: best[kind] = (k, t)
+S = {k: d for k, d in S.items() if any(k == b[0] for b in best.values())}
 cells = float(side) * side
 out = {"grid": [side, side], "note": __doc__.split("\n")[0]}
 for k, d in S.items():
@@ -31,7 +37,10 @@ for k, d in S.items():
         r["valu_per_cell_unit"] = v["SQ_INSTS_VALU"] / per
         r["lds_per_cell_unit"] = v["SQ_INSTS_LDS"] / per
         r["salu_per_cell_unit"] = v["SQ_INSTS_SALU"] / per
-        r["unit"] = {"gbm": "tree", "rf": "tree level", "svr": "support vector"}[kind]
+        r["unit"] = {"gbm": "tree", "rf": "tree level (full depth)", "svr": "support vector"}[kind]
+    if kind == "rf":      # two LDS instructions per walk and level walked (node record, key): the levels the waves really descended
+        r["levels_walked_per_cell"] = v["SQ_INSTS_LDS"] * 64.0 / cells / 2.0
+        r["levels_full_depth_per_cell"] = units["rf"]
     out[k] = r
 json.dump(out, open(os.path.join(ROOT, "profiles", "r03_members_pmc_derived.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
