@@ -1209,6 +1209,7 @@ static size_t gbc_lds_bytes() {
 // lanes of a wave read the same predictor).  R independent walks per lane keep the two dependent
 // LDS reads of a level in flight.
 constexpr int RF_COARSE_BYTES = LUT_COARSE * (int)sizeof(float);
+constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a terminal node's record (rf_walk_loop5x.inc tests for it)
 // LDS accesses by 32-bit byte address (the walk's node addresses come out of LDS data, so no pointer
 // arithmetic may be attached to them); the kernel's dynamic LDS starts at address 0 (no static LDS)
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int max_nodes, int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
     constexpr int R = rf_walks(LOG2R);
     constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1460,6 +1461,61 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
+    // WAVE-UNIFORM PREFIX (round 3; grids).  The wave's 64 R cells are neighbours: near the root of a tree they all go the
+    // same way.  With LANE = TREE (64 trees at a time, node records read from global memory) every tree is descended for as
+    // long as the split threshold lies outside the wave's [min, max] rank of the split's predictor; where that stops -- at
+    // a terminal node, then the whole wave shares the tree's prediction, or at the first split that separates the wave's
+    // cells -- is where the cell walks of the tree loop below START (entry node in the low 16 bits, levels descended in
+    // bits 16..30, bit 31 = terminal).  The cells end at the same nodes as from the root: identical planes.
+    constexpr int EB = 16;                                         // batches of 64 trees held in registers
+    unsigned entry[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) entry[b] = 0u;
+    if (prefix && n_trees <= 64 * EB) {
+        const int lane = threadIdx.x & 63;
+        int mn[12], mx[12];                                        // R = 5 walks: p <= 12 (one key byte)
+#pragma unroll
+        for (int v = 0; v < 12; ++v) {
+            mn[v] = 0x7fffffff; mx[v] = -1;
+            if (v < p) {
+                int a = 0x7fffffff, b = -1;
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+                    if (!na[c]) {
+                        const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
+                        a = min(a, rk); b = max(b, rk);
+                    }
+#pragma unroll
+                for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
+                mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            if (b * 64 < n_trees) {
+                const int t = b * 64 + lane;
+                bool walking = t < n_trees;
+                const int o = tree_off[min(t, n_trees - 1)];
+                unsigned nd = 0u, plen = 0u, term = 0u;
+                while (__builtin_amdgcn_ballot_w64(walking)) {
+                    if (walking) {
+                        const uint2 rec = gnodes[o + (int)nd];
+                        if (rec.x == RF_LEAF_WORD) { term = 1u; walking = false; }
+                        else {
+                            const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
+                            int lo = mn[0], hi = mx[0];
+#pragma unroll
+                            for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
+                            if (lo > j) { nd = (rec.y >> 16) >> 3; ++plen; }            // every cell's rank > j: right
+                            else if (hi <= j) { nd = (rec.y & 0xFFFFu) >> 3; ++plen; }   // every cell's rank <= j: left
+                            else walking = false;
+                        }
+                    }
+                }
+                entry[b] = nd | (plen << 16) | (term << 31);
+            }
+        }
+    }
     __syncthreads();                                               // coarse table no longer needed: buffer 0 may be written
     {
         const int o = tree_off[0], cnt = tree_off[1] - o;
@@ -1468,30 +1524,57 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     __syncthreads();
     // tree t's scalars (offsets, depth) are fetched one iteration ahead: an s_load at the top of every tree
     // would stall all 16 waves for its latency, 500 times
-    int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1;
+    int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1, o3 = n_trees > 2 ? tree_off[3] : o2;
     int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
     int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
+    unsigned ecur = 0u;
+    // The node records travel global -> registers -> LDS one tree AND one iteration ahead: tree t + 2 is requested at the top
+    // of iteration t and parked at the top of iteration t + 1 (its buffer, tree t's, is free after the barrier that ends
+    // iteration t), so the request has a whole iteration to arrive even when the walks are short (most of a forest's trees
+    // end, for a wave of neighbouring cells, at or near the entry node).
+    uint2 pn[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        const int e = threadIdx.x + q * 1024;
+        if (n_trees > 1 && e < o2 - o1) pn[q] = gnodes[o1 + e];
+    }
     for (int t = 0; t < n_trees; ++t) {
+        if ((t & 63) == 0) {
+            ecur = 0u;
+#pragma unroll
+            for (int b = 0; b < EB; ++b) if ((t >> 6) == b) ecur = entry[b];
+        }
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
         const unsigned boff = (t & 1) ? buf_bytes : 0u, noff = (t & 1) ? 0u : buf_bytes;
-        const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0;
-        const int o3 = t + 3 <= n_trees ? tree_off[t + 3] : o2;        // consumed two iterations from now
+        const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0, cnt2 = t + 2 < n_trees ? o3 - o2 : 0;
+        const int o4 = t + 4 <= n_trees ? tree_off[t + 4] : o3;        // consumed two iterations from now
         const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
         const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
-        uint2 pn[PF];
+        {   // park tree t + 1 in the other buffer, child addresses moved there; then request tree t + 2
+            const unsigned reloc = noff * 0x10001u;
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            if (e < cnt1) pn[q] = gnodes[o1 + e];
+            for (int q = 0; q < PF; ++q) {
+                const int e = threadIdx.x + q * 1024;
+                if (e < cnt1) { uint2 nd = pn[q]; nd.y += reloc; *(uint2 *)(smem + noff + (unsigned)e * 8u) = nd; }
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = threadIdx.x + q * 1024;
+                if (e < cnt2) pn[q] = gnodes[o2 + e];
+            }
         }
+        // the walks start at the wave's entry node of this tree and descend what is left of the tree's depth
+        const int plen = (int)((ent >> 16) & 0x7FFFu);
+        const int lev = (ent >> 31) ? 0 : levels - plen, shal = max(shallow - plen, 0);
 #pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = boff;
+        for (int c = 0; c < R; ++c) node[c] = boff + ((ent & 0xFFFFu) << 3);
         if constexpr (R == 5 && HAND) {
             // five walks: the level loop by hand (tools/gen_rf_walk_asm.py) -- the walks rotated so that the two wait states an
             // SDWA select needs after v_cmp's write of VCC are the previous walk's next node read and the next walk's key wait
-            // levels - 1 of them with a next level: the first min(shallowest leaf, levels - 1) untested, the others leave the
+            // lev - 1 of them with a next level: the first min(shallowest leaf, lev - 1) untested, the others leave the
             // loop when every walk of the wave has reached a terminal node; then the last level
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
+            int c0 = min(shal, lev - 1), cnt = lev - 1 - c0;
+            if (lev > 0)
                 asm volatile(
 #include "rf_walk_loop5x.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
@@ -1500,8 +1583,8 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
         } else if constexpr (R == 4 && HAND) {
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
+            int c0 = min(shal, lev - 1), cnt = lev - 1 - c0;
+            if (lev > 0)
                 asm volatile(
 #include "rf_walk_loop4x.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
@@ -1509,7 +1592,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
                       "v115", "v116", "v117", "v118", "v120");
         } else
-        for (int l = 0; l < levels; ++l) {
+        for (int l = 0; l < lev; ++l) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 const uint2v nd = lds_u2(node[c]);
@@ -1526,15 +1609,8 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
             acc[c] = acc[c] + pending[c];
             pending[c] = glval[o + (int)((node[c] - boff) >> 3)];
         }
-        // park the next tree in the other buffer, child addresses moved there
-        const unsigned reloc = noff * 0x10001u;
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            if (e < cnt1) { uint2 nd = pn[q]; nd.y += reloc; *(uint2 *)(smem + noff + (unsigned)e * 8u) = nd; }
-        }
-        __syncthreads();
-        o = o1; o1 = o2; o2 = o3;
+        __syncthreads();                                           // every wave has left tree t; tree t + 1 is parked
+        o = o1; o1 = o2; o2 = o3; o3 = o4;
         levels = levels1; levels1 = levels2;
         shallow = shallow1; shallow1 = shallow2;
     }
@@ -2036,7 +2112,6 @@ static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64
 }
 
 enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomForest node records (build_rf_nodes_t)
-constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a terminal node's record (rf_walk_loop5x.inc tests for it)
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
 struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
@@ -2424,7 +2499,8 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
                              : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
         MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
         hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips);
+                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips,
+                           strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
         return MHS_OK;
     }
     const size_t bytes = rf_walk_lds(m, log2r, big);

@@ -364,25 +364,26 @@ def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_orde
         assert not torch.equal(auto, b) and float((auto - b).abs().max()) <= 1e-13 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("n,dtype", [(1400, "f32"), (4600, "f64"), (4600, "i16")])
-def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, monkeypatch):
+@pytest.mark.parametrize("n,dtype,ncol", [(1400, "f32", 257), (4600, "f64", 257), (4600, "i16", 257), (1400, "f32", 1100)])
+def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, monkeypatch):
     """The default forest walk (round 3: double-buffered, five walks per lane, hand-scheduled level loop) against the
     compiler's loop, the four-walk forms, the barrier-free triple-buffered kernel (MHS_RF_TRIPLE_BUFFER: three buffers, LDS
     counters between the waves, hand-scheduled loops too), round 2's single-buffer forms and the node walk: bit-identical
     planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).
     The default also walks a lane's five cells on five ADJACENT rows (123 rows: a ragged last strip) and lets a wave leave a
     tree once all its walks sit at terminal nodes (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: round 2's cell order / every tree
-    to its full depth).  Seven trees: a count that is a multiple neither of the two nor of the three buffers.  (Two more restructurings were
+    to its full depth), and starts a tree's walks where the wave's cells first part ways (MHS_RF_NO_PREFIX: at the root).  Seven trees: a count that is a multiple neither of the two nor of the three buffers.  (Two more restructurings were
     measured in round 3 and removed again, see DESIGN.md section 4 and profiles/r03_tree_variants.txt.)"""
     import torch
     from machisplin_amd import synth
-    g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=257, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=ncol, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
     prm = synth.rf_params(Xs, ys, 9, n_trees=7)
     nodes = np.diff(prm["tree_offsets"]).max()
     assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
     m = hip.models.from_param_dict(prm)
     fast = hip.predict(stack, m)
     for envs in ({"MHS_RF_COMPILER_LOOP": "1"}, {"MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_COMPILER_LOOP": "1"},
+                 {"MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_NO_PREFIX": "1", "MHS_RF_FOUR_WALKS": "1"},
                  {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"},

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03_final
 mkdir -p $O
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q --durations=5 > $O/gputest_full.log 2>&1; tail -4 $O/gputest_full.log | cut -c1-160
+timeout 1500 python -m pytest tests -m gpu -q --durations=5 > $O/gputest_full.log 2>&1; tail -4 $O/gputest_full.log | cut -c1-160
 timeout 900 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench_cfg3_n1.err; tail -c 300 $O/bench_cfg3_n1.json; echo
 timeout 900 python bench.py --tps-mode tiled --no-cpu-baseline > $O/bench_cfg3_n1_tiled_tps.json 2>/dev/null
 timeout 600 python bench.py --workload cfg2 > $O/bench_cfg2_n1.json 2>/dev/null
@@ -18,6 +18,7 @@ head -8 $O/cfg3_rocprofv3_kernel_stats.csv | cut -c1-150
 find /tmp/kst4 -name "*kernel_stats.csv" -exec cp {} $O/cfg4_rocprofv3_kernel_stats.csv \;
 timeout 600 python tools/fit_speed.py 500 2000 5000 10000 20000 2>&1 | grep -v "^/opt" > $O/fit_speed.txt; cat $O/fit_speed.txt
 timeout 900 python tools/r03_tree_variants.py 8000 3 2>&1 | grep -v "^/opt" > $O/tree_variants.txt; cat $O/tree_variants.txt
+timeout 900 python tools/r03_tree_variants.py 6000 2 cfg5 2>&1 | grep -v "^/opt" > $O/tree_variants_cfg5.txt; cat $O/tree_variants_cfg5.txt
 timeout 900 python tools/r03_host_abi.py 10000 0 1 2>&1 | grep -v "^/opt" > $O/host_abi.txt; cat $O/host_abi.txt
 timeout 900 python tools/r03_host_abi.py 20000 0 1 2>&1 | grep -v "^/opt" > $O/host_abi_20000.txt; cat $O/host_abi_20000.txt
 for f in $O/bench_*.json; do python - "$f" <<'PY'

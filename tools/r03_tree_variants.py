@@ -41,7 +41,8 @@ cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, early e
 for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
-                       ("rf", [("5 walks on adjacent rows, a wave leaves a tree at its deepest leaf (default)", {}),
+                       ("rf", [("walks start where the wave's cells part ways, 5 walks on adjacent rows, early exit (default)", {}),
+                               ("walks start at the root, 5 walks on adjacent rows, early exit", {"MHS_RF_NO_PREFIX": "1"}),
                                ("5 walks on adjacent rows, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
                                ("5 walks a fifth of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
                                ("5 walks a fifth of the grid apart, full depth (round 3 before the early exit)", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}),
