@@ -1422,6 +1422,60 @@ static int64_t rf_lane_count(const PredGeom &g, int R, int strips) {      // lan
 }
 static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R && !getenv("MHS_RF_FAR_WALKS"); }
 
+// WAVE-UNIFORM PREFIX of the forest walks (round 3; grids).  With LANE = TREE (64 trees at a time, node records read from
+// global memory) every tree is descended for as long as the split threshold lies outside the wave's [min, max] rank of
+// the split's predictor (the ranks are the keys already parked in LDS).  entry[b], lane l = tree 64 b + l: entry node in
+// the low 16 bits, levels descended in bits 16..30, bit 31 = the entry node is terminal.
+constexpr int RF_ENTRY_BATCHES = 16;                                // batches of 64 trees held in registers
+template <int R>
+__device__ __forceinline__ void rf_prefix_entries(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
+                                                  const int *__restrict__ tree_off, int n_trees, int p, const char *smem,
+                                                  unsigned lane_base, const bool (&na)[R]) {
+    const int lane = threadIdx.x & 63;
+    int mn[12], mx[12];                                            // p <= 12 (one key byte)
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {
+        mn[v] = 0x7fffffff; mx[v] = -1;
+        if (v < p) {
+            int a = 0x7fffffff, b = -1;
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+                if (!na[c]) {
+                    const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
+                    a = min(a, rk); b = max(b, rk);
+                }
+#pragma unroll
+            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
+            mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
+        if (b * 64 < n_trees) {
+            const int t = b * 64 + lane;
+            bool walking = t < n_trees;
+            const int o = tree_off[min(t, n_trees - 1)];
+            unsigned nd = 0u, plen = 0u, term = 0u;
+            while (__builtin_amdgcn_ballot_w64(walking)) {
+                if (walking) {
+                    const uint2 rec = gnodes[o + (int)nd];
+                    if (rec.x == RF_LEAF_WORD) { term = 1u; walking = false; }
+                    else {
+                        const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
+                        int lo = mn[0], hi = mx[0];
+#pragma unroll
+                        for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
+                        if (lo > j) { nd = (rec.y >> 16) >> 3; ++plen; }            // every cell's rank > j: right
+                        else if (hi <= j) { nd = (rec.y & 0xFFFFu) >> 3; ++plen; }   // every cell's rank <= j: left
+                        else walking = false;
+                    }
+                }
+            }
+            entry[b] = nd | (plen << 16) | (term << 31);
+        }
+    }
+}
+
 // Double-buffered form for trees of up to 4095 nodes (two buffers stay within the 16-bit child addresses): the
 // next tree travels global -> registers -> the other LDS buffer WHILE this one is walked, the node predictions are
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
@@ -1461,61 +1515,15 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
-    // WAVE-UNIFORM PREFIX (round 3; grids).  The wave's 64 R cells are neighbours: near the root of a tree they all go the
-    // same way.  With LANE = TREE (64 trees at a time, node records read from global memory) every tree is descended for as
-    // long as the split threshold lies outside the wave's [min, max] rank of the split's predictor; where that stops -- at
-    // a terminal node, then the whole wave shares the tree's prediction, or at the first split that separates the wave's
-    // cells -- is where the cell walks of the tree loop below START (entry node in the low 16 bits, levels descended in
-    // bits 16..30, bit 31 = terminal).  The cells end at the same nodes as from the root: identical planes.
-    constexpr int EB = 16;                                         // batches of 64 trees held in registers
+    // The wave's 64 R cells are neighbours: near the root of a tree they all go the same way.  Where that stops -- at a
+    // terminal node, then the whole wave shares the tree's prediction, or at the first split that separates the wave's cells
+    // -- is where the cell walks of the tree loop below START (rf_prefix_entries).  The cells end at the same nodes as
+    // from the root: identical planes.
+    constexpr int EB = RF_ENTRY_BATCHES;
     unsigned entry[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) entry[b] = 0u;
-    if (prefix && n_trees <= 64 * EB) {
-        const int lane = threadIdx.x & 63;
-        int mn[12], mx[12];                                        // R = 5 walks: p <= 12 (one key byte)
-#pragma unroll
-        for (int v = 0; v < 12; ++v) {
-            mn[v] = 0x7fffffff; mx[v] = -1;
-            if (v < p) {
-                int a = 0x7fffffff, b = -1;
-#pragma unroll
-                for (int c = 0; c < R; ++c)
-                    if (!na[c]) {
-                        const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
-                        a = min(a, rk); b = max(b, rk);
-                    }
-#pragma unroll
-                for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-                mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            if (b * 64 < n_trees) {
-                const int t = b * 64 + lane;
-                bool walking = t < n_trees;
-                const int o = tree_off[min(t, n_trees - 1)];
-                unsigned nd = 0u, plen = 0u, term = 0u;
-                while (__builtin_amdgcn_ballot_w64(walking)) {
-                    if (walking) {
-                        const uint2 rec = gnodes[o + (int)nd];
-                        if (rec.x == RF_LEAF_WORD) { term = 1u; walking = false; }
-                        else {
-                            const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
-                            int lo = mn[0], hi = mx[0];
-#pragma unroll
-                            for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
-                            if (lo > j) { nd = (rec.y >> 16) >> 3; ++plen; }            // every cell's rank > j: right
-                            else if (hi <= j) { nd = (rec.y & 0xFFFFu) >> 3; ++plen; }   // every cell's rank <= j: left
-                            else walking = false;
-                        }
-                    }
-                }
-                entry[b] = nd | (plen << 16) | (term << 31);
-            }
-        }
-    }
+    if (prefix && n_trees <= 64 * EB) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
     __syncthreads();                                               // coarse table no longer needed: buffer 0 may be written
     {
         const int o = tree_off[0], cnt = tree_off[1] - o;
@@ -1655,7 +1663,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
     constexpr int R = rf_walks(LOG2R);
     constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // node records per thread in flight
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
@@ -1680,6 +1688,11 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
+    unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave (rf_prefix_entries)
+#pragma unroll
+    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
+    if (prefix && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
+    unsigned ecur = 0u;
     __syncthreads();                                               // coarse table no longer needed
     for (int t = 0; t < 2 && t < n_trees; ++t) {
         const int o = tree_off[t], cnt = tree_off[t + 1] - o;
@@ -1689,7 +1702,14 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
     __syncthreads();
     auto step = [&](auto slot_tag, const int t) {
         constexpr int SLOT = decltype(slot_tag)::value, SLOT2 = (SLOT + 2) % 3;
-        const int o = tree_off[t], levels = depth[t], shallow = dmin ? dmin[t] : levels;
+        if ((t & 63) == 0) {
+            ecur = 0u;
+#pragma unroll
+            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
+        }
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
+        const int plen = (int)((ent >> 16) & 0x7FFFu);
+        const int o = tree_off[t], levels = (ent >> 31) ? 0 : depth[t] - plen, shallow = max((dmin ? dmin[t] : depth[t]) - plen, 0);
         const bool more = t + 2 < n_trees;
         const int o2 = more ? tree_off[t + 2] : 0, cnt2 = more ? tree_off[t + 3] - o2 : 0;
         uint2 pn[PF];
@@ -1701,7 +1721,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
         lds_wait_ge(CNT + 4u * SLOT, 16u * (unsigned)(t / 3 + 1));      // tree t is parked
         unsigned node[R];
 #pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = 0u;
+        for (int c = 0; c < R; ++c) node[c] = (ent & 0xFFFFu) << 3;
         if constexpr (R == 4) {
             int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
             if (levels > 0)
@@ -2330,11 +2350,13 @@ static int rf_walk_db_log2r(const mhs_model *m) {
 
 // triple-buffered kernel: buffer stride (bytes, a template parameter) and walks per lane, false = does not apply
 static bool rf_walk_tb_config(const mhs_model *m, int *log2r, int *stride) {
-    if (!getenv("MHS_RF_TRIPLE_BUFFER")) return false;      // opt-in: as fast as two buffers + five walks (169 ms), no faster
+    // the default where it fits (waves that start deep in a tree, or skip it, must not wait for the one wave that walks
+    // it from near the root: 125 -> 97 ms per 1e8 cells with four walks); MHS_RF_DOUBLE_BUFFER etc.: the other kernels
+    if (getenv("MHS_RF_DOUBLE_BUFFER") || getenv("MHS_RF_SINGLE_BUFFER") || getenv("MHS_RF_COMPILER_LOOP")) return false;
     const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
-    for (int st : {16384, 24576}) {
+    for (int st : {16384, 24576, 25600}) {
         if ((size_t)m->rf_max_nodes * 8 > (size_t)st) continue;
-        for (int l2 = five ? 3 : 2; l2 >= 2; --l2)
+        for (int l2 = five && st != 25600 ? 3 : 2; l2 >= 2; --l2)      // the widest stride is instantiated for four walks only
             if ((m->p * rf_walks(l2) * 4) <= 255 &&
                 (size_t)3 * st + 32 + (size_t)1024 * (((size_t)m->p * rf_walks(l2)) | 1) * 4 <= LDS_MAX) {
                 *log2r = l2; *stride = st;
@@ -2468,11 +2490,13 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
 #define MHS_TB(L2, ST) (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>)
         auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
-                                     : (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576));
+                : tb_stride == 24576 ? (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576))
+                                     : MHS_TB(2, 25600);
 #undef MHS_TB
         MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
         hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips);
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips,
+                           strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
         return MHS_OK;
     }
     if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane

@@ -366,9 +366,9 @@ def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_orde
 
 @pytest.mark.parametrize("n,dtype,ncol", [(1400, "f32", 257), (4600, "f64", 257), (4600, "i16", 257), (1400, "f32", 1100)])
 def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, monkeypatch):
-    """The default forest walk (round 3: double-buffered, five walks per lane, hand-scheduled level loop) against the
-    compiler's loop, the four-walk forms, the barrier-free triple-buffered kernel (MHS_RF_TRIPLE_BUFFER: three buffers, LDS
-    counters between the waves, hand-scheduled loops too), round 2's single-buffer forms and the node walk: bit-identical
+    """The default forest walk (round 3: the barrier-free triple-buffered kernel -- three buffers, LDS counters between the
+    waves, hand-scheduled level loops -- where three trees and the keys fit, else the double-buffered one, MHS_RF_DOUBLE_BUFFER)
+    against the compiler's loop, the four-walk forms, round 2's single-buffer forms and the node walk: bit-identical
     planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).
     The default also walks a lane's five cells on five ADJACENT rows (123 rows: a ragged last strip) and lets a wave leave a
     tree once all its walks sit at terminal nodes (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: round 2's cell order / every tree
@@ -389,6 +389,8 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, monkeyp
                  {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
+                 {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"},
+                 {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():

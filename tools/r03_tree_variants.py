@@ -41,15 +41,13 @@ cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, early e
 for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
-                       ("rf", [("walks start where the wave's cells part ways, 5 walks on adjacent rows, early exit (default)", {}),
-                               ("walks start at the root, 5 walks on adjacent rows, early exit", {"MHS_RF_NO_PREFIX": "1"}),
-                               ("5 walks on adjacent rows, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
-                               ("5 walks a fifth of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
-                               ("5 walks a fifth of the grid apart, full depth (round 3 before the early exit)", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}),
-                               ("4 walks on adjacent rows, early exit", {"MHS_RF_FOUR_WALKS": "1"}),
+                       ("rf", [("three buffers, no barrier; walks on adjacent rows start where the wave's cells part ways and end at its deepest leaf (default)", {}),
+                               ("two buffers + a barrier per tree, 5 walks, otherwise the same", {"MHS_RF_DOUBLE_BUFFER": "1"}),
+                               ("two buffers, walks start at the root", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_NO_PREFIX": "1"}),
+                               ("two buffers, walks start at the root, every tree to its full depth", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_NO_PREFIX": "1", "MHS_RF_FULL_DEPTH": "1"}),
+                               ("the same with a lane's walks a fifth of the grid apart (round 3 before these changes)", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}),
+                               ("two buffers, 4 walks, prefix, early exit", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}),
                                ("double-buffered, 5 walks, the compiler's loop (round 2)", {"MHS_RF_COMPILER_LOOP": "1"}),
-                               ("triple-buffered, no barrier", {"MHS_RF_TRIPLE_BUFFER": "1"}),
-                               ("double-buffered, 4 walks", {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}),
                                ("split-node records, one buffer, 4 walks", {"MHS_RF_FORCE_COMPACT": "1"})])):
     ref = None
     for name, env in variants:
