@@ -4,6 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03_final
 mkdir -p $O
 export TMPDIR=/tmp
+bash tools/r03_members_pmc.sh 10000 brv > $O/members_pmc.log 2>&1; cp gpurun_out/r3/pmc/summary.json $O/members_pmc_summary.json; cp gpurun_out/r3/pmc/units.json $O/members_pmc_units.json; cp gpurun_out/r3/pmc/summary.json profiles/r03_members_pmc_summary.json; cp gpurun_out/r3/pmc/units.json profiles/r03_members_pmc_units.json; python tools/r03_pmc_derive.py > /dev/null; cp profiles/r03_members_pmc_derived.json $O/members_pmc_derived.json
 timeout 1500 python -m pytest tests -m gpu -q --durations=5 > $O/gputest_full.log 2>&1; tail -4 $O/gputest_full.log | cut -c1-160
 timeout 900 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench_cfg3_n1.err; tail -c 300 $O/bench_cfg3_n1.json; echo
 timeout 900 python bench.py --tps-mode tiled --no-cpu-baseline > $O/bench_cfg3_n1_tiled_tps.json 2>/dev/null
@@ -19,6 +20,7 @@ find /tmp/kst4 -name "*kernel_stats.csv" -exec cp {} $O/cfg4_rocprofv3_kernel_st
 timeout 600 python tools/fit_speed.py 500 2000 5000 10000 20000 2>&1 | grep -v "^/opt" > $O/fit_speed.txt; cat $O/fit_speed.txt
 timeout 900 python tools/r03_tree_variants.py 8000 3 2>&1 | grep -v "^/opt" > $O/tree_variants.txt; cat $O/tree_variants.txt
 timeout 900 python tools/r03_tree_variants.py 6000 2 cfg5 2>&1 | grep -v "^/opt" > $O/tree_variants_cfg5.txt; cat $O/tree_variants_cfg5.txt
+timeout 900 python tools/r03_gbm_coherent.py 8000 3 2>&1 | grep -v "^/opt" > $O/gbm_coherent.txt; cat $O/gbm_coherent.txt
 timeout 900 python tools/r03_host_abi.py 10000 0 1 2>&1 | grep -v "^/opt" > $O/host_abi.txt; cat $O/host_abi.txt
 timeout 900 python tools/r03_host_abi.py 20000 0 1 2>&1 | grep -v "^/opt" > $O/host_abi_20000.txt; cat $O/host_abi_20000.txt
 for f in $O/bench_*.json; do python - "$f" <<'PY'
