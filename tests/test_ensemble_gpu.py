@@ -364,8 +364,9 @@ def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_orde
         assert not torch.equal(auto, b) and float((auto - b).abs().max()) <= 1e-13 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("n,dtype,ncol", [(1400, "f32", 257), (4600, "f64", 257), (4600, "i16", 257), (1400, "f32", 1100)])
-def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, monkeypatch):
+@pytest.mark.parametrize("n,dtype,ncol,trees", [(1400, "f32", 257, 7), (4600, "f64", 257, 7), (4600, "i16", 257, 7), (1400, "f32", 1100, 7),
+                                                (700, "f32", 257, 130), (300, "f32", 257, 520)])
+def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, monkeypatch):
     """The default forest walk (round 3: the barrier-free triple-buffered kernel -- three buffers, LDS counters between the
     waves, hand-scheduled level loops -- where three trees and the keys fit, else the double-buffered one, MHS_RF_DOUBLE_BUFFER)
     against the compiler's loop, the four-walk forms, round 2's single-buffer forms and the node walk: bit-identical
@@ -377,7 +378,7 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, monkeyp
     import torch
     from machisplin_amd import synth
     g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=ncol, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
-    prm = synth.rf_params(Xs, ys, 9, n_trees=7)
+    prm = synth.rf_params(Xs, ys, 9, n_trees=trees)     # 130: the entry registers are reloaded every 64 trees; 520: more than they hold
     nodes = np.diff(prm["tree_offsets"]).max()
     assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
     m = hip.models.from_param_dict(prm)
