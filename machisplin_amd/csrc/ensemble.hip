@@ -1782,6 +1782,56 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
     }
 }
 
+// rf_prefix_entries for the COMPACT records (split nodes only; a state is a split record's byte address or D + the index of a
+// terminal node, D = 8 x the tree's splits): entry state in the low 16 bits, levels descended above them.
+template <int R>
+__device__ __forceinline__ void rf_prefix_entries_compact(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
+                                                          const int *__restrict__ coff, int n_trees, int p, const char *smem,
+                                                          unsigned lane_base, const bool (&na)[R]) {
+    const int lane = threadIdx.x & 63;
+    int mn[12], mx[12];
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {
+        mn[v] = 0x7fffffff; mx[v] = -1;
+        if (v < p) {
+            int a = 0x7fffffff, b = -1;
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+                if (!na[c]) {
+                    const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
+                    a = min(a, rk); b = max(b, rk);
+                }
+#pragma unroll
+            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
+            mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
+        if (b * 64 < n_trees) {
+            const int t = min(b * 64 + lane, n_trees - 1);
+            const int cb = coff[t];
+            const unsigned D = (unsigned)(coff[t + 1] - cb - 1) * 8u;
+            unsigned state = 0u, plen = 0u;
+            bool walking = b * 64 + lane < n_trees && state < D;
+            while (__builtin_amdgcn_ballot_w64(walking)) {
+                if (walking) {
+                    const uint2 rec = gnodes[cb + (int)(state >> 3)];
+                    const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
+                    int lo = mn[0], hi = mx[0];
+#pragma unroll
+                    for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
+                    if (lo > j) { state = rec.y >> 16; ++plen; }
+                    else if (hi <= j) { state = rec.y & 0xFFFFu; ++plen; }
+                    else walking = false;
+                    if (state >= D) walking = false;
+                }
+            }
+            entry[b] = state | (plen << 16);
+        }
+    }
+}
+
 // COMPACT form for trees beyond the double-buffered kernel's 4 095 nodes (a 20 000-station forest: ~12 000 nodes per
 // tree).  Half of a tree's nodes are terminals, which the walk never needs to READ -- it only has to remember which one
 // it reached.  LDS holds the records of the split nodes alone plus one all-zero record at byte address D = 8 * splits
@@ -1800,7 +1850,7 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
                                                                const int *__restrict__ depth, const void *__restrict__ sorted,
                                                                const int *__restrict__ sorted_off, int n_trees, int cmax, int p,
                                                                StackDev s, PredGeom g, double weight, int accumulate,
-                                                               double *__restrict__ out, const int *__restrict__ dmin, int strips) {
+                                                               double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned nt = blockDim.x;
@@ -1824,6 +1874,11 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
     }
+    unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave
+#pragma unroll
+    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
+    if (prefix && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries_compact<R>(entry, gnodes, coff, n_trees, p, smem, lane_base, na);
+    unsigned ecur = 0u;
     __syncthreads();                                               // coarse table no longer needed
     {
         const int o = coff[0], cnt = coff[1] - o;
@@ -1848,8 +1903,16 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
             const int e = (int)threadIdx.x + q * (int)nt;
             if (e < cnt1) pn[q] = gnodes[c1 + e];
         }
+        if ((t & 63) == 0) {
+            ecur = 0u;
 #pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = 0u;
+            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
+        }
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
+        const int plen = (int)(ent >> 16);
+        const int lev = (ent & 0xFFFFu) >= D ? 0 : levels - plen, shal = min(max(shallow - plen, 0), lev);
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
         auto level = [&]() {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -1865,8 +1928,8 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
         };
         // no state is terminal above the tree's shallowest leaf; from there on the wave leaves the tree as soon as every
         // state of every lane is a terminal code (>= D)
-        for (int l = 0; l < shallow; ++l) level();
-        for (int l = shallow; l < levels; ++l) {
+        for (int l = 0; l < shal; ++l) level();
+        for (int l = shal; l < lev; ++l) {
             const unsigned lowest = min(min(node[0], node[1]), min(node[2], node[3]));
             if (!__builtin_amdgcn_ballot_w64(lowest < D)) break;
             level();
@@ -2562,7 +2625,8 @@ static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGe
                  : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
-                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips);
+                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips,
+                       strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
     return MHS_OK;
 }
 

@@ -393,7 +393,7 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
                  {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"},
                  {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FULL_DEPTH": "1"},
-                 {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
+                 {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():
             monkeypatch.setenv(e, v)
         other = hip.predict(stack, m)

@@ -34,9 +34,10 @@ def run(kind, env):
     for k in env: del os.environ[k]
     return best, out.clone()
 
-cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, early exit (default)", {}),
-                         ("same, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
-                         ("same, 4 walks a quarter of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
+cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, prefix, early exit (default)", {}),
+                         ("same, walks start at the root", {"MHS_RF_NO_PREFIX": "1"}),
+                         ("walks at the root, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
+                         ("4 walks a quarter of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
                          ("round 3 before the early exit", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"})]),)
 for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
