@@ -196,7 +196,7 @@ class Workload:
                 ipp = pm.get("valu_per_cell_unit", 15.07)
                 rowtile = self.geom.ncol >= 0.93 * (-(-self.geom.ncol // 192) * 192)      # launch_svr's choice (ensemble.hip)
                 if rowtile:
-                    ipp = min(ipp, 14.07)      # the LAT term once per wave: one fma less per (cell, SV) than the PMC pass's kernel
+                    ipp = min(ipp, 13.07)      # the LAT term and the |x|^2 term once per wave: an fma and an add less per (cell, SV) than svr_kernel
                 rows.append({"kernel": "svr_rt_kernel" if rowtile else "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop",
                              "issue_view": {"achieved": band_cells * nsv / 64.0 * ipp / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",

@@ -39,7 +39,7 @@ cfg5_variants = (("rf", [("split-node records, 4 walks on adjacent rows, prefix,
                          ("walks at the root, every tree to its full depth", {"MHS_RF_FULL_DEPTH": "1"}),
                          ("4 walks a quarter of the grid apart, early exit", {"MHS_RF_FAR_WALKS": "1"}),
                          ("round 3 before the early exit", {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"})]),)
-for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term once per wave and support vector (round 3)", {}),
+for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tiles: the LAT term and the wave's largest |x|^2 term once per wave and support vector (round 3)", {}),
                                 ("lane per cell (round 2)", {"MHS_SVR_NO_ROWTILE": "1"})]),
                        ("gbm", [("row tiles (round 3)", {}), ("lane per cell (round 2)", {"MHS_GBM_NO_ROWTILE": "1"})]),
                        ("rf", [("three buffers, no barrier; walks on adjacent rows start where the wave's cells part ways and end at its deepest leaf (default)", {}),
@@ -53,6 +53,7 @@ for kind, variants in cfg5_variants if shape == "cfg5" else (("svr", [("row tile
     ref = None
     for name, env in variants:
         dt, plane = run(kind, env)
-        same = "" if ref is None else ("  == first" if torch.equal(torch.nan_to_num(plane), torch.nan_to_num(ref)) else "  DIFFERS from first")
+        same = "" if ref is None else ("  == first" if torch.equal(torch.nan_to_num(plane), torch.nan_to_num(ref)) else
+                                       "  max |diff| / max |first| = %.1e" % float((torch.nan_to_num(plane) - torch.nan_to_num(ref)).abs().max() / torch.nan_to_num(ref).abs().max()))
         if ref is None: ref = plane
         print(f"{kind:4s} {name:60s} {dt*1e3:9.2f} ms  -> 1e8 cells: {dt*1e8/(side*side)*1e3:8.1f} ms{same}", flush=True)
