@@ -21,7 +21,10 @@ import numpy as np
 
 # Compute units the fitting rank keeps free of one long ensemble kernel (the forest) so that the spline can be fitted
 # beside the grid kernels (mhs_fit_reserve_cus; 0 = off; a multiple of 8).  Measured on cfg3: DESIGN.md section 9.
-FIT_RESERVE_CUS = 32
+# 64 since the end of round 3: the fit must END while the forest runs (afterwards it competes with ksvm's grid-filling blocks
+# for every one of its small launches), and the forest got short -- on 32 units the fit outlived it and finished at 301 ms of a
+# 309 ms step; on 64 it is done at 135 ms, the forest pays 131 instead of 112 ms, the step takes 298 (48: 305, 96: 324, 0: 328).
+FIT_RESERVE_CUS = 64
 # ... only while the fit is a latency-bound chain (62 ms alone at 5 000 stations, 143 ms on 32 units): at 20 000
 # stations it is compute-bound (1.2 s on the whole chip) and confining it to an eighth of the chip costs seconds
 FIT_RESERVE_MAX_STATIONS = 6000
