@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void svr_kernel(const double *__restrict__ svp
 // predictor of every model (V73:127-138) and the same for all of the wave's cells, so its term b_LAT x_LAT + a of the
 // exponent is formed ONCE per wave and support vector -- 128 vectors at a time, two per lane, parked in a wave-private
 // 1 KB of LDS and read back as a broadcast -- instead of once per cell: 14 VALU instructions per (cell, SV) instead of
-// 15.  Same fma, same order as svr_kernel: identical planes.
+// 15.  A wave that does NOT fold its cells' q (below) adds exactly what svr_kernel adds, bit for bit; a folding wave's plane
+// agrees with svr_kernel's to ~2e-13 of the prediction (tests: test_ksvm_row_tile_kernel_*).
 template <int P, int R>
 __global__ __launch_bounds__(256) void svr_rt_kernel(const double *__restrict__ svp, int nsv, int stride,
                                                      int npos, const double *__restrict__ xcs,
@@ -1447,12 +1448,14 @@ static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R && !getenv
 // the split's predictor (the ranks are the keys already parked in LDS).  entry[b], lane l = tree 64 b + l: entry node in
 // the low 16 bits, levels descended in bits 16..30, bit 31 = the entry node is terminal.
 constexpr int RF_ENTRY_BATCHES = 16;                                // batches of 64 trees held in registers
+constexpr int RF_PREFIX_MAX_P = 12;                                 // the wave's [min, max] ranks are held for this many predictors;
+                                                                    // forests with more walk from the root (prefix off)
 template <int R>
 __device__ __forceinline__ void rf_prefix_entries(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
                                                   const int *__restrict__ tree_off, int n_trees, int p, const char *smem,
                                                   unsigned lane_base, const bool (&na)[R]) {
     const int lane = threadIdx.x & 63;
-    int mn[12], mx[12];                                            // p <= 12 (one key byte)
+    int mn[RF_PREFIX_MAX_P], mx[RF_PREFIX_MAX_P];                  // callers guarantee p <= RF_PREFIX_MAX_P
 #pragma unroll
     for (int v = 0; v < 12; ++v) {
         mn[v] = 0x7fffffff; mx[v] = -1;
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
     unsigned entry[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) entry[b] = 0u;
-    if (prefix && n_trees <= 64 * EB) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
+    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * EB) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
     __syncthreads();                                               // coarse table no longer needed: buffer 0 may be written
     {
         const int o = tree_off[0], cnt = tree_off[1] - o;
@@ -1711,7 +1714,7 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
     unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave (rf_prefix_entries)
 #pragma unroll
     for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (prefix && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
+    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
     unsigned ecur = 0u;
     __syncthreads();                                               // coarse table no longer needed
     for (int t = 0; t < 2 && t < n_trees; ++t) {
@@ -1897,7 +1900,7 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
     unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave
 #pragma unroll
     for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (prefix && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries_compact<R>(entry, gnodes, coff, n_trees, p, smem, lane_base, na);
+    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries_compact<R>(entry, gnodes, coff, n_trees, p, smem, lane_base, na);
     unsigned ecur = 0u;
     __syncthreads();                                               // coarse table no longer needed
     {

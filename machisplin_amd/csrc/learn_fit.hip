@@ -47,26 +47,27 @@ __device__ __forceinline__ double ld_f64(const unsigned long long *p) { return _
 // All blocks of the (cooperatively launched) grid meet here.  The slots the blocks exchange are written and read
 // with agent-scope atomics, which are coherent across the XCDs' L2s by themselves: waiting for this thread's
 // stores (vmcnt) before the arrival is all the ordering needed -- no L2 write-back.
-__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned nblocks, unsigned &target) {
+__device__ __forceinline__ void grid_barrier(unsigned long long *counter, unsigned nblocks, unsigned long long &target) {
     if (nblocks > 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this thread's slot stores have been performed
     __syncthreads();
     if (nblocks > 1) {
         target += nblocks;
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
     }
 }
 
-// arg-max of (key, idx) over the block, ties to the smaller idx; every thread returns the winner
+// arg-max of (key, idx) over the block, ties to the LARGER idx (libsvm's select_working_set scans t = 0 .. 2n-1 with
+// '>=' / '<=': the last of equal candidates wins; SMO_NONE = -1 loses every tie); every thread returns the winner
 __device__ __forceinline__ void block_argmax(double &key, int &idx, double *skey, int *sidx) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double k2 = __shfl_xor(key, o);
         const int i2 = __shfl_xor(idx, o);
-        if (k2 > key || (k2 == key && i2 < idx)) { key = k2; idx = i2; }
+        if (k2 > key || (k2 == key && i2 > idx)) { key = k2; idx = i2; }
     }
     const int wave = threadIdx.x >> 6;
     __syncthreads();
@@ -77,17 +78,18 @@ __device__ __forceinline__ void block_argmax(double &key, int &idx, double *skey
     for (int w = 1; w < SMO_T / 64; ++w) {
         const double k2 = skey[w];
         const int i2 = sidx[w];
-        if (k2 > key || (k2 == key && i2 < idx)) { key = k2; idx = i2; }
+        if (k2 > key || (k2 == key && i2 > idx)) { key = k2; idx = i2; }
     }
 }
 
 // slots (unsigned long long words, per parity and block): I: {gmax, a_i, idx, gmax2}; J: {-obj, a_j, G_j, K_ij, idx}
 constexpr int SLOT_W = 8;
+constexpr int SMO_NONE = -1;      // "no candidate": below every variable index, so it never wins a tie
 struct SmoOut { double rho; long long iters; double violation; int status; };
 
 __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict__ K, const double *__restrict__ y, int n,
                                                         double C, double eps, double tol, long long max_iter,
-                                                        unsigned long long *slots, unsigned *counter,
+                                                        unsigned long long *slots, unsigned long long *counter,
                                                         double *__restrict__ al_out, double *__restrict__ as_out,
                                                         double *__restrict__ kb_out, SmoOut *out) {
     __shared__ double skey[SMO_T / 64], spay[4];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
         kb[r] = 0.0; al[r] = 0.0; as[r] = 0.0;
         yk[r] = k < n ? y[k] : 0.0;
     }
-    unsigned target = 0;
+    unsigned long long target = 0;
     long long it = 0;
     double viol = INFINITY;
     int status = 0;
@@ -112,14 +114,14 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
         const int par = (int)(it & 1);
         // ---- i = argmax over I_up of -s G ; gmax2 = max over I_low of s G
         double best = NEG, low = NEG;
-        int bi = 0x7fffffff;
+        int bi = SMO_NONE;
 #pragma unroll
         for (int r = 0; r < SMO_E; ++r) {
             const int k = g0 + r * stride;
             if (k < n) {
                 const double gu = kb[r] + eps - yk[r], gd = -kb[r] + eps + yk[r];     // gradients of alpha_k, alpha*_k
-                if (al[r] < C && (-gu > best || (-gu == best && k < bi))) { best = -gu; bi = k; }
-                if (as[r] > 0.0 && (gd > best || (gd == best && k + n < bi))) { best = gd; bi = k + n; }
+                if (al[r] < C && (-gu > best || (-gu == best && k > bi))) { best = -gu; bi = k; }
+                if (as[r] > 0.0 && (gd > best || (gd == best && k + n > bi))) { best = gd; bi = k + n; }
                 if (al[r] > 0.0) low = fmax(low, gu);
                 if (as[r] < C) low = fmax(low, -gd);
             }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
             const int st = bi < n ? bi : bi - n;
 #pragma unroll
             for (int r = 0; r < SMO_E; ++r)
-                if (g0 + r * stride == st && bi != 0x7fffffff) {
+                if (g0 + r * stride == st && bi != SMO_NONE) {
                     const double ai_local = bi < n ? al[r] : as[r];
                     if (nb > 1) st_f64(slotI + ((size_t)par * SMO_MAXB + blockIdx.x) * SLOT_W + 1, ai_local);
                     else spay[0] = ai_local;
@@ -148,26 +150,26 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
         double gmax = best, gmax2 = low, a_i;
         int i = bi;
         if (nb > 1) {
-            gmax = NEG; gmax2 = NEG; i = 0x7fffffff; a_i = 0.0;
+            gmax = NEG; gmax2 = NEG; i = SMO_NONE; a_i = 0.0;
             for (unsigned b = 0; b < nb; ++b) {
                 const unsigned long long *s = slotI + ((size_t)par * SMO_MAXB + b) * SLOT_W;
                 const double v = ld_f64(s + 0);
                 const int id = (int)(unsigned)ld_u64(s + 2);
                 gmax2 = fmax(gmax2, ld_f64(s + 3));
-                if (v > gmax || (v == gmax && id < i)) { gmax = v; i = id; a_i = ld_f64(s + 1); }
+                if (id != SMO_NONE && (v > gmax || (v == gmax && id > i))) { gmax = v; i = id; a_i = ld_f64(s + 1); }
             }
         } else {
             a_i = spay[0];
         }
         viol = gmax + gmax2;
-        if (i == 0x7fffffff || !(gmax2 > NEG) || viol < tol) break;
+        if (i == SMO_NONE || !(gmax2 > NEG) || viol < tol) break;
         if (it >= max_iter) { status = 1; break; }
         const int si = i < n ? 1 : -1, ist = i < n ? i : i - n;
         // ---- j = argmin over I_low, -s G < gmax, of -(gmax + s G)^2 / (2 - 2 K_ij)
         const double *Ki = K + (int64_t)ist * n;
         double ki[SMO_E];
         double jb = NEG, jg = 0.0, ja = 0.0, jk = 0.0;
-        int jx = 0x7fffffff;
+        int jx = SMO_NONE;
 #pragma unroll
         for (int r = 0; r < SMO_E; ++r) {
             const int k = g0 + r * stride;
@@ -178,11 +180,11 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
                 if (!(q > 0.0)) q = TAU;
                 if (al[r] > 0.0 && -gu < gmax) {          // alpha_k in I_low
                     const double b = gmax + gu, o = (b * b) / q;
-                    if (o > jb || (o == jb && k < jx)) { jb = o; jx = k; jg = gu; ja = al[r]; jk = ki[r]; }
+                    if (o > jb || (o == jb && k > jx)) { jb = o; jx = k; jg = gu; ja = al[r]; jk = ki[r]; }
                 }
                 if (as[r] < C && gd < gmax) {             // alpha*_k in I_low
                     const double b = gmax - gd, o = (b * b) / q;
-                    if (o > jb || (o == jb && k + n < jx)) { jb = o; jx = k + n; jg = gd; ja = as[r]; jk = ki[r]; }
+                    if (o > jb || (o == jb && k + n > jx)) { jb = o; jx = k + n; jg = gd; ja = as[r]; jk = ki[r]; }
                 }
             }
         }
@@ -191,28 +193,28 @@ __global__ __launch_bounds__(SMO_T) void svr_smo_kernel(const double *__restrict
             block_argmax(jb, jx, skey, sidx);
             // the thread that holds the winner publishes its payload
             unsigned long long *s = slotJ + ((size_t)par * SMO_MAXB + blockIdx.x) * SLOT_W;
-            if (mine == jx && jx != 0x7fffffff) {
+            if (mine == jx && jx != SMO_NONE) {
                 if (nb > 1) { st_f64(s + 0, jb); st_f64(s + 1, ja); st_f64(s + 2, jg); st_f64(s + 3, jk); st_u64(s + 4, (unsigned long long)(unsigned)jx); }
                 else { spay[1] = ja; spay[2] = jg; spay[3] = jk; }
             }
-            if (nb > 1 && jx == 0x7fffffff && threadIdx.x == 0) { st_f64(s + 0, NEG); st_u64(s + 4, 0x7fffffffull); }
+            if (nb > 1 && jx == SMO_NONE && threadIdx.x == 0) { st_f64(s + 0, NEG); st_u64(s + 4, (unsigned long long)(unsigned)SMO_NONE); }
         }
         grid_barrier(counter, nb, target);
         double a_j, G_j, K_ij;
         int j = jx;
         if (nb > 1) {
             double ob = NEG;
-            j = 0x7fffffff; a_j = G_j = K_ij = 0.0;
+            j = SMO_NONE; a_j = G_j = K_ij = 0.0;
             for (unsigned b = 0; b < nb; ++b) {
                 const unsigned long long *s = slotJ + ((size_t)par * SMO_MAXB + b) * SLOT_W;
                 const double v = ld_f64(s + 0);
                 const int id = (int)(unsigned)ld_u64(s + 4);
-                if (id != 0x7fffffff && (v > ob || (v == ob && id < j))) { ob = v; j = id; a_j = ld_f64(s + 1); G_j = ld_f64(s + 2); K_ij = ld_f64(s + 3); }
+                if (id != SMO_NONE && (v > ob || (v == ob && id > j))) { ob = v; j = id; a_j = ld_f64(s + 1); G_j = ld_f64(s + 2); K_ij = ld_f64(s + 3); }
             }
         } else {
             a_j = spay[1]; G_j = spay[2]; K_ij = spay[3];
         }
-        if (j == 0x7fffffff) break;                        // no feasible direction left (libsvm: j == -1)
+        if (j == SMO_NONE) break;                        // no feasible direction left (libsvm: j == -1)
         const int sj = j < n ? 1 : -1, jst = j < n ? j : j - n;
         // ---- the two-variable subproblem (libsvm Solver::Solve), evaluated by every thread alike
         const double G_i = -(double)si * gmax;
@@ -507,7 +509,7 @@ int mhs_svr_fit(const double *X, const double *y, int64_t n, int p, double sigma
     hipStream_t s = ctx().stream;
     DevBuf<double> dZ, dt, dK, dbeta, dkb, dal, das;
     DevBuf<unsigned long long> dslots;
-    DevBuf<unsigned> dcount;
+    DevBuf<unsigned long long> dcount;
     DevBuf<SmoOut> dout;
     MHS_HIP(dZ.alloc((size_t)n * p)); MHS_HIP(dt.alloc((size_t)n)); MHS_HIP(dK.alloc((size_t)n * n));
     MHS_HIP(dbeta.alloc((size_t)n)); MHS_HIP(dkb.alloc((size_t)n)); MHS_HIP(dal.alloc((size_t)n)); MHS_HIP(das.alloc((size_t)n));
@@ -515,7 +517,7 @@ int mhs_svr_fit(const double *X, const double *y, int64_t n, int p, double sigma
     MHS_HIP(hipMemcpyAsync(dZ.p, Z.data(), sizeof(double) * Z.size(), hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(dt.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemsetAsync(dslots.p, 0, sizeof(unsigned long long) * 4 * SMO_MAXB * SLOT_W, s));
-    MHS_HIP(hipMemsetAsync(dcount.p, 0, sizeof(unsigned), s));
+    MHS_HIP(hipMemsetAsync(dcount.p, 0, sizeof(unsigned long long), s));
     MHS_HIP(hipMemsetAsync(dout.p, 0, sizeof(SmoOut), s));
     hipLaunchKernelGGL(rbf_gram_kernel, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, s, dZ.p, (int)n, p, sigma, dK.p);
     MHS_HIP(hipGetLastError());
@@ -525,7 +527,7 @@ int mhs_svr_fit(const double *X, const double *y, int64_t n, int p, double sigma
         int nn = (int)n;
         long long mi = max_iter > 0 ? (long long)max_iter : std::max<long long>(10000000LL, 100LL * n);
         unsigned long long *sl = dslots.p;
-        unsigned *cn = dcount.p;
+        unsigned long long *cn = dcount.p;
         double *ao = dal.p, *so = das.p, *ko = dkb.p;
         SmoOut *oo = dout.p;
         void *args[] = {&Kp, &yp, &nn, &C, &epsilon, &tol, &mi, &sl, &cn, &ao, &so, &ko, &oo};

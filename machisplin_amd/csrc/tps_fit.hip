@@ -1640,119 +1640,6 @@ __global__ void add_diag_kernel(double *A, int64_t ld, int off, int m, double la
     if (i < m) A[(int64_t)(off + i) * ld + off + i] += lam;
 }
 
-// ------------------------------------------------------------------- Cholesky --
-constexpr int NB = 64;  // panel width
-
-// single block (256 threads): unblocked Cholesky of the nb x nb diagonal block in LDS
-__global__ __launch_bounds__(256) void potf2_kernel(double *__restrict__ A, int64_t ld, int off, int nb,
-                                                    int *__restrict__ info) {
-    __shared__ double s[NB][NB + 1];
-    double *a = A + (int64_t)off * ld + off;
-    for (int e = threadIdx.x; e < nb * nb; e += 256) { const int i = e % nb, j = e / nb; s[i][j] = a[i + (int64_t)j * ld]; }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const double djj = s[j][j];
-        if (!(djj > 0.0)) { if (threadIdx.x == 0) atomicCAS(info, 0, off + j + 1); return; }
-        const double l = sqrt(djj);
-        __syncthreads();
-        if (threadIdx.x == 0) s[j][j] = l;
-        for (int i = j + 1 + threadIdx.x; i < nb; i += 256) s[i][j] /= l;
-        __syncthreads();
-        // trailing update of the lower triangle
-        const int rem = nb - j - 1;
-        for (int e = threadIdx.x; e < rem * rem; e += 256) {
-            const int i = j + 1 + e % rem, c = j + 1 + e / rem;
-            if (i >= c) s[i][c] -= s[i][j] * s[c][j];
-        }
-        __syncthreads();
-    }
-    for (int e = threadIdx.x; e < nb * nb; e += 256) { const int i = e % nb, j = e / nb; if (i >= j) a[i + (int64_t)j * ld] = s[i][j]; }
-}
-
-// panel solve: X = A[off+nb:, off:off+nb] * L^-T, one thread per row
-__global__ __launch_bounds__(256) void trsm_kernel(double *__restrict__ A, int64_t ld, int off, int nb,
-                                                   int t) {
-    __shared__ double L[NB][NB + 1];
-    const double *d = A + (int64_t)off * ld + off;
-    for (int e = threadIdx.x; e < nb * nb; e += 256) { const int i = e % nb, j = e / nb; L[i][j] = (i >= j) ? d[i + (int64_t)j * ld] : 0.0; }
-    __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= t) return;
-    double *row = A + (int64_t)off * ld + off + nb + r;
-    double x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < nb) {
-            double s = row[(int64_t)j * ld];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= x[k] * L[j][k];
-            x[j] = s / L[j][j];
-            row[(int64_t)j * ld] = x[j];
-        }
-    }
-}
-
-// trailing update C -= P P' on the lower triangle with v_mfma_f64_16x16x4_f64.
-// P = A[off2:off2+t, pc:pc+nb] (t x nb), C = A[off2:, off2:].  Block tile 64x64, 4 waves as
-// 2x2 of 32x32; the two 64 x nb panel tiles are staged in LDS with a row stride of 80
-// doubles so the four k-rows of one ds_read_b64 wave access land on disjoint banks.
-typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int SYRK_LDS_STRIDE = 80;
-
-__global__ __launch_bounds__(256) void syrk_mfma_kernel(double *__restrict__ A, int64_t ld, int off2,
-                                                        int pc, int nb, int t) {
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi) return;  // lower triangle of tiles only
-    __shared__ double sI[NB * SYRK_LDS_STRIDE];
-    __shared__ double sJ[NB * SYRK_LDS_STRIDE];
-    const int i0 = bi * 64, j0 = bj * 64;
-    // stage P[i0:i0+64, 0:nb] and P[j0:j0+64, 0:nb]; element (r, k) at s[k*STRIDE + r]
-    for (int e = threadIdx.x; e < 64 * nb; e += 256) {
-        const int r = e & 63, k = e >> 6;
-        const double *pcol = A + (int64_t)(pc + k) * ld + off2;
-        sI[k * SYRK_LDS_STRIDE + r] = (i0 + r < t) ? pcol[i0 + r] : 0.0;
-        sJ[k * SYRK_LDS_STRIDE + r] = (j0 + r < t) ? pcol[j0 + r] : 0.0;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;  // wave's 32x32 sub-tile
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // acc[a][b]: D'[row = j][col = i] tile, i-sub-block a, j-sub-block b
-    d4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < nb; k0 += 4) {
-        double fi[2], fj[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            fi[a] = sI[(k0 + l4) * SYRK_LDS_STRIDE + wi + a * 16 + l15];
-            fj[a] = sJ[(k0 + l4) * SYRK_LDS_STRIDE + wj + a * 16 + l15];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                // A-operand rows = j (P_j), B-operand cols = i (P_i): D'[j][i] += sum_k P[j][k] P[i][k]
-                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[b], fi[a], acc[a][b], 0, 0, 0);
-    }
-    // D' layout: lane holds D'[row = l4 + 4 r][col = l15]  ->  C[i = col][j = row]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wi + a * 16 + l15;
-                const int j = j0 + wj + b * 16 + l4 + 4 * r;
-                if (i < t && j < t && i >= j) {
-                    double *c = A + (int64_t)(off2 + j) * ld + off2 + i;
-                    *c -= acc[a][b][r];
-                }
-            }
-}
-
 // =============================================================================================
 // Small matrices (the reference-tiled mode fits 130-750 stations per tile, V73:690-722): the blocked
 // band reduction above is four launches and two events per panel, and with several tiles being fitted
@@ -1956,58 +1843,6 @@ static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h) {
     const unsigned char *c = (const unsigned char *)p;
     for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
     return h;
-}
-
-// single block: solve L L' x = b in place (L = lower triangle of A[off:off+m, off:off+m])
-__global__ __launch_bounds__(1024) void potrs_kernel(const double *__restrict__ A, int64_t ld, int off,
-                                                     int m, double *__restrict__ x) {
-    __shared__ double scratch[17];
-    __shared__ double piv;
-    const double *L = A + (int64_t)off * ld + off;
-    // forward, column oriented: x_j /= L_jj ; x[j+1:] -= x_j L[j+1:, j]
-    for (int j = 0; j < m; ++j) {
-        if (threadIdx.x == 0) { x[j] /= L[j + (int64_t)j * ld]; piv = x[j]; }
-        __syncthreads();
-        const double xj = piv;
-        const double *c = L + (int64_t)j * ld;
-        for (int i = j + 1 + threadIdx.x; i < m; i += blockDim.x) x[i] -= xj * c[i];
-        __syncthreads();
-    }
-    // backward, dot oriented on columns of L: x_j = (x_j - sum_{i>j} L[i][j] x_i) / L_jj
-    for (int j = m - 1; j >= 0; --j) {
-        const double *c = L + (int64_t)j * ld;
-        double s = 0.0;
-        for (int i = j + 1 + threadIdx.x; i < m; i += blockDim.x) s = fma(c[i], x[i], s);
-        s = block_sum(s, scratch);
-        if (threadIdx.x == 0) x[j] = (x[j] - s) / c[j];
-        __syncthreads();
-    }
-}
-
-static int cholesky_solve(double *A, int64_t ld, int off, int m, double *x_dev, int *info_dev, hipStream_t s) {
-    struct { int *p; } info = {info_dev};
-    MHS_HIP(hipMemsetAsync(info.p, 0, sizeof(int), s));
-    for (int j = 0; j < m; j += NB) {
-        const int nb = std::min(NB, m - j);
-        const int t = m - j - nb;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, s, A, ld, off + j, nb, info.p);
-        if (t > 0) {
-            hipLaunchKernelGGL(trsm_kernel, dim3((t + 255) / 256), dim3(256), 0, s, A, ld, off + j, nb, t);
-            const int nt = (t + 63) / 64;
-            hipLaunchKernelGGL(syrk_mfma_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, off + j + nb,
-                               off + j, nb, t);
-        }
-    }
-    hipLaunchKernelGGL(potrs_kernel, dim3(1), dim3(1024), 0, s, A, ld, off, m, x_dev);
-    MHS_HIP(hipGetLastError());
-    int h_info = 0;
-    MHS_HIP(hipMemcpyAsync(&h_info, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    MHS_HIP(hipStreamSynchronize(s));
-    if (h_info != 0) {
-        set_error("mhs_tps_fit: Q2'KQ2 + lambda I is not positive definite (pivot %d)", h_info);
-        return MHS_ERR_NUMERIC;
-    }
-    return MHS_OK;
 }
 
 // fields' Krig.replicates: unique locations (first-appearance order), means, counts

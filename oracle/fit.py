@@ -53,7 +53,8 @@ def svr_smo(K, y, C=1.0, epsilon=0.1, tol=1e-3, max_iter=10_000_000):
         mg = -s * G
         if not up.any() or not low.any():
             break
-        i = int(np.flatnonzero(up)[np.argmax(mg[up])])
+        iu = np.flatnonzero(up)                          # libsvm scans t = 0 .. 2n-1 with '>=': the LAST maximiser wins a tie
+        i = int(iu[iu.size - 1 - np.argmax(mg[iu][::-1])])
         gmax = mg[i]
         gmax2 = np.max(-mg[low])
         if gmax + gmax2 < tol:
@@ -64,7 +65,7 @@ def svr_smo(K, y, C=1.0, epsilon=0.1, tol=1e-3, max_iter=10_000_000):
         aq = QD[i] + QD - 2.0 * s[i] * s * Qi
         aq = np.where(aq > 0, aq, TAU)
         obj = np.where(cand, -(b * b) / aq, np.inf)
-        j = int(np.argmin(obj))
+        j = int(obj.size - 1 - np.argmin(obj[::-1]))     # 'obj_diff <= obj_diff_min': the last minimiser
         if not np.isfinite(obj[j]):
             break
         Qj = s[j] * s * np.concatenate([K[j % n], K[j % n]])

@@ -407,6 +407,35 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
+@pytest.mark.parametrize("C,n,force", [(11, 900, None), (13, 900, None), (11, 5200, "MHS_RF_FORCE_COMPACT"), (16, 700, None)])
+def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
+    """p = C + 2 >= 13 predictors (11+ covariate layers, V73:127-138 adds LONG and LAT): the wave-uniform prefix keeps the
+    wave's [min, max] ranks for 12 predictors only, so these forests must start their walks at the root (round-3 advisor
+    finding: a split on predictor >= 12 used predictor 0's range).  Grid of 123 rows (strips + prefix would be on), every
+    walk form that fits, against the oracle and against the generic node walk bit for bit."""
+    import torch
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=257, C=C, dtype="f32", nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
+    prm = synth.rf_params(Xs, ys, 11, n_trees=9)
+    bv = np.asarray(prm["best_var"])[np.asarray(prm["status"]) == -3] - 1        # 0-based split predictors
+    assert np.isin(np.arange(12, C + 2), bv).all(), "no split on a predictor >= 12"
+    m = hip.models.from_param_dict(prm)
+    if force:
+        monkeypatch.setenv(force, "1")
+    fast = hip.predict(stack, m)
+    if force:
+        monkeypatch.delenv(force)
+    monkeypatch.setenv("MHS_TREES_GENERIC", "1")
+    generic = hip.predict(stack, m)
+    monkeypatch.delenv("MHS_TREES_GENERIC")
+    assert torch.equal(torch.isnan(fast), torch.isnan(generic))
+    assert torch.equal(torch.nan_to_num(fast), torch.nan_to_num(generic))
+    want = oe.predict(prm, X)
+    got = fast.cpu().numpy().ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
 def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     """Trees of ~18 000 nodes (30 000 stations): too many for 16-bit byte addresses and for nodes + predictions in
     LDS, so the walk takes its BIG form (node indices, predictions read from global memory).  Same results."""
@@ -469,6 +498,74 @@ def test_ksvm_window_and_point_paths_match_the_oracle(hip, C, dtype):
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
     assert np.array_equal(win, got.reshape(61, 83)[7:40, 11:70], equal_nan=True)
     assert np.abs(pts - oe.predict(prm, Xs[:100])).max() <= _tol(want)
+
+
+@pytest.mark.parametrize("dtype,C", [("f32", 3), ("f64", 3), ("i16", 3), ("f32", 5)])
+def test_ksvm_row_tile_kernel_alone_matches_the_oracle(hip, dtype, C, monkeypatch):
+    """svr_rt_kernel on its own (the round-3 verdict's item 4): 560 columns = two full 192-cell waves and a ragged third
+    (176 cells), 1 % NoData cells inside the waves, against the oracle at 1e-11 of the prediction; a window whose first
+    column is not a multiple of 192; and the lane-per-cell kernel (MHS_SVR_NO_ROWTILE=1) at 1e-12 -- the row-tile kernel
+    folds the wave's largest q = sigma |x|^2 / 700 into the per-wave term and scales back with one exponential per cell, so
+    the two agree to rounding, not bitwise."""
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=37, ncol=560, C=C, n=333, dtype=dtype, nodata_frac=0.01, gbm_trees=2, rf_trees=1)
+    prm = params[KINDS.index("v")]
+    model = hip.models.from_param_dict(prm)
+    want = oe.predict(prm, X)
+    got = hip.predict(stack, model).cpu().numpy().ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    win = hip.predict(stack, model, window=(3, 30, 7, 552)).cpu().numpy()       # 545 columns from column 7: tiles shifted by 7
+    ref = want.reshape(37, 560)[3:30, 7:552]
+    assert np.array_equal(np.isnan(win), np.isnan(ref))
+    assert np.nanmax(np.abs(win - ref)) <= _tol(want)
+    monkeypatch.setenv("MHS_SVR_NO_ROWTILE", "1")
+    plain = hip.predict(stack, model).cpu().numpy().ravel()
+    monkeypatch.delenv("MHS_SVR_NO_ROWTILE")
+    assert np.array_equal(np.isnan(got), np.isnan(plain))
+    assert not np.array_equal(got, plain, equal_nan=True), "the row-tile kernel did not run (identical planes)"
+    assert np.nanmax(np.abs(got - plain)) <= 1e-12 * np.nanmax(np.abs(plain))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_ksvm_row_tile_kernel_keeps_the_addition_where_a_wave_spreads(hip, dtype, monkeypatch):
+    """A covariate JUMP inside a wave: with q = sigma |x~|^2 / 700 spreading more than 0.5 over the wave's 192 cells the
+    row-tile kernel must keep the per-pair addition (folding would flush terms the cell's back-scaling cannot restore).
+    Plane 0 steps up by 16 standard deviations from column 250 on (inside the second wave of every row), sigma = 2:
+    the spread is 2 * 16^2 / 700 = 0.73.  Rows 20.. have no jump (those waves fold).  Against the oracle at 1e-11."""
+    import torch
+    from machisplin_amd import synth
+    nrow, ncol, C = 41, 560, 3
+    g = synth.grid(nrow, ncol)
+    planes, nodata = synth.covariates(g, C, 5, dtype=dtype, nodata_frac=0.01)
+    sd0 = float(torch.nan_to_num(planes[0].double()).std())
+    planes[0, :20, 250:] += 16.0 * sd0
+    stack = hip.RasterStack(g, planes, nodata)
+    host = planes.cpu().numpy().astype(np.float64)
+    x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, nrow, ncol)
+    X = oe.stack_predictors(host, (x, y))
+    rng = np.random.default_rng(5)
+    ok = np.flatnonzero(~np.isnan(X).any(axis=1))
+    idx = rng.choice(ok, 400, replace=False)
+    Xs = X[idx]
+    uv = np.column_stack([(idx % ncol + 0.5) / ncol, (idx // ncol + 0.5) / nrow])
+    prm = synth.svr_params(Xs, synth.response(Xs, uv, 5), 5)
+    prm["sigma"] = 2.0
+    xt = (X - prm["x_center"]) / prm["x_scale"]
+    q = 2.0 / 700.0 * (xt * xt).sum(1).reshape(nrow, ncol)
+    assert np.nanmax(q[3, 192:384]) - np.nanmin(q[3, 192:384]) > 0.5 and np.nanmax(q[30, 192:384]) - np.nanmin(q[30, 192:384]) < 0.5
+    model = hip.models.from_param_dict(prm)
+    want = oe.predict(prm, X)
+    got = hip.predict(stack, model).cpu().numpy().ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanstd(want) > 1e-3 * np.nanmax(np.abs(want))           # the kernel sums are not all flushed to a constant
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+    monkeypatch.setenv("MHS_SVR_NO_ROWTILE", "1")
+    plain = hip.predict(stack, model).cpu().numpy().ravel()
+    monkeypatch.delenv("MHS_SVR_NO_ROWTILE")
+    assert np.nanmax(np.abs(got - plain)) <= 1e-12 * np.nanmax(np.abs(plain))
+    # the unfolded waves add exactly what the lane-per-cell kernel adds: bit-identical there
+    a, b = got.reshape(nrow, ncol), plain.reshape(nrow, ncol)
+    assert np.array_equal(a[:20, 192:384], b[:20, 192:384], equal_nan=True)
 
 
 def test_loaders_reject_malformed_models(hip):

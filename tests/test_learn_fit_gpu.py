@@ -77,6 +77,37 @@ def test_svr_fit_with_more_stations_than_one_block_holds(hip):
     assert np.array_equal(again.beta, m.beta) and again.n_iter == m.n_iter      # deterministic
 
 
+def test_svr_fit_breaks_ties_toward_the_larger_index(hip):
+    """libsvm's rule (the last of equal candidates wins, see tests/test_oracle_fit.py) on the device, within a block and
+    across blocks: integer responses, ONE iteration (the C entry point reports 'no convergence' and still hands back
+    beta), the two variables that moved are the oracle's; and to convergence the device follows the oracle's count."""
+    import ctypes as C
+    from machisplin_amd import _lib
+    for n in (240, 8300):                                                # one block; two cooperative blocks
+        rng, X, _ = _data(n=n, p=4, seed=3)
+        y = rng.integers(180, 190, n).astype(float)
+        Z = (X - X.mean(0)) / X.std(0, ddof=1)
+        t = (y - y.mean()) / y.std(ddof=1)
+        K = of.rbf_gram(Z, 0.3)
+        want, _, _ = of.svr_smo(K, t, max_iter=1)
+        Xf = np.asfortranarray(X)
+        beta, xc, xs = np.zeros(n), np.empty(4), np.empty(4)
+        b, yc, ys, it = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        rc = _lib.lib().mhs_svr_fit(Xf.ctypes.data, y.ctypes.data, n, 4, 0.3, 1.0, 0.1, 1e-3, 1, beta.ctypes.data, C.byref(b),
+                                    xc.ctypes.data, xs.ctypes.data, C.byref(yc), C.byref(ys), C.byref(it))
+        assert rc != 0 and it.value == 1
+        assert np.array_equal(np.flatnonzero(beta), np.flatnonzero(want)), (n, np.flatnonzero(beta), np.flatnonzero(want))
+        top = np.flatnonzero(y == y.max())
+        assert top[-1] in np.flatnonzero(beta)
+        assert np.allclose(beta[np.flatnonzero(want)], want[np.flatnonzero(want)], rtol=1e-12)
+    rng, X, _ = _data(n=240, p=4, seed=3)
+    y = rng.integers(180, 190, 240).astype(float)
+    m = hip.models.Ksvm.fit(X, y, 0.3)
+    Z = (X - X.mean(0)) / X.std(0, ddof=1)
+    ob, orho, oit = of.svr_smo(of.rbf_gram(Z, 0.3), (y - y.mean()) / y.std(ddof=1))
+    assert abs(m.n_iter - oit) <= 0.05 * oit and np.abs(m.beta - ob).max() < 2e-2
+
+
 @pytest.mark.parametrize("p", [3, 5, 7])
 def test_nnet_fit_follows_vmmin(hip, p):
     rng, X, y = _data(400, p, seed=11 + p)

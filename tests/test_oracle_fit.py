@@ -68,6 +68,37 @@ def test_svr_smo_is_libsvm():
     assert m["alpha"].size == ref.support_.size
 
 
+def test_svr_smo_breaks_ties_as_libsvm_does():
+    """Integer responses (the bundled bio_1 column is 187, 224, 225 ...: data-raw/sampling.csv) tie the gradients at
+    iteration 0, and libsvm's select_working_set scans t = 0 .. 2n-1 with '>=' / '<=': the LAST of equal candidates wins.
+    After ONE iteration the two variables that moved are libsvm's (max_iter = 1), i being the last maximiser of y."""
+    sk = pytest.importorskip("sklearn.svm")
+    import warnings
+    rng, X, _ = _data(n=240, p=4, seed=3)
+    y = rng.integers(180, 190, 240).astype(float)                      # ten distinct values: 20-odd ties at the top
+    Z = (X - X.mean(0)) / X.std(0, ddof=1)
+    t = (y - y.mean()) / y.std(ddof=1)
+    K = of.rbf_gram(Z, 0.3)
+    beta, _, it = of.svr_smo(K, t, max_iter=1)
+    moved = np.flatnonzero(beta)
+    assert it == 1 and moved.size == 2
+    top = np.flatnonzero(t == t.max())
+    assert top.size > 5 and top[-1] in moved and not np.isin(top[:-1], moved).any()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = sk.SVR(kernel="rbf", gamma=0.3, C=1.0, epsilon=0.1, tol=1e-3, max_iter=1, shrinking=False).fit(Z, t)
+    assert np.array_equal(np.sort(ref.support_), moved)
+    assert np.allclose(ref.dual_coef_[0], beta[np.sort(ref.support_)], rtol=1e-5)
+    # and to convergence the two agree as closely as on tie-free data (libsvm keeps Q in float32)
+    full, rho, it_full = of.svr_smo(K, t)
+    ref = sk.SVR(kernel="rbf", gamma=0.3, C=1.0, epsilon=0.1, tol=1e-3, shrinking=False).fit(Z, t)
+    want = np.zeros(t.size)
+    want[ref.support_] = ref.dual_coef_[0]
+    assert np.abs(K @ (full - want)).max() < 5e-3
+    if hasattr(ref, "n_iter_"):
+        assert abs(int(np.ravel(ref.n_iter_)[0]) - it_full) <= 0.1 * it_full
+
+
 def test_gbm_step_rule_on_crafted_curves():
     k = np.arange(1, 201)
     u_shaped = 1.0 + 0.5 * np.exp(-k / 10.0) + 1e-5 * (k - 60.0) ** 2 / 60.0      # minimum near stage 60
