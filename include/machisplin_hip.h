@@ -130,6 +130,18 @@ MHS_API int mhs_host_gcv_tridiag(const double *diag, const double *offdiag, cons
 MHS_API int mhs_host_gcv_band(const double *ab, int bw, const double *g, int64_t m, int64_t n_unique,
                               int64_t n_obs, double pure_ss, double lambda, int gcv_mode,
                               double *lambda_out, double *gcv_out, double *eff_df_out, double *q_out);
+/* Test hooks of the round-4 GCV route (tps_band32.hip; the route itself runs inside mhs_tps_fit, fields::Tps at V73:722,
+ * V73:751).  mhs_band32_reduce: the 32-column-panel band reduction of a symmetric matrix B (m x m, column-major, m >= 66)
+ * with a right-hand side: ab[j * 33 + d] = Bb[j + d][j] (B = Q Bb Q'), gq = Q'g, and Qr = Q r for a probe vector r;
+ * *breakdown = 1 when a panel's Cholesky-QR met a non-positive pivot (the fit then falls back to the 8-column route).
+ * mhs_band32_gcv_terms: for each lambda[k] the number of negative pivots of Bb + lambda I (= eigenvalues of Bb below
+ * -lambda), tr (Bb + lambda I)^-1 and g'(Bb + lambda I)^-2 g from the twisted, self-differentiating LDL' sweep (deriv = 0:
+ * the counts only).  mhs_band32_solve: q = (Bb + lambda I)^-1 g by the same sweep with the factor stored.            */
+MHS_API int mhs_band32_reduce(const double *B, const double *g, int64_t m, double *ab, double *gq,
+                              const double *r, double *Qr, int *breakdown);
+MHS_API int mhs_band32_gcv_terms(const double *ab, const double *g, int64_t m, const double *lambda, int n_lambda,
+                                 int deriv, double *neg, double *tr_inv, double *gM2g);
+MHS_API int mhs_band32_solve(const double *ab, const double *g, int64_t m, double lambda, double *q);
 /* build a spline object from coefficients captured elsewhere (e.g. from a real
  * fields::Tps object: $c, $d, $knots (scaled), $transform$x.center/$x.scale)   */
 MHS_API int mhs_tps_from_coef(const double *knots_uv /* n x 2 column-major, scaled */,

@@ -65,6 +65,9 @@ SIGNATURES = {
                                        _dp, _dp, _dp, _vp]),
     "mhs_host_gcv_band": (C.c_int, [_vp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, C.c_double, C.c_int,
                                     _dp, _dp, _dp, _vp]),
+    "mhs_band32_reduce": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
+    "mhs_band32_gcv_terms": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mhs_band32_solve": (C.c_int, [_vp, _vp, _i64, C.c_double, _vp]),
     "mhs_tps_from_coef": (C.c_int, [_vp, _vp, _vp, _i64, C.c_double, _vp, _vp, C.POINTER(_vp)]),
     "mhs_tps_size": (C.c_int, [_vp, C.POINTER(_i64)]),
     "mhs_tps_get": (C.c_int, [_vp, _vp, _vp, _vp, _dp, _vp, _vp, _dp, _dp]),

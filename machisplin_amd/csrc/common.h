@@ -38,6 +38,7 @@ struct FitLane {
     std::vector<hipEvent_t> pool;
     char *arena = nullptr;
     size_t arena_cap = 0;
+    double *pinned = nullptr;                  // page-locked host scratch of the band-32 GCV search (lambdas in, terms out)
 };
 
 struct Context {

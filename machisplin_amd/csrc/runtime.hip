@@ -121,14 +121,19 @@ int fit_lane(int i, FitLane **out) {
     // mhs_fit_reserve_cus walks c.lanes and rebuilds their masked streams under this mutex
     std::lock_guard<std::mutex> lk(mask_mutex());
     while ((int)c.lanes.size() <= i) {
-        FitLane *L = new FitLane();
         int prio_lo = 0, prio_hi = 0;
         MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        MHS_HIP(hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi));
-        MHS_HIP(hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio_hi));
-        if (c.masked_cus > 0 && !c.comp_mask.empty()) {
-            MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data()));
-            MHS_HIP(hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)c.comp_mask.size(), c.comp_mask.data()));
+        FitLane *L = new FitLane();
+        hipError_t e = hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess && c.masked_cus > 0 && !c.comp_mask.empty()) {
+            e = hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
+        }
+        if (e != hipSuccess) {      // nothing half-built stays behind
+            for (hipStream_t q : {L->s, L->s2, L->ms, L->ms2}) if (q) (void)hipStreamDestroy(q);
+            delete L;
+            return hip_fail(e, "fit_lane: stream creation", __FILE__, __LINE__);
         }
         c.lanes.push_back(L);
     }
@@ -263,6 +268,7 @@ int mhs_shutdown(void) {
         for (hipEvent_t e : L->pool) (void)hipEventDestroy(e);
         if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); }
         if (L->arena) (void)hipFree(L->arena);
+        if (L->pinned) (void)hipHostFree(L->pinned);
         (void)hipStreamDestroy(L->s2); (void)hipStreamDestroy(L->s);
         delete L;
     }

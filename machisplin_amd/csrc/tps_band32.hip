@@ -1,0 +1,1790 @@
+// GCV route of the spline fit, round 4: fields::Tps(x, Y) (V73:722, V73:751) needs lambda = arg min GCV over B = Q2'KQ2.
+//
+// Round 1-3 reduced B to a band of width 8 with 8-column Householder panels -- n/8 panels, each a chain of three globally
+// dependent launches: 624 links at n = 5 000, 52 of the fit's 62 ms, 3 % of the FP64 peak (tps_fit.hip, kept as the
+// fallback).  This file cuts the DEPTH of that chain:
+//
+//   stage 1   B = Q Bb Q', Bb of bandwidth 32, with 32-COLUMN panels: n/32 links.  A panel P (t x 32) is factorised by
+//             CholeskyQR2 -- two passes of {Gram matrix on MFMA, 32 x 32 Cholesky, row-wise triangular solve}, every block
+//             of rows working alone between two launches -- and the compact-WY form H = I - V T V' the two-sided update
+//             needs is RECONSTRUCTED from the orthonormal factor: H [I; 0] = Q D (D = diag(+-1)) <=> L U = [I; 0] - Q D with
+//             the signs chosen so that every pivot is >= 1 (Ballard et al., "Reconstructing Householder vectors from TSQR",
+//             2015); V = L, T = U L1^-T.  Only the 32 x 32 top block is sequential, every block of rows redoes it.
+//             Then Y = A22 V (MFMA, split-K), W = Y T - 1/2 V (T'(V'Y)T), A22 -= V W' + W V' (MFMA rank-64, the first block
+//             column ahead of the rest so that the next panel starts behind it).
+//   GCV       on the band itself, on the GPU: for one lambda ONE forward sweep of an LDL' recurrence over T + lambda I that
+//             carries its own derivative with respect to lambda gives the inertia, tr (T + lambda I)^-1 = sum d'_j / d_j and
+//             g'(T + lambda I)^-2 g = -d/dlambda sum y_j^2 / d_j: no back substitution, no stored factor.  A sweep is a
+//             chain of m column steps; it runs from BOTH ends to the middle (twisted factorisation: two blocks per lambda,
+//             a third kernel joins them), and a search round evaluates hundreds of lambdas side by side -- the search is
+//             organised in few, wide rounds (1 023-point multi-section for the two extreme eigenvalues, the 40-point
+//             bracket, the 200-point grid, a speculatively expanded golden section).
+//   solve     (Bb + lambda I) q = g by the same sweep with the factor stored, c2 = Q q one launch per panel.
+//
+// tests/test_band32_gpu.py checks every piece against a numpy restatement kept with the test infrastructure.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "common.h"
+#include "devmath.h"
+#include "tps_band32.h"
+
+namespace mhs {
+
+constexpr int NB = B32_NB;                 // 32
+constexpr int MAXPART_H = B32_MAXPART;
+constexpr int CHR = 256;                   // rows per chunk: one row per thread
+constexpr int PT_S = CHR + 2;              // LDS stride of a transposed chunk Pt[a][i]: == 2 (mod 32), so the 16 x 4 MFMA
+                                           // operand reads Pt[a0 + l15][k0 + l4] touch 32 distinct bank pairs per half-wave
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ small helpers --
+// What a previous launch wrote sits in another XCD's L2 or in HBM: a load of it costs ~2 us, and a loop of "load, add" over
+// the partial results of 10-20 blocks is a chain of them (the first version of this file spent 40 us of every small kernel
+// that way).  Every kernel below therefore ISSUES all of its global loads before it waits for any of them.
+__device__ __forceinline__ double frcp(double d) {      // 1 / d to ~1 ulp: v_rcp_f64 and two Newton steps (no div_scale / div_fixup)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+// acc += Pt[ta-tile]' Pt[tb-tile] over the chunk's 256 rows: D[a][b] = sum_i Pa[i][a] Pb[i][b]
+__device__ __forceinline__ void gram_chunk(const double *__restrict__ Pa, const double *__restrict__ Pb, d4v &acc, int ta, int tb) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const double *pa = Pa + (ta * 16 + l15) * PT_S + l4, *pb = Pb + (tb * 16 + l15) * PT_S + l4;
+#pragma unroll 8
+    for (int k0 = 0; k0 < CHR; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void store_tile32(double *__restrict__ out, const d4v &acc, int ta, int tb) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(ta * 16 + l4 + 4 * r) * NB + tb * 16 + l15] = acc[r];
+}
+// the sum of up to MAXPART 32 x 32 partial matrices (added in block order), entry e = tid + 256 q: loads first, adds after
+struct Parts4 { double v[4][MAXPART_H]; };
+__device__ __forceinline__ void parts_issue(Parts4 &P, const double *__restrict__ part, int nparts) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < MAXPART_H; ++p) {
+            const double x = part[(size_t)(p < nparts ? p : 0) * NB * NB + threadIdx.x + 256 * q];
+            P.v[q][p] = p < nparts ? x : 0.0;
+        }
+}
+__device__ __forceinline__ void parts_sum(const Parts4 &P, double (*G)[NB + 1]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < MAXPART_H; ++p) s += P.v[q][p];
+        const int e = threadIdx.x + 256 * q;
+        G[e >> 5][e & 31] = s;
+    }
+}
+
+// G (lower triangle, LDS [32][33]) -> its Cholesky factor L in place (G = L L'), 256 threads.  One barrier per column:
+// step k reads column k (rows > k, untouched by this step) and updates the columns right of it with the unscaled
+// entries, G[i][j] -= G[i][k] G[j][k] / G[k][k]; the columns are scaled by 1 / sqrt(pivot) at the end.  Returns false
+// (in every thread) if a pivot was not positive -- the panel was numerically rank deficient.
+__device__ __forceinline__ bool chol32_lds(double (*G)[NB + 1], double *sd /* [32] */) {
+    const int i = threadIdx.x >> 3, jg = threadIdx.x & 7;
+    bool ok = true;
+    for (int k = 0; k < NB - 1; ++k) {
+        __syncthreads();
+        double d = G[k][k];
+        if (!(d > 0.0) || !(d < 1e300)) { ok = false; d = 1.0; }
+        // straight-line: every thread rewrites its four entries (unchanged where the step does not reach), so that the
+        // step is one batch of LDS reads and one of writes instead of four predicated read-modify-write round trips
+        const double gik = G[i][k] * frcp(d);
+        double gjk[4], old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gjk[q] = G[jg + 8 * q][k]; old[q] = G[i][jg + 8 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = jg + 8 * q;
+            G[i][j] = (i > k && j > k && j <= i) ? old[q] - gik * gjk[q] : old[q];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        double d = G[threadIdx.x][threadIdx.x];
+        if (!(d > 0.0) || !(d < 1e300)) { ok = false; d = 1.0; }
+        sd[threadIdx.x] = sqrt(d);
+    }
+    ok = __syncthreads_and(ok);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = jg + 8 * q;
+        if (j < i) G[i][j] = G[i][j] / sd[j];
+        else if (j == i) G[i][j] = sd[j];
+    }
+    __syncthreads();
+    return ok;
+}
+
+// The solve with the row in REGISTERS and the factor read from LDS as broadcast 16-byte reads -- 264 ds_read_b128 and 496
+// v_fma_f64 per row.  Two things make this the fast form (measured, round 4): (1) the compiler, left alone, hoists all
+// 528 reads out of the row loop and spills ~700 registers -- so the LDS offset is laundered through an empty asm that
+// also consumes the row just finished, every second row, which pins each pair of rows' reads behind the previous pair's
+// arithmetic; (2) the factor in the SCALAR cache instead (s_load from a per-block slot of global memory, SGPR operands)
+// was tried and costs ~1 us per batch of loads, 30 batches a row: 35 us per 256 rows against ~2 here.
+// Lp: [32][32] row-major (Lp[j][k] = L[j][k], k < j), then 32 reciprocals of the diagonal; 16-byte aligned.
+constexpr int TRS_SIZE = NB * NB + NB;
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) d2v *lds_c2ptr;
+typedef const __attribute__((address_space(3))) double *lds_cptr;
+__device__ __forceinline__ void trs_pack(double *__restrict__ Lp, const double (*L)[NB + 1], const double *rinv) {
+    for (int e = threadIdx.x; e < NB * NB; e += 256) Lp[e] = L[e >> 5][e & 31];
+    if (threadIdx.x < NB) Lp[NB * NB + threadIdx.x] = rinv[threadIdx.x];
+    __syncthreads();
+}
+__device__ __forceinline__ void row_trsm_reg(double (&x)[NB], const double *Lp) {
+    unsigned off = (unsigned)(uintptr_t)(lds_cptr)Lp;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if ((j & 1) == 0) asm volatile("" : "+v"(off) : "v"(x[j > 0 ? j - 1 : 0]) : "memory");
+        lds_c2ptr row = (lds_c2ptr)(uintptr_t)(off + (unsigned)(j * NB * sizeof(double)));
+        double s0 = x[j], s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k += 2) {
+            const d2v l = row[k >> 1];
+            s0 = fma(-x[k], l.x, s0);
+            if (k + 1 < j) s1 = fma(-x[k + 1], l.y, s1);
+        }
+        x[j] = (s0 + s1) * ((lds_cptr)(uintptr_t)off)[NB * NB + j];
+    }
+}
+
+// sum of x[a] over the block's 256 threads for a = 0 .. 31, in a fixed order: thread (a, seg) adds 32 consecutive rows,
+// thread a adds the 8 segments.  Result in threads 0 .. 31 (value a).  Pt: >= 32 * PT_S doubles, red: [8][32].
+__device__ __forceinline__ double block_colsum32(const double (&x)[NB], double *Pt, double (*red)[NB]) {
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NB; ++a) Pt[a * PT_S + threadIdx.x] = x[a];
+    __syncthreads();
+    {
+        const int a = threadIdx.x & 31, seg = threadIdx.x >> 5;
+        const double *src = Pt + a * PT_S + seg * 32;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) s += src[q];
+        red[seg][a] = s;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NB) {
+#pragma unroll
+        for (int seg = 0; seg < 8; ++seg) tot += red[seg][threadIdx.x];
+    }
+    return tot;
+}
+
+// the V row of B-row il (0-based inside the panel) as the panel stores it in place: zeros above the unit diagonal
+__device__ __forceinline__ void load_v_row(double (&v)[NB], const double *__restrict__ Ppan, int64_t ld, int il, bool ok) {
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+        const double x = Ppan[(int64_t)a * ld + (ok ? il : 0)];
+        v[a] = !ok || il < a ? 0.0 : (il == a ? 1.0 : x);
+    }
+}
+// up to 16 x 32 partial sums of 32 values (added in block order) by threads 0 .. 31: loads first
+__device__ __forceinline__ double sum_parts_32(const double *__restrict__ part, int nparts) {
+    double v[MAXPART_H];
+    const int a = threadIdx.x & 31;
+#pragma unroll
+    for (int p = 0; p < MAXPART_H; ++p) { const double x = part[(size_t)(p < nparts ? p : 0) * NB + a]; v[p] = p < nparts ? x : 0.0; }
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < MAXPART_H; ++p) s += v[p];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- stage 1 kernels --
+// K0: partial Gram matrices of the panel P = A[r0 :, c0 : c0 + 32] (t rows), one per block of cpb chunks
+__global__ __launch_bounds__(256) void b32_gram_kernel(const double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
+                                                       double *__restrict__ Gpart) {
+    __shared__ double Pt[NB * PT_S];
+    const int wave = threadIdx.x >> 6, ta = wave >> 1, tb = wave & 1;
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
+        const bool ok = i < t;
+        const double *src = A + (int64_t)c0 * ld + r0 + (ok ? i : 0);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) { const double x = src[(int64_t)a * ld]; Pt[a * PT_S + threadIdx.x] = ok ? x : 0.0; }
+        __syncthreads();
+        gram_chunk(Pt, Pt, acc, ta, tb);
+        __syncthreads();
+    }
+    store_tile32(Gpart + (size_t)blockIdx.x * NB * NB, acc, ta, tb);
+}
+
+// K1: R1 = chol(P'P), Q1 = P R1^-1 (in place), partial Gram matrices of Q1
+__global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
+                                                          const double *__restrict__ Gin, int nparts, double *__restrict__ Gout,
+                                                          double *__restrict__ R1out, double *__restrict__ Qtop,
+                                                          int *__restrict__ flags) {
+    __shared__ double Pt[NB * PT_S];
+    __shared__ double G[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Lp[TRS_SIZE];
+    __shared__ double sd[NB], rinv[NB];
+    double x[NB];      // the first chunk's row travels while the Gram matrix is summed and factorised
+    {
+        Parts4 P;
+        parts_issue(P, Gin, nparts);
+        const int i = blockIdx.x * cpb * CHR + threadIdx.x;
+        const double *row = A + (int64_t)c0 * ld + r0 + (i < t ? i : 0);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) x[a] = row[(int64_t)a * ld];
+        parts_sum(P, G);
+    }
+    const bool ok_chol = chol32_lds(G, sd);
+    if (threadIdx.x < NB) rinv[threadIdx.x] = 1.0 / sd[threadIdx.x];
+    if (!ok_chol && threadIdx.x == 0) atomicOr(flags, 1);
+    __syncthreads();
+    trs_pack(Lp, G, rinv);
+    if (blockIdx.x == 0) {      // R1[k][j] = L[j][k], dense row-major
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q, k = e >> 5, j = e & 31;
+            R1out[e] = j >= k ? G[j][k] : 0.0;
+        }
+    }
+    const int wave = threadIdx.x >> 6, ta = wave >> 1, tb = wave & 1;
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
+        const bool ok = i < t;
+        double *row = A + (int64_t)c0 * ld + r0 + (ok ? i : 0);
+        if (ch > 0) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) x[a] = row[(int64_t)a * ld];
+        }
+        if (!ok) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) x[a] = 0.0;
+        }
+        row_trsm_reg(x, Lp);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) { if (ok) row[(int64_t)a * ld] = x[a]; Pt[a * PT_S + threadIdx.x] = x[a]; }
+        if (i < NB) {      // the top block once more, aside: K2 overwrites it in place while other blocks still need it
+#pragma unroll
+            for (int a = 0; a < NB; ++a) Qtop[i * NB + a] = x[a];
+        }
+        __syncthreads();
+        gram_chunk(Pt, Pt, acc, ta, tb);
+        __syncthreads();
+    }
+    store_tile32(Gout + (size_t)blockIdx.x * NB * NB, acc, ta, tb);
+}
+
+// K2: R2 = chol(Q1'Q1), Q = Q1 R2^-1; LU of [I; 0] - Q D on the top block (every block), V = -(Q D) U^-1 for its rows; dense V
+// in both layouts; partial sums of V'g.  Block 0 leaves L1, U, L2, D aside for b32_tfin (T and the band entries are not on
+// this kernel's path: they ride along with the symmetric product).  Requires t >= 32.
+constexpr int AUX_LM = 0, AUX_UT = NB * NB, AUX_L2 = 2 * NB * NB, AUX_D = 3 * NB * NB, AUX_SIZE = 3 * NB * NB + NB;
+__global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
+                                                          const double *__restrict__ Gin, int nparts, const double *__restrict__ Qtop,
+                                                          double *__restrict__ Zc, int64_t vs, double *__restrict__ Vr,
+                                                          double *__restrict__ aux, const double *__restrict__ g,
+                                                          double *__restrict__ sgpart, int *__restrict__ flags) {
+    __shared__ double Pt[NB * PT_S];
+    __shared__ double G[NB][NB + 1];            // L2 (R2 = L2')
+    __shared__ double X[NB][NB + 1];            // top block of Q, eliminated in place
+    __shared__ double Lm[NB][NB + 1];           // L1 (strictly lower)
+    __shared__ double Ut[NB][NB + 1];           // Ut[c][k] = U[k][c]
+    __shared__ __attribute__((aligned(16))) double Lp2[TRS_SIZE], Lpu[TRS_SIZE];      // R2' and U' packed for the row solves
+    __shared__ double sd[NB], rinv[NB], Dv[NB], ruinv[NB], red[8][NB];
+    double xrow[NB];                            // the first chunk's row of Q1
+    double qt[NB];                              // threads 0 .. 31: a row of the top block
+    {
+        Parts4 P;
+        parts_issue(P, Gin, nparts);
+        const bool top = threadIdx.x < NB;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) qt[a] = Qtop[(top ? threadIdx.x : 0) * NB + a];
+        const int i = blockIdx.x * cpb * CHR + threadIdx.x;
+        const double *row = A + (int64_t)c0 * ld + r0 + (i < t ? i : 0);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) xrow[a] = row[(int64_t)a * ld];
+        parts_sum(P, G);
+    }
+    const bool ok_chol = chol32_lds(G, sd);
+    if (threadIdx.x < NB) rinv[threadIdx.x] = 1.0 / sd[threadIdx.x];
+    if (!ok_chol && threadIdx.x == 0) atomicOr(flags, 2);
+    __syncthreads();
+    trs_pack(Lp2, G, rinv);
+    if (threadIdx.x < 64) {      // top block: Q1[0:32, :] R2^-1 (thread = row; the wave's other lanes ride along)
+        row_trsm_reg(qt, Lp2);
+        if (threadIdx.x < NB) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) X[threadIdx.x][a] = qt[a];
+        }
+    }
+    const int i8 = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    for (int k = 0; k < NB; ++k) {      // LU of [I; 0] - Q D, signs chosen on the way (see the header)
+        __syncthreads();
+        const double piv = X[k][k];
+        const double Dk = piv >= 0.0 ? -1.0 : 1.0, ukk = 1.0 + fabs(piv);
+        const double lik = -Dk * X[i8][k] * frcp(ukk);
+        double xk[4], old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xk[q] = X[k][cg + 8 * q]; old[q] = X[i8][cg + 8 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = cg + 8 * q;
+            if (i8 > k) X[i8][c] = c > k ? old[q] - lik * xk[q] : old[q];
+        }
+        if (i8 > k && cg == 0) Lm[i8][k] = lik;
+        if (threadIdx.x == 0) { Dv[k] = Dk; ruinv[k] = frcp(ukk); Ut[k][k] = ukk; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // U[k][c] = -D_c X[k][c] (c > k): thread (c = i8, k = cg + 8 q)
+        const int k = cg + 8 * q;
+        if (k < i8) Ut[i8][k] = -Dv[i8] * X[k][i8];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = threadIdx.x; e < NB * NB; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            aux[AUX_LM + e] = c < r ? Lm[r][c] : 0.0;
+            aux[AUX_UT + e] = c <= r ? Ut[r][c] : 0.0;
+            aux[AUX_L2 + e] = c <= r ? G[r][c] : 0.0;
+        }
+        if (threadIdx.x < NB) aux[AUX_D + threadIdx.x] = Dv[threadIdx.x];
+    }
+    trs_pack(Lpu, Ut, ruinv);
+    double sgacc = 0.0;
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int chunk = blockIdx.x * cpb + ch;
+        const int i = chunk * CHR + threadIdx.x;
+        const bool ok = i < t;
+        double *row = A + (int64_t)c0 * ld + r0 + (ok ? i : 0);
+        __syncthreads();
+        if (ch > 0) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) xrow[a] = row[(int64_t)a * ld];
+        }
+        const double gi = ok ? g[i] : 0.0;
+        double x[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) x[a] = ok ? xrow[a] : 0.0;
+        if (i >= NB) {
+            row_trsm_reg(x, Lp2);                                        // q = q1 R2^-1
+#pragma unroll
+            for (int a = 0; a < NB; ++a) x[a] *= -Dv[a];
+            row_trsm_reg(x, Lpu);                                        // v U = -(q D)
+            if (ok) {
+#pragma unroll
+                for (int a = 0; a < NB; ++a) row[(int64_t)a * ld] = x[a];
+            }
+        } else {      // the top block: V = L1 below the unit diagonal, in place too (b32_tfin adds R~ on and above it)
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                x[a] = a < i ? Lm[i][a] : (a == i ? 1.0 : 0.0);
+                if (a < i) row[(int64_t)a * ld] = x[a];
+            }
+        }
+        double prod[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            if (ok) { Zc[(int64_t)a * vs + i] = x[a]; }
+            prod[a] = x[a] * gi;
+        }
+        if (i < t + 64) {      // row-major copy, and zero rows past the end for the symmetric product's last k-steps
+            double2 *dst = (double2 *)(Vr + (int64_t)i * NB);
+#pragma unroll
+            for (int a = 0; a < NB; a += 2) dst[a >> 1] = ok ? make_double2(x[a], x[a + 1]) : make_double2(0.0, 0.0);
+        }
+        const double tot = block_colsum32(prod, Pt, red);
+        sgacc += tot;
+    }
+    // rows t .. t + 63 of Vr that no chunk of this grid reaches
+    {
+        const int covered = (int)gridDim.x * cpb * CHR;
+        if (blockIdx.x == gridDim.x - 1 && covered < t + 64) {
+            for (int i = covered + threadIdx.x; i < t + 64; i += 256)
+                for (int a = 0; a < NB; ++a) Vr[(int64_t)i * NB + a] = 0.0;
+        }
+    }
+    if (threadIdx.x < NB) sgpart[(size_t)blockIdx.x * NB + threadIdx.x] = sgacc;
+}
+
+// T = U L1^-T and the band entries R~ = D R2 R1 of a Cholesky-QR panel, from what K2's block 0 left aside.  One block,
+// launched as an extra block of the symmetric product (nothing before b32_w_kernel needs T).
+__device__ __forceinline__ void b32_tfin(double *__restrict__ A, int64_t ld, int c0, int r0, const double *__restrict__ aux,
+                                         const double *__restrict__ R1, double *__restrict__ Tout, double *smem) {
+    double(*Lm)[NB + 1] = (double(*)[NB + 1])smem;
+    double(*Ut)[NB + 1] = Lm + NB;
+    double(*L2)[NB + 1] = Ut + NB;
+    double(*R1s)[NB + 1] = L2 + NB;
+    double(*X)[NB + 1] = R1s + NB;
+    double *Dv = (double *)(X + NB);
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        Lm[r][c] = aux[AUX_LM + e]; Ut[r][c] = aux[AUX_UT + e]; L2[r][c] = aux[AUX_L2 + e]; R1s[r][c] = R1[e];
+    }
+    if (threadIdx.x < NB) Dv[threadIdx.x] = aux[AUX_D + threadIdx.x];
+    __syncthreads();
+    const int i8 = threadIdx.x >> 3, cg = threadIdx.x & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // R~[r][a] = D_r sum_{k = r .. a} R2[r][k] R1[k][a], R2[r][k] = L2[k][r]
+        const int r = i8, a = cg + 8 * q;
+        if (a >= r) {
+            double s = 0.0;
+            for (int k = r; k <= a; ++k) s = fma(L2[k][r], R1s[k][a], s);
+            A[(int64_t)(c0 + a) * ld + r0 + r] = Dv[r] * s;
+        }
+    }
+    // T L1' = U, right-looking over the columns of T: column k is final at step k
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = cg + 8 * q; X[i8][c] = c >= i8 ? Ut[c][i8] : 0.0; }
+    for (int k = 0; k < NB - 1; ++k) {
+        __syncthreads();
+        const double trk = X[i8][k];
+        double lc[4], old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lc[q] = Lm[cg + 8 * q][k]; old[q] = X[i8][cg + 8 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = cg + 8 * q;
+            if (c > k) X[i8][c] = old[q] - trk * lc[q];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) Tout[e] = X[e >> 5][e & 31];
+}
+constexpr int TFIN_LDS = 5 * NB * (NB + 1) + NB;      // doubles
+
+// The SHORT last panel (t < 64 rows, possibly fewer rows than columns): classical Householder QR in one block -- the
+// Cholesky route needs t >= 32 and full column rank.  Same outputs as K1 + K2 + b32_tfin (one partial of V'g).
+__global__ __launch_bounds__(256) void b32_panel_small_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t,
+                                                              double *__restrict__ Zc, int64_t vs, double *__restrict__ Vr,
+                                                              double *__restrict__ Tout, const double *__restrict__ g,
+                                                              double *__restrict__ sgpart) {
+    __shared__ double P[64][NB + 1], V[64][NB + 1], Gs[NB][NB + 1], Ts[NB][NB + 1];
+    __shared__ double wpart[8][NB], taus[NB], ssh[2], red[8][NB];
+    __shared__ double Pt[NB * PT_S];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * NB; e += 256) {
+        const int i = e & 63, a = e >> 6;
+        P[i][a] = i < t ? A[(int64_t)(c0 + a) * ld + r0 + i] : 0.0;
+        V[i][a] = 0.0;
+    }
+    __syncthreads();
+    const int nref = min(NB, t - 1);
+    for (int j = 0; j < NB; ++j) {
+        if (j < nref) {
+            if (tid < 64) {
+                double s = tid > j && tid < t ? P[tid][j] * P[tid][j] : 0.0;
+                s = wave_sum(s);
+                if (tid == 0) ssh[0] = s;
+            }
+            __syncthreads();
+            const double ss = ssh[0], alpha = P[j][j];
+            double beta = alpha, tau = 0.0, scal = 0.0;
+            if (ss != 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            __syncthreads();
+            if (tid < 64) V[tid][j] = tid < j || tid >= t ? 0.0 : (tid == j ? 1.0 : P[tid][j] * scal);
+            if (tid == 0) taus[j] = tau;
+            __syncthreads();
+            {      // w_c = v' P[:, c] for c > j: thread (c, seg) over 8 rows each
+                const int c = tid & 31, seg = tid >> 5;
+                double s = 0.0;
+                if (c > j)
+                    for (int q = 0; q < 8; ++q) { const int i = seg * 8 + q; s = fma(V[i][j], P[i][c], s); }
+                wpart[seg][c] = s;
+            }
+            __syncthreads();
+            {
+                const int i = tid >> 2, cq = tid & 3;
+                const double vi = V[i][j];
+                for (int q = 0; q < 8; ++q) {
+                    const int c = cq + 4 * q;
+                    if (c > j && i >= j) {
+                        double w = 0.0;
+                        for (int s8 = 0; s8 < 8; ++s8) w += wpart[s8][c];
+                        P[i][c] -= tau * w * vi;
+                    }
+                }
+                if (tid == 0) P[j][j] = beta;
+            }
+            __syncthreads();
+        } else {
+            if (tid == 0) taus[j] = 0.0;
+            __syncthreads();
+        }
+    }
+    // G = V'V
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int a = e >> 5, b = e & 31;
+        double s = 0.0;
+        for (int i = 0; i < 64; ++i) s = fma(V[i][a], V[i][b], s);
+        Gs[a][b] = s;
+        Ts[a][b] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {      // larft: T[0:j, j] = -tau_j T[0:j, 0:j] G[0:j, j]
+        if (tid < j) {
+            double s = 0.0;
+            for (int l = tid; l < j; ++l) s = fma(Ts[tid][l], Gs[l][j], s);
+            Ts[tid][j] = -taus[j] * s;
+        }
+        if (tid == j) Ts[j][j] = taus[j];
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * NB; e += 256) Tout[e] = Ts[e >> 5][e & 31];
+    // outputs: in place (R on / above the diagonal, V below), dense V, the partial of V'g
+    double x[NB], prod[NB];
+    const int i = tid;
+    const bool ok = i < t;
+    const double gi = ok ? g[i] : 0.0;
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+        x[a] = ok && i < 64 ? V[i][a] : 0.0;
+        prod[a] = x[a] * gi;
+        if (ok) {
+            A[(int64_t)(c0 + a) * ld + r0 + i] = i > a ? x[a] : P[i][a];
+            Zc[(int64_t)a * vs + i] = x[a];
+        }
+    }
+    if (i < t + 64) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) Vr[(int64_t)i * NB + a] = x[a];
+    }
+    const double tot = block_colsum32(prod, Pt, red);
+    if (tid < NB) sgpart[tid] = tot;
+}
+
+// K3: Y = A22 V as split-K partial sums.  Block = 64 rows x one column range; its four waves take a quarter of the range
+// each and keep a 64 x 32 accumulator (8 MFMA tiles): per k-step of 4 columns a lane loads two 16-byte row pairs of A22
+// (the 64 rows as {even, odd} x {low, high} tiles, so that the loads are 256 contiguous bytes per column) and two V
+// entries (row-major V: 128 contiguous bytes per knot).  A22 is read exactly once: the kernel streams.  One EXTRA block
+// (blockIdx.x == gridDim.x - 1, blockIdx.y == 0) finishes the panel's T and band entries beside it (b32_tfin).
+__global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                       const double *__restrict__ Vr, double *__restrict__ Ypart, int64_t vs,
+                                                       int ws, int tfin, const double *__restrict__ aux, const double *__restrict__ R1,
+                                                       double *__restrict__ Tout) {
+    __shared__ double red[4][NB][66];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0 && tfin) b32_tfin(A, ld, r0 - NB, r0, aux, R1, Tout, &red[0][0][0]);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int I0 = blockIdx.x * 64;
+    const int jbeg = blockIdx.y * ws + wave * (ws >> 2);
+    const int jend = min(jbeg + (ws >> 2), (t + 3) & ~3);
+    const double *Ab = A + (int64_t)r0 * ld + r0;
+    d4v acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4v){0.0, 0.0, 0.0, 0.0};
+    const int rp0 = I0 + 2 * l15, rp1 = rp0 + 32;
+    const bool ok00 = rp0 < t, ok01 = rp0 + 1 < t, ok10 = rp1 < t, ok11 = rp1 + 1 < t;
+    const double *a0p = Ab + (ok00 ? rp0 : 0), *a1p = Ab + (ok10 ? rp1 : 0);
+#pragma unroll 4
+    for (int j = jbeg; j < jend; j += 4) {
+        const int col = min(j + l4, t - 1);
+        const double2 a0 = *(const double2 *)(a0p + (int64_t)col * ld);
+        const double2 a1 = *(const double2 *)(a1p + (int64_t)col * ld);
+        const double *vrow = Vr + (int64_t)(j + l4) * NB + l15;
+        const double b0 = vrow[0], b1 = vrow[16];
+        const double x0 = ok00 ? a0.x : 0.0, x1 = ok01 ? a0.y : 0.0, x2 = ok10 ? a1.x : 0.0, x3 = ok11 ? a1.y : 0.0;
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1, acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b0, acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b1, acc[2][1], 0, 0, 0);
+        acc[3][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b0, acc[3][0], 0, 0, 0);
+        acc[3][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b1, acc[3][1], 0, 0, 0);
+    }
+    // tile rt = 2 h + parity holds rows I0 + 32 h + 2 m + parity, m = l4 + 4 r; column n = 16 nt + l15
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][nt * 16 + l15][32 * (rt >> 1) + 2 * (l4 + 4 * r) + (rt & 1)] = acc[rt][nt][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * 64; e += 256) {
+        const int n = e >> 6, row = e & 63;
+        const double s = (red[0][n][row] + red[1][n][row]) + (red[2][n][row] + red[3][n][row]);
+        if (I0 + row < t) Ypart[((int64_t)blockIdx.y * NB + n) * vs + I0 + row] = s;
+    }
+}
+static_assert(sizeof(double) * 4 * NB * 66 >= sizeof(double) * TFIN_LDS, "b32_tfin borrows the symmetric product's LDS");
+
+// K4a: Y = sum of the split-K partials (at most 4), W^ = Y T on MFMA (row-major), the block's share of M = V'Y, and
+// g <- H'g = g - V T'(V'g)
+constexpr int SYMM_MAXSPLIT = 4;
+__global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, const double *__restrict__ Ypart, int64_t vs,
+                                                    const double *__restrict__ Vr, const double *__restrict__ Tm,
+                                                    const double *__restrict__ sgpart, int nsg, double *__restrict__ g,
+                                                    double *__restrict__ Wh, double *__restrict__ Mpart) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *Vt = smem, *Yt = smem + NB * PT_S;
+    double(*Ts)[NB + 1] = (double(*)[NB + 1])(smem + 2 * NB * PT_S);
+    double *zs = smem + 2 * NB * PT_S + NB * (NB + 1), *sg = zs + NB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, ta = wave >> 1, tb = wave & 1;
+    d4v macc = {0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
+        const bool ok = i < t;
+        const int ii = ok ? i : 0;
+        // everything this chunk reads from global memory, issued together
+        double tq[4], sgv = 0.0, gi, v[NB];
+        if (ch == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tq[q] = Tm[threadIdx.x + 256 * q];
+            if (threadIdx.x < NB) sgv = sum_parts_32(sgpart, nsg);
+        }
+        gi = g[ii];
+        {
+            const double2 *src = (const double2 *)(Vr + (int64_t)ii * NB);
+#pragma unroll
+            for (int a = 0; a < NB; a += 2) { const double2 q = src[a >> 1]; v[a] = ok ? q.x : 0.0; v[a + 1] = ok ? q.y : 0.0; }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double yp[16][SYMM_MAXSPLIT];
+#pragma unroll
+            for (int n = 0; n < 16; ++n)
+#pragma unroll
+                for (int sp = 0; sp < SYMM_MAXSPLIT; ++sp) {
+                    const double x = Ypart[((int64_t)(sp < nsplit ? sp : 0) * NB + half * 16 + n) * vs + ii];
+                    yp[n][sp] = sp < nsplit && ok ? x : 0.0;
+                }
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                double s = 0.0;
+#pragma unroll
+                for (int sp = 0; sp < SYMM_MAXSPLIT; ++sp) s += yp[n][sp];
+                Yt[(half * 16 + n) * PT_S + threadIdx.x] = s;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) Vt[a * PT_S + threadIdx.x] = v[a];
+        if (ch == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Ts[e >> 5][e & 31] = tq[q]; }
+            if (threadIdx.x < NB) sg[threadIdx.x] = sgv;
+            __syncthreads();
+            if (threadIdx.x < NB) {      // z = T' sg
+                const int a = threadIdx.x;
+                double s = 0.0;
+                for (int b = 0; b <= a; ++b) s = fma(Ts[b][a], sg[b], s);
+                zs[a] = s;
+            }
+        }
+        __syncthreads();
+        if (ok) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) gi = fma(-v[a], zs[a], gi);
+            g[i] = gi;
+        }
+        gram_chunk(Vt, Yt, macc, ta, tb);
+        // W^ = Y T: wave w takes rows 64 w .. 64 w + 63 (4 row tiles) x 2 column tiles; T is upper triangular
+        d4v wacc[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wacc[rt][nt] = (d4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < NB; k0 += 4) {
+            const double b0 = Ts[k0 + l4][l15], b1 = Ts[k0 + l4][16 + l15];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const double av = Yt[(k0 + l4) * PT_S + wave * 64 + rt * 16 + l15];
+                if (k0 < 16) wacc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, wacc[rt][0], 0, 0, 0);
+                wacc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, wacc[rt][1], 0, 0, 0);
+            }
+        }
+        const int rbase = (blockIdx.x * cpb + ch) * CHR + wave * 64;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + rt * 16 + l4 + 4 * r;
+                if (row < t) {
+                    Wh[(int64_t)row * NB + l15] = wacc[rt][0][r];
+                    Wh[(int64_t)row * NB + 16 + l15] = wacc[rt][1][r];
+                }
+            }
+        __syncthreads();
+    }
+    store_tile32(Mpart + (size_t)blockIdx.x * NB * NB, macc, ta, tb);
+}
+constexpr size_t B32_W_LDS = sizeof(double) * (2 * NB * PT_S + NB * (NB + 1) + 2 * NB);
+
+// K4b: S = sym(T' sym(M) T), W = W^ - 1/2 V S on MFMA -> the W half of Z (column-major)
+__global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const double *__restrict__ Mpart, int nM,
+                                                       const double *__restrict__ Tm, const double *__restrict__ Vr,
+                                                       const double *__restrict__ Wh, double *__restrict__ Zw, int64_t vs) {
+    __shared__ double Vt[NB * PT_S];
+    __shared__ double M[NB][NB + 1], X[NB][NB + 1], S[NB][NB + 1], Ts[NB][NB + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    {
+        Parts4 P;
+        parts_issue(P, Mpart, nM);
+        double tq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tq[q] = Tm[threadIdx.x + 256 * q];
+        parts_sum(P, M);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Ts[e >> 5][e & 31] = tq[q]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) { const int a = e >> 5, c = e & 31; S[a][c] = 0.5 * (M[a][c] + M[c][a]); }
+    __syncthreads();
+    // full-length, unrolled products (T carries explicit zeros below its diagonal): the reads of a trip are in flight together
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // X = sym(M) T
+        const int a = e >> 5, c = e & 31;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < NB; b += 2) { s0 = fma(S[a][b], Ts[b][c], s0); s1 = fma(S[a][b + 1], Ts[b + 1][c], s1); }
+        X[a][c] = s0 + s1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // T' X
+        const int a = e >> 5, c = e & 31;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int d = 0; d < NB; d += 2) { s0 = fma(Ts[d][a], X[d][c], s0); s1 = fma(Ts[d + 1][a], X[d + 1][c], s1); }
+        M[a][c] = s0 + s1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) { const int a = e >> 5, c = e & 31; S[a][c] = -0.25 * (M[a][c] + M[c][a]); }      // -1/2 sym
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int cbase = (blockIdx.x * cpb + ch) * CHR;
+        const int i = cbase + threadIdx.x;
+        const bool ok = i < t;
+        {
+            const double2 *src = (const double2 *)(Vr + (int64_t)(ok ? i : 0) * NB);
+            double v[NB];
+#pragma unroll
+            for (int a = 0; a < NB; a += 2) { const double2 q = src[a >> 1]; v[a] = ok ? q.x : 0.0; v[a + 1] = ok ? q.y : 0.0; }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < NB; ++a) Vt[a * PT_S + threadIdx.x] = v[a];
+        }
+        // accumulators start at W^ (rows l4 + 4 r of the tile, column l15)
+        d4v wacc[4][2];
+        const int rbase = cbase + wave * 64;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + rt * 16 + l4 + 4 * r;
+                const int rr = row < t ? row : 0;
+                const double w0 = Wh[(int64_t)rr * NB + l15], w1 = Wh[(int64_t)rr * NB + 16 + l15];
+                wacc[rt][0][r] = row < t ? w0 : 0.0;
+                wacc[rt][1][r] = row < t ? w1 : 0.0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < NB; k0 += 4) {
+            const double b0 = S[k0 + l4][l15], b1 = S[k0 + l4][16 + l15];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const double av = Vt[(k0 + l4) * PT_S + wave * 64 + rt * 16 + l15];
+                wacc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, wacc[rt][0], 0, 0, 0);
+                wacc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, wacc[rt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + rt * 16 + l4 + 4 * r;
+                if (row < t) {
+                    Zw[(int64_t)l15 * vs + row] = wacc[rt][0][r];
+                    Zw[(int64_t)(16 + l15) * vs + row] = wacc[rt][1][r];
+                }
+            }
+    }
+}
+
+// K5: A22 -= V W' + W V' = Z Zs' with Z = [V | W] (t x 64, column-major, stride vs) and Zs = [W | V], on 128 x 128 tiles of
+// the whole t x t block (full symmetric storage).  The tile loop is tps_fit.hip's band_rankk_kernel with K = 64: 4 waves
+// x 64 x 64, K streamed through two LDS buffers in chunks of 16, the C tile preloaded into the accumulators with a negated
+// operand.  col0_only: the first block column only (look-ahead: the next panel lives in its first 32 columns).
+constexpr int RK_T = 128, RK_KC = 16, RK_S = RK_T + 16, RK_K = 2 * NB;
+__global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                           const double *__restrict__ Z, int64_t vs, int nt, int col0_only) {
+    __shared__ __attribute__((aligned(16))) double sI[2][RK_KC * RK_S];
+    __shared__ __attribute__((aligned(16))) double sJ[2][RK_KC * RK_S];
+    int bi, bj;
+    if (col0_only) { bi = blockIdx.x; bj = 0; }
+    else { bi = blockIdx.x % nt; bj = 1 + blockIdx.x / nt; }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    double *C = A + (int64_t)r0 * ld + r0;
+    d4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = bj * RK_T + wj + a * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = bi * RK_T + wi + b * 16 + l15;
+                acc[a][b][r] = (i < t && l < t) ? C[(int64_t)l * ld + i] : 0.0;
+            }
+        }
+    const int gk = tid >> 6, gr = tid & 63;
+    const int rI0 = bi * RK_T + gr, rI1 = rI0 + 64, rJ0 = bj * RK_T + gr, rJ1 = rJ0 + 64;
+    double gI[4][2], gJ[4][2];
+#define RK_GLOAD(K0)                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+        const int kp = (K0) + gk + 4 * q;                                                              \
+        const double *cp = Z + (int64_t)kp * vs, *cq = Z + (int64_t)((kp + NB) & (RK_K - 1)) * vs;    \
+        gI[q][0] = rI0 < t ? cp[rI0] : 0.0; gI[q][1] = rI1 < t ? cp[rI1] : 0.0;                        \
+        gJ[q][0] = rJ0 < t ? cq[rJ0] : 0.0; gJ[q][1] = rJ1 < t ? cq[rJ1] : 0.0;                        \
+    }
+#define RK_SSTORE(BUF)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+        sI[BUF][(gk + 4 * q) * RK_S + gr] = gI[q][0]; sI[BUF][(gk + 4 * q) * RK_S + gr + 64] = gI[q][1]; \
+        sJ[BUF][(gk + 4 * q) * RK_S + gr] = gJ[q][0]; sJ[BUF][(gk + 4 * q) * RK_S + gr + 64] = gJ[q][1]; \
+    }
+    RK_GLOAD(0)
+    RK_SSTORE(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prologue load (the C tile) pending into the loop
+    __syncthreads();
+    for (int c = 0; c < RK_K / RK_KC; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < RK_K / RK_KC) { RK_GLOAD((c + 1) * RK_KC) }
+#pragma unroll
+        for (int kk = 0; kk < RK_KC; kk += 4) {
+            double fi[4], fj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                fj[a] = -sJ[buf][(kk + l4) * RK_S + wj + a * 16 + l15];
+                fi[a] = sI[buf][(kk + l4) * RK_S + wi + a * 16 + l15];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[a], fi[b], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < RK_K / RK_KC) {
+            RK_SSTORE(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef RK_GLOAD
+#undef RK_SSTORE
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = bj * RK_T + wj + a * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = bi * RK_T + wi + b * 16 + l15;
+                if (i < t && l < t) C[(int64_t)l * ld + i] = acc[a][b][r];
+            }
+        }
+}
+
+// lower band of B -> ab[j * 33 + d] = B[j + d][j]
+__global__ void b32_extract_kernel(const double *__restrict__ A, int64_t ld, int off0, int m, double *__restrict__ ab) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * (NB + 1)) return;
+    const int j = e / (NB + 1), d = e - j * (NB + 1);
+    ab[e] = (j + d < m) ? A[(int64_t)(off0 + j) * ld + off0 + j + d] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------ Q'g replay, Q q --
+// g <- H_p' g for ANOTHER right-hand side with a stored reduction (the reduction cache's refits): two launches per panel
+// that repeat what K2 (partials of V'g, same row blocks, same order) and K4a (z = T' sum, g -= V z) did to g during the
+// reduction, so that the rotated right-hand side is the full fit's bit for bit.
+__global__ __launch_bounds__(256) void b32_qt_part_kernel(const double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
+                                                          const double *__restrict__ g, double *__restrict__ sgpart) {
+    __shared__ double Pt[NB * PT_S];
+    __shared__ double red[8][NB];
+    double sgacc = 0.0;
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
+        const bool ok = i < t;
+        double v[NB], prod[NB];
+        load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, ok);
+        const double gi = ok ? g[i] : 0.0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) prod[a] = v[a] * gi;
+        sgacc += block_colsum32(prod, Pt, red);
+    }
+    if (threadIdx.x < NB) sgpart[(size_t)blockIdx.x * NB + threadIdx.x] = sgacc;
+}
+__global__ __launch_bounds__(256) void b32_qt_apply_kernel(const double *__restrict__ A, int64_t ld, int c0, int r0, int t,
+                                                           const double *__restrict__ Tm, const double *__restrict__ sgpart, int nsg,
+                                                           double *__restrict__ g) {
+    __shared__ double Ts[NB][NB + 1], zs[NB], sg[NB];
+    for (int e = threadIdx.x; e < NB * NB; e += 256) Ts[e >> 5][e & 31] = Tm[e];
+    if (threadIdx.x < NB) sg[threadIdx.x] = sum_parts_32(sgpart, nsg);
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int a = threadIdx.x;
+        double s = 0.0;
+        for (int b = 0; b <= a; ++b) s = fma(Ts[b][a], sg[b], s);
+        zs[a] = s;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * CHR + threadIdx.x;
+    if (i >= t) return;
+    double v[NB];
+    load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, true);
+    double gi = g[i];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) gi = fma(-v[a], zs[a], gi);
+    g[i] = gi;
+}
+
+// r <- Q r = H_0 H_1 ... H_{P-1} r, one many-block launch per panel: launch p applies panel p (r -= V_p (T_p s_p), s_p =
+// V_p'r summed from the previous launch's partials) and, in the same pass over its rows, forms the partials of s_{p-1}.
+__global__ __launch_bounds__(256) void b32_bt_step_kernel(const double *__restrict__ A, int64_t ld, int off0, int m, int p,
+                                                          int npanels, const double *__restrict__ Tall, double *__restrict__ r,
+                                                          double *__restrict__ part /* [2][BT_MAXBLK][32] */) {
+    __shared__ double Pt[NB * PT_S];
+    __shared__ double red[8][NB], ssum[NB], zs[NB];
+    const int i = blockIdx.x * CHR + threadIdx.x;
+    double ri = i < m ? r[i] : 0.0;
+    if (p < npanels) {
+        const int base = p * NB + NB;
+        {      // 8 groups of 32 threads take every 8th block's partial (loads in flight together), then the groups in order
+            const int a = threadIdx.x & 31, grp = threadIdx.x >> 5;
+            double v[B32_BT_MAXBLK / 8];
+#pragma unroll
+            for (int q = 0; q < B32_BT_MAXBLK / 8; ++q) {
+                const unsigned b = grp + 8 * q;
+                const double x = part[((size_t)(p & 1) * B32_BT_MAXBLK + (b < gridDim.x ? b : 0)) * NB + a];
+                v[q] = b < gridDim.x ? x : 0.0;
+            }
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < B32_BT_MAXBLK / 8; ++q) sacc += v[q];
+            red[grp][a] = sacc;
+        }
+        __syncthreads();
+        if (threadIdx.x < NB) {
+            double s = 0.0;
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) s += red[grp][threadIdx.x];
+            ssum[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < NB) {
+            const int a = threadIdx.x;
+            const double *T = Tall + (size_t)p * NB * NB;
+            double s = 0.0;
+            for (int b = a; b < NB; ++b) s = fma(T[a * NB + b], ssum[b], s);
+            zs[a] = s;
+        }
+        __syncthreads();
+        const int il = i - base;
+        if (il >= 0 && i < m) {
+            double v[NB];
+            load_v_row(v, A + (int64_t)(off0 + p * NB) * ld + off0 + base, ld, il, true);
+#pragma unroll
+            for (int a = 0; a < NB; ++a) ri = fma(-v[a], zs[a], ri);
+            r[i] = ri;
+        }
+    }
+    if (p > 0) {
+        const int q = p - 1, base = q * NB + NB, il = i - base;
+        const bool ok = il >= 0 && i < m;
+        double v[NB], prod[NB];
+        load_v_row(v, A + (int64_t)(off0 + q * NB) * ld + off0 + base, ld, il, ok);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) prod[a] = v[a] * ri;
+        const double tot = block_colsum32(prod, Pt, red);
+        if (threadIdx.x < NB) part[((size_t)(q & 1) * B32_BT_MAXBLK + blockIdx.x) * NB + threadIdx.x] = tot;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------- GCV terms on the band --
+// One lambda, one direction: LDL' of M = Bb + lambda I column by column on a window of 34 live rows in LDS, 256 threads, one
+// barrier per column, carrying d/dlambda of every quantity (DERIV).  Logical index jj runs from the top (dir 0: matrix
+// index jj) or from the bottom (dir 1: matrix index m-1-jj); the sweep eliminates `ncols` columns and leaves the window
+// holding the 32 x 32 block behind them (the middle block of the twisted factorisation, with the eliminated part's Schur
+// complement folded in), which b32_mid_kernel joins with the other direction's.  STORE (the final solve): the factor's
+// columns and the forward-substituted right-hand side go to global memory.
+//   window: entry (r, c), r >= c, at Wb[r mod 40][r - c] -- band-relative, so only ROW indices wrap and every column offset
+//   a thread needs is a constant of the thread; the 528 entries (jj + i, jj + k), 1 <= k <= i <= 32, a step updates are
+//   dealt to the threads as three slots each (slot e = tid + 256 q; rows of the triangle are contiguous in e).
+constexpr int SW = 64;                       // rows jj .. jj + 33 are live; index mod 64 (one v_and)
+constexpr int SWS = NB + 2;                  // row stride (doubles): offsets 0 .. 32 = the band, 33 = the right-hand side y
+constexpr int SYO = NB + 1;                  // offset of y in a row
+constexpr int SDUMMY = SW * SWS;             // where idle slots write
+constexpr int SCH = 7;                       // rows per staging chunk (7 x 34 = 238 values: one register per thread)
+constexpr int SWIN = 2 * NB * NB + 2 * NB;   // doubles of a stored window: W, dW (32 x 32, [a][b]), y, dy
+struct SweepLds {
+    double W[SW * SWS + 2], dW[SW * SWS + 2];
+    double stage[2][SCH][NB + 2];            // [..][33] = g of the row
+};
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // no vmcnt(0): the staging loads stay in flight
+
+// A step subtracts p_i l_k from entry (jj + i, jj + k) for 1 <= k <= i <= 32 (528 entries) and p_i (y_jj / d) from y_(jj+i)
+// (32 more: the right-hand side rides along as offset 33 of every row, "k = 0, offset 33").  560 slots, three per thread
+// (slot e = tid + 256 q); the step is straight-line code -- all of a thread's LDS reads are issued before anything waits,
+// idle slots write to a dummy word -- because a chain of predicated read-modify-write blocks costs an LDS round trip each.
+struct SweepSlots { int i[3], k[3], offk[3], offw[3]; bool on[3]; };
+__device__ __forceinline__ SweepSlots sweep_slots() {
+    SweepSlots s;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = threadIdx.x + 256 * q, ntri = NB * (NB + 1) / 2;
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);      // row of the triangle: i (i - 1) / 2 <= e < i (i + 1) / 2
+        while (i * (i - 1) / 2 > e) --i;
+        while (i * (i + 1) / 2 <= e) ++i;
+        if (e < ntri) { s.on[q] = true; s.i[q] = i; s.k[q] = e - i * (i - 1) / 2 + 1; s.offk[q] = s.k[q]; s.offw[q] = i - s.k[q]; }
+        else if (e < ntri + NB) { s.on[q] = true; s.i[q] = e - ntri + 1; s.k[q] = 0; s.offk[q] = SYO; s.offw[q] = SYO; }
+        else { s.on[q] = false; s.i[q] = 1; s.k[q] = 1; s.offk[q] = 1; s.offw[q] = 0; }
+    }
+    return s;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ void sweep_step(SweepLds &L, const SweepSlots &sl, int o, double &neg, double &tr, double &q2,
+                                           double *__restrict__ Lcol, double *__restrict__ ycol) {
+    int ai[3], ak[3], aw[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ri = (o + sl.i[q]) & (SW - 1), rk = (o + sl.k[q]) & (SW - 1);
+        ai[q] = ri * SWS + sl.i[q]; ak[q] = rk * SWS + sl.offk[q];
+        aw[q] = sl.on[q] ? ri * SWS + sl.offw[q] : SDUMMY;
+    }
+    double d = L.W[o * SWS], dd = 0.0, pi[3], pk[3], w[3], dpi[3], dpk[3], dw[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { pi[q] = L.W[ai[q]]; pk[q] = L.W[ak[q]]; w[q] = L.W[aw[q]]; }
+    if (DERIV) {
+        dd = L.dW[o * SWS];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { dpi[q] = L.dW[ai[q]]; dpk[q] = L.dW[ak[q]]; dw[q] = L.dW[aw[q]]; }
+    }
+    if (d == 0.0) d = -1e-300;
+    const double inv = frcp(d);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double lk = pk[q] * inv;
+        L.W[aw[q]] = w[q] - pi[q] * lk;
+        if (DERIV) {
+            const double dlk = (dpk[q] - lk * dd) * inv;
+            L.dW[aw[q]] = dw[q] - (dpi[q] * lk + pi[q] * dlk);
+        }
+        if (Lcol && sl.on[q] && sl.k[q] == 0) Lcol[sl.i[q]] = pi[q] * inv;
+    }
+    if ((threadIdx.x >> 6) == 2) {      // one wave keeps the books (lane 0's copy is the one written out)
+        const double y0 = L.W[o * SWS + SYO];
+        if (d < 0.0) neg += 1.0;
+        if (DERIV) {
+            const double dy0 = L.dW[o * SWS + SYO];
+            tr += dd * inv;
+            q2 -= (2.0 * y0 * dy0 * d - y0 * y0 * dd) * (inv * inv);
+        }
+        if (Lcol && threadIdx.x == 128) { Lcol[0] = d; *ycol = y0; }
+    }
+}
+
+// value of the band at logical (row r, column r - d) and of g at logical row r
+__device__ __forceinline__ double band_at(const double *__restrict__ ab, int m, int dir, int r, int d) {
+    if (r - d < 0 || r >= m) return 0.0;
+    return dir == 0 ? ab[(int64_t)(r - d) * (NB + 1) + d] : ab[(int64_t)(m - 1 - r) * (NB + 1) + d];
+}
+
+template <bool DERIV, bool STORE>
+__global__ __launch_bounds__(256) void b32_sweep_kernel(const double *__restrict__ ab, const double *__restrict__ g, int m, int n0,
+                                                        int n1, const double *__restrict__ lams, double *__restrict__ win,
+                                                        double *__restrict__ res, double *__restrict__ Lbuf,
+                                                        double *__restrict__ ybuf) {
+    __shared__ SweepLds L;
+    const int dir = blockIdx.y, ncols = dir == 0 ? n0 : n1;
+    const double lam = lams[blockIdx.x];
+    const int tid = threadIdx.x;
+    const SweepSlots sl = sweep_slots();
+    for (int e = tid; e < SW * SWS + 2; e += 256) { L.W[e] = 0.0; L.dW[e] = 0.0; }
+    __syncthreads();
+    const int last_row = STORE ? m - 1 : min(m - 1, ncols + NB - 1);      // rows the sweep needs
+    // rows 0 .. 32
+    for (int e = tid; e < (NB + 1) * (NB + 1); e += 256) {
+        const int r = e / (NB + 1), dgl = e - r * (NB + 1);
+        if (dgl <= r && r <= last_row) {
+            L.W[r * SWS + dgl] = band_at(ab, m, dir, r, dgl) + (dgl == 0 ? lam : 0.0);
+            if (DERIV && dgl == 0) L.dW[r * SWS] = 1.0;
+        }
+    }
+    if (tid <= NB && tid <= last_row) L.W[tid * SWS + SYO] = g[dir == 0 ? tid : m - 1 - tid];
+    // staging: chunk c = rows 33 + 7 c .. 39 + 7 c, entered at steps 7 c .. 7 c + 6; thread (srr, sd): offset sd of row srr
+    const int srr = tid / (NB + 2), sd = tid - srr * (NB + 2);
+    auto fetch = [&](int c) -> double {
+        const int r = NB + 1 + SCH * c + srr;
+        if (tid >= SCH * (NB + 2) || r > last_row) return 0.0;
+        return sd <= NB ? band_at(ab, m, dir, r, sd) : g[dir == 0 ? r : m - 1 - r];
+    };
+    auto stash = [&](int buf, double v) { if (tid < SCH * (NB + 2)) L.stage[buf][srr][sd] = v; };
+    stash(0, fetch(0));
+    __syncthreads();
+    double neg = 0.0, tr = 0.0, q2 = 0.0, pending = 0.0;
+    int o = 0, cstep = 0, chunk = 0;
+    double *Lcol = nullptr, *ycol = nullptr;
+    for (int jj = 0; jj < ncols; ++jj) {
+        if (cstep == 0) pending = fetch(chunk + 1);
+        if (STORE) {
+            const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj);      // dir 1's columns follow dir 0's in the buffers
+            Lcol = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1);
+            ycol = ybuf + col + (int64_t)blockIdx.x * (n0 + n1);
+        }
+        sweep_step<DERIV>(L, sl, o, neg, tr, q2, Lcol, ycol);
+        if ((tid >> 6) == 3) {      // the last wave: row jj + 33 enters (its slot held row jj - 31, long dead)
+            const int lane = tid & 63, pr = (o + NB + 1) & (SW - 1);
+            if (lane <= SYO) {
+                const double v = L.stage[chunk & 1][cstep][lane];      // zero past the last row (fetch)
+                L.W[pr * SWS + lane] = v + (lane == 0 && jj + NB + 1 <= last_row ? lam : 0.0);
+                if (DERIV) L.dW[pr * SWS + lane] = lane == 0 && jj + NB + 1 <= last_row ? 1.0 : 0.0;
+            }
+        }
+        if (cstep == SCH - 1) { stash((chunk + 1) & 1, pending); cstep = 0; ++chunk; }
+        else ++cstep;
+        o = (o + 1) & (SW - 1);
+        lds_barrier();
+    }
+    // the block behind the eliminated columns: logical rows / columns ncols .. ncols + 31
+    double *wout = win + ((int64_t)blockIdx.x * 2 + dir) * SWIN;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int a = e >> 5, b = e & 31;
+        if (b <= a) {
+            const int pa = (o + a) & (SW - 1);
+            wout[e] = L.W[pa * SWS + (a - b)];
+            wout[NB * NB + e] = DERIV ? L.dW[pa * SWS + (a - b)] : 0.0;
+        }
+    }
+    if (tid < NB) {
+        const int pa = (o + tid) & (SW - 1);
+        wout[2 * NB * NB + tid] = L.W[pa * SWS + SYO];
+        wout[2 * NB * NB + NB + tid] = DERIV ? L.dW[pa * SWS + SYO] : 0.0;
+    }
+    if (tid == 128) {
+        double *r3 = res + ((int64_t)blockIdx.x * 2 + dir) * 4;
+        r3[0] = neg; r3[1] = tr; r3[2] = q2;
+    }
+}
+
+// joins the two directions of one lambda: S = Wtop + Wbot (mirrored) - (the block itself), eliminates its mb columns
+template <bool DERIV>
+__global__ __launch_bounds__(256) void b32_mid_kernel(const double *__restrict__ ab, const double *__restrict__ g, int m, int mid,
+                                                      int mb, const double *__restrict__ lams, const double *__restrict__ win,
+                                                      const double *__restrict__ res, double *__restrict__ out) {
+    __shared__ SweepLds L;
+    const int tid = threadIdx.x;
+    const double lam = lams[blockIdx.x];
+    const double *wt = win + ((int64_t)blockIdx.x * 2) * SWIN, *wb = wt + SWIN;
+    const SweepSlots sl = sweep_slots();
+    for (int e = tid; e < SW * SWS + 2; e += 256) { L.W[e] = 0.0; L.dW[e] = 0.0; }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int a = e >> 5, b = e & 31;
+        if (b <= a && a < mb) {
+            const int eb = (mb - 1 - b) * NB + (mb - 1 - a);      // the other direction counts the block's rows backwards
+            const double orig = ab[(int64_t)(mid + b) * (NB + 1) + (a - b)] + (a == b ? lam : 0.0);
+            L.W[a * SWS + (a - b)] = (wt[e] + wb[eb]) - orig;
+            if (DERIV) L.dW[a * SWS + (a - b)] = (wt[NB * NB + e] + wb[NB * NB + eb]) - (a == b ? 1.0 : 0.0);
+        }
+    }
+    if (tid < mb) {
+        L.W[tid * SWS + SYO] = (wt[2 * NB * NB + tid] + wb[2 * NB * NB + (mb - 1 - tid)]) - g[mid + tid];
+        if (DERIV) L.dW[tid * SWS + SYO] = wt[2 * NB * NB + NB + tid] + wb[2 * NB * NB + NB + (mb - 1 - tid)];
+    }
+    __syncthreads();
+    double neg = 0.0, tr = 0.0, q2 = 0.0;
+    for (int jj = 0; jj < mb; ++jj) {
+        sweep_step<DERIV>(L, sl, jj, neg, tr, q2, nullptr, nullptr);
+        lds_barrier();
+    }
+    if (tid == 128) {
+        const double *r0 = res + (int64_t)blockIdx.x * 8, *r1 = r0 + 4;
+        out[blockIdx.x * 4 + 0] = neg + r0[0] + r1[0];
+        out[blockIdx.x * 4 + 1] = tr + r0[1] + r1[1];
+        out[blockIdx.x * 4 + 2] = q2 + r0[2] + r1[2];
+    }
+}
+
+// ================================================================================================ host side ==
+int band32_npanels(int m) {
+    int np = 0;
+    for (int c = 0; m - c - NB >= 2; c += NB) ++np;
+    return np;
+}
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t band32_layout(Band32Ws *w, char *base, int m, int64_t n) {
+    size_t off = 0;
+    auto take = [&](size_t doubles) -> double * {
+        off = al256(off);
+        double *p = base ? (double *)(base + off) : nullptr;
+        off += doubles * sizeof(double);
+        return p;
+    };
+    const size_t vs = (size_t)n, np = (size_t)std::max(1, band32_npanels(m));
+    Band32Ws d;
+    d.Gp1 = take((size_t)MAXPART_H * NB * NB);
+    d.Gp2 = take((size_t)MAXPART_H * NB * NB);
+    d.R1 = take(NB * NB);
+    d.Qtop = take(NB * NB);
+    d.aux = take(AUX_SIZE + 32);
+    for (int k = 0; k < 2; ++k) { d.Zc[k] = take(2 * NB * vs + 16); d.Vr[k] = take(((size_t)m + 256) * NB); }
+    d.Yp = take((size_t)SYMM_MAXSPLIT * NB * vs);
+    d.Wh = take(((size_t)m + 256) * NB);
+    d.Mp = take((size_t)MAXPART_H * NB * NB);
+    d.sgp = take((size_t)MAXPART_H * NB);
+    d.Tall = take(np * NB * NB);
+    d.ab = take((size_t)m * (NB + 1) + 64);
+    d.win = take((size_t)B32_MAXLAM * 2 * SWIN);
+    d.res = take((size_t)B32_MAXLAM * 8);
+    d.lamd = take((size_t)B32_MAXLAM);
+    d.out = take((size_t)B32_MAXLAM * 4);
+    d.Lbuf = take((size_t)m * (NB + 1) + 64);
+    d.ybuf = take((size_t)m + 64);
+    d.btpart = take((size_t)2 * B32_BT_MAXBLK * NB);
+    off = al256(off);
+    d.flags = base ? (int *)(base + off) : nullptr;
+    off += 256;
+    if (w) *w = d;
+    return off;
+}
+size_t band32_workspace_bytes(int m, int64_t n) { return band32_layout(nullptr, nullptr, m, n); }
+void band32_carve(Band32Ws &w, char *base, int m, int64_t n) { (void)band32_layout(&w, base, m, n); }
+
+int band32_pinned(FitLane &L, double **out) {
+    if (!L.pinned) MHS_HIP(hipHostMalloc((void **)&L.pinned, sizeof(double) * (size_t)B32_MAXLAM * 8, hipHostMallocDefault));
+    *out = L.pinned;
+    return MHS_OK;
+}
+
+// chunks of 256 rows per block so that a panel has at most MAXPART row blocks
+static inline void row_blocks(int t, int *cpb, int *nblk) {
+    const int nch = (t + CHR - 1) / CHR;
+    *cpb = (nch + B32_MAXPART - 1) / B32_MAXPART;
+    *nblk = (nch + *cpb - 1) / *cpb;
+}
+
+int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t ld, int m, int64_t vs, double *g_dev, Band32Ws &ws,
+                  int *breakdown) {
+    const int npanels = band32_npanels(m), off0 = 3;
+    std::vector<hipEvent_t> &pool = L.pool;
+    while ((int)pool.size() < 2 * npanels + 2) {
+        hipEvent_t e;
+        MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pool.push_back(e);
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        MHS_HIP(hipFuncSetAttribute((const void *)b32_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32_W_LDS));
+        attr_done = true;
+    }
+    MHS_HIP(hipMemsetAsync(ws.flags, 0, sizeof(int), s));
+    hipEvent_t pending_rest = nullptr;
+    for (int p = 0; p < npanels; ++p) {
+        const int c = p * NB, t = m - c - NB, c0 = off0 + c, r0 = off0 + c + NB;
+        double *Zc = ws.Zc[p & 1], *Vr = ws.Vr[p & 1], *Tp = ws.Tall + (size_t)p * NB * NB, *gp = g_dev + c + NB;
+        int cpb, nblk;
+        row_blocks(t, &cpb, &nblk);
+        int nsg = nblk;
+        if (t >= 64) {
+            hipLaunchKernelGGL(b32_gram_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1);
+            hipLaunchKernelGGL(b32_cholqr1_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1, nblk, ws.Gp2, ws.R1, ws.Qtop, ws.flags);
+            hipLaunchKernelGGL(b32_cholqr2_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp2, nblk, ws.Qtop, Zc, vs, Vr, ws.aux,
+                               gp, ws.sgp, ws.flags);
+        } else {
+            hipLaunchKernelGGL(b32_panel_small_kernel, dim3(1), dim3(256), 0, s, A, ld, c0, r0, t, Zc, vs, Vr, Tp, gp, ws.sgp);
+            nsg = 1; cpb = 1; nblk = 1;
+        }
+        // Y = A22 V: the whole trailing matrix as the previous panel's update left it
+        if (pending_rest) { MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0)); pending_rest = nullptr; }
+        const int nrb = (t + 63) / 64;
+        int nsplit = std::max(1, std::min(SYMM_MAXSPLIT, (512 + nrb / 2) / nrb));
+        int wsplit = (((t + nsplit - 1) / nsplit) + 15) & ~15;
+        nsplit = (t + wsplit - 1) / wsplit;
+        hipLaunchKernelGGL(b32_symm_kernel, dim3(nrb + 1, nsplit), dim3(256), 0, s, A, ld, r0, t, Vr, ws.Yp, vs, wsplit, t >= 64 ? 1 : 0, ws.aux, ws.R1, Tp);
+        hipLaunchKernelGGL(b32_w_kernel, dim3(nblk), dim3(256), B32_W_LDS, s, t, cpb, nsplit, ws.Yp, vs, Vr, Tp, ws.sgp, nsg, gp, ws.Wh, ws.Mp);
+        hipLaunchKernelGGL(b32_wfin_kernel, dim3(nblk), dim3(256), 0, s, t, cpb, ws.Mp, nblk, Tp, Vr, ws.Wh, Zc + (int64_t)NB * vs, vs);
+        const int nt = (t + RK_T - 1) / RK_T;
+        hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt), dim3(256), 0, s, A, ld, r0, t, Zc, vs, nt, 1);
+        if (nt > 1) {
+            hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
+            MHS_HIP(hipEventRecord(ev_block, s));
+            MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
+            hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt * (nt - 1)), dim3(256), 0, s2, A, ld, r0, t, Zc, vs, nt, 0);
+            MHS_HIP(hipEventRecord(ev_rest, s2));
+            pending_rest = ev_rest;
+        }
+    }
+    if (pending_rest) MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0));
+    hipLaunchKernelGGL(b32_extract_kernel, dim3((unsigned)((m * (NB + 1) + 255) / 256)), dim3(256), 0, s, A, ld, off0, m, ws.ab);
+    MHS_HIP(hipGetLastError());
+    int h_flags = 0;
+    MHS_HIP(hipMemcpyAsync(&h_flags, ws.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    *breakdown = h_flags != 0;
+    return MHS_OK;
+}
+
+int band32_qt(hipStream_t s, const double *A, int64_t ld, int m, const double *Tall, double *g_dev, double *sgp) {
+    const int npanels = band32_npanels(m), off0 = 3;
+    for (int p = 0; p < npanels; ++p) {
+        const int c = p * NB, t = m - c - NB, c0 = off0 + c, r0 = off0 + c + NB;
+        int cpb, nblk;
+        row_blocks(t, &cpb, &nblk);
+        if (t < 64) { cpb = 1; nblk = 1; }
+        hipLaunchKernelGGL(b32_qt_part_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, g_dev + c + NB, sgp);
+        hipLaunchKernelGGL(b32_qt_apply_kernel, dim3((t + CHR - 1) / CHR), dim3(256), 0, s, A, ld, c0, r0, t, Tall + (size_t)p * NB * NB, sgp, nblk,
+                           g_dev + c + NB);
+    }
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
+int band32_backtransform(hipStream_t s, const double *A, int64_t ld, int m, const double *Tall, double *r_dev, double *btpart) {
+    const int npanels = band32_npanels(m);
+    const unsigned nblk = (unsigned)((m + CHR - 1) / CHR);
+    if (nblk > (unsigned)B32_BT_MAXBLK) { set_error("band32_backtransform: order %d too large", m); return MHS_ERR_INVALID; }
+    for (int p = npanels; p >= 0; --p)
+        hipLaunchKernelGGL(b32_bt_step_kernel, dim3(nblk), dim3(256), 0, s, A, ld, 3, m, p, npanels, Tall, r_dev, btpart);
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------- the search --
+static inline void split_mid(int m, int *mid, int *mb, int *n0, int *n1) {
+    *mb = std::min(NB, m);
+    *mid = std::max(0, (m - NB) / 2);
+    *n0 = *mid;
+    *n1 = m - *mid - *mb;
+}
+
+int Band32Search::eval_batch(const double *lam, int count, bool deriv, double *neg, double *tr, double *q2) {
+    int mid, mb, n0, n1;
+    split_mid(m, &mid, &mb, &n0, &n1);
+    for (int base = 0; base < count; base += B32_MAXLAM) {
+        const int nl = std::min(B32_MAXLAM, count - base);
+        double *hl = pin, *hr = pin + B32_MAXLAM;
+        memcpy(hl, lam + base, sizeof(double) * nl);
+        double *dl = ws->lamd;
+        MHS_HIP(hipMemcpyAsync(dl, hl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
+        if (deriv) {
+            hipLaunchKernelGGL((b32_sweep_kernel<true, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
+                               (double *)nullptr, (double *)nullptr);
+            hipLaunchKernelGGL((b32_mid_kernel<true>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
+        } else {
+            hipLaunchKernelGGL((b32_sweep_kernel<false, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
+                               (double *)nullptr, (double *)nullptr);
+            hipLaunchKernelGGL((b32_mid_kernel<false>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
+        }
+        MHS_HIP(hipGetLastError());
+        MHS_HIP(hipMemcpyAsync(hr, ws->out, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, s));
+        MHS_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nl; ++i) {
+            if (neg) neg[base + i] = hr[4 * i];
+            if (tr) tr[base + i] = hr[4 * i + 1];
+            if (q2) q2[base + i] = hr[4 * i + 2];
+        }
+        ++rounds;
+    }
+    return MHS_OK;
+}
+
+void Band32Search::gcv_from_terms(double lam, double tr_inv, double qq, double *gcv, double *tra) const {
+    const double rss = lam * lam * qq;
+    const double trv = 3.0 + (double)m - lam * tr_inv;
+    double mse = rss / (double)n;
+    if (N - n > 0) mse += pure_ss / (double)(N - n);
+    const double den = 1.0 - trv / (double)n;
+    if (gcv) *gcv = den > 0 ? mse / (den * den) : NAN;
+    if (tra) *tra = trv;
+}
+
+// The two extreme eigenvalues by multi-section on the inertia count, P points per bracket and round (a constant: the
+// sequence of brackets, hence the last bits of lambda, must not depend on anything but the band).  emax starts from
+// [largest diagonal entry, Gershgorin bound], emin from (hi 2^-200, smallest diagonal entry]; a bracket whose ends are
+// positive and more than a factor 4 apart is cut geometrically, otherwise linearly.
+static const int EIG_P = 63;
+static const double EIG_TOL = 1e-10;      // lambda moves by about half the relative error of either end (they only place the grid)
+int Band32Search::find_lambda(int mode, double *lam_out) {
+    const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gcv32 m=%d] %-24s %8.3f ms (%d rounds so far)\n", m, what, std::chrono::duration<double, std::milli>(now - t_last).count(), rounds);
+        t_last = now;
+    };
+    const int W = NB + 1;
+    double dmax = ab_host[0], dmin = ab_host[0], ghi = ab_host[0];
+    for (int j = 0; j < m; ++j) {
+        double r = 0.0;
+        for (int d = 1; d <= NB; ++d) {
+            if (j + d < m) r += fabs(ab_host[(size_t)j * W + d]);
+            if (j - d >= 0) r += fabs(ab_host[(size_t)(j - d) * W + d]);
+        }
+        const double a = ab_host[(size_t)j * W];
+        dmax = std::max(dmax, a); dmin = std::min(dmin, a); ghi = std::max(ghi, a + r);
+    }
+    if (!(dmin > 0.0)) { set_error("mhs_tps_fit: the projected matrix has a non-positive diagonal entry"); return MHS_ERR_NUMERIC; }
+    double lo[2] = {dmax, dmin * ldexp(1.0, -200)}, hi[2] = {ghi * (1.0 + 1e-12) + 1e-300, dmin};
+    const int64_t kth[2] = {m - 1, 0};
+    bool done[2] = {false, false};
+    std::vector<double> xs(2 * EIG_P), cnt(2 * EIG_P);
+    {   // the ends themselves: count(lo) must not exceed k, count(hi) must
+        double e4[4] = {-lo[0], -hi[0], -lo[1], -hi[1]}, c4[4];
+        if (int rc = eval_batch(e4, 4, false, c4, nullptr, nullptr)) return rc;
+        if (c4[0] > (double)kth[0]) lo[0] = 0.0;                 // cannot happen for an SPD matrix (emax >= every diagonal entry)
+        if (!(c4[1] > (double)kth[0])) hi[0] = 2.0 * ghi + 1.0;
+        if (c4[2] > (double)kth[1]) { done[1] = true; lo[1] = hi[1] = 1e-300; }      // an eigenvalue below every floor: as the legacy route's max(ev, 1e-300)
+        else if (!(c4[3] > (double)kth[1])) { done[1] = true; lo[1] = hi[1] = dmin; }   // emin <= every diagonal entry: equality only
+    }
+    for (int it = 0; it < 60; ++it) {
+        int live = 0;
+        for (int e = 0; e < 2; ++e) {
+            if (done[e]) continue;
+            if (hi[e] - lo[e] <= EIG_TOL * std::max(fabs(lo[e]), fabs(hi[e]))) { done[e] = true; continue; }
+            const bool geo = lo[e] > 0.0 && hi[e] > 4.0 * lo[e];
+            bool distinct = true;
+            for (int i = 0; i < EIG_P; ++i) {
+                const double f = (double)(i + 1) / (double)(EIG_P + 1);
+                const double x = geo ? lo[e] * exp(f * log(hi[e] / lo[e])) : lo[e] + (hi[e] - lo[e]) * f;
+                xs[e * EIG_P + i] = x;
+                if (!(x > lo[e]) || !(x < hi[e]) || (i > 0 && !(x > xs[e * EIG_P + i - 1]))) distinct = false;
+            }
+            if (!distinct) {
+                const double midp = 0.5 * (lo[e] + hi[e]);
+                if (midp <= lo[e] || midp >= hi[e]) { done[e] = true; continue; }
+                for (int i = 0; i < EIG_P; ++i) xs[e * EIG_P + i] = midp;
+            }
+            ++live;
+        }
+        if (!live) break;
+        std::vector<double> lamv;
+        std::vector<int> owner;
+        for (int e = 0; e < 2; ++e)
+            if (!done[e]) for (int i = 0; i < EIG_P; ++i) { lamv.push_back(-xs[e * EIG_P + i]); owner.push_back(e * EIG_P + i); }
+        std::vector<double> cv(lamv.size());
+        if (int rc = eval_batch(lamv.data(), (int)lamv.size(), false, cv.data(), nullptr, nullptr)) return rc;
+        for (size_t q = 0; q < owner.size(); ++q) cnt[owner[q]] = cv[q];
+        for (int e = 0; e < 2; ++e) {
+            if (done[e]) continue;
+            double nlo = lo[e], nhi = hi[e];
+            for (int i = 0; i < EIG_P; ++i) {
+                if (cnt[e * EIG_P + i] > (double)kth[e]) { nhi = xs[e * EIG_P + i]; break; }
+                nlo = xs[e * EIG_P + i];
+            }
+            lo[e] = nlo; hi[e] = nhi;
+        }
+    }
+    const double emax = 0.5 * (lo[0] + hi[0]), emin = std::max(0.5 * (lo[1] + hi[1]), 1e-300);
+    lap("extreme eigenvalues");
+    // gcv.Krig's bracket: l1 = emax 4^k until trA < 3.05, l2 = emin / 4^k until trA > 0.95 n
+    double lamb[40], negb[40], trb[40];
+    for (int i = 0; i < 20; ++i) { lamb[i] = emax * pow(4.0, i); lamb[20 + i] = emin / pow(4.0, i); }
+    if (int rc = eval_batch(lamb, 40, true, negb, trb, nullptr)) return rc;
+    double l1 = emax, l2 = emin;
+    for (int k = 0; k < 20; ++k) {
+        if (negb[k] > 0) { *lam_out = NAN; return MHS_OK; }
+        double tra;
+        gcv_from_terms(lamb[k], trb[k], 0.0, nullptr, &tra);
+        if (tra < 3.0 + 0.05) break;
+        l1 *= 4.0;
+    }
+    for (int k = 0; k < 20; ++k) {
+        if (negb[20 + k] > 0) break;
+        double tra;
+        gcv_from_terms(lamb[20 + k], trb[20 + k], 0.0, nullptr, &tra);
+        if (tra > 0.95 * (double)n) break;
+        l2 /= 4.0;
+    }
+    lap("bracket (40 evals)");
+    const int nstep = 200;
+    std::vector<double> lamv(nstep), negv(nstep), trv(nstep), q2v(nstep), gcvv(nstep);
+    const double la = log(l2), lb = log(l1);
+    for (int i = 0; i < nstep; ++i) lamv[i] = exp(la + (lb - la) * (double)i / (double)(nstep - 1));
+    if (int rc = eval_batch(lamv.data(), nstep, true, negv.data(), trv.data(), q2v.data())) return rc;
+    std::vector<double> grid, gv;
+    for (int i = 0; i < nstep; ++i) {
+        double gcv = NAN;
+        if (!(negv[i] > 0)) gcv_from_terms(lamv[i], trv[i], q2v[i], &gcv, nullptr);
+        if (!std::isnan(gcv)) { grid.push_back(lamv[i]); gv.push_back(gcv); }
+    }
+    lap("grid (200 evals)");
+    if (grid.empty()) { *lam_out = NAN; return MHS_OK; }
+    size_t il = 0;
+    for (size_t i = 1; i < gv.size(); ++i) if (gv[i] < gv[il]) il = i;
+    if (il == 0 || il + 1 == gv.size()) { *lam_out = grid[il]; return MHS_OK; }
+    // Golden sections, expanded speculatively: the points a search visits depend on the path of comparisons only, so the
+    // tree of the next DEPTH steps (2^(DEPTH+1) - 2 points) is evaluated in ONE round and the true path replayed on it --
+    // the very iterates of the sequential search (same formulas, same operands), DEPTH steps per round.
+    auto fbatch = [&](const std::vector<double> &pts, std::vector<double> &vals, bool is_log) -> int {
+        std::vector<double> lv(pts.size()), ng(pts.size()), tv(pts.size()), qv(pts.size());
+        for (size_t i = 0; i < pts.size(); ++i) lv[i] = is_log ? exp(pts[i]) : pts[i];
+        if (int rc = eval_batch(lv.data(), (int)lv.size(), true, ng.data(), tv.data(), qv.data())) return rc;
+        vals.resize(pts.size());
+        for (size_t i = 0; i < pts.size(); ++i) {
+            double gcv = NAN;
+            if (!(ng[i] > 0)) gcv_from_terms(lv[i], tv[i], qv[i], &gcv, nullptr);
+            vals[i] = gcv;
+        }
+        return MHS_OK;
+    };
+    const int DEPTH = 7;
+    if (mode == MHS_GCV_FIELDS) {      // golden.section.search, tol = 0.01 GCVmin, at most 25 steps
+        const double r = 0.61803399, con = 1.0 - r, tol = 0.01 * gv[il];
+        const double ax = grid[il - 1], bx = grid[il], cx = grid[il + 1];
+        struct St { double x0, x1, x2, x3; };
+        St st;
+        st.x0 = ax; st.x3 = cx;
+        if (fabs(cx - bx) > fabs(bx - ax)) { st.x1 = bx; st.x2 = bx + con * (cx - bx); }
+        else { st.x2 = bx; st.x1 = bx - con * (bx - ax); }
+        double f1 = NAN, f2 = NAN;
+        bool have = false;
+        int steps = 0;
+        bool stop = false;
+        while (!stop && steps < 25) {
+            const int depth = std::min(DEPTH, 25 - steps);
+            // node id in a complete binary tree: root 1, child 2 id (f2 < f1) / 2 id + 1 (else); the point a child adds
+            std::vector<St> node((size_t)1 << (depth + 1));
+            std::vector<double> pts;
+            std::vector<int> slot((size_t)1 << (depth + 1), -1);
+            node[1] = st;
+            if (!have) { pts.push_back(st.x1); pts.push_back(st.x2); }
+            for (int id = 1; id < (1 << depth); ++id) {
+                const St &q = node[id];
+                St a = q, b = q;
+                a.x0 = q.x1; a.x1 = q.x2; a.x2 = r * a.x1 + con * q.x3;
+                b.x3 = q.x2; b.x2 = q.x1; b.x1 = r * b.x2 + con * q.x0;
+                node[2 * id] = a; node[2 * id + 1] = b;
+                slot[2 * id] = (int)pts.size(); pts.push_back(a.x2);
+                slot[2 * id + 1] = (int)pts.size(); pts.push_back(b.x1);
+            }
+            std::vector<double> vals;
+            if (int rc = fbatch(pts, vals, false)) return rc;
+            if (!have) { f1 = vals[0]; f2 = vals[1]; have = true; }
+            int id = 1;
+            for (int d = 0; d < depth && !stop; ++d) {
+                if (f2 < f1) { id = 2 * id; f1 = f2; f2 = vals[slot[id]]; }
+                else { id = 2 * id + 1; f2 = f1; f1 = vals[slot[id]]; }
+                ++steps;
+                if (fabs(f2 - f1) < tol) stop = true;
+            }
+            st = node[id];
+        }
+        lap("golden section");
+        *lam_out = f1 < f2 ? st.x1 : st.x2;
+        return MHS_OK;
+    }
+    // converged: golden section on log(lambda) down to 1e-13
+    {
+        double lo2 = log(grid[il - 1]), hi2 = log(grid[il + 1]);
+        const double r = 0.5 * (sqrt(5.0) - 1.0);
+        struct St { double lo, hi, x1, x2; };
+        St st;
+        st.lo = lo2; st.hi = hi2; st.x1 = hi2 - r * (hi2 - lo2); st.x2 = lo2 + r * (hi2 - lo2);
+        double f1 = NAN, f2 = NAN;
+        bool have = false, stop = false;
+        int steps = 0;
+        while (!stop && steps < 200) {
+            const int depth = std::min(DEPTH, 200 - steps);
+            std::vector<St> node((size_t)1 << (depth + 1));
+            std::vector<double> pts;
+            std::vector<int> slot((size_t)1 << (depth + 1), -1);
+            node[1] = st;
+            if (!have) { pts.push_back(st.x1); pts.push_back(st.x2); }
+            for (int id = 1; id < (1 << depth); ++id) {
+                const St &q = node[id];
+                St a = q, b = q;
+                a.hi = q.x2; a.x2 = q.x1; a.x1 = a.hi - r * (a.hi - a.lo);          // f1 < f2
+                b.lo = q.x1; b.x1 = q.x2; b.x2 = b.lo + r * (b.hi - b.lo);          // else
+                node[2 * id] = a; node[2 * id + 1] = b;
+                slot[2 * id] = (int)pts.size(); pts.push_back(a.x1);
+                slot[2 * id + 1] = (int)pts.size(); pts.push_back(b.x2);
+            }
+            std::vector<double> vals;
+            if (int rc = fbatch(pts, vals, true)) return rc;
+            if (!have) { f1 = vals[0]; f2 = vals[1]; have = true; }
+            int id = 1;
+            for (int d = 0; d < depth && !stop; ++d) {
+                if (f1 < f2) { id = 2 * id; f2 = f1; f1 = vals[slot[id]]; }
+                else { id = 2 * id + 1; f1 = f2; f2 = vals[slot[id]]; }
+                ++steps;
+                if (fabs(node[id].hi - node[id].lo) < 1e-13) stop = true;
+            }
+            st = node[id];
+        }
+        lap("golden section (converged)");
+        *lam_out = exp(0.5 * (st.lo + st.hi));
+    }
+    return MHS_OK;
+}
+
+// q = (Bb + lambda I)^-1 g: the twisted sweep once more with the factor stored, then the joint block and the two back
+// substitutions on the host (O(33 m) work on 1.3 MB at n = 5 000).
+int Band32Search::solve(double lam, double *gcv, double *eff_df, double *q_host) {
+    int mid, mb, n0, n1;
+    split_mid(m, &mid, &mb, &n0, &n1);
+    const int W = NB + 1;
+    double *dl = ws->lamd;
+    pin[0] = lam;
+    MHS_HIP(hipMemcpyAsync(dl, pin, sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((b32_sweep_kernel<true, true>), dim3(1, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
+    MHS_HIP(hipGetLastError());
+    std::vector<double> Lh((size_t)(n0 + n1) * W + 1), yh((size_t)(n0 + n1) + 1), wh(2 * SWIN), rh(8);
+    MHS_HIP(hipMemcpyAsync(Lh.data(), ws->Lbuf, sizeof(double) * (size_t)(n0 + n1) * W, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipMemcpyAsync(yh.data(), ws->ybuf, sizeof(double) * (size_t)(n0 + n1), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipMemcpyAsync(wh.data(), ws->win, sizeof(double) * 2 * SWIN, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipMemcpyAsync(rh.data(), ws->res, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipStreamSynchronize(s));
+    // joint block S (mb x mb) with its derivative, right-hand side y
+    std::vector<double> S((size_t)mb * mb, 0.0), dS((size_t)mb * mb, 0.0), y(mb), dy(mb);
+    const double *wt = wh.data(), *wb = wh.data() + SWIN;
+    for (int a = 0; a < mb; ++a) {
+        for (int b = 0; b <= a; ++b) {
+            const int e = a * NB + b, eb = (mb - 1 - b) * NB + (mb - 1 - a);
+            const double orig = ab_host[(size_t)(mid + b) * W + (a - b)] + (a == b ? lam : 0.0);
+            S[(size_t)a * mb + b] = (wt[e] + wb[eb]) - orig;
+            dS[(size_t)a * mb + b] = (wt[NB * NB + e] + wb[NB * NB + eb]) - (a == b ? 1.0 : 0.0);
+        }
+        y[a] = (wt[2 * NB * NB + a] + wb[2 * NB * NB + (mb - 1 - a)]) - g_host[mid + a];
+        dy[a] = wt[2 * NB * NB + NB + a] + wb[2 * NB * NB + NB + (mb - 1 - a)];
+    }
+    // LDL' of S with the derivative carried along (the same recurrences as the device sweep), forward substitution
+    double neg = rh[0] + rh[4], tr = rh[1] + rh[5], q2 = rh[2] + rh[6];
+    std::vector<double> dm(mb), Lm((size_t)mb * mb, 0.0);
+    for (int j = 0; j < mb; ++j) {
+        double d = S[(size_t)j * mb + j];
+        if (d == 0.0) d = -1e-300;
+        if (d < 0) neg += 1.0;
+        const double dd = dS[(size_t)j * mb + j], inv = 1.0 / d;
+        tr += dd * inv;
+        q2 -= (2.0 * y[j] * dy[j] * d - y[j] * y[j] * dd) * (inv * inv);
+        dm[j] = d;
+        for (int i = j + 1; i < mb; ++i) {
+            const double pi = S[(size_t)i * mb + j], dpi = dS[(size_t)i * mb + j];
+            const double li = pi * inv, dli = (dpi - li * dd) * inv;
+            Lm[(size_t)i * mb + j] = li;
+            dy[i] -= dli * y[j] + li * dy[j];
+            y[i] -= li * y[j];
+            for (int k = j + 1; k <= i; ++k) {
+                const double pk = S[(size_t)k * mb + j], lk = pk * inv, dlk = (dS[(size_t)k * mb + j] - lk * dd) * inv;
+                dS[(size_t)i * mb + k] -= dpi * lk + pi * dlk;
+                S[(size_t)i * mb + k] -= pi * lk;
+            }
+        }
+    }
+    if (neg > 0) { set_error("mhs_tps_fit: band matrix + lambda I is not positive definite"); return MHS_ERR_NUMERIC; }
+    gcv_from_terms(lam, tr, q2, gcv, eff_df);
+    // back substitution: the joint block, then outwards on both sides
+    std::vector<double> x((size_t)m, 0.0);
+    for (int j = mb - 1; j >= 0; --j) {
+        double sacc = y[j] / dm[j];
+        for (int i = j + 1; i < mb; ++i) sacc -= Lm[(size_t)i * mb + j] * x[mid + i];
+        x[mid + j] = sacc;
+    }
+    for (int j = n0 - 1; j >= 0; --j) {
+        const double *c = &Lh[(size_t)j * W];
+        double s0 = yh[j] / c[0], s1 = 0.0;
+        for (int i = 1; i <= NB; i += 2) { s0 -= c[i] * x[j + i]; s1 -= c[i + 1] * x[j + i + 1 < m ? j + i + 1 : j + i]; }
+        x[j] = s0 + s1;
+    }
+    for (int jj = n1 - 1; jj >= 0; --jj) {
+        const double *c = &Lh[(size_t)(n0 + jj) * W];
+        const int r = m - 1 - jj;
+        double s0 = yh[n0 + jj] / c[0], s1 = 0.0;
+        for (int i = 1; i <= NB; i += 2) { s0 -= c[i] * x[r - i]; s1 -= c[i + 1] * x[r - i - 1 >= 0 ? r - i - 1 : r - i]; }
+        x[r] = s0 + s1;
+    }
+    memcpy(q_host, x.data(), sizeof(double) * (size_t)m);
+    return MHS_OK;
+}
+
+}  // namespace mhs
+
+using namespace mhs;
+
+// ---- test hooks (include/machisplin_hip.h) ------------------------------------------------------------------------
+extern "C" int mhs_band32_reduce(const double *B, const double *g, int64_t m64, double *ab, double *gq, const double *r, double *Qr,
+                                 int *breakdown) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(B && g && ab && gq && breakdown, "NULL argument");
+    MHS_REQUIRE(m64 >= 66 && m64 <= B32_MAX_M, "m must be between 66 and 32 768");
+    const int m = (int)m64;
+    const int64_t n = m + 3, ld = (n + 15) & ~(int64_t)15;
+    FitLane *L = nullptr;
+    if (int rc = fit_lane(0, &L)) return rc;
+    hipStream_t s = L->s;
+    DevBuf<double> dA, dg, dr;
+    DevBuf<char> dws;
+    MHS_HIP(dA.alloc((size_t)ld * n + 4)); MHS_HIP(dg.alloc((size_t)m + 64)); MHS_HIP(dr.alloc((size_t)m + 64));
+    MHS_HIP(dws.alloc(band32_workspace_bytes(m, n)));
+    // same placement as the fit: B starts at row / column 3, row 3 of every column on a 16-byte boundary
+    double *A = dA.p + 1;
+    MHS_HIP(hipMemsetAsync(dA.p, 0, sizeof(double) * ((size_t)ld * n + 4), s));
+    MHS_HIP(hipMemcpy2DAsync(A + 3 * ld + 3, sizeof(double) * ld, B, sizeof(double) * m, sizeof(double) * m, (size_t)m, hipMemcpyHostToDevice, s));
+    MHS_HIP(hipMemcpyAsync(dg.p, g, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    Band32Ws w;
+    band32_carve(w, dws.p, m, n);
+    if (int rc = band32_reduce(*L, s, L->s2, A, ld, m, n, dg.p, w, breakdown)) return rc;
+    MHS_HIP(hipMemcpyAsync(ab, w.ab, sizeof(double) * (size_t)m * (B32_NB + 1), hipMemcpyDeviceToHost, s));
+    MHS_HIP(hipMemcpyAsync(gq, dg.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+    if (r && Qr) {
+        MHS_HIP(hipMemcpyAsync(dr.p, r, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        if (int rc = band32_backtransform(s, A, ld, m, w.Tall, dr.p, w.btpart)) return rc;
+        MHS_HIP(hipMemcpyAsync(Qr, dr.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+    }
+    MHS_HIP(hipStreamSynchronize(s));
+    MHS_HIP(hipStreamSynchronize(L->s2));
+    return MHS_OK;
+}
+
+static int hook_search(const double *ab, const double *g, int m, Band32Search &bs, Band32Ws &w, DevBuf<char> &dws, DevBuf<double> &dg) {
+    FitLane *L = nullptr;
+    if (int rc = fit_lane(0, &L)) return rc;
+    const int64_t n = m + 3;
+    MHS_HIP(dws.alloc(band32_workspace_bytes(m, n)));
+    MHS_HIP(dg.alloc((size_t)m + 64));
+    band32_carve(w, dws.p, m, n);
+    double *pin = nullptr;
+    if (int rc = band32_pinned(*L, &pin)) return rc;
+    MHS_HIP(hipMemcpyAsync(w.ab, ab, sizeof(double) * (size_t)m * (B32_NB + 1), hipMemcpyHostToDevice, L->s));
+    MHS_HIP(hipMemcpyAsync(dg.p, g, sizeof(double) * m, hipMemcpyHostToDevice, L->s));
+    bs.s = L->s; bs.ab_dev = w.ab; bs.g_dev = dg.p; bs.ab_host = ab; bs.g_host = g; bs.m = m; bs.n = n; bs.N = n; bs.pure_ss = 0.0; bs.ws = &w; bs.pin = pin;
+    return MHS_OK;
+}
+
+extern "C" int mhs_band32_gcv_terms(const double *ab, const double *g, int64_t m, const double *lambda, int n_lambda, int deriv,
+                                    double *neg, double *tr_inv, double *gM2g) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(ab && g && lambda && neg && n_lambda >= 1 && m >= 2 && m <= B32_MAX_M, "bad arguments");
+    Band32Search bs;
+    Band32Ws w;
+    DevBuf<char> dws;
+    DevBuf<double> dg;
+    if (int rc = hook_search(ab, g, (int)m, bs, w, dws, dg)) return rc;
+    return bs.eval_batch(lambda, n_lambda, deriv != 0, neg, deriv ? tr_inv : nullptr, deriv ? gM2g : nullptr);
+}
+
+extern "C" int mhs_band32_solve(const double *ab, const double *g, int64_t m, double lambda, double *q) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(ab && g && q && m >= 2 && m <= B32_MAX_M, "bad arguments");
+    Band32Search bs;
+    Band32Ws w;
+    DevBuf<char> dws;
+    DevBuf<double> dg;
+    if (int rc = hook_search(ab, g, (int)m, bs, w, dws, dg)) return rc;
+    double gcv, df;
+    return bs.solve(lambda, &gcv, &df, q);
+}

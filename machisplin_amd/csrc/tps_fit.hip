@@ -26,6 +26,7 @@
 #include "devmath.h"
 #include "tps_host.h"
 #include "tps_chol.h"
+#include "tps_band32.h"
 
 namespace mhs {
 
@@ -1818,7 +1819,10 @@ struct ReductionEntry {
     int64_t ld = 0;
     int npanels = 0;
     double *Ared = nullptr, *Tall = nullptr, *aux = nullptr;   // device
-    std::vector<double> ab;                                    // host: m x (BW + 1)
+    std::vector<double> ab;                                    // host: m x (BW + 1), or m x 33 on the 32-column route
+    bool b32 = false;                                          // reduced by tps_band32.hip (round 4)
+    size_t bytes = 0;                                          // device bytes held (the cache's budget counts them)
+    uint64_t stamp = 0;                                        // last use (least recently used entries are evicted first)
     ~ReductionEntry() {
         for (double *q : {refl, tau, Ared, Tall, aux}) if (q) (void)hipFree(q);
         (void)hipGetLastError();
@@ -1828,8 +1832,36 @@ struct ReductionCache {
     std::mutex mu;
     bool enabled = false;
     std::unordered_multimap<uint64_t, std::shared_ptr<ReductionEntry>> map;
+    size_t bytes = 0;
+    uint64_t clock = 0;
 };
 static ReductionCache g_rcache;
+// Device bytes the cache may pin (MHS_RCACHE_MAX_MB, default 4096): a band-route entry is a full copy of the reduced matrix
+// (200 MB at n = 5 000), and a tiled Step 3 adds one per tile spline above 259 stations -- unbounded, they would compete
+// with the arenas, whose own hipMalloc failures are hard errors (round-3 advisor finding).
+static size_t rcache_budget() {
+    static const size_t b = [] { const char *e = getenv("MHS_RCACHE_MAX_MB"); const long long mb = e ? atoll(e) : 4096; return (size_t)std::max(0LL, mb) << 20; }();
+    return b;
+}
+// insert under the lock: evicts least-recently-used entries until the new one fits; an entry larger than the whole budget
+// (or a device with less than twice its size free) is not kept at all
+static void rcache_insert(uint64_t key, const std::shared_ptr<ReductionEntry> &e) {
+    std::vector<std::shared_ptr<ReductionEntry>> dead;      // freed after the lock is released (hipFree synchronises)
+    {
+        std::lock_guard<std::mutex> lk(g_rcache.mu);
+        if (!g_rcache.enabled || e->bytes > rcache_budget()) return;
+        while (g_rcache.bytes + e->bytes > rcache_budget() && !g_rcache.map.empty()) {
+            auto victim = g_rcache.map.begin();
+            for (auto it = g_rcache.map.begin(); it != g_rcache.map.end(); ++it) if (it->second->stamp < victim->second->stamp) victim = it;
+            g_rcache.bytes -= victim->second->bytes;
+            dead.push_back(std::move(victim->second));
+            g_rcache.map.erase(victim);
+        }
+        e->stamp = ++g_rcache.clock;
+        g_rcache.bytes += e->bytes;
+        g_rcache.map.emplace(key, e);
+    }
+}
 void reduction_cache_clear() {      // mhs_shutdown / mhs_init on another device: nothing of the old device survives
     std::vector<std::shared_ptr<ReductionEntry>> dead;
     {
@@ -1837,6 +1869,7 @@ void reduction_cache_clear() {      // mhs_shutdown / mhs_init on another device
         g_rcache.enabled = false;
         for (auto &kv : g_rcache.map) dead.push_back(std::move(kv.second));
         g_rcache.map.clear();
+        g_rcache.bytes = 0;
     }
 }
 static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h) {
@@ -1957,6 +1990,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     struct P { double *p; };
     P A, duv, dsw, vbuf, pbuf, wbuf, gbuf, tau, Vd, Vd2, Wd, Wd2, Yp, Mp, Tall, abd, chw, Zb, Zb2, Gp, v3buf, w3buf, ypbuf, auxb;
     const bool fixed = !std::isnan(lambda);
+    // Round 4: the GCV route of fits with 320+ unknowns is tps_band32.hip's (32-column panels, GCV on the band on the GPU);
+    // MHS_FIT_LEGACY_BAND=1 keeps the 8-column route below, which is also what a fit falls back to when a panel of the new
+    // route turns out numerically rank deficient (its Cholesky-QR needs cond(P)^2 < 1 / eps).
+    static const bool legacy_env = getenv("MHS_FIT_LEGACY_BAND") != nullptr;
+    bool use_b32 = !fixed && !legacy_env && m >= B32_MIN_M && m <= B32_MAX_M;
+    char *b32base = nullptr;
     int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme (MHS_DELAY_T overrides)
     if (const char *e = getenv("MHS_DELAY_T")) t_delay = std::max(BW, atoi(e));
     int *info_dev = nullptr;
@@ -1991,6 +2030,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         abd.p = ar.take<double>((size_t)m * (BW + 1));
         info_dev = ar.take<int>(1);
         tall_sc = ar.take<TallScratch>(1);
+        b32base = ar.take<char>(use_b32 ? band32_workspace_bytes(m, n) : 1);
     };
     {
         ArenaCarver dry{nullptr};
@@ -2007,18 +2047,22 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     // mhs_tps_reduction_cache: the reduction of this station set may already be there (another response layer)
     const bool small_route = !fixed && m <= TRI_SMALL_CUT && m >= 3;
     // band route: cacheable while every panel is a register-resident one (band_qt_kernel mirrors that kernel's update of g)
-    const bool band_cacheable = !fixed && !small_route && npanels > 0 && m - BW <= PANEL_THREADS * PANEL_RPT;
+    // (the register back-transform holds BT_THREADS * BT_RPT rows: a cached refit past that would read buffers it never wrote)
+    const bool band_cacheable = !fixed && !small_route && !use_b32 && npanels > 0 && m - BW <= PANEL_THREADS * PANEL_RPT && m <= BT_THREADS * BT_RPT;
     std::shared_ptr<ReductionEntry> hit_sp;
     uint64_t rkey = 0;
     bool rcache_on = false;
-    if (small_route || band_cacheable) {
+    if (small_route || band_cacheable || use_b32) {
         std::lock_guard<std::mutex> lk(g_rcache.mu);
         rcache_on = g_rcache.enabled;
         if (rcache_on) {
             rkey = fnv1a(sw.data(), sizeof(double) * sw.size(), fnv1a(uv.data(), sizeof(double) * uv.size(), 1469598103934665603ull ^ (uint64_t)n));
             auto range = g_rcache.map.equal_range(rkey);
             for (auto it = range.first; it != range.second && !hit_sp; ++it)
-                if (it->second->n == n && it->second->band == band_cacheable && it->second->uv == uv && it->second->sw == sw) hit_sp = it->second;
+                if (it->second->n == n && it->second->band == band_cacheable && it->second->b32 == use_b32 && it->second->uv == uv && it->second->sw == sw) {
+                    hit_sp = it->second;
+                    hit_sp->stamp = ++g_rcache.clock;
+                }
         }
     }
     const ReductionEntry *hit = hit_sp.get();      // kept alive by hit_sp whatever another thread does to the map
@@ -2028,64 +2072,69 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     }
 
     static const bool fused_proj = getenv("MHS_PROJ_PASSES") == nullptr;
+    auto build_A = [&]() -> int {      // the projected matrix A = Q'KQ (run again when the 32-column route hands the fit back)
     if (hit) {
-        // nothing to build: the reflectors, the tridiagonal and the projected rows come from the cache
-    } else if (fused_proj) {
-        // A = Q'KQ = K - W V' - V W' in two passes over kernel entries computed on the fly (see gram_y_kernel)
-        for (int k = 0; k < 3; ++k)
-            MHS_HIP(hipMemcpyAsync(v3buf.p + (size_t)k * n, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        const unsigned rb = (unsigned)((n + 63) / 64);
-        const unsigned nsp = (unsigned)std::min<int64_t>(GY_MAXSPLIT, std::max<int64_t>(1, (1024 + rb - 1) / rb));
-        hipLaunchKernelGGL(gram_y_kernel, dim3(rb, nsp), dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, v3buf.p, ctx().log_tab, ypbuf.p);
-        MHS_HIP(hipGetLastError());
-        std::vector<double> Yp((size_t)nsp * 3 * n), Y(3 * (size_t)n, 0.0), W(3 * (size_t)n);
-        MHS_HIP(hipMemcpyAsync(Yp.data(), ypbuf.p, sizeof(double) * Yp.size(), hipMemcpyDeviceToHost, s));
-        MHS_HIP(hipStreamSynchronize(s));
-        for (unsigned sp = 0; sp < nsp; ++sp)
-            for (size_t e = 0; e < 3 * (size_t)n; ++e) Y[e] += Yp[(size_t)sp * 3 * n + e];
-        double G[3][3], Tm3[3][3] = {{0}}, M3[3][3], S3[3][3], TM[3][3];
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                double g = 0.0, mm = 0.0;
-                for (int64_t i = 0; i < n; ++i) { g += hv[a][i] * hv[b][i]; mm += hv[a][i] * Y[(size_t)b * n + i]; }
-                G[a][b] = g; M3[a][b] = mm;
+            // nothing to build: the reflectors, the tridiagonal and the projected rows come from the cache
+        } else if (fused_proj) {
+            // A = Q'KQ = K - W V' - V W' in two passes over kernel entries computed on the fly (see gram_y_kernel)
+            for (int k = 0; k < 3; ++k)
+                MHS_HIP(hipMemcpyAsync(v3buf.p + (size_t)k * n, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            const unsigned rb = (unsigned)((n + 63) / 64);
+            const unsigned nsp = (unsigned)std::min<int64_t>(GY_MAXSPLIT, std::max<int64_t>(1, (1024 + rb - 1) / rb));
+            hipLaunchKernelGGL(gram_y_kernel, dim3(rb, nsp), dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, v3buf.p, ctx().log_tab, ypbuf.p);
+            MHS_HIP(hipGetLastError());
+            std::vector<double> Yp((size_t)nsp * 3 * n), Y(3 * (size_t)n, 0.0), W(3 * (size_t)n);
+            MHS_HIP(hipMemcpyAsync(Yp.data(), ypbuf.p, sizeof(double) * Yp.size(), hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipStreamSynchronize(s));
+            for (unsigned sp = 0; sp < nsp; ++sp)
+                for (size_t e = 0; e < 3 * (size_t)n; ++e) Y[e] += Yp[(size_t)sp * 3 * n + e];
+            double G[3][3], Tm3[3][3] = {{0}}, M3[3][3], S3[3][3], TM[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double g = 0.0, mm = 0.0;
+                    for (int64_t i = 0; i < n; ++i) { g += hv[a][i] * hv[b][i]; mm += hv[a][i] * Y[(size_t)b * n + i]; }
+                    G[a][b] = g; M3[a][b] = mm;
+                }
+            for (int j = 0; j < 3; ++j) {      // larft (forward, columnwise): Q = H1 H2 H3 = I - V T V'
+                Tm3[j][j] = htau[j];
+                for (int i = 0; i < j; ++i) {
+                    double sum = 0.0;
+                    for (int l = i; l < j; ++l) sum += Tm3[i][l] * G[l][j];
+                    Tm3[i][j] = -htau[j] * sum;
+                }
             }
-        for (int j = 0; j < 3; ++j) {      // larft (forward, columnwise): Q = H1 H2 H3 = I - V T V'
-            Tm3[j][j] = htau[j];
-            for (int i = 0; i < j; ++i) {
-                double sum = 0.0;
-                for (int l = i; l < j; ++l) sum += Tm3[i][l] * G[l][j];
-                Tm3[i][j] = -htau[j] * sum;
+            for (int a = 0; a < 3; ++a)        // S = T' (1/2 (M + M')) T
+                for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += 0.5 * (M3[a][c] + M3[c][a]) * Tm3[c][b]; TM[a][b] = t; }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += Tm3[c][a] * TM[c][b]; S3[a][b] = t; }
+            for (int64_t i = 0; i < n; ++i)
+                for (int b = 0; b < 3; ++b) {
+                    double t = 0.0;
+                    for (int c = 0; c < 3; ++c) t += Y[(size_t)c * n + i] * Tm3[c][b] - 0.5 * hv[c][i] * 0.5 * (S3[c][b] + S3[b][c]);
+                    W[(size_t)b * n + i] = t;
+                }
+            MHS_HIP(hipMemcpyAsync(w3buf.p, W.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+            dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+            hipLaunchKernelGGL(gram_proj_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld, ctx().log_tab, v3buf.p, w3buf.p, A.p);
+            MHS_HIP(hipGetLastError());
+            MHS_HIP(hipStreamSynchronize(s));      // W (host vector) is read by the copy above
+        } else {
+            dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+            hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld,
+                               ctx().log_tab, A.p);
+            // A <- H3 H2 H1 A H1 H2 H3 (full-length reflectors, leading zeros)
+            MHS_HIP(hipMemcpyAsync(tau.p + n, htau, sizeof(double) * 3, hipMemcpyHostToDevice, s));
+            for (int k = 0; k < 3; ++k) {
+                MHS_HIP(hipMemcpyAsync(vbuf.p, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, pbuf.p);
+                hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
+                hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
             }
         }
-        for (int a = 0; a < 3; ++a)        // S = T' (1/2 (M + M')) T
-            for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += 0.5 * (M3[a][c] + M3[c][a]) * Tm3[c][b]; TM[a][b] = t; }
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) { double t = 0.0; for (int c = 0; c < 3; ++c) t += Tm3[c][a] * TM[c][b]; S3[a][b] = t; }
-        for (int64_t i = 0; i < n; ++i)
-            for (int b = 0; b < 3; ++b) {
-                double t = 0.0;
-                for (int c = 0; c < 3; ++c) t += Y[(size_t)c * n + i] * Tm3[c][b] - 0.5 * hv[c][i] * 0.5 * (S3[c][b] + S3[b][c]);
-                W[(size_t)b * n + i] = t;
-            }
-        MHS_HIP(hipMemcpyAsync(w3buf.p, W.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
-        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
-        hipLaunchKernelGGL(gram_proj_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld, ctx().log_tab, v3buf.p, w3buf.p, A.p);
         MHS_HIP(hipGetLastError());
-        MHS_HIP(hipStreamSynchronize(s));      // W (host vector) is read by the copy above
-    } else {
-        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
-        hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld,
-                           ctx().log_tab, A.p);
-        // A <- H3 H2 H1 A H1 H2 H3 (full-length reflectors, leading zeros)
-        MHS_HIP(hipMemcpyAsync(tau.p + n, htau, sizeof(double) * 3, hipMemcpyHostToDevice, s));
-        for (int k = 0; k < 3; ++k) {
-            MHS_HIP(hipMemcpyAsync(vbuf.p, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, pbuf.p);
-            hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
-            hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
-        }
-    }
+        return MHS_OK;
+    };
+    if (int rc = build_A()) return rc;
     MHS_HIP(hipGetLastError());
     lap("gram + projection");
     // rows 0..2 of the projected matrix, columns 3..n-1 (by symmetry: columns 0..2, rows 3..)
@@ -2137,10 +2186,9 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                                         (size_t)m, hipMemcpyDeviceToDevice, s) == hipSuccess;
             ok = ok && hipMemcpyAsync(e->tau, tau.p, sizeof(double) * m, hipMemcpyDeviceToDevice, s) == hipSuccess;
             ok = ok && hipStreamSynchronize(s) == hipSuccess;
-            if (ok) {
-                std::lock_guard<std::mutex> lk(g_rcache.mu);
-                if (g_rcache.enabled) g_rcache.map.emplace(rkey, e);
-            } else (void)hipGetLastError();
+            e->bytes = sizeof(double) * ((size_t)m * m + (size_t)m);
+            if (ok) rcache_insert(rkey, e);
+            else (void)hipGetLastError();
         }
         TridiagGcv tg;
         tg.a = td.data(); tg.b = te.data(); tg.g = g.data(); tg.m = m; tg.n = n; tg.N = N; tg.pure_ss = pure_ss;
@@ -2156,6 +2204,66 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         MHS_HIP(hipStreamSynchronize(s));
         lap("solve + back-transform");
     } else {
+      bool done_b32 = false;
+      if (use_b32) {
+        // ---- round 4: 32-column panels, GCV on the band on the GPU (tps_band32.hip)
+        Band32Ws w32;
+        band32_carve(w32, b32base, m, n);
+        double *pin = nullptr;
+        if (int rc = band32_pinned(L, &pin)) return rc;
+        MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        const double *redA = A.p, *redT = w32.Tall;
+        int64_t red_ld = ld;
+        std::vector<double> ab32((size_t)m * (B32_NB + 1)), g((size_t)m), q((size_t)m);
+        int breakdown = 0;
+        if (hit) {
+            redA = hit->Ared; redT = hit->Tall; red_ld = hit->ld;
+            ab32 = hit->ab;
+            MHS_HIP(hipMemcpyAsync(w32.ab, ab32.data(), sizeof(double) * ab32.size(), hipMemcpyHostToDevice, s));
+            if (int rc = band32_qt(s, redA, red_ld, m, redT, gbuf.p, w32.sgp)) return rc;
+        } else {
+            if (int rc = band32_reduce(L, s, confined ? L.ms2 : L.s2, A.p, ld, m, vs, gbuf.p, w32, &breakdown)) return rc;
+        }
+        if (!breakdown) {
+            if (!hit) MHS_HIP(hipMemcpyAsync(ab32.data(), w32.ab, sizeof(double) * ab32.size(), hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipMemcpyAsync(g.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipStreamSynchronize(s));
+            lap(hit ? "Q'g with the cached 32-column reduction" : "band reduction (GPU, 32-column panels)");
+            if (!hit && rcache_on) {      // keep the reduction for the next response layer on these stations
+                const int np32 = band32_npanels(m);
+                auto e = std::make_shared<ReductionEntry>();
+                e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->Atop = Atop; e->b32 = true; e->ld = ld; e->npanels = np32; e->ab = ab32;
+                const size_t abytes = sizeof(double) * (size_t)ld * (size_t)(3 + m), tbytes = sizeof(double) * (size_t)np32 * B32_NB * B32_NB;
+                e->bytes = abytes + tbytes;
+                size_t free_b = 0, total_b = 0;
+                bool ok = e->bytes <= rcache_budget() && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * e->bytes;
+                ok = ok && hipMalloc((void **)&e->Ared, abytes) == hipSuccess && hipMalloc((void **)&e->Tall, tbytes) == hipSuccess;
+                ok = ok && hipMemcpyAsync(e->Ared, A.p, abytes, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                     hipMemcpyAsync(e->Tall, w32.Tall, tbytes, hipMemcpyDeviceToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                if (ok) rcache_insert(rkey, e);
+                else (void)hipGetLastError();
+            }
+            Band32Search bs;
+            bs.s = s; bs.ab_dev = w32.ab; bs.g_dev = gbuf.p; bs.ab_host = ab32.data(); bs.g_host = g.data(); bs.m = m; bs.n = n; bs.N = N;
+            bs.pure_ss = pure_ss; bs.ws = &w32; bs.pin = pin;
+            if (int rc = bs.find_lambda(gcv_mode, &lam)) return rc;
+            if (std::isnan(lam)) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
+            lap("GCV search (GPU, band of 32)");
+            if (int rc = bs.solve(lam, &gcv, &eff_df, q.data())) return rc;
+            MHS_HIP(hipMemcpyAsync(gbuf.p, q.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
+            if (int rc = band32_backtransform(s, redA, red_ld, m, redT, gbuf.p, w32.btpart)) return rc;
+            MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipStreamSynchronize(s));
+            lap("solve + back-transform");
+            done_b32 = true;
+        } else {
+            // a panel was numerically rank deficient: the matrix is rebuilt and the 8-column Householder route takes the fit
+            use_b32 = false;
+            if (int rc = build_A()) return rc;
+            lap("32-column route handed the fit back: matrix rebuilt");
+        }
+      }
+      if (!done_b32) {
         // reduce B to bandwidth BW in place (blocked), rotating g = Q' w2 along
         MHS_HIP(hipMemcpyAsync(gbuf.p, wv.data() + 3, sizeof(double) * m, hipMemcpyHostToDevice, s));
         const bool store_aux = band_cacheable && rcache_on && !hit;
@@ -2277,10 +2385,9 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                  hipMemcpyAsync(e->Tall, Tall.p, sizeof(double) * (size_t)npanels * BW * BW, hipMemcpyDeviceToDevice, s) == hipSuccess &&
                  hipMemcpyAsync(e->aux, auxb.p, sizeof(double) * (size_t)npanels * PANEL_AUX, hipMemcpyDeviceToDevice, s) == hipSuccess &&
                  hipStreamSynchronize(s) == hipSuccess;
-            if (ok) {
-                std::lock_guard<std::mutex> lk(g_rcache.mu);
-                if (g_rcache.enabled) g_rcache.map.emplace(rkey, e);
-            } else (void)hipGetLastError();
+            e->bytes = abytes + sizeof(double) * (size_t)npanels * (BW * BW + PANEL_AUX);
+            if (ok) rcache_insert(rkey, e);
+            else (void)hipGetLastError();
         }
         }
         BandGcv bg;
@@ -2306,6 +2413,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         MHS_HIP(hipMemcpyAsync(c2.data(), gbuf.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
         lap("solve + back-transform");
+      }
     }
 
     // d = R^-1 (w1 - Atop c2) ; c~ = Q [0; c2] ; c = W^1/2 c~

@@ -530,15 +530,17 @@ def test_ksvm_row_tile_kernel_alone_matches_the_oracle(hip, dtype, C, monkeypatc
 def test_ksvm_row_tile_kernel_keeps_the_addition_where_a_wave_spreads(hip, dtype, monkeypatch):
     """A covariate JUMP inside a wave: with q = sigma |x~|^2 / 700 spreading more than 0.5 over the wave's 192 cells the
     row-tile kernel must keep the per-pair addition (folding would flush terms the cell's back-scaling cannot restore).
-    Plane 0 steps up by 16 standard deviations from column 250 on (inside the second wave of every row), sigma = 2:
-    the spread is 2 * 16^2 / 700 = 0.73.  Rows 20.. have no jump (those waves fold).  Against the oracle at 1e-11."""
+    Plane 0 carries a spike of 16 standard deviations on three columns (250..252, inside the second wave) of rows 0..19 --
+    too few cells to move the model's centre and scale -- and sigma = 2: the spread is ~2 * 16^2 / 700 = 0.73, and a wave that
+    folded anyway would flush the terms of its ordinary cells.  Rows 20.. have no spike (those waves fold).  Against the oracle
+    at 1e-11."""
     import torch
     from machisplin_amd import synth
     nrow, ncol, C = 41, 560, 3
     g = synth.grid(nrow, ncol)
     planes, nodata = synth.covariates(g, C, 5, dtype=dtype, nodata_frac=0.01)
     sd0 = float(torch.nan_to_num(planes[0].double()).std())
-    planes[0, :20, 250:] += 16.0 * sd0
+    planes[0, :20, 250:253] += 16.0 * sd0
     stack = hip.RasterStack(g, planes, nodata)
     host = planes.cpu().numpy().astype(np.float64)
     x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, nrow, ncol)

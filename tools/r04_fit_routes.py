@@ -1,0 +1,56 @@
+"""Round 4: the GCV fit on the 32-column route (tps_band32.hip) against the 8-column route it replaces (MHS_FIT_LEGACY_BAND=1
+in a child process), lambda and coefficients compared, phases printed (MHS_FIT_TIMING=1).
+    python tools/r04_fit_routes.py [sizes...]"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+
+
+def run(sizes, tag):
+    import machisplin_amd as m
+    m.init()
+    out = {}
+    for n in sizes:
+        rng = np.random.default_rng(n)
+        cells = rng.choice(10000 * 10000, n, replace=False)
+        xy = np.column_stack([(cells % 10000 + 0.5) / 1200.0 - 78.0, -5.0 - (cells // 10000 + 0.5) / 1200.0])
+        u = (xy - xy.min(0)) / (xy.max(0) - xy.min(0))
+        y = np.sin(6 * u[:, 0]) * np.cos(5 * u[:, 1]) + 0.1 * rng.standard_normal(n)
+        best = 1e30
+        for rep in range(4):
+            if rep == 3:
+                os.environ["MHS_FIT_TIMING"] = "1"
+            t0 = time.perf_counter()
+            t = m.Tps(xy, y)
+            dt = time.perf_counter() - t0
+            os.environ.pop("MHS_FIT_TIMING", None)
+            if rep < 3:
+                best = min(best, dt)
+        mm = n - 3
+        print(f"[{tag}] n={n:6d} GCV fit {best * 1e3:9.2f} ms  lambda={t.lambda_:.12g}  eff_df={t.eff_df:.6f}  "
+              f"{4 * mm ** 3 / 3 / best / 1e12:6.2f} TF/s on 4/3 m^3 ({100 * 4 * mm ** 3 / 3 / best / 78.6e12:.1f} % of 78.6 TF)", flush=True)
+        out[n] = (t.lambda_, t.c.copy(), t.d.copy())
+    return out
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        sizes = [int(a) for a in sys.argv[3:]]
+        res = run(sizes, "8-column")
+        np.savez(sys.argv[2], **{f"lam{n}": res[n][0] for n in sizes}, **{f"c{n}": res[n][1] for n in sizes}, **{f"d{n}": res[n][2] for n in sizes})
+        sys.exit(0)
+    sizes = [int(a) for a in sys.argv[1:]] or [2000, 5000]
+    new = run(sizes, "32-column")
+    tmp = "/tmp/r04_legacy.npz"
+    env = dict(os.environ, MHS_FIT_LEGACY_BAND="1")
+    subprocess.run([sys.executable, __file__, "--child", tmp] + [str(n) for n in sizes], check=True, env=env)
+    old = np.load(tmp)
+    for n in sizes:
+        lam, c, d = new[n]
+        print(f"n={n}: lambda rel diff {abs(lam - old[f'lam{n}']) / old[f'lam{n}']:.2e}   c rel diff {np.abs(c - old[f'c{n}']).max() / np.abs(c).max():.2e}"
+              f"   d rel diff {np.abs(d - old[f'd{n}']).max() / np.abs(d).max():.2e}", flush=True)
