@@ -125,7 +125,12 @@ int fit_lane(int i, FitLane **out) {
         MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         FitLane *L = new FitLane();
         hipError_t e = hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio_hi);
+        // the second stream carries the bulk of a trailing update while the first factorises the next panel: one priority
+        // level down (MHS_FIT_S2_SAME_PRIO keeps round 3's setting), so that the panel's few blocks win a freed compute unit
+        // against the update's hundreds of queued ones
+        static const bool same_prio = getenv("MHS_FIT_S2_SAME_PRIO") != nullptr;
+        const int prio2 = (!same_prio && prio_hi < prio_lo) ? prio_hi + 1 : prio_hi;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio2);
         if (e == hipSuccess && c.masked_cus > 0 && !c.comp_mask.empty()) {
             e = hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
             if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)c.comp_mask.size(), c.comp_mask.data());

@@ -9,6 +9,7 @@ namespace mhs {
 constexpr int B32_NB = 32;               // band width of the reduction
 constexpr int B32_MAXPART = 16;          // row blocks (partial sums) per panel: their sums are loaded in ONE batch
 constexpr int B32_BT_MAXBLK = 128;       // row blocks of the back-transform (up to 32 768 unknowns)
+constexpr int B32_PANEL_REC = 2 * B32_NB * B32_NB;      // doubles a panel leaves for the back-transform: T, then the top block of V
 constexpr int B32_MIN_M = 320;           // smallest order the route is used for (below: tps_fit.hip's 8-column route)
 constexpr int B32_MAX_M = B32_BT_MAXBLK * 256;
 constexpr int B32_MAXLAM = 1024;         // lambdas per search round

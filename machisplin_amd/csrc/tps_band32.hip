@@ -183,12 +183,15 @@ __device__ __forceinline__ double block_colsum32(const double (&x)[NB], double *
     return tot;
 }
 
-// the V row of B-row il (0-based inside the panel) as the panel stores it in place: zeros above the unit diagonal
-__device__ __forceinline__ void load_v_row(double (&v)[NB], const double *__restrict__ Ppan, int64_t ld, int il, bool ok) {
+// the V row of B-row il (0-based inside the panel): rows 32.. sit in place below the band, the top block V1 (a full 32 x 32
+// matrix in the basis-kernel form, where the panel keeps the band entries) in the panel's record
+__device__ __forceinline__ void load_v_row(double (&v)[NB], const double *__restrict__ Ppan, int64_t ld, int il, bool ok,
+                                           const double *__restrict__ V1) {
+    const bool top = il < NB;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
-        const double x = Ppan[(int64_t)a * ld + (ok ? il : 0)];
-        v[a] = !ok || il < a ? 0.0 : (il == a ? 1.0 : x);
+        const double x = top ? V1[(ok ? il : 0) * NB + a] : Ppan[(int64_t)a * ld + (ok ? il : 0)];
+        v[a] = ok ? x : 0.0;
     }
 }
 // up to 16 x 32 partial sums of 32 values (added in block order) by threads 0 .. 31: loads first
@@ -282,82 +285,88 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
     store_tile32(Gout + (size_t)blockIdx.x * NB * NB, acc, ta, tb);
 }
 
-// K2: R2 = chol(Q1'Q1), Q = Q1 R2^-1; LU of [I; 0] - Q D on the top block (every block), V = -(Q D) U^-1 for its rows; dense V
-// in both layouts; partial sums of V'g.  Block 0 leaves L1, U, L2, D aside for b32_tfin (T and the band entries are not on
-// this kernel's path: they ride along with the symmetric product).  Requires t >= 32.
-constexpr int AUX_LM = 0, AUX_UT = NB * NB, AUX_L2 = 2 * NB * NB, AUX_D = 3 * NB * NB, AUX_SIZE = 3 * NB * NB + NB;
+// K2: the second Cholesky-QR pass and the Householder reconstruction WITHOUT a serial step (round 4, second form; the first
+// form -- chol(Q1'Q1), a modified LU of [I; 0] - Q D, two triangular solves per row -- spent 45 us of a 55 us kernel in its
+// 95 barrier-separated column steps):
+//   * Q1 is orthonormal up to E = Q1'Q1 - I = O(eps cond(P)^2) <= ~1e-8, so chol(I + E) is its own expansion: with Phi(X) =
+//     strict upper + half the diagonal, U = Phi(E) - Phi(Phi(E)'Phi(E)), R2 = I + U and R2^-1 = I - U + U^2, both to O(E^3);
+//     beyond max |E| = 1e-5 the panel is flagged and the fit falls back.  Q = Q1 (I - U + U^2) is one MFMA product.
+//   * the reconstruction in Yamamoto's basis-kernel form: with D_k = -sign(Q_kk) and Q^ = Q D, H = I - V T V', V = [I; 0] -
+//     Q^, T = (I - Q^_1)^-T is orthogonal and H [I; 0] = Q^ -- no triangular structure, so V is Q with its signs flipped
+//     (plus the identity on the top block V1, which goes to the panel's record because the panel keeps the band entries
+//     there) and T is a 32 x 32 inverse that nothing before b32_w_kernel needs: b32_tfin forms it beside the symmetric
+//     product.  cond(V1) stays below ~10 even for 64-row panels (the signs put Q^_1's diagonal at -|.|).
+constexpr int AUX_U = 0, AUX_D = NB * NB, AUX_SIZE = NB * NB + NB;
+constexpr int PREC = B32_PANEL_REC;      // doubles per panel record: T (32 x 32, row-major), then V1
 __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
                                                           const double *__restrict__ Gin, int nparts, const double *__restrict__ Qtop,
                                                           double *__restrict__ Zc, int64_t vs, double *__restrict__ Vr,
-                                                          double *__restrict__ aux, const double *__restrict__ g,
-                                                          double *__restrict__ sgpart, int *__restrict__ flags) {
+                                                          double *__restrict__ aux, double *__restrict__ rec,
+                                                          const double *__restrict__ g, double *__restrict__ sgpart,
+                                                          int *__restrict__ flags) {
     __shared__ double Pt[NB * PT_S];
-    __shared__ double G[NB][NB + 1];            // L2 (R2 = L2')
-    __shared__ double X[NB][NB + 1];            // top block of Q, eliminated in place
-    __shared__ double Lm[NB][NB + 1];           // L1 (strictly lower)
-    __shared__ double Ut[NB][NB + 1];           // Ut[c][k] = U[k][c]
-    __shared__ __attribute__((aligned(16))) double Lp2[TRS_SIZE], Lpu[TRS_SIZE];      // R2' and U' packed for the row solves
-    __shared__ double sd[NB], rinv[NB], Dv[NB], ruinv[NB], red[8][NB];
+    __shared__ double Em[NB][NB + 1];           // E, then I - U + U^2 (the MFMA's B operand)
+    __shared__ double U1[NB][NB + 1], Um[NB][NB + 1], Xs[NB][NB + 1], Qt[NB][NB + 1];
+    __shared__ double Dv[NB], red[8][NB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     double xrow[NB];                            // the first chunk's row of Q1
-    double qt[NB];                              // threads 0 .. 31: a row of the top block
     {
         Parts4 P;
         parts_issue(P, Gin, nparts);
-        const bool top = threadIdx.x < NB;
+        double qt4[4];
 #pragma unroll
-        for (int a = 0; a < NB; ++a) qt[a] = Qtop[(top ? threadIdx.x : 0) * NB + a];
+        for (int q = 0; q < 4; ++q) qt4[q] = Qtop[threadIdx.x + 256 * q];
         const int i = blockIdx.x * cpb * CHR + threadIdx.x;
         const double *row = A + (int64_t)c0 * ld + r0 + (i < t ? i : 0);
 #pragma unroll
         for (int a = 0; a < NB; ++a) xrow[a] = row[(int64_t)a * ld];
-        parts_sum(P, G);
-    }
-    const bool ok_chol = chol32_lds(G, sd);
-    if (threadIdx.x < NB) rinv[threadIdx.x] = 1.0 / sd[threadIdx.x];
-    if (!ok_chol && threadIdx.x == 0) atomicOr(flags, 2);
-    __syncthreads();
-    trs_pack(Lp2, G, rinv);
-    if (threadIdx.x < 64) {      // top block: Q1[0:32, :] R2^-1 (thread = row; the wave's other lanes ride along)
-        row_trsm_reg(qt, Lp2);
-        if (threadIdx.x < NB) {
+        parts_sum(P, Em);
 #pragma unroll
-            for (int a = 0; a < NB; ++a) X[threadIdx.x][a] = qt[a];
-        }
-    }
-    const int i8 = threadIdx.x >> 3, cg = threadIdx.x & 7;
-    for (int k = 0; k < NB; ++k) {      // LU of [I; 0] - Q D, signs chosen on the way (see the header)
-        __syncthreads();
-        const double piv = X[k][k];
-        const double Dk = piv >= 0.0 ? -1.0 : 1.0, ukk = 1.0 + fabs(piv);
-        const double lik = -Dk * X[i8][k] * frcp(ukk);
-        double xk[4], old[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { xk[q] = X[k][cg + 8 * q]; old[q] = X[i8][cg + 8 * q]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = cg + 8 * q;
-            if (i8 > k) X[i8][c] = c > k ? old[q] - lik * xk[q] : old[q];
-        }
-        if (i8 > k && cg == 0) Lm[i8][k] = lik;
-        if (threadIdx.x == 0) { Dv[k] = Dk; ruinv[k] = frcp(ukk); Ut[k][k] = ukk; }
+        for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Qt[e >> 5][e & 31] = qt4[q]; }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {      // U[k][c] = -D_c X[k][c] (c > k): thread (c = i8, k = cg + 8 q)
-        const int k = cg + 8 * q;
-        if (k < i8) Ut[i8][k] = -Dv[i8] * X[k][i8];
+    bool bad = false;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // E and U1 = Phi(E)
+        const int a = e >> 5, b = e & 31;
+        const double ev = 0.5 * (Em[a][b] + Em[b][a]) - (a == b ? 1.0 : 0.0);
+        bad |= !(fabs(ev) <= 1e-5);
+        U1[a][b] = a < b ? ev : (a == b ? 0.5 * ev : 0.0);
+    }
+    bad = __syncthreads_or(bad);
+    if (bad && threadIdx.x == 0) atomicOr(flags, 2);
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // X = U1'U1
+        const int a = e >> 5, b = e & 31;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NB; k += 2) { s0 = fma(U1[k][a], U1[k][b], s0); s1 = fma(U1[k + 1][a], U1[k + 1][b], s1); }
+        Xs[a][b] = s0 + s1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // U = U1 - Phi(X)
+        const int a = e >> 5, b = e & 31;
+        Um[a][b] = U1[a][b] - (a < b ? Xs[a][b] : (a == b ? 0.5 * Xs[a][b] : 0.0));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // I - U + U^2
+        const int a = e >> 5, b = e & 31;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NB; k += 2) { s0 = fma(Um[a][k], Um[k][b], s0); s1 = fma(Um[a][k + 1], Um[k + 1][b], s1); }
+        Em[a][b] = ((a == b ? 1.0 : 0.0) - Um[a][b]) + (s0 + s1);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {      // the signs: D_k = -sign((Q1_top (I - U + U^2))_kk)
+        const int k = threadIdx.x;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < NB; j += 2) { s0 = fma(Qt[k][j], Em[j][k], s0); s1 = fma(Qt[k][j + 1], Em[j + 1][k], s1); }
+        Dv[k] = (s0 + s1) >= 0.0 ? -1.0 : 1.0;
     }
     __syncthreads();
     if (blockIdx.x == 0) {
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            const int r = e >> 5, c = e & 31;
-            aux[AUX_LM + e] = c < r ? Lm[r][c] : 0.0;
-            aux[AUX_UT + e] = c <= r ? Ut[r][c] : 0.0;
-            aux[AUX_L2 + e] = c <= r ? G[r][c] : 0.0;
-        }
+        for (int e = threadIdx.x; e < NB * NB; e += 256) aux[AUX_U + e] = Um[e >> 5][e & 31];
         if (threadIdx.x < NB) aux[AUX_D + threadIdx.x] = Dv[threadIdx.x];
     }
-    trs_pack(Lpu, Ut, ruinv);
     double sgacc = 0.0;
     for (int ch = 0; ch < cpb; ++ch) {
         const int chunk = blockIdx.x * cpb + ch;
@@ -370,24 +379,49 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
             for (int a = 0; a < NB; ++a) xrow[a] = row[(int64_t)a * ld];
         }
         const double gi = ok ? g[i] : 0.0;
-        double x[NB];
 #pragma unroll
-        for (int a = 0; a < NB; ++a) x[a] = ok ? xrow[a] : 0.0;
-        if (i >= NB) {
-            row_trsm_reg(x, Lp2);                                        // q = q1 R2^-1
+        for (int a = 0; a < NB; ++a) Pt[a * PT_S + threadIdx.x] = ok ? xrow[a] : 0.0;
+        __syncthreads();
+        {      // Q = Q1 (I - U + U^2): wave w's 64 rows, in place (a wave reads only its own rows)
+            d4v acc[4][2];
 #pragma unroll
-            for (int a = 0; a < NB; ++a) x[a] *= -Dv[a];
-            row_trsm_reg(x, Lpu);                                        // v U = -(q D)
-            if (ok) {
+            for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                for (int a = 0; a < NB; ++a) row[(int64_t)a * ld] = x[a];
+                for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = (d4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k0 = 0; k0 < NB; k0 += 4) {
+                const double b0 = Em[k0 + l4][l15], b1 = Em[k0 + l4][16 + l15];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const double av = Pt[(k0 + l4) * PT_S + wave * 64 + rt * 16 + l15];
+                    acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[rt][0], 0, 0, 0);
+                    acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[rt][1], 0, 0, 0);
+                }
             }
-        } else {      // the top block: V = L1 below the unit diagonal, in place too (b32_tfin adds R~ on and above it)
 #pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                x[a] = a < i ? Lm[i][a] : (a == i ? 1.0 : 0.0);
-                if (a < i) row[(int64_t)a * ld] = x[a];
-            }
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = wave * 64 + rt * 16 + l4 + 4 * r;
+                    Pt[l15 * PT_S + rw] = acc[rt][0][r];
+                    Pt[(16 + l15) * PT_S + rw] = acc[rt][1][r];
+                }
+        }
+        __syncthreads();
+        double x[NB];      // the row of V = [I; 0] - Q D
+#pragma unroll
+        for (int a = 0; a < NB; ++a) x[a] = (a == i ? 1.0 : 0.0) - Dv[a] * Pt[a * PT_S + threadIdx.x];
+        if (!ok) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) x[a] = 0.0;
+        }
+        if (ok && i >= NB) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) row[(int64_t)a * ld] = x[a];
+        }
+        if (i < NB) {      // the top block V1 goes to the panel's record
+#pragma unroll
+            for (int a = 0; a < NB; ++a) rec[NB * NB + i * NB + a] = x[a];
         }
         double prod[NB];
 #pragma unroll
@@ -414,57 +448,60 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
     if (threadIdx.x < NB) sgpart[(size_t)blockIdx.x * NB + threadIdx.x] = sgacc;
 }
 
-// T = U L1^-T and the band entries R~ = D R2 R1 of a Cholesky-QR panel, from what K2's block 0 left aside.  One block,
-// launched as an extra block of the symmetric product (nothing before b32_w_kernel needs T).
+// T = V1^-T (Gauss-Jordan between two LDS copies: one barrier per column) and the band entries R~ = D (I + U) R1 of a
+// Cholesky-QR panel.  One block, launched as an extra block of the symmetric product (nothing before b32_w_kernel needs T).
 __device__ __forceinline__ void b32_tfin(double *__restrict__ A, int64_t ld, int c0, int r0, const double *__restrict__ aux,
-                                         const double *__restrict__ R1, double *__restrict__ Tout, double *smem) {
-    double(*Lm)[NB + 1] = (double(*)[NB + 1])smem;
-    double(*Ut)[NB + 1] = Lm + NB;
-    double(*L2)[NB + 1] = Ut + NB;
-    double(*R1s)[NB + 1] = L2 + NB;
-    double(*X)[NB + 1] = R1s + NB;
-    double *Dv = (double *)(X + NB);
+                                         const double *__restrict__ R1, double *__restrict__ rec, int *__restrict__ flags,
+                                         double *smem) {
+    double(*Us)[NB + 1] = (double(*)[NB + 1])smem;
+    double(*R1s)[NB + 1] = Us + NB;
+    double(*Ma)[NB + 1] = R1s + NB;
+    double(*Mb)[NB + 1] = Ma + NB;
+    double *Dv = (double *)(Mb + NB);
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
         const int r = e >> 5, c = e & 31;
-        Lm[r][c] = aux[AUX_LM + e]; Ut[r][c] = aux[AUX_UT + e]; L2[r][c] = aux[AUX_L2 + e]; R1s[r][c] = R1[e];
+        Us[r][c] = aux[AUX_U + e]; R1s[r][c] = R1[e]; Ma[r][c] = rec[NB * NB + e];
     }
     if (threadIdx.x < NB) Dv[threadIdx.x] = aux[AUX_D + threadIdx.x];
     __syncthreads();
     const int i8 = threadIdx.x >> 3, cg = threadIdx.x & 7;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {      // R~[r][a] = D_r sum_{k = r .. a} R2[r][k] R1[k][a], R2[r][k] = L2[k][r]
+    for (int q = 0; q < 4; ++q) {      // R~[r][a] = D_r sum_{k = r .. a} (I + U)[r][k] R1[k][a]
         const int r = i8, a = cg + 8 * q;
         if (a >= r) {
-            double s = 0.0;
-            for (int k = r; k <= a; ++k) s = fma(L2[k][r], R1s[k][a], s);
+            double s = R1s[r][a];
+            for (int k = r; k <= a; ++k) s = fma(Us[r][k], R1s[k][a], s);
             A[(int64_t)(c0 + a) * ld + r0 + r] = Dv[r] * s;
         }
     }
-    // T L1' = U, right-looking over the columns of T: column k is final at step k
+    bool bad = false;
+    for (int k = 0; k < NB; ++k) {      // in-place inverse, reading one copy and writing the other
+        double(*Mi)[NB + 1] = (k & 1) ? Mb : Ma;
+        double(*Mo)[NB + 1] = (k & 1) ? Ma : Mb;
+        const double p = Mi[k][k], f = Mi[i8][k];
+        bad |= !(fabs(p) > 1e-6);
+        const double rp = frcp(p);
+        double mk[4], mi[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int c = cg + 8 * q; X[i8][c] = c >= i8 ? Ut[c][i8] : 0.0; }
-    for (int k = 0; k < NB - 1; ++k) {
-        __syncthreads();
-        const double trk = X[i8][k];
-        double lc[4], old[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { lc[q] = Lm[cg + 8 * q][k]; old[q] = X[i8][cg + 8 * q]; }
+        for (int q = 0; q < 4; ++q) { mk[q] = Mi[k][cg + 8 * q]; mi[q] = Mi[i8][cg + 8 * q]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = cg + 8 * q;
-            if (c > k) X[i8][c] = old[q] - trk * lc[q];
+            const double rowk = c == k ? rp : mk[q] * rp;
+            Mo[i8][c] = i8 == k ? rowk : (c == k ? -f * rp : mi[q] - f * rowk);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) Tout[e] = X[e >> 5][e & 31];
+    if (bad && threadIdx.x == 0) atomicOr(flags, 4);
+    for (int e = threadIdx.x; e < NB * NB; e += 256) rec[e] = Ma[e & 31][e >> 5];      // 32 steps: the inverse is back in Ma; T = its transpose
 }
-constexpr int TFIN_LDS = 5 * NB * (NB + 1) + NB;      // doubles
+constexpr int TFIN_LDS = 4 * NB * (NB + 1) + NB;      // doubles
 
 // The SHORT last panel (t < 64 rows, possibly fewer rows than columns): classical Householder QR in one block -- the
 // Cholesky route needs t >= 32 and full column rank.  Same outputs as K1 + K2 + b32_tfin (one partial of V'g).
 __global__ __launch_bounds__(256) void b32_panel_small_kernel(double *__restrict__ A, int64_t ld, int c0, int r0, int t,
                                                               double *__restrict__ Zc, int64_t vs, double *__restrict__ Vr,
-                                                              double *__restrict__ Tout, const double *__restrict__ g,
+                                                              double *__restrict__ rec, const double *__restrict__ g,
                                                               double *__restrict__ sgpart) {
     __shared__ double P[64][NB + 1], V[64][NB + 1], Gs[NB][NB + 1], Ts[NB][NB + 1];
     __shared__ double wpart[8][NB], taus[NB], ssh[2], red[8][NB];
@@ -541,7 +578,7 @@ __global__ __launch_bounds__(256) void b32_panel_small_kernel(double *__restrict
         if (tid == j) Ts[j][j] = taus[j];
         __syncthreads();
     }
-    for (int e = tid; e < NB * NB; e += 256) Tout[e] = Ts[e >> 5][e & 31];
+    for (int e = tid; e < NB * NB; e += 256) { rec[e] = Ts[e >> 5][e & 31]; rec[NB * NB + e] = V[e >> 5][e & 31]; }
     // outputs: in place (R on / above the diagonal, V below), dense V, the partial of V'g
     double x[NB], prod[NB];
     const int i = tid;
@@ -572,10 +609,10 @@ __global__ __launch_bounds__(256) void b32_panel_small_kernel(double *__restrict
 __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
                                                        const double *__restrict__ Vr, double *__restrict__ Ypart, int64_t vs,
                                                        int ws, int tfin, const double *__restrict__ aux, const double *__restrict__ R1,
-                                                       double *__restrict__ Tout) {
+                                                       double *__restrict__ rec, int *__restrict__ flags) {
     __shared__ double red[4][NB][66];
     if (blockIdx.x == gridDim.x - 1) {
-        if (blockIdx.y == 0 && tfin) b32_tfin(A, ld, r0 - NB, r0, aux, R1, Tout, &red[0][0][0]);
+        if (blockIdx.y == 0 && tfin) b32_tfin(A, ld, r0 - NB, r0, aux, R1, rec, flags, &red[0][0][0]);
         return;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -591,22 +628,34 @@ __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, i
     const int rp0 = I0 + 2 * l15, rp1 = rp0 + 32;
     const bool ok00 = rp0 < t, ok01 = rp0 + 1 < t, ok10 = rp1 < t, ok11 = rp1 + 1 < t;
     const double *a0p = Ab + (ok00 ? rp0 : 0), *a1p = Ab + (ok10 ? rp1 : 0);
-#pragma unroll 4
-    for (int j = jbeg; j < jend; j += 4) {
-        const int col = min(j + l4, t - 1);
-        const double2 a0 = *(const double2 *)(a0p + (int64_t)col * ld);
-        const double2 a1 = *(const double2 *)(a1p + (int64_t)col * ld);
-        const double *vrow = Vr + (int64_t)(j + l4) * NB + l15;
-        const double b0 = vrow[0], b1 = vrow[16];
-        const double x0 = ok00 ? a0.x : 0.0, x1 = ok01 ? a0.y : 0.0, x2 = ok10 ? a1.x : 0.0, x3 = ok11 ? a1.y : 0.0;
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1, acc[1][1], 0, 0, 0);
-        acc[2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b0, acc[2][0], 0, 0, 0);
-        acc[2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b1, acc[2][1], 0, 0, 0);
-        acc[3][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b0, acc[3][0], 0, 0, 0);
-        acc[3][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b1, acc[3][1], 0, 0, 0);
+    // four k-steps per trip, their sixteen global loads issued before the first MFMA (the compiler declines to unroll this
+    // loop by itself: with two loads in flight per wave the kernel streamed at 2.7 TB/s)
+    for (int j = jbeg; j < jend; j += 16) {
+        double2 a0[4], a1[4];
+        double b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jc = j + 4 * u + l4;
+            const int col = min(jc, t - 1);
+            a0[u] = *(const double2 *)(a0p + (int64_t)col * ld);
+            a1[u] = *(const double2 *)(a1p + (int64_t)col * ld);
+            const double *vrow = Vr + (int64_t)min(jc, t + 59) * NB + l15;      // rows t .. t + 63 of Vr are zero
+            b0[u] = vrow[0]; b1[u] = vrow[16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = j + 4 * u < jend;
+            const double x0 = ok00 && live ? a0[u].x : 0.0, x1 = ok01 && live ? a0[u].y : 0.0;
+            const double x2 = ok10 && live ? a1[u].x : 0.0, x3 = ok11 && live ? a1[u].y : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1[u], acc[1][1], 0, 0, 0);
+            acc[2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b0[u], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b1[u], acc[2][1], 0, 0, 0);
+            acc[3][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b0[u], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b1[u], acc[3][1], 0, 0, 0);
+        }
     }
     // tile rt = 2 h + parity holds rows I0 + 32 h + 2 m + parity, m = l4 + 4 r; column n = 16 nt + l15
 #pragma unroll
@@ -681,9 +730,10 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
             __syncthreads();
             if (threadIdx.x < NB) {      // z = T' sg
                 const int a = threadIdx.x;
-                double s = 0.0;
-                for (int b = 0; b <= a; ++b) s = fma(Ts[b][a], sg[b], s);
-                zs[a] = s;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+                for (int b = 0; b < NB; b += 2) { s0 = fma(Ts[b][a], sg[b], s0); s1 = fma(Ts[b + 1][a], sg[b + 1], s1); }
+                zs[a] = s0 + s1;
             }
         }
         __syncthreads();
@@ -693,7 +743,7 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
             g[i] = gi;
         }
         gram_chunk(Vt, Yt, macc, ta, tb);
-        // W^ = Y T: wave w takes rows 64 w .. 64 w + 63 (4 row tiles) x 2 column tiles; T is upper triangular
+        // W^ = Y T: wave w takes rows 64 w .. 64 w + 63 (4 row tiles) x 2 column tiles
         d4v wacc[4][2];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
@@ -705,7 +755,7 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const double av = Yt[(k0 + l4) * PT_S + wave * 64 + rt * 16 + l15];
-                if (k0 < 16) wacc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, wacc[rt][0], 0, 0, 0);
+                wacc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, wacc[rt][0], 0, 0, 0);
                 wacc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, wacc[rt][1], 0, 0, 0);
             }
         }
@@ -909,7 +959,8 @@ __global__ void b32_extract_kernel(const double *__restrict__ A, int64_t ld, int
 // that repeat what K2 (partials of V'g, same row blocks, same order) and K4a (z = T' sum, g -= V z) did to g during the
 // reduction, so that the rotated right-hand side is the full fit's bit for bit.
 __global__ __launch_bounds__(256) void b32_qt_part_kernel(const double *__restrict__ A, int64_t ld, int c0, int r0, int t, int cpb,
-                                                          const double *__restrict__ g, double *__restrict__ sgpart) {
+                                                          const double *__restrict__ rec, const double *__restrict__ g,
+                                                          double *__restrict__ sgpart) {
     __shared__ double Pt[NB * PT_S];
     __shared__ double red[8][NB];
     double sgacc = 0.0;
@@ -917,7 +968,7 @@ __global__ __launch_bounds__(256) void b32_qt_part_kernel(const double *__restri
         const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
         const bool ok = i < t;
         double v[NB], prod[NB];
-        load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, ok);
+        load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, ok, rec + NB * NB);
         const double gi = ok ? g[i] : 0.0;
 #pragma unroll
         for (int a = 0; a < NB; ++a) prod[a] = v[a] * gi;
@@ -932,17 +983,18 @@ __global__ __launch_bounds__(256) void b32_qt_apply_kernel(const double *__restr
     for (int e = threadIdx.x; e < NB * NB; e += 256) Ts[e >> 5][e & 31] = Tm[e];
     if (threadIdx.x < NB) sg[threadIdx.x] = sum_parts_32(sgpart, nsg);
     __syncthreads();
-    if (threadIdx.x < NB) {
+    if (threadIdx.x < NB) {      // the very sums of b32_w_kernel
         const int a = threadIdx.x;
-        double s = 0.0;
-        for (int b = 0; b <= a; ++b) s = fma(Ts[b][a], sg[b], s);
-        zs[a] = s;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < NB; b += 2) { s0 = fma(Ts[b][a], sg[b], s0); s1 = fma(Ts[b + 1][a], sg[b + 1], s1); }
+        zs[a] = s0 + s1;
     }
     __syncthreads();
     const int i = blockIdx.x * CHR + threadIdx.x;
     if (i >= t) return;
     double v[NB];
-    load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, true);
+    load_v_row(v, A + (int64_t)c0 * ld + r0, ld, i, true, Tm + NB * NB);
     double gi = g[i];
 #pragma unroll
     for (int a = 0; a < NB; ++a) gi = fma(-v[a], zs[a], gi);
@@ -984,16 +1036,16 @@ __global__ __launch_bounds__(256) void b32_bt_step_kernel(const double *__restri
         __syncthreads();
         if (threadIdx.x < NB) {
             const int a = threadIdx.x;
-            const double *T = Tall + (size_t)p * NB * NB;
+            const double *T = Tall + (size_t)p * PREC;
             double s = 0.0;
-            for (int b = a; b < NB; ++b) s = fma(T[a * NB + b], ssum[b], s);
+            for (int b = 0; b < NB; ++b) s = fma(T[a * NB + b], ssum[b], s);
             zs[a] = s;
         }
         __syncthreads();
         const int il = i - base;
         if (il >= 0 && i < m) {
             double v[NB];
-            load_v_row(v, A + (int64_t)(off0 + p * NB) * ld + off0 + base, ld, il, true);
+            load_v_row(v, A + (int64_t)(off0 + p * NB) * ld + off0 + base, ld, il, true, Tall + (size_t)p * PREC + NB * NB);
 #pragma unroll
             for (int a = 0; a < NB; ++a) ri = fma(-v[a], zs[a], ri);
             r[i] = ri;
@@ -1003,7 +1055,7 @@ __global__ __launch_bounds__(256) void b32_bt_step_kernel(const double *__restri
         const int q = p - 1, base = q * NB + NB, il = i - base;
         const bool ok = il >= 0 && i < m;
         double v[NB], prod[NB];
-        load_v_row(v, A + (int64_t)(off0 + q * NB) * ld + off0 + base, ld, il, ok);
+        load_v_row(v, A + (int64_t)(off0 + q * NB) * ld + off0 + base, ld, il, ok, Tall + (size_t)q * PREC + NB * NB);
 #pragma unroll
         for (int a = 0; a < NB; ++a) prod[a] = v[a] * ri;
         const double tot = block_colsum32(prod, Pt, red);
@@ -1134,29 +1186,34 @@ __global__ __launch_bounds__(256) void b32_sweep_kernel(const double *__restrict
     auto stash = [&](int buf, double v) { if (tid < SCH * (NB + 2)) L.stage[buf][srr][sd] = v; };
     stash(0, fetch(0));
     __syncthreads();
-    double neg = 0.0, tr = 0.0, q2 = 0.0, pending = 0.0;
-    int o = 0, cstep = 0, chunk = 0;
+    double neg = 0.0, tr = 0.0, q2 = 0.0;
+    int o = 0, jj = 0;
     double *Lcol = nullptr, *ycol = nullptr;
-    for (int jj = 0; jj < ncols; ++jj) {
-        if (cstep == 0) pending = fetch(chunk + 1);
-        if (STORE) {
-            const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj);      // dir 1's columns follow dir 0's in the buffers
-            Lcol = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1);
-            ycol = ybuf + col + (int64_t)blockIdx.x * (n0 + n1);
-        }
-        sweep_step<DERIV>(L, sl, o, neg, tr, q2, Lcol, ycol);
-        if ((tid >> 6) == 3) {      // the last wave: row jj + 33 enters (its slot held row jj - 31, long dead)
-            const int lane = tid & 63, pr = (o + NB + 1) & (SW - 1);
-            if (lane <= SYO) {
-                const double v = L.stage[chunk & 1][cstep][lane];      // zero past the last row (fetch)
-                L.W[pr * SWS + lane] = v + (lane == 0 && jj + NB + 1 <= last_row ? lam : 0.0);
-                if (DERIV) L.dW[pr * SWS + lane] = lane == 0 && jj + NB + 1 <= last_row ? 1.0 : 0.0;
+    // chunk by chunk: the next chunk's rows are requested, seven columns are eliminated, then the rows are parked in LDS --
+    // the loop nest (rather than a step counter) is what lets the compiler wait for the load only there
+    for (int chunk = 0; jj < ncols; ++chunk) {
+        const double pending = fetch(chunk + 1);
+        const int nst = min(SCH, ncols - jj);
+#pragma unroll 1
+        for (int cstep = 0; cstep < nst; ++cstep, ++jj) {
+            if (STORE) {
+                const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj);      // dir 1's columns follow dir 0's in the buffers
+                Lcol = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1);
+                ycol = ybuf + col + (int64_t)blockIdx.x * (n0 + n1);
             }
+            sweep_step<DERIV>(L, sl, o, neg, tr, q2, Lcol, ycol);
+            if ((tid >> 6) == 3) {      // the last wave: row jj + 33 enters (its slot held row jj - 31, long dead)
+                const int lane = tid & 63, pr = (o + NB + 1) & (SW - 1);
+                if (lane <= SYO) {
+                    const double v = L.stage[chunk & 1][cstep][lane];      // zero past the last row (fetch)
+                    L.W[pr * SWS + lane] = v + (lane == 0 && jj + NB + 1 <= last_row ? lam : 0.0);
+                    if (DERIV) L.dW[pr * SWS + lane] = lane == 0 && jj + NB + 1 <= last_row ? 1.0 : 0.0;
+                }
+            }
+            o = (o + 1) & (SW - 1);
+            lds_barrier();
         }
-        if (cstep == SCH - 1) { stash((chunk + 1) & 1, pending); cstep = 0; ++chunk; }
-        else ++cstep;
-        o = (o + 1) & (SW - 1);
-        lds_barrier();
+        stash((chunk + 1) & 1, pending);      // read again two barriers later at the earliest
     }
     // the block behind the eliminated columns: logical rows / columns ncols .. ncols + 31
     double *wout = win + ((int64_t)blockIdx.x * 2 + dir) * SWIN;
@@ -1245,7 +1302,7 @@ static size_t band32_layout(Band32Ws *w, char *base, int m, int64_t n) {
     d.Wh = take(((size_t)m + 256) * NB);
     d.Mp = take((size_t)MAXPART_H * NB * NB);
     d.sgp = take((size_t)MAXPART_H * NB);
-    d.Tall = take(np * NB * NB);
+    d.Tall = take(np * PREC);
     d.ab = take((size_t)m * (NB + 1) + 64);
     d.win = take((size_t)B32_MAXLAM * 2 * SWIN);
     d.res = take((size_t)B32_MAXLAM * 8);
@@ -1294,14 +1351,14 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
     hipEvent_t pending_rest = nullptr;
     for (int p = 0; p < npanels; ++p) {
         const int c = p * NB, t = m - c - NB, c0 = off0 + c, r0 = off0 + c + NB;
-        double *Zc = ws.Zc[p & 1], *Vr = ws.Vr[p & 1], *Tp = ws.Tall + (size_t)p * NB * NB, *gp = g_dev + c + NB;
+        double *Zc = ws.Zc[p & 1], *Vr = ws.Vr[p & 1], *Tp = ws.Tall + (size_t)p * PREC, *gp = g_dev + c + NB;
         int cpb, nblk;
         row_blocks(t, &cpb, &nblk);
         int nsg = nblk;
         if (t >= 64) {
             hipLaunchKernelGGL(b32_gram_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1);
             hipLaunchKernelGGL(b32_cholqr1_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1, nblk, ws.Gp2, ws.R1, ws.Qtop, ws.flags);
-            hipLaunchKernelGGL(b32_cholqr2_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp2, nblk, ws.Qtop, Zc, vs, Vr, ws.aux,
+            hipLaunchKernelGGL(b32_cholqr2_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp2, nblk, ws.Qtop, Zc, vs, Vr, ws.aux, Tp,
                                gp, ws.sgp, ws.flags);
         } else {
             hipLaunchKernelGGL(b32_panel_small_kernel, dim3(1), dim3(256), 0, s, A, ld, c0, r0, t, Zc, vs, Vr, Tp, gp, ws.sgp);
@@ -1313,7 +1370,7 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
         int nsplit = std::max(1, std::min(SYMM_MAXSPLIT, (512 + nrb / 2) / nrb));
         int wsplit = (((t + nsplit - 1) / nsplit) + 15) & ~15;
         nsplit = (t + wsplit - 1) / wsplit;
-        hipLaunchKernelGGL(b32_symm_kernel, dim3(nrb + 1, nsplit), dim3(256), 0, s, A, ld, r0, t, Vr, ws.Yp, vs, wsplit, t >= 64 ? 1 : 0, ws.aux, ws.R1, Tp);
+        hipLaunchKernelGGL(b32_symm_kernel, dim3(nrb + 1, nsplit), dim3(256), 0, s, A, ld, r0, t, Vr, ws.Yp, vs, wsplit, t >= 64 ? 1 : 0, ws.aux, ws.R1, Tp, ws.flags);
         hipLaunchKernelGGL(b32_w_kernel, dim3(nblk), dim3(256), B32_W_LDS, s, t, cpb, nsplit, ws.Yp, vs, Vr, Tp, ws.sgp, nsg, gp, ws.Wh, ws.Mp);
         hipLaunchKernelGGL(b32_wfin_kernel, dim3(nblk), dim3(256), 0, s, t, cpb, ws.Mp, nblk, Tp, Vr, ws.Wh, Zc + (int64_t)NB * vs, vs);
         const int nt = (t + RK_T - 1) / RK_T;
@@ -1344,8 +1401,8 @@ int band32_qt(hipStream_t s, const double *A, int64_t ld, int m, const double *T
         int cpb, nblk;
         row_blocks(t, &cpb, &nblk);
         if (t < 64) { cpb = 1; nblk = 1; }
-        hipLaunchKernelGGL(b32_qt_part_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, g_dev + c + NB, sgp);
-        hipLaunchKernelGGL(b32_qt_apply_kernel, dim3((t + CHR - 1) / CHR), dim3(256), 0, s, A, ld, c0, r0, t, Tall + (size_t)p * NB * NB, sgp, nblk,
+        hipLaunchKernelGGL(b32_qt_part_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, Tall + (size_t)p * PREC, g_dev + c + NB, sgp);
+        hipLaunchKernelGGL(b32_qt_apply_kernel, dim3((t + CHR - 1) / CHR), dim3(256), 0, s, A, ld, c0, r0, t, Tall + (size_t)p * PREC, sgp, nblk,
                            g_dev + c + NB);
     }
     MHS_HIP(hipGetLastError());

@@ -2233,7 +2233,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 const int np32 = band32_npanels(m);
                 auto e = std::make_shared<ReductionEntry>();
                 e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->Atop = Atop; e->b32 = true; e->ld = ld; e->npanels = np32; e->ab = ab32;
-                const size_t abytes = sizeof(double) * (size_t)ld * (size_t)(3 + m), tbytes = sizeof(double) * (size_t)np32 * B32_NB * B32_NB;
+                const size_t abytes = sizeof(double) * (size_t)ld * (size_t)(3 + m), tbytes = sizeof(double) * (size_t)np32 * B32_PANEL_REC;
                 e->bytes = abytes + tbytes;
                 size_t free_b = 0, total_b = 0;
                 bool ok = e->bytes <= rcache_budget() && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * e->bytes;

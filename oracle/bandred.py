@@ -52,10 +52,37 @@ def householder_from_q(Q):
 
 
 def cholqr2_householder(P):
-    """Returns V, T, Rt with (I - V T V')' P = [Rt; 0], Rt upper triangular (its diagonal may carry either sign)."""
+    """Returns V, T, Rt with (I - V T V')' P = [Rt; 0], Rt upper triangular (its diagonal may carry either sign).  The LU
+    form of the reconstruction (the first version of the GPU kernel; V unit lower trapezoidal, T upper triangular)."""
     Q, R = cholqr2(P)
     V, T, D = householder_from_q(Q)
     return V, T, D[:, None] * R
+
+
+def _phi(X):
+    return np.triu(X, 1) + 0.5 * np.diag(np.diag(X))
+
+
+def cholqr_expansion_yamamoto(P):
+    """The form the GPU kernels use now (b32_cholqr1/2_kernel + b32_tfin): first pass R1 = chol(P'P), Q1 = P R1^-1; the
+    second pass through the EXPANSION of chol(I + E), E = Q1'Q1 - I: U = Phi(E) - Phi(Phi(E)'Phi(E)), R2 = I + U, R2^-1 =
+    I - U + U^2 (both to O(E^3)); then Yamamoto's basis-kernel representation H = I - V T V', V = [I; 0] - Q D, T = (I -
+    (Q D)_top)^-T with D_k = -sign(Q_kk): no triangular structure, no serial step.  Returns V, T, Rt as above."""
+    t, b = P.shape
+    R1 = np.linalg.cholesky(P.T @ P).T
+    Q1 = np.linalg.solve(R1.T, P.T).T
+    E = Q1.T @ Q1 - np.eye(b)
+    E = 0.5 * (E + E.T)
+    if not np.max(np.abs(E)) <= 1e-5:
+        raise np.linalg.LinAlgError("panel too ill-conditioned for the expansion")
+    U1 = _phi(E)
+    U = U1 - _phi(U1.T @ U1)
+    Q = Q1 @ (np.eye(b) - U + U @ U)
+    D = np.where(np.diag(Q[:b]) >= 0, -1.0, 1.0)
+    V = -(Q * D)
+    V[:b] += np.eye(b)
+    T = np.linalg.inv(V[:b]).T
+    return V, T, D[:, None] * ((np.eye(b) + U) @ R1)
 
 
 def householder_panel(P):
@@ -89,7 +116,7 @@ def householder_panel(P):
 
 
 # ------------------------------------------------------------------------------------------------ band reduction --
-def band_reduce(B, g, b=32, small=None):
+def band_reduce(B, g, b=32, small=None, form="yamamoto"):
     """B = Q Bb Q' with Bb of bandwidth b; returns the band ab[d, j] = Bb[j + d, j] (d = 0 .. b), g rotated to Q'g, the
     panels' (c, V, T) for the back-transform and the largest cond(P) met.  Panels with fewer than `small` (default b + 1) rows
     take the classical Householder form."""
@@ -105,7 +132,7 @@ def band_reduce(B, g, b=32, small=None):
         if t >= small:
             sv = np.linalg.svd(P, compute_uv=False)
             worst = max(worst, sv[0] / sv[-1])
-            V, T, R = cholqr2_householder(P)
+            V, T, R = cholqr_expansion_yamamoto(P) if form == "yamamoto" else cholqr2_householder(P)
         else:
             V, T, R = householder_panel(P)
         A[r0:, c:c + b] = 0.0

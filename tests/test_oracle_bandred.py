@@ -32,6 +32,19 @@ def test_householder_reconstruction_from_an_orthonormal_factor():
     assert np.allclose(np.tril(T, -1), 0)
 
 
+def test_expansion_and_basis_kernel_form():
+    """The form the kernels use: chol(I + E) by its expansion, Yamamoto's V = [I; 0] - Q D, T = (I - (Q D)_top)^-T."""
+    rng = np.random.default_rng(1)
+    for t in (64, 300):
+        P = rng.standard_normal((t, 32)) @ np.diag(10.0 ** rng.uniform(-3, 0, 32)) @ (np.eye(32) + 0.3 * rng.standard_normal((32, 32)))
+        V, T, R = br.cholqr_expansion_yamamoto(P)
+        H = np.eye(t) - V @ T @ V.T
+        assert np.max(np.abs(H.T @ H - np.eye(t))) < 5e-14
+        HP = H.T @ P
+        assert np.max(np.abs(HP[32:])) < 1e-13 * np.max(np.abs(P)) and np.max(np.abs(HP[:32] - R)) < 1e-13 * np.max(np.abs(P))
+        assert np.allclose(np.tril(R, -1), 0) and np.linalg.cond(V[:32]) < 20
+
+
 def test_band_reduction_and_gcv_terms():
     B, g = _tps_matrix(430, 1)        # m = 427: ends with a short panel (t = 11)
     m = B.shape[0]
