@@ -36,15 +36,24 @@ VALU_ISSUE_PEAK_G = 1024 * 2.4 / 4.0   # G wave-instructions/s: 1024 SIMDs, one 
 LDS_CYCLE_PEAK_G = 256 * 2.4           # G LDS-array cycles/s: 256 CUs at 2.4 GHz (MI355X guide: ds_read_b64 = ds_read_b32 = 2 cycles)
 
 
+PMC_FILES = ("r04_8d_members_pmc_derived.json", "r03_members_pmc_derived.json")
+
+
 def pmc_derived():
-    """profiles/r03_members_pmc_derived.json (tools/r03_members_pmc.sh + tools/r03_pmc_derive.py): per-unit instruction
-    counts and pipe utilisations of the three heavy member kernels from rocprofv3 --pmc passes on a torch-free driver."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_members_pmc_derived.json")) as f:
-            d = json.load(f)
-        return {("gbm" if "gbm" in k else "rf" if "rf_" in k else "svr"): v for k, v in d.items() if isinstance(v, dict)}
-    except (OSError, ValueError):
-        return {}
+    """profiles/r04_8d_members_pmc_derived.json (tools/r04_members_pmc.sh + tools/r04_pmc_derive.py; round 3's file if this
+    round's is absent): per-unit instruction counts and pipe utilisations of the member kernels from rocprofv3 --pmc passes
+    of a torch-free driver over cfg3's own 10 000 x 10 000 SURVEY-8d planes.  Every figure the roofline rows take from it is
+    a property of THOSE rasters and of that run, not of the timed steps; the rows say so ("pmc_source")."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            out = {("gbm" if "gbm" in k else "rf" if "rf_" in k else "small" if "small" in k else "svr"): v for k, v in d.items() if isinstance(v, dict)}
+            out["_source"] = "profiles/%s (%s planes, %s x %s cells)" % (name, d.get("rasters", "8d"), d.get("grid", ["?", "?"])[0], d.get("grid", ["?", "?"])[1])
+            return out
+        except (OSError, ValueError):
+            continue
+    return {}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the north-star target is quoted on
@@ -114,6 +123,13 @@ class Workload:
         self.cells = side * side
         self.last = None
         self.rank0_share = None
+        self.reservation = None
+        if world == 1 and tps_mode == "global" and cfg["ensemble"]:
+            # setup, untimed: how many compute units (if any) the forest leaves to the spline fit -- measured, not a constant
+            self.run.calibrate_reservation()
+            self.reservation = self.run.reservation_calibration
+            for v in self.ops.timings.values():
+                v.clear()
         if world > 1 and tps_mode == "global":
             # Load balance (setup, untimed): rank 0 also carries the spline fit, so it gets fewer rows.  One
             # calibration pass with equal bands gives this GPU's time for all cells and the stand-alone fit time;
@@ -136,6 +152,10 @@ class Workload:
                 v.clear()
             self.run = sharded.ShardedMltps(PerModelOps(self.ops), dist, rank, world, side, side,
                                             rank0_share=self.rank0_share)
+            self.run.calibrate_reservation()      # collective; rank 0 keeps what it measured fastest
+            self.reservation = self.run.reservation_calibration
+            for v in self.ops.timings.values():
+                v.clear()
 
     def step(self):
         self.last = self.run.step()
@@ -181,9 +201,16 @@ class Workload:
             ms = mean_ms(fk)
             if ms:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
-                rows.append({"kernel": "small_members_kernel (%s)" % fk[6:-3], "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "work": "gam + nnet + earth in one pass: read C fp32 planes once + read-modify-write the fp64 plane once"})
+                pm = pmc.get("small", {})
+                # ten logistic units per cell (nnet, V73:468) + 15 hinges + the linear model: compute, not traffic, bounds it
+                ipc = pm.get("valu_per_cell_unit", 420.0)
+                rows.append({"kernel": "small_members_kernel (%s)" % fk[6:-3], "bound": "valu-issue", "launch_ms": ms,
+                             "achieved": band_cells / 64.0 * ipc / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
+                             "work": "gam + nnet + earth in one pass: %.0f VALU wave-instructions per cell / 64 lanes (%s); 20 B/cell of HBM "
+                                     "traffic (C fp32 planes read once, the fp64 plane read-modify-written once)" % (
+                                         ipc, "SQ_INSTS_VALU, " + pmc["_source"] if "valu_per_cell_unit" in pm else "counted in the source, no PMC pass"),
+                             "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation",) if kk in pm},
+                             "hbm_view": {"achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS}})
         for prm in self.params:
             k = prm["kind"]
             ms = mean_ms("model_%s_ms" % k)
@@ -193,16 +220,14 @@ class Workload:
                 nsv, p = prm["sv"].shape
                 fl = band_cells * nsv * (3.0 * p + 2.0)
                 pm = pmc.get("svr", {})
-                ipp = pm.get("valu_per_cell_unit", 15.07)
                 rowtile = self.geom.ncol >= 0.93 * (-(-self.geom.ncol // 192) * 192)      # launch_svr's choice (ensemble.hip)
-                if rowtile:
-                    ipp = min(ipp, 13.07)      # the LAT term and the |x|^2 term once per wave: an fma and an add less per (cell, SV) than svr_kernel
+                ipp = pm.get("valu_per_cell_unit", 14.4 if rowtile else 15.07)      # measured (SQ_INSTS_VALU); the defaults are round 3's counts
                 rows.append({"kernel": "svr_rt_kernel" if rowtile else "svr_kernel", "bound": "fp64-valu", "launch_ms": ms, "achieved": fl / ms / 1e9,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "work": "(3p+2) flop per (cell, SV), exp = 1 flop",
                              "issue_view": {"achieved": band_cells * nsv / 64.0 * ipp / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
                                             "frac": band_cells * nsv / 64.0 * ipp / ms / 1e6 / VALU_ISSUE_PEAK_G,
-                                            "work": "%.2f VALU wave-instructions per (cell, SV) / 64 lanes (SQ_INSTS_VALU, profiles/r03_members_pmc_*), "
-                                                    "12 of them FP64" % ipp},
+                                            "work": "%.2f VALU wave-instructions per (cell, SV) / 64 lanes (SQ_INSTS_VALU, %s), "
+                                                    "12 of them FP64" % (ipp, pmc.get("_source", "round-3 count"))},
                              "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "lds_array_busy") if kk in pm}})
             elif k == "gbm":
                 # Grids: gbm_coherent_kernel (a probe on the device prices it against the tree-order row-tile kernel).  Both are
@@ -229,11 +254,15 @@ class Workload:
                 inst = band_cells * nt / 64.0 * ipt
                 rows.append({"kernel": "gbm_coherent_kernel" if coherent else "gbm_lutreg_rt_kernel", "bound": "valu-issue", "launch_ms": ms,
                              "achieved": inst / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
-                             "work": "%.2f VALU wave-instructions per (cell, tree) / 64 lanes (SQ_INSTS_VALU pass on the same rasters, "
-                                     "profiles/r03_members_pmc_*): per wave of 64 x 4 cells a tree whose splits fall the same way for every cell is "
+                             "work": "%.2f VALU wave-instructions per (cell, tree) / 64 lanes (SQ_INSTS_VALU pass, "
+                                     "%s -- a property of those rasters): per wave of 64 x 4 cells a tree whose splits fall the same way for every cell is "
                                      "summed once (lane = tree), one or two straddling splits cost a clamp-add and a multiply-add per cell; "
-                                     "reference walk = %.0f node visits/cell, %.3g visits/s" % (
-                                         ipt, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                                     "reference walk = %.0f node visits/cell, %.3g visits/s.  The instruction mix is mostly FP32 (2-cycle issue), so "
+                                     "`frac` is the PMC pass's measured VALU utilisation when there is one; the count-based figure is in issue_view" % (
+                                         ipt, pmc.get("_source", "no PMC file"), self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                             "issue_view": {"achieved": inst / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s", "frac": inst / ms / 1e6 / VALU_ISSUE_PEAK_G,
+                                            "work": "count x rate against one wave64 instruction per 4 cycles (an upper reading for FP32-heavy code)"},
+                             "frac_override": pm.get("valu_issue_utilisation"),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
                              "probe": probe,
                              "pmc": {kk: pm[kk] for kk in ("valu_issue_utilisation", "salu_per_valu", "lds_array_busy") if kk in pm}})
@@ -254,9 +283,10 @@ class Workload:
                 rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_tb_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
                              "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
                              "work": "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "
-                                     "%.0f levels/cell walked (a wave of neighbouring cells starts a tree where its cells part ways and leaves it at its deepest leaf; SQ_INSTS_LDS pass) "
+                                     "%.0f levels/cell walked (a wave of neighbouring cells starts a tree where its cells part ways and leaves it at its deepest leaf; "
+                                     "share of the full depth from SQ_INSTS_LDS / 2 in %s -- measured on those rasters, not in this run) "
                                      "of %d levels/cell of full tree depth; %.0f node visits/cell on the reference's walk, %.3g visits/s" % (
-                                         levels, full, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
+                                         levels, pmc.get("_source", "no PMC file: full depth assumed"), full, self.mean_visits[k], self.mean_visits[k] * band_cells / (ms * 1e-3)),
                              "node_visits_per_s": self.mean_visits[k] * band_cells / (ms * 1e-3),
                              "pmc": {kk: pm[kk] for kk in ("lds_array_busy", "lds_bank_conflict_share_of_lds_cycles", "lds_cycles_per_lds_instruction",
                                                            "lds_cmd_fifo_full_share", "valu_issue_utilisation") if kk in pm},
@@ -283,6 +313,11 @@ class Workload:
                 pmc_t[kn] = pmc[kind]["hbm_bytes_per_cell_fetch_x2_plus_write"]
         for r in rows:
             r["frac"] = r["achieved"] / r["peak"]
+            if r.get("frac_override") is not None:      # gbm: the measured pipe utilisation leads, the count-based figure stays in issue_view
+                r["frac"] = r.pop("frac_override")
+            else:
+                r.pop("frac_override", None)
+            r["pmc_source"] = pmc.get("_source")
             parts = [pmc_t.get(kn.split("<")[0]) for kn in r["kernel"].split("+")]
             r["traffic"] = sum(parts) * band_cells if all(x is not None for x in parts) else None
         return rows
@@ -342,6 +377,98 @@ class Workload:
                 "host_abi_equals_resident_bitwise": same_host,
                 "note": "f64 planes = the f32 planes widened (same values), what terra holds in RAM; host ABI = "
                         "mhs_ensemble_predict with pageable host buffers, as mhsr_ensemble_predict calls it"}
+
+    def raster_sensitivity(self, side=4000):
+        """How much of the heavy members' speed is a property of the synthetic rasters (round-3 verdict, item 2).  The three
+        tree / kernel members are timed, outside the timed loop, on the NW `side` x `side` window of this workload's grid
+        (LONG / LAT unchanged) holding (a) the SURVEY 8d planes the steps run on, (b) the reference's OWN rasters -- the bundled
+        TWI and slope overviews (tests/golden/cfg1_extdata.npz, /root/reference/README.md:84-96, inst/extdata/*.aux.xml;
+        1238 x 1632 INT2S, mirrored into a mosaic; alt.tif is a missing blob, its plane stays synthetic) --, (c) the 8d planes
+        plus white noise of 1 / 10 / 100 % of each covariate's range.  ms per 1e8 cells; for the forest also round 2's walk
+        (no prefix, full depth, far walks, two buffers), for ksvm also the lane-per-cell kernel, for gbm the probe's verdict."""
+        import ctypes as C
+        from machisplin_amd import _lib, synth
+        torch, mhs = self.torch, self.mhs
+        if not self.cfg["ensemble"] or self.geom.nrow < side or self.geom.ncol < side or self.cfg["layers"] != 3:
+            return None
+        g = synth.grid(side, side)
+        base = self.stack.planes[:, :side, :side].contiguous()
+        variants = [("survey_8d_planes", base, "the planes of the timed steps (six sinusoids of 0.5-6 cycles across the 10 000-cell side)")]
+        fixture = os.path.join(ROOT, "tests", "golden", "cfg1_extdata.npz")
+        if os.path.exists(fixture):
+            d = np.load(fixture)
+            def mosaic(a):
+                a = a.astype(np.float32)
+                a[a == -32768] = np.nan
+                ny, nx = -(-side // a.shape[0]), -(-side // a.shape[1])
+                rows = []
+                for iy in range(ny):
+                    t = a[::-1] if iy & 1 else a
+                    rows.append(np.concatenate([t[:, ::-1] if ix & 1 else t for ix in range(nx)], axis=1))
+                return np.ascontiguousarray(np.concatenate(rows, axis=0)[:side, :side])
+            real = base.clone()
+            real[1] = torch.from_numpy(mosaic(d["slope"])).cuda()
+            real[2] = torch.from_numpy(mosaic(d["TWI"])).cuda()
+            variants.append(("bundled_twi_slope_overviews", real, "the reference's bundled TWI.tif / slope.tif overviews (1238 x 1632 INT2S, NoData -> NA), "
+                             "mirrored into a %d x %d mosaic; alt: synthetic (alt.tif is not in the repository)" % (side, side)))
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(7)
+        for frac in (0.01, 0.1, 1.0):
+            noisy = base.clone()
+            for k in range(base.shape[0]):
+                lo, hi = synth.COV_RANGES[k]
+                noisy[k] += (torch.rand((side, side), device="cuda", generator=gen) - 0.5) * (frac * (hi - lo))
+            variants.append(("survey_8d_plus_%g%%_white_noise" % (100 * frac), noisy, "uniform noise of %g %% of the covariate's range on every cell" % (100 * frac)))
+        kinds = [p["kind"] for p in self.params]
+        out = torch.empty((side, side), dtype=torch.float64, device="cuda")
+        scale = 1e8 / (side * side)
+
+        def timed(stack, model, env=()):
+            for e in env:
+                os.environ[e] = "1"
+            try:
+                mhs.predict(stack, model, out=out)
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    mhs.predict(stack, model, out=out)
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t1) * 1e3)
+            finally:
+                for e in env:
+                    del os.environ[e]
+            return best * scale
+
+        rows = []
+        small_ms = sum(float(np.mean(v[-max(1, len(v) // 2):])) for k, v in self.ops.timings.items()
+                       if k.startswith("model_") and "+" in k and v) * 1e8 / self.cells
+        spline_ms = (float(np.mean(self.ops.timings["tps_eval_ms"][-2:])) if self.ops.timings.get("tps_eval_ms") else 0.0) * 1e8 / self.cells
+        for name, planes, what in variants:
+            stack = mhs.RasterStack(g, planes, float("nan"))
+            row = {"rasters": name, "what": what}
+            for kind, key in (("gbm", "gbm"), ("rf", "forest"), ("svr", "ksvm")):
+                model = self.models[kinds.index(kind)]
+                row[key + "_ms_per_1e8_cells"] = timed(stack, model)
+                if kind == "gbm":
+                    cst, cnt = C.c_int64(0), C.c_int64(0)
+                    _lib.check(_lib.lib().mhs_gbm_probe_last(model._h, C.byref(cst), C.byref(cnt)))
+                    if cnt.value:
+                        row["gbm_probe"] = {"estimated_cost_vs_tree_order_kernel": 0.12 + cst.value / (100.0 * cnt.value),
+                                            "coherent_kernel_ran": bool(cst.value < 83 * cnt.value)}
+                    row["gbm_tree_order_kernel_ms_per_1e8_cells"] = timed(stack, model, ("MHS_GBM_NO_COHERENT",))
+                elif kind == "rf":
+                    row["forest_round2_walk_ms_per_1e8_cells"] = timed(stack, model, ("MHS_RF_DOUBLE_BUFFER", "MHS_RF_NO_PREFIX", "MHS_RF_FULL_DEPTH", "MHS_RF_FAR_WALKS"))
+                else:
+                    row["ksvm_lane_per_cell_kernel_ms_per_1e8_cells"] = timed(stack, model, ("MHS_SVR_NO_ROWTILE",))
+            heavy = row["gbm_ms_per_1e8_cells"] + row["forest_ms_per_1e8_cells"] + row["ksvm_ms_per_1e8_cells"]
+            row["ensemble_plus_spline_mcells_per_s_estimate"] = 1e8 / ((heavy + small_ms + spline_ms) * 1e-3) / 1e6
+            rows.append(row)
+            del stack
+        return {"window": "NW %d x %d cells of the workload's grid, float32 planes resident in HBM; ms per 1e8 cells = time x %.4g" % (side, side, scale),
+                "estimate": "the three heavy members here + this run's fused small members (%.1f ms) and spline evaluation (%.1f ms) per 1e8 cells; the forest "
+                            "un-masked (no compute units reserved for the fit)" % (small_ms, spline_ms),
+                "variants": rows}
 
     def phase_table(self):
         """COLLECTIVE (every rank calls it): per-rank phase times [band, spline evaluation, fit inside the step,
@@ -851,6 +978,23 @@ def main():
         return
 
     phase_table = wl.phase_table() if world > 1 else None     # collective: outside the rank-0 block
+    # N > 1, global mode: the same Steps 2-5 with Step 3 the way the reference computes it above 1 500 px (tiles dealt over the
+    # ranks, no serial fit) for the record, so that one SCALE run shows both modes (collective; outside the timed region)
+    tiled_mode = None
+    if world > 1 and args.tps_mode == "global" and cfg["ensemble"] and not cfg.get("tiled") and not os.environ.get("MHS_BENCH_SKIP_TILED"):
+        from machisplin_amd import sharded
+        run2 = sharded.TiledTpsShardedMltps(PerModelOps(wl.ops), dist, rank, world, cfg["side"], cfg["side"], tile_edge=1500)
+        run2.step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            run2.step()
+        fence()
+        t2 = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        tiled_mode = {"tps_mode": "reference-tiled Step 3 (V73:636-897), tiles dealt over the ranks, one all-gather", "steps": 3,
+                      "ms_per_step": float(t2.item()) * 1e3, "mcells_per_s": wl.cells / float(t2.item()) / 1e6}
+        del run2
     if rank == 0:
         wl.measure_mean_visits()
         table = wl.kernel_table()
@@ -867,6 +1011,14 @@ def main():
         f64_boundary = None
         if world == 1 and cfg["ensemble"] and wl.cells <= 2 * 10 ** 8 and not os.environ.get("MHS_BENCH_SKIP_F64"):
             f64_boundary = wl.f64_boundary()
+        raster_sensitivity = None
+        if world == 1 and cfg["ensemble"] and not os.environ.get("MHS_BENCH_SKIP_SENSITIVITY"):
+            reserved = wl.ops.reserve(0)
+            try:
+                raster_sensitivity = wl.raster_sensitivity()
+            finally:
+                if reserved:
+                    wl.ops.reserve(reserved)
         knots, resid = wl.ops.X[:, -2:], wl.run.ops.station_residuals()[1]
         fit_ms = 1e30
         for _ in range(2):
@@ -926,7 +1078,44 @@ def main():
         # N = 1: what the row-band driver should do on 2 / 4 / 8 GPUs, from this run's parts and model_check's own formula --
         # a prediction for the first real SCALE run to be held against (8-GPU boxes are the driver's, not the builder's)
         projected = None
-        if world == 1 and table:
+        if world == 1 and table and args.tps_mode == "tiled":
+            # Reference-tiled Step 3 (V73:656-747) has NO serial fit: every rank predicts its band and fits + evaluates its
+            # share of the tiles (LPT-dealt on stations x cells), ONE all-gather moves bands and tile planes, every rank mosaics.
+            # Model: step(N) = max(ens / N, tiles(N)) + gather(N) + mosaic + Step 5, with
+            #   tiles(N)  = the stand-alone time of all tiles x the heaviest rank's cost share, but never less than one wave of
+            #               8 tiles side by side (8 / n_tiles of the stand-alone time: the library fits 8 tiles at once);
+            #   gather(N) = one rank's chunk (its band + its tile planes, 8 B per cell) over one 153 GB/s xGMI link per peer;
+            #   mosaic + Step 5 measured here, stand-alone.
+            from machisplin_amd import sharded
+            run = wl.run
+            ens = sum(r["launch_ms"] for r in table if not r["kernel"].startswith("tps_"))
+            step1 = dt / args.steps * 1e3
+            costs = [float(c) for c in run.layout["cost"]]
+            tiles_view = [run._tile_view(run.full, run.owner[h] * run.chunk, h) for h in range(len(run.keep))]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run.ops.tps_mosaic(run.layout["nRx"], run.layout["nCx"], run.keep, tiles_view, run.total)
+            torch.cuda.synchronize()
+            mosaic_ms = (time.perf_counter() - t1) * 1e3
+            tiles_alone = max(tiled_ms - mosaic_ms, 1e-3)
+            tiles_in_step = float(np.mean(tm["tps_tiles_ms"][-max(1, len(tm["tps_tiles_ms"]) // 2):])) if tm.get("tps_tiles_ms") else None
+            tail1 = max(0.0, step1 - max(ens, tiles_in_step or 0.0))      # mosaic, the band sums, Step 5 as this run had them
+            projected = {"model": "step(N) = max(ens / N, tiles(N)) + gather(N) + tail; tiles(N) = stand-alone tile time x max(heaviest rank's LPT cost share, "
+                                  "8 / n_tiles); gather(N) = (band + tile planes of one rank) x 8 B over one 153 GB/s xGMI link per peer; tail = this run's step "
+                                  "minus max(ens, tiles in the step) = mosaic + feathering + band sums + Step 5.  No serial fit in this mode.",
+                         "ensemble_ms_n1": ens, "tiles_ms_alone": tiles_alone, "tiles_ms_in_step_n1": tiles_in_step, "mosaic_ms": mosaic_ms,
+                         "tail_ms": tail1, "step_ms_n1": step1, "n_tiles": len(costs)}
+            tile_cells = float(sum(run.cells))
+            for N in (2, 4, 8):
+                owner = sharded.assign_tiles(costs, N)
+                load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(N)]
+                share = max(max(load) / sum(costs), min(1.0, 8.0 / len(costs)))
+                tiles_n = tiles_alone * share
+                gather = (wl.cells + tile_cells) * 8.0 / N / 153e9 * 1e3
+                step = max(ens / N, tiles_n) + gather + tail1
+                projected["n%d" % N] = {"band_ms": ens / N, "tiles_ms": tiles_n, "heaviest_rank_cost_share": max(load) / sum(costs), "gather_ms": gather,
+                                        "step_ms": step, "mcells_per_s": wl.cells / step / 1e3, "speedup_over_n1": step1 / step}
+        elif world == 1 and table:
             ens = sum(r["launch_ms"] for r in table if not r["kernel"].startswith("tps_"))
             spl = sum(r["launch_ms"] for r in table if r["kernel"].startswith("tps_"))
             step1 = dt / args.steps * 1e3
@@ -964,7 +1153,7 @@ def main():
                                     "reference-tiled (ceil(n/1500)^2 overlapping tiles with their own GCV fits, mosaic, feathering, V73:636-897), tiles dealt over the ranks"),
                        "parallelism": ("rowband%d + bcast(coef) + 1 all-gather" if args.tps_mode == "global" else
                                        "rowband%d + Step-3 tiles dealt over the ranks + 1 all-gather") % world,
-                       "rank0_row_share": wl.rank0_share},
+                       "rank0_row_share": wl.rank0_share, "fit_reservation": wl.reservation},
             "roofline": ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work", "pmc",
                                                "ops_view", "issue_view") if k in dom} if dom else None),  # None only if rank 0 was given no rows at all
             "kernels": table,
@@ -973,7 +1162,8 @@ def main():
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "tps_eval_check": eval_check,
-            "f64_boundary": f64_boundary, "model_check": model_check, "projected": projected,
+            "f64_boundary": f64_boundary, "raster_sensitivity": raster_sensitivity, "model_check": model_check, "projected": projected,
+            "tiled_mode_same_run": tiled_mode,
             "lambda": wl.last.get("lambda"), "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only

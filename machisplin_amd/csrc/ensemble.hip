@@ -84,6 +84,10 @@ struct mhs_model {
     unsigned *lut_cls = nullptr;         // device, 5 class words per tree (rank threshold << 3 | predictor; gbm_coherent_kernel)
     int *gbm_probe = nullptr;            // device, GBC_PROBE_SLOTS x 8 ints: per launch, what the probe blocks summed
     std::atomic<unsigned> gbm_probe_next{0};
+    // NA cells of a window, compacted for the MissingNode walk (round 4): 4 buffers in turn, {count, overflow, cell indices ...}
+    unsigned *na_list[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t na_cap[4] = {0, 0, 0, 0};
+    std::atomic<unsigned> na_next{0};
     std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
     std::vector<double> lut_thr;         // host, n_trees x lut_S split values
@@ -480,8 +484,9 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
                                                    const TreeChunk *__restrict__ chunks, int n_chunks,
                                                    int n_trees, double init_f, int p, StackDev s,
                                                    PredGeom g, double weight, int accumulate,
-                                                   double *__restrict__ out) {
+                                                   double *__restrict__ out, const unsigned *__restrict__ na_gate = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (NA_ONLY && na_gate && na_gate[1] == 0u) return;          // the compacted NA list held every NA cell: nothing left to do here
     double *xs = (double *)smem;                                  // [p][R*256]
     Node *lnodes = (Node *)(smem + (size_t)p * R * 256 * sizeof(double));
     const int64_t total = (int64_t)g.nr * g.nc;
@@ -562,6 +567,67 @@ __global__ __launch_bounds__(256) void tree_kernel(const Node *__restrict__ gnod
     }
 }
 
+
+// NA cells of a gbm window (round 4).  The predicate-LUT kernels skip cells with an NA covariate; gbm routes those through
+// its MissingNode children (gbm_pred).  The strided NA-only pass above walks all 10 000 trees in every BLOCK that holds a
+// single NA cell among its 1 024 -- on the reference's bundled rasters (0.09 % NoData along the coast) that was 214 of
+// 401 ms per 1e8 cells.  Now: one pass over the planes appends the NA cells to a list (na_collect_kernel), and the walk
+// runs over the list, 256 NA cells per block (gbm_na_list_kernel).  A window with more NA cells than the list holds sets
+// the overflow word and the strided pass takes over.
+__global__ __launch_bounds__(256) void na_collect_kernel(StackDev s, PredGeom g, unsigned cap, unsigned *__restrict__ list) {
+    const int64_t total = (int64_t)g.nr * g.nc;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+    bool na = false;
+    for (int j = 0; j < s.C; ++j) na |= isnan(predictor(s, g, j, row, col));
+    if (na) {
+        const unsigned slot = atomicAdd(&list[0], 1u);
+        if (slot < cap) list[2 + slot] = (unsigned)i;
+        else list[1] = 1u;
+    }
+}
+template <bool LDS_NODES>
+__global__ __launch_bounds__(256) void gbm_na_list_kernel(const Node *__restrict__ gnodes, const int *__restrict__ tree_off,
+                                                          const TreeChunk *__restrict__ chunks, int n_chunks, double init_f, int p,
+                                                          StackDev s, PredGeom g, double weight, int accumulate,
+                                                          double *__restrict__ out, const unsigned *__restrict__ list, unsigned cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (list[1]) return;                                          // overflow: the strided pass does the work
+    double *xs = (double *)smem;                                  // [p][256]
+    Node *lnodes = (Node *)(smem + (size_t)p * 256 * sizeof(double));
+    const unsigned count = min(list[0], cap);
+    for (unsigned base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        const bool live = base + threadIdx.x < count;
+        const int64_t i = list[2 + (live ? base + threadIdx.x : base)];
+        const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
+        for (int j = 0; j < p; ++j) xs[j * 256 + threadIdx.x] = predictor(s, g, j, row, col);
+        double acc = 0.0;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const TreeChunk tc = chunks[ch];
+            if (LDS_NODES) {
+                __syncthreads();
+                const int4 *src = (const int4 *)(gnodes + tc.node_begin);
+                int4 *dst = (int4 *)lnodes;
+                for (int e = threadIdx.x; e < tc.node_count; e += 256) dst[e] = src[e];
+                __syncthreads();
+            }
+            for (int t = tc.first_tree; t < tc.first_tree + tc.n_trees; ++t) {
+                const int tbase = LDS_NODES ? tree_off[t] - tc.node_begin : tree_off[t];
+                Node nd;
+                if constexpr (LDS_NODES) nd = lnodes[tbase]; else nd = gnodes[tbase];
+                while (nd.var >= 0) {
+                    const double xv = xs[nd.var * 256 + threadIdx.x];
+                    const unsigned nxt = isnan(xv) ? nd.missing : (xv < nd.val ? nd.left : nd.right);
+                    if constexpr (LDS_NODES) nd = lnodes[tbase + nxt]; else nd = gnodes[tbase + nxt];
+                }
+                acc = acc + nd.val;
+            }
+        }
+        if (live) emit(out, (int64_t)row * g.ld_out + col, init_f + acc, weight, accumulate);
+        __syncthreads();
+    }
+}
 
 // ---------------------------------------------------------- gbm: predicate LUT --
 // Trees grown with interaction.depth = 5 (V73:493) have <= 5 splits, so a tree is a function
@@ -2149,7 +2215,7 @@ static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g
         auto kern = tree_kernel<GBM, true, TREE_R, false, true>;
         MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(kern, dim3(blocks, (unsigned)shares), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks,
-                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, mm->split_scratch);
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, mm->split_scratch, (const unsigned *)nullptr);
         hipLaunchKernelGGL(tree_finalize_kernel<GBM>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            mm->split_scratch, shares, total, m->init_f, m->n_trees, g, w, acc, out);
         return MHS_OK;
@@ -2159,12 +2225,12 @@ static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g
         auto kern = tree_kernel<GBM, true, TREE_R, NA_ONLY>;
         MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks,
-                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out, (const unsigned *)nullptr);
     } else {
         auto kern = tree_kernel<GBM, false, TREE_R, NA_ONLY>;
         MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), xs_bytes, st, m->nodes, m->tree_off, m->chunks,
-                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out);
+                           m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out, (const unsigned *)nullptr);
     }
     return MHS_OK;
 }
@@ -2347,6 +2413,57 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, 
     return MHS_OK;
 }
 
+// the MissingNode walk of a window's NA cells behind a predicate-LUT kernel: compacted list, strided pass on overflow
+static int launch_gbm_na(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc, double *out, hipStream_t st,
+                         int64_t total) {
+    if (getenv("MHS_GBM_NA_STRIDED") || total >= (1LL << 32)) return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+    mhs_model *mm = const_cast<mhs_model *>(m);
+    const unsigned slot = mm->na_next.fetch_add(1) % 4;
+    const size_t want = (size_t)std::max<int64_t>(4096, total / 8);      // up to 12.5 % NA cells; beyond: the strided pass
+    {
+        std::lock_guard<std::mutex> lk(mm->mu);
+        if (mm->na_cap[slot] < want) {
+            if (mm->na_list[slot]) { MHS_HIP(hipStreamSynchronize(st)); (void)hipFree(mm->na_list[slot]); mm->na_list[slot] = nullptr; mm->na_cap[slot] = 0; }
+            MHS_HIP(hipMalloc((void **)&mm->na_list[slot], sizeof(unsigned) * (want + 2)));
+            mm->na_cap[slot] = want;
+        }
+    }
+    unsigned *list = mm->na_list[slot];
+    const unsigned cap = (unsigned)mm->na_cap[slot];
+    MHS_HIP(hipMemsetAsync(list, 0, 2 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(na_collect_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, g, cap, list);
+    const unsigned lblocks = (unsigned)std::min<int64_t>(2048, (total / 8 + 255) / 256 + 1);
+    const size_t xs_bytes = (size_t)m->p * 256 * sizeof(double);
+    if (m->lds_ok) {
+        const size_t bytes = xs_bytes + (size_t)m->max_chunk_nodes * sizeof(Node);
+        MHS_HIP(hipFuncSetAttribute((const void *)gbm_na_list_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(gbm_na_list_kernel<true>, dim3(lblocks), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks, m->n_chunks, m->init_f,
+                           m->p, s, g, w, acc, out, list, cap);
+    } else {
+        MHS_HIP(hipFuncSetAttribute((const void *)gbm_na_list_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
+        hipLaunchKernelGGL(gbm_na_list_kernel<false>, dim3(lblocks), dim3(256), xs_bytes, st, m->nodes, m->tree_off, m->chunks, m->n_chunks,
+                           m->init_f, m->p, s, g, w, acc, out, list, cap);
+    }
+    // the strided NA-only pass, gated on the overflow word (its blocks return at once otherwise)
+    const int64_t half = (total + TREE_R - 1) / TREE_R;
+    const unsigned blocks = (unsigned)((half + 255) / 256);
+    const size_t xs4 = (size_t)m->p * TREE_R * 256 * sizeof(double);
+    if (m->lds_ok) {
+        const size_t bytes = xs4 + (size_t)m->max_chunk_nodes * sizeof(Node);
+        auto kern = tree_kernel<true, true, TREE_R, true>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->nodes, m->tree_off, m->chunks, m->n_chunks, m->n_trees, m->init_f, m->p,
+                           s, g, w, acc, out, (const unsigned *)list);
+    } else {
+        auto kern = tree_kernel<true, false, TREE_R, true>;
+        MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs4));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), xs4, st, m->nodes, m->tree_off, m->chunks, m->n_chunks, m->n_trees, m->init_f, m->p,
+                           s, g, w, acc, out, (const unsigned *)list);
+    }
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
 static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
                           double w, int acc, double *out, hipStream_t st, int64_t total) {
     const int key64 = s.dtype == MHS_F64;
@@ -2389,7 +2506,7 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
         hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
                            m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe);
-        if (!probe) return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+        if (!probe) return launch_gbm_na(m, s, g, w, acc, out, st, total);
     }
     if (rt_ok) {
         const int64_t ntiles = (int64_t)g.nr * tpr;
@@ -2398,7 +2515,7 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
         MHS_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_bytes));
         hipLaunchKernelGGL(rk, dim3(rblocks), dim3(256), lut_bytes, st, tt.lut_rt, (const u64x8 *)tt.lut_rt_meta, tt.sorted, tt.sorted_off,
                            m->n_trees_padded, m->init_f, m->p, s, g, tpr, w, acc, out, (const int *)probe);
-        return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+        return launch_gbm_na(m, s, g, w, acc, out, st, total);
     }
     const size_t bytes = in_regs ? lut_bytes : (size_t)m->p * 256 * LUT_R * sizeof(float) + lut_bytes;
     auto kern = in_regs ? (m->lut_S == 5 ? (key64 ? gbm_lutreg_kernel<5, true> : gbm_lutreg_kernel<5, false>)
@@ -2408,7 +2525,7 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, m->lut, tt.lut_meta, tt.sorted, key64, tt.sorted_off,
                        m->n_trees_padded, m->init_f, m->p, s, g, w, acc, out);
     // cells with an NA covariate: walked through their MissingNode children
-    return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+    return launch_gbm_na(m, s, g, w, acc, out, st, total);
 }
 
 
@@ -2815,6 +2932,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->tree_off) (void)hipFree(m->tree_off);
     if (m->chunks) (void)hipFree(m->chunks);
     if (m->split_scratch) (void)hipFree(m->split_scratch);
+    for (unsigned *q : m->na_list) if (q) (void)hipFree(q);
     if (m->lut) (void)hipFree(m->lut);
     if (m->lut_meta) (void)hipFree(m->lut_meta);
     if (m->lut_rt) (void)hipFree(m->lut_rt);

@@ -20,18 +20,12 @@ import os
 import numpy as np
 
 # Compute units the fitting rank keeps free of one long ensemble kernel (the forest) so that the spline can be fitted
-# beside the grid kernels (mhs_fit_reserve_cus; 0 = off; a multiple of 8).  Measured on cfg3: DESIGN.md section 9.
-# 64 since the end of round 3: the fit must END while the forest runs (afterwards it competes with ksvm's grid-filling blocks
-# for every one of its small launches), and the forest got short -- on 32 units the fit outlived it and finished at 301 ms of a
-# 309 ms step; on 64 it is done at 135 ms, the forest pays 131 instead of 112 ms, the step takes 298 (48: 305, 96: 324, 0: 328).
-FIT_RESERVE_CUS = 64
-# ... only while the fit is a latency-bound chain (62 ms alone at 5 000 stations, 143 ms on 32 units): at 20 000
-# stations it is compute-bound (1.2 s on the whole chip) and confining it to an eighth of the chip costs seconds
-FIT_RESERVE_MAX_STATIONS = 6000
-# ... and while the fitting rank's band is large enough for its forest to run as long as the confined fit (143 ms at
-# 5 000 stations; the forest takes ~2.1 ns per cell with 500 trees): with a shorter band the fit would be left
-# confined AND starved once the forest is done
-FIT_RESERVE_MIN_CELLS = 60_000_000
+# beside the grid kernels (mhs_fit_reserve_cus; 0 = off; the cost to the masked kernel comes in quanta of 32 units).
+# Whether that pays, and with how many units, depends on how long the forest and the fit take on THIS box with THIS
+# workload -- rounds 2 and 3 re-tuned three hand-set constants twice (32 -> 64 units; "up to 6 000 stations"; "bands of 6e7+
+# cells") because the forest got shorter.  Round 4: no constants.  ShardedMltps.calibrate_reservation() times whole steps
+# with each candidate and keeps the fastest; without that call nothing is reserved (MHS_FIT_RESERVE_CUS forces a value).
+FIT_RESERVE_CANDIDATES = (0, 32, 64, 96)
 
 
 # Bands are cut at multiples of this many grid rows: the coherent gbm kernel sums a cell's trees in an order that depends on
@@ -133,8 +127,36 @@ class ShardedMltps:
         self.pred = torch.zeros((self.band, ncol), **kw) if world > 1 else self.full   # this rank's chunk
         self.total = torch.zeros((nrow, ncol), **kw)                  # final.TPS, then pred.elev + final.TPS
         self.torch = torch
-        self.fit_reserve_cus = int(os.environ.get("MHS_FIT_RESERVE_CUS", FIT_RESERVE_CUS))
-        self.fit_reserve_min_cells = FIT_RESERVE_MIN_CELLS
+        self.fit_reserve_cus = int(os.environ.get("MHS_FIT_RESERVE_CUS", 0))
+        self.reservation_calibration = None
+
+    def calibrate_reservation(self, candidates=FIT_RESERVE_CANDIDATES, repeats: int = 2):
+        """Times whole steps with 0 / 32 / 64 / 96 compute units kept free for the fit on the fitting rank and keeps the
+        fastest setting (COLLECTIVE at N > 1: every rank steps along, rank 0 decides for itself -- only its forest is masked).
+        A setup call, outside any timed region; MHS_FIT_RESERVE_CUS overrides it.  Returns {units: step ms}."""
+        import time
+        torch = self.torch
+        if "MHS_FIT_RESERVE_CUS" in os.environ or not hasattr(self.ops, "reserve"):
+            return None
+        timings = {}
+        for cus in candidates:
+            self.fit_reserve_cus = cus
+            best = float("inf")
+            for _ in range(repeats):
+                if self.world > 1:
+                    self.dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                self.step()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            timings[cus] = best
+        if self.rank == 0:
+            self.fit_reserve_cus = min(timings, key=lambda c: (timings[c], c))
+        else:
+            self.fit_reserve_cus = 0
+        self.reservation_calibration = {"step_ms_by_reserved_units": timings, "chosen": self.fit_reserve_cus}
+        return timings
 
     def step(self):
         # The whole step is enqueued on a stream of its own (ops.side_stream, non-blocking), never on the NULL stream:
@@ -158,10 +180,9 @@ class ShardedMltps:
         # prioritised small grid gets its slots within a millisecond or two of its launch, so the residuals cost
         # nothing on the critical path, and rank 0 fits the spline while every rank's band is still running
         # ... provided its small dependent kernels find workgroup slots beside grid-filling kernels: the fitting rank
-        # launches the forest with FIT_RESERVE_CUS compute units masked out and confines the fit to them.
-        small_fit = getattr(ops, "n_stations", FIT_RESERVE_MAX_STATIONS + 1) <= FIT_RESERVE_MAX_STATIONS
-        long_band = nb * self.ncol >= self.fit_reserve_min_cells
-        reserve = getattr(ops, "reserve", None) if (self.rank == 0 and self.fit_reserve_cus > 0 and small_fit and long_band) else None
+        # launches the forest with fit_reserve_cus compute units masked out and confines the fit to them (the number comes
+        # from calibrate_reservation's measurement, or is 0).
+        reserve = getattr(ops, "reserve", None) if (self.rank == 0 and self.fit_reserve_cus > 0 and nb > 0) else None
         prev = reserve(self.fit_reserve_cus) if reserve else None
         try:
             if nb > 0:
@@ -249,7 +270,6 @@ class TiledTpsShardedMltps:
         # no reservation here by default: the tiles' evaluations are real work (773 ms per cfg3 step when confined to 32
         # units); off the NULL stream the small fits and evaluations find their slots beside the band (546 ms)
         self.fit_reserve_cus = int(os.environ.get("MHS_TILED_FIT_RESERVE_CUS", 0))
-        self.fit_reserve_min_cells = FIT_RESERVE_MIN_CELLS
 
     def _tile_view(self, buf, base, h):
         r0, r1, c0, c1 = self.keep[h]
@@ -271,7 +291,7 @@ class TiledTpsShardedMltps:
         nb = self.r1 - self.r0
         # this rank's tiles (small fits + their evaluations) run beside its band on the compute units the forest is
         # launched without (mhs_fit_reserve_cus), when the band is long enough for that to pay
-        reserve = getattr(ops, "reserve", None) if (self.fit_reserve_cus > 0 and nb * self.ncol >= self.fit_reserve_min_cells) else None
+        reserve = getattr(ops, "reserve", None) if (self.fit_reserve_cus > 0 and nb > 0) else None
         prev = reserve(self.fit_reserve_cus) if reserve else None
         try:
             if nb > 0:

@@ -90,6 +90,30 @@ def test_gbm_routes_na_through_missing_nodes(hip):
     assert np.abs(got - oe.predict(prm, X)).max() <= _tol(got)
 
 
+@pytest.mark.parametrize("frac", [0.002, 0.3])
+def test_gbm_na_cells_through_the_compacted_list_equal_the_strided_pass(hip, frac, monkeypatch):
+    """gbm's MissingNode routing for cells with an NA covariate (gbm_pred; terra::predict(rast_stack, gbm), V73:497): round 4
+    walks them from a compacted list instead of in every block that holds one (0.09 % NoData on the reference's rasters cost
+    half the kernel).  0.2 % NA: the list; 30 % NA: more than the list holds -> the overflow word hands the window back to
+    the strided pass.  Either way the plane is the strided pass's, bit for bit, and the oracle's."""
+    import torch
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=160, ncol=300, dtype="f32", nodata_frac=frac, n=900, gbm_trees=400, rf_trees=2)
+    prm = params[0]
+    assert prm["kind"] == "gbm"
+    m = hip.models.from_param_dict(prm)
+    a = hip.predict(stack, m)
+    acc = hip.predict(stack, m, weight=0.5, accumulate=True, out=a.clone())
+    monkeypatch.setenv("MHS_GBM_NA_STRIDED", "1")
+    b = hip.predict(stack, m)
+    monkeypatch.delenv("MHS_GBM_NA_STRIDED")
+    assert not torch.isnan(a).any() and torch.equal(a, b)
+    assert torch.allclose(acc, 1.5 * a, rtol=1e-15, atol=0)
+    want = oe.predict(prm, X)
+    assert np.nanmax(np.abs(a.cpu().numpy().ravel() - want)) <= _tol(want)
+    win = hip.predict(stack, m, window=(5, 150, 3, 290))      # another tiling of the coherent kernel: equal to rounding
+    assert float((win - a[5:150, 3:290]).abs().max()) <= 1e-13 * float(a.abs().max())
+
+
 def test_sklearn_fitted_structures(hip):
     """Real fitted trees / SVR / MLP (exported by tests/modelgen.py) rather than synthetic ones."""
     from sklearn.ensemble import GradientBoostingRegressor, RandomForestRegressor
@@ -530,8 +554,8 @@ def test_ksvm_row_tile_kernel_alone_matches_the_oracle(hip, dtype, C, monkeypatc
 def test_ksvm_row_tile_kernel_keeps_the_addition_where_a_wave_spreads(hip, dtype, monkeypatch):
     """A covariate JUMP inside a wave: with q = sigma |x~|^2 / 700 spreading more than 0.5 over the wave's 192 cells the
     row-tile kernel must keep the per-pair addition (folding would flush terms the cell's back-scaling cannot restore).
-    Plane 0 carries a spike of 16 standard deviations on three columns (250..252, inside the second wave) of rows 0..19 --
-    too few cells to move the model's centre and scale -- and sigma = 2: the spread is ~2 * 16^2 / 700 = 0.73, and a wave that
+    Plane 0 carries a spike of 24 standard deviations on three columns (250..252, inside the second wave) of rows 0..19 --
+    too few cells to move the model's centre and scale -- and sigma = 2: the spread is ~2 * 24^2 / 700 = 1.6, and a wave that
     folded anyway would flush the terms of its ordinary cells.  Rows 20.. have no spike (those waves fold).  Against the oracle
     at 1e-11."""
     import torch
@@ -540,7 +564,7 @@ def test_ksvm_row_tile_kernel_keeps_the_addition_where_a_wave_spreads(hip, dtype
     g = synth.grid(nrow, ncol)
     planes, nodata = synth.covariates(g, C, 5, dtype=dtype, nodata_frac=0.01)
     sd0 = float(torch.nan_to_num(planes[0].double()).std())
-    planes[0, :20, 250:253] += 16.0 * sd0
+    planes[0, :20, 250:253] += 24.0 * sd0
     stack = hip.RasterStack(g, planes, nodata)
     host = planes.cpu().numpy().astype(np.float64)
     x, y = otps.cell_centres(g.xmin, g.ymax, g.xres, g.yres, nrow, ncol)

@@ -317,13 +317,17 @@ def test_fit_beside_the_forest_changes_no_number(hip):
     for reserve in (0, 32):
         ops = sharded.HipOps(stack, xy, resp, mods, weights, wt_total)
         run = sharded.ShardedMltps(ops, None, 0, 1, side, side)
-        run.fit_reserve_cus, run.fit_reserve_min_cells = reserve, 0      # (the band-length rule would switch it off at this size)
+        run.fit_reserve_cus = reserve
         o = run.step()
         torch.cuda.synchronize()
         outs.append((o["final"].clone(), o["lambda"], o["rsq_model"], o["rsq_final"]))
         assert models.fit_reserve_cus(0) == 0                      # the step leaves the setting as it found it
     assert torch.equal(torch.nan_to_num(outs[0][0]), torch.nan_to_num(outs[1][0]))
     assert outs[0][1:] == outs[1][1:]
+    # round 4: the number of units comes from a measurement, not from constants
+    cal = run.calibrate_reservation(candidates=(0, 32), repeats=1)
+    assert set(cal) == {0, 32} and run.fit_reserve_cus in (0, 32) and run.reservation_calibration["chosen"] == run.fit_reserve_cus
+    assert models.fit_reserve_cus(0) == 0
     with pytest.raises(hip.MhsError):
         models.fit_reserve_cus(12)                                 # not a multiple of 8
     with pytest.raises(hip.MhsError):
