@@ -16,7 +16,7 @@ constexpr int B32_MAXLAM = 1024;         // lambdas per search round
 
 // device work space of one fit on this route, carved from the lane's arena
 struct Band32Ws {
-    double *Gp1, *Gp2, *R1, *Qtop, *aux, *Zc[2], *Vr[2], *Yp, *Wh, *Mp, *sgp, *Tall, *ab, *win, *res, *lamd, *out, *Lbuf, *ybuf, *btpart;
+    double *Gp1, *Gp2, *R1, *Qtop, *aux, *Zc[2], *Vr[2], *Yp, *Wh, *Mp, *sgp, *Tall, *ab, *abF, *abR, *win, *res, *lamd, *out, *Lbuf, *ybuf, *btpart;
     int *flags;
 };
 size_t band32_workspace_bytes(int m, int64_t n);
@@ -45,6 +45,8 @@ struct Band32Search {
     Band32Ws *ws = nullptr;
     double *pin = nullptr;            // pinned host buffer: B32_MAXLAM lambdas, then 4 doubles per lambda of results
     int rounds = 0;                   // evaluation rounds made (diagnostic)
+    bool packed = false;              // ws->abF / abR hold this band and right-hand side
+    int pack();
     // per lambda: eigenvalues of Bb below -lambda (inertia), tr (Bb + lambda I)^-1, g'(Bb + lambda I)^-2 g
     int eval_batch(const double *lam, int count, bool deriv, double *neg, double *tr, double *q2);
     int find_lambda(int mode, double *lam_out);

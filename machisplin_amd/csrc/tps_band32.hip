@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 #include "common.h"
 #include "devmath.h"
@@ -41,6 +42,22 @@ constexpr int CHR = 256;                   // rows per chunk: one row per thread
 constexpr int PT_S = CHR + 2;              // LDS stride of a transposed chunk Pt[a][i]: == 2 (mod 32), so the 16 x 4 MFMA
                                            // operand reads Pt[a0 + l15][k0 + l4] touch 32 distinct bank pairs per half-wave
 typedef double d4v __attribute__((ext_vector_type(4)));
+
+// -DB32_PROF: block 0 of every stage-1 kernel adds the shader-clock cycles between its phase marks to a table the host
+// prints after the reduction (a development build; the shipped library carries none of this)
+#ifdef B32_PROF
+__device__ unsigned long long b32_prof_tab[8][16];
+#define B32_PROF_BEGIN unsigned long long prof_t = __builtin_readcyclecounter();
+#define B32_MARK(K, P)                                                                              \
+    do {                                                                                            \
+        const unsigned long long prof_n = __builtin_readcyclecounter();                             \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) b32_prof_tab[K][P] += prof_n - prof_t; \
+        prof_t = prof_n;                                                                            \
+    } while (0)
+#else
+#define B32_PROF_BEGIN
+#define B32_MARK(K, P)
+#endif
 
 // ------------------------------------------------------------------------------------------------ small helpers --
 // What a previous launch wrote sits in another XCD's L2 or in HBM: a load of it costs ~2 us, and a loop of "load, add" over
@@ -64,6 +81,19 @@ __device__ __forceinline__ void store_tile32(double *__restrict__ out, const d4v
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(ta * 16 + l4 + 4 * r) * NB + tb * 16 + l15] = acc[r];
 }
+// one 16 x 16 tile (wave w: rows 16 (w >> 1) .., columns 16 (w & 1) ..) of the 32 x 32 product X Y (TA: X'Y) of two LDS
+// matrices, on MFMA; entry r of the result is row 16 (w >> 1) + (lane >> 4) + 4 r, column 16 (w & 1) + (lane & 15)
+template <bool TA>
+__device__ __forceinline__ d4v mm32_tile(const double (*X)[NB + 1], const double (*Y)[NB + 1]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, ta = wave >> 1, tb = wave & 1;
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        const double a = TA ? X[k0 + l4][ta * 16 + l15] : X[ta * 16 + l15][k0 + l4];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Y[k0 + l4][tb * 16 + l15], acc, 0, 0, 0);
+    }
+    return acc;
+}
 // the sum of up to MAXPART 32 x 32 partial matrices (added in block order), entry e = tid + 256 q: loads first, adds after
 struct Parts4 { double v[4][MAXPART_H]; };
 __device__ __forceinline__ void parts_issue(Parts4 &P, const double *__restrict__ part, int nparts) {
@@ -86,19 +116,51 @@ __device__ __forceinline__ void parts_sum(const Parts4 &P, double (*G)[NB + 1]) 
     }
 }
 
-// G (lower triangle, LDS [32][33]) -> its Cholesky factor L in place (G = L L'), 256 threads.  One barrier per column:
-// step k reads column k (rows > k, untouched by this step) and updates the columns right of it with the unscaled
-// entries, G[i][j] -= G[i][k] G[j][k] / G[k][k]; the columns are scaled by 1 / sqrt(pivot) at the end.  Returns false
-// (in every thread) if a pivot was not positive -- the panel was numerically rank deficient.
+// G (lower triangle, LDS [32][33]) -> its Cholesky factor L in place (G = L L'), 256 threads.  One barrier per PAIR of
+// columns: a step reads columns k and k + 1 as they stand, redoes column k's effect on column k + 1 in registers and
+// updates the columns right of them with the unscaled entries, G[i][j] -= G[i][k] G[j][k] / G[k][k] and then the same with
+// k + 1 -- entry by entry the very operations of the one-column loop (a barrier-separated LDS round trip costs ~470 ns, and
+// 31 of them were 14.6 us of the first pass's 32; the elimination in one wave's registers, broadcasting through v_readlane
+// or through the LDS, was tried and is slower still: the compiler spills what it hoists).  The columns are scaled by
+// 1 / sqrt(pivot) at the end.  Returns false (in every thread) if a pivot was not positive -- the panel was numerically
+// rank deficient.
 __device__ __forceinline__ bool chol32_lds(double (*G)[NB + 1], double *sd /* [32] */) {
+    __shared__ double Gf[NB][NB + 1];      // the odd columns 1 .. 29 as their pair's step leaves them
     const int i = threadIdx.x >> 3, jg = threadIdx.x & 7;
     bool ok = true;
-    for (int k = 0; k < NB - 1; ++k) {
+    for (int k = 0; k < NB - 2; k += 2) {
+        __syncthreads();
+        // straight-line: every thread rewrites its four entries (unchanged where the step does not reach), so that the
+        // step is one batch of LDS reads and one of writes instead of four predicated read-modify-write round trips
+        double d = G[k][k];
+        const double e = G[k + 1][k], d1raw = G[k + 1][k + 1], gi0 = G[i][k], gi1 = G[i][k + 1];
+        double gj0[4], gj1[4], old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gj0[q] = G[jg + 8 * q][k]; gj1[q] = G[jg + 8 * q][k + 1]; old[q] = G[i][jg + 8 * q]; }
+        if (!(d > 0.0) || !(d < 1e300)) { ok = false; d = 1.0; }
+        const double r0 = frcp(d);
+        const double ek = e * r0;                         // what row k + 1 subtracts from the rows below it in column k's step
+        double d1 = d1raw - ek * e;
+        if (!(d1 > 0.0) || !(d1 < 1e300)) { ok = false; d1 = 1.0; }
+        const double r1 = frcp(d1);
+        const double gik = gi0 * r0;
+        const double gik1 = (i > k ? gi1 - gik * e : gi1) * r1;      // column k + 1 of row i after column k's step
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = jg + 8 * q;
+            const double v0 = (i > k && j > k && j <= i) ? old[q] - gik * gj0[q] : old[q];
+            const double gj1u = j > k ? gj1[q] - (gj0[q] * r0) * e : gj1[q];      // G[j][k + 1] after column k's step
+            // column k + 1 is still being READ by other threads in this step: its updated entries (final: no later step
+            // touches them) go to the second copy
+            double *dst = j == k + 1 ? &Gf[i][j] : &G[i][j];
+            *dst = (i > k + 1 && j > k + 1 && j <= i) ? v0 - gik1 * gj1u : v0;
+        }
+    }
+    {   // column 30 (the last one with a row below it)
+        const int k = NB - 2;
         __syncthreads();
         double d = G[k][k];
         if (!(d > 0.0) || !(d < 1e300)) { ok = false; d = 1.0; }
-        // straight-line: every thread rewrites its four entries (unchanged where the step does not reach), so that the
-        // step is one batch of LDS reads and one of writes instead of four predicated read-modify-write round trips
         const double gik = G[i][k] * frcp(d);
         double gjk[4], old[4];
 #pragma unroll
@@ -111,15 +173,16 @@ __device__ __forceinline__ bool chol32_lds(double (*G)[NB + 1], double *sd /* [3
     }
     __syncthreads();
     if (threadIdx.x < NB) {
-        double d = G[threadIdx.x][threadIdx.x];
+        const int t = threadIdx.x;
+        double d = ((t & 1) && t < NB - 2) ? Gf[t][t] : G[t][t];
         if (!(d > 0.0) || !(d < 1e300)) { ok = false; d = 1.0; }
-        sd[threadIdx.x] = sqrt(d);
+        sd[t] = sqrt(d);
     }
     ok = __syncthreads_and(ok);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = jg + 8 * q;
-        if (j < i) G[i][j] = G[i][j] / sd[j];
+        if (j < i) G[i][j] = (((j & 1) && j < NB - 2) ? Gf[i][j] : G[i][j]) / sd[j];
         else if (j == i) G[i][j] = sd[j];
     }
     __syncthreads();
@@ -213,6 +276,7 @@ __global__ __launch_bounds__(256) void b32_gram_kernel(const double *__restrict_
     __shared__ double Pt[NB * PT_S];
     const int wave = threadIdx.x >> 6, ta = wave >> 1, tb = wave & 1;
     d4v acc = {0.0, 0.0, 0.0, 0.0};
+    B32_PROF_BEGIN
     for (int ch = 0; ch < cpb; ++ch) {
         const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
         const bool ok = i < t;
@@ -220,10 +284,13 @@ __global__ __launch_bounds__(256) void b32_gram_kernel(const double *__restrict_
 #pragma unroll
         for (int a = 0; a < NB; ++a) { const double x = src[(int64_t)a * ld]; Pt[a * PT_S + threadIdx.x] = ok ? x : 0.0; }
         __syncthreads();
+        B32_MARK(0, 0);
         gram_chunk(Pt, Pt, acc, ta, tb);
         __syncthreads();
+        B32_MARK(0, 1);
     }
     store_tile32(Gpart + (size_t)blockIdx.x * NB * NB, acc, ta, tb);
+    B32_MARK(0, 2);
 }
 
 // K1: R1 = chol(P'P), Q1 = P R1^-1 (in place), partial Gram matrices of Q1
@@ -236,6 +303,7 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
     __shared__ __attribute__((aligned(16))) double Lp[TRS_SIZE];
     __shared__ double sd[NB], rinv[NB];
     double x[NB];      // the first chunk's row travels while the Gram matrix is summed and factorised
+    B32_PROF_BEGIN
     {
         Parts4 P;
         parts_issue(P, Gin, nparts);
@@ -245,7 +313,9 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
         for (int a = 0; a < NB; ++a) x[a] = row[(int64_t)a * ld];
         parts_sum(P, G);
     }
+    B32_MARK(1, 0);
     const bool ok_chol = chol32_lds(G, sd);
+    B32_MARK(1, 1);
     if (threadIdx.x < NB) rinv[threadIdx.x] = 1.0 / sd[threadIdx.x];
     if (!ok_chol && threadIdx.x == 0) atomicOr(flags, 1);
     __syncthreads();
@@ -259,6 +329,7 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
     }
     const int wave = threadIdx.x >> 6, ta = wave >> 1, tb = wave & 1;
     d4v acc = {0.0, 0.0, 0.0, 0.0};
+    B32_MARK(1, 2);
     for (int ch = 0; ch < cpb; ++ch) {
         const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
         const bool ok = i < t;
@@ -272,6 +343,7 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
             for (int a = 0; a < NB; ++a) x[a] = 0.0;
         }
         row_trsm_reg(x, Lp);
+        B32_MARK(1, 3);
 #pragma unroll
         for (int a = 0; a < NB; ++a) { if (ok) row[(int64_t)a * ld] = x[a]; Pt[a * PT_S + threadIdx.x] = x[a]; }
         if (i < NB) {      // the top block once more, aside: K2 overwrites it in place while other blocks still need it
@@ -279,10 +351,13 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
             for (int a = 0; a < NB; ++a) Qtop[i * NB + a] = x[a];
         }
         __syncthreads();
+        B32_MARK(1, 4);
         gram_chunk(Pt, Pt, acc, ta, tb);
         __syncthreads();
+        B32_MARK(1, 5);
     }
     store_tile32(Gout + (size_t)blockIdx.x * NB * NB, acc, ta, tb);
+    B32_MARK(1, 6);
 }
 
 // K2: the second Cholesky-QR pass and the Householder reconstruction WITHOUT a serial step (round 4, second form; the first
@@ -306,10 +381,11 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
                                                           int *__restrict__ flags) {
     __shared__ double Pt[NB * PT_S];
     __shared__ double Em[NB][NB + 1];           // E, then I - U + U^2 (the MFMA's B operand)
-    __shared__ double U1[NB][NB + 1], Um[NB][NB + 1], Xs[NB][NB + 1], Qt[NB][NB + 1];
+    __shared__ double U1[NB][NB + 1], Um[NB][NB + 1], Qt[NB][NB + 1];
     __shared__ double Dv[NB], red[8][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     double xrow[NB];                            // the first chunk's row of Q1
+    B32_PROF_BEGIN
     {
         Parts4 P;
         parts_issue(P, Gin, nparts);
@@ -325,6 +401,7 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
         for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Qt[e >> 5][e & 31] = qt4[q]; }
     }
     __syncthreads();
+    B32_MARK(2, 0);
     bool bad = false;
     for (int e = threadIdx.x; e < NB * NB; e += 256) {      // E and U1 = Phi(E)
         const int a = e >> 5, b = e & 31;
@@ -334,25 +411,21 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
     }
     bad = __syncthreads_or(bad);
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // X = U1'U1
-        const int a = e >> 5, b = e & 31;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < NB; k += 2) { s0 = fma(U1[k][a], U1[k][b], s0); s1 = fma(U1[k + 1][a], U1[k + 1][b], s1); }
-        Xs[a][b] = s0 + s1;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // U = U1 - Phi(X)
-        const int a = e >> 5, b = e & 31;
-        Um[a][b] = U1[a][b] - (a < b ? Xs[a][b] : (a == b ? 0.5 * Xs[a][b] : 0.0));
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // I - U + U^2
-        const int a = e >> 5, b = e & 31;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < NB; k += 2) { s0 = fma(Um[a][k], Um[k][b], s0); s1 = fma(Um[a][k + 1], Um[k + 1][b], s1); }
-        Em[a][b] = ((a == b ? 1.0 : 0.0) - Um[a][b]) + (s0 + s1);
+    {   // U = U1 - Phi(U1'U1), then I - U + U^2: two 32 x 32 products on MFMA (a tile per wave)
+        const int ta = wave >> 1, tb = wave & 1;
+        const d4v x = mm32_tile<true>(U1, U1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = ta * 16 + l4 + 4 * r, b = tb * 16 + l15;
+            Um[a][b] = U1[a][b] - (a < b ? x[r] : (a == b ? 0.5 * x[r] : 0.0));
+        }
+        __syncthreads();
+        const d4v y = mm32_tile<false>(Um, Um);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = ta * 16 + l4 + 4 * r, b = tb * 16 + l15;
+            Em[a][b] = ((a == b ? 1.0 : 0.0) - Um[a][b]) + y[r];
+        }
     }
     __syncthreads();
     if (threadIdx.x < NB) {      // the signs: D_k = -sign((Q1_top (I - U + U^2))_kk)
@@ -368,6 +441,7 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
         if (threadIdx.x < NB) aux[AUX_D + threadIdx.x] = Dv[threadIdx.x];
     }
     double sgacc = 0.0;
+    B32_MARK(2, 1);
     for (int ch = 0; ch < cpb; ++ch) {
         const int chunk = blockIdx.x * cpb + ch;
         const int i = chunk * CHR + threadIdx.x;
@@ -408,6 +482,7 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
                 }
         }
         __syncthreads();
+        B32_MARK(2, 3);
         double x[NB];      // the row of V = [I; 0] - Q D
 #pragma unroll
         for (int a = 0; a < NB; ++a) x[a] = (a == i ? 1.0 : 0.0) - Dv[a] * Pt[a * PT_S + threadIdx.x];
@@ -434,8 +509,10 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
 #pragma unroll
             for (int a = 0; a < NB; a += 2) dst[a >> 1] = ok ? make_double2(x[a], x[a + 1]) : make_double2(0.0, 0.0);
         }
+        B32_MARK(2, 4);
         const double tot = block_colsum32(prod, Pt, red);
         sgacc += tot;
+        B32_MARK(2, 5);
     }
     // rows t .. t + 63 of Vr that no chunk of this grid reaches
     {
@@ -446,6 +523,7 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
         }
     }
     if (threadIdx.x < NB) sgpart[(size_t)blockIdx.x * NB + threadIdx.x] = sgacc;
+    B32_MARK(2, 6);
 }
 
 // T = V1^-T (Gauss-Jordan between two LDS copies: one barrier per column) and the band entries R~ = D (I + U) R1 of a
@@ -617,6 +695,7 @@ __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, i
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     const int I0 = blockIdx.x * 64;
+    B32_PROF_BEGIN
     const int jbeg = blockIdx.y * ws + wave * (ws >> 2);
     const int jend = min(jbeg + (ws >> 2), (t + 3) & ~3);
     const double *Ab = A + (int64_t)r0 * ld + r0;
@@ -658,6 +737,7 @@ __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, i
         }
     }
     // tile rt = 2 h + parity holds rows I0 + 32 h + 2 m + parity, m = l4 + 4 r; column n = 16 nt + l15
+    B32_MARK(3, 0);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -670,6 +750,7 @@ __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, i
         const double s = (red[0][n][row] + red[1][n][row]) + (red[2][n][row] + red[3][n][row]);
         if (I0 + row < t) Ypart[((int64_t)blockIdx.y * NB + n) * vs + I0 + row] = s;
     }
+    B32_MARK(3, 1);
 }
 static_assert(sizeof(double) * 4 * NB * 66 >= sizeof(double) * TFIN_LDS, "b32_tfin borrows the symmetric product's LDS");
 
@@ -686,6 +767,7 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
     double *zs = smem + 2 * NB * PT_S + NB * (NB + 1), *sg = zs + NB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, ta = wave >> 1, tb = wave & 1;
     d4v macc = {0.0, 0.0, 0.0, 0.0};
+    B32_PROF_BEGIN
     for (int ch = 0; ch < cpb; ++ch) {
         const int i = (blockIdx.x * cpb + ch) * CHR + threadIdx.x;
         const bool ok = i < t;
@@ -737,12 +819,14 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
             }
         }
         __syncthreads();
+        B32_MARK(4, 0);
         if (ok) {
 #pragma unroll
             for (int a = 0; a < NB; ++a) gi = fma(-v[a], zs[a], gi);
             g[i] = gi;
         }
         gram_chunk(Vt, Yt, macc, ta, tb);
+        B32_MARK(4, 1);
         // W^ = Y T: wave w takes rows 64 w .. 64 w + 63 (4 row tiles) x 2 column tiles
         d4v wacc[4][2];
 #pragma unroll
@@ -771,8 +855,10 @@ __global__ __launch_bounds__(256) void b32_w_kernel(int t, int cpb, int nsplit, 
                 }
             }
         __syncthreads();
+        B32_MARK(4, 2);
     }
     store_tile32(Mpart + (size_t)blockIdx.x * NB * NB, macc, ta, tb);
+    B32_MARK(4, 3);
 }
 constexpr size_t B32_W_LDS = sizeof(double) * (2 * NB * PT_S + NB * (NB + 1) + 2 * NB);
 
@@ -783,6 +869,7 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
     __shared__ double Vt[NB * PT_S];
     __shared__ double M[NB][NB + 1], X[NB][NB + 1], S[NB][NB + 1], Ts[NB][NB + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    B32_PROF_BEGIN
     {
         Parts4 P;
         parts_issue(P, Mpart, nM);
@@ -794,26 +881,22 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
         for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Ts[e >> 5][e & 31] = tq[q]; }
     }
     __syncthreads();
+    B32_MARK(5, 0);
     for (int e = threadIdx.x; e < NB * NB; e += 256) { const int a = e >> 5, c = e & 31; S[a][c] = 0.5 * (M[a][c] + M[c][a]); }
     __syncthreads();
-    // full-length, unrolled products (T carries explicit zeros below its diagonal): the reads of a trip are in flight together
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // X = sym(M) T
-        const int a = e >> 5, c = e & 31;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int b = 0; b < NB; b += 2) { s0 = fma(S[a][b], Ts[b][c], s0); s1 = fma(S[a][b + 1], Ts[b + 1][c], s1); }
-        X[a][c] = s0 + s1;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {      // T' X
-        const int a = e >> 5, c = e & 31;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int d = 0; d < NB; d += 2) { s0 = fma(Ts[d][a], X[d][c], s0); s1 = fma(Ts[d + 1][a], X[d + 1][c], s1); }
-        M[a][c] = s0 + s1;
+    {   // X = sym(M) T, then T'X: two 32 x 32 products on MFMA (a tile per wave)
+        const int ta = wave >> 1, tb = wave & 1;
+        const d4v x = mm32_tile<false>(S, Ts);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[ta * 16 + l4 + 4 * r][tb * 16 + l15] = x[r];
+        __syncthreads();
+        const d4v y = mm32_tile<true>(Ts, X);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[ta * 16 + l4 + 4 * r][tb * 16 + l15] = y[r];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < NB * NB; e += 256) { const int a = e >> 5, c = e & 31; S[a][c] = -0.25 * (M[a][c] + M[c][a]); }      // -1/2 sym
+    B32_MARK(5, 1);
     for (int ch = 0; ch < cpb; ++ch) {
         const int cbase = (blockIdx.x * cpb + ch) * CHR;
         const int i = cbase + threadIdx.x;
@@ -841,6 +924,7 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
                 wacc[rt][1][r] = row < t ? w1 : 0.0;
             }
         __syncthreads();
+        B32_MARK(5, 2);
 #pragma unroll
         for (int k0 = 0; k0 < NB; k0 += 4) {
             const double b0 = S[k0 + l4][l15], b1 = S[k0 + l4][16 + l15];
@@ -861,6 +945,7 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
                     Zw[(int64_t)(16 + l15) * vs + row] = wacc[rt][1][r];
                 }
             }
+        B32_MARK(5, 3);
     }
 }
 
@@ -870,16 +955,16 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
 // operand.  col0_only: the first block column only (look-ahead: the next panel lives in its first 32 columns).
 constexpr int RK_T = 128, RK_KC = 16, RK_S = RK_T + 16, RK_K = 2 * NB;
 __global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
-                                                           const double *__restrict__ Z, int64_t vs, int nt, int col0_only) {
+                                                           const double *__restrict__ Z, int64_t vs, int nt) {
     __shared__ __attribute__((aligned(16))) double sI[2][RK_KC * RK_S];
     __shared__ __attribute__((aligned(16))) double sJ[2][RK_KC * RK_S];
-    int bi, bj;
-    if (col0_only) { bi = blockIdx.x; bj = 0; }
-    else { bi = blockIdx.x % nt; bj = 1 + blockIdx.x / nt; }
+    const int bi = blockIdx.x % nt, bj = blockIdx.x / nt;
+    const int lmin = NB;      // columns 0 .. 31 belong to b32_strip_kernel (and, by now, to the next panel's kernels)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
     double *C = A + (int64_t)r0 * ld + r0;
     d4v acc[4][4];
+    B32_PROF_BEGIN
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -910,6 +995,7 @@ __global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ 
     RK_SSTORE(0)
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prologue load (the C tile) pending into the loop
     __syncthreads();
+    B32_MARK(6, 4);
     for (int c = 0; c < RK_K / RK_KC; ++c) {
         const int buf = c & 1;
         if (c + 1 < RK_K / RK_KC) { RK_GLOAD((c + 1) * RK_KC) }
@@ -933,6 +1019,7 @@ __global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ 
     }
 #undef RK_GLOAD
 #undef RK_SSTORE
+    B32_MARK(6, 5);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -941,9 +1028,59 @@ __global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ 
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int i = bi * RK_T + wi + b * 16 + l15;
-                if (i < t && l < t) C[(int64_t)l * ld + i] = acc[a][b][r];
+                if (i < t && l < t && l >= lmin) C[(int64_t)l * ld + i] = acc[a][b][r];
             }
         }
+    B32_MARK(6, 6);
+}
+
+// K5a: the same update for columns 0 .. 31 of A22 alone -- the next panel and the next diagonal block of the band, ALL the
+// next panel's kernels wait for.  (The first version ran K5 on the whole first block column, 128 columns: one CU needs
+// 6.8 us of FP64 MFMA time for a 128 x 128 x 64 tile, and 40 CUs were busy.)  Block = 64 rows, wave = 16 rows x 32 columns;
+// no LDS: a lane loads its 16 + 2 x 16 MFMA operands straight from Z (16 contiguous doubles per quarter-wave), all before
+// the first MFMA.
+__global__ __launch_bounds__(256) void b32_strip_kernel(double *__restrict__ A, int64_t ld, int r0, int t, const double *__restrict__ Z,
+                                                        int64_t vs) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int i = blockIdx.x * 64 + wave * 16 + l15;      // row of A22 this lane's B operands and results belong to
+    double *C = A + (int64_t)r0 * ld + r0;
+    B32_PROF_BEGIN
+    if (blockIdx.x * 64 + wave * 16 >= t) return;
+    const int ii = i < t ? i : 0;
+    d4v acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = a * 16 + l4 + 4 * r;
+            const double x = C[(int64_t)(l < t ? l : 0) * ld + ii];
+            acc[a][r] = (i < t && l < t) ? x : 0.0;
+        }
+    double fi[RK_K / 4], fj[2][RK_K / 4];
+#pragma unroll
+    for (int q = 0; q < RK_K / 4; ++q) {
+        const int kp = 4 * q + l4;
+        fi[q] = Z[(int64_t)kp * vs + ii];
+        const double *cq = Z + (int64_t)((kp + NB) & (RK_K - 1)) * vs;
+        fj[0][q] = cq[l15 < t ? l15 : 0];
+        fj[1][q] = cq[16 + l15 < t ? 16 + l15 : 0];
+    }
+    B32_MARK(6, 0);
+#pragma unroll
+    for (int q = 0; q < RK_K / 4; ++q) {
+        const double b = i < t ? fi[q] : 0.0;
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 < t ? -fj[0][q] : 0.0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(16 + l15 < t ? -fj[1][q] : 0.0, b, acc[1], 0, 0, 0);
+    }
+    B32_MARK(6, 1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = a * 16 + l4 + 4 * r;
+            if (i < t && l < t) C[(int64_t)l * ld + i] = acc[a][r];
+        }
+    B32_MARK(6, 2);
 }
 
 // lower band of B -> ab[j * 33 + d] = B[j + d][j]
@@ -1275,6 +1412,305 @@ __global__ __launch_bounds__(256) void b32_mid_kernel(const double *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------ the sweep, one WAVE per chain --
+// The kernel above spends ~1 000 cycles per column: four waves share a chain, so every column ends in an s_barrier behind
+// the slowest wave's LDS round trips.  Here a chain is ONE wave (LDS operations of a wave complete in order: no barrier at
+// all, a column costs what its ~35 LDS and ~70 FP64 instructions cost) and the window is stored by COLUMNS, unrotated:
+//       Wc[c * 36 + d]  = entry (row c + d, column c), d = 0 .. 32;    [33] = 0 (the band ends);    [34] = y_c
+// so the pivot column is contiguous, every address a lane uses moves by one column (36 entries) per step -- a
+// trip of eight steps is straight-line code whose LDS instructions differ in their immediate offsets only -- and a chunk
+// of the band arrives as a linear copy (b32_pack34_kernel lays the band out as 34-entry columns, once per direction).
+// The step subtracts p_i l_k from entry (jj + i, jj + k), 0 <= k <= i <= 32, i >= 1 (k = 0: the right-hand side, "l_0" =
+// y_jj / d): 560 entries in 53 units of 4 rows x 3 columns (rows 4 A + 1 .. 4 A + 4, columns 3 b .. 3 b + 2, clipped by
+// k <= i), one unit per lane: 4 + 3 pivot-column reads feed 12 entries.  With DERIV an entry is the pair (value, d/dlambda)
+// and moves as one 16-byte LDS access.  96 columns are resident; after 64 steps the 32 live ones move to the front and the
+// next 64 (in registers since the chunk began) are parked behind them.
+constexpr int S1_ST = 36, S1_NC = 96, S1_CH = 64, S1_U = 8, S1_PF = (S1_CH * (NB + 2)) / 64;
+constexpr int S1_ZO = NB + 1, S1_YO = NB + 2;      // per column: [33] stays zero, [34] = y
+constexpr int S1_IDLE = 64 + S1_U * S1_ST;         // a word per lane for the slots outside the triangle, reached with the steps' immediate offsets
+template <bool DERIV> struct S1Elem { typedef double T; };
+template <> struct S1Elem<true> { typedef d2v T; };
+template <class E> __device__ __forceinline__ E s1_get(unsigned a) { return *(const __attribute__((address_space(3))) E *)(uintptr_t)a; }
+template <class E> __device__ __forceinline__ void s1_put(unsigned a, E v) { *(__attribute__((address_space(3))) E *)(uintptr_t)a = v; }
+__device__ __forceinline__ double s1_val(double e) { return e; }
+__device__ __forceinline__ double s1_val(d2v e) { return e.x; }
+__device__ __forceinline__ double s1_der(double) { return 0.0; }
+__device__ __forceinline__ double s1_der(d2v e) { return e.y; }
+__device__ __forceinline__ void s1_make(double &e, double v, double) { e = v; }
+__device__ __forceinline__ void s1_make(d2v &e, double v, double dv) { e.x = v; e.y = dv; }
+
+// layout the sweeps read: column c of direction 0 is B[c .. c + 32][c], of direction 1 (the matrix mirrored) B[m-1-c][m-1-c-d]
+__global__ void b32_pack34_kernel(const double *__restrict__ ab, const double *__restrict__ g, int m, double *__restrict__ abF,
+                                  double *__restrict__ abR) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * (NB + 2)) return;
+    const int c = e / (NB + 2), d = e - c * (NB + 2);
+    if (d <= NB) {
+        abF[e] = ab[(int64_t)c * (NB + 1) + d];
+        const int cc = m - 1 - c - d;
+        abR[e] = cc >= 0 ? ab[(int64_t)cc * (NB + 1) + d] : 0.0;
+    } else {
+        abF[e] = g[c];
+        abR[e] = g[m - 1 - c];
+    }
+}
+
+template <bool DERIV, bool STORE>
+__global__ __launch_bounds__(64) void b32_sweep1_kernel(const double *__restrict__ abF, const double *__restrict__ abR, int m, int n0,
+                                                        int n1, const double *__restrict__ lams, double *__restrict__ win,
+                                                        double *__restrict__ res, double *__restrict__ Lbuf,
+                                                        double *__restrict__ ybuf) {
+    typedef typename S1Elem<DERIV>::T E;
+    constexpr unsigned ES = sizeof(E), CS = S1_ST * ES;      // bytes per entry, per column
+    __shared__ __attribute__((aligned(16))) E Wc[S1_NC * S1_ST + S1_IDLE];
+    const int dir = blockIdx.y, ncols = dir == 0 ? n0 : n1, lane = threadIdx.x;
+    const double *__restrict__ src = dir == 0 ? abF : abR;
+    const double lam = lams[blockIdx.x];
+    const int last_row = STORE ? m - 1 : min(m - 1, ncols + NB - 1);      // rows the sweep needs
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) E *)Wc;
+    // this lane's unit: rows i0 .. i0 + 3, columns k0 .. k0 + 2 (column 0 = the right-hand side)
+    int ua = 7;
+#pragma unroll
+    for (int a = 7; a >= 1; --a) {
+        const int pre = a == 1 ? 2 : a == 2 ? 5 : a == 3 ? 10 : a == 4 ? 16 : a == 5 ? 23 : a == 6 ? 32 : 42;
+        if (lane < pre) ua = a - 1;
+    }
+    const int upre = ua == 0 ? 0 : ua == 1 ? 2 : ua == 2 ? 5 : ua == 3 ? 10 : ua == 4 ? 16 : ua == 5 ? 23 : ua == 6 ? 32 : 42;
+    const bool idle = lane >= 53;
+    const int ub = idle ? 0 : lane - upre, i0 = 4 * ua + 1, k0 = 3 * ub;
+    // byte addresses for the column at the head of the window; a_pk: entry k of the pivot column (k = 0: y), a_pk2: entry
+    // k + 1 (k = 0: y) -- what "column k" of a TWO-column step reads from the first of its columns
+    // Slots outside the triangle (and the eleven idle lanes) read and write a word of their OWN behind the window, which
+    // does not move: forty lanes storing to one dummy address serialise (42 cycles per ds_write_b64 instead of 6).
+    unsigned a_piv = base, a_pi = base + (unsigned)i0 * ES, a_pk[3], a_pk2[3], a_w[4][3];
+    bool on[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int k = k0 + c;
+        a_pk[c] = base + (unsigned)(k == 0 ? S1_YO : k) * ES;
+        a_pk2[c] = base + (unsigned)(k == 0 ? S1_YO : k + 1) * ES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r;
+            on[r][c] = !idle && k <= i;
+            a_w[r][c] = base + (unsigned)(!on[r][c] ? S1_NC * S1_ST + lane : k == 0 ? i * S1_ST + S1_YO : k * S1_ST + (i - k)) * ES;
+        }
+    }
+    auto advance = [&](unsigned bytes) {
+        a_piv += bytes; a_pi += bytes;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a_pk[c] += bytes; a_pk2[c] += bytes;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a_w[r][c] += on[r][c] ? bytes : 0u;
+        }
+    };
+    // value of element e of the linear stream of columns c_lo, c_lo + 1, .. (34 entries each: 33 of the band, then g)
+    auto fetch = [&](int c_lo, int e) -> double {
+        const int c = c_lo + e / (NB + 2), d = e % (NB + 2);
+        const bool ok = d <= NB ? c + d <= last_row : c <= last_row;
+        return ok ? src[(int64_t)c_lo * (NB + 2) + e] : 0.0;
+    };
+    auto park = [&](int slot_col, int c_lo, int e, double v) {      // into LDS column slot_col + e / 34
+        const int cl = e / (NB + 2), d = e % (NB + 2);
+        const bool diag = d == 0 && c_lo + cl <= last_row;
+        E x;
+        s1_make(x, v + (diag ? lam : 0.0), diag ? 1.0 : 0.0);
+        Wc[(slot_col + cl) * S1_ST + (d <= NB ? d : S1_YO)] = x;
+    };
+    {
+        E z;
+        s1_make(z, 0.0, 0.0);
+        for (int e = lane; e < S1_NC * S1_ST + S1_IDLE; e += 64) Wc[e] = z;
+        for (int e = lane; e < S1_NC * (NB + 2); e += 64) park(0, 0, e, fetch(0, e));
+    }
+    double neg = 0.0, tr = 0.0, q2 = 0.0;
+    int jj = 0;
+    const uint64_t t_cyc = __builtin_readcyclecounter(), t_wall = wall_clock64();
+    auto book = [&](double d, double dd, double inv, double y, double dy) {
+        if (d < 0.0) neg += 1.0;
+        if (DERIV) {
+            tr += dd * inv;
+            q2 -= (2.0 * y * dy * d - y * y * dd) * (inv * inv);
+        }
+    };
+    // one column
+    auto step = [&](auto tag) {
+        constexpr unsigned off = (unsigned)decltype(tag)::value * CS;
+        const E pv = s1_get<E>(a_piv + off), yv = s1_get<E>(a_piv + off + S1_YO * ES);
+        E pi[4], pk[3], w[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pi[r] = s1_get<E>(a_pi + off + r * ES);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pk[c] = s1_get<E>(a_pk[c] + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[r][c] = s1_get<E>(a_w[r][c] + off);
+        double d = s1_val(pv);
+        const double dd = s1_der(pv);
+        if (d == 0.0) d = -1e-300;
+        const double inv = frcp(d);
+        double lk[3], dlk[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lk[c] = s1_val(pk[c]) * inv;
+            dlk[c] = DERIV ? fma(-lk[c], dd, s1_der(pk[c])) * inv : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                E x;
+                s1_make(x, fma(-s1_val(pi[r]), lk[c], s1_val(w[r][c])),
+                        DERIV ? fma(-s1_der(pi[r]), lk[c], fma(-s1_val(pi[r]), dlk[c], s1_der(w[r][c]))) : 0.0);
+                s1_put<E>(a_w[r][c] + off, x);
+            }
+        book(d, dd, inv, s1_val(yv), s1_der(yv));
+        if (STORE) {
+            const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj) + (int64_t)decltype(tag)::value;      // dir 1's columns follow dir 0's in the buffers
+            double *Lcol = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1);
+            if (!idle && ub == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Lcol[i0 + r] = s1_val(pi[r]) * inv;
+            }
+            if (lane == 0) { Lcol[0] = d; ybuf[col + (int64_t)blockIdx.x * (n0 + n1)] = s1_val(yv); }
+        }
+    };
+    // two columns (s, s + 1) in one pass over the window: with p = column s and q = column s + 1 as they stand,
+    //       l_1 = p_1 / d,   d' = q_1 - p_1 l_1,   p'_i = q_i - p_i l_1   (column s + 1 after the first elimination),
+    //       entry (s + i, s + k) -= p_i (p_k / d) + p'_i (p'_k / d'),   2 <= k <= i <= 33   (p_33 = 0: the band ends)
+    // -- every lane redoes the 2 x 2 pivot block and the 4 + 3 entries of p' it needs; the window entries make ONE round trip
+    // through the LDS for two columns.  Unit (rows, columns) (i', k') of the one-column step stand for (i' + 1, k' + 1) here.
+    auto step2 = [&](auto tag) {
+        constexpr unsigned off = (unsigned)decltype(tag)::value * CS;
+        const E pv = s1_get<E>(a_piv + off), p1 = s1_get<E>(a_piv + off + ES), qv = s1_get<E>(a_piv + off + CS);
+        const E y0 = s1_get<E>(a_piv + off + S1_YO * ES), y1 = s1_get<E>(a_piv + off + CS + S1_YO * ES);
+        E pi[4], qi[4], pk[3], qk[3], w[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pi[r] = s1_get<E>(a_pi + off + (r + 1) * ES); qi[r] = s1_get<E>(a_pi + off + CS + r * ES); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pk[c] = s1_get<E>(a_pk2[c] + off); qk[c] = s1_get<E>(a_pk[c] + off + CS); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[r][c] = s1_get<E>(a_w[r][c] + off + CS);
+        double d = s1_val(pv);
+        const double dd = s1_der(pv);
+        if (d == 0.0) d = -1e-300;
+        const double inv = frcp(d);
+        const double l1 = s1_val(p1) * inv, dl1 = DERIV ? fma(-l1, dd, s1_der(p1)) * inv : 0.0;
+        double d2 = fma(-s1_val(p1), l1, s1_val(qv));
+        const double dd2 = DERIV ? fma(-s1_der(p1), l1, fma(-s1_val(p1), dl1, s1_der(qv))) : 0.0;
+        if (d2 == 0.0) d2 = -1e-300;
+        const double inv2 = frcp(d2);
+        double pp[4], dpp[4], lk[3], dlk[3], lk2[3], dlk2[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pp[r] = fma(-s1_val(pi[r]), l1, s1_val(qi[r]));
+            dpp[r] = DERIV ? fma(-s1_der(pi[r]), l1, fma(-s1_val(pi[r]), dl1, s1_der(qi[r]))) : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lk[c] = s1_val(pk[c]) * inv;
+            dlk[c] = DERIV ? fma(-lk[c], dd, s1_der(pk[c])) * inv : 0.0;
+            const double pkp = fma(-s1_val(pk[c]), l1, s1_val(qk[c]));
+            const double dpkp = DERIV ? fma(-s1_der(pk[c]), l1, fma(-s1_val(pk[c]), dl1, s1_der(qk[c]))) : 0.0;
+            lk2[c] = pkp * inv2;
+            dlk2[c] = DERIV ? fma(-lk2[c], dd2, dpkp) * inv2 : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                E x;
+                s1_make(x, fma(-pp[r], lk2[c], fma(-s1_val(pi[r]), lk[c], s1_val(w[r][c]))),
+                        DERIV ? fma(-dpp[r], lk2[c], fma(-pp[r], dlk2[c], fma(-s1_der(pi[r]), lk[c], fma(-s1_val(pi[r]), dlk[c], s1_der(w[r][c])))))
+                              : 0.0);
+                s1_put<E>(a_w[r][c] + off + CS, x);
+            }
+        // the right-hand side of row s + 1 as the first elimination leaves it (the formulas of the entries above, k = 0)
+        const double ly = s1_val(y0) * inv, dly = DERIV ? fma(-ly, dd, s1_der(y0)) * inv : 0.0;
+        const double y1p = fma(-s1_val(p1), ly, s1_val(y1));
+        const double dy1p = DERIV ? fma(-s1_der(p1), ly, fma(-s1_val(p1), dly, s1_der(y1))) : 0.0;
+        book(d, dd, inv, s1_val(y0), s1_der(y0));
+        book(d2, dd2, inv2, y1p, dy1p);
+        if (STORE) {
+            const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj) + (int64_t)decltype(tag)::value;
+            double *La = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1), *Lb = La + (NB + 1);
+            if (!idle && ub == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (i0 + r + 1 <= NB) La[i0 + r + 1] = s1_val(pi[r]) * inv;
+                    Lb[i0 + r] = pp[r] * inv2;
+                }
+            }
+            if (lane == 0) {
+                double *yc = ybuf + col + (int64_t)blockIdx.x * (n0 + n1);
+                La[0] = d; La[1] = l1; Lb[0] = d2; yc[0] = s1_val(y0); yc[1] = y1p;
+            }
+        }
+    };
+    for (int j0 = 0; j0 < ncols; j0 += S1_CH) {
+        const bool more = j0 + S1_CH < ncols;
+        double pf[S1_PF];
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < S1_PF; ++q) pf[q] = fetch(j0 + S1_NC, lane + 64 * q);
+        }
+        const int nst = min(S1_CH, ncols - j0);
+        int s = 0;
+#pragma unroll 1
+        for (; s + S1_U <= nst; s += S1_U) {
+            step2(std::integral_constant<int, 0>{}); step2(std::integral_constant<int, 2>{});
+            step2(std::integral_constant<int, 4>{}); step2(std::integral_constant<int, 6>{});
+            advance(S1_U * CS);
+            jj += S1_U;
+        }
+#pragma unroll 1
+        for (; s + 2 <= nst; s += 2) {
+            step2(std::integral_constant<int, 0>{});
+            advance(2 * CS);
+            jj += 2;
+        }
+        if (s < nst) {
+            step(std::integral_constant<int, 0>{});
+            advance(CS);
+            ++jj;
+        }
+        if (more) {
+            for (int e = lane; e < NB * S1_ST; e += 64) Wc[e] = Wc[S1_CH * S1_ST + e];
+#pragma unroll
+            for (int q = 0; q < S1_PF; ++q) park(NB, j0 + S1_NC, lane + 64 * q, pf[q]);
+            advance(0u - (unsigned)S1_CH * CS);
+        }
+    }
+    // the block behind the eliminated columns: logical rows / columns ncols .. ncols + 31
+    const int o = ncols == 0 ? 0 : ncols - ((ncols - 1) / S1_CH) * S1_CH;
+    double *wout = win + ((int64_t)blockIdx.x * 2 + dir) * SWIN;
+    for (int e = lane; e < NB * NB; e += 64) {
+        const int a = e >> 5, b = e & 31;
+        if (b <= a) {
+            const E x = Wc[(o + b) * S1_ST + (a - b)];
+            wout[e] = s1_val(x);
+            wout[NB * NB + e] = s1_der(x);
+        }
+    }
+    if (lane < NB) {
+        const E x = Wc[(o + lane) * S1_ST + S1_YO];
+        wout[2 * NB * NB + lane] = s1_val(x);
+        wout[2 * NB * NB + NB + lane] = s1_der(x);
+    }
+    if (lane == 0) {
+        double *r3 = res + ((int64_t)blockIdx.x * 2 + dir) * 4;
+        r3[0] = neg; r3[1] = tr; r3[2] = q2;
+        // diagnostic (MHS_FIT_TIMING prints it): shader-clock cycles of direction 0, 100 MHz ticks of direction 1
+        r3[3] = dir == 0 ? (double)(__builtin_readcyclecounter() - t_cyc) : (double)(wall_clock64() - t_wall);
+    }
+}
+static_assert(S1_ZO == NB + 1 && S1_YO < S1_ST, "a two-column step reads entry 33 of its first column as zero");
+static_assert(S1_PF * 64 == S1_CH * (NB + 2), "a chunk of new columns is a whole number of loads per lane");
+
 // ================================================================================================ host side ==
 int band32_npanels(int m) {
     int np = 0;
@@ -1304,6 +1740,8 @@ static size_t band32_layout(Band32Ws *w, char *base, int m, int64_t n) {
     d.sgp = take((size_t)MAXPART_H * NB);
     d.Tall = take(np * PREC);
     d.ab = take((size_t)m * (NB + 1) + 64);
+    d.abF = take((size_t)m * (NB + 2) + 64);
+    d.abR = take((size_t)m * (NB + 2) + 64);
     d.win = take((size_t)B32_MAXLAM * 2 * SWIN);
     d.res = take((size_t)B32_MAXLAM * 8);
     d.lamd = take((size_t)B32_MAXLAM);
@@ -1373,16 +1811,17 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
         hipLaunchKernelGGL(b32_symm_kernel, dim3(nrb + 1, nsplit), dim3(256), 0, s, A, ld, r0, t, Vr, ws.Yp, vs, wsplit, t >= 64 ? 1 : 0, ws.aux, ws.R1, Tp, ws.flags);
         hipLaunchKernelGGL(b32_w_kernel, dim3(nblk), dim3(256), B32_W_LDS, s, t, cpb, nsplit, ws.Yp, vs, Vr, Tp, ws.sgp, nsg, gp, ws.Wh, ws.Mp);
         hipLaunchKernelGGL(b32_wfin_kernel, dim3(nblk), dim3(256), 0, s, t, cpb, ws.Mp, nblk, Tp, Vr, ws.Wh, Zc + (int64_t)NB * vs, vs);
+        // the rest of A22 on the second stream (it needs W, nothing of the strip), the strip in front of the next panel
         const int nt = (t + RK_T - 1) / RK_T;
-        hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt), dim3(256), 0, s, A, ld, r0, t, Zc, vs, nt, 1);
-        if (nt > 1) {
-            hipEvent_t ev_block = pool[2 * p], ev_rest = pool[2 * p + 1];
-            MHS_HIP(hipEventRecord(ev_block, s));
-            MHS_HIP(hipStreamWaitEvent(s2, ev_block, 0));
-            hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt * (nt - 1)), dim3(256), 0, s2, A, ld, r0, t, Zc, vs, nt, 0);
+        if (t > NB) {
+            hipEvent_t ev_w = pool[2 * p], ev_rest = pool[2 * p + 1];
+            MHS_HIP(hipEventRecord(ev_w, s));
+            MHS_HIP(hipStreamWaitEvent(s2, ev_w, 0));
+            hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt * nt), dim3(256), 0, s2, A, ld, r0, t, Zc, vs, nt);
             MHS_HIP(hipEventRecord(ev_rest, s2));
             pending_rest = ev_rest;
         }
+        hipLaunchKernelGGL(b32_strip_kernel, dim3((t + 63) / 64), dim3(256), 0, s, A, ld, r0, t, Zc, vs);
     }
     if (pending_rest) MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0));
     hipLaunchKernelGGL(b32_extract_kernel, dim3((unsigned)((m * (NB + 1) + 255) / 256)), dim3(256), 0, s, A, ld, off0, m, ws.ab);
@@ -1391,6 +1830,20 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
     MHS_HIP(hipMemcpyAsync(&h_flags, ws.flags, sizeof(int), hipMemcpyDeviceToHost, s));
     MHS_HIP(hipStreamSynchronize(s));
     *breakdown = h_flags != 0;
+#ifdef B32_PROF
+    {
+        unsigned long long tab[8][16];
+        MHS_HIP(hipMemcpyFromSymbol(tab, HIP_SYMBOL(b32_prof_tab), sizeof(tab)));
+        static const char *names[7] = {"gram", "cholqr1", "cholqr2", "symm", "w", "wfin", "rankk"};
+        for (int k = 0; k < 7; ++k) {
+            fprintf(stderr, "[b32 prof m=%d] %-8s", m, names[k]);
+            for (int q = 0; q < 8; ++q) fprintf(stderr, " %8.2f", (double)tab[k][q] / 2400.0 / npanels);
+            fprintf(stderr, "   us per panel (block 0)\n");
+        }
+        memset(tab, 0, sizeof(tab));
+        MHS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(b32_prof_tab), tab, sizeof(tab)));
+    }
+#endif
     return MHS_OK;
 }
 
@@ -1427,9 +1880,25 @@ static inline void split_mid(int m, int *mid, int *mb, int *n0, int *n1) {
     *n1 = m - *mid - *mb;
 }
 
+// the band as 34-entry columns, one copy per direction (b32_sweep1_kernel reads them as linear streams)
+int Band32Search::pack() {
+    if (packed) return MHS_OK;
+    hipLaunchKernelGGL(b32_pack34_kernel, dim3((unsigned)((m * (NB + 2) + 255) / 256)), dim3(256), 0, s, ab_dev, g_dev, m, ws->abF, ws->abR);
+    MHS_HIP(hipGetLastError());
+    packed = true;
+    return MHS_OK;
+}
+
+static bool sweep_four_waves() {      // MHS_B32_SWEEP4=1: the first version of the sweep (four waves per chain), kept for comparison
+    static const bool v = [] { const char *e = getenv("MHS_B32_SWEEP4"); return e && e[0] == '1'; }();
+    return v;
+}
+
 int Band32Search::eval_batch(const double *lam, int count, bool deriv, double *neg, double *tr, double *q2) {
     int mid, mb, n0, n1;
     split_mid(m, &mid, &mb, &n0, &n1);
+    if (int rc = pack()) return rc;
+    const bool four = sweep_four_waves();
     for (int base = 0; base < count; base += B32_MAXLAM) {
         const int nl = std::min(B32_MAXLAM, count - base);
         double *hl = pin, *hr = pin + B32_MAXLAM;
@@ -1437,17 +1906,31 @@ int Band32Search::eval_batch(const double *lam, int count, bool deriv, double *n
         double *dl = ws->lamd;
         MHS_HIP(hipMemcpyAsync(dl, hl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
         if (deriv) {
-            hipLaunchKernelGGL((b32_sweep_kernel<true, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
-                               (double *)nullptr, (double *)nullptr);
+            if (four)
+                hipLaunchKernelGGL((b32_sweep_kernel<true, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
+                                   (double *)nullptr, (double *)nullptr);
+            else
+                hipLaunchKernelGGL((b32_sweep1_kernel<true, false>), dim3(nl, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res,
+                                   (double *)nullptr, (double *)nullptr);
             hipLaunchKernelGGL((b32_mid_kernel<true>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
         } else {
-            hipLaunchKernelGGL((b32_sweep_kernel<false, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
-                               (double *)nullptr, (double *)nullptr);
+            if (four)
+                hipLaunchKernelGGL((b32_sweep_kernel<false, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
+                                   (double *)nullptr, (double *)nullptr);
+            else
+                hipLaunchKernelGGL((b32_sweep1_kernel<false, false>), dim3(nl, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res,
+                                   (double *)nullptr, (double *)nullptr);
             hipLaunchKernelGGL((b32_mid_kernel<false>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
         }
         MHS_HIP(hipGetLastError());
         MHS_HIP(hipMemcpyAsync(hr, ws->out, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, s));
         MHS_HIP(hipStreamSynchronize(s));
+        if (!four && getenv("MHS_FIT_TIMING")) {
+            double r8[8];
+            MHS_HIP(hipMemcpy(r8, ws->res, sizeof(r8), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[gcv32 m=%d] sweep of %d + %d columns, %d lambdas%s: %.0f cycles, %.1f us (100 MHz counter)\n", m, n0, n1, nl,
+                    deriv ? " with derivative" : "", r8[3], r8[7] * 0.01);
+        }
         for (int i = 0; i < nl; ++i) {
             if (neg) neg[base + i] = hr[4 * i];
             if (tr) tr[base + i] = hr[4 * i + 1];
@@ -1472,8 +1955,9 @@ void Band32Search::gcv_from_terms(double lam, double tr_inv, double qq, double *
 // sequence of brackets, hence the last bits of lambda, must not depend on anything but the band).  emax starts from
 // [largest diagonal entry, Gershgorin bound], emin from (hi 2^-200, smallest diagonal entry]; a bracket whose ends are
 // positive and more than a factor 4 apart is cut geometrically, otherwise linearly.
-static const int EIG_P = 63;
-static const double EIG_TOL = 1e-10;      // lambda moves by about half the relative error of either end (they only place the grid)
+static const int EIG_P[2] = {63, 255};      // points per round for the largest / the smallest eigenvalue (the smallest starts 200 octaves wide)
+static const int EIG_PMAX = 255;
+static const double EIG_TOL = 2e-9;       // lambda moves by about half the relative error of either end (they only place the grid)
 int Band32Search::find_lambda(int mode, double *lam_out) {
     const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -1484,25 +1968,29 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         t_last = now;
     };
     const int W = NB + 1;
-    double dmax = ab_host[0], dmin = ab_host[0], ghi = ab_host[0];
+    // brackets: |T e_j| <= emax <= min(Gershgorin, |T|_F) (the Frobenius norm of a matrix whose spectrum decays is within
+    // tens of per cent of its largest eigenvalue: a round less than from the Gershgorin bound), 0 < emin <= min T_jj
+    double dmax = ab_host[0], dmin = ab_host[0], ghi = ab_host[0], fro2 = 0.0, cmax2 = 0.0;
     for (int j = 0; j < m; ++j) {
-        double r = 0.0;
+        double r = 0.0, c2 = 0.0;
         for (int d = 1; d <= NB; ++d) {
-            if (j + d < m) r += fabs(ab_host[(size_t)j * W + d]);
-            if (j - d >= 0) r += fabs(ab_host[(size_t)(j - d) * W + d]);
+            if (j + d < m) { const double v = ab_host[(size_t)j * W + d]; r += fabs(v); c2 += v * v; fro2 += 2.0 * v * v; }
+            if (j - d >= 0) { const double v = ab_host[(size_t)(j - d) * W + d]; r += fabs(v); c2 += v * v; }
         }
         const double a = ab_host[(size_t)j * W];
-        dmax = std::max(dmax, a); dmin = std::min(dmin, a); ghi = std::max(ghi, a + r);
+        fro2 += a * a; c2 += a * a;
+        dmax = std::max(dmax, a); dmin = std::min(dmin, a); ghi = std::max(ghi, a + r); cmax2 = std::max(cmax2, c2);
     }
     if (!(dmin > 0.0)) { set_error("mhs_tps_fit: the projected matrix has a non-positive diagonal entry"); return MHS_ERR_NUMERIC; }
-    double lo[2] = {dmax, dmin * ldexp(1.0, -200)}, hi[2] = {ghi * (1.0 + 1e-12) + 1e-300, dmin};
+    const double up = std::min(ghi, sqrt(fro2)) * (1.0 + 1e-9) + 1e-300, down = std::max(dmax, sqrt(cmax2) * (1.0 - 1e-9));
+    double lo[2] = {down, dmin * ldexp(1.0, -200)}, hi[2] = {up, dmin};
     const int64_t kth[2] = {m - 1, 0};
     bool done[2] = {false, false};
-    std::vector<double> xs(2 * EIG_P), cnt(2 * EIG_P);
+    std::vector<double> xs(2 * EIG_PMAX), cnt(2 * EIG_PMAX);
     {   // the ends themselves: count(lo) must not exceed k, count(hi) must
         double e4[4] = {-lo[0], -hi[0], -lo[1], -hi[1]}, c4[4];
         if (int rc = eval_batch(e4, 4, false, c4, nullptr, nullptr)) return rc;
-        if (c4[0] > (double)kth[0]) lo[0] = 0.0;                 // cannot happen for an SPD matrix (emax >= every diagonal entry)
+        if (c4[0] > (double)kth[0]) lo[0] = 0.0;                 // cannot happen for a symmetric matrix (emax >= |T e_j|)
         if (!(c4[1] > (double)kth[0])) hi[0] = 2.0 * ghi + 1.0;
         if (c4[2] > (double)kth[1]) { done[1] = true; lo[1] = hi[1] = 1e-300; }      // an eigenvalue below every floor: as the legacy route's max(ev, 1e-300)
         else if (!(c4[3] > (double)kth[1])) { done[1] = true; lo[1] = hi[1] = dmin; }   // emin <= every diagonal entry: equality only
@@ -1512,18 +2000,19 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         for (int e = 0; e < 2; ++e) {
             if (done[e]) continue;
             if (hi[e] - lo[e] <= EIG_TOL * std::max(fabs(lo[e]), fabs(hi[e]))) { done[e] = true; continue; }
+            const int P = EIG_P[e];
             const bool geo = lo[e] > 0.0 && hi[e] > 4.0 * lo[e];
             bool distinct = true;
-            for (int i = 0; i < EIG_P; ++i) {
-                const double f = (double)(i + 1) / (double)(EIG_P + 1);
+            for (int i = 0; i < P; ++i) {
+                const double f = (double)(i + 1) / (double)(P + 1);
                 const double x = geo ? lo[e] * exp(f * log(hi[e] / lo[e])) : lo[e] + (hi[e] - lo[e]) * f;
-                xs[e * EIG_P + i] = x;
-                if (!(x > lo[e]) || !(x < hi[e]) || (i > 0 && !(x > xs[e * EIG_P + i - 1]))) distinct = false;
+                xs[e * EIG_PMAX + i] = x;
+                if (!(x > lo[e]) || !(x < hi[e]) || (i > 0 && !(x > xs[e * EIG_PMAX + i - 1]))) distinct = false;
             }
             if (!distinct) {
                 const double midp = 0.5 * (lo[e] + hi[e]);
                 if (midp <= lo[e] || midp >= hi[e]) { done[e] = true; continue; }
-                for (int i = 0; i < EIG_P; ++i) xs[e * EIG_P + i] = midp;
+                for (int i = 0; i < P; ++i) xs[e * EIG_PMAX + i] = midp;
             }
             ++live;
         }
@@ -1531,16 +2020,16 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         std::vector<double> lamv;
         std::vector<int> owner;
         for (int e = 0; e < 2; ++e)
-            if (!done[e]) for (int i = 0; i < EIG_P; ++i) { lamv.push_back(-xs[e * EIG_P + i]); owner.push_back(e * EIG_P + i); }
+            if (!done[e]) for (int i = 0; i < EIG_P[e]; ++i) { lamv.push_back(-xs[e * EIG_PMAX + i]); owner.push_back(e * EIG_PMAX + i); }
         std::vector<double> cv(lamv.size());
         if (int rc = eval_batch(lamv.data(), (int)lamv.size(), false, cv.data(), nullptr, nullptr)) return rc;
         for (size_t q = 0; q < owner.size(); ++q) cnt[owner[q]] = cv[q];
         for (int e = 0; e < 2; ++e) {
             if (done[e]) continue;
             double nlo = lo[e], nhi = hi[e];
-            for (int i = 0; i < EIG_P; ++i) {
-                if (cnt[e * EIG_P + i] > (double)kth[e]) { nhi = xs[e * EIG_P + i]; break; }
-                nlo = xs[e * EIG_P + i];
+            for (int i = 0; i < EIG_P[e]; ++i) {
+                if (cnt[e * EIG_PMAX + i] > (double)kth[e]) { nhi = xs[e * EIG_PMAX + i]; break; }
+                nlo = xs[e * EIG_PMAX + i];
             }
             lo[e] = nlo; hi[e] = nhi;
         }
@@ -1697,7 +2186,11 @@ int Band32Search::solve(double lam, double *gcv, double *eff_df, double *q_host)
     double *dl = ws->lamd;
     pin[0] = lam;
     MHS_HIP(hipMemcpyAsync(dl, pin, sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL((b32_sweep_kernel<true, true>), dim3(1, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
+    if (int rc = pack()) return rc;
+    if (sweep_four_waves())
+        hipLaunchKernelGGL((b32_sweep_kernel<true, true>), dim3(1, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
+    else
+        hipLaunchKernelGGL((b32_sweep1_kernel<true, true>), dim3(1, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
     MHS_HIP(hipGetLastError());
     std::vector<double> Lh((size_t)(n0 + n1) * W + 1), yh((size_t)(n0 + n1) + 1), wh(2 * SWIN), rh(8);
     MHS_HIP(hipMemcpyAsync(Lh.data(), ws->Lbuf, sizeof(double) * (size_t)(n0 + n1) * W, hipMemcpyDeviceToHost, s));
