@@ -32,9 +32,11 @@ constexpr int LOG_TAB_N = 1 << LOG_TAB_BITS;
 // grow-only device arena its work buffers are carved from (no hipMalloc / hipFree -- a device-wide
 // synchronisation -- per fit).  mhs_tps_fit uses lane 0; mhs_tps_surface fits its tiles on several lanes
 // from host threads.
+constexpr int FIT_PANEL_CUS = 32;      // compute units the 32-column route's trailing update stays off (a multiple of 8: the same ones in every XCD)
 struct FitLane {
     hipStream_t s = nullptr, s2 = nullptr;
     hipStream_t ms = nullptr, ms2 = nullptr;   // the same pair confined to the compute units mhs_fit_reserve_cus keeps free
+    hipStream_t s2r = nullptr;                 // s2's work of the 32-column route, kept OFF four compute units of every XCD (runtime.hip)
     std::vector<hipEvent_t> pool;
     char *arena = nullptr;
     size_t arena_cap = 0;

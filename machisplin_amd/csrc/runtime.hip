@@ -135,8 +135,19 @@ int fit_lane(int i, FitLane **out) {
             e = hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
             if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&L->ms2, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
         }
+        // The trailing update of the 32-column route (hundreds of blocks, two per compute unit, ~150 KB of LDS between
+        // them) leaves the next panel's 10-20 blocks no compute unit to start on, whatever the priorities: beside it the
+        // panel's first kernels ran 2-5 x slower (gram 9 -> 43 us, first pass 30 -> 72 us at n = 5 000).  Its stream is
+        // therefore masked off the first 32 mask indices = four compute units of each XCD (the index order measured for
+        // mhs_fit_reserve_cus below); MHS_FIT_REST_ALL_CUS=1 restores the unmasked stream.
+        static const bool rest_all = getenv("MHS_FIT_REST_ALL_CUS") != nullptr;
+        if (e == hipSuccess && !rest_all && c.n_cu >= 128) {
+            std::vector<uint32_t> mask((size_t)(c.n_cu + 31) / 32, 0u);
+            for (int q = FIT_PANEL_CUS; q < c.n_cu; ++q) mask[(size_t)q / 32] |= 1u << (q % 32);
+            e = hipExtStreamCreateWithCUMask(&L->s2r, (uint32_t)mask.size(), mask.data());
+        }
         if (e != hipSuccess) {      // nothing half-built stays behind
-            for (hipStream_t q : {L->s, L->s2, L->ms, L->ms2}) if (q) (void)hipStreamDestroy(q);
+            for (hipStream_t q : {L->s, L->s2, L->ms, L->ms2, L->s2r}) if (q) (void)hipStreamDestroy(q);
             delete L;
             return hip_fail(e, "fit_lane: stream creation", __FILE__, __LINE__);
         }
@@ -274,6 +285,7 @@ int mhs_shutdown(void) {
         if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); }
         if (L->arena) (void)hipFree(L->arena);
         if (L->pinned) (void)hipHostFree(L->pinned);
+        if (L->s2r) { (void)hipStreamSynchronize(L->s2r); (void)hipStreamDestroy(L->s2r); }
         (void)hipStreamDestroy(L->s2); (void)hipStreamDestroy(L->s);
         delete L;
     }

@@ -7,7 +7,8 @@
 
 namespace mhs {
 constexpr int B32_NB = 32;               // band width of the reduction
-constexpr int B32_MAXPART = 16;          // row blocks (partial sums) per panel: their sums are loaded in ONE batch
+constexpr int B32_MAXPART = 16;          // partial sums a kernel loads in ONE batch
+constexpr int B32_MAXBLK = 32;           // row blocks (partial sums) per panel: two batches past 16 (panels of more than 4 096 rows)
 constexpr int B32_BT_MAXBLK = 128;       // row blocks of the back-transform (up to 32 768 unknowns)
 constexpr int B32_PANEL_REC = 2 * B32_NB * B32_NB;      // doubles a panel leaves for the back-transform: T, then the top block of V
 constexpr int B32_MIN_M = 320;           // smallest order the route is used for (below: tps_fit.hip's 8-column route)

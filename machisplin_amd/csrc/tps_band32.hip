@@ -105,6 +105,16 @@ __device__ __forceinline__ void parts_issue(Parts4 &P, const double *__restrict_
             P.v[q][p] = p < nparts ? x : 0.0;
         }
 }
+__device__ __forceinline__ void parts_add(const Parts4 &P, double (*G)[NB + 1]) {      // a second batch onto the first one's sums
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < MAXPART_H; ++p) s += P.v[q][p];
+        const int e = threadIdx.x + 256 * q;
+        G[e >> 5][e & 31] += s;
+    }
+}
 __device__ __forceinline__ void parts_sum(const Parts4 &P, double (*G)[NB + 1]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -266,6 +276,17 @@ __device__ __forceinline__ double sum_parts_32(const double *__restrict__ part, 
     double s = 0.0;
 #pragma unroll
     for (int p = 0; p < MAXPART_H; ++p) s += v[p];
+    if (nparts > MAXPART_H) {      // the second batch (panels of more than 4 096 rows)
+#pragma unroll
+        for (int p = 0; p < MAXPART_H; ++p) {
+            const double x = part[(size_t)(MAXPART_H + p < nparts ? MAXPART_H + p : 0) * NB + a];
+            v[p] = MAXPART_H + p < nparts ? x : 0.0;
+        }
+        double s2 = 0.0;
+#pragma unroll
+        for (int p = 0; p < MAXPART_H; ++p) s2 += v[p];
+        s += s2;
+    }
     return s;
 }
 
@@ -312,6 +333,7 @@ __global__ __launch_bounds__(256) void b32_cholqr1_kernel(double *__restrict__ A
 #pragma unroll
         for (int a = 0; a < NB; ++a) x[a] = row[(int64_t)a * ld];
         parts_sum(P, G);
+        if (nparts > MAXPART_H) { parts_issue(P, Gin + (size_t)MAXPART_H * NB * NB, nparts - MAXPART_H); parts_add(P, G); }
     }
     B32_MARK(1, 0);
     const bool ok_chol = chol32_lds(G, sd);
@@ -397,6 +419,7 @@ __global__ __launch_bounds__(256) void b32_cholqr2_kernel(double *__restrict__ A
 #pragma unroll
         for (int a = 0; a < NB; ++a) xrow[a] = row[(int64_t)a * ld];
         parts_sum(P, Em);
+        if (nparts > MAXPART_H) { parts_issue(P, Gin + (size_t)MAXPART_H * NB * NB, nparts - MAXPART_H); parts_add(P, Em); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Qt[e >> 5][e & 31] = qt4[q]; }
     }
@@ -877,6 +900,7 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
 #pragma unroll
         for (int q = 0; q < 4; ++q) tq[q] = Tm[threadIdx.x + 256 * q];
         parts_sum(P, M);
+        if (nM > MAXPART_H) { parts_issue(P, Mpart + (size_t)MAXPART_H * NB * NB, nM - MAXPART_H); parts_add(P, M); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; Ts[e >> 5][e & 31] = tq[q]; }
     }
@@ -1728,16 +1752,16 @@ static size_t band32_layout(Band32Ws *w, char *base, int m, int64_t n) {
     };
     const size_t vs = (size_t)n, np = (size_t)std::max(1, band32_npanels(m));
     Band32Ws d;
-    d.Gp1 = take((size_t)MAXPART_H * NB * NB);
-    d.Gp2 = take((size_t)MAXPART_H * NB * NB);
+    d.Gp1 = take((size_t)B32_MAXBLK * NB * NB);
+    d.Gp2 = take((size_t)B32_MAXBLK * NB * NB);
     d.R1 = take(NB * NB);
     d.Qtop = take(NB * NB);
     d.aux = take(AUX_SIZE + 32);
     for (int k = 0; k < 2; ++k) { d.Zc[k] = take(2 * NB * vs + 16); d.Vr[k] = take(((size_t)m + 256) * NB); }
     d.Yp = take((size_t)SYMM_MAXSPLIT * NB * vs);
     d.Wh = take(((size_t)m + 256) * NB);
-    d.Mp = take((size_t)MAXPART_H * NB * NB);
-    d.sgp = take((size_t)MAXPART_H * NB);
+    d.Mp = take((size_t)B32_MAXBLK * NB * NB);
+    d.sgp = take((size_t)B32_MAXBLK * NB);
     d.Tall = take(np * PREC);
     d.ab = take((size_t)m * (NB + 1) + 64);
     d.abF = take((size_t)m * (NB + 2) + 64);
@@ -1767,7 +1791,7 @@ int band32_pinned(FitLane &L, double **out) {
 // chunks of 256 rows per block so that a panel has at most MAXPART row blocks
 static inline void row_blocks(int t, int *cpb, int *nblk) {
     const int nch = (t + CHR - 1) / CHR;
-    *cpb = (nch + B32_MAXPART - 1) / B32_MAXPART;
+    *cpb = (nch + B32_MAXBLK - 1) / B32_MAXBLK;
     *nblk = (nch + *cpb - 1) / *cpb;
 }
 
@@ -1951,13 +1975,23 @@ void Band32Search::gcv_from_terms(double lam, double tr_inv, double qq, double *
     if (tra) *tra = trv;
 }
 
-// The two extreme eigenvalues by multi-section on the inertia count, P points per bracket and round (a constant: the
+// The two extreme eigenvalues by multi-section on the inertia count, P points per bracket and round (constants: the
 // sequence of brackets, hence the last bits of lambda, must not depend on anything but the band).  emax starts from
-// [largest diagonal entry, Gershgorin bound], emin from (hi 2^-200, smallest diagonal entry]; a bracket whose ends are
-// positive and more than a factor 4 apart is cut geometrically, otherwise linearly.
-static const int EIG_P[2] = {63, 255};      // points per round for the largest / the smallest eigenvalue (the smallest starts 200 octaves wide)
+// [largest column norm, min(Gershgorin, Frobenius)], emin from (dmin 2^-200, dmin = smallest diagonal entry]; a bracket whose
+// ends are positive and more than a factor 4 apart is cut geometrically, otherwise linearly.  emin's FIRST cut is uneven:
+// 200 of its points cover the top 50 octaves (a matrix whose smallest eigenvalue is below 1e-15 of its smallest diagonal
+// entry is singular for every later purpose), 55 the 150 octaves below.  Rounds are what the search costs (a sweep is a
+// chain of m / 2 column steps, ~0.6 ms at n = 5 000, whatever the number of lambdas), so
+//   * the check of the brackets' ends rides along with the first cut (a failed check -- a matrix that is not positive
+//     definite -- repeats the round), and
+//   * gcv.Krig's bracket (tr A at emax 4^k and emin / 4^k) is evaluated SPECULATIVELY in the round that starts with both
+//     eigenvalues known to 1e-6: its 40 points only decide two integers, k1 and k2, and tr A moves by less than
+//     (tr A - 3) or (n - tr A) times the relative error of lambda -- decisions closer than 1e-3 to their threshold (or any
+//     other surprise) are redone with the final eigenvalues.
+static const int EIG_P[2] = {63, 255};      // a round whose bracket is within 256 x the tolerance takes the smallest of 15, 31, 63, 127, 255 points that finishes it
 static const int EIG_PMAX = 255;
-static const double EIG_TOL = 2e-9;       // lambda moves by about half the relative error of either end (they only place the grid)
+static const double EIG_TOL = 3e-10;      // lambda moves by about half the relative error of either end (they only place the grid)
+static const double EIG_SPEC = 1e-6;
 int Band32Search::find_lambda(int mode, double *lam_out) {
     const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -1968,8 +2002,6 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         t_last = now;
     };
     const int W = NB + 1;
-    // brackets: |T e_j| <= emax <= min(Gershgorin, |T|_F) (the Frobenius norm of a matrix whose spectrum decays is within
-    // tens of per cent of its largest eigenvalue: a round less than from the Gershgorin bound), 0 < emin <= min T_jj
     double dmax = ab_host[0], dmin = ab_host[0], ghi = ab_host[0], fro2 = 0.0, cmax2 = 0.0;
     for (int j = 0; j < m; ++j) {
         double r = 0.0, c2 = 0.0;
@@ -1987,25 +2019,31 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
     const int64_t kth[2] = {m - 1, 0};
     bool done[2] = {false, false};
     std::vector<double> xs(2 * EIG_PMAX), cnt(2 * EIG_PMAX);
-    {   // the ends themselves: count(lo) must not exceed k, count(hi) must
-        double e4[4] = {-lo[0], -hi[0], -lo[1], -hi[1]}, c4[4];
-        if (int rc = eval_batch(e4, 4, false, c4, nullptr, nullptr)) return rc;
-        if (c4[0] > (double)kth[0]) lo[0] = 0.0;                 // cannot happen for a symmetric matrix (emax >= |T e_j|)
-        if (!(c4[1] > (double)kth[0])) hi[0] = 2.0 * ghi + 1.0;
-        if (c4[2] > (double)kth[1]) { done[1] = true; lo[1] = hi[1] = 1e-300; }      // an eigenvalue below every floor: as the legacy route's max(ev, 1e-300)
-        else if (!(c4[3] > (double)kth[1])) { done[1] = true; lo[1] = hi[1] = dmin; }   // emin <= every diagonal entry: equality only
-    }
-    for (int it = 0; it < 60; ++it) {
+    bool ends_checked = false, spec_have = false;
+    int np[2] = {EIG_P[0], EIG_P[1]};      // points of this round
+    double spec_e[2] = {0.0, 0.0}, spec_lam[40], spec_neg[40], spec_tr[40];
+    auto relw = [&](int e) { return (hi[e] - lo[e]) / std::max(fabs(lo[e]), fabs(hi[e])); };
+    for (int it = 0; it < 80; ++it) {
         int live = 0;
         for (int e = 0; e < 2; ++e) {
             if (done[e]) continue;
-            if (hi[e] - lo[e] <= EIG_TOL * std::max(fabs(lo[e]), fabs(hi[e]))) { done[e] = true; continue; }
-            const int P = EIG_P[e];
+            if (ends_checked && hi[e] - lo[e] <= EIG_TOL * std::max(fabs(lo[e]), fabs(hi[e]))) { done[e] = true; continue; }
+            int P = EIG_P[e];
+            if (ends_checked)
+                for (int q = 15; q <= EIG_PMAX; q = 2 * q + 1)
+                    if ((hi[e] - lo[e]) / (double)(q + 1) <= 0.5 * EIG_TOL * std::max(fabs(lo[e]), fabs(hi[e]))) { P = q; break; }
+            np[e] = P;
             const bool geo = lo[e] > 0.0 && hi[e] > 4.0 * lo[e];
             bool distinct = true;
             for (int i = 0; i < P; ++i) {
-                const double f = (double)(i + 1) / (double)(P + 1);
-                const double x = geo ? lo[e] * exp(f * log(hi[e] / lo[e])) : lo[e] + (hi[e] - lo[e]) * f;
+                double x;
+                if (e == 1 && !ends_checked) {      // the uneven first cut of emin: hi 2^-o, o = 150 (54 - i) / 55 + 50 below point 55, 0.25 (P - i) above
+                    const double o = i < 55 ? 50.0 + 150.0 * (double)(55 - i) / 56.0 : 0.25 * (double)(P - i);
+                    x = hi[e] * exp2(-o);
+                } else {
+                    const double f = (double)(i + 1) / (double)(P + 1);
+                    x = geo ? lo[e] * exp(f * log(hi[e] / lo[e])) : lo[e] + (hi[e] - lo[e]) * f;
+                }
                 xs[e * EIG_PMAX + i] = x;
                 if (!(x > lo[e]) || !(x < hi[e]) || (i > 0 && !(x > xs[e * EIG_PMAX + i - 1]))) distinct = false;
             }
@@ -2018,16 +2056,40 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         }
         if (!live) break;
         std::vector<double> lamv;
-        std::vector<int> owner;
+        std::vector<int> owner;      // >= 0: xs slot; -1 .. -4: the brackets' ends; <= -10: speculative bracket point -10 - q
         for (int e = 0; e < 2; ++e)
-            if (!done[e]) for (int i = 0; i < EIG_P[e]; ++i) { lamv.push_back(-xs[e * EIG_PMAX + i]); owner.push_back(e * EIG_PMAX + i); }
-        std::vector<double> cv(lamv.size());
-        if (int rc = eval_batch(lamv.data(), (int)lamv.size(), false, cv.data(), nullptr, nullptr)) return rc;
-        for (size_t q = 0; q < owner.size(); ++q) cnt[owner[q]] = cv[q];
+            if (!done[e]) for (int i = 0; i < np[e]; ++i) { lamv.push_back(-xs[e * EIG_PMAX + i]); owner.push_back(e * EIG_PMAX + i); }
+        if (!ends_checked) {
+            const double e4[4] = {-lo[0], -hi[0], -lo[1], -hi[1]};
+            for (int q = 0; q < 4; ++q) { lamv.push_back(e4[q]); owner.push_back(-1 - q); }
+        }
+        const bool spec_now = ends_checked && !spec_have && (done[0] || relw(0) <= EIG_SPEC) && (done[1] || relw(1) <= EIG_SPEC);
+        if (spec_now) {
+            spec_e[0] = 0.5 * (lo[0] + hi[0]); spec_e[1] = std::max(0.5 * (lo[1] + hi[1]), 1e-300);
+            for (int q = 0; q < 20; ++q) { spec_lam[q] = spec_e[0] * pow(4.0, q); spec_lam[20 + q] = spec_e[1] / pow(4.0, q); }
+            for (int q = 0; q < 40; ++q) { lamv.push_back(spec_lam[q]); owner.push_back(-10 - q); }
+        }
+        std::vector<double> cv(lamv.size()), tv(lamv.size());
+        if (int rc = eval_batch(lamv.data(), (int)lamv.size(), spec_now, cv.data(), spec_now ? tv.data() : nullptr, nullptr)) return rc;
+        double c4[4] = {0, 0, 0, 0};
+        for (size_t q = 0; q < owner.size(); ++q) {
+            if (owner[q] >= 0) cnt[owner[q]] = cv[q];
+            else if (owner[q] >= -4) c4[-1 - owner[q]] = cv[q];
+            else { spec_neg[-10 - owner[q]] = cv[q]; spec_tr[-10 - owner[q]] = tv[q]; }
+        }
+        if (spec_now) spec_have = true;
+        bool redo[2] = {false, false};
+        if (!ends_checked) {      // the ends themselves: count(lo) must not exceed k, count(hi) must
+            ends_checked = true;
+            if (c4[0] > (double)kth[0]) { lo[0] = 0.0; redo[0] = true; }                 // cannot happen for a symmetric matrix (emax >= |T e_j|)
+            if (!(c4[1] > (double)kth[0])) { hi[0] = 2.0 * ghi + 1.0; redo[0] = true; }
+            if (c4[2] > (double)kth[1]) { done[1] = true; lo[1] = hi[1] = 1e-300; }      // an eigenvalue below every floor: as the legacy route's max(ev, 1e-300)
+            else if (!(c4[3] > (double)kth[1])) { done[1] = true; lo[1] = hi[1] = dmin; }   // emin <= every diagonal entry: equality only
+        }
         for (int e = 0; e < 2; ++e) {
-            if (done[e]) continue;
+            if (done[e] || redo[e]) continue;
             double nlo = lo[e], nhi = hi[e];
-            for (int i = 0; i < EIG_P[e]; ++i) {
+            for (int i = 0; i < np[e]; ++i) {
                 if (cnt[e * EIG_PMAX + i] > (double)kth[e]) { nhi = xs[e * EIG_PMAX + i]; break; }
                 nlo = xs[e * EIG_PMAX + i];
             }
@@ -2037,23 +2099,51 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
     const double emax = 0.5 * (lo[0] + hi[0]), emin = std::max(0.5 * (lo[1] + hi[1]), 1e-300);
     lap("extreme eigenvalues");
     // gcv.Krig's bracket: l1 = emax 4^k until trA < 3.05, l2 = emin / 4^k until trA > 0.95 n
-    double lamb[40], negb[40], trb[40];
-    for (int i = 0; i < 20; ++i) { lamb[i] = emax * pow(4.0, i); lamb[20 + i] = emin / pow(4.0, i); }
-    if (int rc = eval_batch(lamb, 40, true, negb, trb, nullptr)) return rc;
     double l1 = emax, l2 = emin;
-    for (int k = 0; k < 20; ++k) {
-        if (negb[k] > 0) { *lam_out = NAN; return MHS_OK; }
-        double tra;
-        gcv_from_terms(lamb[k], trb[k], 0.0, nullptr, &tra);
-        if (tra < 3.0 + 0.05) break;
-        l1 *= 4.0;
+    bool bracket_done = false;
+    if (spec_have && fabs(emax - spec_e[0]) <= 4.0 * EIG_SPEC * emax && fabs(emin - spec_e[1]) <= 4.0 * EIG_SPEC * emin) {
+        bool sure = true;
+        int k1 = 0, k2 = 0;
+        for (int k = 0; k < 20 && sure; ++k) {
+            if (spec_neg[k] > 0) { sure = false; break; }
+            double tra;
+            gcv_from_terms(spec_lam[k], spec_tr[k], 0.0, nullptr, &tra);
+            if (!(fabs(tra - 3.05) > 1e-3 * 3.05)) { sure = false; break; }
+            if (tra < 3.0 + 0.05) break;
+            ++k1;
+        }
+        for (int k = 0; k < 20 && sure; ++k) {
+            if (spec_neg[20 + k] > 0) { sure = false; break; }
+            double tra;
+            gcv_from_terms(spec_lam[20 + k], spec_tr[20 + k], 0.0, nullptr, &tra);
+            if (!(fabs(tra - 0.95 * (double)n) > 1e-3 * 0.95 * (double)n)) { sure = false; break; }
+            if (tra > 0.95 * (double)n) break;
+            ++k2;
+        }
+        if (sure) {
+            for (int k = 0; k < k1; ++k) l1 *= 4.0;
+            for (int k = 0; k < k2; ++k) l2 /= 4.0;
+            bracket_done = true;
+        }
     }
-    for (int k = 0; k < 20; ++k) {
-        if (negb[20 + k] > 0) break;
-        double tra;
-        gcv_from_terms(lamb[20 + k], trb[20 + k], 0.0, nullptr, &tra);
-        if (tra > 0.95 * (double)n) break;
-        l2 /= 4.0;
+    if (!bracket_done) {
+        double lamb[40], negb[40], trb[40];
+        for (int i = 0; i < 20; ++i) { lamb[i] = emax * pow(4.0, i); lamb[20 + i] = emin / pow(4.0, i); }
+        if (int rc = eval_batch(lamb, 40, true, negb, trb, nullptr)) return rc;
+        for (int k = 0; k < 20; ++k) {
+            if (negb[k] > 0) { *lam_out = NAN; return MHS_OK; }
+            double tra;
+            gcv_from_terms(lamb[k], trb[k], 0.0, nullptr, &tra);
+            if (tra < 3.0 + 0.05) break;
+            l1 *= 4.0;
+        }
+        for (int k = 0; k < 20; ++k) {
+            if (negb[20 + k] > 0) break;
+            double tra;
+            gcv_from_terms(lamb[20 + k], trb[20 + k], 0.0, nullptr, &tra);
+            if (tra > 0.95 * (double)n) break;
+            l2 /= 4.0;
+        }
     }
     lap("bracket (40 evals)");
     const int nstep = 200;
@@ -2287,7 +2377,7 @@ extern "C" int mhs_band32_reduce(const double *B, const double *g, int64_t m64, 
     MHS_HIP(hipMemcpyAsync(dg.p, g, sizeof(double) * m, hipMemcpyHostToDevice, s));
     Band32Ws w;
     band32_carve(w, dws.p, m, n);
-    if (int rc = band32_reduce(*L, s, L->s2, A, ld, m, n, dg.p, w, breakdown)) return rc;
+    if (int rc = band32_reduce(*L, s, L->s2r ? L->s2r : L->s2, A, ld, m, n, dg.p, w, breakdown)) return rc;
     MHS_HIP(hipMemcpyAsync(ab, w.ab, sizeof(double) * (size_t)m * (B32_NB + 1), hipMemcpyDeviceToHost, s));
     MHS_HIP(hipMemcpyAsync(gq, dg.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
     if (r && Qr) {
@@ -2296,7 +2386,7 @@ extern "C" int mhs_band32_reduce(const double *B, const double *g, int64_t m64, 
         MHS_HIP(hipMemcpyAsync(Qr, dr.p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
     }
     MHS_HIP(hipStreamSynchronize(s));
-    MHS_HIP(hipStreamSynchronize(L->s2));
+    MHS_HIP(hipStreamSynchronize(L->s2r ? L->s2r : L->s2));
     return MHS_OK;
 }
 

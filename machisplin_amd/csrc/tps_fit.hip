@@ -2222,7 +2222,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             MHS_HIP(hipMemcpyAsync(w32.ab, ab32.data(), sizeof(double) * ab32.size(), hipMemcpyHostToDevice, s));
             if (int rc = band32_qt(s, redA, red_ld, m, redT, gbuf.p, w32.sgp)) return rc;
         } else {
-            if (int rc = band32_reduce(L, s, confined ? L.ms2 : L.s2, A.p, ld, m, vs, gbuf.p, w32, &breakdown)) return rc;
+            if (int rc = band32_reduce(L, s, confined ? L.ms2 : (L.s2r ? L.s2r : L.s2), A.p, ld, m, vs, gbuf.p, w32, &breakdown)) return rc;
         }
         if (!breakdown) {
             if (!hit) MHS_HIP(hipMemcpyAsync(ab32.data(), w32.ab, sizeof(double) * ab32.size(), hipMemcpyDeviceToHost, s));
