@@ -14,6 +14,7 @@ constexpr int B32_PANEL_REC = 2 * B32_NB * B32_NB;      // doubles a panel leave
 constexpr int B32_MIN_M = 320;           // smallest order the route is used for (below: tps_fit.hip's 8-column route)
 constexpr int B32_MAX_M = B32_BT_MAXBLK * 256;
 constexpr int B32_MAXLAM = 1024;         // lambdas per search round
+constexpr int B32_PAIR_SPLIT = 768;      // eval_pair: slots of the first batch (the second takes the rest)
 
 // device work space of one fit on this route, carved from the lane's arena
 struct Band32Ws {
@@ -37,7 +38,7 @@ int band32_backtransform(hipStream_t s, const double *A, int64_t ld, int m, cons
 // lambda by GCV on the band (device evaluations, host-driven rounds), then q = (Bb + lambda I)^-1 g (host vector, m).
 // ab_host: the band on the host (m x 33).  Returns MHS_OK or an error code (error text set).
 struct Band32Search {
-    hipStream_t s = nullptr;
+    hipStream_t s = nullptr, s_aux = nullptr;      // s_aux: an idle second stream for a batch beside the main one (optional)
     const double *ab_dev = nullptr, *g_dev = nullptr;
     const double *ab_host = nullptr, *g_host = nullptr;
     int m = 0;
@@ -50,6 +51,10 @@ struct Band32Search {
     int pack();
     // per lambda: eigenvalues of Bb below -lambda (inertia), tr (Bb + lambda I)^-1, g'(Bb + lambda I)^-2 g
     int eval_batch(const double *lam, int count, bool deriv, double *neg, double *tr, double *q2);
+    int eval_pair(const double *lamA, int nA, double *negA, const double *lamB, int nB, double *negB, double *trB);
+    int enqueue(hipStream_t st, int off, const double *lam, int nl, bool deriv);
+    void collect(int off, int nl, double *neg, double *tr, double *q2) const;
+    void report(int off, int nl, bool deriv) const;
     int find_lambda(int mode, double *lam_out);
     int solve(double lam, double *gcv, double *eff_df, double *q_host);
     void gcv_from_terms(double lam, double tr_inv, double qq, double *gcv, double *tra) const;

@@ -1107,6 +1107,93 @@ __global__ __launch_bounds__(256) void b32_strip_kernel(double *__restrict__ A, 
     B32_MARK(6, 2);
 }
 
+// K5a and the NEXT panel's K0 in one launch: the strip update with 256-row blocks dealt as row_blocks(t - 32) deals the next
+// panel (rows 32 .. t - 1 of this A22), each block leaving the partial Gram matrix of its rows beside the updated entries --
+// what b32_gram_kernel would compute from them, bit for bit, without the launch and the round trip through memory between
+// the two (strip 8 us + gap 3 us + Gram 12-15 us under the trailing update's traffic -> ~11 us).  Wave = 64 rows x 32
+// columns (128 MFMAs); block 0's first two waves also update the 32 rows above the panel (the next diagonal block).
+__global__ __launch_bounds__(256) void b32_stripgram_kernel(double *__restrict__ A, int64_t ld, int r0, int t,
+                                                            const double *__restrict__ Z, int64_t vs, int cpb,
+                                                            double *__restrict__ Gpart) {
+    __shared__ double Pt[NB * PT_S];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, ta = wave >> 1, tb = wave & 1;
+    double *C = A + (int64_t)r0 * ld + r0;
+    B32_PROF_BEGIN
+    double fj[2][RK_K / 4];      // rows 0 .. 31 of [W | V], negated: the A operands of every tile
+#pragma unroll
+    for (int q = 0; q < RK_K / 4; ++q) {
+        const double *cq = Z + (int64_t)((4 * q + l4 + NB) & (RK_K - 1)) * vs;
+        fj[0][q] = -cq[l15];
+        fj[1][q] = -cq[16 + l15];
+    }
+    d4v gacc = {0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < cpb; ++ch) {
+        const int base = NB + (blockIdx.x * cpb + ch) * CHR + wave * 64;      // first of the wave's 64 rows of A22
+        d4v acc[4][2];
+        double fi[4][RK_K / 4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row = base + rt * 16 + l15;
+            const bool ok = row < t;
+            const int rr = ok ? row : 0;
+#pragma unroll
+            for (int q = 0; q < RK_K / 4; ++q) { const double x = Z[(int64_t)(4 * q + l4) * vs + rr]; fi[rt][q] = ok ? x : 0.0; }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const double x = C[(int64_t)(a * 16 + l4 + 4 * r) * ld + rr]; acc[rt][a][r] = ok ? x : 0.0; }
+        }
+        B32_MARK(6, 0);
+#pragma unroll
+        for (int q = 0; q < RK_K / 4; ++q)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[0][q], fi[rt][q], acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[1][q], fi[rt][q], acc[rt][1], 0, 0, 0);
+            }
+        B32_MARK(6, 1);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row = base + rt * 16 + l15;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = a * 16 + l4 + 4 * r;
+                    if (row < t) C[(int64_t)l * ld + row] = acc[rt][a][r];
+                    Pt[l * PT_S + wave * 64 + rt * 16 + l15] = acc[rt][a][r];      // zero past the last row
+                }
+        }
+        __syncthreads();
+        B32_MARK(6, 2);
+        gram_chunk(Pt, Pt, gacc, ta, tb);
+        __syncthreads();
+        B32_MARK(0, 1);
+    }
+    store_tile32(Gpart + (size_t)blockIdx.x * NB * NB, gacc, ta, tb);
+    if (blockIdx.x == 0 && wave < 2) {      // rows 0 .. 31 of A22
+        const int row = wave * 16 + l15;
+        d4v acc[2];
+        double fi[RK_K / 4];
+#pragma unroll
+        for (int q = 0; q < RK_K / 4; ++q) fi[q] = Z[(int64_t)(4 * q + l4) * vs + row];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][r] = C[(int64_t)(a * 16 + l4 + 4 * r) * ld + row];
+#pragma unroll
+        for (int q = 0; q < RK_K / 4; ++q) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[0][q], fi[q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[1][q], fi[q], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(int64_t)(a * 16 + l4 + 4 * r) * ld + row] = acc[a][r];
+    }
+    B32_MARK(0, 2);
+}
+
 // lower band of B -> ab[j * 33 + d] = B[j + d][j]
 __global__ void b32_extract_kernel(const double *__restrict__ A, int64_t ld, int off0, int m, double *__restrict__ ab) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1306,94 +1393,6 @@ __device__ __forceinline__ void sweep_step(SweepLds &L, const SweepSlots &sl, in
             q2 -= (2.0 * y0 * dy0 * d - y0 * y0 * dd) * (inv * inv);
         }
         if (Lcol && threadIdx.x == 128) { Lcol[0] = d; *ycol = y0; }
-    }
-}
-
-// value of the band at logical (row r, column r - d) and of g at logical row r
-__device__ __forceinline__ double band_at(const double *__restrict__ ab, int m, int dir, int r, int d) {
-    if (r - d < 0 || r >= m) return 0.0;
-    return dir == 0 ? ab[(int64_t)(r - d) * (NB + 1) + d] : ab[(int64_t)(m - 1 - r) * (NB + 1) + d];
-}
-
-template <bool DERIV, bool STORE>
-__global__ __launch_bounds__(256) void b32_sweep_kernel(const double *__restrict__ ab, const double *__restrict__ g, int m, int n0,
-                                                        int n1, const double *__restrict__ lams, double *__restrict__ win,
-                                                        double *__restrict__ res, double *__restrict__ Lbuf,
-                                                        double *__restrict__ ybuf) {
-    __shared__ SweepLds L;
-    const int dir = blockIdx.y, ncols = dir == 0 ? n0 : n1;
-    const double lam = lams[blockIdx.x];
-    const int tid = threadIdx.x;
-    const SweepSlots sl = sweep_slots();
-    for (int e = tid; e < SW * SWS + 2; e += 256) { L.W[e] = 0.0; L.dW[e] = 0.0; }
-    __syncthreads();
-    const int last_row = STORE ? m - 1 : min(m - 1, ncols + NB - 1);      // rows the sweep needs
-    // rows 0 .. 32
-    for (int e = tid; e < (NB + 1) * (NB + 1); e += 256) {
-        const int r = e / (NB + 1), dgl = e - r * (NB + 1);
-        if (dgl <= r && r <= last_row) {
-            L.W[r * SWS + dgl] = band_at(ab, m, dir, r, dgl) + (dgl == 0 ? lam : 0.0);
-            if (DERIV && dgl == 0) L.dW[r * SWS] = 1.0;
-        }
-    }
-    if (tid <= NB && tid <= last_row) L.W[tid * SWS + SYO] = g[dir == 0 ? tid : m - 1 - tid];
-    // staging: chunk c = rows 33 + 7 c .. 39 + 7 c, entered at steps 7 c .. 7 c + 6; thread (srr, sd): offset sd of row srr
-    const int srr = tid / (NB + 2), sd = tid - srr * (NB + 2);
-    auto fetch = [&](int c) -> double {
-        const int r = NB + 1 + SCH * c + srr;
-        if (tid >= SCH * (NB + 2) || r > last_row) return 0.0;
-        return sd <= NB ? band_at(ab, m, dir, r, sd) : g[dir == 0 ? r : m - 1 - r];
-    };
-    auto stash = [&](int buf, double v) { if (tid < SCH * (NB + 2)) L.stage[buf][srr][sd] = v; };
-    stash(0, fetch(0));
-    __syncthreads();
-    double neg = 0.0, tr = 0.0, q2 = 0.0;
-    int o = 0, jj = 0;
-    double *Lcol = nullptr, *ycol = nullptr;
-    // chunk by chunk: the next chunk's rows are requested, seven columns are eliminated, then the rows are parked in LDS --
-    // the loop nest (rather than a step counter) is what lets the compiler wait for the load only there
-    for (int chunk = 0; jj < ncols; ++chunk) {
-        const double pending = fetch(chunk + 1);
-        const int nst = min(SCH, ncols - jj);
-#pragma unroll 1
-        for (int cstep = 0; cstep < nst; ++cstep, ++jj) {
-            if (STORE) {
-                const int64_t col = (int64_t)(dir == 0 ? jj : n0 + jj);      // dir 1's columns follow dir 0's in the buffers
-                Lcol = Lbuf + (col + (int64_t)blockIdx.x * (n0 + n1)) * (NB + 1);
-                ycol = ybuf + col + (int64_t)blockIdx.x * (n0 + n1);
-            }
-            sweep_step<DERIV>(L, sl, o, neg, tr, q2, Lcol, ycol);
-            if ((tid >> 6) == 3) {      // the last wave: row jj + 33 enters (its slot held row jj - 31, long dead)
-                const int lane = tid & 63, pr = (o + NB + 1) & (SW - 1);
-                if (lane <= SYO) {
-                    const double v = L.stage[chunk & 1][cstep][lane];      // zero past the last row (fetch)
-                    L.W[pr * SWS + lane] = v + (lane == 0 && jj + NB + 1 <= last_row ? lam : 0.0);
-                    if (DERIV) L.dW[pr * SWS + lane] = lane == 0 && jj + NB + 1 <= last_row ? 1.0 : 0.0;
-                }
-            }
-            o = (o + 1) & (SW - 1);
-            lds_barrier();
-        }
-        stash((chunk + 1) & 1, pending);      // read again two barriers later at the earliest
-    }
-    // the block behind the eliminated columns: logical rows / columns ncols .. ncols + 31
-    double *wout = win + ((int64_t)blockIdx.x * 2 + dir) * SWIN;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int a = e >> 5, b = e & 31;
-        if (b <= a) {
-            const int pa = (o + a) & (SW - 1);
-            wout[e] = L.W[pa * SWS + (a - b)];
-            wout[NB * NB + e] = DERIV ? L.dW[pa * SWS + (a - b)] : 0.0;
-        }
-    }
-    if (tid < NB) {
-        const int pa = (o + tid) & (SW - 1);
-        wout[2 * NB * NB + tid] = L.W[pa * SWS + SYO];
-        wout[2 * NB * NB + NB + tid] = DERIV ? L.dW[pa * SWS + SYO] : 0.0;
-    }
-    if (tid == 128) {
-        double *r3 = res + ((int64_t)blockIdx.x * 2 + dir) * 4;
-        r3[0] = neg; r3[1] = tr; r3[2] = q2;
     }
 }
 
@@ -1811,6 +1810,7 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
     }
     MHS_HIP(hipMemsetAsync(ws.flags, 0, sizeof(int), s));
     hipEvent_t pending_rest = nullptr;
+    bool have_gram = false;      // the previous panel's strip kernel left this panel's partial Gram matrices in ws.Gp1
     for (int p = 0; p < npanels; ++p) {
         const int c = p * NB, t = m - c - NB, c0 = off0 + c, r0 = off0 + c + NB;
         double *Zc = ws.Zc[p & 1], *Vr = ws.Vr[p & 1], *Tp = ws.Tall + (size_t)p * PREC, *gp = g_dev + c + NB;
@@ -1818,7 +1818,7 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
         row_blocks(t, &cpb, &nblk);
         int nsg = nblk;
         if (t >= 64) {
-            hipLaunchKernelGGL(b32_gram_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1);
+            if (!have_gram) hipLaunchKernelGGL(b32_gram_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1);
             hipLaunchKernelGGL(b32_cholqr1_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp1, nblk, ws.Gp2, ws.R1, ws.Qtop, ws.flags);
             hipLaunchKernelGGL(b32_cholqr2_kernel, dim3(nblk), dim3(256), 0, s, A, ld, c0, r0, t, cpb, ws.Gp2, nblk, ws.Qtop, Zc, vs, Vr, ws.aux, Tp,
                                gp, ws.sgp, ws.flags);
@@ -1845,7 +1845,13 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
             MHS_HIP(hipEventRecord(ev_rest, s2));
             pending_rest = ev_rest;
         }
-        hipLaunchKernelGGL(b32_strip_kernel, dim3((t + 63) / 64), dim3(256), 0, s, A, ld, r0, t, Zc, vs);
+        have_gram = p + 1 < npanels && t - NB >= 64;      // the next panel takes the Cholesky route: its Gram matrix comes with the strip
+        if (have_gram) {
+            int cpb2, nblk2;
+            row_blocks(t - NB, &cpb2, &nblk2);
+            hipLaunchKernelGGL(b32_stripgram_kernel, dim3(nblk2), dim3(256), 0, s, A, ld, r0, t, Zc, vs, cpb2, ws.Gp1);
+        } else
+            hipLaunchKernelGGL(b32_strip_kernel, dim3((t + 63) / 64), dim3(256), 0, s, A, ld, r0, t, Zc, vs);
     }
     if (pending_rest) MHS_HIP(hipStreamWaitEvent(s, pending_rest, 0));
     hipLaunchKernelGGL(b32_extract_kernel, dim3((unsigned)((m * (NB + 1) + 255) / 256)), dim3(256), 0, s, A, ld, off0, m, ws.ab);
@@ -1913,55 +1919,79 @@ int Band32Search::pack() {
     return MHS_OK;
 }
 
-static bool sweep_four_waves() {      // MHS_B32_SWEEP4=1: the first version of the sweep (four waves per chain), kept for comparison
-    static const bool v = [] { const char *e = getenv("MHS_B32_SWEEP4"); return e && e[0] == '1'; }();
-    return v;
+// one batch on one stream: lambdas up, the two-directional sweep, the joining kernel, the terms down; `off` = the batch's first
+// slot in the per-lambda buffers (two batches may be in flight on two streams)
+int Band32Search::enqueue(hipStream_t st, int off, const double *lam, int nl, bool deriv) {
+    int mid, mb, n0, n1;
+    split_mid(m, &mid, &mb, &n0, &n1);
+    double *hl = pin + off, *hr = pin + B32_MAXLAM + (size_t)4 * off;
+    memcpy(hl, lam, sizeof(double) * nl);
+    double *dl = ws->lamd + off, *dwin = ws->win + (size_t)off * 2 * SWIN, *dres = ws->res + (size_t)off * 8, *dout = ws->out + (size_t)off * 4;
+    MHS_HIP(hipMemcpyAsync(dl, hl, sizeof(double) * nl, hipMemcpyHostToDevice, st));
+    if (deriv) {
+        hipLaunchKernelGGL((b32_sweep1_kernel<true, false>), dim3(nl, 2), dim3(64), 0, st, ws->abF, ws->abR, m, n0, n1, dl, dwin, dres,
+                           (double *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((b32_mid_kernel<true>), dim3(nl), dim3(256), 0, st, ab_dev, g_dev, m, mid, mb, dl, dwin, dres, dout);
+    } else {
+        hipLaunchKernelGGL((b32_sweep1_kernel<false, false>), dim3(nl, 2), dim3(64), 0, st, ws->abF, ws->abR, m, n0, n1, dl, dwin, dres,
+                           (double *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((b32_mid_kernel<false>), dim3(nl), dim3(256), 0, st, ab_dev, g_dev, m, mid, mb, dl, dwin, dres, dout);
+    }
+    MHS_HIP(hipGetLastError());
+    MHS_HIP(hipMemcpyAsync(hr, dout, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, st));
+    return MHS_OK;
+}
+void Band32Search::collect(int off, int nl, double *neg, double *tr, double *q2) const {
+    const double *hr = pin + B32_MAXLAM + (size_t)4 * off;
+    for (int i = 0; i < nl; ++i) {
+        if (neg) neg[i] = hr[4 * i];
+        if (tr) tr[i] = hr[4 * i + 1];
+        if (q2) q2[i] = hr[4 * i + 2];
+    }
+}
+void Band32Search::report(int off, int nl, bool deriv) const {
+    if (!getenv("MHS_FIT_TIMING")) return;
+    int mid, mb, n0, n1;
+    split_mid(m, &mid, &mb, &n0, &n1);
+    double r8[8];
+    if (hipMemcpy(r8, ws->res + (size_t)off * 8, sizeof(r8), hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[gcv32 m=%d] sweep of %d + %d columns, %d lambdas%s: %.0f cycles, %.1f us (100 MHz counter)\n", m, n0, n1, nl,
+            deriv ? " with derivative" : "", r8[3], r8[7] * 0.01);
 }
 
 int Band32Search::eval_batch(const double *lam, int count, bool deriv, double *neg, double *tr, double *q2) {
-    int mid, mb, n0, n1;
-    split_mid(m, &mid, &mb, &n0, &n1);
     if (int rc = pack()) return rc;
-    const bool four = sweep_four_waves();
     for (int base = 0; base < count; base += B32_MAXLAM) {
         const int nl = std::min(B32_MAXLAM, count - base);
-        double *hl = pin, *hr = pin + B32_MAXLAM;
-        memcpy(hl, lam + base, sizeof(double) * nl);
-        double *dl = ws->lamd;
-        MHS_HIP(hipMemcpyAsync(dl, hl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
-        if (deriv) {
-            if (four)
-                hipLaunchKernelGGL((b32_sweep_kernel<true, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
-                                   (double *)nullptr, (double *)nullptr);
-            else
-                hipLaunchKernelGGL((b32_sweep1_kernel<true, false>), dim3(nl, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res,
-                                   (double *)nullptr, (double *)nullptr);
-            hipLaunchKernelGGL((b32_mid_kernel<true>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
-        } else {
-            if (four)
-                hipLaunchKernelGGL((b32_sweep_kernel<false, false>), dim3(nl, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res,
-                                   (double *)nullptr, (double *)nullptr);
-            else
-                hipLaunchKernelGGL((b32_sweep1_kernel<false, false>), dim3(nl, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res,
-                                   (double *)nullptr, (double *)nullptr);
-            hipLaunchKernelGGL((b32_mid_kernel<false>), dim3(nl), dim3(256), 0, s, ab_dev, g_dev, m, mid, mb, dl, ws->win, ws->res, ws->out);
-        }
-        MHS_HIP(hipGetLastError());
-        MHS_HIP(hipMemcpyAsync(hr, ws->out, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, s));
+        const auto w0 = std::chrono::steady_clock::now();
+        if (int rc = enqueue(s, 0, lam + base, nl, deriv)) return rc;
         MHS_HIP(hipStreamSynchronize(s));
-        if (!four && getenv("MHS_FIT_TIMING")) {
-            double r8[8];
-            MHS_HIP(hipMemcpy(r8, ws->res, sizeof(r8), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[gcv32 m=%d] sweep of %d + %d columns, %d lambdas%s: %.0f cycles, %.1f us (100 MHz counter)\n", m, n0, n1, nl,
-                    deriv ? " with derivative" : "", r8[3], r8[7] * 0.01);
-        }
-        for (int i = 0; i < nl; ++i) {
-            if (neg) neg[base + i] = hr[4 * i];
-            if (tr) tr[base + i] = hr[4 * i + 1];
-            if (q2) q2[base + i] = hr[4 * i + 2];
-        }
+        if (getenv("MHS_FIT_TIMING"))
+            fprintf(stderr, "[gcv32 m=%d] round of %d lambdas: %.3f ms on the host clock\n", m, nl,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+        report(0, nl, deriv);
+        collect(0, nl, neg ? neg + base : nullptr, tr ? tr + base : nullptr, q2 ? q2 + base : nullptr);
         ++rounds;
     }
+    return MHS_OK;
+}
+
+// Two batches side by side: inertia counts for lamA (on s) and counts + tr M^-1 for lamB (on s_aux; on s when there is no
+// second stream).  A batch with derivatives needs 61 KB of LDS a chain -- two chains a compute unit -- so folding the
+// speculative bracket's 40 lambdas into a 380-lambda cut turned the whole round into a two-wave launch of the slower kernel.
+int Band32Search::eval_pair(const double *lamA, int nA, double *negA, const double *lamB, int nB, double *negB, double *trB) {
+    if (int rc = pack()) return rc;
+    if (nA > B32_PAIR_SPLIT || nB > B32_MAXLAM - B32_PAIR_SPLIT) { set_error("Band32Search::eval_pair: batch too large"); return MHS_ERR_INVALID; }
+    hipStream_t sb = s_aux ? s_aux : s;
+    if (int rc = enqueue(s, 0, lamA, nA, false)) return rc;
+    if (int rc = enqueue(sb, B32_PAIR_SPLIT, lamB, nB, true)) return rc;
+    MHS_HIP(hipStreamSynchronize(s));
+    if (sb != s) MHS_HIP(hipStreamSynchronize(sb));
+    report(0, nA, false);
+    report(B32_PAIR_SPLIT, nB, true);
+    collect(0, nA, negA, nullptr, nullptr);
+    collect(B32_PAIR_SPLIT, nB, negB, trB, nullptr);
+    ++rounds;
     return MHS_OK;
 }
 
@@ -1988,7 +2018,7 @@ void Band32Search::gcv_from_terms(double lam, double tr_inv, double qq, double *
 //     eigenvalues known to 1e-6: its 40 points only decide two integers, k1 and k2, and tr A moves by less than
 //     (tr A - 3) or (n - tr A) times the relative error of lambda -- decisions closer than 1e-3 to their threshold (or any
 //     other surprise) are redone with the final eigenvalues.
-static const int EIG_P[2] = {63, 255};      // a round whose bracket is within 256 x the tolerance takes the smallest of 15, 31, 63, 127, 255 points that finishes it
+static const int EIG_P[2] = {127, 255};      // a round whose bracket is within 256 x the tolerance takes the smallest of 15, 31, 63, 127, 255 points that finishes it
 static const int EIG_PMAX = 255;
 static const double EIG_TOL = 3e-10;      // lambda moves by about half the relative error of either end (they only place the grid)
 static const double EIG_SPEC = 1e-6;
@@ -2003,15 +2033,23 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
     };
     const int W = NB + 1;
     double dmax = ab_host[0], dmin = ab_host[0], ghi = ab_host[0], fro2 = 0.0, cmax2 = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double r = 0.0, c2 = 0.0;
-        for (int d = 1; d <= NB; ++d) {
-            if (j + d < m) { const double v = ab_host[(size_t)j * W + d]; r += fabs(v); c2 += v * v; fro2 += 2.0 * v * v; }
-            if (j - d >= 0) { const double v = ab_host[(size_t)(j - d) * W + d]; r += fabs(v); c2 += v * v; }
+    {   // one pass over the band: entry (j + d, j) counts for row j + d and, mirrored, for row j
+        std::vector<double> rs((size_t)m + NB + 1, 0.0), cs((size_t)m + NB + 1, 0.0);
+        for (int j = 0; j < m; ++j) {
+            const double *col = ab_host + (size_t)j * W;
+            double r = 0.0, c2 = 0.0;
+            for (int d = 1; d <= NB; ++d) {      // entries past the last row are stored as zeros
+                const double v = col[d], a = fabs(v), q = v * v;
+                r += a; c2 += q;
+                rs[(size_t)j + d] += a; cs[(size_t)j + d] += q;
+            }
+            rs[j] += r; cs[j] += c2;
+            fro2 += 2.0 * c2 + col[0] * col[0];
         }
-        const double a = ab_host[(size_t)j * W];
-        fro2 += a * a; c2 += a * a;
-        dmax = std::max(dmax, a); dmin = std::min(dmin, a); ghi = std::max(ghi, a + r); cmax2 = std::max(cmax2, c2);
+        for (int j = 0; j < m; ++j) {
+            const double a = ab_host[(size_t)j * W];
+            dmax = std::max(dmax, a); dmin = std::min(dmin, a); ghi = std::max(ghi, a + rs[j]); cmax2 = std::max(cmax2, cs[j] + a * a);
+        }
     }
     if (!(dmin > 0.0)) { set_error("mhs_tps_fit: the projected matrix has a non-positive diagonal entry"); return MHS_ERR_NUMERIC; }
     const double up = std::min(ghi, sqrt(fro2)) * (1.0 + 1e-9) + 1e-300, down = std::max(dmax, sqrt(cmax2) * (1.0 - 1e-9));
@@ -2056,7 +2094,7 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         }
         if (!live) break;
         std::vector<double> lamv;
-        std::vector<int> owner;      // >= 0: xs slot; -1 .. -4: the brackets' ends; <= -10: speculative bracket point -10 - q
+        std::vector<int> owner;      // >= 0: xs slot; -1 .. -4: the brackets' ends
         for (int e = 0; e < 2; ++e)
             if (!done[e]) for (int i = 0; i < np[e]; ++i) { lamv.push_back(-xs[e * EIG_PMAX + i]); owner.push_back(e * EIG_PMAX + i); }
         if (!ends_checked) {
@@ -2067,17 +2105,17 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
         if (spec_now) {
             spec_e[0] = 0.5 * (lo[0] + hi[0]); spec_e[1] = std::max(0.5 * (lo[1] + hi[1]), 1e-300);
             for (int q = 0; q < 20; ++q) { spec_lam[q] = spec_e[0] * pow(4.0, q); spec_lam[20 + q] = spec_e[1] / pow(4.0, q); }
-            for (int q = 0; q < 40; ++q) { lamv.push_back(spec_lam[q]); owner.push_back(-10 - q); }
         }
-        std::vector<double> cv(lamv.size()), tv(lamv.size());
-        if (int rc = eval_batch(lamv.data(), (int)lamv.size(), spec_now, cv.data(), spec_now ? tv.data() : nullptr, nullptr)) return rc;
+        std::vector<double> cv(lamv.size());
+        if (spec_now) {
+            if (int rc = eval_pair(lamv.data(), (int)lamv.size(), cv.data(), spec_lam, 40, spec_neg, spec_tr)) return rc;
+            spec_have = true;
+        } else if (int rc = eval_batch(lamv.data(), (int)lamv.size(), false, cv.data(), nullptr, nullptr)) return rc;
         double c4[4] = {0, 0, 0, 0};
         for (size_t q = 0; q < owner.size(); ++q) {
             if (owner[q] >= 0) cnt[owner[q]] = cv[q];
-            else if (owner[q] >= -4) c4[-1 - owner[q]] = cv[q];
-            else { spec_neg[-10 - owner[q]] = cv[q]; spec_tr[-10 - owner[q]] = tv[q]; }
+            else c4[-1 - owner[q]] = cv[q];
         }
-        if (spec_now) spec_have = true;
         bool redo[2] = {false, false};
         if (!ends_checked) {      // the ends themselves: count(lo) must not exceed k, count(hi) must
             ends_checked = true;
@@ -2095,6 +2133,9 @@ int Band32Search::find_lambda(int mode, double *lam_out) {
             }
             lo[e] = nlo; hi[e] = nhi;
         }
+        if (timing)
+            fprintf(stderr, "[gcv32 m=%d] cut %d: %d + %d points, relative widths now %.2e (largest) %.2e (smallest)\n", m, it, done[0] ? 0 : np[0],
+                    done[1] ? 0 : np[1], relw(0), relw(1));
     }
     const double emax = 0.5 * (lo[0] + hi[0]), emin = std::max(0.5 * (lo[1] + hi[1]), 1e-300);
     lap("extreme eigenvalues");
@@ -2277,10 +2318,7 @@ int Band32Search::solve(double lam, double *gcv, double *eff_df, double *q_host)
     pin[0] = lam;
     MHS_HIP(hipMemcpyAsync(dl, pin, sizeof(double), hipMemcpyHostToDevice, s));
     if (int rc = pack()) return rc;
-    if (sweep_four_waves())
-        hipLaunchKernelGGL((b32_sweep_kernel<true, true>), dim3(1, 2), dim3(256), 0, s, ab_dev, g_dev, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
-    else
-        hipLaunchKernelGGL((b32_sweep1_kernel<true, true>), dim3(1, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
+    hipLaunchKernelGGL((b32_sweep1_kernel<true, true>), dim3(1, 2), dim3(64), 0, s, ws->abF, ws->abR, m, n0, n1, dl, ws->win, ws->res, ws->Lbuf, ws->ybuf);
     MHS_HIP(hipGetLastError());
     std::vector<double> Lh((size_t)(n0 + n1) * W + 1), yh((size_t)(n0 + n1) + 1), wh(2 * SWIN), rh(8);
     MHS_HIP(hipMemcpyAsync(Lh.data(), ws->Lbuf, sizeof(double) * (size_t)(n0 + n1) * W, hipMemcpyDeviceToHost, s));

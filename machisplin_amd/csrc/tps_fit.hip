@@ -2244,7 +2244,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 else (void)hipGetLastError();
             }
             Band32Search bs;
-            bs.s = s; bs.ab_dev = w32.ab; bs.g_dev = gbuf.p; bs.ab_host = ab32.data(); bs.g_host = g.data(); bs.m = m; bs.n = n; bs.N = N;
+            bs.s = s; bs.s_aux = confined ? L.ms2 : L.s2; bs.ab_dev = w32.ab; bs.g_dev = gbuf.p; bs.ab_host = ab32.data(); bs.g_host = g.data(); bs.m = m; bs.n = n; bs.N = N;
             bs.pure_ss = pure_ss; bs.ws = &w32; bs.pin = pin;
             if (int rc = bs.find_lambda(gcv_mode, &lam)) return rc;
             if (std::isnan(lam)) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
