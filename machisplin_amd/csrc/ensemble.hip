@@ -1300,6 +1300,7 @@ constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a term
 // LDS accesses by 32-bit byte address (the walk's node addresses come out of LDS data, so no pointer
 // arithmetic may be attached to them); the kernel's dynamic LDS starts at address 0 (no static LDS)
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2v lds_u2(unsigned a) { return *(__attribute__((address_space(3))) const uint2v *)(uintptr_t)a; }
 __device__ __forceinline__ unsigned lds_u32(unsigned a) { return *(__attribute__((address_space(3))) const unsigned *)(uintptr_t)a; }
 __device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
@@ -1856,6 +1857,147 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
                 if (e < cnt2) *(uint2 *)(smem + (unsigned)SLOT2 * STRIDE + (unsigned)e * 8u) = pn[q];
             }
             lds_signal(CNT + 4u * SLOT2);
+        }
+    };
+    for (int t = 0; t < n_trees; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, t + 2);
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        if (live[c])
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+
+// LOADER-WAVE form (round 4).  Round 3's ablation of the kernel above: of 64.6 ms (8 000 x 8 000 cells, 500 trees) the walks are 23
+// and the "bare tree loop" 25 -- every one of the 16 waves spends ~260 instructions per tree on its share of the staging (eight
+// address computations, PF predicated global loads, PF predicated LDS stores, two counter polls).  Here ONE wave of the block
+// does nothing but stage: tree u travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers,
+// no ds_write; M0 reaches all 160 KB and the data is in LDS at the issuing wave's vmcnt(0) -- tools/micro/lds_dma_range.hip),
+// ~25 instructions per tree on one wave instead of ~40 on each of sixteen.  The other 15 waves (960 lanes x R cells) only walk:
+// per tree one readlane of the prefix entry, three scalar loads, a poll that is skipped while the loader is known to be ahead
+// (the three staged counters come in one ds_read_b96 and their sum is the number of trees parked), the hand-scheduled level
+// loop, one ds_add, R prediction loads.  Same buffers, same counters, same records and the same order of additions as
+// rf_walk_tb_kernel: identical planes.  The records' array carries 1 KB of padding behind the last tree (build_rf_nodes_t) for
+// the last chunk's over-read.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+}
+constexpr int RF_LD_WALKERS = 15;                                   // walking waves per block; wave 15 is the loader
+
+template <int LOG2R, bool K64, int STRIDE>
+__global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restrict__ gnodes,
+                                                          const double *__restrict__ glval,
+                                                          const int *__restrict__ tree_off,
+                                                          const int *__restrict__ depth,
+                                                          const void *__restrict__ sorted,
+                                                          const int *__restrict__ sorted_off, int n_trees,
+                                                          int p, StackDev s, PredGeom g,
+                                                          double weight, int accumulate,
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
+    constexpr int R = rf_walks(LOG2R);
+    constexpr unsigned TREE_BYTES = 3u * STRIDE;
+    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
+    constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
+    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
+    const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const bool loader = threadIdx.x >= 64 * RF_LD_WALKERS;          // wave-uniform
+    // the loader's lanes shadow the block's first wave (they take part in the cooperative rank search and emit nothing)
+    const int64_t i0 = (int64_t)blockIdx.x * (64 * RF_LD_WALKERS) + (loader ? threadIdx.x - 64 * RF_LD_WALKERS : threadIdx.x);
+    int row[R], col[R];
+    bool na[R], live[R];
+    double acc[R], pending[R];
+    rf_lane_cells<R>(g, i0, strips, row, col, live);
+#pragma unroll
+    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    unsigned entry[RF_ENTRY_BATCHES];
+#pragma unroll
+    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
+    if (!loader && prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES)
+        rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
+    __syncthreads();                                               // coarse table no longer needed
+    if (threadIdx.x < 8) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = 0u;
+    __syncthreads();
+    if (loader) {
+        const unsigned lane16 = (threadIdx.x & 63u) * 16u;
+        for (int u = 0; u < n_trees; ++u) {
+            const unsigned slot = (unsigned)u % 3u;
+            const int o = tree_off[u], cnt = tree_off[u + 1] - o;
+            if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)RF_LD_WALKERS * (unsigned)(u / 3));   // every walker has left tree u - 3
+            const char *src = (const char *)(gnodes + o) + lane16;
+            const unsigned dst = slot * (unsigned)STRIDE;
+            const int chunks = (cnt + 127) >> 7;                    // 128 records = 1 KB per instruction
+            for (int q = 0; q < chunks; ++q)
+                glds16(src + (size_t)q * 1024u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)q * 1024u)));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_signal(CNT + 4u * slot);
+        }
+        return;
+    }
+    unsigned ecur = 0u, parked = 0u;                               // parked: trees 0 .. parked - 1 are known to be in LDS
+    auto step = [&](auto slot_tag, const int t) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        if ((t & 63) == 0) {
+            ecur = 0u;
+#pragma unroll
+            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
+        }
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
+        const int plen = (int)((ent >> 16) & 0x7FFFu);
+        const int o = tree_off[t], levels = (ent >> 31) ? 0 : depth[t] - plen, shallow = max((dmin ? dmin[t] : depth[t]) - plen, 0);
+        // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
+        // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
+        if (parked <= (unsigned)t)
+            for (;;) {
+                uint4v cv;                                                   // staged[0..2] and the zero word behind them
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
+                parked = (unsigned)__builtin_amdgcn_readfirstlane((int)(cv.x + cv.y + cv.z));
+                if (parked > (unsigned)t) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        unsigned node[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = (ent & 0xFFFFu) << 3;
+        if constexpr (R == 4) {
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
+                asm volatile(
+#include "rf_walk_loop4xo.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
+                      "v115", "v116", "v117", "v118", "v120");
+        } else {
+            static_assert(R == 5, "hand loops exist for four and five walks");
+            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
+            if (levels > 0)
+                asm volatile(
+#include "rf_walk_loop5xo.inc"
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
+                      [c0] "+s"(c0)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
+                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
+        }
+        lds_signal(CNT + 16u + 4u * SLOT);                               // this wave has left tree t
+        const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            pending[c] = *(const double *)(lv + node[c]);
         }
     };
     for (int t = 0; t < n_trees; t += 3) {
@@ -2601,7 +2743,7 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     sort_unique(sorted, off, flat);
     for (int v = 0; v < m->p; ++v)
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
-    std::vector<unsigned long long> rec(nn ? nn : 1, 0ull);
+    std::vector<unsigned long long> rec((nn ? nn : 1) + 128, 0ull);      // + 1 KB: rf_walk_ld_kernel's last LDS-DMA chunk reads past the last tree
     const unsigned R = (unsigned)rf_walks(log2r);
     if (form == RF_COMPACT) {
         // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
@@ -2688,10 +2830,13 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
         const int R = rf_walks(tb_l2);
         const int strips = rf_strips(g, R);
-        const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
+        const bool ld = !getenv("MHS_RF_NO_LOADER");               // one staging wave + 15 walking waves (rf_walk_ld_kernel)
+        const int64_t per_block = ld ? 64 * RF_LD_WALKERS : 1024;
+        const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
         const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
         const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-#define MHS_TB(L2, ST) (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>)
+#define MHS_TB(L2, ST) (ld ? (key64 ? rf_walk_ld_kernel<L2, true, ST> : rf_walk_ld_kernel<L2, false, ST>) \
+                           : (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>))
         auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
                 : tb_stride == 24576 ? (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576))
                                      : MHS_TB(2, 25600);

@@ -411,6 +411,8 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
                  {"MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_NO_PREFIX": "1", "MHS_RF_FOUR_WALKS": "1"},
                  {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
+                 {"MHS_RF_NO_LOADER": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_NO_PREFIX": "1"},
+                 {"MHS_RF_NO_LOADER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
