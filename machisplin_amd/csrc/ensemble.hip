@@ -1874,21 +1874,22 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 
 // LOADER-WAVE form (round 4).  Round 3's ablation of the kernel above: of 64.6 ms (8 000 x 8 000 cells, 500 trees) the walks are 23
 // and the "bare tree loop" 25 -- every one of the 16 waves spends ~260 instructions per tree on its share of the staging (eight
-// address computations, PF predicated global loads, PF predicated LDS stores, two counter polls).  Here ONE wave of the block
-// does nothing but stage: tree u travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers,
-// no ds_write; M0 reaches all 160 KB and the data is in LDS at the issuing wave's vmcnt(0) -- tools/micro/lds_dma_range.hip),
-// ~25 instructions per tree on one wave instead of ~40 on each of sixteen.  The other 15 waves (960 lanes x R cells) only walk:
-// per tree one readlane of the prefix entry, three scalar loads, a poll that is skipped while the loader is known to be ahead
-// (the three staged counters come in one ds_read_b96 and their sum is the number of trees parked), the hand-scheduled level
-// loop, one ds_add, R prediction loads.  Same buffers, same counters, same records and the same order of additions as
-// rf_walk_tb_kernel: identical planes.  The records' array carries 1 KB of padding behind the last tree (build_rf_nodes_t) for
-// the last chunk's over-read.
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
-}
-constexpr int RF_LD_WALKERS = 15;                                   // walking waves per block; wave 15 is the loader
+// address computations, PF predicated global loads, PF predicated LDS stores, two counter polls).  Here NL waves of the block
+// (the last ones) do nothing but stage, tree u being loader u % NL's; the other 16 - NL waves (x 64 lanes x R cells) only walk.
+// A loader's REGISTERS are the fourth buffer: it requests its next tree (STRIDE bytes = PF x 16 bytes per lane, all in flight,
+// straight-line code) as soon as it has written the previous one to LDS, and the records wait in registers until every walker
+// has left the buffer's previous tree.  A walker's step: four readlanes (prefix entry, first record, depth, shallowest leaf --
+// the scalars of 64 trees come in one vector load each), a poll that is skipped while the buffer's cached counter says the tree
+// is parked (the three staged counters come in one ds_read_b128), the hand-scheduled level loop, one ds_add, R prediction
+// loads that are consumed TWO trees later.  Same buffers, counters, records and order of additions as rf_walk_tb_kernel:
+// identical planes.  The records' array carries STRIDE bytes of padding behind the last tree for the loaders' over-read.
+// Measured on the way (profiles/r04_forest_variants.txt): staging by LDS-DMA (global_load_lds_dwordx4, M0 reaches all 160 KB, data
+// visible at the issuer's vmcnt(0): tools/micro/lds_dma_range.hip) runs at the DMA path's own cadence, 1.5 us per 24.8 KB tree
+// whatever is in flight and even from L2 -- no faster than one register loader (1.35 us, bound by one load round trip per tree).
+// bits of `flags` beside RF_LD_PREFIX: timing experiments (MHS_RF_LD_FLAGS; 2 / 4 / 8 / 32 give wrong planes)
+enum { RF_LD_PREFIX = 1, RF_LD_ABLATE_WALKS = 2, RF_LD_ABLATE_STAGING = 4, RF_LD_ABLATE_PRED = 8, RF_LD_FEW_TREES = 32, RF_LD_SETUP_ONLY = 128 };
 
-template <int LOG2R, bool K64, int STRIDE>
+template <int LOG2R, bool K64, int STRIDE, int NL>
 __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restrict__ gnodes,
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
@@ -1897,8 +1898,8 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
-    constexpr int R = rf_walks(LOG2R);
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int flags) {
+    constexpr int R = rf_walks(LOG2R), WALKERS = 16 - NL;
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
     static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
     constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
@@ -1907,15 +1908,31 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
     const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const bool loader = threadIdx.x >= 64 * RF_LD_WALKERS;          // wave-uniform
-    // the loader's lanes shadow the block's first wave (they take part in the cooperative rank search and emit nothing)
-    const int64_t i0 = (int64_t)blockIdx.x * (64 * RF_LD_WALKERS) + (loader ? threadIdx.x - 64 * RF_LD_WALKERS : threadIdx.x);
+    const bool loader = threadIdx.x >= 64 * WALKERS;               // wave-uniform
+    // the loaders' lanes shadow the block's first waves (they take part in the cooperative rank search and emit nothing)
+    const int64_t i0 = (int64_t)blockIdx.x * (64 * WALKERS) + (loader ? threadIdx.x - 64 * WALKERS : threadIdx.x);
     int row[R], col[R];
     bool na[R], live[R];
-    double acc[R], pending[R];
+    if (strips == 2) {
+        // COMPACT wave tiles: 16 columns x 4 R rows (lane = column + 16 x row group, a lane's R walks on adjacent rows) instead of
+        // 64 columns x R rows -- on smooth rasters the wave's predictor ranges are narrower, its prefix longer and its deepest
+        // leaf nearer (CPU study tools/r04_rf_slice_sim.py: 3.6 -> 1.8 levels walked per wave and tree on the 8d planes)
+        const int wave = (int)(threadIdx.x >> 6), lane_ = (int)(threadIdx.x & 63u);
+        const int64_t tile = (int64_t)blockIdx.x * WALKERS + (loader ? wave - WALKERS : wave);
+        const int tiles_x = (g.nc + 15) / 16;
+        const int64_t ty = tile / tiles_x;
+        const int tx = (int)(tile - ty * tiles_x);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int64_t r = ty * (4 * R) + (lane_ >> 4) * R + c;
+            const int cc = tx * 16 + (lane_ & 15);
+            live[c] = r < g.nr && cc < g.nc;
+            row[c] = (int)min(r, (int64_t)g.nr - 1); col[c] = min(cc, g.nc - 1);
+        }
+    } else
     rf_lane_cells<R>(g, i0, strips, row, col, live);
 #pragma unroll
-    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
+    for (int c = 0; c < R; ++c) na[c] = false;
     for (int j = 0; j < p; ++j) {
         float r[R];
         if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
@@ -1926,47 +1943,77 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     unsigned entry[RF_ENTRY_BATCHES];
 #pragma unroll
     for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (!loader && prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES)
+    // (measured and not kept, profiles/r04_forest_variants.txt: the chains of eight batches interleaved -- finished chains re-read,
+    // 6.1 -> 8.5 ms of 48 on 8 000 x 8 000 cells --; the upper levels descended once per block with the block's ranges and each
+    // wave continuing from there: 6.7 ms.  The prefix is bound by the gather rate of its lane = tree record loads.)
+    if (!loader && (flags & RF_LD_PREFIX) && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES)
         rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
     __syncthreads();                                               // coarse table no longer needed
     if (threadIdx.x < 8) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = 0u;
     __syncthreads();
     if (loader) {
+        constexpr int PF = (STRIDE + 1023) / 1024;                  // 16-byte pieces per lane and tree
+        static_assert(PF <= 25, "one named register quad per piece below");
         const unsigned lane16 = (threadIdx.x & 63u) * 16u;
-        for (int u = 0; u < n_trees; ++u) {
+        const int first = (int)(threadIdx.x >> 6) - WALKERS;         // this loader's trees: first, first + NL, ...
+        // named quads, not an array: hipcc keeps a 25 x 16-byte array in scratch memory; always PF pieces, straight-line: under
+        // `piece < pieces of this tree` it waits vmcnt(0) between the loads
+        uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, r19, r20, r21, r22, r23, r24;
+        const char *src = nullptr;
+#define MHS_RF_ALL(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) \
+                      F(21) F(22) F(23) F(24)
+#define MHS_RF_LOAD(Q) if constexpr (Q < PF) r##Q = *(const uint4 *)(src + (size_t)Q * 1024u);
+#define MHS_RF_STORE(Q) if constexpr (Q < PF) *(uint4 *)(smem + slot * (unsigned)STRIDE + (unsigned)Q * 1024u + lane16) = r##Q;
+#define MHS_RF_REQUEST(U) { \
+            src = (const char *)(gnodes + tree_off[(flags & RF_LD_FEW_TREES) ? (U) & 7 : (U)]) + lane16; \
+            if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_LOAD) } }
+        if (flags & RF_LD_SETUP_ONLY) return;
+        if (first < n_trees) MHS_RF_REQUEST(first)
+        for (int u = first; u < n_trees; u += NL) {
             const unsigned slot = (unsigned)u % 3u;
-            const int o = tree_off[u], cnt = tree_off[u + 1] - o;
-            if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)RF_LD_WALKERS * (unsigned)(u / 3));   // every walker has left tree u - 3
-            const char *src = (const char *)(gnodes + o) + lane16;
-            const unsigned dst = slot * (unsigned)STRIDE;
-            const int chunks = (cnt + 127) >> 7;                    // 128 records = 1 KB per instruction
-            for (int q = 0; q < chunks; ++q)
-                glds16(src + (size_t)q * 1024u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)q * 1024u)));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_signal(CNT + 4u * slot);
+            if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)(u / 3));   // every walker has left tree u - 3
+            if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_STORE) }
+            lds_signal(CNT + 4u * slot);                             // the LDS unit executes a wave's operations in order
+            if (u + NL < n_trees) MHS_RF_REQUEST(u + NL)
         }
+#undef MHS_RF_REQUEST
+#undef MHS_RF_STORE
+#undef MHS_RF_LOAD
+#undef MHS_RF_ALL
         return;
     }
-    unsigned ecur = 0u, parked = 0u;                               // parked: trees 0 .. parked - 1 are known to be in LDS
+    if (flags & RF_LD_SETUP_ONLY) return;
+    double acc[R], pend[3][R];                                     // pend[b]: predictions of the last tree walked in buffer b
+#pragma unroll
+    for (int c = 0; c < R; ++c) { acc[c] = 0.0; pend[0][c] = 0.0; pend[1][c] = 0.0; pend[2][c] = 0.0; }
+    unsigned ecur = 0u;
+    unsigned staged[3] = {0u, 0u, 0u};                             // cached counters: buffer b has held staged[b] trees so far
+    int ocur = 0, dcur = 0, mcur = 0;                              // lane l: first record, depth and shallowest leaf of tree 64 b + l
+    const int lane = threadIdx.x & 63;
     auto step = [&](auto slot_tag, const int t) {
         constexpr int SLOT = decltype(slot_tag)::value;
-        if ((t & 63) == 0) {
-            ecur = 0u;
+        if ((t & 63) == 0) {                                             // the next 64 trees' scalars: one vector load each instead of
+            ecur = 0u;                                                   // three scalar loads (and their waits) per tree
 #pragma unroll
             for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
+            const int tl = min(t + lane, n_trees - 1);
+            ocur = tree_off[tl]; dcur = depth[tl]; mcur = dmin ? dmin[tl] : dcur;
         }
         const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
         const int plen = (int)((ent >> 16) & 0x7FFFu);
-        const int o = tree_off[t], levels = (ent >> 31) ? 0 : depth[t] - plen, shallow = max((dmin ? dmin[t] : depth[t]) - plen, 0);
+        const int o = __builtin_amdgcn_readlane(ocur, t & 63), dep = __builtin_amdgcn_readlane(dcur, t & 63), dmn = __builtin_amdgcn_readlane(mcur, t & 63);
+        const int levels = ((ent >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dep - plen, shallow = max(dmn - plen, 0);
         // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
         // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
-        if (parked <= (unsigned)t)
+        if (staged[SLOT] <= (unsigned)(t / 3))
             for (;;) {
                 uint4v cv;                                                   // staged[0..2] and the zero word behind them
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
-                parked = (unsigned)__builtin_amdgcn_readfirstlane((int)(cv.x + cv.y + cv.z));
-                if (parked > (unsigned)t) break;
-                __builtin_amdgcn_s_sleep(2);
+                staged[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.x);
+                staged[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.y);
+                staged[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.z);
+                if (staged[SLOT] > (unsigned)(t / 3)) break;
+                __builtin_amdgcn_s_sleep(1);
             }
         unsigned node[R];
 #pragma unroll
@@ -1981,23 +2028,24 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
                       "v115", "v116", "v117", "v118", "v120");
         } else {
-            static_assert(R == 5, "hand loops exist for four and five walks");
+            static_assert(R == 4 || R == 5, "hand loops exist for four and five walks");
             int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
             if (levels > 0)
                 asm volatile(
 #include "rf_walk_loop5xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
+                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[R - 1]), [cnt] "+s"(cnt),
                       [c0] "+s"(c0)
                     : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
         }
-        lds_signal(CNT + 16u + 4u * SLOT);                               // this wave has left tree t
+        // this wave has left tree t: lane 0 adds 1 (every lane is active here: no branch around the ds_add)
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(CNT + 16u + 4u * SLOT), "v"(1u) : "memory");
         const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
 #pragma unroll
         for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = *(const double *)(lv + node[c]);
+            acc[c] = acc[c] + pend[(SLOT + 1) % 3][c];                   // tree t - 2's, requested two steps ago; still in tree order
+            if (!(flags & RF_LD_ABLATE_PRED)) pend[SLOT][c] = *(const double *)(lv + node[c]);
         }
     };
     for (int t = 0; t < n_trees; t += 3) {
@@ -2007,7 +2055,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
+        acc[c] = (acc[c] + pend[(n_trees + 1) % 3][c]) + pend[(n_trees + 2) % 3][c];   // trees n - 2 and n - 1
         if (live[c])
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }
@@ -2743,7 +2791,7 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     sort_unique(sorted, off, flat);
     for (int v = 0; v < m->p; ++v)
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
-    std::vector<unsigned long long> rec((nn ? nn : 1) + 128, 0ull);      // + 1 KB: rf_walk_ld_kernel's last LDS-DMA chunk reads past the last tree
+    std::vector<unsigned long long> rec((nn ? nn : 1) + 3200, 0ull);     // + 25 600 bytes: rf_walk_ld_kernel's loaders read whole strides
     const unsigned R = (unsigned)rf_walks(log2r);
     if (form == RF_COMPACT) {
         // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
@@ -2830,12 +2878,16 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
         const int R = rf_walks(tb_l2);
         const int strips = rf_strips(g, R);
-        const bool ld = !getenv("MHS_RF_NO_LOADER");               // one staging wave + 15 walking waves (rf_walk_ld_kernel)
-        const int64_t per_block = ld ? 64 * RF_LD_WALKERS : 1024;
-        const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
+        const bool ld = !getenv("MHS_RF_NO_LOADER");               // staging waves + walking waves (rf_walk_ld_kernel)
+        const bool ld1 = ld && !getenv("MHS_RF_TWO_LOADERS");
+        const int64_t per_block = ld ? 64 * (ld1 ? 15 : 14) : 1024;
+        unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
+        const bool tiles16 = ld && strips && !getenv("MHS_RF_STRIP_WAVES");     // 16 x 4R-cell wave tiles (default) or 64 x R strips
+        if (tiles16) blocks = (unsigned)((((int64_t)(g.nc + 15) / 16) * ((g.nr + 4 * R - 1) / (4 * R)) + per_block / 64 - 1) / (per_block / 64));
         const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
         const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-#define MHS_TB(L2, ST) (ld ? (key64 ? rf_walk_ld_kernel<L2, true, ST> : rf_walk_ld_kernel<L2, false, ST>) \
+#define MHS_TB(L2, ST) (ld1 ? (key64 ? rf_walk_ld_kernel<L2, true, ST, 1> : rf_walk_ld_kernel<L2, false, ST, 1>) \
+                      : ld ? (key64 ? rf_walk_ld_kernel<L2, true, ST, 2> : rf_walk_ld_kernel<L2, false, ST, 2>) \
                            : (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>))
         auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
                 : tb_stride == 24576 ? (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576))
@@ -2843,8 +2895,8 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
 #undef MHS_TB
         MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
         hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips,
-                           strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles16 ? 2 : strips,
+                           (int)(strips && dmin && !getenv("MHS_RF_NO_PREFIX")) | (ld && getenv("MHS_RF_LD_FLAGS") ? atoi(getenv("MHS_RF_LD_FLAGS")) & ~1 : 0));
         return MHS_OK;
     }
     if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane

@@ -34,6 +34,8 @@ def planes_at(rows, cols, noise=0.0, noise_seed=0):
 
 def main():
     n_waves = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    TW = int(sys.argv[2]) if len(sys.argv) > 2 else 64          # wave tile: TW columns x TH rows (TW x TH = 256 cells)
+    TH = 256 // TW
     geom = synth.grid(SIDE, SIDE)
     xy, rows, cols, uv = synth.stations(geom, N, SEED)
     cov = np.column_stack(planes_at(rows, cols))
@@ -64,11 +66,11 @@ def main():
     for name, noise in (("8d planes", 0.0), ("8d + 1% noise", 0.01), ("8d + 10% noise", 0.1), ("bundled", None)):
         if noise is None and bundled is None:
             continue
-        sizes, rest, terminal = [], [], 0
+        sizes, rest, terminal, plens = [], [], 0, []
         for w in range(n_waves):
-            r0 = int(rng.integers(0, SIDE // 4)) * 4
-            c0 = int(rng.integers(0, SIDE // 64)) * 64
-            rr, cc = np.meshgrid(np.arange(r0, r0 + 4), np.arange(c0, c0 + 64), indexing="ij")
+            r0 = int(rng.integers(0, SIDE // TH)) * TH
+            c0 = int(rng.integers(0, SIDE // TW)) * TW
+            rr, cc = np.meshgrid(np.arange(r0, r0 + TH), np.arange(c0, c0 + TW), indexing="ij")
             if noise is None:
                 arrs = [k for k in bundled.keys() if bundled[k].ndim == 2][:2]
                 pl = []
@@ -88,14 +90,16 @@ def main():
             for t in range(nt):
                 o = off[t]
                 k = o
+                pl = 0
                 while not term[k]:
                     v, s = var[k], thr[k]
                     if mx[v] <= s:
-                        k = o + left[k]
+                        k = o + left[k]; pl += 1
                     elif mn[v] > s:
-                        k = o + right[k]
+                        k = o + right[k]; pl += 1
                     else:
                         break
+                plens.append(pl)
                 if term[k]:
                     terminal += 1
                     continue
@@ -115,6 +119,7 @@ def main():
         sizes, rest = np.array(sizes), np.array(rest)
         tot = n_waves * nt
         q = np.percentile(sizes, [50, 75, 90, 95, 99]) if sizes.size else []
+        print(f"tile {TW} x {TH}: prefix levels mean {np.mean(plens):.2f}; levels walked per (wave, tree) incl. skipped trees {rest.sum() / tot:.2f}")
         print(f"{name:16s}: terminal at the prefix {100 * terminal / tot:5.1f} %; subtree nodes mean {sizes.mean():7.1f} median/75/90/95/99 {q};"
               f"  <=32: {100 * (sizes <= 32).mean():.1f} %  <=64: {100 * (sizes <= 64).mean():.1f} %  <=128: {100 * (sizes <= 128).mean():.1f} %"
               f"  <=256: {100 * (sizes <= 256).mean():.1f} %;  levels left mean {rest.mean():.2f} max {rest.max()};"
