@@ -280,7 +280,7 @@ class Workload:
                 levels = full * min(1.0, walked_share)
                 cyc = band_cells * levels / 64.0 * 4.0
                 tb = not big and int(np.diff(prm["tree_offsets"]).max()) * 8 <= 25600      # rf_walk_tb_config (ensemble.hip)
-                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_tb_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
+                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_ld_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
                              "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
                              "work": "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "
                                      "%.0f levels/cell walked (a wave of neighbouring cells starts a tree where its cells part ways and leaves it at its deepest leaf; "
@@ -308,7 +308,7 @@ class Workload:
                     pmc_t[kn.split("::")[-1].split("<")[0]] = d["fetch_bytes_per_cell_x2_corrected"] + d["write_bytes_per_cell"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass
-        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("gbm", "gbm_coherent_kernel"), ("rf", "rf_walk_db_kernel"), ("rf", "rf_walk_tb_kernel"), ("svr", "svr_kernel"), ("svr", "svr_rt_kernel")):
+        for kind, kn in (("gbm", "gbm_lutreg_rt_kernel"), ("gbm", "gbm_coherent_kernel"), ("rf", "rf_walk_db_kernel"), ("rf", "rf_walk_tb_kernel"), ("rf", "rf_walk_ld_kernel"), ("svr", "svr_kernel"), ("svr", "svr_rt_kernel")):
             if "hbm_bytes_per_cell_fetch_x2_plus_write" in pmc.get(kind, {}):      # round 3's passes (fresh output plane: no RMW read)
                 pmc_t[kn] = pmc[kind]["hbm_bytes_per_cell_fetch_x2_plus_write"]
         for r in rows:

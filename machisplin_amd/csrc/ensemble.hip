@@ -3547,6 +3547,11 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         if (small(models[0])) while (first_end < n_models && small(models[first_end]) && models[first_end]->kind > models[first_end - 1]->kind) ++first_end;
         if (small(models[last_start])) while (last_start > first_end && small(models[last_start - 1]) && models[last_start - 1]->kind < models[last_start]->kind) --last_start;
         const size_t need = (size_t)nr * covars->ld * esz * (size_t)covars->n_layers + (size_t)nr * nc * sizeof(double) + 512;
+        // Round 4: every member before the last group runs on the UPLOAD bands (no whole-window middle group): the coherent gbm
+        // kernel (40 ms per 1e8 cells) is as short as the upload of three float64 planes (43 ms at 56 GB/s), so with gbm alone on
+        // the upload bands the last band's gbm ran after the last upload, fully exposed (+22 ms on cfg3); the forest's bands
+        // cover it.  A banded launch costs the partly filled last round of its blocks, < 1 ms per band and member.
+        if (last_start > first_end && !getenv("MHS_HOST_MIDDLE_GROUP")) first_end = last_start;
         if (last_start >= first_end && need <= ((size_t)96 << 30))
             return host_window_pipeline(models, weights, n_models, first_end, last_start, wt_total, g, covars, r0, r1, c0, c1, out_host);
     }

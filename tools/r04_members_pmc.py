@@ -92,6 +92,7 @@ for prm in params:
                 d[L[kk]] = d[R[kk]] = d[kk] + 1
             total += int(d.max())
         units["rf"] = float(total)
+        units["rf_trees"] = float(len(off) - 1)
 import json
 os.makedirs(outdir, exist_ok=True)
 with open(os.path.join(outdir, "units.json"), "w") as f:

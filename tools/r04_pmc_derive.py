@@ -40,7 +40,12 @@ for k, d in S.items():
         r["salu_per_cell_unit"] = v["SQ_INSTS_SALU"] / per
         r["unit"] = {"gbm": "tree", "rf": "tree level (full depth)", "svr": "support vector", "small": "cell (gam + nnet + earth)"}[kind]
     if kind == "rf":      # two LDS instructions per walk and level walked (node record, key): the levels the waves really descended
-        r["levels_walked_per_cell"] = v["SQ_INSTS_LDS"] * 64.0 / cells / 2.0
+        staging = 0.0
+        if "rf_walk_ld" in k:   # the loader wave's ds_write_b128 (25 per tree and block of 15 wave tiles of 16 x 16 cells) + its counter add and poll
+            blocks = -(-((side + 15) // 16) * ((side + 15) // 16) // 15)
+            staging = blocks * float(U.get("rf_trees", 500.0)) * 27.0
+            r["lds_staging_wave_instructions"] = staging
+        r["levels_walked_per_cell"] = (v["SQ_INSTS_LDS"] - staging) * 64.0 / cells / 2.0
         r["levels_full_depth_per_cell"] = units["rf"]
     out[k] = r
 json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_members_pmc_derived.json"), "w"), indent=1)
