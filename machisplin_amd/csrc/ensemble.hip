@@ -1881,13 +1881,16 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 // has left the buffer's previous tree.  A walker's step: four readlanes (prefix entry, first record, depth, shallowest leaf --
 // the scalars of 64 trees come in one vector load each), a poll that is skipped while the buffer's cached counter says the tree
 // is parked (the three staged counters come in one ds_read_b128), the hand-scheduled level loop, one ds_add, R prediction
-// loads that are consumed TWO trees later.  Same buffers, counters, records and order of additions as rf_walk_tb_kernel:
+// loads that are consumed FIVE trees later.  Same buffers, counters, records and order of additions as rf_walk_tb_kernel:
 // identical planes.  The records' array carries STRIDE bytes of padding behind the last tree for the loaders' over-read.
 // Measured on the way (profiles/r04_forest_variants.txt): staging by LDS-DMA (global_load_lds_dwordx4, M0 reaches all 160 KB, data
 // visible at the issuer's vmcnt(0): tools/micro/lds_dma_range.hip) runs at the DMA path's own cadence, 1.5 us per 24.8 KB tree
 // whatever is in flight and even from L2 -- no faster than one register loader (1.35 us, bound by one load round trip per tree).
-// bits of `flags` beside RF_LD_PREFIX: timing experiments (MHS_RF_LD_FLAGS; 2 / 4 / 8 / 32 give wrong planes)
-enum { RF_LD_PREFIX = 1, RF_LD_ABLATE_WALKS = 2, RF_LD_ABLATE_STAGING = 4, RF_LD_ABLATE_PRED = 8, RF_LD_FEW_TREES = 32, RF_LD_SETUP_ONLY = 128 };
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {      // 64 lanes x 16 bytes global -> LDS at lds_dst + 16 lane
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// bits of `flags` beside RF_LD_PREFIX: timing experiments (MHS_RF_LD_FLAGS; 2 / 4 / 32 / 128 give wrong planes)
+enum { RF_LD_PREFIX = 1, RF_LD_ABLATE_WALKS = 2, RF_LD_ABLATE_STAGING = 4, RF_LD_ABLATE_SYNC = 8, RF_LD_FEW_TREES = 32, RF_LD_NO_DMA = 64, RF_LD_SETUP_ONLY = 128 };
 
 template <int LOG2R, bool K64, int STRIDE, int NL>
 __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restrict__ gnodes,
@@ -1967,7 +1970,33 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
 #define MHS_RF_REQUEST(U) { \
             src = (const char *)(gnodes + tree_off[(flags & RF_LD_FEW_TREES) ? (U) & 7 : (U)]) + lane16; \
             if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_LOAD) } }
-        if (flags & RF_LD_SETUP_ONLY) return;
+        if (flags & (RF_LD_SETUP_ONLY | RF_LD_ABLATE_SYNC)) return;
+        if (NL == 1 && !(flags & RF_LD_NO_DMA)) {
+            // ONE loader, TWO trees in flight: even trees through the registers (requested while their buffer is still being
+            // walked), odd trees by LDS-DMA (no registers, issued once the buffer is free; the data is in LDS at vmcnt(0)).
+            // Either path alone is one round trip per tree (1.2 - 1.5 us); alternating, a pair costs about one.
+            MHS_RF_REQUEST(0)
+            for (int u = 0; u < n_trees; u += 2) {
+                unsigned slot = (unsigned)u % 3u;
+                if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)(u / 3));
+                if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_STORE) }
+                lds_signal(CNT + 4u * slot);
+                if (u + 2 < n_trees) MHS_RF_REQUEST(u + 2)
+                if (u + 1 < n_trees) {
+                    slot = (unsigned)(u + 1) % 3u;
+                    if (u + 1 >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)((u + 1) / 3));
+                    if (!(flags & RF_LD_ABLATE_STAGING)) {
+                        const char *dsrc = (const char *)(gnodes + tree_off[(flags & RF_LD_FEW_TREES) ? (u + 1) & 7 : u + 1]) + lane16;
+#pragma unroll
+                        for (int q = 0; q < PF; ++q)
+                            glds16(dsrc + (size_t)q * 1024u, (unsigned)__builtin_amdgcn_readfirstlane((int)(slot * (unsigned)STRIDE + (unsigned)q * 1024u)));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    lds_signal(CNT + 4u * slot);
+                }
+            }
+            return;
+        }
         if (first < n_trees) MHS_RF_REQUEST(first)
         for (int u = first; u < n_trees; u += NL) {
             const unsigned slot = (unsigned)u % 3u;
@@ -1983,21 +2012,30 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         return;
     }
     if (flags & RF_LD_SETUP_ONLY) return;
-    double acc[R], pend[3][R];                                     // pend[b]: predictions of the last tree walked in buffer b
+    constexpr int PD = 6;                                          // a tree's predictions are added PD - 1 trees after their request
+    double acc[R], pend[PD][R];                                    // pend[t % PD]: predictions of tree t
 #pragma unroll
-    for (int c = 0; c < R; ++c) { acc[c] = 0.0; pend[0][c] = 0.0; pend[1][c] = 0.0; pend[2][c] = 0.0; }
+    for (int c = 0; c < R; ++c) {
+        acc[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) pend[k][c] = 0.0;
+    }
     unsigned ecur = 0u;
     unsigned staged[3] = {0u, 0u, 0u};                             // cached counters: buffer b has held staged[b] trees so far
     int ocur = 0, dcur = 0, mcur = 0;                              // lane l: first record, depth and shallowest leaf of tree 64 b + l
     const int lane = threadIdx.x & 63;
-    auto step = [&](auto slot_tag, const int t) {
-        constexpr int SLOT = decltype(slot_tag)::value;
+    auto step = [&](auto slot_tag, auto pidx_tag, const int t) {
+        constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
         if ((t & 63) == 0) {                                             // the next 64 trees' scalars: one vector load each instead of
             ecur = 0u;                                                   // three scalar loads (and their waits) per tree
 #pragma unroll
             for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
             const int tl = min(t + lane, n_trees - 1);
             ocur = tree_off[tl]; dcur = depth[tl]; mcur = dmin ? dmin[tl] : dcur;
+            // the three loads are awaited HERE: left pending, hipcc puts s_waitcnt vmcnt(0) in front of every step's readlanes
+            // (it cannot count the loads issued since around the loop) and every step then waits for the previous step's
+            // prediction loads as well
+            asm volatile("" : "+v"(ocur), "+v"(dcur), "+v"(mcur));
         }
         const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
         const int plen = (int)((ent >> 16) & 0x7FFFu);
@@ -2005,7 +2043,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         const int levels = ((ent >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dep - plen, shallow = max(dmn - plen, 0);
         // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
         // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
-        if (staged[SLOT] <= (unsigned)(t / 3))
+        if (staged[SLOT] <= (unsigned)(t / 3) && !(flags & RF_LD_ABLATE_SYNC))
             for (;;) {
                 uint4v cv;                                                   // staged[0..2] and the zero word behind them
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
@@ -2044,18 +2082,32 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
 #pragma unroll
         for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pend[(SLOT + 1) % 3][c];                   // tree t - 2's, requested two steps ago; still in tree order
-            if (!(flags & RF_LD_ABLATE_PRED)) pend[SLOT][c] = *(const double *)(lv + node[c]);
+            acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];                  // tree t - (PD - 1)'s; still in tree order
+            pend[PIDX][c] = *(const double *)(lv + node[c]);             // (unconditional: behind a branch hipcc waits vmcnt(0) at once)
         }
     };
-    for (int t = 0; t < n_trees; t += 3) {
-        step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, t + 2);
+    static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
+    for (int t = 0; t < n_trees; t += 6) {
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4);
+        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5);
+    }
+    // trees n - (PD - 1) .. n - 1 are still pending (slots never written hold 0.0)
+    for (int k = n_trees - (PD - 1); k < n_trees; ++k) {
+        const int q = ((k % PD) + PD) % PD;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            double v = pend[0][c];
+#pragma unroll
+            for (int z = 1; z < PD; ++z) if (q == z) v = pend[z][c];
+            acc[c] = acc[c] + v;
+        }
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) {
-        acc[c] = (acc[c] + pend[(n_trees + 1) % 3][c]) + pend[(n_trees + 2) % 3][c];   // trees n - 2 and n - 1
         if (live[c])
             emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
     }

@@ -391,8 +391,11 @@ def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_orde
 @pytest.mark.parametrize("n,dtype,ncol,trees", [(1400, "f32", 257, 7), (4600, "f64", 257, 7), (4600, "i16", 257, 7), (1400, "f32", 1100, 7),
                                                 (700, "f32", 257, 130), (300, "f32", 257, 520)])
 def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, monkeypatch):
-    """The default forest walk (round 3: the barrier-free triple-buffered kernel -- three buffers, LDS counters between the
-    waves, hand-scheduled level loops -- where three trees and the keys fit, else the double-buffered one, MHS_RF_DOUBLE_BUFFER)
+    """The default forest walk (round 4: rf_walk_ld_kernel -- one loader wave stages the trees, even ones through its registers and
+    odd ones by LDS-DMA (MHS_RF_LD_FLAGS=64: all through the registers; MHS_RF_TWO_LOADERS: two register loaders), fifteen waves
+    of 16 x 16 cells walk (MHS_RF_STRIP_WAVES: 64 x 4) -- where three trees and the keys fit; MHS_RF_NO_LOADER: round 3's
+    barrier-free triple-buffered kernel -- three buffers, LDS counters between the
+    waves, hand-scheduled level loops --, else the double-buffered one, MHS_RF_DOUBLE_BUFFER)
     against the compiler's loop, the four-walk forms, round 2's single-buffer forms and the node walk: bit-identical
     planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).
     The default also walks a lane's five cells on five ADJACENT rows (123 rows: a ragged last strip) and lets a wave leave a
@@ -411,6 +414,8 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
                  {"MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_NO_PREFIX": "1", "MHS_RF_FOUR_WALKS": "1"},
                  {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
+                 {"MHS_RF_STRIP_WAVES": "1"}, {"MHS_RF_TWO_LOADERS": "1"}, {"MHS_RF_LD_FLAGS": "64"}, {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_TWO_LOADERS": "1"},
+                 {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_TWO_LOADERS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_NO_LOADER": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_NO_PREFIX": "1"},
                  {"MHS_RF_NO_LOADER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"},

@@ -14,7 +14,9 @@ g = synth.grid(side, side)
 base, nodata = synth.covariates(g10, 3, seed, dtype="f32", window=(0, side, 0, side))
 stack = m.RasterStack(g, base, nodata)
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
-for name, env in (("full", {}), ("setup only", {"MHS_RF_LD_FLAGS": "128"}), ("setup only, no prefix (keys only)", {"MHS_RF_LD_FLAGS": "128", "MHS_RF_NO_PREFIX": "1"})):
+for name, env in (("full", {}), ("setup only", {"MHS_RF_LD_FLAGS": "128"}), ("setup only, no prefix (keys only)", {"MHS_RF_LD_FLAGS": "128", "MHS_RF_NO_PREFIX": "1"}),
+                  ("walks + staging off", {"MHS_RF_LD_FLAGS": "6"}), ("walks + staging + loader / walker synchronisation off", {"MHS_RF_LD_FLAGS": "14"}),
+                  ("staging + synchronisation off (walks on garbage)", {"MHS_RF_LD_FLAGS": "12"})):
     os.environ.update(env)
     m.predict(stack, mod, out=out); torch.cuda.synchronize()
     best = 1e9

@@ -50,10 +50,11 @@ def rasters():
     yield "8d + 10 % white noise", noisy
 
 
-variants = [("one loader wave (the next tree waits in its registers) + 15 walking waves of 16 x 16 cells (round 4 default)", {}),
+variants = [("one loader wave (even trees through its registers, odd trees by LDS-DMA) + 15 walking waves of 16 x 16 cells (round 4 default)", {}),
             ("16 waves stage and walk (round 3: rf_walk_tb_kernel)", {"MHS_RF_NO_LOADER": "1"}),
             ("loader wave, walks start at the root", {"MHS_RF_NO_PREFIX": "1"}),
             ("two buffers + a barrier per tree, 5 walks (round 3's first half)", {"MHS_RF_DOUBLE_BUFFER": "1"}),
+            ("one loader wave, every tree through its registers (no LDS-DMA for the odd trees)", {"MHS_RF_LD_FLAGS": "64"}),
             ("one loader wave, waves of 64 x 4 cells", {"MHS_RF_STRIP_WAVES": "1"}),
             ("two loader waves + 14 walking waves, waves of 16 x 16 cells", {"MHS_RF_TWO_LOADERS": "1"}),
             ("TIMING ONLY: keys and prefix only (no tree loop)", {"MHS_RF_LD_FLAGS": "128"}),
@@ -61,8 +62,8 @@ variants = [("one loader wave (the next tree waits in its registers) + 15 walkin
             ("TIMING ONLY: loader wave, staging off", {"MHS_RF_LD_FLAGS": "4"}),
             ("TIMING ONLY: loader wave, walks + staging off", {"MHS_RF_LD_FLAGS": "6"}),
             ("TIMING ONLY: loader wave, the first 8 trees staged over and over (always in L2)", {"MHS_RF_LD_FLAGS": "32"}),
-            ("TIMING ONLY: loader wave, walks off, the first 8 trees staged over and over", {"MHS_RF_LD_FLAGS": "34"}),
-            ("TIMING ONLY: loader wave, walks + staging + prediction loads off", {"MHS_RF_LD_FLAGS": "14"})]
+            ("TIMING ONLY: loader wave, walks off, the first 8 trees staged over and over", {"MHS_RF_LD_FLAGS": "34"})
+]
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 for rname, planes in rasters():
     stack = m.RasterStack(g, planes, nodata)
