@@ -16,6 +16,8 @@
 #     reproduces bit for bit.
 #   * (where kernlab / nnet are installed) kernlab::ksvm and nnet::nnet fits of tests/golden/r_inputs/learn_fit.csv with
 #     the RNG-dependent inputs fixed (sigma; initial weights), and their predict() values.
+#   * (where gbm / randomForest / kernlab are installed) gbm, randomForest and ksvm fits on 300 stations with their structures in
+#     the loaders' flat layout and their predict() over a 48 x 64 crop of the bundled TWI / slope overviews (round 4).
 # sessionInfo() is stored next to the numbers.
 suppressPackageStartupMessages({ library(fields); library(terra) })
 inp <- file.path("tests", "golden", "r_inputs")
@@ -96,6 +98,54 @@ if (requireNamespace("nnet", quietly = TRUE)) {
   w(as.numeric(predict(nn, nn.in)) * mx + mn, "learn_nnet_predict.csv")                       # V73:468-470
   nn25 <- nnet::nnet(resp ~ a + b + LONG + LAT, data = nn.in, size = 10, linout = TRUE, maxit = 25, Wts = w0, trace = FALSE)
   w(nn25$wts, "learn_nnet_wts_maxit25.csv")
+}
+# ---- tree / kernel members predicted over a raster crop (SURVEY.md 8a-3, 8a-4, 8a-8), where gbm / randomForest / kernlab are installed --
+# tests/golden/r_inputs/members_stations.csv: resp + alt, slope, TWI, LONG, LAT at 300 stations; members_crop.csv: the same five
+# predictors at the 48 x 64 cells of a crop of the bundled TWI / slope overviews (terra cell order).  For each package the
+# FITTED STRUCTURE is written in the flat layout the library's loaders take (include/machisplin_hip.h: mhs_gbm_load,
+# mhs_rf_load, mhs_svr_load) together with the package's own predict() over the crop: the test loads the structure and must
+# reproduce the prediction, which pins the evaluators (not the trainers) against the packages the reference calls at
+# V73:497 (gbm), V73:521-523 (randomForest) and V73:582-584 (ksvm).
+st <- read.csv(file.path(inp, "members_stations.csv"), comment.char = "#", header = FALSE, skip = 2,
+               col.names = c("resp", "alt", "slope", "TWI", "LONG", "LAT"))
+crop <- read.csv(file.path(inp, "members_crop.csv"), comment.char = "#", header = FALSE, skip = 2,
+                 col.names = c("alt", "slope", "TWI", "LONG", "LAT"))
+if (requireNamespace("gbm", quietly = TRUE)) {
+  set.seed(1)
+  gb <- gbm::gbm(resp ~ alt + slope + TWI + LONG + LAT, data = st, distribution = "gaussian", n.trees = 300,
+                 interaction.depth = 5, shrinkage = 0.01, bag.fraction = 0.75, n.minobsinnode = 5, verbose = FALSE)
+  nt <- 250                                                                  # "best.trees" < n.trees, as V73:497 cuts the object
+  rows <- NULL
+  for (i in seq_len(nt)) {
+    tr <- gb$trees[[i]]                                                      # SplitVar, SplitCodePred, LeftNode, RightNode, MissingNode, ...
+    rows <- rbind(rows, cbind(i - 1, tr[[1]], tr[[2]], tr[[3]], tr[[4]], tr[[5]]))
+  }
+  w(rows, "members_gbm_nodes.csv")                                           # tree, SplitVar (0-based, -1 terminal), SplitCodePred, Left, Right, Missing
+  w(c(initF = gb$initF, n.trees = nt, p = 5), "members_gbm_scalars.csv")
+  w(as.numeric(gbm::predict.gbm(gb, crop, n.trees = nt, type = "response")), "members_gbm_predict.csv")
+}
+if (requireNamespace("randomForest", quietly = TRUE)) {
+  set.seed(2)
+  rf <- randomForest::randomForest(resp ~ alt + slope + TWI + LONG + LAT, data = st, ntree = 60)   # V73:517 passes no ntree; 60 keeps the file small
+  f <- rf$forest
+  rows <- NULL
+  for (t in seq_len(f$ntree)) {
+    k <- seq_len(f$ndbigtree[t])
+    rows <- rbind(rows, cbind(t - 1, f$leftDaughter[k, t], f$rightDaughter[k, t], f$nodestatus[k, t], f$bestvar[k, t],
+                              f$xbestsplit[k, t], f$nodepred[k, t]))
+  }
+  w(rows, "members_rf_nodes.csv")                                            # tree, leftDaughter, rightDaughter (1-based), nodestatus, bestvar (1-based), xbestsplit, nodepred
+  w(as.numeric(predict(rf, crop, type = "response")), "members_rf_predict.csv")
+}
+if (requireNamespace("kernlab", quietly = TRUE)) {
+  sigma <- 0.2
+  sv <- kernlab::ksvm(resp ~ alt + slope + TWI + LONG + LAT, data = st, kpar = list(sigma = sigma))   # eps-svr, rbfdot, scaled = TRUE
+  sc <- kernlab::scaling(sv)
+  w(cbind(unlist(kernlab::coef(sv)), kernlab::xmatrix(sv)), "members_ksvm_sv.csv")      # alpha, then the scaled support vector (5 columns)
+  w(c(b = kernlab::b(sv), sigma = sigma, nSV = kernlab::nSV(sv)), "members_ksvm_scalars.csv")
+  w(rbind(sc$x.scale$`scaled:center`, sc$x.scale$`scaled:scale`), "members_ksvm_xscale.csv")
+  w(c(sc$y.scale$`scaled:center`, sc$y.scale$`scaled:scale`), "members_ksvm_yscale.csv")
+  w(as.numeric(kernlab::predict(sv, crop)), "members_ksvm_predict.csv")
 }
 writeLines(capture.output(sessionInfo()), file.path(out, "sessionInfo.txt"))
 cat("wrote", length(list.files(out)), "files to", out, "\n")

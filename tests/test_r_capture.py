@@ -152,3 +152,86 @@ def test_hip_learner_fits_match_r(hip):
     r25 = _csv("learn_nnet_wts_maxit25.csv")
     nn = hip.models.Nnet.fit(X, y, w0, maxit=25)
     assert np.abs(nn.wts - r25).max() < 1e-6 * np.abs(r25).max()
+
+
+# ---- round 4: gbm / randomForest / ksvm structures fitted in R, predicted over a crop of the bundled rasters ----------------------------
+def _member_inputs():
+    crop = np.loadtxt(os.path.join(GOLD, "r_inputs", "members_crop.csv"), delimiter=",", skiprows=2)
+    st = np.loadtxt(os.path.join(GOLD, "r_inputs", "members_stations.csv"), delimiter=",", skiprows=2)
+    return crop, st
+
+
+def test_member_inputs_are_reproducible():
+    """the crop / station tables the R script reads are what tests/golden/make_member_inputs.py writes from the committed
+    overviews (runs everywhere): 48 x 64 cells in terra cell order, no NoData, integer responses"""
+    crop, st = _member_inputs()
+    assert crop.shape == (48 * 64, 5) and st.shape == (300, 6)
+    z = np.load(os.path.join(GOLD, "cfg1_extdata.npz"))
+    assert np.array_equal(crop[:, 2].reshape(48, 64), z["TWI"][744:792, 222:286].astype(np.float64))
+    assert np.array_equal(crop[:, 1].reshape(48, 64), z["slope"][744:792, 222:286].astype(np.float64))
+    assert np.array_equal(st[:, 0], np.round(st[:, 0]))
+    assert np.all(np.diff(crop[:64, 3]) > 0) and crop[0, 4] > crop[64, 4]          # LONG grows along a row, LAT falls down the rows
+
+
+def _r_member_params(kind):
+    """the R-side structure files -> the parameter dicts of machisplin_amd.models.from_param_dict / oracle.ensemble.predict"""
+    if kind == "gbm":
+        nodes = _csv("members_gbm_nodes.csv").reshape(-1, 6)
+        init_f, nt, p = _csv("members_gbm_scalars.csv")[:3]
+        tree = nodes[:, 0].astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(np.bincount(tree, minlength=int(nt)))])
+        return {"kind": "gbm", "init_f": float(init_f), "tree_offsets": off, "split_var": nodes[:, 1].astype(np.int32),
+                "split_val": nodes[:, 2], "left": nodes[:, 3].astype(np.int32), "right": nodes[:, 4].astype(np.int32),
+                "missing": nodes[:, 5].astype(np.int32), "p": int(p)}
+    if kind == "rf":
+        nodes = _csv("members_rf_nodes.csv").reshape(-1, 7)
+        tree = nodes[:, 0].astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(np.bincount(tree))])
+        return {"kind": "rf", "tree_offsets": off, "left": nodes[:, 1].astype(np.int32), "right": nodes[:, 2].astype(np.int32),
+                "status": nodes[:, 3].astype(np.int32), "best_var": nodes[:, 4].astype(np.int32), "split": nodes[:, 5],
+                "node_pred": nodes[:, 6], "p": 5}
+    sv = _csv("members_ksvm_sv.csv").reshape(-1, 6)
+    b, sigma = _csv("members_ksvm_scalars.csv")[:2]
+    xs = _csv("members_ksvm_xscale.csv").reshape(2, 5)
+    yc, ys = _csv("members_ksvm_yscale.csv")[:2]
+    return {"kind": "svr", "alpha": sv[:, 0], "sv": np.ascontiguousarray(sv[:, 1:]), "b": float(b), "sigma": float(sigma),
+            "x_center": xs[0], "x_scale": xs[1], "y_center": float(yc), "y_scale": float(ys)}
+
+
+MEMBERS = [("gbm", "members_gbm_predict.csv"), ("rf", "members_rf_predict.csv"), ("svr", "members_ksvm_predict.csv")]
+
+
+@pytest.mark.parametrize("kind,pred", MEMBERS)
+def test_oracle_members_match_the_packages(kind, pred):
+    """oracle.ensemble.predict on the structure R fitted == the package's own predict() over the crop (gbm_pred, randomForest's
+    regForest, kernlab's predict.ksvm): what ties the evaluators' oracle to the packages of V73:497 / 521 / 582"""
+    if not os.path.exists(os.path.join(CAP, pred)):
+        pytest.skip("no capture of this package")
+    from oracle import ensemble as oe
+    crop, _ = _member_inputs()
+    want = _csv(pred)
+    got = oe.predict(_r_member_params(kind), crop)
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max(), kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,pred", MEMBERS)
+def test_hip_members_match_the_packages(hip, kind, pred):
+    """the HIP evaluators through the C ABI, on the crop as a float64 raster stack (what terra holds), against the package's
+    predict(): grid kernels (rf_walk_ld_kernel / gbm_coherent_kernel / svr_rt_kernel need >= 16 rows) and the point path"""
+    if not os.path.exists(os.path.join(CAP, pred)):
+        pytest.skip("no capture of this package")
+    import torch
+    crop, _ = _member_inputs()
+    want = _csv(pred)
+    prm = _r_member_params(kind)
+    m = hip.models.from_param_dict(prm)
+    pts = m.predict_points(crop)
+    assert np.abs(pts - want).max() <= 1e-9 * np.abs(want).max(), kind
+    z = np.load(os.path.join(GOLD, "cfg1_extdata.npz"))
+    xmin, ymax, xres, yres = (float(v) for v in z["geom"][:4])
+    g = hip.Geometry(xmin + 222 * xres, ymax - 744 * yres, xres, yres, 48, 64)
+    planes = torch.from_numpy(np.ascontiguousarray(crop[:, :3].T.reshape(3, 48, 64))).cuda()
+    grid = hip.predict(hip.RasterStack(g, planes, float("nan")), m).cpu().numpy().ravel()
+    # the grid path generates LONG / LAT from the affine (xmin + (col + 0.5) xres): the same doubles as the table's to rounding
+    assert np.abs(grid - want).max() <= 1e-9 * np.abs(want).max(), kind
