@@ -110,6 +110,7 @@ struct mhs_model {
     std::vector<double> rf_thr;              // host, split value per node
     std::vector<unsigned short> rf_left, rf_var;  // host, per node (var 0xFFFF = terminal)
     int rf_max_nodes = 0;
+    int rf_max_depth = 0;                    // deepest tree (rf_walk_ld_kernel packs a tree's level counts in 6 bits each)
     int rf_log2r = -1;                       // walks per lane rf_nodes were built for
     int rf_form = 0;                         // ... and in which form: RF_SMALL (16-bit byte addresses, predictions in LDS),
                                              // RF_BIG (node indices, predictions in global memory), RF_COMPACT (split nodes only)
@@ -2020,45 +2021,52 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
 #pragma unroll
         for (int k = 0; k < PD; ++k) pend[k][c] = 0.0;
     }
-    unsigned ecur = 0u;
     unsigned staged[3] = {0u, 0u, 0u};                             // cached counters: buffer b has held staged[b] trees so far
-    int ocur = 0, dcur = 0, mcur = 0;                              // lane l: first record, depth and shallowest leaf of tree 64 b + l
+    int ocur = 0;                                                  // lane l: first record of tree 64 b + l
+    unsigned wcur = 0u;                                            // lane l: its walk -- entry node's byte address | c0 << 19 | cnt << 25 | walks << 31
     const int lane = threadIdx.x & 63;
-    auto step = [&](auto slot_tag, auto pidx_tag, const int t) {
+    auto step = [&](auto slot_tag, auto pidx_tag, const int t, const unsigned k3) {      // k3 = t / 3
         constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
-        if ((t & 63) == 0) {                                             // the next 64 trees' scalars: one vector load each instead of
-            ecur = 0u;                                                   // three scalar loads (and their waits) per tree
+        if ((t & 63) == 0) {
+            // The next 64 trees' scalars, lane = tree: one vector load each instead of three scalar loads (and their waits) per
+            // tree, and the walk's loop counts (levels without / with the exit test) formed here on the vector unit, 64 trees per
+            // instruction, instead of a dozen scalar instructions per tree on the CU's one scalar unit (the PMC pass counts
+            // 0.8 scalar per vector instruction in this kernel)
+            unsigned ecur = 0u;
 #pragma unroll
             for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
             const int tl = min(t + lane, n_trees - 1);
-            ocur = tree_off[tl]; dcur = depth[tl]; mcur = dmin ? dmin[tl] : dcur;
-            // the three loads are awaited HERE: left pending, hipcc puts s_waitcnt vmcnt(0) in front of every step's readlanes
-            // (it cannot count the loads issued since around the loop) and every step then waits for the previous step's
+            ocur = tree_off[tl];
+            const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
+            const int plen = (int)((ecur >> 16) & 0x7FFFu);
+            const int levels = ((ecur >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
+            const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63: depth of a tree of <= 3 200 nodes
+            wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
+            // the loads are awaited HERE: left pending, hipcc puts s_waitcnt vmcnt(0) in front of every step's readlanes (it
+            // cannot count the loads issued since around the loop) and every step then waits for the previous steps'
             // prediction loads as well
-            asm volatile("" : "+v"(ocur), "+v"(dcur), "+v"(mcur));
+            asm volatile("" : "+v"(ocur), "+v"(wcur));
         }
-        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
-        const int plen = (int)((ent >> 16) & 0x7FFFu);
-        const int o = __builtin_amdgcn_readlane(ocur, t & 63), dep = __builtin_amdgcn_readlane(dcur, t & 63), dmn = __builtin_amdgcn_readlane(mcur, t & 63);
-        const int levels = ((ent >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dep - plen, shallow = max(dmn - plen, 0);
+        const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)wcur, t & 63);
+        const int o = __builtin_amdgcn_readlane(ocur, t & 63);
         // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
         // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
-        if (staged[SLOT] <= (unsigned)(t / 3) && !(flags & RF_LD_ABLATE_SYNC))
+        if (staged[SLOT] <= k3 && !(flags & RF_LD_ABLATE_SYNC))
             for (;;) {
                 uint4v cv;                                                   // staged[0..2] and the zero word behind them
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
                 staged[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.x);
                 staged[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.y);
                 staged[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.z);
-                if (staged[SLOT] > (unsigned)(t / 3)) break;
+                if (staged[SLOT] > k3) break;
                 __builtin_amdgcn_s_sleep(1);
             }
         unsigned node[R];
 #pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = (ent & 0xFFFFu) << 3;
+        for (int c = 0; c < R; ++c) node[c] = wk & 0x7FFF8u;
+        int c0 = (int)((wk >> 19) & 63u), cnt = (int)((wk >> 25) & 63u);
         if constexpr (R == 4) {
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
+            if (wk >> 31)
                 asm volatile(
 #include "rf_walk_loop4xo.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
@@ -2067,8 +2075,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
                       "v115", "v116", "v117", "v118", "v120");
         } else {
             static_assert(R == 4 || R == 5, "hand loops exist for four and five walks");
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
+            if (wk >> 31)
                 asm volatile(
 #include "rf_walk_loop5xo.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[R - 1]), [cnt] "+s"(cnt),
@@ -2087,13 +2094,14 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         }
     };
     static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
-    for (int t = 0; t < n_trees; t += 6) {
-        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2);
-        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3);
-        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4);
-        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5);
+    unsigned k3 = 0u;
+    for (int t = 0; t < n_trees; t += 6, k3 += 2u) {
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t, k3);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1, k3);
+        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2, k3);
+        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3, k3 + 1u);
+        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4, k3 + 1u);
+        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5, k3 + 1u);
     }
     // trees n - (PD - 1) .. n - 1 are still pending (slots never written hold 0.0)
     for (int k = n_trees - (PD - 1); k < n_trees; ++k) {
@@ -2930,7 +2938,7 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
         if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
         const int R = rf_walks(tb_l2);
         const int strips = rf_strips(g, R);
-        const bool ld = !getenv("MHS_RF_NO_LOADER");               // staging waves + walking waves (rf_walk_ld_kernel)
+        const bool ld = !getenv("MHS_RF_NO_LOADER") && m->rf_max_depth <= 63;      // staging waves + walking waves (rf_walk_ld_kernel)
         const bool ld1 = ld && !getenv("MHS_RF_TWO_LOADERS");
         const int64_t per_block = ld ? 64 * (ld1 ? 15 : 14) : 1024;
         unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
@@ -3430,6 +3438,7 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
                 }
             }
             depth[(size_t)t] = dmax;
+            m->rf_max_depth = std::max(m->rf_max_depth, dmax);
             shallow[(size_t)t] = std::min(dlow, dmax);
         }
         if (paired) {
