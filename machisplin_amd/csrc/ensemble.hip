@@ -3520,6 +3520,19 @@ int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weigh
 // that finished rows travel back under the rows still being computed (40, 40, 16, 4 %: the exposed download is the 4 %).
 // Everything between them runs once over the whole window.  Per cell the members are still accumulated in the caller's
 // order, so the plane equals the one-piece evaluation bit for bit.  The window lives in the persistent arena.
+// Error returns of the host-pointer pipelines: copies between the caller's pageable buffers and the arena may still be in flight on
+// the three pipe streams when a later call fails; the caller is free to release its buffers once the entry point has returned,
+// so every exit that is not the normal one drains the streams first (round-3 advisor finding).
+struct PipeDrain {
+    Context &c;
+    bool done = false;
+    explicit PipeDrain(Context &ctx_) : c(ctx_) {}
+    ~PipeDrain() {
+        if (done) return;
+        (void)hipStreamSynchronize(c.pipe_h2d); (void)hipStreamSynchronize(c.pipe_comp); (void)hipStreamSynchronize(c.pipe_d2h);
+    }
+};
+
 static int host_window_pipeline(const mhs_model *const *models, const double *weights, int n_models, int first_end, int last_start,
                                 double wt_total, const mhs_grid *g, const mhs_stack *covars, int64_t r0, int64_t r1, int64_t c0,
                                 int64_t c1, double *out_host) {
@@ -3530,6 +3543,7 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
     std::lock_guard<std::mutex> lk(pipe_mutex());
     if (int rc = host_pipe(in_bytes + (size_t)nr * nc * sizeof(double))) return rc;
     Context &c = ctx();
+    PipeDrain drain(c);
     char *in = c.pipe_arena;
     double *outp = (double *)(c.pipe_arena + in_bytes);
     const int pct[4] = {4, 16, 40, 40};
@@ -3586,6 +3600,7 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
     }
     MHS_HIP(hipStreamSynchronize(c.pipe_d2h));
     MHS_HIP(hipStreamSynchronize(c.pipe_comp));
+    drain.done = true;
     if (timing) fprintf(stderr, "[mhs_ensemble_predict] window pipeline: uploads issued by %.1f ms, all done at %.1f ms\n", t_up - t_start, now_ms() - t_start);
     return MHS_OK;
 }
@@ -3646,6 +3661,7 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     std::lock_guard<std::mutex> lk(pipe_mutex());
     if (int rc = host_pipe(2 * (in_bytes + out_bytes))) return rc;
     Context &c = ctx();
+    PipeDrain drain(c);
     char *in[2] = {c.pipe_arena, c.pipe_arena + in_bytes};
     double *outb[2] = {(double *)(c.pipe_arena + 2 * in_bytes), (double *)(c.pipe_arena + 2 * in_bytes + out_bytes)};
     const bool timing = getenv("MHS_HOST_TIMING") != nullptr;
@@ -3707,6 +3723,7 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     if (int rc = download(nb - 1)) return rc;
     MHS_HIP(hipStreamSynchronize(c.pipe_d2h));
     MHS_HIP(hipStreamSynchronize(c.pipe_comp));
+    drain.done = true;
     return MHS_OK;
 }
 
