@@ -3104,6 +3104,9 @@ static int launch_members(const mhs_model *const *models, const double *weights,
     for (int want : {K_RF, K_SVR, K_GBM})
         for (int q = 0; q < n_models && mask_kind < 0; ++q)
             if (models[q]->kind == want) mask_kind = want;
+    // MHS_MASK_ALSO_SVR=1 (experiment, round 4): ksvm leaves the reserved units free as well -- a SMALL reservation held for
+    // the forest's and ksvm's 190 ms instead of a large one for the forest's 70
+    static const bool also_svr = getenv("MHS_MASK_ALSO_SVR") != nullptr;
     while (k < n_models) {
         const int acc = (k > 0 || accumulate_first) ? 1 : 0;
         // the longest run lm? nnet? earth? starting at k (each at most once, in that order)
@@ -3134,11 +3137,11 @@ static int launch_members(const mhs_model *const *models, const double *weights,
         // mhs_fit_reserve_cus: the chosen long member runs on the masked stream, fenced by two events so that it keeps
         // its place in the caller's stream order
         const int kind = models[k]->kind;
-        if (!masked_done && ctx().reserved_cus > 0 && grid && total >= (1 << 22) && kind == mask_kind) {
+        if (ctx().reserved_cus > 0 && grid && total >= (1 << 22) && ((!masked_done && kind == mask_kind) || (also_svr && kind == K_SVR))) {
             Context &c = ctx();
             std::lock_guard<std::mutex> lk(mask_mutex());
             if (c.masked_stream) {
-                masked_done = true;
+                if (kind == mask_kind) masked_done = true;
                 if (getenv("MHS_MASK_DEBUG")) fprintf(stderr, "[mask] kind %d on the masked stream %p (caller stream %p), %d CUs reserved\n", kind, (void *)c.masked_stream, (void *)st, c.reserved_cus);
                 MHS_HIP(hipEventRecord(c.mask_ev0, st));
                 MHS_HIP(hipStreamWaitEvent(c.masked_stream, c.mask_ev0, 0));
