@@ -3104,9 +3104,9 @@ static int launch_members(const mhs_model *const *models, const double *weights,
     for (int want : {K_RF, K_SVR, K_GBM})
         for (int q = 0; q < n_models && mask_kind < 0; ++q)
             if (models[q]->kind == want) mask_kind = want;
-    // MHS_MASK_ALSO_SVR=1 (experiment, round 4): ksvm leaves the reserved units free as well -- a SMALL reservation held for
-    // the forest's and ksvm's 190 ms instead of a large one for the forest's 70
-    static const bool also_svr = getenv("MHS_MASK_ALSO_SVR") != nullptr;
+    // (round 4, measured and not kept: a SMALL reservation held for the forest's and ksvm's 190 ms instead of a large one for the
+    // forest's 70 -- the 32-column fit wants the whole chip for its MFMA updates: confined to 8 / 16 / 32 units it ends after
+    // 486 / 336 / 259 ms of a cfg3 step, so the calibration of sharded.py now reserves nothing)
     while (k < n_models) {
         const int acc = (k > 0 || accumulate_first) ? 1 : 0;
         // the longest run lm? nnet? earth? starting at k (each at most once, in that order)
@@ -3137,11 +3137,11 @@ static int launch_members(const mhs_model *const *models, const double *weights,
         // mhs_fit_reserve_cus: the chosen long member runs on the masked stream, fenced by two events so that it keeps
         // its place in the caller's stream order
         const int kind = models[k]->kind;
-        if (ctx().reserved_cus > 0 && grid && total >= (1 << 22) && ((!masked_done && kind == mask_kind) || (also_svr && kind == K_SVR))) {
+        if (!masked_done && ctx().reserved_cus > 0 && grid && total >= (1 << 22) && kind == mask_kind) {
             Context &c = ctx();
             std::lock_guard<std::mutex> lk(mask_mutex());
             if (c.masked_stream) {
-                if (kind == mask_kind) masked_done = true;
+                masked_done = true;
                 if (getenv("MHS_MASK_DEBUG")) fprintf(stderr, "[mask] kind %d on the masked stream %p (caller stream %p), %d CUs reserved\n", kind, (void *)c.masked_stream, (void *)st, c.reserved_cus);
                 MHS_HIP(hipEventRecord(c.mask_ev0, st));
                 MHS_HIP(hipStreamWaitEvent(c.masked_stream, c.mask_ev0, 0));
