@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
                                                             const void *__restrict__ sorted, const int *__restrict__ sorted_off,
                                                             int n_trees_padded, double init_f, int p, StackDev s, PredGeom g,
                                                             int tiles_per_row, double weight, int accumulate,
-                                                            double *__restrict__ out, int *__restrict__ probe) {
+                                                            double *__restrict__ out, int *__restrict__ probe, int tile16) {
     constexpr int S = 5, CH = LUT_CHUNK, CLS_STRIDE = 384, R = LUT_R;
     if (!PROBE && probe && !gbc_coherent_pays(probe)) return;
     if (PROBE) n_trees_padded = min(n_trees_padded, GBC_PROBE_CHUNKS * CH);
@@ -1075,19 +1075,24 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
     // footprint a wave can have, hence the narrowest rank ranges.  The tiles are anchored to the GRID (rows at multiples of
     // R, columns at multiples of 64 of the grid, clipped by the window), so that a cell meets the same companions -- and
     // its sum the same order -- whether the window is evaluated whole or in row bands cut at multiples of R
-    const int roff = (int)(g.r0 % R), coff = (int)(g.c0 % 64);
-    const int64_t ntiles = (int64_t)((g.nr + roff + R - 1) / R) * tiles_per_row;
+    // Round 4 (tile16): 16 columns x 4 R rows per wave (lane = column + 16 x row group, a lane's R cells one below the other)
+    // instead of 64 columns x R rows -- the forest's tile (rf_walk_ld_kernel): narrower rank ranges on smooth rasters, more
+    // trees without a straddling split.  Anchored to the grid at multiples of 16 rows and 16 columns (BAND_ALIGN = 16 rows).
+    const int TW = tile16 ? 16 : 64, TH = tile16 ? 4 * R : R;
+    const int roff = (int)(g.r0 % TH), coff = (int)(g.c0 % TW);
+    const int64_t ntiles = (int64_t)((g.nr + roff + TH - 1) / TH) * tiles_per_row;
     int64_t tile = (int64_t)blockIdx.x * GBC_WAVES + wave;
     if (PROBE) tile = ntiles >= GBC_PROBE_BLOCKS * GBC_WAVES ? tile * (ntiles / (GBC_PROBE_BLOCKS * GBC_WAVES)) : tile % ntiles;
     const bool live = tile < ntiles;
     if (!live) tile = ntiles - 1;
-    const int trow = (int)(tile / tiles_per_row) * R - roff, tcol = (int)(tile % tiles_per_row) * 64 - coff;
+    const int trow = (int)(tile / tiles_per_row) * TH - roff + (tile16 ? (lane >> 4) * R : 0);
+    const int tcol = (int)(tile % tiles_per_row) * TW - coff + (tile16 ? (lane & 15) : lane);
     int row[R], col[R];
     bool na[R], ok[R];
     double acc[R];
 #pragma unroll
     for (int c = 0; c < R; ++c) {
-        const int rr = trow + c, cc = tcol + lane;
+        const int rr = trow + c, cc = tcol;
         ok[c] = live && cc >= 0 && cc < g.nc && rr >= 0 && rr < g.nr;
         row[c] = min(max(rr, 0), g.nr - 1); col[c] = min(max(cc, 0), g.nc - 1);
         na[c] = false; acc[c] = 0.0;
@@ -2727,9 +2732,11 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     // when the rows are long enough that the ragged last tile of a row wastes little (MHS_GBM_NO_ROWTILE: never)
     const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
     const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
-    const int ctpr = (int)((g.nc + g.c0 % 64 + 63) / 64);
+    const bool gbc_strips = getenv("MHS_GBM_STRIP_WAVES") != nullptr;      // round 3's 64 x 4-cell wave tiles instead of 16 x 16
+    const int ctw = gbc_strips ? 64 : 16, cth = gbc_strips ? LUT_R : 4 * LUT_R;
+    const int ctpr = (int)((g.nc + g.c0 % ctw + ctw - 1) / ctw);
     const bool rt_ok = in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R);
-    const bool coh_ok = in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * 64 &&
+    const bool coh_ok = in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * ctw &&
                         !getenv("MHS_GBM_NO_COHERENT");
     // Grids: the coherent kernel where neighbouring cells share their trees' outcomes, the tree-order row-tile kernel where
     // they do not (white-noise rasters) -- decided on the device by a probe of 64 tiles (large windows; small ones are not
@@ -2744,18 +2751,18 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
         probe = mm->gbm_probe + (size_t)(mm->gbm_probe_next.fetch_add(1) % GBC_PROBE_SLOTS) * 2 * GBC_PROBE_BLOCKS;
     }
     if (coh_ok) {
-        const int64_t ntiles = (int64_t)((g.nr + g.r0 % LUT_R + LUT_R - 1) / LUT_R) * ctpr;
+        const int64_t ntiles = (int64_t)((g.nr + g.r0 % cth + cth - 1) / cth) * ctpr;
         const unsigned cblocks = (unsigned)((ntiles + GBC_WAVES - 1) / GBC_WAVES);
         if (probe) {
             auto pk = key64 ? gbm_coherent_kernel<true, true> : gbm_coherent_kernel<false, true>;
             MHS_HIP(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
             hipLaunchKernelGGL(pk, dim3(GBC_PROBE_BLOCKS), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe);
+                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1);
         }
         auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
         hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe);
+                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1);
         if (!probe) return launch_gbm_na(m, s, g, w, acc, out, st, total);
     }
     if (rt_ok) {

@@ -1,4 +1,4 @@
-"""Round 4: stand-alone times of the randomForest kernel variants on cfg3's forest (5 000 stations, 500 trees) over side x side
+"""Round 4: stand-alone times of the randomForest (or, with MHS_TOOL_MEMBER=gbm, the gbm) kernel variants on cfg3's forest (5 000 stations, 500 trees) over side x side
 cells of (a) the SURVEY 8d planes, (b) the bundled TWI / slope overviews mirrored to the window (+ synthetic alt), (c) 8d +
 10 % white noise.  Variants are selected with the library's environment switches; every plane is compared bit for bit with the
 first variant's.
@@ -23,7 +23,8 @@ seed = synth.BASE_SEED + 3
 xy, rows, cols, uv = synth.stations(g10, 5000, seed)
 X = np.column_stack([synth.covariates_at(g10, 3, seed, rows, cols), xy])
 y = synth.response(X, uv, seed)
-prm = synth.rf_params(X, y, seed)
+member = os.environ.get("MHS_TOOL_MEMBER", "rf")
+prm = synth.rf_params(X, y, seed) if member == "rf" else synth.gbm_params(X, y, seed)
 mod = m.models.from_param_dict(prm)
 g = synth.grid(side, side)
 base, nodata = synth.covariates(g10, 3, seed, dtype="f32", window=(0, side, 0, side))
@@ -64,6 +65,12 @@ variants = [("one loader wave (even trees through its registers, odd trees by LD
             ("TIMING ONLY: loader wave, the first 8 trees staged over and over (always in L2)", {"MHS_RF_LD_FLAGS": "32"}),
             ("TIMING ONLY: loader wave, walks off, the first 8 trees staged over and over", {"MHS_RF_LD_FLAGS": "34"})
 ]
+if member == "gbm":
+    variants = [("coherent kernel, waves of 16 x 16 cells, device-side probe (round 4 default)", {}),
+                ("coherent kernel, waves of 64 x 4 cells, probe (round 3)", {"MHS_GBM_STRIP_WAVES": "1"}),
+                ("coherent kernel forced, 16 x 16", {"MHS_GBM_FORCE_COHERENT": "1"}),
+                ("coherent kernel forced, 64 x 4", {"MHS_GBM_FORCE_COHERENT": "1", "MHS_GBM_STRIP_WAVES": "1"}),
+                ("tree-order row-tile kernel", {"MHS_GBM_NO_COHERENT": "1"})]
 out = torch.empty((side, side), dtype=torch.float64, device="cuda")
 for rname, planes in rasters():
     stack = m.RasterStack(g, planes, nodata)
@@ -83,7 +90,7 @@ for rname, planes in rasters():
             del os.environ[k]
         plane = out.clone()
         same = "" if ref is None else ("  == first" if torch.equal(torch.nan_to_num(plane), torch.nan_to_num(ref)) and torch.equal(torch.isnan(plane), torch.isnan(ref))
-                                       else "  DIFFERS: max |diff| = %.3e" % float((torch.nan_to_num(plane) - torch.nan_to_num(ref)).abs().max()))
+                                       else "  DIFFERS: max |diff| = %.3e (max |first| = %.3e)" % (float((torch.nan_to_num(plane) - torch.nan_to_num(ref)).abs().max()), float(torch.nan_to_num(ref).abs().max())))
         if ref is None:
             ref = plane
         print(f"[{rname}] {name:70s} {best * 1e3:9.2f} ms  -> 1e8 cells: {best * 1e8 / (side * side) * 1e3:8.1f} ms{same}", flush=True)
