@@ -230,8 +230,9 @@ def test_cfg5_five_covariate_ensemble_rows(hip):
         b = hip.predict(stack, mods[k], window=(r0 - 1000, r1 + 24, 0, side))
         if k == 4:
             assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b[1000:1000 + (r1 - r0)]))
-        else:      # gbm: whole 4-row tiles (anchored to the grid) hold the same bits, the window's clipped edge tiles the same to rounding
-            lo, hi = -r0 % 4, (r1 - r0) - r1 % 4
+        else:      # gbm: whole 16-row tiles (anchored to the grid; round 4: 16 x 16 cells) hold the same bits, the window's clipped edge tiles the same to rounding
+            lo, hi = -r0 % 16, (r1 - r0) - r1 % 16
+            assert hi - lo >= 16
             assert torch.equal(torch.nan_to_num(a[lo:hi]), torch.nan_to_num(b[1000 + lo:1000 + hi]))
             assert float((torch.nan_to_num(a) - torch.nan_to_num(b[1000:1000 + (r1 - r0)])).abs().max()) <= 1e-13 * float(a.abs().max())
 
