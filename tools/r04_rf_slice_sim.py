@@ -35,7 +35,7 @@ def planes_at(rows, cols, noise=0.0, noise_seed=0):
 def main():
     n_waves = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     TW = int(sys.argv[2]) if len(sys.argv) > 2 else 64          # wave tile: TW columns x TH rows (TW x TH = 256 cells)
-    TH = 256 // TW
+    TH = int(sys.argv[3]) if len(sys.argv) > 3 else 256 // TW   # (a third argument: rows, e.g. 240 16 = a block of 15 wave tiles)
     geom = synth.grid(SIDE, SIDE)
     xy, rows, cols, uv = synth.stations(geom, N, SEED)
     cov = np.column_stack(planes_at(rows, cols))
