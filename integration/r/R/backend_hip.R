@@ -99,3 +99,28 @@ mhs_interpolate <- function(r, object) {
 # instead of one predict.gbm per gbm.more
 .mhs_gbm_holdout_stages <- function(handle, x.holdout, step.size, n.fitted)
   .Call("mhsr_gbm_staged_points", handle, as.matrix(x.holdout), as.integer(step.size), as.integer(n.fitted))
+
+
+# ---- Step 2 as it is threaded through machisplin.mltps (V73:442-619), all six members -----------------------------------
+# The loop  for(k in mods.run)  keeps its fits, its variable-importance lines and its station residuals (O(stations) work in
+# the packages); only the raster side of each  if (k=="x")  block -- the terra::predict(rast_stack, model) pair and the
+# pred.elev accumulation -- is replaced by ONE call that records the fitted member, and the division by the weight total
+# after the loop by ONE call that evaluates all recorded members in a single pass over the raster.  The edit list, by V73
+# line (INTEGRATION.md section 2 repeats it):
+#   before V73:447   hip <- .mhs_ready(); S2 <- .mhs_step2_new()
+#   V73:468-475 (n)  if (hip) S2 <- .mhs_step2_member(S2, "n", mod.nn.tps.FINAL,   OptX.mfit.wt[[iter.mod]], n.covars, max2.resp.f, min.resp.f) else { <the eight lines> }
+#   V73:497-499 (b)  if (hip) S2 <- .mhs_step2_member(S2, "b", mod.brt.tps.FINAL,  OptX.mfit.wt[[iter.mod]], n.covars) else { <the three lines> }
+#   V73:521-523 (r)  if (hip) S2 <- .mhs_step2_member(S2, "r", mod.rf.tps.FINAL,   OptX.mfit.wt[[iter.mod]], n.covars) else { ... }
+#   V73:543-545 (m)  if (hip) S2 <- .mhs_step2_member(S2, "m", mod.MARS.tps.FINAL, OptX.mfit.wt[[iter.mod]], n.covars) else { ... }
+#   V73:582-584 (v)  if (hip) S2 <- .mhs_step2_member(S2, "v", mod.SVM.tps.FINAL,  OptX.mfit.wt[[iter.mod]], n.covars) else { ... }
+#   V73:604-606 (g)  if (hip) S2 <- .mhs_step2_member(S2, "g", mod.GAM.tps.FINAL,  OptX.mfit.wt[[iter.mod]], n.covars) else { ... }
+#   V73:619          pred.elev <- if (hip) .mhs_step2_finish(S2, covar.ras, OptX.mfit.wt.tot) else (pred.elev/OptX.mfit.wt.tot)
+# The members are summed in the loop's order (mods.run), each times its weight, then divided by the unrounded total -- the
+# arithmetic of V73:471-475 ... 606 and 619.
+.mhs_step2_new <- function() list(handles = list(), wts = numeric(0))
+.mhs_step2_member <- function(S2, k, mod, wt, n.covars, max2.resp.f = 1, min.resp.f = 0) {
+  S2$handles[[length(S2$handles) + 1L]] <- .mhs_model(k, mod, n.covars, max2.resp.f, min.resp.f)
+  S2$wts <- c(S2$wts, as.numeric(wt))
+  S2
+}
+.mhs_step2_finish <- function(S2, covar.ras, OptX.mfit.wt.tot) mhs_ensemble_raster(covar.ras, S2$handles, S2$wts, OptX.mfit.wt.tot)
