@@ -805,9 +805,16 @@ class TileWorkload:
         if small:
             ms, _ = timed(lambda: mm.members_predict(stack, [f["models"][i] for i in small], [f["weights"][i] for i in small], out=out))
             by = cells * (4.0 * self.cfg["layers"] + 8.0)
-            rows_tab.append({"kernel": "small_members_kernel (gam+nnet+earth)", "bound": "hbm", "launch_ms": ms, "achieved": by / ms / 1e6,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
-                             "work": "read C fp32 planes once + write the fp64 plane once"})
+            # ten logistic units per cell (nnet) + the hinges + the linear model: compute, not traffic, bounds it -- the same label
+            # and instruction count as in the cfg3 line (884 VALU wave-instructions per cell in the SQ_INSTS_VALU pass of
+            # profiles/r04_8d_members_pmc_derived.json, five predictors; this workload's units have the same member shapes)
+            ipc = 884.0
+            rows_tab.append({"kernel": "small_members_kernel (gam+nnet+earth)", "bound": "valu-issue", "launch_ms": ms,
+                             "achieved": cells / 64.0 * ipc / ms / 1e6, "peak": VALU_ISSUE_PEAK_G, "unit": "Gwave-instr/s",
+                             "frac": cells / 64.0 * ipc / ms / 1e6 / VALU_ISSUE_PEAK_G,
+                             "work": "gam + nnet + earth in one pass: %.0f VALU wave-instructions per cell / 64 lanes (profiles/r04_8d_members_pmc_derived.json); "
+                                     "read C fp32 planes once + write the fp64 plane once" % ipc,
+                             "hbm_view": {"achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS}})
         if sv:
             m = f["models"][sv[0]]
             ms, _ = timed(lambda: mm.members_predict(stack, [m], [f["weights"][sv[0]]], accumulate=True, out=out))
