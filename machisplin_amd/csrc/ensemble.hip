@@ -79,6 +79,8 @@ struct mhs_model {
     void *lut_sorted = nullptr;          // device, sorted distinct key-space thresholds, predictor after predictor
                                          // (float keys for float32 / int16 planes, double keys for float64 planes)
     int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
+    int *axis_rank = nullptr;            // device, the LONG rank of every grid column, then the LAT rank of every grid row (publish_axis_ranks)
+    int axis_ncol = 0;
     double *lut_rt = nullptr;            // device, the same leaf values with every tree's levels ordered uniform-first
     int *lut_rt_meta = nullptr;          // device, LUT_RT_DW dwords per tree (gbm_lutreg_rt_kernel)
     unsigned *lut_cls = nullptr;         // device, 5 class words per tree (rank threshold << 3 | predictor; gbm_coherent_kernel)
@@ -1058,7 +1060,8 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
                                                             const void *__restrict__ sorted, const int *__restrict__ sorted_off,
                                                             int n_trees_padded, double init_f, int p, StackDev s, PredGeom g,
                                                             int tiles_per_row, double weight, int accumulate,
-                                                            double *__restrict__ out, int *__restrict__ probe, int tile16) {
+                                                            double *__restrict__ out, int *__restrict__ probe, int tile16,
+                                                            const int *__restrict__ axis_rank, int axis_ncol) {
     constexpr int S = 5, CH = LUT_CHUNK, CLS_STRIDE = 384, R = LUT_R;
     if (!PROBE && probe && !gbc_coherent_pays(probe)) return;
     if (PROBE) n_trees_padded = min(n_trees_padded, GBC_PROBE_CHUNKS * CH);
@@ -1104,7 +1107,11 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
     for (int j = 0; j < LUT_REG_P; ++j) {
         float r[R] = {0.f, 0.f, 0.f, 0.f};
         if (j < p) {
-            if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+            if (axis_rank && j >= s.C && !s.all_from_planes) {      // LONG / LAT ranks by table (publish_axis_ranks)
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+                    r[c] = (float)(j == s.C ? axis_rank[g.c0 + col[c]] : axis_rank[(int64_t)axis_ncol + g.r0 + row[c]]);
+            } else if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
             else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
         }
 #pragma unroll
@@ -1759,7 +1766,8 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix,
+                                                          const int *, int) {      // (rf_walk_ld_kernel's axis-rank table: same launch code)
     constexpr int R = rf_walks(LOG2R);
     constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // node records per thread in flight
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
@@ -1907,7 +1915,8 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
                                                           const int *__restrict__ sorted_off, int n_trees,
                                                           int p, StackDev s, PredGeom g,
                                                           double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int flags) {
+                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int flags,
+                                                          const int *__restrict__ axis_rank, int axis_ncol) {
     constexpr int R = rf_walks(LOG2R), WALKERS = 16 - NL;
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
     static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
@@ -1944,7 +1953,11 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     for (int c = 0; c < R; ++c) na[c] = false;
     for (int j = 0; j < p; ++j) {
         float r[R];
-        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        if (axis_rank && j >= s.C && !s.all_from_planes) {          // LONG / LAT: the rank is a function of the column / the row (publish_axis_ranks)
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+                r[c] = (float)(j == s.C ? axis_rank[g.c0 + col[c]] : axis_rank[(int64_t)axis_ncol + g.r0 + row[c]]);
+        } else if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
         else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
 #pragma unroll
         for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
@@ -2542,7 +2555,7 @@ enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomFores
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
 struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
-                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; };
+                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; const int *axis_rank = nullptr; int axis_ncol = 0; };
 
 // fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
 template <typename T>
@@ -2568,6 +2581,25 @@ static void sort_unique(std::vector<std::vector<KT>> &sorted, std::vector<int> &
     if (flat.empty()) flat.push_back((KT)0);
 }
 
+// Round 4: the ranks of the two coordinate predictors by table.  LONG's key is the grid column and LAT's minus the grid row
+// (lut_ranks_t), so rank = #{thresholds <= key} is a function of the column / of the row alone: one table entry per grid
+// column, then one per grid row, instead of a coarse-table staging, two barriers and ~18 search steps per cell and predictor
+// (two of cfg3's five predictors; the rank keys are 9 % of the forest kernel and 20 % of the coherent gbm kernel).
+template <typename KT>
+static int publish_axis_ranks(mhs_model *m, const std::vector<std::vector<KT>> &sorted, int C, const mhs_grid &grid) {
+    if (m->p != C + 2 || grid.ncol <= 0 || grid.nrow <= 0 || (int64_t)grid.ncol + grid.nrow > (1 << 26)) {
+        if (m->axis_rank) m->retired.push_back((void *)m->axis_rank);
+        m->axis_rank = nullptr; m->axis_ncol = 0;
+        return MHS_OK;
+    }
+    std::vector<int> ar((size_t)grid.ncol + (size_t)grid.nrow);
+    const std::vector<KT> &sl = sorted[(size_t)C], &st = sorted[(size_t)C + 1];
+    for (int64_t c = 0; c < grid.ncol; ++c) ar[(size_t)c] = (int)(std::upper_bound(sl.begin(), sl.end(), (KT)c) - sl.begin());
+    for (int64_t r = 0; r < grid.nrow; ++r) ar[(size_t)grid.ncol + (size_t)r] = (int)(std::upper_bound(st.begin(), st.end(), -(KT)r) - st.begin());
+    m->axis_ncol = (int)grid.ncol;
+    return publish(m, ar, &m->axis_rank);
+}
+
 // key-space thresholds of every split for this grid, the sorted distinct thresholds of each
 // predictor and every split's rank among them (see gbm_lut_kernel); cached per geometry and key type
 template <typename KT>
@@ -2589,6 +2621,7 @@ static int build_lut_meta_t(mhs_model *m, const mhs_grid &grid, int C) {
     sort_unique(sorted, off, flat);
     for (int v = 0; v < m->p; ++v)
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("gbm: too many distinct split values"); return MHS_ERR_INVALID; }
+    if (int rc = publish_axis_ranks(m, sorted, C, grid)) return rc;
     std::vector<int> meta((size_t)m->n_trees_padded * LUT_META_DW, 0);
     const float never = -33554432.f;   // c - rank <= 0 for every rank: the padded predicates read 0
     for (int t = 0; t < m->n_trees_padded; ++t) {
@@ -2664,7 +2697,7 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, 
         if (int rc = key64 ? build_lut_meta_t<double>(m, grid, C) : build_lut_meta_t<float>(m, grid, C)) return rc;
         m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
     }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr, nullptr, m->lut_rt, m->lut_rt_meta, m->lut_cls};
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, m->lut_meta, nullptr, nullptr, m->lut_rt, m->lut_rt_meta, m->lut_cls, m->axis_rank, m->axis_ncol};
     return MHS_OK;
 }
 
@@ -2757,12 +2790,14 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
             auto pk = key64 ? gbm_coherent_kernel<true, true> : gbm_coherent_kernel<false, true>;
             MHS_HIP(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
             hipLaunchKernelGGL(pk, dim3(GBC_PROBE_BLOCKS), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1);
+                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1,
+                               getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank, tt.axis_ncol);
         }
         auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
         hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1);
+                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1,
+                               getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank, tt.axis_ncol);
         if (!probe) return launch_gbm_na(m, s, g, w, acc, out, st, total);
     }
     if (rt_ok) {
@@ -2858,6 +2893,7 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     sort_unique(sorted, off, flat);
     for (int v = 0; v < m->p; ++v)
         if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
+    if (int rc = publish_axis_ranks(m, sorted, C, grid)) return rc;
     std::vector<unsigned long long> rec((nn ? nn : 1) + 3200, 0ull);     // + 25 600 bytes: rf_walk_ld_kernel's loaders read whole strides
     const unsigned R = (unsigned)rf_walks(log2r);
     if (form == RF_COMPACT) {
@@ -2916,7 +2952,8 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, 
         m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
         m->rf_log2r = log2r; m->rf_form = form;
     }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes, form == RF_COMPACT ? m->rf_coff : nullptr};
+    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes, form == RF_COMPACT ? m->rf_coff : nullptr, nullptr, nullptr, nullptr,
+                     m->axis_rank, m->axis_ncol};
     return MHS_OK;
 }
 
@@ -2961,9 +2998,11 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
                                      : MHS_TB(2, 25600);
 #undef MHS_TB
         MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
+        const int *axr = getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank;
         hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
                            m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles16 ? 2 : strips,
-                           (int)(strips && dmin && !getenv("MHS_RF_NO_PREFIX")) | (ld && getenv("MHS_RF_LD_FLAGS") ? atoi(getenv("MHS_RF_LD_FLAGS")) & ~1 : 0));
+                           (int)(strips && dmin && !getenv("MHS_RF_NO_PREFIX")) | (ld && getenv("MHS_RF_LD_FLAGS") ? atoi(getenv("MHS_RF_LD_FLAGS")) & ~1 : 0),
+                           axr, tt.axis_ncol);
         return MHS_OK;
     }
     if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane
@@ -3208,6 +3247,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->gbm_probe) (void)hipFree(m->gbm_probe);
     if (m->lut_sorted) (void)hipFree(m->lut_sorted);
     if (m->lut_sorted_off) (void)hipFree(m->lut_sorted_off);
+    if (m->axis_rank) (void)hipFree(m->axis_rank);
     if (m->rf_nodes) (void)hipFree(m->rf_nodes);
     if (m->rf_lval) (void)hipFree(m->rf_lval);
     if (m->rf_depth) (void)hipFree(m->rf_depth);

@@ -52,6 +52,7 @@ def rasters():
 
 
 variants = [("one loader wave (even trees through its registers, odd trees by LDS-DMA) + 15 walking waves of 16 x 16 cells (round 4 default)", {}),
+            ("the same with the LONG / LAT ranks searched like the covariates' (no per-column / per-row tables)", {"MHS_NO_AXIS_RANKS": "1"}),
             ("16 waves stage and walk (round 3: rf_walk_tb_kernel)", {"MHS_RF_NO_LOADER": "1"}),
             ("loader wave, walks start at the root", {"MHS_RF_NO_PREFIX": "1"}),
             ("two buffers + a barrier per tree, 5 walks (round 3's first half)", {"MHS_RF_DOUBLE_BUFFER": "1"}),
@@ -67,6 +68,7 @@ variants = [("one loader wave (even trees through its registers, odd trees by LD
 ]
 if member == "gbm":
     variants = [("coherent kernel, waves of 16 x 16 cells, device-side probe (round 4 default)", {}),
+                ("the same with the LONG / LAT ranks searched like the covariates'", {"MHS_NO_AXIS_RANKS": "1"}),
                 ("coherent kernel, waves of 64 x 4 cells, probe (round 3)", {"MHS_GBM_STRIP_WAVES": "1"}),
                 ("coherent kernel forced, 16 x 16", {"MHS_GBM_FORCE_COHERENT": "1"}),
                 ("coherent kernel forced, 64 x 4", {"MHS_GBM_FORCE_COHERENT": "1", "MHS_GBM_STRIP_WAVES": "1"}),
