@@ -2042,6 +2042,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     unsigned staged[3] = {0u, 0u, 0u};                             // cached counters: buffer b has held staged[b] trees so far
     int ocur = 0;                                                  // lane l: first record of tree 64 b + l
     unsigned wcur = 0u;                                            // lane l: its walk -- entry node's byte address | c0 << 19 | cnt << 25 | walks << 31
+    double tpcur = 0.0;                                            // lane l: the prediction of its tree's entry node where the wave does not walk the tree
     const int lane = threadIdx.x & 63;
     auto step = [&](auto slot_tag, auto pidx_tag, const int t, const unsigned k3) {      // k3 = t / 3
         constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
@@ -2060,10 +2061,13 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
             const int levels = ((ecur >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
             const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63: depth of a tree of <= 3 200 nodes
             wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
+            // a tree the wave does not walk (its cells share the entry node: two thirds of the trees on smooth rasters) has ONE
+            // prediction for all of them: fetched here, lane = tree, instead of by four 64-lane loads of one address in its step
+            tpcur = levels > 0 ? 0.0 : glval[ocur + (int)(ecur & 0xFFFFu)];
             // the loads are awaited HERE: left pending, hipcc puts s_waitcnt vmcnt(0) in front of every step's readlanes (it
             // cannot count the loads issued since around the loop) and every step then waits for the previous steps'
             // prediction loads as well
-            asm volatile("" : "+v"(ocur), "+v"(wcur));
+            asm volatile("" : "+v"(ocur), "+v"(wcur), "+v"(tpcur));
         }
         const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)wcur, t & 63);
         const int o = __builtin_amdgcn_readlane(ocur, t & 63);
@@ -2106,9 +2110,14 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(CNT + 16u + 4u * SLOT), "v"(1u) : "memory");
         const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];                  // tree t - (PD - 1)'s; still in tree order
-            pend[PIDX][c] = *(const double *)(lv + node[c]);             // (unconditional: behind a branch hipcc waits vmcnt(0) at once)
+        for (int c = 0; c < R; ++c) acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];      // tree t - (PD - 1)'s; still in tree order
+        if (wk >> 31) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) pend[PIDX][c] = *(const double *)(lv + node[c]);
+        } else {
+            const double tv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tpcur), t & 63), __builtin_amdgcn_readlane(__double2loint(tpcur), t & 63));
+#pragma unroll
+            for (int c = 0; c < R; ++c) pend[PIDX][c] = tv;
         }
     };
     static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
