@@ -350,6 +350,16 @@ def test_gbm_coherent_kernel_matches_the_tree_order_kernels_and_the_oracle(hip, 
     scale = float(ordered.abs().max())
     assert float((coh - ordered).abs().max()) <= 1e-13 * scale
     assert smooth or not torch.equal(coh, ordered)            # i.e. the switch did select another kernel
+    # round 4: the LONG / LAT ranks come from per-column / per-row tables (the same ranks: the same bits) and the wave tiles are
+    # 16 x 16 cells (round 3's 64 x 4 tiles: the same leaves in another order)
+    monkeypatch.setenv("MHS_NO_AXIS_RANKS", "1")
+    searched = hip.predict(stack, m, window=win)
+    monkeypatch.delenv("MHS_NO_AXIS_RANKS")
+    assert torch.equal(searched, coh)
+    monkeypatch.setenv("MHS_GBM_STRIP_WAVES", "1")
+    strips = hip.predict(stack, m, window=win)
+    monkeypatch.delenv("MHS_GBM_STRIP_WAVES")
+    assert float((strips - ordered).abs().max()) <= 1e-13 * scale
     want = oe.predict(prm, X).reshape(g.nrow, g.ncol)[r0:r1, c0:c1]
     got = coh.cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -415,6 +425,7 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
                  {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
                  {"MHS_RF_STRIP_WAVES": "1"}, {"MHS_RF_TWO_LOADERS": "1"}, {"MHS_RF_LD_FLAGS": "64"}, {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_TWO_LOADERS": "1"},
+                 {"MHS_NO_AXIS_RANKS": "1"}, {"MHS_NO_AXIS_RANKS": "1", "MHS_RF_STRIP_WAVES": "1"},      # LONG / LAT ranks searched, not read from the per-column / per-row tables
                  {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_TWO_LOADERS": "1", "MHS_RF_FULL_DEPTH": "1"},
                  {"MHS_RF_NO_LOADER": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_NO_PREFIX": "1"},
                  {"MHS_RF_NO_LOADER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FAR_WALKS": "1"},
