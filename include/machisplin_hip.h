@@ -76,7 +76,9 @@ typedef struct mhs_model mhs_model;  /* one fitted ensemble member */
 MHS_API const char *mhs_last_error(void);
 MHS_API const char *mhs_version(void);
 /* select HIP device `device`, create the library stream, upload constant tables.
- * Idempotent for the same device; MHS_ERR_NODEVICE if there is no GPU. */
+ * Idempotent for the same device; MHS_ERR_NODEVICE if there is no GPU.  Several devices from one
+ * process: mhs_init_devices (section "several devices"); mhs_init(d) is mhs_init_devices(1, &d)
+ * and leaves an earlier mhs_init_devices whose slot 0 sits on d untouched. */
 MHS_API int mhs_init(int device);
 MHS_API int mhs_shutdown(void);
 MHS_API int mhs_device_count(int *count);
@@ -375,6 +377,97 @@ MHS_API int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const doubl
                                 const double *cov1_at_stations, int64_t tile_edge, double lambda,
                                 int gcv_mode, double *out_dev, int64_t ld, int64_t *tiles_out,
                                 void *stream);
+
+/* ------------------------------------------------------------ several devices --
+ * ONE host process drives 1..16 devices ("mhs_init(int n_devices) ... library may use internal host
+ * threads + HIP streams (one per GPU)"; the reference's host is a single-threaded R session, V73:117).  The reference
+ * side: machisplin.tiles.create -> machisplin.mltps per tile -> machisplin.tiles.merge (README.md:157-215,
+ * V73:1165-1256, 1392-1548) and the cell-wise independence of machisplin.mltps Steps 2-5 (V73:442-930).
+ *
+ * mhs_init_devices(n, ids) brings up device SLOTS 0..n-1 on the physical devices ids[k] (NULL = 0..n-1).  Ids may
+ * repeat: several slots on one GPU run every code path below on a one-GPU box (the collective then degrades to device
+ * copies, because RCCL refuses two ranks on one device).  Every entry point declared ABOVE this section keeps working on
+ * slot 0 (mhs_init(d) == mhs_init_devices(1, &d)); model and spline handles made there are replicated onto the other
+ * slots by the calls below, on first use, and the replicas are freed with the handle.                               */
+MHS_API int mhs_init_devices(int n_devices, const int *device_ids);
+MHS_API int mhs_device_slots(int *n_slots, int *device_ids /* may be NULL; room for 16 */);
+
+/* covariate planes cut into row bands, band k resident on slot k (cuts at multiples of 16 rows) */
+typedef struct mhs_multi_stack mhs_multi_stack;
+/* slot0_share: the share of the rows slot 0 takes -- it also carries the spline fit; NaN = equal bands */
+MHS_API int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share,
+                                   mhs_multi_stack **out);
+MHS_API int mhs_multi_stack_free(mhs_multi_stack *ms);
+MHS_API int mhs_multi_stack_bands(const mhs_multi_stack *ms, int *n_slots, int64_t *r0 /* 16 */, int64_t *r1 /* 16 */);
+
+typedef struct mhs_mltps_info {
+    double rsq_model, rsq_final;       /* rsq.model / rsq.final (V73:917-925) */
+    double lambda;                     /* the global fit's lambda (NaN with the reference-tiled Step 3) */
+    int64_t n_knots;                   /* ... and its unique knots */
+    int64_t tiles_rows, tiles_cols;    /* Step-3 tile layout (1 x 1 = global fit) */
+    int32_t used_tps;                  /* 1: final = pred.elev + final.TPS; 0: pred.elev alone (V73:925-930) */
+    int32_t n_slots;
+    int32_t collective;                /* 0 none (host output), 1 RCCL all-gather, 2 peer copies (aliased slots / no librccl) */
+    int32_t reserved_;
+    int64_t band_r0[16], band_r1[16];  /* rows of every slot */
+    double band_ms[16];                /* device time of every slot's ensemble band (HIP events) */
+    double tiles_ms[16];               /* reference-tiled Step 3: wall time of every slot's tile fits + evaluations */
+    double fit_ms;                     /* wall time of the global spline fit on slot 0 */
+    double step_ms;                    /* wall time of the whole call */
+    double upload_ms, download_ms;     /* mhs_mltps_grid_multi only: host <-> device */
+    double suggested_slot0_share;      /* the slot0_share that would have balanced THIS step (NaN if undetermined) */
+} mhs_mltps_info;
+
+/* machisplin.mltps Steps 2-5 for one response layer (V73:442-930) over the device slots: ensemble on every band;
+ * res.FINAL at the stations and the fields::Tps fit on slot 0 (tile_edge <= 0 or one tile: the global fit of V73:748-753;
+ * otherwise the reference's tiles dealt over the slots by cost, V73:636-747); every slot evaluates the spline on its rows
+ * with the WHOLE grid's evaluation plan, sums, reads its stations' cells; rsq.final > rsq.model selects the sum (V73:925).
+ * X is the n x p station table dat_tps (column-major: covariates, LONG, LAT -- cell-centre coordinates), complete cases
+ * only (V73:154).  gather != 0: ONE all-gather (RCCL over xGMI) stitches the final plane on every device
+ * (mhs_multi_final_dev).  The N-slot planes equal the one-slot planes bit for bit.                                   */
+MHS_API int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weights, int n_models,
+                                     double wt_total, mhs_multi_stack *ms, const double *X, const double *resp,
+                                     int64_t n, int64_t tile_edge, double lambda, int gcv_mode, int gather,
+                                     mhs_mltps_info *info /* may be NULL */);
+/* the last step's final plane: every slot's rows down its own PCIe link into final_host (nrow x ncol, row-major) */
+MHS_API int mhs_multi_final_download(const mhs_multi_stack *ms, double *final_host);
+/* ... or its device pointers on one slot: the slot's rows (band_dev, ld = ncol) and, after gather, the whole grid */
+MHS_API int mhs_multi_final_dev(const mhs_multi_stack *ms, int slot, double **band_dev, int64_t *r0, int64_t *r1,
+                                double **full_dev);
+/* Host planes in, host plane out, ONE call: what the R shim binds in place of V73:447-930 for a layer (upload of the
+ * bands, the steps above, download).  slot0_share NaN = automatic (equal bands, then what the last call of the same
+ * shape measured).                                                                                                   */
+MHS_API int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, int n_models, double wt_total,
+                                 const mhs_grid *g, const mhs_stack *covars_host, const double *X, const double *resp,
+                                 int64_t n, int64_t tile_edge, double lambda, int gcv_mode, double slot0_share,
+                                 double *final_host, mhs_mltps_info *info /* may be NULL */);
+
+/* One (tile, layer) run of machisplin.tiles.* (README.md:157-215): the fitted members of that tile and layer and the
+ * tile's station table (complete cases; X n x p column-major with cell-centre LONG / LAT of the TILE's raster).        */
+typedef struct mhs_unit {
+    const mhs_model *const *models;
+    const double *weights;
+    int32_t n_models, reserved_;
+    double wt_total;
+    const double *X, *resp;
+    int64_t n;
+} mhs_unit;
+typedef struct mhs_units_info {
+    int32_t n_slots, reserved_;
+    int64_t n_units;
+    double step_ms, unit_ms_sum, unit_ms_max;
+    double slot_ms[16];                /* sum of the unit times per slot */
+} mhs_units_info;
+/* machisplin.tiles.create (out_ncol x out_nrow tiles, feather_d pixels of overlap, V73:1165-1256) -> machisplin.mltps
+ * Steps 2-5 per tile and response layer -> machisplin.tiles.merge per layer (V73:1392-1548), over the device slots:
+ * unit u = layer * n_tiles + tile (tiles row-major from the south-west) runs on slot u mod N with no exchange; layer l is
+ * merged on slot l mod N (its tiles arrive over xGMI) and lands in merged_host[l] (nrow x ncol; a NULL entry skips the
+ * layer's merge).  units[u] as above; tps = 0 returns pred.elev alone (V73:934-953); rsq (may be NULL) receives
+ * rsq.model, rsq.final per unit.                                                                                     */
+MHS_API int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_host, int64_t out_ncol, int64_t out_nrow,
+                                  double feather_d, int n_layers, const mhs_unit *units, int tps, int64_t tile_edge,
+                                  double lambda, int gcv_mode, double *const *merged_host, double *rsq,
+                                  mhs_units_info *info /* may be NULL */);
 
 /* ------------------------------------------------------------- raster wire formats --
  * the formats on either side of the path.  Covariates arrive

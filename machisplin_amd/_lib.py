@@ -44,6 +44,27 @@ class TiffInfo(C.Structure):
                 ("yres", C.c_double)]
 
 
+class MltpsInfo(C.Structure):
+    """struct mhs_mltps_info"""
+    _fields_ = [("rsq_model", C.c_double), ("rsq_final", C.c_double), ("lambda_", C.c_double), ("n_knots", C.c_int64),
+                ("tiles_rows", C.c_int64), ("tiles_cols", C.c_int64), ("used_tps", C.c_int32), ("n_slots", C.c_int32),
+                ("collective", C.c_int32), ("reserved_", C.c_int32), ("band_r0", C.c_int64 * 16), ("band_r1", C.c_int64 * 16),
+                ("band_ms", C.c_double * 16), ("tiles_ms", C.c_double * 16), ("fit_ms", C.c_double), ("step_ms", C.c_double),
+                ("upload_ms", C.c_double), ("download_ms", C.c_double), ("suggested_slot0_share", C.c_double)]
+
+
+class Unit(C.Structure):
+    """struct mhs_unit"""
+    _fields_ = [("models", C.POINTER(C.c_void_p)), ("weights", C.POINTER(C.c_double)), ("n_models", C.c_int32),
+                ("reserved_", C.c_int32), ("wt_total", C.c_double), ("X", C.c_void_p), ("resp", C.c_void_p), ("n", C.c_int64)]
+
+
+class UnitsInfo(C.Structure):
+    """struct mhs_units_info"""
+    _fields_ = [("n_slots", C.c_int32), ("reserved_", C.c_int32), ("n_units", C.c_int64), ("step_ms", C.c_double),
+                ("unit_ms_sum", C.c_double), ("unit_ms_max", C.c_double), ("slot_ms", C.c_double * 16)]
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -123,6 +144,19 @@ SIGNATURES = {
     "mhs_tps_tiles_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64, _vp]),
     "mhs_tps_surface_dev": (C.c_int, [C.POINTER(Grid), _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _i64,
                                       _vp, _vp]),
+    "mhs_init_devices": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "mhs_device_slots": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mhs_multi_stack_create": (C.c_int, [C.POINTER(Grid), C.POINTER(Stack), C.c_double, C.POINTER(_vp)]),
+    "mhs_multi_stack_free": (C.c_int, [_vp]),
+    "mhs_multi_stack_bands": (C.c_int, [_vp, C.POINTER(C.c_int), _vp, _vp]),
+    "mhs_mltps_grid_multi_dev": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, _vp, _vp, _vp, _i64, _i64, C.c_double,
+                                           C.c_int, C.c_int, C.POINTER(MltpsInfo)]),
+    "mhs_multi_final_download": (C.c_int, [_vp, _vp]),
+    "mhs_multi_final_dev": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp)]),
+    "mhs_mltps_grid_multi": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, C.POINTER(Grid), C.POINTER(Stack), _vp, _vp,
+                                       _i64, _i64, C.c_double, C.c_int, C.c_double, _vp, C.POINTER(MltpsInfo)]),
+    "mhs_tiles_units_multi": (C.c_int, [C.POINTER(Grid), C.POINTER(Stack), _i64, _i64, C.c_double, C.c_int, C.POINTER(Unit),
+                                        C.c_int, _i64, C.c_double, C.c_int, C.POINTER(_vp), _vp, C.POINTER(UnitsInfo)]),
 }
 
 _lock = threading.Lock()

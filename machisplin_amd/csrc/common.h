@@ -74,10 +74,30 @@ struct Context {
     std::vector<uint32_t> comp_mask;      // the reserved units' mask (for lanes created later)
     hipEvent_t mask_ev0 = nullptr, mask_ev1 = nullptr;
 };
-std::mutex &pipe_mutex();             // one pipelined host-pointer call at a time
+// Device slots (round 5): the library drives up to MAX_SLOTS devices from ONE host process (what a single-threaded R
+// session needs, SURVEY.md 8b: "library may use internal host threads + HIP streams (one per GPU)").  A slot = one
+// Context (streams, arenas, pools, caches) bound to one physical device; several slots may name the same physical
+// device (that is how the multi-device drivers are tested on a one-GPU box).  Every host thread has a CURRENT slot
+// (thread-local, 0 by default -- the only slot mhs_init() creates): ctx(), pipe_mutex(), mask_mutex(), the block pool
+// and the reduction cache all resolve through it.  A thread the library starts inherits its parent's slot explicitly
+// (SlotBind), because both the slot and HIP's current device are per-thread state.
+constexpr int MAX_SLOTS = 16;
+int current_slot();
+int slot_count();                     // slots initialised by mhs_init / mhs_init_devices
+int bind_slot(int slot);              // make `slot` this thread's current slot and its device HIP's current device
+struct SlotBind {                     // RAII: bind for a scope, restore the previous slot (and device) on exit
+    int prev;
+    explicit SlotBind(int slot) : prev(current_slot()) { (void)bind_slot(slot); }
+    ~SlotBind() { (void)bind_slot(prev); }
+    SlotBind(const SlotBind &) = delete;
+    SlotBind &operator=(const SlotBind &) = delete;
+};
+std::mutex &pipe_mutex();             // one pipelined host-pointer call at a time (per slot)
 int host_pipe(size_t arena_bytes);    // streams / events on first use; grows the arena (grow-only) to at least arena_bytes
-std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences
-Context &ctx();
+std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences (per slot)
+std::mutex &mosaic_mutex();           // one user of the slot's mosaic arena at a time
+Context &ctx();                       // the current slot's context
+Context &ctx_slot(int slot);
 int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)
 // mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
@@ -90,7 +110,8 @@ void *pool_alloc(size_t bytes);
 void pool_release(void *p);
 void pool_clear();
 int require_ready();
-void reduction_cache_clear();           // tps_fit.hip: drop every cached reduction (mhs_shutdown)
+void reduction_cache_clear();           // tps_fit.hip: drop every cached reduction of the current slot (mhs_shutdown)
+void multi_reset();                     // multi.hip: drop the multi-device drivers' per-slot state (mhs_shutdown, mhs_init_devices)
 // Blocking host -> device copy that does NOT go through the NULL stream: a plain hipMemcpy synchronises with every
 // blocking stream -- the CU-masked streams of mhs_fit_reserve_cus are blocking ones, so it would wait for the forest.
 int h2d_sync(void *dst, const void *src, size_t bytes);
@@ -126,6 +147,19 @@ struct mhs_tps;
 namespace mhs {
 int upload_knots(mhs_tps *t);  // (re)build t->knots_dev from t->c / t->knots_uv
 int tps_free_quiet(mhs_tps *t);   // mhs_tps_free without its device-wide wait (the caller has synchronised)
+// rows [b0, b1) of the window [r0, r1) x [c0, c1) with the window's own plan (tps_eval.hip); out_dev holds row b0 first
+int tps_predict_rows_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                         int64_t b0, int64_t b1, double *out_dev, int64_t ld, void *stream);
+}
+
+struct mhs_model;
+namespace mhs {
+// ensemble.hip: the handle's twin on device slot `slot` (built on first use; owned by the handle)
+int model_on_slot(const mhs_model *m, int slot, const mhs_model **out);
+// ensemble.hip: pred.elev on grid rows [b0, b1) from a device buffer holding only those rows of every plane
+int ensemble_band_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
+                      const void *band_data, int n_layers, int dtype, int64_t ld, double nodata, int64_t b0, int64_t b1,
+                      double *out_dev, int64_t ld_out, hipStream_t st);
 }
 
 // fitted spline handle (opaque to callers)

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -120,6 +121,12 @@ struct mhs_model {
     int *rf_coff = nullptr;                  // device, n_trees + 1 record offsets of the COMPACT form
     int rf_cmax = 0;                         // COMPACT: most records in a tree (its split nodes + 1)
     int rf_compact_ok = 0;                   // every tree's leaf codes fit 16 bits (8 * splits + nodes <= 65535)
+    // Several device slots (mhs_init_devices): the buffers above live on ONE device.  The handle remembers the loader
+    // call that built it (with copies of its flat arrays) and the multi-device drivers build a replica per slot on
+    // first use (model_on_slot); replicas are owned by the handle and freed with it.
+    int slot = 0, device = -1;               // where the buffers above live
+    std::function<int(mhs_model **)> reload;
+    mhs_model *replica[mhs::MAX_SLOTS] = {};
 };
 
 namespace mhs {
@@ -3233,6 +3240,55 @@ static int make_geom(const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int6
     return MHS_OK;
 }
 
+// pred.elev on rows [b0, b1) of the grid from a device buffer that holds ONLY those rows of every covariate plane (plane k
+// at band_data + k * (b1 - b0) * ld elements): the device copy is described with the PARENT grid's affine, so cell centres --
+// and with them every member's value -- are those of the one-piece evaluation (multi.hip: one row band per device).
+int ensemble_band_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
+                      const void *band_data, int n_layers, int dtype, int64_t ld, double nodata, int64_t b0, int64_t b1,
+                      double *out_dev, int64_t ld_out, hipStream_t st) {
+    MHS_REQUIRE(models && weights && n_models >= 1 && g && band_data && out_dev, "bad ensemble arguments");
+    MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
+    MHS_REQUIRE(dtype == MHS_F64 || dtype == MHS_F32 || dtype == MHS_I16, "bad stack dtype");
+    for (int k = 0; k < n_models; ++k)
+        MHS_REQUIRE(models[k] && n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
+    if (b1 == b0) return MHS_OK;
+    const size_t esz = dtype == MHS_F64 ? 8 : dtype == MHS_F32 ? 4 : 2;
+    PredGeom pg;
+    if (int rc = make_geom(g, b0, b1, 0, g->ncol, ld_out, &pg)) return rc;
+    StackDev sd;
+    sd.data = (const char *)band_data - (size_t)b0 * ld * esz; sd.C = n_layers; sd.dtype = dtype;
+    sd.plane_stride = (b1 - b0) * ld; sd.ld = ld; sd.nodata = nodata;
+    sd.has_nodata = !std::isnan(nodata); sd.all_from_planes = 0;
+    if (int rc = launch_members(models, weights, n_models, sd, pg, 0, out_dev, st, g)) return rc;
+    const int64_t total = (b1 - b0) * g->ncol;
+    hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out_dev, (int)(b1 - b0),
+                       (int)g->ncol, ld_out, wt_total);
+    MHS_HIP(hipGetLastError());
+    return MHS_OK;
+}
+
+// The handle's twin on another device slot, built on first use from the remembered loader call.
+int model_on_slot(const mhs_model *m, int slot, const mhs_model **out) {
+    MHS_REQUIRE(m && out && slot >= 0 && slot < MAX_SLOTS, "bad arguments");
+    const int dev = ctx_slot(slot).device;
+    if (m->slot == slot && m->device == dev) { *out = m; return MHS_OK; }
+    mhs_model *w = const_cast<mhs_model *>(m);
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (w->replica[slot] && w->replica[slot]->device != dev) {      // the slots were re-initialised on other devices
+        mhs_model_free(w->replica[slot]);
+        w->replica[slot] = nullptr;
+    }
+    if (!w->replica[slot]) {
+        MHS_REQUIRE((bool)w->reload, "model handle cannot be replicated");
+        SlotBind bind(slot);
+        mhs_model *r = nullptr;
+        if (int rc = w->reload(&r)) return rc;
+        w->replica[slot] = r;
+    }
+    *out = w->replica[slot];
+    return MHS_OK;
+}
+
 }  // namespace mhs
 
 using namespace mhs;
@@ -3241,6 +3297,7 @@ extern "C" {
 
 int mhs_model_free(mhs_model *m) {
     if (!m) return MHS_OK;
+    for (mhs_model *&r : m->replica) if (r) { mhs_model_free(r); r = nullptr; }
     if (m->dpar) (void)hipFree(m->dpar);
     if (m->ipar) (void)hipFree(m->ipar);
     if (m->nodes) (void)hipFree(m->nodes);
@@ -3273,6 +3330,8 @@ int mhs_lm_load(const double *coef, int p, mhs_model **out) {
     mhs_model *m = new mhs_model();
     m->kind = K_LM; m->p = p;
     if (int rc = to_device(coef, (size_t)p + 1, &m->dpar)) { mhs_model_free(m); return rc; }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [v = std::vector<double>(coef, coef + p + 1), p](mhs_model **o) { return mhs_lm_load(v.data(), p, o); };
     *out = m;
     return MHS_OK;
 }
@@ -3284,6 +3343,10 @@ int mhs_nnet_load(const double *wts, int p, int size, double y_scale, double y_s
     mhs_model *m = new mhs_model();
     m->kind = K_NNET; m->p = p; m->n0 = size; m->s0 = y_scale; m->s1 = y_shift;
     if (int rc = to_device(wts, (size_t)(p + 1) * size + size + 1, &m->dpar)) { mhs_model_free(m); return rc; }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [v = std::vector<double>(wts, wts + (size_t)(p + 1) * size + size + 1), p, size, y_scale, y_shift](mhs_model **o) {
+        return mhs_nnet_load(v.data(), p, size, y_scale, y_shift, o);
+    };
     *out = m;
     return MHS_OK;
 }
@@ -3312,6 +3375,11 @@ int mhs_earth_load(const double *coef, const int32_t *dirs, const double *cuts, 
     int rc = to_device(dp.data(), dp.size(), &m->dpar);
     if (!rc) rc = to_device(ip.data(), ip.size(), &m->ipar);
     if (rc) { mhs_model_free(m); return rc; }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [c = std::vector<double>(coef, coef + nterms), d = std::vector<int32_t>(dirs, dirs + (size_t)nterms * p),
+                 q = std::vector<double>(cuts, cuts + (size_t)nterms * p), nterms, p](mhs_model **o) {
+        return mhs_earth_load(c.data(), d.data(), q.data(), nterms, p, o);
+    };
     *out = m;
     return MHS_OK;
 }
@@ -3353,6 +3421,12 @@ int mhs_svr_load(const double *alpha, const double *sv, int64_t nsv, int p, doub
     m->kind = K_SVR; m->p = p; m->n0 = (int)nkeep; m->n1 = stride; m->n2 = npos; m->s4 = amax;
     m->s0 = b; m->s1 = sigma; m->s2 = y_center; m->s3 = y_scale;
     if (int rc = to_device(h.data(), h.size(), &m->dpar)) { mhs_model_free(m); return rc; }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [a = std::vector<double>(alpha, alpha + nsv), v = std::vector<double>(sv, sv + (size_t)nsv * p), nsv, p, b, sigma,
+                 xc = std::vector<double>(x_center, x_center + p), xs = std::vector<double>(x_scale, x_scale + p), y_center,
+                 y_scale](mhs_model **o) {
+        return mhs_svr_load(a.data(), v.data(), nsv, p, b, sigma, xc.data(), xs.data(), y_center, y_scale, o);
+    };
     *out = m;
     return MHS_OK;
 }
@@ -3425,6 +3499,13 @@ int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets, co
         if (int rc = to_device(lut.data(), lut.size(), &m->lut)) { mhs_model_free(m); return rc; }
         m->lut_host = std::move(lut);
     }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [init_f, n_trees, to = std::vector<int64_t>(tree_offsets, tree_offsets + n_trees + 1),
+                 sv = std::vector<int32_t>(split_var, split_var + nn), sl = std::vector<double>(split_val, split_val + nn),
+                 l = std::vector<int32_t>(left, left + nn), r = std::vector<int32_t>(right, right + nn),
+                 ms = std::vector<int32_t>(missing, missing + nn), p](mhs_model **o) {
+        return mhs_gbm_load(init_f, n_trees, to.data(), sv.data(), sl.data(), l.data(), r.data(), ms.data(), p, o);
+    };
     *out = m;
     return MHS_OK;
 }
@@ -3517,6 +3598,13 @@ int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *lef
             if (rc) { mhs_model_free(m); return rc; }
         }
     }
+    m->slot = current_slot(); m->device = ctx().device;
+    m->reload = [n_trees, to = std::vector<int64_t>(tree_offsets, tree_offsets + n_trees + 1), l = std::vector<int32_t>(left, left + nn),
+                 r = std::vector<int32_t>(right, right + nn), st = std::vector<int32_t>(status, status + nn),
+                 bv = std::vector<int32_t>(best_var, best_var + nn), sp = std::vector<double>(split, split + nn),
+                 np_ = std::vector<double>(node_pred, node_pred + nn), p](mhs_model **o) {
+        return mhs_rf_load(n_trees, to.data(), l.data(), r.data(), st.data(), bv.data(), sp.data(), np_.data(), p, o);
+    };
     *out = m;
     return MHS_OK;
 }

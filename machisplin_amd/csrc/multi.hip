@@ -1,0 +1,869 @@
+// Several devices behind the C ABI (round 5): ONE host process -- the single-threaded R session of the reference
+// (V73:117 forces n.cores = 1) -- drives 1..16 MI355X through one call.
+//
+// The reference side of this is README.md:157-215 (machisplin.tiles.create -> machisplin.mltps per tile ->
+// machisplin.tiles.merge; "embarrassingly parallel" tiles) and machisplin.mltps Steps 2-5 themselves (V73:442-930), whose
+// cells are independent given the fitted members and the spline coefficients.  Two drivers:
+//
+//   * ROW BANDS (mhs_mltps_grid_multi*, BASELINE configs 3 and 5): the grid is cut into contiguous row bands, one per
+//     device slot (cuts at multiples of 16 rows, the tile height of gbm's coherent kernel).  A host thread per slot
+//     uploads its band of the covariates, predicts the ensemble on it, slot 0 also computes the station residuals and fits
+//     the spline (its band is made shorter by slot0_share), every slot evaluates the spline on ITS band with the whole
+//     grid's evaluation plan and adds.  The coefficient "broadcast" is a host-memory hand-over (one process).  The output
+//     goes either straight down every device's own PCIe link into the caller's host plane, or -- `gather` -- is stitched
+//     on every device by ONE RCCL all-gather over xGMI (chunks of equal height, slot 0's rows parked at the end of its
+//     chunk, so the gathered chunks ARE the grid in place).  With the reference-tiled Step 3 (tile_edge > 0) the tiles are
+//     dealt over the slots by cost and travel with the bands.
+//   * (TILE, LAYER) UNITS (mhs_tiles_units_multi, BASELINE config 4): machisplin.tiles.create's user tiles x response
+//     layers as independent mltps runs, unit u = layer * n_tiles + tile on slot u mod N, no exchange while units run; a
+//     layer's tile planes are then brought to the layer's owner (l mod N) -- peer copies over xGMI, the same data movement
+//     an all-gather restricted to the owner makes -- merged (machisplin.tiles.merge) and written to the caller's plane.
+//
+// Slots may alias one physical device (mhs_init_devices with repeated ids): every code path above then runs on a one-GPU
+// box -- peer copies become device copies, and the RCCL step, which refuses two ranks on one device, is replaced by the
+// same copies.  tests/test_multi_gpu.py compares 2 / 4 slots on GPU 0 with the one-device planes bit for bit.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "common.h"
+
+using namespace mhs;
+
+namespace {
+
+constexpr int64_t BAND_ROWS_ALIGN = 16;      // = ensemble.hip's BAND_ALIGN: bands of whole coherent-kernel tiles
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------- per-slot resources --
+struct MultiSlot {
+    hipStream_t s = nullptr;                 // the band work of this slot (non-blocking)
+    hipEvent_t e0 = nullptr, e1 = nullptr;   // timing of the band kernels
+};
+MultiSlot g_ms[MAX_SLOTS];
+std::mutex g_ms_mu;
+
+int multi_slot(int slot, MultiSlot **out) {   // call with the thread bound to `slot`
+    std::lock_guard<std::mutex> lk(g_ms_mu);
+    MultiSlot &m = g_ms[slot];
+    if (!m.s) {
+        MHS_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
+        MHS_HIP(hipEventCreate(&m.e0));
+        MHS_HIP(hipEventCreate(&m.e1));
+    }
+    *out = &m;
+    return MHS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- RCCL --
+// Bound at run time (dlopen): the library has no link-time dependency on librccl, and a Python host has torch's copy of
+// the same soname mapped already.  Single-process, one communicator per slot (ncclCommInitAll), one thread per slot.
+typedef void *nccl_comm;
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(nccl_comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    nccl_comm comm[MAX_SLOTS] = {};
+    int n = 0;                                // communicators live for this many slots
+    bool tried = false, usable = false;
+    std::string why;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+constexpr int NCCL_FLOAT64 = 8;               // ncclFloat64 / ncclDouble (rccl.h: ncclDataType_t)
+
+// true when every slot sits on a device of its own (RCCL refuses two ranks on one device)
+bool slots_distinct() {
+    const int n = slot_count();
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (ctx_slot(a).device == ctx_slot(b).device) return false;
+    return true;
+}
+
+// communicators for the current slots, or `usable = false` with the reason (aliased slots, library missing)
+void rccl_prepare() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    const int n = slot_count();
+    if (g_rccl.tried && g_rccl.n == n) return;
+    g_rccl.tried = true; g_rccl.usable = false; g_rccl.n = n;
+    if (n < 2) { g_rccl.why = "one slot"; return; }
+    if (!slots_distinct()) { g_rccl.why = "slots share a physical device (RCCL needs one device per rank): peer copies instead"; return; }
+    if (getenv("MHS_MULTI_NO_RCCL")) { g_rccl.why = "MHS_MULTI_NO_RCCL is set: peer copies instead"; return; }
+    if (!g_rccl.h) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.h) break;
+        }
+        if (!g_rccl.h) { g_rccl.why = std::string("librccl not found: ") + dlerror(); return; }
+        g_rccl.CommInitAll = (int (*)(nccl_comm *, int, const int *))dlsym(g_rccl.h, "ncclCommInitAll");
+        g_rccl.CommDestroy = (int (*)(nccl_comm))dlsym(g_rccl.h, "ncclCommDestroy");
+        g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, nccl_comm, hipStream_t))dlsym(g_rccl.h, "ncclAllGather");
+        g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.h, "ncclGetErrorString");
+        if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.why = "librccl lacks ncclCommInitAll / ncclAllGather"; return; }
+    }
+    int devs[MAX_SLOTS];
+    for (int k = 0; k < n; ++k) devs[k] = ctx_slot(k).device;
+    const int rc = g_rccl.CommInitAll(g_rccl.comm, n, devs);
+    if (rc != 0) {
+        g_rccl.why = std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return;
+    }
+    g_rccl.usable = true;
+    g_rccl.why = "rccl";
+}
+
+void rccl_reset() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.usable && g_rccl.CommDestroy)
+        for (int k = 0; k < g_rccl.n; ++k) if (g_rccl.comm[k]) { (void)g_rccl.CommDestroy(g_rccl.comm[k]); g_rccl.comm[k] = nullptr; }
+    g_rccl.tried = g_rccl.usable = false;
+    g_rccl.n = 0;
+}
+
+// --------------------------------------------------------------------------------------- thread team --
+struct Barrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    uint64_t phase = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t ph = phase;
+        if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); }
+        else cv.wait(lk, [&] { return phase != ph; });
+    }
+};
+
+// One host thread per slot runs `body(slot)`; the first failure's status and message are carried to the caller.  A body
+// must pass every barrier it shares with the others even after a failure (Team::failed() says when to skip the work).
+struct Team {
+    int n;
+    Barrier bar;
+    std::atomic<int> rc{MHS_OK};
+    std::mutex err_mu;
+    std::string err;
+    explicit Team(int n_) : n(n_), bar(n_) {}
+    bool failed() const { return rc.load() != MHS_OK; }
+    void fail(int code) {
+        int expected = MHS_OK;
+        if (rc.compare_exchange_strong(expected, code)) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            err = mhs_last_error();              // thread-local in the worker
+        }
+    }
+    template <typename F>
+    int run(F body) {
+        const int home = current_slot();
+        std::vector<std::thread> th;
+        auto wrap = [&](int slot) {
+            SlotBind bind(slot);
+            body(slot);
+        };
+        for (int k = 1; k < n; ++k) th.emplace_back(wrap, k);
+        wrap(0);
+        for (std::thread &t : th) t.join();
+        (void)bind_slot(home);
+        if (failed()) { set_error("%s", err.c_str()); return rc.load(); }
+        return MHS_OK;
+    }
+};
+
+// `step` only if nobody has failed yet; a failure is recorded
+#define TEAM_DO(team, expr)                                      \
+    do {                                                         \
+        if (!(team).failed()) { const int rc_ = (expr); if (rc_ != MHS_OK) (team).fail(rc_); } \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ row bands --
+// Chunks of `band` rows, one per slot; slot 0 may hold fewer (n0) -- its rows sit at the END of its chunk, `lead` rows in
+// -- so that chunk k starts at grid row k * band - lead and equal-sized chunks tile the grid (sharded.row_bands).
+struct BandPlan {
+    int64_t band = 0, lead = 0;
+    std::vector<int64_t> r0, r1;
+};
+
+BandPlan plan_bands(int64_t nrow, int n, double slot0_share) {
+    BandPlan p;
+    p.r0.assign((size_t)n, 0); p.r1.assign((size_t)n, 0);
+    if (n == 1) { p.band = nrow; p.r1[0] = nrow; return p; }
+    const int64_t even = (nrow + n - 1) / n;
+    const int64_t align = even >= BAND_ROWS_ALIGN ? BAND_ROWS_ALIGN : 1;
+    auto up = [&](int64_t v) { return (v + align - 1) / align * align; };
+    auto equal = [&] {
+        p.band = up(even); p.lead = 0;
+        for (int k = 0; k < n; ++k) { p.r0[(size_t)k] = std::min<int64_t>(k * p.band, nrow); p.r1[(size_t)k] = std::min<int64_t>((k + 1) * p.band, nrow); }
+    };
+    if (std::isnan(slot0_share)) { equal(); return p; }
+    const double sh = std::min(std::max(slot0_share, 0.0), 1.0);
+    int64_t n0 = std::min<int64_t>(nrow, (int64_t)llround(sh * (double)nrow / (double)align) * align);
+    const int64_t rest = nrow - n0, others = n - 1;
+    const int64_t h = up((rest + others - 1) / others);
+    if (n0 > h) { equal(); return p; }          // slot 0 must not be the tallest band
+    p.band = std::max(h, n0); p.lead = p.band - n0;
+    p.r0[0] = 0; p.r1[0] = n0;
+    for (int k = 1; k < n; ++k) {
+        p.r0[(size_t)k] = std::min<int64_t>(n0 + (k - 1) * h, nrow);
+        p.r1[(size_t)k] = std::min<int64_t>(n0 + k * h, nrow);
+    }
+    // chunk k (k >= 1) starts at grid row n0 + (k - 1) h = k band - lead only when h == band: true unless n0 > h (handled)
+    return p;
+}
+
+}  // namespace
+
+// one slot's share of a multi-device raster stack
+struct MultiBand {
+    int64_t r0 = 0, r1 = 0;
+    char *cov = nullptr;          // C planes of rows [r0, r1), plane k at k * (r1 - r0) * ld elements
+    double *ens = nullptr;        // pred.elev on the band (rows x ncol)
+    double *tot = nullptr;        // pred.elev + final.TPS on the band
+    double *full = nullptr;       // gather target: n * band rows x ncol (the grid starts `lead` rows in)
+    double *tps_full = nullptr;   // reference-tiled Step 3: final.TPS on the whole grid (mosaic + feather)
+    double *tiles = nullptr;      // ... and every tile's keep window
+    size_t tiles_cap = 0;
+};
+
+struct mhs_multi_stack {
+    mhs_grid g{};
+    int C = 0, dtype = 0;
+    int64_t ld = 0;               // elements per stored row (= ncol)
+    double nodata = NAN;
+    int n = 0;
+    BandPlan plan;
+    MultiBand b[MAX_SLOTS];
+    int used_tps = 0;             // which plane holds the last step's final: 1 = tot, 0 = ens
+    bool gathered = false;
+    bool have_result = false;
+};
+
+namespace {
+
+size_t elem_size(int dtype) { return dtype == MHS_F64 ? 8 : dtype == MHS_F32 ? 4 : 2; }
+
+// what the last steps measured, for the automatic slot-0 share of the next stack of the same shape
+struct Balance { int n = 0; int64_t nrow = 0, ncol = 0, stations = 0; double share = NAN; };
+Balance g_balance;
+std::mutex g_balance_mu;
+
+int free_stack(mhs_multi_stack *ms) {
+    if (!ms) return MHS_OK;
+    const int home = current_slot();
+    for (int k = 0; k < ms->n; ++k) {
+        (void)bind_slot(k);
+        MultiBand &b = ms->b[k];
+        if (g_ms[k].s) (void)hipStreamSynchronize(g_ms[k].s);
+        for (void *q : {(void *)b.cov, (void *)b.ens, (void *)b.tot, (void *)b.full, (void *)b.tps_full, (void *)b.tiles})
+            if (q) (void)hipFree(q);
+    }
+    (void)bind_slot(home);
+    delete ms;
+    return MHS_OK;
+}
+
+}  // namespace
+
+void mhs::multi_reset() {
+    rccl_reset();
+    std::lock_guard<std::mutex> lk(g_ms_mu);
+    for (int k = 0; k < MAX_SLOTS; ++k) {
+        MultiSlot &m = g_ms[k];
+        if (!m.s) continue;
+        if (ctx_slot(k).ready) {
+            SlotBind bind(k);
+            (void)hipStreamSynchronize(m.s); (void)hipStreamDestroy(m.s);
+            (void)hipEventDestroy(m.e0); (void)hipEventDestroy(m.e1);
+        }
+        m = MultiSlot();
+    }
+}
+
+extern "C" {
+
+int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share, mhs_multi_stack **out) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(g && covars_host && covars_host->data && out, "NULL argument");
+    MHS_REQUIRE(g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
+    MHS_REQUIRE(covars_host->n_layers >= 1 && covars_host->n_layers <= 64, "bad number of layers");
+    MHS_REQUIRE(covars_host->dtype == MHS_F64 || covars_host->dtype == MHS_F32 || covars_host->dtype == MHS_I16, "bad stack dtype");
+    MHS_REQUIRE(covars_host->ld >= g->ncol && covars_host->plane_stride >= covars_host->ld * g->nrow, "stack strides smaller than the grid");
+    const int n = slot_count();
+    mhs_multi_stack *ms = new mhs_multi_stack();
+    ms->g = *g; ms->C = covars_host->n_layers; ms->dtype = covars_host->dtype; ms->ld = g->ncol; ms->nodata = covars_host->nodata;
+    ms->n = n;
+    ms->plan = plan_bands(g->nrow, n, slot0_share);
+    const size_t esz = elem_size(ms->dtype);
+    Team team(n);
+    const int rc = team.run([&](int slot) {
+        MultiBand &b = ms->b[slot];
+        b.r0 = ms->plan.r0[(size_t)slot]; b.r1 = ms->plan.r1[(size_t)slot];
+        const int64_t nb = b.r1 - b.r0;
+        auto work = [&]() -> int {
+            MultiSlot *S = nullptr;
+            if (int rc2 = multi_slot(slot, &S)) return rc2;
+            if (nb == 0) return MHS_OK;
+            const size_t plane = (size_t)nb * (size_t)ms->ld * esz;
+            MHS_HIP(hipMalloc((void **)&b.cov, plane * (size_t)ms->C));
+            MHS_HIP(hipMalloc((void **)&b.ens, sizeof(double) * (size_t)nb * (size_t)g->ncol));
+            MHS_HIP(hipMalloc((void **)&b.tot, sizeof(double) * (size_t)nb * (size_t)g->ncol));
+            for (int k = 0; k < ms->C; ++k) {
+                const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)b.r0 * covars_host->ld) * esz;
+                if (covars_host->ld == g->ncol)
+                    MHS_HIP(hipMemcpyAsync(b.cov + plane * k, src, plane, hipMemcpyHostToDevice, S->s));
+                else
+                    MHS_HIP(hipMemcpy2DAsync(b.cov + plane * k, (size_t)ms->ld * esz, src, (size_t)covars_host->ld * esz, (size_t)g->ncol * esz,
+                                             (size_t)nb, hipMemcpyHostToDevice, S->s));
+            }
+            MHS_HIP(hipStreamSynchronize(S->s));
+            return MHS_OK;
+        };
+        TEAM_DO(team, work());
+    });
+    if (rc) { free_stack(ms); return rc; }
+    *out = ms;
+    return MHS_OK;
+}
+
+int mhs_multi_stack_free(mhs_multi_stack *ms) { return free_stack(ms); }
+
+int mhs_multi_stack_bands(const mhs_multi_stack *ms, int *n_slots, int64_t *r0, int64_t *r1) {
+    MHS_REQUIRE(ms && n_slots, "NULL argument");
+    *n_slots = ms->n;
+    for (int k = 0; k < ms->n; ++k) {
+        if (r0) r0[k] = ms->b[k].r0;
+        if (r1) r1[k] = ms->b[k].r1;
+    }
+    return MHS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Longest-processing-time deal of the Step-3 tiles (sharded.assign_tiles): heaviest first onto the least loaded slot
+std::vector<int> assign_tiles(const std::vector<double> &cost, int n) {
+    std::vector<int> order(cost.size()), owner(cost.size(), 0);
+    for (size_t h = 0; h < cost.size(); ++h) order[h] = (int)h;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    std::vector<double> load((size_t)n, 0.0);
+    for (int h : order) {
+        int best = 0;
+        for (int k = 1; k < n; ++k) if (load[(size_t)k] < load[(size_t)best]) best = k;
+        owner[(size_t)h] = best;
+        load[(size_t)best] += cost[(size_t)h];
+    }
+    return owner;
+}
+
+struct StepShared {
+    // Step 2 at the stations / Step 3's fit, produced by slot 0
+    std::vector<double> resid;
+    double rsq_model = NAN, tss = NAN;
+    // global fit: the coefficients every slot rebuilds its spline handle from
+    int64_t nk = 0;
+    std::vector<double> c, knots_uv;
+    double d[3] = {0, 0, 0}, center[2] = {0, 0}, scale[2] = {1, 1}, lambda = NAN;
+    // reference-tiled Step 3
+    int64_t nRx = 1, nCx = 1;
+    std::vector<int64_t> fit_win, keep_win;
+    std::vector<int> owner;
+    std::vector<size_t> tile_off;             // offset of tile h in every slot's tile area (doubles)
+    // Step 5
+    std::vector<double> f_actual;
+    int used_tps = 0;
+    double rsq_final = NAN;
+    double fit_ms = 0, band_ms[MAX_SLOTS] = {}, tiles_ms[MAX_SLOTS] = {};
+};
+
+}  // namespace
+
+extern "C" {
+
+// Steps 2-5 of machisplin.mltps for one response layer on a resident multi-device stack (V73:442-930).
+int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total,
+                             mhs_multi_stack *ms, const double *X, const double *resp, int64_t n, int64_t tile_edge,
+                             double lambda, int gcv_mode, int gather, mhs_mltps_info *info) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(models && weights && n_models >= 1 && n_models <= 8 && ms && X && resp && n > 3, "bad arguments");
+    MHS_REQUIRE(ms->n == slot_count(), "the stack was built for another set of device slots");
+    MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
+    const int N = ms->n;
+    const mhs_grid g = ms->g;
+    const int p = ms->C + 2;
+    int kind0 = 0, p0 = 0;
+    for (int k = 0; k < n_models; ++k) {
+        MHS_REQUIRE(models[k] != nullptr, "NULL model");
+        if (int rc = mhs_model_info(models[k], &kind0, &p0, nullptr)) return rc;
+        MHS_REQUIRE(p0 == p, "a model's predictor count does not match the stack (layers + 2)");
+    }
+    const double t_step0 = now_ms();
+    // knots = the LONG / LAT columns of dat_tps (V73:688,751): the last two columns of X; their cells for Step 5
+    const double *knots = X + (size_t)(p - 2) * (size_t)n;
+    std::vector<int64_t> rows((size_t)n), cols((size_t)n);
+    if (int rc = mhs_cells_from_xy(&g, knots, n, rows.data(), cols.data())) return rc;
+    StepShared S;
+    S.f_actual.assign((size_t)n, NAN);
+    int64_t nt = 1;
+    if (tile_edge > 0) {
+        if (int rc = mhs_step3_tile_windows(&g, tile_edge, 0.2, 0.025, &S.nRx, &S.nCx, nullptr, nullptr, 0)) return rc;
+        nt = S.nRx * S.nCx;
+    }
+    const bool tiled = nt > 1;
+    if (tiled) {
+        S.fit_win.resize((size_t)nt * 4); S.keep_win.resize((size_t)nt * 4);
+        if (int rc = mhs_step3_tile_windows(&g, tile_edge, 0.2, 0.025, &S.nRx, &S.nCx, S.fit_win.data(), S.keep_win.data(), nt)) return rc;
+        std::vector<double> cost((size_t)nt);
+        S.tile_off.resize((size_t)nt + 1);
+        size_t off = 0;
+        for (int64_t h = 0; h < nt; ++h) {
+            const int64_t *f = &S.fit_win[(size_t)h * 4], *kw = &S.keep_win[(size_t)h * 4];
+            int64_t cnt = 0;
+            for (int64_t i = 0; i < n; ++i)
+                if (rows[(size_t)i] >= f[0] && rows[(size_t)i] < f[1] && cols[(size_t)i] >= f[2] && cols[(size_t)i] < f[3] && !std::isnan(X[i])) ++cnt;
+            const double cells = (double)((kw[1] - kw[0]) * (kw[3] - kw[2]));
+            cost[(size_t)h] = (double)cnt * cells + (double)cnt * (double)cnt * (double)cnt;
+            S.tile_off[(size_t)h] = off;
+            off += ((size_t)cells + 31) & ~(size_t)31;
+        }
+        S.tile_off[(size_t)nt] = off;
+        S.owner = assign_tiles(cost, N);
+    }
+    if (gather) rccl_prepare();
+    const bool use_rccl = gather && g_rccl.usable;
+    std::vector<const mhs_model *> mods((size_t)N * (size_t)n_models);
+    std::vector<mhs_tps *> tps((size_t)N, nullptr);
+    Team team(N);
+    const int rc = team.run([&](int slot) {
+        MultiBand &b = ms->b[slot];
+        const int64_t nb = b.r1 - b.r0;
+        MultiSlot *M = nullptr;
+        TEAM_DO(team, multi_slot(slot, &M));
+        // this slot's twins of the fitted members
+        for (int k = 0; k < n_models; ++k) TEAM_DO(team, model_on_slot(models[k], slot, &mods[(size_t)slot * n_models + k]));
+        const mhs_model *const *my = &mods[(size_t)slot * n_models];
+        // ---- Step 2 on the band (V73:447-619): enqueued, not waited for
+        if (nb > 0 && !team.failed()) {
+            auto launch = [&]() -> int {
+                MHS_HIP(hipEventRecord(M->e0, M->s));
+                if (int rc2 = ensemble_band_dev(my, weights, n_models, wt_total, &g, b.cov, ms->C, ms->dtype, ms->ld, ms->nodata, b.r0, b.r1,
+                                                b.ens, g.ncol, M->s)) return rc2;
+                MHS_HIP(hipEventRecord(M->e1, M->s));
+                return MHS_OK;
+            };
+            TEAM_DO(team, launch());
+        }
+        // ---- slot 0: res.FINAL at the stations (V73:477-620) and, for the global Step 3, the fit (V73:751)
+        if (slot == 0 && !team.failed()) {
+            auto fit = [&]() -> int {
+                S.resid.resize((size_t)n);
+                if (int rc2 = mhs_residual_points(my, weights, n_models, wt_total, X, resp, n, S.resid.data())) return rc2;
+                double mean = 0.0, ss = 0.0, rs = 0.0;
+                for (int64_t i = 0; i < n; ++i) mean += resp[i];
+                mean /= (double)n;
+                for (int64_t i = 0; i < n; ++i) { ss += (resp[i] - mean) * (resp[i] - mean); rs += S.resid[(size_t)i] * S.resid[(size_t)i]; }
+                S.tss = ss; S.rsq_model = 1.0 - rs / ss;
+                if (tiled) return MHS_OK;
+                const double t0 = now_ms();
+                mhs_tps *t = nullptr;
+                if (int rc2 = mhs_tps_fit(knots, S.resid.data(), n, lambda, gcv_mode, &t)) return rc2;
+                S.fit_ms = now_ms() - t0;
+                tps[0] = t;
+                if (int rc2 = mhs_tps_size(t, &S.nk)) return rc2;
+                S.c.resize((size_t)S.nk); S.knots_uv.resize((size_t)S.nk * 2);
+                return mhs_tps_get(t, S.c.data(), S.d, S.knots_uv.data(), &S.lambda, S.center, S.scale, nullptr, nullptr);
+            };
+            TEAM_DO(team, fit());
+        }
+        team.bar.wait();                                               // residuals (and the global fit) are there
+        if (!tiled) {
+            // ---- Step 3, global: every slot evaluates ITS rows with the whole grid's plan (V73:753)
+            if (slot != 0 && nb > 0)
+                TEAM_DO(team, mhs_tps_from_coef(S.knots_uv.data(), S.c.data(), S.d, S.nk, S.lambda, S.center, S.scale, &tps[(size_t)slot]));
+            if (nb > 0)
+                TEAM_DO(team, tps_predict_rows_dev(tps[(size_t)slot], &g, 0, g.nrow, 0, g.ncol, b.r0, b.r1, b.tot, g.ncol, M->s));
+        } else {
+            // ---- Step 3 the way the reference computes it above 1500 px (V73:636-747): this slot's tiles, then every tile
+            // from its owner (peer copies), mosaic + feather on the whole grid, this slot's rows of it
+            const double t0 = now_ms();
+            auto my_tiles = [&]() -> int {
+                if (b.tiles_cap < S.tile_off[(size_t)nt]) {
+                    if (b.tiles) { MHS_HIP(hipStreamSynchronize(M->s)); MHS_HIP(hipFree(b.tiles)); b.tiles = nullptr; b.tiles_cap = 0; }
+                    MHS_HIP(hipMalloc((void **)&b.tiles, sizeof(double) * S.tile_off[(size_t)nt]));
+                    b.tiles_cap = S.tile_off[(size_t)nt];
+                }
+                if (!b.tps_full) MHS_HIP(hipMalloc((void **)&b.tps_full, sizeof(double) * (size_t)g.nrow * (size_t)g.ncol));
+                std::vector<int64_t> ids;
+                std::vector<double *> outs;
+                for (int64_t h = 0; h < nt; ++h)
+                    if (S.owner[(size_t)h] == slot) { ids.push_back(h); outs.push_back(b.tiles + S.tile_off[(size_t)h]); }
+                if (ids.empty()) return MHS_OK;
+                return mhs_tps_tiles_dev(&g, knots, S.resid.data(), n, X /* covariate 1 at the stations */, tile_edge, lambda, gcv_mode,
+                                         ids.data(), (int64_t)ids.size(), outs.data());
+            };
+            TEAM_DO(team, my_tiles());
+            S.tiles_ms[slot] = now_ms() - t0;
+            team.bar.wait();                                           // every tile is final on its owner
+            auto bring = [&]() -> int {
+                std::vector<const double *> ptrs((size_t)nt);
+                for (int64_t h = 0; h < nt; ++h) {
+                    const int o = S.owner[(size_t)h];
+                    ptrs[(size_t)h] = b.tiles + S.tile_off[(size_t)h];
+                    if (o == slot) continue;
+                    const size_t bytes = sizeof(double) * (S.tile_off[(size_t)h + 1] - S.tile_off[(size_t)h]);
+                    MHS_HIP(hipMemcpyPeerAsync(b.tiles + S.tile_off[(size_t)h], ctx_slot(slot).device, ms->b[o].tiles + S.tile_off[(size_t)h],
+                                               ctx_slot(o).device, bytes, M->s));
+                }
+                if (int rc2 = mhs_mosaic_feather_dev(&g, S.nRx, S.nCx, S.keep_win.data(), ptrs.data(), 0, b.tps_full, g.ncol, nullptr, M->s)) return rc2;
+                if (nb > 0)
+                    MHS_HIP(hipMemcpyAsync(b.tot, b.tps_full + (size_t)b.r0 * (size_t)g.ncol, sizeof(double) * (size_t)nb * (size_t)g.ncol,
+                                           hipMemcpyDeviceToDevice, M->s));
+                return MHS_OK;
+            };
+            TEAM_DO(team, bring());
+        }
+        // ---- Step 5 on the band (V73:906-917): sum, the stations' cells
+        if (nb > 0 && !team.failed()) {
+            auto step5 = [&]() -> int {
+                if (int rc2 = mhs_scale_add_dev(b.ens, 1.0, b.tot, b.tot, nb * g.ncol, M->s)) return rc2;
+                std::vector<int64_t> rr, cc, idx;
+                for (int64_t i = 0; i < n; ++i)
+                    if (rows[(size_t)i] >= b.r0 && rows[(size_t)i] < b.r1 && cols[(size_t)i] >= 0) {
+                        rr.push_back(rows[(size_t)i] - b.r0); cc.push_back(cols[(size_t)i]); idx.push_back(i);
+                    }
+                std::vector<double> f(rr.size());
+                if (int rc2 = mhs_gather_cells_dev(b.tot, g.ncol, rr.data(), cc.data(), (int64_t)rr.size(), f.data(), M->s)) return rc2;
+                for (size_t q = 0; q < idx.size(); ++q) S.f_actual[(size_t)idx[q]] = f[q];
+                return MHS_OK;
+            };
+            TEAM_DO(team, step5());
+        }
+        team.bar.wait();                                               // every station's cell has been read
+        if (slot == 0 && !team.failed()) {                             // V73:917-930: keep the sum iff it improves R^2
+            double rs = 0.0;
+            for (int64_t i = 0; i < n; ++i) { const double e = resp[i] - S.f_actual[(size_t)i]; rs += e * e; }
+            S.rsq_final = 1.0 - rs / S.tss;
+            S.used_tps = S.rsq_final > S.rsq_model ? 1 : 0;
+        }
+        team.bar.wait();
+        // ---- the one collective: stitch the final plane on every device.  (Every thread reads failed() right after the
+        // barrier above and nothing runs in between, so all of them take the same branch -- a collective must not be entered
+        // by some ranks only.)
+        const bool go = !team.failed();
+        if (gather && go) {
+            auto stitch = [&]() -> int {
+                const int64_t band = ms->plan.band;
+                if (!b.full) MHS_HIP(hipMalloc((void **)&b.full, sizeof(double) * (size_t)band * (size_t)N * (size_t)g.ncol));
+                const double *src = S.used_tps ? b.tot : b.ens;
+                // this slot's rows at their place in the gather target (slot 0's at the end of its chunk)
+                double *mine = b.full + ((size_t)ms->plan.lead + (size_t)b.r0) * (size_t)g.ncol;
+                if (nb > 0) MHS_HIP(hipMemcpyAsync(mine, src, sizeof(double) * (size_t)nb * (size_t)g.ncol, hipMemcpyDeviceToDevice, M->s));
+                return MHS_OK;
+            };
+            int rcs = stitch();
+            if (rcs) team.fail(rcs);
+            team.bar.wait();                                           // every slot's target exists
+            const bool go2 = !team.failed();
+            if (go2 && use_rccl) {
+                const size_t count = (size_t)ms->plan.band * (size_t)g.ncol;
+                const int rcn = g_rccl.AllGather(b.full + (size_t)slot * count, b.full, count, NCCL_FLOAT64, g_rccl.comm[slot], M->s);
+                if (rcn != 0) { set_error("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rcn) : "?"); team.fail(MHS_ERR_HIP); }
+            } else if (go2 && nb > 0) {
+                // aliased slots (or no librccl): every slot PUSHES its rows into the other slots' targets -- the mesh pattern of
+                // SURVEY.md section 8e
+                auto push = [&]() -> int {
+                    const double *mine = b.full + ((size_t)ms->plan.lead + (size_t)b.r0) * (size_t)g.ncol;
+                    for (int o = 0; o < N; ++o) {
+                        if (o == slot) continue;
+                        double *dst = ms->b[o].full + ((size_t)ms->plan.lead + (size_t)b.r0) * (size_t)g.ncol;
+                        MHS_HIP(hipMemcpyPeerAsync(dst, ctx_slot(o).device, mine, ctx_slot(slot).device, sizeof(double) * (size_t)nb * (size_t)g.ncol, M->s));
+                    }
+                    return MHS_OK;
+                };
+                rcs = push();
+                if (rcs) team.fail(rcs);
+            }
+        }
+        if (M) (void)hipStreamSynchronize(M->s);
+        if (nb > 0 && M && !team.failed()) {
+            float ms_f = 0.f;
+            if (hipEventElapsedTime(&ms_f, M->e0, M->e1) == hipSuccess) S.band_ms[slot] = (double)ms_f;
+        }
+        team.bar.wait();                                               // pushes have landed everywhere
+        if (tps[(size_t)slot]) { (void)mhs_tps_free(tps[(size_t)slot]); tps[(size_t)slot] = nullptr; }
+    });
+    if (rc) return rc;
+    ms->used_tps = S.used_tps;
+    ms->gathered = gather != 0;
+    ms->have_result = true;
+    const double step_ms = now_ms() - t_step0;
+    // the share of the rows that would have balanced this step: slot 0's band + fit against the other slots' bands
+    double suggested = NAN;
+    if (N > 1 && !tiled) {
+        double ms_per_row = 0.0;
+        int64_t rows_timed = 0;
+        for (int k = 0; k < N; ++k) if (ms->b[k].r1 > ms->b[k].r0) { ms_per_row += S.band_ms[k]; rows_timed += ms->b[k].r1 - ms->b[k].r0; }
+        if (rows_timed > 0 && ms_per_row > 0) {
+            const double cells_ms = ms_per_row / (double)rows_timed * (double)g.nrow;
+            const double s0 = 1.0 / N - S.fit_ms * (N - 1) / ((double)N * cells_ms);
+            suggested = std::min(std::max(s0, 0.0), 1.0 / N);
+            std::lock_guard<std::mutex> lk(g_balance_mu);
+            g_balance = Balance{N, g.nrow, g.ncol, n, suggested};
+        }
+    }
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->rsq_model = S.rsq_model; info->rsq_final = S.rsq_final; info->lambda = tiled ? NAN : S.lambda;
+        info->n_knots = tiled ? 0 : S.nk; info->used_tps = S.used_tps; info->n_slots = N;
+        info->tiles_rows = S.nRx; info->tiles_cols = S.nCx;
+        info->collective = !gather ? 0 : use_rccl ? 1 : 2;
+        info->fit_ms = S.fit_ms; info->step_ms = step_ms; info->suggested_slot0_share = suggested;
+        for (int k = 0; k < N; ++k) {
+            info->band_r0[k] = ms->b[k].r0; info->band_r1[k] = ms->b[k].r1; info->band_ms[k] = S.band_ms[k]; info->tiles_ms[k] = S.tiles_ms[k];
+        }
+    }
+    return MHS_OK;
+}
+
+// The last step's final plane, every slot's rows straight down its own PCIe link into the caller's plane (row-major, ld = ncol)
+int mhs_multi_final_download(const mhs_multi_stack *ms, double *final_host) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(ms && final_host && ms->have_result, "no result to download");
+    Team team(ms->n);
+    return team.run([&](int slot) {
+        const MultiBand &b = ms->b[slot];
+        const int64_t nb = b.r1 - b.r0;
+        auto work = [&]() -> int {
+            if (nb == 0) return MHS_OK;
+            MultiSlot *M = nullptr;
+            if (int rc2 = multi_slot(slot, &M)) return rc2;
+            const double *src = ms->used_tps ? b.tot : b.ens;
+            MHS_HIP(hipMemcpyAsync(final_host + (size_t)b.r0 * (size_t)ms->g.ncol, src, sizeof(double) * (size_t)nb * (size_t)ms->g.ncol,
+                                   hipMemcpyDeviceToHost, M->s));
+            MHS_HIP(hipStreamSynchronize(M->s));
+            return MHS_OK;
+        };
+        TEAM_DO(team, work());
+    });
+}
+
+// Device pointers of the last step's planes on one slot: the slot's own rows [r0, r1) (band_dev, ld = ncol) and, after a
+// step with `gather`, the stitched grid (full_dev, nrow x ncol).  Any output pointer may be NULL.
+int mhs_multi_final_dev(const mhs_multi_stack *ms, int slot, double **band_dev, int64_t *r0, int64_t *r1, double **full_dev) {
+    MHS_REQUIRE(ms && slot >= 0 && slot < ms->n && ms->have_result, "bad arguments");
+    const MultiBand &b = ms->b[slot];
+    if (band_dev) *band_dev = ms->used_tps ? b.tot : b.ens;
+    if (r0) *r0 = b.r0;
+    if (r1) *r1 = b.r1;
+    if (full_dev) *full_dev = (ms->gathered && b.full) ? b.full + (size_t)ms->plan.lead * (size_t)ms->g.ncol : nullptr;
+    return MHS_OK;
+}
+
+// The same from host planes to a host plane in ONE call -- what the R shim binds (terra holds the rasters in RAM,
+// V73:468-606): upload the bands, Steps 2-5, download.  slot0_share: NaN = automatic (equal bands the first time, then
+// what the last step of the same shape measured).
+int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
+                         const mhs_stack *covars_host, const double *X, const double *resp, int64_t n, int64_t tile_edge,
+                         double lambda, int gcv_mode, double slot0_share, double *final_host, mhs_mltps_info *info) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(g && covars_host && final_host, "NULL argument");
+    double share = slot0_share;
+    if (std::isnan(share)) {
+        std::lock_guard<std::mutex> lk(g_balance_mu);
+        if (g_balance.n == slot_count() && g_balance.nrow == g->nrow && g_balance.ncol == g->ncol && g_balance.stations == n) share = g_balance.share;
+    }
+    mhs_multi_stack *ms = nullptr;
+    const double t0 = now_ms();
+    if (int rc = mhs_multi_stack_create(g, covars_host, share, &ms)) return rc;
+    const double t1 = now_ms();
+    int rc = mhs_mltps_grid_multi_dev(models, weights, n_models, wt_total, ms, X, resp, n, tile_edge, lambda, gcv_mode, 0, info);
+    const double t2 = now_ms();
+    if (!rc) rc = mhs_multi_final_download(ms, final_host);
+    if (info && !rc) { info->upload_ms = t1 - t0; info->download_ms = now_ms() - t2; }
+    (void)mhs_multi_stack_free(ms);
+    return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------- (tile, layer) units --
+namespace {
+
+struct UnitSlot {                 // what one slot keeps while its units run
+    int tile = -1;                // the tile whose covariates are resident
+    char *cov = nullptr;
+    size_t cov_cap = 0;
+    double *ens = nullptr, *tps = nullptr;      // scratch planes of the largest tile
+    std::vector<double *> merge_in;             // a layer's tile planes on the merging slot
+    double *merged = nullptr;
+};
+
+}  // namespace
+
+extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_host, int64_t out_ncol, int64_t out_nrow,
+                                     double feather_d, int n_layers, const mhs_unit *units, int tps, int64_t tile_edge,
+                                     double lambda, int gcv_mode, double *const *merged_host, double *rsq,
+                                     mhs_units_info *info) {
+    if (int rc = require_ready()) return rc;
+    MHS_REQUIRE(g && covars_host && covars_host->data && units && merged_host, "NULL argument");
+    MHS_REQUIRE(g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
+    MHS_REQUIRE(out_ncol >= 1 && out_nrow >= 1 && out_ncol * out_nrow <= 4096 && n_layers >= 1, "bad tile layout");
+    MHS_REQUIRE(covars_host->dtype == MHS_F64 || covars_host->dtype == MHS_F32 || covars_host->dtype == MHS_I16, "bad stack dtype");
+    MHS_REQUIRE(covars_host->ld >= g->ncol && covars_host->plane_stride >= covars_host->ld * g->nrow, "stack strides smaller than the grid");
+    const int N = slot_count();
+    const int64_t n_tiles = out_ncol * out_nrow, n_units = n_tiles * n_layers;
+    const int C = covars_host->n_layers, p = C + 2;
+    const size_t esz = elem_size(covars_host->dtype);
+    std::vector<double> boxes((size_t)n_tiles * 4);
+    std::vector<int64_t> win((size_t)n_tiles * 4);
+    if (int rc = mhs_tiles_create_windows(g, out_ncol, out_nrow, feather_d, boxes.data(), win.data())) return rc;   // V73:1165-1208
+    int64_t max_cells = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) max_cells = std::max(max_cells, (win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]));
+    for (int64_t u = 0; u < n_units; ++u) {
+        const mhs_unit &U = units[u];
+        MHS_REQUIRE(U.models && U.weights && U.n_models >= 1 && U.n_models <= 8 && U.X && U.resp && U.n > 3, "bad unit");
+        MHS_REQUIRE(U.wt_total != 0.0 && !std::isnan(U.wt_total), "a unit's wt_total must be non-zero");
+    }
+    const double t_start = now_ms();
+    std::vector<double *> plane((size_t)n_units, nullptr);          // unit u's final plane, on its owner's device
+    std::vector<double> rsq_model((size_t)n_units, NAN), rsq_final((size_t)n_units, NAN), unit_ms((size_t)n_units, 0.0);
+    std::vector<UnitSlot> us((size_t)N);
+    Team team(N);
+    const int rc = team.run([&](int slot) {
+        UnitSlot &L = us[(size_t)slot];
+        MultiSlot *M = nullptr;
+        TEAM_DO(team, multi_slot(slot, &M));
+        auto alloc = [&]() -> int {
+            MHS_HIP(hipMalloc((void **)&L.ens, sizeof(double) * (size_t)max_cells));
+            if (tps) MHS_HIP(hipMalloc((void **)&L.tps, sizeof(double) * (size_t)max_cells));
+            return MHS_OK;
+        };
+        TEAM_DO(team, alloc());
+        // a tile's response layers share its stations: the Step-3 tiles' reductions are built by the first layer this slot
+        // runs on the tile and reused by the others (bit-identical fits); nothing outlives the call
+        TEAM_DO(team, mhs_tps_reduction_cache(1));
+        // ---- this slot's units, layer-major (u = layer * n_tiles + tile, slot u mod N: sharded.unit_owner)
+        for (int64_t u = slot; u < n_units && !team.failed(); u += N) {
+            const int64_t t = u % n_tiles;
+            const mhs_unit &U = units[u];
+            const int64_t *w = &win[(size_t)t * 4];
+            const int64_t nr = w[1] - w[0], nc = w[3] - w[2];
+            auto run = [&]() -> int {
+                const double t0 = now_ms();
+                // terra::crop(rast, e.ext[[t]]): the tile's geometry and its rows x cols of every plane (V73:1207)
+                mhs_grid gt = {g->xmin + (double)w[2] * g->xres, g->ymax - (double)w[0] * g->yres, g->xres, g->yres, nr, nc};
+                if (L.tile != (int)t) {
+                    const size_t need = (size_t)nr * (size_t)nc * esz * (size_t)C;
+                    if (need > L.cov_cap) {
+                        if (L.cov) { MHS_HIP(hipStreamSynchronize(M->s)); MHS_HIP(hipFree(L.cov)); L.cov = nullptr; L.cov_cap = 0; }
+                        MHS_HIP(hipMalloc((void **)&L.cov, need));
+                        L.cov_cap = need;
+                    }
+                    for (int k = 0; k < C; ++k) {
+                        const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)w[0] * covars_host->ld + (size_t)w[2]) * esz;
+                        MHS_HIP(hipMemcpy2DAsync(L.cov + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
+                                                 (size_t)nc * esz, (size_t)nr, hipMemcpyHostToDevice, M->s));
+                    }
+                    L.tile = (int)t;
+                }
+                std::vector<const mhs_model *> my((size_t)U.n_models);
+                int p0 = 0;
+                for (int k = 0; k < U.n_models; ++k) {
+                    MHS_REQUIRE(U.models[k] != nullptr, "NULL model in a unit");
+                    if (int rc2 = mhs_model_info(U.models[k], nullptr, &p0, nullptr)) return rc2;
+                    MHS_REQUIRE(p0 == p, "a unit's model does not match the stack (layers + 2 predictors)");
+                    if (int rc2 = model_on_slot(U.models[k], slot, &my[(size_t)k])) return rc2;
+                }
+                MHS_HIP(hipMalloc((void **)&plane[(size_t)u], sizeof(double) * (size_t)nr * (size_t)nc));
+                // Step 2 (V73:447-620)
+                if (int rc2 = ensemble_band_dev(my.data(), U.weights, U.n_models, U.wt_total, &gt, L.cov, C, covars_host->dtype, nc,
+                                                covars_host->nodata, 0, nr, L.ens, nc, M->s)) return rc2;
+                std::vector<double> res((size_t)U.n);
+                if (int rc2 = mhs_residual_points(my.data(), U.weights, U.n_models, U.wt_total, U.X, U.resp, U.n, res.data())) return rc2;
+                double mean = 0.0, tss = 0.0, rs = 0.0;
+                for (int64_t i = 0; i < U.n; ++i) mean += U.resp[i];
+                mean /= (double)U.n;
+                for (int64_t i = 0; i < U.n; ++i) { tss += (U.resp[i] - mean) * (U.resp[i] - mean); rs += res[(size_t)i] * res[(size_t)i]; }
+                rsq_model[(size_t)u] = 1.0 - rs / tss;
+                const double *fin = L.ens;
+                if (tps) {
+                    // Step 3 + 4 (V73:636-897) on the tile, Step 5 (V73:902-930)
+                    const double *knots = U.X + (size_t)(p - 2) * (size_t)U.n;
+                    if (int rc2 = mhs_tps_surface_dev(&gt, knots, res.data(), U.n, U.X, tile_edge, lambda, gcv_mode, L.tps, nc, nullptr, M->s)) return rc2;
+                    if (int rc2 = mhs_scale_add_dev(L.ens, 1.0, L.tps, L.tps, nr * nc, M->s)) return rc2;
+                    std::vector<int64_t> rows((size_t)U.n), cols((size_t)U.n);
+                    if (int rc2 = mhs_cells_from_xy(&gt, knots, U.n, rows.data(), cols.data())) return rc2;
+                    std::vector<double> f((size_t)U.n);
+                    if (int rc2 = mhs_gather_cells_dev(L.tps, nc, rows.data(), cols.data(), U.n, f.data(), M->s)) return rc2;
+                    rs = 0.0;
+                    for (int64_t i = 0; i < U.n; ++i) { const double e = U.resp[i] - f[(size_t)i]; rs += e * e; }
+                    rsq_final[(size_t)u] = 1.0 - rs / tss;
+                    if (rsq_final[(size_t)u] > rsq_model[(size_t)u]) fin = L.tps;
+                }
+                MHS_HIP(hipMemcpyAsync(plane[(size_t)u], fin, sizeof(double) * (size_t)nr * (size_t)nc, hipMemcpyDeviceToDevice, M->s));
+                MHS_HIP(hipStreamSynchronize(M->s));
+                unit_ms[(size_t)u] = now_ms() - t0;
+                return MHS_OK;
+            };
+            TEAM_DO(team, run());
+        }
+        if (ctx().ready) (void)mhs_tps_reduction_cache(0);
+        team.bar.wait();                                               // every unit's plane is final on its owner
+        // ---- machisplin.tiles.merge (V73:1392-1548) of layer l on slot l mod N: its tiles come over xGMI
+        for (int l = slot; l < n_layers && !team.failed(); l += N) {
+            if (!merged_host[l]) continue;
+            auto merge = [&]() -> int {
+                if (L.merge_in.empty()) {
+                    L.merge_in.assign((size_t)n_tiles, nullptr);
+                    for (int64_t t = 0; t < n_tiles; ++t)
+                        MHS_HIP(hipMalloc((void **)&L.merge_in[(size_t)t], sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]))));
+                    MHS_HIP(hipMalloc((void **)&L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol));
+                }
+                std::vector<const double *> ptrs((size_t)n_tiles);
+                for (int64_t t = 0; t < n_tiles; ++t) {
+                    const int64_t u = (int64_t)l * n_tiles + t;
+                    const int owner = (int)(u % N);
+                    const size_t bytes = sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]));
+                    if (owner == slot) { ptrs[(size_t)t] = plane[(size_t)u]; continue; }
+                    MHS_HIP(hipMemcpyPeerAsync(L.merge_in[(size_t)t], ctx_slot(slot).device, plane[(size_t)u], ctx_slot(owner).device, bytes, M->s));
+                    ptrs[(size_t)t] = L.merge_in[(size_t)t];
+                }
+                if (int rc2 = mhs_mosaic_feather_dev(g, out_nrow, out_ncol, win.data(), ptrs.data(), 1, L.merged, g->ncol, nullptr, M->s)) return rc2;
+                MHS_HIP(hipMemcpyAsync(merged_host[l], L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol, hipMemcpyDeviceToHost, M->s));
+                MHS_HIP(hipStreamSynchronize(M->s));
+                return MHS_OK;
+            };
+            TEAM_DO(team, merge());
+        }
+        team.bar.wait();                                               // nobody reads a unit plane any more
+        if (M) (void)hipStreamSynchronize(M->s);
+        for (int64_t u = slot; u < n_units; u += N) if (plane[(size_t)u]) (void)hipFree(plane[(size_t)u]);
+        for (double *q : L.merge_in) if (q) (void)hipFree(q);
+        for (void *q : {(void *)L.cov, (void *)L.ens, (void *)L.tps, (void *)L.merged}) if (q) (void)hipFree(q);
+    });
+    if (rc) return rc;
+    if (rsq) for (int64_t u = 0; u < n_units; ++u) { rsq[2 * u] = rsq_model[(size_t)u]; rsq[2 * u + 1] = rsq_final[(size_t)u]; }
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->n_slots = N; info->n_units = n_units; info->step_ms = now_ms() - t_start;
+        for (int64_t u = 0; u < n_units; ++u) {
+            info->unit_ms_sum += unit_ms[(size_t)u];
+            info->unit_ms_max = std::max(info->unit_ms_max, unit_ms[(size_t)u]);
+            info->slot_ms[u % N] += unit_ms[(size_t)u];
+        }
+    }
+    return MHS_OK;
+}

@@ -27,15 +27,32 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
          : e == hipErrorOutOfMemory ? MHS_ERR_ALLOC : MHS_ERR_HIP;
 }
 
-Context &ctx() {
-    static Context c;
-    return c;
+// ------------------------------------------------------------------ device slots --
+namespace {
+struct Slots {
+    Context c[MAX_SLOTS];
+    std::mutex pipe_mu[MAX_SLOTS], mask_mu[MAX_SLOTS], mosaic_mu[MAX_SLOTS];
+    int count = 0;                        // slots 0 .. count - 1 are ready
+};
+Slots &slots() { static Slots s; return s; }
+thread_local int t_slot = 0;
+}  // namespace
+
+int current_slot() { return t_slot; }
+int slot_count() { return slots().count; }
+Context &ctx_slot(int slot) { return slots().c[slot]; }
+Context &ctx() { return slots().c[t_slot]; }
+
+int bind_slot(int slot) {
+    if (slot < 0 || slot >= MAX_SLOTS) { set_error("bind_slot: slot %d out of range", slot); return MHS_ERR_INVALID; }
+    t_slot = slot;
+    const Context &c = slots().c[slot];
+    if (c.ready || c.device >= 0) MHS_HIP(hipSetDevice(c.device));
+    return MHS_OK;
 }
 
-std::mutex &mask_mutex() {
-    static std::mutex m;
-    return m;
-}
+std::mutex &mask_mutex() { return slots().mask_mu[t_slot]; }
+std::mutex &mosaic_mutex() { return slots().mosaic_mu[t_slot]; }
 
 namespace {
 struct BlockPool {
@@ -43,14 +60,14 @@ struct BlockPool {
     std::unordered_map<void *, size_t> cls;                 // every block handed out or parked -> its class (0 = direct)
     std::unordered_map<size_t, std::vector<void *>> parked;
 };
-BlockPool &block_pool() { static BlockPool p; return p; }
+BlockPool &block_pool(int slot) { static BlockPool p[MAX_SLOTS]; return p[slot]; }
 constexpr size_t POOL_MAX_CLASS = (size_t)64 << 20;
 }  // namespace
 
 void *pool_alloc(size_t bytes) {
     size_t c = 256;
     while (c < bytes) c <<= 1;
-    BlockPool &bp = block_pool();
+    BlockPool &bp = block_pool(current_slot());
     if (c <= POOL_MAX_CLASS) {
         std::lock_guard<std::mutex> lk(bp.mu);
         auto it = bp.parked.find(c);
@@ -66,31 +83,36 @@ void *pool_alloc(size_t bytes) {
 
 void pool_release(void *p) {
     if (!p) return;
-    BlockPool &bp = block_pool();
-    size_t c = 0;
-    {
-        std::lock_guard<std::mutex> lk(bp.mu);
-        auto it = bp.cls.find(p);
-        if (it == bp.cls.end()) return;                    // not ours (or the pool was cleared): leave it
-        c = it->second;
-        if (c) { bp.parked[c].push_back(p); return; }
-        bp.cls.erase(it);
+    // the block goes back to the pool of the slot it came from, whichever slot the releasing thread is bound to (a
+    // handle may be freed from the host's main thread after a worker thread of another slot built it)
+    const int cur = current_slot();
+    for (int k = 0; k < MAX_SLOTS; ++k) {
+        const int slot = (cur + k) % MAX_SLOTS;
+        BlockPool &bp = block_pool(slot);
+        size_t c = 0;
+        {
+            std::lock_guard<std::mutex> lk(bp.mu);
+            auto it = bp.cls.find(p);
+            if (it == bp.cls.end()) continue;
+            c = it->second;
+            if (c) { bp.parked[c].push_back(p); return; }
+            bp.cls.erase(it);
+        }
+        (void)hipFree(p);
+        return;
     }
-    (void)hipFree(p);
+    // not ours (or the pool was cleared): leave it
 }
 
 void pool_clear() {
-    BlockPool &bp = block_pool();
+    BlockPool &bp = block_pool(current_slot());
     std::lock_guard<std::mutex> lk(bp.mu);
     for (auto &kv : bp.cls) (void)hipFree(kv.first);
     bp.cls.clear();
     bp.parked.clear();
 }
 
-std::mutex &pipe_mutex() {
-    static std::mutex m;
-    return m;
-}
+std::mutex &pipe_mutex() { return slots().pipe_mu[t_slot]; }
 
 int host_pipe(size_t arena_bytes) {
     Context &c = ctx();
@@ -207,17 +229,12 @@ int mhs_device_count(int *count) {
     return MHS_OK;
 }
 
-int mhs_init(int device) {
-    Context &c = ctx();
-    if (c.ready && c.device == device) return MHS_OK;
-    if (c.ready) mhs_shutdown();
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n == 0) {
-        set_error("mhs_init: no HIP device visible (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
-        return MHS_ERR_NODEVICE;
-    }
-    MHS_REQUIRE(device >= 0 && device < n, "device index out of range");
+// One slot = one Context on one physical device.  Called with the thread bound to nothing in particular; leaves the
+// calling thread bound to the slot it found it on.
+static int init_slot(int slot, int device) {
+    Context &c = ctx_slot(slot);
+    c.device = device;                          // bind_slot needs it before the context is ready
+    SlotBind bind(slot);
     MHS_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     MHS_HIP(hipGetDeviceProperties(&prop, device));
@@ -247,18 +264,14 @@ int mhs_init(int device) {
         MHS_HIP(hipMalloc((void **)&c.exp_tab, sizeof(double) * et.size()));
         MHS_HIP(hipMemcpy(c.exp_tab, et.data(), sizeof(double) * et.size(), hipMemcpyHostToDevice));
     }
-    c.device = device;
     c.ready = true;
-    // streams (CU-masked ones among them) are destroyed while the HIP runtime is still whole, whatever the host forgets:
-    // handlers run in reverse order of registration, so this one runs before the runtime's own
-    static bool registered = false;
-    if (!registered) { registered = true; std::atexit([] { (void)mhs_shutdown(); }); }
     return MHS_OK;
 }
 
-int mhs_shutdown(void) {
-    Context &c = ctx();
-    if (!c.ready) return MHS_OK;
+static void shutdown_slot(int slot) {
+    Context &c = ctx_slot(slot);
+    if (!c.ready) { c = Context(); return; }
+    SlotBind bind(slot);
     (void)hipStreamSynchronize(c.stream);
     reduction_cache_clear();              // device pointers of this device must not outlive it
     pool_clear();                         // (handles that outlive the shutdown release into an empty pool: ignored)
@@ -290,6 +303,63 @@ int mhs_shutdown(void) {
         delete L;
     }
     c = Context();
+}
+
+int mhs_init_devices(int n_devices, const int *device_ids) {
+    MHS_REQUIRE(n_devices >= 1 && n_devices <= MAX_SLOTS, "n_devices must be between 1 and 16");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error("mhs_init: no HIP device visible (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return MHS_ERR_NODEVICE;
+    }
+    for (int k = 0; k < n_devices; ++k) {
+        const int d = device_ids ? device_ids[k] : k;
+        MHS_REQUIRE(d >= 0 && d < n, "device index out of range");
+    }
+    Slots &S = slots();
+    bool same = S.count == n_devices;
+    for (int k = 0; same && k < n_devices; ++k)
+        same = S.c[k].ready && S.c[k].device == (device_ids ? device_ids[k] : k);
+    if (same) return bind_slot(0);
+    if (S.count > 0) mhs_shutdown();
+    multi_reset();                                    // per-device state of the multi-device drivers (multi.hip)
+    for (int k = 0; k < n_devices; ++k) {
+        if (int rc = init_slot(k, device_ids ? device_ids[k] : k)) {
+            for (int q = 0; q <= k; ++q) shutdown_slot(q);
+            S.count = 0;
+            return rc;
+        }
+        S.count = k + 1;
+    }
+    // streams (CU-masked ones among them) are destroyed while the HIP runtime is still whole, whatever the host forgets:
+    // handlers run in reverse order of registration, so this one runs before the runtime's own
+    static bool registered = false;
+    if (!registered) { registered = true; std::atexit([] { (void)mhs_shutdown(); }); }
+    return bind_slot(0);
+}
+
+int mhs_init(int device) {
+    Slots &S = slots();
+    // slot 0 on `device` is all a one-device caller asks for: a host that has brought up several devices with
+    // mhs_init_devices keeps them (the Python binding calls mhs_init from every helper)
+    if (S.count >= 1 && S.c[0].ready && S.c[0].device == device) return bind_slot(0);
+    return mhs_init_devices(1, &device);
+}
+
+int mhs_device_slots(int *n_slots, int *device_ids) {
+    MHS_REQUIRE(n_slots != nullptr, "n_slots is NULL");
+    *n_slots = slots().count;
+    if (device_ids) for (int k = 0; k < slots().count; ++k) device_ids[k] = slots().c[k].device;
+    return MHS_OK;
+}
+
+int mhs_shutdown(void) {
+    Slots &S = slots();
+    multi_reset();
+    for (int k = 0; k < MAX_SLOTS; ++k) shutdown_slot(k);
+    S.count = 0;
+    (void)bind_slot(0);
     return MHS_OK;
 }
 

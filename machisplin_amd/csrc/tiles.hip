@@ -289,8 +289,7 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
     // 18 bytes per cell of scratch (two sums, two counts) + the seams' boxes, from a grow-only arena: a hipMalloc /
     // hipFree pair of 1.8 GB per call cost 40-60 ms per merged layer at 10 000^2 cells (and the free synchronises the
     // device).  One call at a time uses it; the call ends with a stream synchronisation.
-    static std::mutex arena_mu;
-    std::lock_guard<std::mutex> arena_lock(arena_mu);
+    std::lock_guard<std::mutex> arena_lock(mosaic_mutex());
     struct Span { double *p; };
     struct SpanB { unsigned char *p; };
     struct SpanI { int *p; };

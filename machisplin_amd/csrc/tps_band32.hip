@@ -1803,11 +1803,8 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
         MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pool.push_back(e);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        MHS_HIP(hipFuncSetAttribute((const void *)b32_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32_W_LDS));
-        attr_done = true;
-    }
+    // per call: the attribute is per device, and fits run on several lanes (host threads) and device slots
+    MHS_HIP(hipFuncSetAttribute((const void *)b32_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32_W_LDS));
     MHS_HIP(hipMemsetAsync(ws.flags, 0, sizeof(int), s));
     hipEvent_t pending_rest = nullptr;
     bool have_gram = false;      // the previous panel's strip kernel left this panel's partial Gram matrices in ws.Gp1

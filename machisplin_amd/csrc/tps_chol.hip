@@ -465,11 +465,8 @@ int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, doubl
         hipLaunchKernelGGL(chol_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, ld, off, m, m_pad, rhs_dev);
     }
     static const size_t diag_lds = (size_t)(CH_NB * CH_LDP + (CH_NB - CH_SB) * CH_SB + CH_SB * (CH_SB + 1) + CH_SB + CH_NB) * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MHS_HIP(hipFuncSetAttribute((const void *)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-        attr_done = true;
-    }
+    // per call: the attribute is per device, and factorisations run on several lanes (host threads) and device slots
+    MHS_HIP(hipFuncSetAttribute((const void *)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
     std::vector<hipEvent_t> &pool = L.pool;
     while ((int)pool.size() < 2 * np + 4) {
         hipEvent_t e;

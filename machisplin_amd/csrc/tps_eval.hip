@@ -125,6 +125,10 @@ constexpr int FF_PAD = 2;                // bins beyond the window on every side
 struct FarGeom {
     int tx, ty, ntx, nty;                // tile size (cells), tiles per direction
     double t[FF_N];                      // Chebyshev points of the first kind on [-1, 1]
+    // rows of the window one launch writes, [row_lo, row_hi), and the tile rows that cover them, [ty_lo, ty_hi): the
+    // whole window by default; a row band of it when several devices share the window's plan (tps_predict_rows_dev) --
+    // tiles, nodes and every cell's arithmetic are then those of the one-piece evaluation, bit for bit
+    int row_lo, row_hi, ty_lo, ty_hi;
 };
 
 // far-field sum (plus the affine part) at the 16 x 16 nodes of every tile; one wave per tile,
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(256) void tps_ff_nodes_kernel(const Knot *__restric
     __shared__ double2 tab[LOG_TAB_N];
     stage_log_table(tab, gtab);
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= f.ntx * f.nty) return;
+    const int tile = f.ty_lo * f.ntx + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= f.ty_hi * f.ntx) return;
     const int tyi = tile / f.ntx, txi = tile - tyi * f.ntx;
     const int a = lane & 15, bg = lane >> 4;
     const double hx = 0.5 * (double)f.tx * g.xres, hy = 0.5 * (double)f.ty * g.yres;
@@ -178,13 +182,15 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
     const int wave = threadIdx.x >> 6;
     const int cchunks = f.tx / 64, rchunks = f.ty / EVAL_TILE_ROWS;
     const int txi = blockIdx.x / cchunks, cc = blockIdx.x - txi * cchunks;
-    const int tyi = blockIdx.y / rchunks, rc = blockIdx.y - tyi * rchunks;
+    const int by = blockIdx.y + f.ty_lo * rchunks;
+    const int tyi = by / rchunks, rc = by - tyi * rchunks;
     const int tile = tyi * f.ntx + txi;
     const int lcol = cc * 64 + lane;                                  // column within the tile
     const int lrow0 = rc * EVAL_TILE_ROWS + wave * EVAL_ROWS;         // first row within the tile
     const int col = txi * f.tx + lcol;
     const int row0 = tyi * f.ty + lrow0;
-    if (tyi * f.ty + rc * EVAL_TILE_ROWS >= g.nr || txi * f.tx + cc * 64 >= g.nc) return;   // whole block outside
+    if (tyi * f.ty + rc * EVAL_TILE_ROWS >= f.row_hi || tyi * f.ty + (rc + 1) * EVAL_TILE_ROWS <= f.row_lo ||
+        txi * f.tx + cc * 64 >= g.nc) return;   // whole block outside
     for (int i = threadIdx.x; i < LOG_TAB_N; i += 64 * EVAL_WAVES) tab[i] = gtab[i];
     sF[threadIdx.x] = nodes[(int64_t)tile * FF_NODES + threadIdx.x];
     __syncthreads();
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
     if (col < g.nc) {
 #pragma unroll
         for (int k = 0; k < EVAL_ROWS; ++k)
-            if (row0 + k < g.nr) out[(int64_t)(row0 + k) * g.ld + col] = acc[k];
+            if (row0 + k >= f.row_lo && row0 + k < f.row_hi) out[(int64_t)(row0 + k - f.row_lo) * g.ld + col] = acc[k];
     }
 }
 
@@ -464,14 +470,25 @@ int mhs_tps_eval_plan(const mhs_tps *t, int *tile_cols, int *tile_rows, int64_t 
 
 int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                              int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream) {
+    return tps_predict_rows_dev(t, g, r0, r1, c0, c1, r0, r1, out_dev, ld, stream);
+}
+
+}  // extern "C"
+
+// Rows [b0, b1) of the window [r0, r1) x [c0, c1), evaluated with the WINDOW's plan (far-field tile size, tile origin,
+// path decision): out_dev holds row b0 at offset 0.  The multi-device drivers cut a window into row bands, one per device;
+// every band's cells then get exactly the arithmetic of the one-piece evaluation.
+int mhs::tps_predict_rows_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                              int64_t b0, int64_t b1, double *out_dev, int64_t ld, void *stream) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(t && g && out_dev, "NULL argument");
     MHS_REQUIRE(g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
     MHS_REQUIRE(0 <= r0 && r0 <= r1 && r1 <= g->nrow && 0 <= c0 && c0 <= c1 && c1 <= g->ncol,
                 "window outside the grid");
+    MHS_REQUIRE(r0 <= b0 && b0 <= b1 && b1 <= r1, "row band outside the window");
     MHS_REQUIRE(ld >= c1 - c0, "ld smaller than the window width");
     MHS_REQUIRE(r1 - r0 < (1LL << 30) && c1 - c0 < (1LL << 30), "window too large");
-    if (r1 == r0 || c1 == c0) return MHS_OK;
+    if (b1 == b0 || c1 == c0) return MHS_OK;
     const EvalGeom e = make_geom(t, g, r0, r1, c0, c1, ld);
     FarGeom f;
     bool far = false;
@@ -486,8 +503,10 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
         Pm.last_stream = pick_stream(stream);
         Pm.in_flight = true;
         const mhs_tps::FarPlan &P = t->far;
-        const int ntiles = f.ntx * f.nty;
-        dim3 cgrid((unsigned)(f.ntx * (f.tx / 64)), (unsigned)(f.nty * (f.ty / EVAL_TILE_ROWS)));
+        f.row_lo = (int)(b0 - r0); f.row_hi = (int)(b1 - r0);
+        f.ty_lo = f.row_lo / f.ty; f.ty_hi = (f.row_hi + f.ty - 1) / f.ty;
+        const int ntiles = f.ntx * (f.ty_hi - f.ty_lo);
+        dim3 cgrid((unsigned)(f.ntx * (f.tx / 64)), (unsigned)((f.ty_hi - f.ty_lo) * (f.ty / EVAL_TILE_ROWS)));
         MHS_REQUIRE(cgrid.y <= 65535u, "too many rows for one launch");
         hipLaunchKernelGGL(tps_ff_nodes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, pick_stream(stream),
                            P.sorted_dev, (int)t->n, P.bin_start_dev, ctx().log_tab, e, f, P.nodes_dev);
@@ -496,14 +515,18 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
         MHS_HIP(hipGetLastError());
         return MHS_OK;
     }
-    dim3 grid((unsigned)((e.nc + 63) / 64), (unsigned)((e.nr + EVAL_TILE_ROWS - 1) / EVAL_TILE_ROWS));
+    // the direct sum does not depend on the window: the band is evaluated as a window of its own
+    const EvalGeom eb = make_geom(t, g, b0, b1, c0, c1, ld);
+    dim3 grid((unsigned)((eb.nc + 63) / 64), (unsigned)((eb.nr + EVAL_TILE_ROWS - 1) / EVAL_TILE_ROWS));
     // gridDim.y is limited to 65535: 16 rows per block covers > 1e6 rows
     MHS_REQUIRE(grid.y <= 65535u, "too many rows for one launch");
     hipLaunchKernelGGL(tps_eval_grid_kernel, grid, dim3(64 * EVAL_WAVES), 0, pick_stream(stream),
-                       t->knots_dev, (int)t->n, ctx().log_tab, e, out_dev);
+                       t->knots_dev, (int)t->n, ctx().log_tab, eb, out_dev);
     MHS_HIP(hipGetLastError());
     return MHS_OK;
 }
+
+extern "C" {
 
 int mhs_tps_predict_grid(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0,
                          int64_t c1, double *out_host) {

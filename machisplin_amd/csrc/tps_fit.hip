@@ -1835,7 +1835,8 @@ struct ReductionCache {
     size_t bytes = 0;
     uint64_t clock = 0;
 };
-static ReductionCache g_rcache;
+static ReductionCache g_rcache_slots[MAX_SLOTS];      // one per device slot: entries hold device pointers
+#define g_rcache (g_rcache_slots[current_slot()])
 // Device bytes the cache may pin (MHS_RCACHE_MAX_MB, default 4096): a band-route entry is a full copy of the reduced matrix
 // (200 MB at n = 5 000), and a tiled Step 3 adds one per tile spline above 259 stations -- unbounded, they would compete
 // with the arenas, whose own hipMalloc failures are hard errors (round-3 advisor finding).

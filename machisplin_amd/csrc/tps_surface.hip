@@ -38,9 +38,10 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     std::atomic<int> first_rc{MHS_OK};
     std::mutex err_mu;
     std::string err_msg;
+    const int slot = current_slot();
     auto worker = [&](int lane_id) {
         FitLane &L = *lanes[(size_t)lane_id];
-        (void)hipSetDevice(ctx().device);   // the current device is per host thread
+        SlotBind bind(slot);                // the slot and HIP's current device are per host thread
         // mhs_fit_reserve_cus active: the tiles' evaluations stay, like their fits, on the reserved compute units
         const hipStream_t ls = (ctx().reserved_cus > 0 && L.ms) ? L.ms : L.s;
         std::vector<double> sx, sy, sr, txy;
