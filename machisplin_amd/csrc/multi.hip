@@ -471,11 +471,12 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             auto fit = [&]() -> int {
                 S.resid.resize((size_t)n);
                 if (int rc2 = mhs_residual_points(my, weights, n_models, wt_total, X, resp, n, S.resid.data())) return rc2;
-                double mean = 0.0, ss = 0.0, rs = 0.0;
-                for (int64_t i = 0; i < n; ++i) mean += resp[i];
-                mean /= (double)n;
-                for (int64_t i = 0; i < n; ++i) { ss += (resp[i] - mean) * (resp[i] - mean); rs += S.resid[(size_t)i] * S.resid[(size_t)i]; }
-                S.tss = ss; S.rsq_model = 1.0 - rs / ss;
+                // R's sum() and mean() accumulate in long double (V73:912-917 run in R): so do these
+                long double msum = 0.0L, ss = 0.0L, rs = 0.0L;
+                for (int64_t i = 0; i < n; ++i) msum += resp[i];
+                const double mean = (double)(msum / (long double)n);
+                for (int64_t i = 0; i < n; ++i) { ss += (long double)((resp[i] - mean) * (resp[i] - mean)); rs += (long double)(S.resid[(size_t)i] * S.resid[(size_t)i]); }
+                S.tss = (double)ss; S.rsq_model = 1.0 - (double)rs / (double)ss;
                 if (tiled) return MHS_OK;
                 const double t0 = now_ms();
                 mhs_tps *t = nullptr;
@@ -553,9 +554,9 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         }
         team.bar.wait();                                               // every station's cell has been read
         if (slot == 0 && !team.failed()) {                             // V73:917-930: keep the sum iff it improves R^2
-            double rs = 0.0;
-            for (int64_t i = 0; i < n; ++i) { const double e = resp[i] - S.f_actual[(size_t)i]; rs += e * e; }
-            S.rsq_final = 1.0 - rs / S.tss;
+            long double rs = 0.0L;
+            for (int64_t i = 0; i < n; ++i) { const double e = resp[i] - S.f_actual[(size_t)i]; rs += (long double)(e * e); }
+            S.rsq_final = 1.0 - (double)rs / S.tss;
             S.used_tps = S.rsq_final > S.rsq_model ? 1 : 0;
         }
         team.bar.wait();
@@ -793,11 +794,12 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                                                 covars_host->nodata, 0, nr, L.ens, nc, M->s)) return rc2;
                 std::vector<double> res((size_t)U.n);
                 if (int rc2 = mhs_residual_points(my.data(), U.weights, U.n_models, U.wt_total, U.X, U.resp, U.n, res.data())) return rc2;
-                double mean = 0.0, tss = 0.0, rs = 0.0;
-                for (int64_t i = 0; i < U.n; ++i) mean += U.resp[i];
-                mean /= (double)U.n;
-                for (int64_t i = 0; i < U.n; ++i) { tss += (U.resp[i] - mean) * (U.resp[i] - mean); rs += res[(size_t)i] * res[(size_t)i]; }
-                rsq_model[(size_t)u] = 1.0 - rs / tss;
+                long double msum = 0.0L, tss_l = 0.0L, rs = 0.0L;      // R's sum() / mean(): long double accumulators
+                for (int64_t i = 0; i < U.n; ++i) msum += U.resp[i];
+                const double mean = (double)(msum / (long double)U.n);
+                for (int64_t i = 0; i < U.n; ++i) { tss_l += (long double)((U.resp[i] - mean) * (U.resp[i] - mean)); rs += (long double)(res[(size_t)i] * res[(size_t)i]); }
+                const double tss = (double)tss_l;
+                rsq_model[(size_t)u] = 1.0 - (double)rs / tss;
                 const double *fin = L.ens;
                 if (tps) {
                     // Step 3 + 4 (V73:636-897) on the tile, Step 5 (V73:902-930)
@@ -808,9 +810,9 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                     if (int rc2 = mhs_cells_from_xy(&gt, knots, U.n, rows.data(), cols.data())) return rc2;
                     std::vector<double> f((size_t)U.n);
                     if (int rc2 = mhs_gather_cells_dev(L.tps, nc, rows.data(), cols.data(), U.n, f.data(), M->s)) return rc2;
-                    rs = 0.0;
-                    for (int64_t i = 0; i < U.n; ++i) { const double e = U.resp[i] - f[(size_t)i]; rs += e * e; }
-                    rsq_final[(size_t)u] = 1.0 - rs / tss;
+                    rs = 0.0L;
+                    for (int64_t i = 0; i < U.n; ++i) { const double e = U.resp[i] - f[(size_t)i]; rs += (long double)(e * e); }
+                    rsq_final[(size_t)u] = 1.0 - (double)rs / tss;
                     if (rsq_final[(size_t)u] > rsq_model[(size_t)u]) fin = L.tps;
                 }
                 MHS_HIP(hipMemcpyAsync(plane[(size_t)u], fin, sizeof(double) * (size_t)nr * (size_t)nc, hipMemcpyDeviceToDevice, M->s));

@@ -59,7 +59,8 @@ def test_row_bands_over_slots_equal_the_single_device_chain_bit_for_bit(hip, til
             got, info = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp, tile_edge=tile_edge, slot0_share=share)
             assert info["n_slots"] == n_slots and info["used_tps"] and info["collective"] == "none"
             assert sum(b - a for a, b in info["bands"]) == NROW and all(a % 16 == 0 for a, _ in info["bands"][1:])
-            assert info["rsq_model"] == ref["rsq_model"] and info["rsq_final"] == ref["rsq_final"]
+            # the two R^2 are O(n) host sums: long double accumulators in the library (as R's sum), numpy's pairwise sum in the mirror
+            assert info["rsq_model"] == pytest.approx(ref["rsq_model"], rel=1e-13) and info["rsq_final"] == pytest.approx(ref["rsq_final"], rel=1e-13)
             assert np.array_equal(got, want, equal_nan=True), (n_slots, share, np.nanmax(np.abs(got - want)))
         # resident bands, the stitched plane on every slot
         ms = multi.MultiStack(g, host, nodata, slot0_share=0.12 if n_slots > 1 else None)
@@ -158,7 +159,7 @@ def test_tile_layer_units_over_slots_equal_the_python_chain(hip):
         multi.init_devices(n_slots, [0] * n_slots)
         outs, rsq, info = multi.tiles_units_multi(g, host, nodata, 2, 2, 24, units, T_LAYERS, tile_edge=100)
         assert info["n_slots"] == n_slots and info["n_units"] == 4 * T_LAYERS
-        assert np.array_equal(rsq, want_rsq), n_slots
+        assert np.allclose(rsq, want_rsq, rtol=1e-13, atol=0), n_slots
         for l in range(T_LAYERS):
             assert np.array_equal(outs[l], want[l], equal_nan=True), (n_slots, l)
     # a layer whose merge is skipped stays untouched; smooth members only (tps = False) return pred.elev
