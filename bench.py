@@ -89,6 +89,11 @@ def parse():
     ap.add_argument("--tps-mode", default="global", choices=["global", "tiled"],
                     help="Step 3 of the row-band workloads: one global fit (the north-star primitive, default) or the reference's "
                          "own ceil(n/1500)^2 overlapping tiles dealt over the ranks (no serial fit)")
+    ap.add_argument("--in-library", action="store_true",
+                    help="drive the --gpus devices from ONE process through the library's own multi-device entry points "
+                         "(mhs_init_devices + mhs_mltps_grid_multi_dev / mhs_tiles_units_multi: the path the single-threaded R host "
+                         "takes) instead of one process per GPU under torch.distributed; with fewer physical devices than --gpus "
+                         "the slots share devices (plumbing only, flagged in the line)")
     return ap.parse_args()
 
 
@@ -902,8 +907,140 @@ class TileWorkload:
                 "host": host, "unit_s": t_unit, "gpu_over_cpu": t_unit * n_units * 1e3 / ms_per_step}
 
 
+def main_in_library(args):
+    """`--in-library`: the same step driven by ONE host process over N device slots (csrc/multi.hip).  Launched plainly
+    (`python bench.py --gpus N --in-library`) or under torch.distributed.run as the driver launches bench.py -- then rank 0
+    drives all N devices and the other ranks only stand at the barriers (they never touch a GPU)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        if rank != 0:
+            dist.barrier()          # start of the timed region on rank 0
+            dist.barrier()          # its end
+            dist.destroy_process_group()
+            return
+    import machisplin_amd as mhs
+    from machisplin_amd import multi, synth
+    N = args.gpus
+    ndev = torch.cuda.device_count()
+    ids = [k % max(ndev, 1) for k in range(N)]
+    torch.cuda.set_device(0)
+    multi.init_devices(N, ids)
+    cfg = WORKLOADS[args.workload]
+    line = {"metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    driver = {"host": "one process, one host thread per device slot (mhs_init_devices)", "device_ids": ids,
+              "slots_share_devices": len(set(ids)) < N}
+    if cfg.get("tiled"):
+        # BASELINE configs[3]: machisplin.tiles.create -> mltps per (tile, layer) -> machisplin.tiles.merge in ONE library call,
+        # host planes in, host planes out (what the R shim hands over): PCIe is inside the call
+        side, n, L = cfg["side"], cfg["stations"], cfg["resp_layers"]
+        g = synth.grid(side, side)
+        seed = synth.BASE_SEED + 4
+        xy, rows, cols, uv = synth.stations(g, n, seed)
+        tl = mhs.tiles.tiles_create(g, xy, out_ncol=cfg["tiles"][1], out_nrow=cfg["tiles"][0], feather_d=cfg["feather_d"])
+        planes, nodata = synth.covariates(g, cfg["layers"], seed, dtype="f32")
+        host = planes.cpu().numpy()
+        del planes
+        torch.cuda.empty_cache()
+        full_cov = synth.covariates_at(g, cfg["layers"], seed, rows, cols)
+        X = np.column_stack([full_cov, xy])
+        base = synth.response(X, uv, seed)
+        rng = np.random.default_rng(seed + 99)
+        resp = np.column_stack([(1.0 + 0.1 * l) * base + 3.0 * np.sin((2 + l) * uv[:, 0]) + 0.5 * rng.standard_normal(n) for l in range(L)])
+        _, wts, tot = mhs.models.select_weights([0.22, 0.12, 0.18, 0.41], labels="gnmv")
+        nt = len(tl["dat"])
+        units = [[None] * nt for _ in range(L)]
+        for t in range(nt):
+            sel = tl["dat"][t]
+            gt = tl["geom"][t]
+            tr, tc = mhs.tiles.cells_from_xy(gt, xy[sel])
+            Xt = np.column_stack([full_cov[sel], gt.x_from_col(tc), gt.y_from_row(tr)])       # the TILE raster's cell centres (V73:127-154)
+            ok = (tr >= 0) & ~np.isnan(Xt).any(axis=1) & ~np.isnan(resp[sel]).any(axis=1)
+            for l in range(L):
+                params = synth.ensemble_params(X[sel], resp[sel, l], seed + 7 * l + t, which="gnmv")
+                units[l][t] = {"models": [mhs.models.from_param_dict(p) for p in params], "weights": wts, "wt_total": tot,
+                               "X": Xt[ok], "resp": resp[sel, l][ok]}
+        kw = dict(tile_edge=cfg.get("tile_edge", 1500))
+        run = lambda: multi.tiles_units_multi(g, host, nodata, cfg["tiles"][1], cfg["tiles"][0], cfg["feather_d"], units, L, **kw)
+        cells = side * side * L
+        line["unit"] = "Mcells/s (cells x response layers)"
+        config = {"workload": cfg["name"], "stations": n, "grid": [side, side], "response_layers": L, "user_tiles": list(cfg["tiles"]),
+                  "parallelism": "in-library: (tile, layer) units round-robin over %d device slot(s), a layer's tiles to its owner over xGMI, "
+                                 "tiles.merge there (mhs_tiles_units_multi)" % N,
+                  "boundary": "host planes in, merged host planes out: PCIe inside the timed region (float32 covariates up, 12 float64 planes down)"}
+    else:
+        wl = Workload(cfg, mhs, torch, None, 0, 1, args.tps_mode)
+        host = wl.stack.planes.cpu().numpy()
+        g, cells = wl.geom, wl.cells
+        tile_edge = 1500 if args.tps_mode == "tiled" else None
+        # the bands' balance (setup, untimed): one step with equal bands tells what share slot 0 -- which also fits -- should take
+        ms = multi.MultiStack(g, host, wl.stack.nodata)
+        info = ms.step(wl.models, wl.weights, wl.wt_total, wl.X, wl.resp, tile_edge=tile_edge, gather=True)
+        share = info["suggested_slot0_share"]
+        if N > 1 and share == share:
+            ms.free()
+            ms = multi.MultiStack(g, host, wl.stack.nodata, slot0_share=share)
+        run = lambda: ms.step(wl.models, wl.weights, wl.wt_total, wl.X, wl.resp, tile_edge=tile_edge, gather=True)
+        line["unit"] = "Mcells/s"
+        config = {"workload": cfg["name"], "stations": cfg["stations"], "grid": [cfg["side"], cfg["side"]],
+                  "covariates": "%d x float32 planes, band k resident in slot k's HBM" % cfg["layers"],
+                  "members": [p["kind"] for p in wl.params], "gbm_trees": cfg["gbm_trees"], "rf_trees": cfg["rf_trees"],
+                  "tps_mode": args.tps_mode, "slot0_row_share": None if share != share else share,
+                  "parallelism": "in-library: rowband%d over device slots, coefficients handed over in host memory, 1 all-gather "
+                                 "(mhs_mltps_grid_multi_dev, gather = 1)" % N}
+    for _ in range(args.warmup):
+        last = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    line.update({"value": cells * args.steps / dt / 1e6, "ms_per_step": dt / args.steps * 1e3, "config": config})
+    if cfg.get("tiled"):
+        outs, rsq, uinfo = last
+        driver.update(uinfo)
+        line.update({"rsq_model_mean": float(np.nanmean(rsq[:, :, 0])), "rsq_final_mean": float(np.nanmean(rsq[:, :, 1])),
+                     "roofline": None, "cpu_baseline": None})
+    else:
+        driver.update({k: last[k] for k in ("bands", "band_ms", "tiles_ms", "fit_ms", "step_ms", "collective", "suggested_slot0_share")})
+        line.update({"lambda": last["lambda"], "rsq_model": last["rsq_model"], "rsq_final": last["rsq_final"]})
+        # the dominant kernel's roofline: the slots launch the kernels of the one-device step on their bands; the member-by-member
+        # HIP-event table is taken from that step on slot 0's device over the whole grid (outside the timed region)
+        for _ in range(2):
+            wl.step()
+        wl.collect()
+        table = wl.kernel_table()
+        dom = max(table, key=lambda r: r["launch_ms"]) if table else None
+        line["roofline"] = ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work", "pmc",
+                                                  "issue_view") if k in dom} if dom else None)
+        if line["roofline"] is not None:
+            line["roofline"]["measured_on"] = "one device, whole grid: the same kernel every slot launches on its band"
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or N > 1) else wl.cpu_baseline(line["ms_per_step"])
+        # the in-library planes against the one-process-per-GPU driver's arithmetic on one device (bit for bit)
+        one = wl.last["final"].cpu().numpy()
+        line["equals_one_device_plane"] = bool(np.array_equal(ms.download(), one, equal_nan=True))
+        ms.free()
+    line["in_library"] = driver
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.in_library:
+        return main_in_library(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,57 +1,56 @@
-# R-side multi-GPU driver for machisplin.tiles.* runs (UNTESTED HERE: no R in the build image; the same scheme runs in
-# Python as machisplin_amd/sharded.py::TileShardedMltps and is covered there).  The reference's only parallelism ever was
-# snowfall's sfLapply over response layers (old/...V69.R:964); its current README runs machisplin.mltps once per tile of
-# machisplin.tiles.create and merges with machisplin.tiles.merge (README.md:157-215).  Here the (tile, layer) units of such a
-# run are dealt over the node's GPUs: one R worker process per GPU (parallel::makeCluster, type "PSOCK" -- a HIP context must
-# not be forked), each worker binds its device with options(machisplin.device = rank) before the backend initialises, runs
-# machisplin.mltps for its units with options(machisplin.backend = "hip") and returns the final rasters' values; the master
-# merges every layer with machisplin.tiles.merge.  The library has no collective inside: planes travel through R's own
-# serialisation, 8 bytes per cell and unit (cfg4: 48 units x 25 M cells = 9.7 GB over the workers' sockets -- minutes of R
-# time against the step's second on the GPUs: write the units to GeoTIFF on the workers instead when that matters).
+# R side of the multi-GPU drop-in (UNTESTED IN R: no R in the build image; the .Call entry points below are executed against
+# a stub R runtime in tests/test_r_shim_exec.py, and the library calls behind them in tests/test_multi_gpu.py).
 #
-#   tiles  <- machisplin.tiles.create(int.values, covar.ras, out.ncol = 2, out.nrow = 2, feather.d = 50)
-#   finals <- mhs_tiles_mltps(tiles, n.gpus = 4)            # list over response layers of lists over tiles
-#   bio1   <- machisplin.tiles.merge(finals[[1]], in.ncol = 2, in.nrow = 3)
+# ONE R process drives every GPU of the node: mhs_init_devices(8) brings up eight device slots inside libmachisplin_hip.so,
+# and each of the two calls below hands the WHOLE job to the library, which runs one host thread and one set of HIP streams
+# per GPU and moves planes between GPUs itself (RCCL all-gather / peer copies over xGMI).  Nothing travels through R's
+# serialisation and there are no PSOCK workers (the round-4 design, priced by its own comment at minutes of R time).
+#
+# The reference's parallelism: snowfall's sfLapply over response layers in old versions (old/...V69.R:964), none today
+# (n.cores forced to 1, V73:117); its README runs machisplin.mltps once per tile of machisplin.tiles.create and merges with
+# machisplin.tiles.merge (README.md:157-215).  Model FITTING (Step 1 and the final fits, V73:176-436) stays in R and in the
+# CRAN packages, single-threaded as the reference runs it; what goes to the GPUs is everything raster-sized.
 
-mhs_unit_owner <- function(tile, layer, n.tiles, n.gpus) {
-  u <- (layer - 1L) * n.tiles + (tile - 1L)                  # layer-major numbering, as sharded.unit_owner
-  c(rank = u %% n.gpus, slot = u %/% n.gpus)
+mhs_init_devices <- function(n.gpus, ids = NULL) {
+  .Call("mhsr_init_devices", as.integer(n.gpus), if (is.null(ids)) NULL else as.integer(ids))
 }
 
-mhs_tiles_mltps <- function(tiles, n.gpus = 1L, ...) {
-  n.tiles <- length(tiles$dat)
-  n.layers <- ncol(tiles$dat[[1]]) - 2L                      # long, lat, then the response layers
-  units <- expand.grid(tile = seq_len(n.tiles), layer = seq_len(n.layers))
-  units$rank <- mapply(function(t, l) mhs_unit_owner(t, l, n.tiles, n.gpus)[["rank"]], units$tile, units$layer)
-  cl <- parallel::makeCluster(n.gpus, type = "PSOCK")
-  on.exit(parallel::stopCluster(cl))
-  parallel::clusterApply(cl, seq_len(n.gpus) - 1L, function(rank) {
-    options(machisplin.backend = "hip", machisplin.device = rank)
-    library(MACHISPLIN)
-    invisible(.Call("mhsr_init", as.integer(rank)))
-  })
-  run.rank <- function(mine, tiles, ...) {
-    # a worker keeps ONE tile's rasters in memory at a time; its layers share the Step-3 reductions (mhsr_tps_reduction_cache)
-    out <- vector("list", nrow(mine))
-    for (t in unique(mine$tile)) {
-      ras <- terra::rast(tiles$rast[[t]])
-      .Call("mhsr_tps_reduction_cache", 1L)
-      for (k in which(mine$tile == t)) {
-        l <- mine$layer[k]
-        dat <- tiles$dat[[t]][, c(1, 2, 2 + l)]
-        res <- machisplin.mltps(int.values = dat, covar.ras = ras, n.cores = 1, ...)
-        out[[k]] <- list(tile = t, layer = l, values = terra::values(res[[1]]$final), geom = c(nrow(ras), ncol(ras)))
-      }
-      .Call("mhsr_tps_reduction_cache", 0L)
-    }
-    out
+# ---- machisplin.mltps Steps 2-5 of ONE response layer over all GPUs (replaces V73:447-930 behind `if (hip)`) -------------
+# handles / OptX.mfit.wt / OptX.mfit.wt.tot: the fitted members as .mhs_step2_member collects them (mods.run order, rounded
+# kept weights, unrounded total -- V73:337-392); dat: dat_tps[[i]] (resp, covariates, LONG, LAT -- V73:145-154).
+# Returns list(final = SpatRaster, rsq.model, rsq.final, lambda, used.tps): `final` is what V73:925-930 selects.
+mhs_mltps_multi <- function(covar.ras, handles, OptX.mfit.wt, OptX.mfit.wt.tot, dat, tile.edge = 1500L, lambda = NA_real_,
+                            slot0.share = getOption("machisplin.slot0.share", NA_real_)) {
+  X <- as.matrix(dat[, -1, drop = FALSE])
+  out <- .Call("mhsr_mltps_grid_multi", handles, as.numeric(OptX.mfit.wt), OptX.mfit.wt.tot, .mhs_geom(covar.ras),
+               terra::values(covar.ras), X, as.numeric(dat[, 1]), as.integer(tile.edge), lambda, 0L, slot0.share)
+  options(machisplin.slot0.share = out[[7]])               # what this call measured: the next layer's bands are balanced with it
+  list(final = terra::setValues(covar.ras[[1]], out[[1]]), rsq.model = out[[2]], rsq.final = out[[3]], lambda = out[[4]],
+       used.tps = out[[5]] == 1L, n.slots = out[[6]])
+}
+
+# ---- a machisplin.tiles.* run over all GPUs (README.md:157-215) ------------------------------------------------------------
+#   tiles <- machisplin.tiles.create(int.values, covar.ras, out.ncol = 2, out.nrow = 2, feather.d = 50)
+#   fits  <- mhs_tiles_fit(tiles, ...)                     # Step 1 + the final fits per (tile, layer): in R, unchanged
+#   bio   <- mhs_tiles_mltps(covar.ras, tiles, fits, out.ncol = 2, out.nrow = 2, feather.d = 50)   # list of merged SpatRasters
+#
+# fits[[l]][[t]] = list(handles, wts, wt.tot, dat) for response layer l and tile t (tiles row-major from the south-west,
+# V73:1192-1197): the members fitted on tile t's stations, their weights, and the tile's dat_tps (resp, covariates, LONG, LAT
+# at the TILE raster's cell centres).  The library crops covar.ras to every tile itself (mhs_tiles_create_windows repeats
+# V73:1165-1208), runs unit (l, t) on GPU ((l - 1) * n.tiles + t - 1) %% n.gpus, brings a layer's tiles to its owner over xGMI
+# and merges them as machisplin.tiles.merge does (V73:1392-1548).
+mhs_tiles_mltps <- function(covar.ras, tiles, fits, out.ncol, out.nrow, feather.d = 50, tps = TRUE, tile.edge = 1500L,
+                            lambda = NA_real_) {
+  n.layers <- length(fits)
+  n.tiles <- out.ncol * out.nrow
+  units <- vector("list", n.layers * n.tiles)
+  for (l in seq_len(n.layers)) for (t in seq_len(n.tiles)) {
+    f <- fits[[l]][[t]]
+    units[[(l - 1L) * n.tiles + t]] <- list(f$handles, as.numeric(f$wts), f$wt.tot, as.matrix(f$dat[, -1, drop = FALSE]),
+                                            as.numeric(f$dat[, 1]))
   }
-  parts <- parallel::clusterApply(cl, seq_len(n.gpus) - 1L, function(rank, units, tiles, run.rank, ...)
-    run.rank(units[units$rank == rank, , drop = FALSE], tiles, ...), units, tiles, run.rank, ...)
-  finals <- lapply(seq_len(n.layers), function(l) vector("list", n.tiles))
-  for (p in parts) for (u in p) {
-    r <- terra::rast(tiles$rast[[u$tile]][[1]])
-    finals[[u$layer]][[u$tile]] <- terra::setValues(r, u$values)
-  }
-  finals
+  out <- .Call("mhsr_tiles_units_multi", .mhs_geom(covar.ras), terra::values(covar.ras), as.integer(out.ncol),
+               as.integer(out.nrow), feather.d, units, as.integer(n.layers), as.integer(tps), as.integer(tile.edge), lambda, 0L)
+  list(final = lapply(out[[1]], function(v) terra::setValues(covar.ras[[1]], v)),
+       rsq = array(out[[2]], c(2L, n.tiles, n.layers), dimnames = list(c("rsq.model", "rsq.final"), NULL, NULL)))
 }

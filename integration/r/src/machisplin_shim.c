@@ -241,6 +241,109 @@ SEXP mhsr_tps_reduction_cache(SEXP enable) {
     return enable;
 }
 
+/* ---- several devices from the one R process (include/machisplin_hip.h, "several devices") ---- */
+
+/* mhs_init_devices: n device slots on the devices `ids` (NULL = 0 .. n - 1) */
+SEXP mhsr_init_devices(SEXP n, SEXP ids) {
+    int nn = Rf_asInteger(n);
+    if (nn == NA_INTEGER || nn < 1 || nn > 16) Rf_error("mhsr_init_devices: n must be 1..16");
+    if (!Rf_isNull(ids) && Rf_length(ids) != nn) Rf_error("mhsr_init_devices: length(ids) must equal n");
+    chk(mhs_init_devices(nn, Rf_isNull(ids) ? NULL : INTEGER(ids)));
+    int slots = 0;
+    chk(mhs_device_slots(&slots, NULL));
+    return Rf_ScalarInteger(slots);
+}
+
+static const mhs_model **model_handles(SEXP models, int *n) {
+    *n = Rf_length(models);
+    const mhs_model **h = (const mhs_model **)R_alloc((size_t)(*n > 0 ? *n : 1), sizeof(*h));
+    for (int i = 0; i < *n; ++i) {
+        h[i] = (const mhs_model *)R_ExternalPtrAddr(VECTOR_ELT(models, i));
+        if (!h[i]) Rf_error("machisplin_hip: a model handle has been freed");
+    }
+    return h;
+}
+
+/* machisplin.mltps Steps 2-5 for one response layer (V73:447-930) over every device slot in ONE call: covars =
+ * terra::values(covar.ras) (ncell x C, planar as it stands), X = as.matrix(dat_tps[, predictors]) (n x p: covariates, LONG,
+ * LAT), resp the response column.  Returns list(final (terra cell order), rsq.model, rsq.final, lambda, used.tps,
+ * n.slots, slot0.share for the next call). */
+SEXP mhsr_mltps_grid_multi(SEXP models, SEXP weights, SEXP wt_total, SEXP geom, SEXP covars, SEXP X, SEXP resp, SEXP tile_edge,
+                           SEXP lambda, SEXP mode, SEXP slot0_share) {
+    mhs_grid g = grid_from(geom);
+    int n = 0;
+    const mhs_model **h = model_handles(models, &n);
+    if (!Rf_isReal(covars) || !Rf_isMatrix(covars) || (int64_t)Rf_nrows(covars) != g.nrow * g.ncol)
+        Rf_error("mhsr_mltps_grid_multi: covars must be terra::values(covar.ras), an ncell x layers double matrix");
+    if (!Rf_isReal(X) || !Rf_isMatrix(X) || Rf_ncols(X) != Rf_ncols(covars) + 2 || Rf_length(resp) != Rf_nrows(X))
+        Rf_error("mhsr_mltps_grid_multi: X must be n x (layers + 2) and resp of length n");
+    if (Rf_length(weights) != n) Rf_error("mhsr_mltps_grid_multi: one weight per model");
+    mhs_stack st = { REAL(covars), Rf_ncols(covars), MHS_F64, (int64_t)g.nrow * g.ncol, g.ncol, R_NaN };
+    double lam = Rf_asReal(lambda), share = Rf_asReal(slot0_share);
+    mhs_mltps_info info;
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 7));
+    SEXP fin = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)g.nrow * g.ncol));
+    int rc = mhs_mltps_grid_multi(h, REAL(weights), n, Rf_asReal(wt_total), &g, &st, REAL(X), REAL(resp), (int64_t)Rf_nrows(X),
+                                  (int64_t)Rf_asInteger(tile_edge), ISNA(lam) ? R_NaN : lam, Rf_asInteger(mode),
+                                  ISNA(share) ? R_NaN : share, REAL(fin), &info);
+    if (rc == 0) {
+        SET_VECTOR_ELT(out, 0, fin); SET_VECTOR_ELT(out, 1, Rf_ScalarReal(info.rsq_model)); SET_VECTOR_ELT(out, 2, Rf_ScalarReal(info.rsq_final));
+        SET_VECTOR_ELT(out, 3, Rf_ScalarReal(info.lambda)); SET_VECTOR_ELT(out, 4, Rf_ScalarInteger(info.used_tps));
+        SET_VECTOR_ELT(out, 5, Rf_ScalarInteger(info.n_slots)); SET_VECTOR_ELT(out, 6, Rf_ScalarReal(info.suggested_slot0_share));
+    }
+    UNPROTECT(2);
+    chk(rc);
+    return out;
+}
+
+/* machisplin.tiles.create -> machisplin.mltps Steps 2-5 per (tile, layer) -> machisplin.tiles.merge (README.md:157-215,
+ * V73:1165-1256, 1392-1548) over every device slot in ONE call.  units: list of length n.layers * n.tiles, layer-major
+ * (unit (l - 1) * n.tiles + t), each list(models, weights, wt.total, X, resp) of that tile's fits and station table.
+ * Returns list(planes = list over layers of numeric vectors in terra cell order, rsq = 2 x n.units matrix). */
+SEXP mhsr_tiles_units_multi(SEXP geom, SEXP covars, SEXP out_ncol, SEXP out_nrow, SEXP feather_d, SEXP units, SEXP n_layers,
+                            SEXP tps, SEXP tile_edge, SEXP lambda, SEXP mode) {
+    mhs_grid g = grid_from(geom);
+    int L = Rf_asInteger(n_layers), nc = Rf_asInteger(out_ncol), nr = Rf_asInteger(out_nrow);
+    if (L == NA_INTEGER || L < 1 || nc < 1 || nr < 1) Rf_error("mhsr_tiles_units_multi: bad layout");
+    int nu = Rf_length(units);
+    if (nu != L * nc * nr) Rf_error("mhsr_tiles_units_multi: need n.layers * out.ncol * out.nrow = %d units, got %d", L * nc * nr, nu);
+    if (!Rf_isReal(covars) || !Rf_isMatrix(covars) || (int64_t)Rf_nrows(covars) != g.nrow * g.ncol)
+        Rf_error("mhsr_tiles_units_multi: covars must be terra::values(covar.ras), an ncell x layers double matrix");
+    mhs_unit *u = (mhs_unit *)R_alloc((size_t)nu, sizeof(*u));
+    for (int i = 0; i < nu; ++i) {
+        SEXP e = VECTOR_ELT(units, i);
+        if (TYPEOF(e) != VECSXP || Rf_length(e) != 5) Rf_error("mhsr_tiles_units_multi: unit %d must be list(models, weights, wt.total, X, resp)", i + 1);
+        int nm = 0;
+        u[i].models = model_handles(VECTOR_ELT(e, 0), &nm);
+        u[i].n_models = nm; u[i].reserved_ = 0;
+        if (Rf_length(VECTOR_ELT(e, 1)) != nm) Rf_error("mhsr_tiles_units_multi: unit %d: one weight per model", i + 1);
+        u[i].weights = REAL(VECTOR_ELT(e, 1));
+        u[i].wt_total = Rf_asReal(VECTOR_ELT(e, 2));
+        SEXP X = VECTOR_ELT(e, 3), y = VECTOR_ELT(e, 4);
+        if (!Rf_isReal(X) || !Rf_isMatrix(X) || Rf_ncols(X) != Rf_ncols(covars) + 2 || Rf_length(y) != Rf_nrows(X))
+            Rf_error("mhsr_tiles_units_multi: unit %d: X must be n x (layers + 2) and resp of length n", i + 1);
+        u[i].X = REAL(X); u[i].resp = REAL(y); u[i].n = (int64_t)Rf_nrows(X);
+    }
+    mhs_stack st = { REAL(covars), Rf_ncols(covars), MHS_F64, (int64_t)g.nrow * g.ncol, g.ncol, R_NaN };
+    double lam = Rf_asReal(lambda);
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+    SEXP planes = PROTECT(Rf_allocVector(VECSXP, L));
+    SEXP rsq = PROTECT(Rf_allocMatrix(REALSXP, 2, nu));
+    double **ptr = (double **)R_alloc((size_t)L, sizeof(*ptr));
+    for (int l = 0; l < L; ++l) {
+        SEXP v = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)g.nrow * g.ncol));
+        SET_VECTOR_ELT(planes, l, v);
+        UNPROTECT(1);
+        ptr[l] = REAL(v);
+    }
+    int rc = mhs_tiles_units_multi(&g, &st, nc, nr, Rf_asReal(feather_d), L, u, Rf_asInteger(tps), (int64_t)Rf_asInteger(tile_edge),
+                                   ISNA(lam) ? R_NaN : lam, Rf_asInteger(mode), ptr, REAL(rsq), NULL);
+    if (rc == 0) { SET_VECTOR_ELT(out, 0, planes); SET_VECTOR_ELT(out, 1, rsq); }
+    UNPROTECT(3);
+    chk(rc);
+    return out;
+}
+
 /* library.dynam.unload / R exit: the library's streams go while the HIP runtime is still whole (mhs_init also registers
  * an atexit handler, so this is belt and braces) */
 void R_unload_machisplin_hip(DllInfo *info) {
