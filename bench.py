@@ -1020,6 +1020,7 @@ def main_in_library(args):
         for _ in range(2):
             wl.step()
         wl.collect()
+        wl.measure_mean_visits()
         table = wl.kernel_table()
         dom = max(table, key=lambda r: r["launch_ms"]) if table else None
         line["roofline"] = ({k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "work", "pmc",
