@@ -429,8 +429,9 @@ class Workload:
         scale = 1e8 / (side * side)
 
         def timed(stack, model, env=()):
-            for e in env:
-                os.environ[e] = "1"
+            env = dict(e if isinstance(e, tuple) else (e, "1") for e in env)
+            for e, v in env.items():
+                os.environ[e] = v
             try:
                 mhs.predict(stack, model, out=out)
                 torch.cuda.synchronize()
@@ -463,7 +464,8 @@ class Workload:
                                             "coherent_kernel_ran": bool(cst.value < 83 * cnt.value)}
                     row["gbm_tree_order_kernel_ms_per_1e8_cells"] = timed(stack, model, ("MHS_GBM_NO_COHERENT",))
                 elif kind == "rf":
-                    row["forest_round2_walk_ms_per_1e8_cells"] = timed(stack, model, ("MHS_RF_DOUBLE_BUFFER", "MHS_RF_NO_PREFIX", "MHS_RF_FULL_DEPTH", "MHS_RF_FAR_WALKS"))
+                    # the plain walk: double-buffered kernel, every tree from the root to its full depth (round 2's, minus its cell order)
+                    row["forest_plain_walk_ms_per_1e8_cells"] = timed(stack, model, (("MHS_RF_KERNEL", "db"), "MHS_RF_PLAIN"))
                 else:
                     row["ksvm_lane_per_cell_kernel_ms_per_1e8_cells"] = timed(stack, model, ("MHS_SVR_NO_ROWTILE",))
             heavy = row["gbm_ms_per_1e8_cells"] + row["forest_ms_per_1e8_cells"] + row["ksvm_ms_per_1e8_cells"]

@@ -90,6 +90,8 @@ struct mhs_model {
     // NA cells of a window, compacted for the MissingNode walk (round 4): 4 buffers in turn, {count, overflow, cell indices ...}
     unsigned *na_list[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t na_cap[4] = {0, 0, 0, 0};
+    hipEvent_t na_done[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded behind the last kernel that reads the buffer
+    hipStream_t na_stream[4] = {nullptr, nullptr, nullptr, nullptr}; // ... on this stream
     std::atomic<unsigned> na_next{0};
     std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
     std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
@@ -1335,180 +1337,10 @@ __device__ __forceinline__ uint2v lds_u2(unsigned a) { return *(__attribute__((a
 __device__ __forceinline__ unsigned lds_u32(unsigned a) { return *(__attribute__((address_space(3))) const unsigned *)(uintptr_t)a; }
 __device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
 
-// BIG: trees of more than 8191 nodes (or whose predictions do not fit beside the keys): the children words hold
-// node INDICES (one extra shift per level) and the node predictions stay in global memory -- one read per tree
-// and walk -- so that a 12 000-node tree of a 20 000-station forest (96 KB of nodes) still walks in LDS.
 // walks per lane for the "log2r" code the forest tables are built with: 1 -> 2, 2 -> 4, 3 -> 5 (the double-buffered
 // kernel only: five walks' keys still fit beside two tree buffers when the trees are small)
 __host__ __device__ constexpr int rf_walks(int code) { return code >= 3 ? code + 2 : (1 << code); }   // 1 2 4 | 5 6 7 8
 
-template <int LOG2R, bool BIG>
-__global__ __launch_bounds__(1024) void rf_walk_kernel(const uint2 *__restrict__ gnodes,
-                                                       const double *__restrict__ glval,
-                                                       const int *__restrict__ tree_off,
-                                                       const int *__restrict__ depth,
-                                                       const void *__restrict__ sorted, int key64,
-                                                       const int *__restrict__ sorted_off, int n_trees,
-                                                       int max_nodes, int p, StackDev s, PredGeom g,
-                                                       double weight, int accumulate,
-                                                       double *__restrict__ out) {
-    constexpr int R = 1 << LOG2R;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *lnodes = (uint2 *)smem;                                 // [max_nodes], byte address = 8 * node
-    const unsigned lval_off = (unsigned)max_nodes * 8u;            // double [max_nodes] (not BIG)
-    double *lval = (double *)(smem + lval_off);
-    const unsigned tree_bytes = max(BIG ? lval_off : lval_off * 2u, (unsigned)RF_COARSE_BYTES);
-    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
-    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
-    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
-    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int row[R], col[R];
-    bool na[R];
-    double acc[R];
-    unsigned node[R];
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        int64_t i = i0 + c * part;
-        if (i >= total) i = total - 1;
-        row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        na[c] = false; acc[c] = 0.0;
-    }
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        lut_ranks<R, 1024>(j, sorted, key64, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    for (int t = 0; t < n_trees; ++t) {
-        const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 1024) { lnodes[e] = gnodes[o + e]; if (!BIG) lval[e] = glval[o + e]; }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = 0u;
-        for (int l = 0; l < levels; ++l) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const uint2v nd = lds_u2(BIG ? node[c] << 3 : node[c]);
-                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                // node = k > nd.x ? WORD_1(nd.y) : WORD_0(nd.y); an SDWA instruction may read VCC two wait
-                // states after the VALU write at the earliest
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < R; ++c) acc[c] = acc[c] + (BIG ? glval[o + (int)node[c]] : lds_f64(node[c] + lval_off));
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        const int64_t i = i0 + c * part;
-        if (i0 < part && i < total)
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
-// TREE-MAJOR form for BIG trees (a 20 000-station forest: ~12 000 nodes = 96 KB per tree).  In rf_walk_kernel<BIG> every
-// block stages every tree for ONE batch of 2 048 cells -- all 16 waves idle while 96 KB travel global -> LDS between two
-// barriers, 500 times per block -- and staging is as long as the walk.  Here a block keeps a staged tree for NB batches
-// of cells: the -rank keys of every batch live in REGISTERS (the walk needs them in LDS, indexed by the node's
-// predictor, so the lane copies the batch's P * R keys into its private LDS slots before walking it -- 28 writes
-// against ~140 reads of the walk), 512 threads x R = 4 independent walks x NB = 4 batches = 8 192 cells per block and
-// staging, and the node predictions (global memory) are requested after each batch's walk and added after the last.
-template <int NB, int P, bool K64>
-__global__ __launch_bounds__(512) void rf_walk_tm_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
-                                                         const int *__restrict__ tree_off, const int *__restrict__ depth,
-                                                         const void *__restrict__ sorted, const int *__restrict__ sorted_off,
-                                                         int n_trees, int max_nodes, StackDev s, PredGeom g, double weight,
-                                                         int accumulate, double *__restrict__ out) {
-    constexpr int R = 4, KPB = P * R;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *lnodes = (uint2 *)smem;                                 // [max_nodes], node index -> record
-    const unsigned tree_bytes = max((unsigned)max_nodes * 8u, (unsigned)RF_COARSE_BYTES);
-    float *coarse = (float *)smem;
-    const unsigned stride = (unsigned)KPB | 1u;
-    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t base = (int64_t)blockIdx.x * (512 * R * NB);
-    unsigned kreg[NB][KPB];
-    double acc[NB][R];
-    bool na[NB][R];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        int row[R], col[R];
-        bool nab[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            int64_t i = base + (int64_t)(b * R + c) * 512 + threadIdx.x;
-            if (i >= total) i = total - 1;
-            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-            nab[c] = false; acc[b][c] = 0.0;
-        }
-        // the rank code is instantiated once per batch (not once per batch and predictor): the ranks pass through the
-        // lane's private LDS slots, which take a run-time predictor index, on their way to the statically indexed kreg
-#pragma unroll 1
-        for (int j = 0; j < P; ++j) {
-            float r[R];
-            if constexpr (K64) lut_ranks_t<R, 512, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, nab, r);
-            else lut_ranks_t<R, 512, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, nab, r);
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                *(__attribute__((address_space(3))) unsigned *)(uintptr_t)(lane_base + 4u * (unsigned)(j * R + c)) = (unsigned)r[c] << 8;
-        }
-#pragma unroll
-        for (int k = 0; k < KPB; ++k) kreg[b][k] = lds_u32(lane_base + 4u * k);
-#pragma unroll
-        for (int c = 0; c < R; ++c) na[b][c] = nab[c];
-    }
-    for (int t = 0; t < n_trees; ++t) {
-        const int o = tree_off[t], cnt = tree_off[t + 1] - o, levels = depth[t];
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 512) lnodes[e] = gnodes[o + e];
-        __syncthreads();
-        double pend[NB][R];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int k = 0; k < KPB; ++k) *(__attribute__((address_space(3))) unsigned *)(uintptr_t)(lane_base + 4u * k) = kreg[b][k];
-            unsigned node[R];
-#pragma unroll
-            for (int c = 0; c < R; ++c) node[c] = 0u;
-            for (int l = 0; l < levels; ++l) {
-#pragma unroll
-                for (int c = 0; c < R; ++c) {
-                    const uint2v nd = lds_u2(node[c] << 3);
-                    const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                    asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                        "s_nop 1\n\t"
-                        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                        : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < R; ++c) pend[b][c] = glval[o + (int)node[c]];
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int c = 0; c < R; ++c) acc[b][c] = acc[b][c] + pend[b][c];
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            const int64_t i = base + (int64_t)(b * R + c) * 512 + threadIdx.x;
-            if (i < total) {
-                const int row = (int)(i / g.nc), col = (int)(i - (int64_t)row * g.nc);
-                emit(out, (int64_t)row * g.ld_out + col, na[b][c] ? NAN : acc[b][c] / (double)n_trees, weight, accumulate);
-            }
-        }
-}
 
 // A lane's R cells in the forest walk kernels.  STRIPS (grids): the same column of R adjacent rows -- the rows are cut
 // into strips of R, a lane index runs along a strip and on into the next one -- so that a wave's 64 R cells are
@@ -1538,7 +1370,7 @@ static int64_t rf_lane_count(const PredGeom &g, int R, int strips) {      // lan
     const int64_t total = (int64_t)g.nr * g.nc;
     return strips ? (((int64_t)g.nr + R - 1) / R) * g.nc : (total + R - 1) / R;
 }
-static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R && !getenv("MHS_RF_FAR_WALKS"); }
+static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R; }
 
 // WAVE-UNIFORM PREFIX of the forest walks (round 3; grids).  With LANE = TREE (64 trees at a time, node records read from
 // global memory) every tree is descended for as long as the split threshold lies outside the wave's [min, max] rank of
@@ -1601,7 +1433,7 @@ __device__ __forceinline__ void rf_prefix_entries(unsigned (&entry)[RF_ENTRY_BAT
 // read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
 // tree costs one barrier.  In the single-buffer form a third of the kernel was staging: every wave idle while
 // 48 KB are copied between two barriers, 500 times per block.
-template <int LOG2R, bool K64, bool HAND = true>
+template <int LOG2R, bool K64>
 __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restrict__ gnodes,
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
@@ -1696,7 +1528,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
         const int lev = (ent >> 31) ? 0 : levels - plen, shal = max(shallow - plen, 0);
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = boff + ((ent & 0xFFFFu) << 3);
-        if constexpr (R == 5 && HAND) {
+        if constexpr (R == 5) {
             // five walks: the level loop by hand (tools/gen_rf_walk_asm.py) -- the walks rotated so that the two wait states an
             // SDWA select needs after v_cmp's write of VCC are the previous walk's next node read and the next walk's key wait
             // lev - 1 of them with a next level: the first min(shallowest leaf, lev - 1) untested, the others leave the
@@ -1710,7 +1542,7 @@ __global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restric
                     : [lb] "v"(lane_base)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
-        } else if constexpr (R == 4 && HAND) {
+        } else if constexpr (R == 4) {
             int c0 = min(shal, lev - 1), cnt = lev - 1 - c0;
             if (lev > 0)
                 asm volatile(
@@ -1774,135 +1606,6 @@ __device__ __forceinline__ void lds_signal(unsigned addr) {      // the wave's f
     else asm volatile("" ::: "memory");
 }
 
-template <int LOG2R, bool K64, int STRIDE>
-__global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restrict__ gnodes,
-                                                          const double *__restrict__ glval,
-                                                          const int *__restrict__ tree_off,
-                                                          const int *__restrict__ depth,
-                                                          const void *__restrict__ sorted,
-                                                          const int *__restrict__ sorted_off, int n_trees,
-                                                          int p, StackDev s, PredGeom g,
-                                                          double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix,
-                                                          const int *, int) {      // (rf_walk_ld_kernel's axis-rank table: same launch code)
-    constexpr int R = rf_walks(LOG2R);
-    constexpr int PF = (STRIDE / 8 + 1023) / 1024;                 // node records per thread in flight
-    constexpr unsigned TREE_BYTES = 3u * STRIDE;
-    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
-    constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
-    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
-    const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int row[R], col[R];
-    bool na[R], live[R];
-    double acc[R], pending[R];
-    rf_lane_cells<R>(g, i0, strips, row, col, live);
-#pragma unroll
-    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave (rf_prefix_entries)
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
-    unsigned ecur = 0u;
-    __syncthreads();                                               // coarse table no longer needed
-    for (int t = 0; t < 2 && t < n_trees; ++t) {
-        const int o = tree_off[t], cnt = tree_off[t + 1] - o;
-        for (int e = threadIdx.x; e < cnt; e += 1024) *(uint2 *)(smem + (unsigned)t * STRIDE + (unsigned)e * 8u) = gnodes[o + e];
-    }
-    if (threadIdx.x < 8) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = threadIdx.x < 2 ? 16u : 0u;
-    __syncthreads();
-    auto step = [&](auto slot_tag, const int t) {
-        constexpr int SLOT = decltype(slot_tag)::value, SLOT2 = (SLOT + 2) % 3;
-        if ((t & 63) == 0) {
-            ecur = 0u;
-#pragma unroll
-            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
-        }
-        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
-        const int plen = (int)((ent >> 16) & 0x7FFFu);
-        const int o = tree_off[t], levels = (ent >> 31) ? 0 : depth[t] - plen, shallow = max((dmin ? dmin[t] : depth[t]) - plen, 0);
-        const bool more = t + 2 < n_trees;
-        const int o2 = more ? tree_off[t + 2] : 0, cnt2 = more ? tree_off[t + 3] - o2 : 0;
-        uint2 pn[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            if (e < cnt2) pn[q] = gnodes[o2 + e];
-        }
-        lds_wait_ge(CNT + 4u * SLOT, 16u * (unsigned)(t / 3 + 1));      // tree t is parked
-        unsigned node[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = (ent & 0xFFFFu) << 3;
-        if constexpr (R == 4) {
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
-                asm volatile(
-#include "rf_walk_loop4xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118", "v120");
-        } else if constexpr (R == 5) {
-            int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;
-            if (levels > 0)
-                asm volatile(
-#include "rf_walk_loop5xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
-                      [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
-        } else
-        for (int l = 0; l < levels; ++l) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const uint2v nd = *((__attribute__((address_space(3))) const uint2v *)(uintptr_t)node[c] + SLOT * (STRIDE / 8));
-                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-            }
-        }
-        lds_signal(CNT + 16u + 4u * SLOT);                               // this wave has left tree t
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = glval[o + (int)(node[c] >> 3)];
-        }
-        if (more) {                                                      // uniform
-            lds_wait_ge(CNT + 16u + 4u * SLOT2, 16u * (unsigned)((t + 2) / 3));   // every wave has left tree t - 1
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = threadIdx.x + q * 1024;
-                if (e < cnt2) *(uint2 *)(smem + (unsigned)SLOT2 * STRIDE + (unsigned)e * 8u) = pn[q];
-            }
-            lds_signal(CNT + 4u * SLOT2);
-        }
-    };
-    for (int t = 0; t < n_trees; t += 3) {
-        step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, t + 2);
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
-        if (live[c])
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
 // LOADER-WAVE form (round 4).  Round 3's ablation of the kernel above: of 64.6 ms (8 000 x 8 000 cells, 500 trees) the walks are 23
 // and the "bare tree loop" 25 -- every one of the 16 waves spends ~260 instructions per tree on its share of the staging (eight
 // address computations, PF predicated global loads, PF predicated LDS stores, two counter polls).  Here NL waves of the block
@@ -1920,10 +1623,11 @@ __global__ __launch_bounds__(1024) void rf_walk_tb_kernel(const uint2 *__restric
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {      // 64 lanes x 16 bytes global -> LDS at lds_dst + 16 lane
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// bits of `flags` beside RF_LD_PREFIX: timing experiments (MHS_RF_LD_FLAGS; 2 / 4 / 32 / 128 give wrong planes)
-enum { RF_LD_PREFIX = 1, RF_LD_ABLATE_WALKS = 2, RF_LD_ABLATE_STAGING = 4, RF_LD_ABLATE_SYNC = 8, RF_LD_FEW_TREES = 32, RF_LD_NO_DMA = 64, RF_LD_SETUP_ONLY = 128 };
+// (round 4's timing experiments -- walks, staging or synchronisation switched off, two loaders, no LDS-DMA -- are in
+// profiles/r04_forest_variants.txt and in the history at commit 55aadea; round 5 removed their switches)
+enum { RF_LD_PREFIX = 1 };
 
-template <int LOG2R, bool K64, int STRIDE, int NL>
+template <int LOG2R, bool K64, int STRIDE>
 __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restrict__ gnodes,
                                                           const double *__restrict__ glval,
                                                           const int *__restrict__ tree_off,
@@ -1934,7 +1638,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
                                                           double weight, int accumulate,
                                                           double *__restrict__ out, const int *__restrict__ dmin, int strips, int flags,
                                                           const int *__restrict__ axis_rank, int axis_ncol) {
-    constexpr int R = rf_walks(LOG2R), WALKERS = 16 - NL;
+    constexpr int R = rf_walks(LOG2R), NL = 1, WALKERS = 16 - NL;
     constexpr unsigned TREE_BYTES = 3u * STRIDE;
     static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
     constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
@@ -1994,7 +1698,6 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         constexpr int PF = (STRIDE + 1023) / 1024;                  // 16-byte pieces per lane and tree
         static_assert(PF <= 25, "one named register quad per piece below");
         const unsigned lane16 = (threadIdx.x & 63u) * 16u;
-        const int first = (int)(threadIdx.x >> 6) - WALKERS;         // this loader's trees: first, first + NL, ...
         // named quads, not an array: hipcc keeps a 25 x 16-byte array in scratch memory; always PF pieces, straight-line: under
         // `piece < pieces of this tree` it waits vmcnt(0) between the loads
         uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, r19, r20, r21, r22, r23, r24;
@@ -2004,10 +1707,9 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
 #define MHS_RF_LOAD(Q) if constexpr (Q < PF) r##Q = *(const uint4 *)(src + (size_t)Q * 1024u);
 #define MHS_RF_STORE(Q) if constexpr (Q < PF) *(uint4 *)(smem + slot * (unsigned)STRIDE + (unsigned)Q * 1024u + lane16) = r##Q;
 #define MHS_RF_REQUEST(U) { \
-            src = (const char *)(gnodes + tree_off[(flags & RF_LD_FEW_TREES) ? (U) & 7 : (U)]) + lane16; \
-            if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_LOAD) } }
-        if (flags & (RF_LD_SETUP_ONLY | RF_LD_ABLATE_SYNC)) return;
-        if (NL == 1 && !(flags & RF_LD_NO_DMA)) {
+            src = (const char *)(gnodes + tree_off[(U)]) + lane16; \
+            MHS_RF_ALL(MHS_RF_LOAD) }
+        {
             // ONE loader, TWO trees in flight: even trees through the registers (requested while their buffer is still being
             // walked), odd trees by LDS-DMA (no registers, issued once the buffer is free; the data is in LDS at vmcnt(0)).
             // Either path alone is one round trip per tree (1.2 - 1.5 us); alternating, a pair costs about one.
@@ -2015,14 +1717,14 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
             for (int u = 0; u < n_trees; u += 2) {
                 unsigned slot = (unsigned)u % 3u;
                 if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)(u / 3));
-                if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_STORE) }
+                MHS_RF_ALL(MHS_RF_STORE)
                 lds_signal(CNT + 4u * slot);
                 if (u + 2 < n_trees) MHS_RF_REQUEST(u + 2)
                 if (u + 1 < n_trees) {
                     slot = (unsigned)(u + 1) % 3u;
                     if (u + 1 >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)((u + 1) / 3));
-                    if (!(flags & RF_LD_ABLATE_STAGING)) {
-                        const char *dsrc = (const char *)(gnodes + tree_off[(flags & RF_LD_FEW_TREES) ? (u + 1) & 7 : u + 1]) + lane16;
+                    {
+                        const char *dsrc = (const char *)(gnodes + tree_off[u + 1]) + lane16;
 #pragma unroll
                         for (int q = 0; q < PF; ++q)
                             glds16(dsrc + (size_t)q * 1024u, (unsigned)__builtin_amdgcn_readfirstlane((int)(slot * (unsigned)STRIDE + (unsigned)q * 1024u)));
@@ -2033,21 +1735,12 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
             }
             return;
         }
-        if (first < n_trees) MHS_RF_REQUEST(first)
-        for (int u = first; u < n_trees; u += NL) {
-            const unsigned slot = (unsigned)u % 3u;
-            if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)(u / 3));   // every walker has left tree u - 3
-            if (!(flags & RF_LD_ABLATE_STAGING)) { MHS_RF_ALL(MHS_RF_STORE) }
-            lds_signal(CNT + 4u * slot);                             // the LDS unit executes a wave's operations in order
-            if (u + NL < n_trees) MHS_RF_REQUEST(u + NL)
-        }
 #undef MHS_RF_REQUEST
 #undef MHS_RF_STORE
 #undef MHS_RF_LOAD
 #undef MHS_RF_ALL
         return;
     }
-    if (flags & RF_LD_SETUP_ONLY) return;
     constexpr int PD = 6;                                          // a tree's predictions are added PD - 1 trees after their request
     double acc[R], pend[PD][R];                                    // pend[t % PD]: predictions of tree t
 #pragma unroll
@@ -2075,7 +1768,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
             ocur = tree_off[tl];
             const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
             const int plen = (int)((ecur >> 16) & 0x7FFFu);
-            const int levels = ((ecur >> 31) || (flags & RF_LD_ABLATE_WALKS)) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
+            const int levels = (ecur >> 31) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
             const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63: depth of a tree of <= 3 200 nodes
             wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
             // a tree the wave does not walk (its cells share the entry node: two thirds of the trees on smooth rasters) has ONE
@@ -2090,7 +1783,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
         const int o = __builtin_amdgcn_readlane(ocur, t & 63);
         // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
         // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
-        if (staged[SLOT] <= k3 && !(flags & RF_LD_ABLATE_SYNC))
+        if (staged[SLOT] <= k3)
             for (;;) {
                 uint4v cv;                                                   // staged[0..2] and the zero word behind them
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
@@ -2730,20 +2423,32 @@ static int build_lut_meta(mhs_model *m, const mhs_grid &grid, int C, int key64, 
 // the MissingNode walk of a window's NA cells behind a predicate-LUT kernel: compacted list, strided pass on overflow
 static int launch_gbm_na(const mhs_model *m, const StackDev &s, const PredGeom &g, double w, int acc, double *out, hipStream_t st,
                          int64_t total) {
-    if (getenv("MHS_GBM_NA_STRIDED") || total >= (1LL << 32)) return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
+    if (total >= (1LL << 32)) return launch_trees<true, true>(m, s, g, w, acc, out, st, total);
     mhs_model *mm = const_cast<mhs_model *>(m);
     const unsigned slot = mm->na_next.fetch_add(1) % 4;
     const size_t want = (size_t)std::max<int64_t>(4096, total / 8);      // up to 12.5 % NA cells; beyond: the strided pass
+    unsigned *list = nullptr;
+    unsigned cap = 0;
     {
+        // One model predicted from several streams or host threads (round-4 advisor finding): launch k + 4 reuses launch k's
+        // buffer, so it first waits -- on the device -- for the event recorded behind launch k's last reader, whichever stream
+        // that ran on; list / cap are read under the lock that guards their reallocation.
         std::lock_guard<std::mutex> lk(mm->mu);
+        if (!mm->na_done[slot]) MHS_HIP(hipEventCreateWithFlags(&mm->na_done[slot], hipEventDisableTiming));
+        else if (mm->na_stream[slot] != st) MHS_HIP(hipStreamWaitEvent(st, mm->na_done[slot], 0));
         if (mm->na_cap[slot] < want) {
-            if (mm->na_list[slot]) { MHS_HIP(hipStreamSynchronize(st)); (void)hipFree(mm->na_list[slot]); mm->na_list[slot] = nullptr; mm->na_cap[slot] = 0; }
+            if (mm->na_list[slot]) {
+                MHS_HIP(hipEventSynchronize(mm->na_done[slot]));
+                MHS_HIP(hipStreamSynchronize(st));
+                (void)hipFree(mm->na_list[slot]); mm->na_list[slot] = nullptr; mm->na_cap[slot] = 0;
+            }
             MHS_HIP(hipMalloc((void **)&mm->na_list[slot], sizeof(unsigned) * (want + 2)));
             mm->na_cap[slot] = want;
         }
+        list = mm->na_list[slot];
+        cap = (unsigned)mm->na_cap[slot];
+        mm->na_stream[slot] = st;
     }
-    unsigned *list = mm->na_list[slot];
-    const unsigned cap = (unsigned)mm->na_cap[slot];
     MHS_HIP(hipMemsetAsync(list, 0, 2 * sizeof(unsigned), st));
     hipLaunchKernelGGL(na_collect_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, g, cap, list);
     const unsigned lblocks = (unsigned)std::min<int64_t>(2048, (total / 8 + 255) / 256 + 1);
@@ -2775,6 +2480,10 @@ static int launch_gbm_na(const mhs_model *m, const StackDev &s, const PredGeom &
                            s, g, w, acc, out, (const unsigned *)list);
     }
     MHS_HIP(hipGetLastError());
+    {
+        std::lock_guard<std::mutex> lk(mm->mu);
+        MHS_HIP(hipEventRecord(mm->na_done[slot], st));
+    }
     return MHS_OK;
 }
 
@@ -2788,13 +2497,11 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
     const size_t lut_bytes = ((size_t)LUT_CHUNK << m->lut_S) * sizeof(double);
     const bool in_regs = m->p <= LUT_REG_P;
     // row-tile form: a wave = 256 consecutive cells of one row (LAT splits and padding levels on the scalar unit); taken
-    // when the rows are long enough that the ragged last tile of a row wastes little (MHS_GBM_NO_ROWTILE: never)
+    // when the rows are long enough that the ragged last tile of a row wastes little
     const int tpr = (g.nc + 64 * LUT_R - 1) / (64 * LUT_R);
-    const bool rowtile_ok = getenv("MHS_GBM_NO_ROWTILE") == nullptr;
-    const bool gbc_strips = getenv("MHS_GBM_STRIP_WAVES") != nullptr;      // round 3's 64 x 4-cell wave tiles instead of 16 x 16
-    const int ctw = gbc_strips ? 64 : 16, cth = gbc_strips ? LUT_R : 4 * LUT_R;
+    const int ctw = 16, cth = 4 * LUT_R;                                   // the coherent kernel's 16 x 16-cell wave tiles
     const int ctpr = (int)((g.nc + g.c0 % ctw + ctw - 1) / ctw);
-    const bool rt_ok = in_regs && rowtile_ok && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R);
+    const bool rt_ok = in_regs && m->lut_S == 5 && tt.lut_rt && (double)g.nc >= 0.93 * (double)tpr * (64 * LUT_R);
     const bool coh_ok = in_regs && m->lut_S == 5 && tt.lut_cls && g.nr >= 2 * LUT_R && (double)g.nc >= 0.8 * (double)ctpr * ctw &&
                         !getenv("MHS_GBM_NO_COHERENT");
     // Grids: the coherent kernel where neighbouring cells share their trees' outcomes, the tree-order row-tile kernel where
@@ -2816,14 +2523,12 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
             auto pk = key64 ? gbm_coherent_kernel<true, true> : gbm_coherent_kernel<false, true>;
             MHS_HIP(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
             hipLaunchKernelGGL(pk, dim3(GBC_PROBE_BLOCKS), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1,
-                               getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank, tt.axis_ncol);
+                               m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, 1, tt.axis_rank, tt.axis_ncol);
         }
         auto ck = key64 ? gbm_coherent_kernel<true> : gbm_coherent_kernel<false>;
         MHS_HIP(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbc_lds_bytes()));
         hipLaunchKernelGGL(ck, dim3(cblocks), dim3(1024), gbc_lds_bytes(), st, m->lut, tt.lut_cls, tt.sorted, tt.sorted_off,
-                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, gbc_strips ? 0 : 1,
-                               getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank, tt.axis_ncol);
+                           m->n_trees_padded, m->init_f, m->p, s, g, ctpr, w, acc, out, probe, 1, tt.axis_rank, tt.axis_ncol);
         if (!probe) return launch_gbm_na(m, s, g, w, acc, out, st, total);
     }
     if (rt_ok) {
@@ -2847,37 +2552,36 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
 }
 
 
-// LDS bytes of rf_walk_kernel for R = 2^log2r walks per lane
-static size_t rf_walk_lds(const mhs_model *m, int log2r, bool big) {
-    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * (big ? 8 : 16), (size_t)RF_COARSE_BYTES);
-    return tree_bytes + (size_t)1024 * (((size_t)m->p << log2r) | 1) * 4;
+// MHS_RF_KERNEL = ld | db | compact pins one of the three forest walk kernels where it applies (the equality tests and the
+// benchmarks' comparisons); unset: the loader-wave kernel, else the double-buffered one, else the split-node one, else the
+// generic node walk.  MHS_RF_PLAIN=1: no wave-uniform prefix and every tree to its full depth (the walk as round 2 had it).
+enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT };
+static int rf_pick() {
+    const char *e = getenv("MHS_RF_KERNEL");
+    if (!e) return RF_PICK_AUTO;
+    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : RF_PICK_AUTO;
 }
+static bool rf_plain() { return getenv("MHS_RF_PLAIN") != nullptr; }
 
-// Configuration of rf_walk_kernel: walks per lane (4, else 2) and whether the trees need the BIG form (node
-// indices instead of 16-bit byte addresses, predictions left in global memory); false = generic walk.
-// The predictor's key offset is one byte.
-// the double-buffered kernel: two node buffers within 16-bit byte addresses, predictions in global memory
+// the double-buffered kernel: two node buffers within 16-bit byte addresses, predictions in global memory.  The predictor's
+// key offset is one byte.
 static size_t rf_walk_db_lds(const mhs_model *m, int log2r) {
     const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
     return tree_bytes + (size_t)1024 * (((size_t)m->p * rf_walks(log2r)) | 1) * 4;
 }
 static int rf_walk_db_log2r(const mhs_model *m) {
     if (m->rf_max_nodes > 4095) return -1;
-    const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
-    for (int l2 = five ? 3 : 2; l2 >= 1; --l2)
+    for (int l2 = 3; l2 >= 1; --l2)
         if ((m->p * rf_walks(l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
     return -1;
 }
 
-// triple-buffered kernel: buffer stride (bytes, a template parameter) and walks per lane, false = does not apply
-static bool rf_walk_tb_config(const mhs_model *m, int *log2r, int *stride) {
-    // the default where it fits (waves that start deep in a tree, or skip it, must not wait for the one wave that walks
-    // it from near the root: 125 -> 97 ms per 1e8 cells with four walks); MHS_RF_DOUBLE_BUFFER etc.: the other kernels
-    if (getenv("MHS_RF_DOUBLE_BUFFER") || getenv("MHS_RF_SINGLE_BUFFER") || getenv("MHS_RF_COMPILER_LOOP")) return false;
-    const bool five = getenv("MHS_RF_FOUR_WALKS") == nullptr;
+// loader-wave kernel (three node buffers): buffer stride (bytes, a template parameter) and walks per lane; false = does not apply
+static bool rf_walk_ld_config(const mhs_model *m, int *log2r, int *stride) {
+    if (m->rf_max_depth > 63) return false;                       // a tree's level counts travel in 6 bits each
     for (int st : {16384, 24576, 25600}) {
         if ((size_t)m->rf_max_nodes * 8 > (size_t)st) continue;
-        for (int l2 = five && st != 25600 ? 3 : 2; l2 >= 2; --l2)      // the widest stride is instantiated for four walks only
+        for (int l2 = st != 25600 ? 3 : 2; l2 >= 2; --l2)      // the widest stride is instantiated for four walks only
             if ((m->p * rf_walks(l2) * 4) <= 255 &&
                 (size_t)3 * st + 32 + (size_t)1024 * (((size_t)m->p * rf_walks(l2)) | 1) * 4 <= LDS_MAX) {
                 *log2r = l2; *stride = st;
@@ -2887,20 +2591,7 @@ static bool rf_walk_tb_config(const mhs_model *m, int *log2r, int *stride) {
     return false;
 }
 
-static bool rf_walk_config(const mhs_model *m, int *log2r, bool *big) {
-    for (int b = 0; b < 2; ++b) {
-        if (b == 0 && m->rf_max_nodes * 8 > 65535) continue;
-        if (b == 1 && m->rf_max_nodes > 65535) continue;
-        for (int l2 = 2; l2 >= 1; --l2)
-            if (((m->p << l2) * 4) <= 255 && rf_walk_lds(m, l2, b == 1) <= (b == 1 ? LDS_MAX : LDS_LIMIT)) {
-                *log2r = l2; *big = b == 1;
-                return true;
-            }
-    }
-    return false;
-}
-
-// key-space node records of the forest for this grid (see rf_walk_kernel); cached per geometry and key type
+// key-space node records of the forest for this grid (see rf_walk_db_kernel); cached per geometry and key type
 template <typename KT>
 static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r, int form) {
     const bool big = form == RF_BIG;
@@ -2983,88 +2674,53 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, 
     return MHS_OK;
 }
 
+// the loader-wave kernel where it applies (or is asked for), else the double-buffered one; *launched = false when neither does
 static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
-                          double w, int acc, double *out, hipStream_t st, int64_t total, int log2r, bool big) {
-    const int key64 = s.dtype == MHS_F64;
-    if (big && m->p >= 5 && m->p <= 8 && !getenv("MHS_RF_BIG_PER_BATCH")) {      // tree-major form (keys in registers, R = 4)
-        constexpr int NB = 4;
-        const size_t tbytes = std::max((size_t)m->rf_max_nodes * 8, (size_t)RF_COARSE_BYTES) + (size_t)512 * (((size_t)m->p * 4) | 1) * 4;
-        if (tbytes <= LDS_MAX && m->rf_max_nodes <= 65535) {
-            TreeTables t2;
-            if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_BIG, key64, &t2)) return rc;
-            const unsigned nblk = (unsigned)((total + 512 * 4 * NB - 1) / (512 * 4 * NB));
-#define MHS_TM(P_) case P_: { auto k = key64 ? rf_walk_tm_kernel<NB, P_, true> : rf_walk_tm_kernel<NB, P_, false>; \
-            MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes)); \
-            hipLaunchKernelGGL(k, dim3(nblk), dim3(512), tbytes, st, (const uint2 *)t2.rf_nodes, m->rf_lval, m->tree_off, m->rf_depth, \
-                               t2.sorted, t2.sorted_off, m->n_trees, m->rf_max_nodes, s, g, w, acc, out); } break;
-            switch (m->p) { MHS_TM(5) MHS_TM(6) MHS_TM(7) MHS_TM(8) }
-#undef MHS_TM
-            return MHS_OK;
-        }
-    }
-    int tb_l2 = 0, tb_stride = 0;
-    if (!big && rf_walk_tb_config(m, &tb_l2, &tb_stride)) {      // triple-buffered, barrier-free tree loop
+                          double w, int acc, double *out, hipStream_t st, int64_t total, bool *launched) {
+    const int key64 = s.dtype == MHS_F64, pick = rf_pick();
+    *launched = false;
+    (void)total;
+    int ld_l2 = 0, ld_stride = 0;
+    if (pick != RF_PICK_DB && rf_walk_ld_config(m, &ld_l2, &ld_stride)) {      // three node buffers, one loader wave, 15 walker waves
         TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, tb_l2, RF_SMALL, key64, &tt)) return rc;
-        const int R = rf_walks(tb_l2);
+        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, ld_l2, RF_SMALL, key64, &tt)) return rc;
+        const int R = rf_walks(ld_l2);
         const int strips = rf_strips(g, R);
-        const bool ld = !getenv("MHS_RF_NO_LOADER") && m->rf_max_depth <= 63;      // staging waves + walking waves (rf_walk_ld_kernel)
-        const bool ld1 = ld && !getenv("MHS_RF_TWO_LOADERS");
-        const int64_t per_block = ld ? 64 * (ld1 ? 15 : 14) : 1024;
+        const int64_t per_block = 64 * 15;
         unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
-        const bool tiles16 = ld && strips && !getenv("MHS_RF_STRIP_WAVES");     // 16 x 4R-cell wave tiles (default) or 64 x R strips
-        if (tiles16) blocks = (unsigned)((((int64_t)(g.nc + 15) / 16) * ((g.nr + 4 * R - 1) / (4 * R)) + per_block / 64 - 1) / (per_block / 64));
-        const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
-        const size_t tbytes = (size_t)3 * tb_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-#define MHS_TB(L2, ST) (ld1 ? (key64 ? rf_walk_ld_kernel<L2, true, ST, 1> : rf_walk_ld_kernel<L2, false, ST, 1>) \
-                      : ld ? (key64 ? rf_walk_ld_kernel<L2, true, ST, 2> : rf_walk_ld_kernel<L2, false, ST, 2>) \
-                           : (key64 ? rf_walk_tb_kernel<L2, true, ST> : rf_walk_tb_kernel<L2, false, ST>))
-        auto tk = tb_stride == 16384 ? (tb_l2 == 3 ? MHS_TB(3, 16384) : MHS_TB(2, 16384))
-                : tb_stride == 24576 ? (tb_l2 == 3 ? MHS_TB(3, 24576) : MHS_TB(2, 24576))
-                                     : MHS_TB(2, 25600);
-#undef MHS_TB
+        if (strips) blocks = (unsigned)((((int64_t)(g.nc + 15) / 16) * ((g.nr + 4 * R - 1) / (4 * R)) + 15 - 1) / 15);   // 16 x 4R-cell wave tiles
+        const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
+        const size_t tbytes = (size_t)3 * ld_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
+#define MHS_LD(L2, ST) (key64 ? rf_walk_ld_kernel<L2, true, ST> : rf_walk_ld_kernel<L2, false, ST>)
+        auto tk = ld_stride == 16384 ? (ld_l2 == 3 ? MHS_LD(3, 16384) : MHS_LD(2, 16384))
+                : ld_stride == 24576 ? (ld_l2 == 3 ? MHS_LD(3, 24576) : MHS_LD(2, 24576))
+                                     : MHS_LD(2, 25600);
+#undef MHS_LD
         MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
-        const int *axr = getenv("MHS_NO_AXIS_RANKS") ? nullptr : tt.axis_rank;
         hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles16 ? 2 : strips,
-                           (int)(strips && dmin && !getenv("MHS_RF_NO_PREFIX")) | (ld && getenv("MHS_RF_LD_FLAGS") ? atoi(getenv("MHS_RF_LD_FLAGS")) & ~1 : 0),
-                           axr, tt.axis_ncol);
+                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips ? 2 : 0,
+                           (int)(strips && dmin), tt.axis_rank, tt.axis_ncol);
+        *launched = true;
         return MHS_OK;
     }
-    if (!big && !getenv("MHS_RF_SINGLE_BUFFER")) {      // the double-buffered kernel has its own choice of walks per lane
-        const int dl = rf_walk_db_log2r(m);
-        if (dl > 0) log2r = dl;
-    }
+    const int log2r = rf_walk_db_log2r(m);
+    if (log2r < 0) return MHS_OK;
     TreeTables tt;
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, big ? RF_BIG : RF_SMALL, key64, &tt)) return rc;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, RF_SMALL, key64, &tt)) return rc;
     const int R = rf_walks(log2r);
-    const int64_t part = (total + R - 1) / R;
-    unsigned blocks = (unsigned)((part + 1023) / 1024);
-    if (!big && rf_walk_db_log2r(m) == log2r && !getenv("MHS_RF_SINGLE_BUFFER")) {
-        const size_t dbytes = rf_walk_db_lds(m, log2r);
-        // grids: a lane's walks on R adjacent rows and the early exit per wave (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: the
-        // round-2 cell order / every tree to its full depth -- the equality tests' switches)
-        const int strips = rf_strips(g, R);
-        blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
-        const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
-        const bool hand = getenv("MHS_RF_COMPILER_LOOP") == nullptr;      // five walks: hand-scheduled level loop (default)
-        auto dk = log2r == 3 ? (hand ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
-                                     : (key64 ? rf_walk_db_kernel<3, true, false> : rf_walk_db_kernel<3, false, false>))
-                : log2r == 2 ? (hand ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
-                                     : (key64 ? rf_walk_db_kernel<2, true, false> : rf_walk_db_kernel<2, false, false>))
-                             : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
-        MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
-        hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips,
-                           strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
-        return MHS_OK;
-    }
-    const size_t bytes = rf_walk_lds(m, log2r, big);
-    auto kern = big ? (log2r == 2 ? rf_walk_kernel<2, true> : rf_walk_kernel<1, true>)
-                    : (log2r == 2 ? rf_walk_kernel<2, false> : rf_walk_kernel<1, false>);
-    MHS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                       m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out);
+    const size_t dbytes = rf_walk_db_lds(m, log2r);
+    // grids: a lane's walks on R adjacent rows and the early exit per wave
+    const int strips = rf_strips(g, R);
+    const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
+    const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
+    auto dk = log2r == 3 ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
+            : log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
+                         : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
+    MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
+    hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
+                       m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips,
+                       strips && dmin);
+    *launched = true;
     return MHS_OK;
 }
 
@@ -3088,14 +2744,14 @@ static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGe
     const size_t bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES) + (size_t)nt * (((size_t)m->p * 4) | 1) * 4;
     const int strips = rf_strips(g, 4);
     const unsigned blocks = (unsigned)((rf_lane_count(g, 4, strips) + nt - 1) / nt);
-    const int *dmin = getenv("MHS_RF_FULL_DEPTH") ? nullptr : m->rf_dmin;
+    const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
     const bool pf4 = (size_t)nt * 4 >= (size_t)m->rf_cmax;
     auto k = pf4 ? (key64 ? rf_walk_compact_kernel<4, true> : rf_walk_compact_kernel<4, false>)
                  : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
                        m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips,
-                       strips && dmin && !getenv("MHS_RF_NO_PREFIX"));
+                       strips && dmin);
     return MHS_OK;
 }
 
@@ -3133,17 +2789,14 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
             break;
         case K_RF:
             if (grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC")) {
-                int log2r = 0;
-                bool big = false;
-                if ((rf_walk_db_log2r(m) < 0 || getenv("MHS_RF_FORCE_COMPACT")) && !getenv("MHS_RF_NO_COMPACT")) {
-                    const int nt = rf_compact_threads(m);
-                    if (nt > 0) {
-                        if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
-                        break;
-                    }
-                }
-                if (rf_walk_config(m, &log2r, &big)) {
-                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, log2r, big)) return rc;
+                const int pick = rf_pick();
+                bool launched = false;
+                if (pick != RF_PICK_COMPACT)
+                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, &launched)) return rc;
+                if (launched) break;
+                const int nt = rf_compact_threads(m);      // trees beyond 4 095 nodes: split nodes only in LDS
+                if (nt > 0) {
+                    if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
                     break;
                 }
             }
@@ -3166,7 +2819,7 @@ static void launch_small(const SmallArgs &a, const StackDev &s, const PredGeom &
 // consecutive in the reference's model order -- goes through one fused pass.  MHS_NO_FUSE=1 launches them one by one.
 static int launch_members(const mhs_model *const *models, const double *weights, int n_models, const StackDev &s,
                           const PredGeom &g, int accumulate_first, double *out, hipStream_t st, const mhs_grid *grid) {
-    static const bool fuse = getenv("MHS_NO_FUSE") == nullptr;
+    constexpr bool fuse = true;
     const int64_t total = (int64_t)g.nr * g.nc;
     int k = 0;
     bool masked_done = false;
@@ -3214,7 +2867,6 @@ static int launch_members(const mhs_model *const *models, const double *weights,
             std::lock_guard<std::mutex> lk(mask_mutex());
             if (c.masked_stream) {
                 masked_done = true;
-                if (getenv("MHS_MASK_DEBUG")) fprintf(stderr, "[mask] kind %d on the masked stream %p (caller stream %p), %d CUs reserved\n", kind, (void *)c.masked_stream, (void *)st, c.reserved_cus);
                 MHS_HIP(hipEventRecord(c.mask_ev0, st));
                 MHS_HIP(hipStreamWaitEvent(c.masked_stream, c.mask_ev0, 0));
                 if (int rc = launch_model(models[k], s, g, weights[k], acc, out, c.masked_stream, grid)) return rc;
@@ -3315,6 +2967,7 @@ int mhs_model_free(mhs_model *m) {
     if (m->chunks) (void)hipFree(m->chunks);
     if (m->split_scratch) (void)hipFree(m->split_scratch);
     for (unsigned *q : m->na_list) if (q) (void)hipFree(q);
+    for (hipEvent_t e : m->na_done) if (e) (void)hipEventDestroy(e);
     if (m->lut) (void)hipFree(m->lut);
     if (m->lut_meta) (void)hipFree(m->lut_meta);
     if (m->lut_rt) (void)hipFree(m->lut_rt);
@@ -3716,7 +3369,7 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
     sd.data = in - (size_t)r0 * covars->ld * esz; sd.C = covars->n_layers; sd.dtype = covars->dtype;
     sd.plane_stride = nr * covars->ld; sd.ld = covars->ld; sd.nodata = covars->nodata;
     sd.has_nodata = !std::isnan(covars->nodata); sd.all_from_planes = 0;
-    const bool timing = getenv("MHS_HOST_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now_ms();
     auto upload = [&](int b) -> int {           // rows [up[b], up[b + 1]) of every layer; blocks the calling thread (pageable source)
@@ -3784,7 +3437,7 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
         // kernel (40 ms per 1e8 cells) is as short as the upload of three float64 planes (43 ms at 56 GB/s), so with gbm alone on
         // the upload bands the last band's gbm ran after the last upload, fully exposed (+22 ms on cfg3); the forest's bands
         // cover it.  A banded launch costs the partly filled last round of its blocks, < 1 ms per band and member.
-        if (last_start > first_end && !getenv("MHS_HOST_MIDDLE_GROUP")) first_end = last_start;
+        if (last_start > first_end) first_end = last_start;
         if (last_start >= first_end && need <= ((size_t)96 << 30))
             return host_window_pipeline(models, weights, n_models, first_end, last_start, wt_total, g, covars, r0, r1, c0, c1, out_host);
     }
@@ -3821,7 +3474,7 @@ int mhs_ensemble_predict(const mhs_model *const *models, const double *weights, 
     PipeDrain drain(c);
     char *in[2] = {c.pipe_arena, c.pipe_arena + in_bytes};
     double *outb[2] = {(double *)(c.pipe_arena + 2 * in_bytes), (double *)(c.pipe_arena + 2 * in_bytes + out_bytes)};
-    const bool timing = getenv("MHS_HOST_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now_ms();
     auto band_rows = [&](int64_t b, int64_t *b0, int64_t *b1) { *b0 = edge[(size_t)b]; *b1 = edge[(size_t)b + 1]; };

@@ -148,10 +148,8 @@ int fit_lane(int i, FitLane **out) {
         FitLane *L = new FitLane();
         hipError_t e = hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi);
         // the second stream carries the bulk of a trailing update while the first factorises the next panel: one priority
-        // level down (MHS_FIT_S2_SAME_PRIO keeps round 3's setting), so that the panel's few blocks win a freed compute unit
-        // against the update's hundreds of queued ones
-        static const bool same_prio = getenv("MHS_FIT_S2_SAME_PRIO") != nullptr;
-        const int prio2 = (!same_prio && prio_hi < prio_lo) ? prio_hi + 1 : prio_hi;
+        // level down, so that the panel's few blocks win a freed compute unit against the update's hundreds of queued ones
+        const int prio2 = prio_hi < prio_lo ? prio_hi + 1 : prio_hi;
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&L->s2, hipStreamNonBlocking, prio2);
         if (e == hipSuccess && c.masked_cus > 0 && !c.comp_mask.empty()) {
             e = hipExtStreamCreateWithCUMask(&L->ms, (uint32_t)c.comp_mask.size(), c.comp_mask.data());
@@ -161,9 +159,8 @@ int fit_lane(int i, FitLane **out) {
         // them) leaves the next panel's 10-20 blocks no compute unit to start on, whatever the priorities: beside it the
         // panel's first kernels ran 2-5 x slower (gram 9 -> 43 us, first pass 30 -> 72 us at n = 5 000).  Its stream is
         // therefore masked off the first 32 mask indices = four compute units of each XCD (the index order measured for
-        // mhs_fit_reserve_cus below); MHS_FIT_REST_ALL_CUS=1 restores the unmasked stream.
-        static const bool rest_all = getenv("MHS_FIT_REST_ALL_CUS") != nullptr;
-        if (e == hipSuccess && !rest_all && c.n_cu >= 128) {
+        // mhs_fit_reserve_cus below).
+        if (e == hipSuccess && c.n_cu >= 128) {
             std::vector<uint32_t> mask((size_t)(c.n_cu + 31) / 32, 0u);
             for (int q = FIT_PANEL_CUS; q < c.n_cu; ++q) mask[(size_t)q / 32] |= 1u << (q % 32);
             e = hipExtStreamCreateWithCUMask(&L->s2r, (uint32_t)mask.size(), mask.data());
@@ -181,8 +178,6 @@ int fit_lane(int i, FitLane **out) {
 
 int h2d_sync(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return MHS_OK;
-    static const bool plain = getenv("MHS_NULL_STREAM_COPIES") != nullptr;      // diagnostic: the old behaviour
-    if (plain) { MHS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MHS_OK; }
     hipStream_t up = ctx().upload;
     MHS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
     MHS_HIP(hipStreamSynchronize(up));

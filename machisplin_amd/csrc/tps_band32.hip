@@ -1947,7 +1947,7 @@ void Band32Search::collect(int off, int nl, double *neg, double *tr, double *q2)
     }
 }
 void Band32Search::report(int off, int nl, bool deriv) const {
-    if (!getenv("MHS_FIT_TIMING")) return;
+    if (!getenv("MHS_TIMING")) return;
     int mid, mb, n0, n1;
     split_mid(m, &mid, &mb, &n0, &n1);
     double r8[8];
@@ -1963,7 +1963,7 @@ int Band32Search::eval_batch(const double *lam, int count, bool deriv, double *n
         const auto w0 = std::chrono::steady_clock::now();
         if (int rc = enqueue(s, 0, lam + base, nl, deriv)) return rc;
         MHS_HIP(hipStreamSynchronize(s));
-        if (getenv("MHS_FIT_TIMING"))
+        if (getenv("MHS_TIMING"))
             fprintf(stderr, "[gcv32 m=%d] round of %d lambdas: %.3f ms on the host clock\n", m, nl,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
         report(0, nl, deriv);
@@ -2020,7 +2020,7 @@ static const int EIG_PMAX = 255;
 static const double EIG_TOL = 3e-10;      // lambda moves by about half the relative error of either end (they only place the grid)
 static const double EIG_SPEC = 1e-6;
 int Band32Search::find_lambda(int mode, double *lam_out) {
-    const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

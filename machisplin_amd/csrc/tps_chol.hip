@@ -477,8 +477,8 @@ int cholesky_solve_mfma(FitLane &L, double *A, int64_t ld, int off, int m, doubl
     // (K = 128, one column of tiles), B is factorised and solved, and the rest of the trailing matrix receives both
     // panels in ONE pass over its tiles (K = 256).  Look-ahead as before: the first two block columns of that pass
     // -- the next pair's own columns -- are launched first on the main stream, the rest on the second stream, and the
-    // next pair's factorisation runs beside it.  MHS_CHOL_K128=1: every panel on its own (K = 128 everywhere).
-    static const bool pairs = getenv("MHS_CHOL_K128") == nullptr;
+    // next pair's factorisation runs beside it.
+    constexpr bool pairs = true;
     hipEvent_t pending = nullptr;     // the second-stream update the next trailing pass has to wait for
     auto syrk = [&](int coff, int xcol, int K, int nt, int ncol) -> int {      // trailing block at coff, nt tiles a side
         if (nt <= 0) return MHS_OK;

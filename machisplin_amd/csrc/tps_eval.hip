@@ -322,10 +322,6 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
         const double cost = ntx * nty * FF_NODES * (double)N / cells + 9.0 * rho * tx * ty + 4.0;
         if (cost < best) { best = cost; btx = tx; bty = ty; }
     }
-    if (const char *ev = getenv("MHS_FF_TILE")) {   // experiments: force the tile width
-        const int tx = atoi(ev);
-        if (tx >= 64 && tx % 64 == 0) { btx = tx; bty = std::max(16, (int)llround((double)tx * aspect / 16.0) * 16); }
-    }
     if (btx == 0) return MHS_OK;
     if (g_eval_mode != 2 && best > 0.5 * (double)N) return MHS_OK;
     const double tile_aspect = ((double)btx * e.xres / e.sx) / ((double)bty * e.yres / e.sy);

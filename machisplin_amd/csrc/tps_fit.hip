@@ -31,23 +31,6 @@
 namespace mhs {
 
 // ------------------------------------------------------------------ Gram matrix --
-__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ u,
-                                                   const double *__restrict__ v,
-                                                   const double *__restrict__ sw, int n, int64_t ld,
-                                                   const double2 *__restrict__ gtab,
-                                                   double *__restrict__ A) {
-    __shared__ double2 tab[LOG_TAB_N];
-    stage_log_table(tab, gtab);
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
-    if (i >= n) return;
-    const double ui = u[i], vi = v[i], si = sw[i] * (0.5 / (8.0 * M_PI));
-    for (int j = j0; j < j0 + 16 && j < n; ++j) {
-        const double dx = ui - u[j], dy = vi - v[j];
-        const double d2 = fma(dy, dy, dx * dx);
-        A[i + (int64_t)j * ld] = si * sw[j] * r2logr2(d2, tab);
-    }
-}
 
 // The null-space projection A <- Q'KQ, Q = H1 H2 H3 = I - V T V' (the three reflectors of the QR of [1 u v]), WITHOUT
 // ever storing K: Q'KQ = K - W V' - V W' with W = Y T - 1/2 V S, Y = K V, S = T'(V'Y)T.  Pass 1 forms Y from kernel
@@ -104,59 +87,6 @@ __global__ __launch_bounds__(256) void gram_proj_kernel(const double *__restrict
         a -= w1 * V3[n + j] + v1 * W3[n + j];
         a -= w2 * V3[2 * (int64_t)n + j] + v2 * W3[2 * (int64_t)n + j];
         A[i + (int64_t)j * ld] = a;
-    }
-}
-
-// --------------------------------------------- two-sided Householder machinery --
-// p = A_sub v  (A_sub = A[off:off+t, off:off+t], symmetric full storage): one wave per row
-__global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ A, int64_t ld, int off,
-                                                   int t, const double *__restrict__ v,
-                                                   double *__restrict__ p) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= t) return;
-    const int lane = threadIdx.x & 63;
-    const double *col = A + (int64_t)(off + row) * ld + off;  // column `row` == row `row`
-    double s = 0.0;
-    for (int j = lane; j < t; j += 64) s = fma(col[j], v[j], s);
-    s = wave_sum(s);
-    if (lane == 0) p[row] = s;
-}
-
-// single block: w = tau p - 0.5 tau^2 (p'v) v ; optionally rotate g: g -= tau (v'g) v
-__global__ __launch_bounds__(1024) void house_w_kernel(const double *__restrict__ p,
-                                                       const double *__restrict__ v,
-                                                       const double *__restrict__ tau_ptr, int t,
-                                                       double *__restrict__ w, double *g) {
-    __shared__ double scratch[17];
-    const double tau = *tau_ptr;
-    double s = 0.0, sg = 0.0;
-    for (int i = threadIdx.x; i < t; i += blockDim.x) {
-        s = fma(p[i], v[i], s);
-        if (g) sg = fma(g[i], v[i], sg);
-    }
-    s = block_sum(s, scratch);
-    if (g) sg = block_sum(sg, scratch);
-    const double alpha = -0.5 * tau * tau * s;
-    for (int i = threadIdx.x; i < t; i += blockDim.x) {
-        w[i] = fma(alpha, v[i], tau * p[i]);
-        if (g) g[i] -= tau * sg * v[i];
-    }
-}
-
-// A_sub -= v w' + w v'
-__global__ __launch_bounds__(256) void syr2_kernel(double *__restrict__ A, int64_t ld, int off, int t,
-                                                   const double *__restrict__ v,
-                                                   const double *__restrict__ w) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
-    if (i >= t) return;
-    const double vi = v[i], wi = w[i];
-    double *a = A + (int64_t)off * ld + off + i;
-    for (int j = j0; j < j0 + 16 && j < t; ++j) {
-        double x = a[(int64_t)j * ld];
-        x -= vi * w[j];
-        x -= wi * v[j];
-        a[(int64_t)j * ld] = x;
     }
 }
 
@@ -998,13 +928,11 @@ constexpr int SYMM_COLS = 4 * SYMM_CPW;  // per block
 // adds more partials: 1 -> 85.8, 2 -> 81.6, 3 -> 82.5, 4 -> 84.3, 8 -> 91.3 ms per fit) -- except where two ranges
 // make slightly more than one block per CU: a block streams its columns at ~35 GB/s whatever else runs, so
 // 264 blocks on 256 CUs take twice as long as 256 (t = 4197: 39 us, t = 3397: 20 us).  Then the split count with
-// the fewest (rounds of 256 blocks) x (rows per block) is taken.  MHS_SYMM_SPLITS overrides.
+// the fewest (rounds of 256 blocks) x (rows per block) is taken.
 static inline int symm_splits(int t) {
-    static const int forced = getenv("MHS_SYMM_SPLITS") ? atoi(getenv("MHS_SYMM_SPLITS")) : 0;
     const int ncg = (t + SYMM_COLS - 1) / SYMM_COLS;
     int want = 2;
-    if (forced > 0) want = std::min(forced, SYMM_MAX_SPLITS);
-    else if (ncg * 2 > 256) {
+    if (ncg * 2 > 256) {
         double best = 1e30;
         for (int sp = 2; sp <= SYMM_MAX_SPLITS; ++sp) {
             const double cost = (double)((ncg * sp + 255) / 256) / sp;
@@ -1969,9 +1897,9 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
 
     // mhs_fit_reserve_cus active: the fit stays on the compute units the ensemble's masked member leaves free
     // (the GCV route only: the Cholesky route takes its two streams from the lane itself)
-    const bool confined = std::isnan(lambda) && ctx().reserved_cus > 0 && L.ms != nullptr && !getenv("MHS_FIT_UNCONFINED");
+    const bool confined = std::isnan(lambda) && ctx().reserved_cus > 0 && L.ms != nullptr;
     hipStream_t s = confined ? L.ms : L.s;
-    const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -1994,14 +1922,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     // Round 4: the GCV route of fits with 320+ unknowns is tps_band32.hip's (32-column panels, GCV on the band on the GPU);
     // MHS_FIT_LEGACY_BAND=1 keeps the 8-column route below, which is also what a fit falls back to when a panel of the new
     // route turns out numerically rank deficient (its Cholesky-QR needs cond(P)^2 < 1 / eps).
-    static const bool legacy_env = getenv("MHS_FIT_LEGACY_BAND") != nullptr;
+    const bool legacy_env = getenv("MHS_FIT_LEGACY_BAND") != nullptr;      // per fit: the tests switch it
     bool use_b32 = !fixed && !legacy_env && m >= B32_MIN_M && m <= B32_MAX_M;
     char *b32base = nullptr;
-    int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme (MHS_DELAY_T overrides)
-    if (const char *e = getenv("MHS_DELAY_T")) t_delay = std::max(BW, atoi(e));
+    const int t_delay = 4000;      // trailing matrices taller than this take the delayed update scheme
     int *info_dev = nullptr;
     TallScratch *tall_sc = nullptr;
-    static const bool tall_multi = getenv("MHS_TALL_PANEL_ONE_BLOCK") == nullptr;
     auto layout = [&](ArenaCarver &ar) {
         A.p = ar.take<double>((size_t)(ld * (3 + m_pad)) + 2);
         if (A.p) A.p += 1;
@@ -2072,11 +1998,10 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     MHS_HIP(hipMemcpyAsync(dsw.p, sw.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
     }
 
-    static const bool fused_proj = getenv("MHS_PROJ_PASSES") == nullptr;
     auto build_A = [&]() -> int {      // the projected matrix A = Q'KQ (run again when the 32-column route hands the fit back)
     if (hit) {
             // nothing to build: the reflectors, the tridiagonal and the projected rows come from the cache
-        } else if (fused_proj) {
+        } else {
             // A = Q'KQ = K - W V' - V W' in two passes over kernel entries computed on the fly (see gram_y_kernel)
             for (int k = 0; k < 3; ++k)
                 MHS_HIP(hipMemcpyAsync(v3buf.p + (size_t)k * n, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -2119,18 +2044,6 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
             hipLaunchKernelGGL(gram_proj_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld, ctx().log_tab, v3buf.p, w3buf.p, A.p);
             MHS_HIP(hipGetLastError());
             MHS_HIP(hipStreamSynchronize(s));      // W (host vector) is read by the copy above
-        } else {
-            dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
-            hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, s, duv.p, duv.p + n, dsw.p, (int)n, ld,
-                               ctx().log_tab, A.p);
-            // A <- H3 H2 H1 A H1 H2 H3 (full-length reflectors, leading zeros)
-            MHS_HIP(hipMemcpyAsync(tau.p + n, htau, sizeof(double) * 3, hipMemcpyHostToDevice, s));
-            for (int k = 0; k < 3; ++k) {
-                MHS_HIP(hipMemcpyAsync(vbuf.p, hv[k].data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(symv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, pbuf.p);
-                hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(1024), 0, s, pbuf.p, vbuf.p, tau.p + n + k, (int)n, wbuf.p, (double *)nullptr);
-                hipLaunchKernelGGL(syr2_kernel, grid, dim3(256), 0, s, A.p, ld, 0, (int)n, vbuf.p, wbuf.p);
-            }
         }
         MHS_HIP(hipGetLastError());
         return MHS_OK;
@@ -2318,7 +2231,7 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
                 switch (nw) { MHS_PANEL(1) MHS_PANEL(2) MHS_PANEL(3) MHS_PANEL(4) default: MHS_PANEL(8) }
 #undef MHS_PANEL
             }
-            else if (!tall_multi || t > TALL_RPB * TALL_MAXBLK)
+            else if (t > TALL_RPB * TALL_MAXBLK)
                 hipLaunchKernelGGL(band_panel_kernel, dim3(1), dim3(1024), 0, s, A.p, ld, c0, r0, t, Vp, vs, Tp, gbuf.p + c + BW);
             else {      // tall panel: one many-block launch per Householder step
                 const unsigned nblk = (unsigned)((t + TALL_RPB - 1) / TALL_RPB);

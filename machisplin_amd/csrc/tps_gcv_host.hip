@@ -580,7 +580,7 @@ double BandGcv::eig_kth(int64_t k) const {
 }
 
 double BandGcv::find_lambda(int mode) const {
-    const bool timing = getenv("MHS_FIT_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

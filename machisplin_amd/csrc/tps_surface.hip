@@ -27,8 +27,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     if (njobs <= 0) return MHS_OK;
     // The tiles' fits are chains of small, latency-bound kernels: several of them run side by side, each on
     // its own lane (two streams + work arena) driven by its own host thread.
-    int64_t want_lanes = TILE_LANES;
-    if (const char *e = getenv("MHS_TILE_LANES")) { const int v = atoi(e); if (v > 0 && v <= 64) want_lanes = v; }
+    const int64_t want_lanes = TILE_LANES;
     const int nlanes = (int)std::min<int64_t>(njobs, want_lanes);
     std::vector<FitLane *> lanes((size_t)nlanes);
     for (int l = 0; l < nlanes; ++l)
@@ -127,7 +126,7 @@ extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const do
     std::vector<int64_t> fit((size_t)nt * 4), keep((size_t)nt * 4), rows((size_t)n), cols((size_t)n);
     if (int rc = mhs_step3_tile_windows(g, tile_edge, 0.2, 0.025, &nRx, &nCx, fit.data(), keep.data(), nt)) return rc;
     if (int rc = mhs_cells_from_xy(g, xy, n, rows.data(), cols.data())) return rc;
-    const bool timing = getenv("MHS_SURFACE_TIMING") != nullptr;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

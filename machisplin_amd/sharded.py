@@ -29,7 +29,8 @@ FIT_RESERVE_CANDIDATES = (0, 32, 64, 96)
 
 
 # Bands are cut at multiples of this many grid rows: the coherent gbm kernel sums a cell's trees in an order that depends on
-# the 4-row tile the cell sits in (tiles anchored to the grid), so bands of whole tiles reproduce the one-GPU planes bit for bit.
+# the 16 x 16-cell tile the cell sits in (tiles anchored to the grid, csrc/ensemble.hip BAND_ALIGN), so bands of whole tiles
+# reproduce the one-GPU planes bit for bit.
 BAND_ALIGN = 16
 
 
@@ -45,7 +46,9 @@ def row_bands(nrow: int, world: int, rank0_share: float | None = None):
     if world == 1:
         return nrow, [(0, nrow)]
     even = -(-nrow // world)
-    align = BAND_ALIGN if even >= 4 * BAND_ALIGN else (4 if even >= 8 else 1)     # toy grids: whole 4-row tiles, or no rule
+    # whole 16-row tiles whenever a rank gets at least one (round-4 advisor finding: the old 4-row rule for toy grids cut
+    # between the rows of a tile); grids with fewer rows than 16 per rank are below the coherent kernel's own threshold
+    align = BAND_ALIGN if even >= BAND_ALIGN else 1
     up = lambda n: -(-n // align) * align
     if rank0_share is None:
         band = up(even)

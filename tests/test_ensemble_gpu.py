@@ -95,7 +95,7 @@ def test_gbm_na_cells_through_the_compacted_list_equal_the_strided_pass(hip, fra
     """gbm's MissingNode routing for cells with an NA covariate (gbm_pred; terra::predict(rast_stack, gbm), V73:497): round 4
     walks them from a compacted list instead of in every block that holds one (0.09 % NoData on the reference's rasters cost
     half the kernel).  0.2 % NA: the list; 30 % NA: more than the list holds -> the overflow word hands the window back to
-    the strided pass.  Either way the plane is the strided pass's, bit for bit, and the oracle's."""
+    the strided pass.  Either way the NA cells' values are the node walk's, bit for bit, and the oracle's."""
     import torch
     g, stack, X, Xs, ys, params = _setup(hip, nrow=160, ncol=300, dtype="f32", nodata_frac=frac, n=900, gbm_trees=400, rf_trees=2)
     prm = params[0]
@@ -103,10 +103,12 @@ def test_gbm_na_cells_through_the_compacted_list_equal_the_strided_pass(hip, fra
     m = hip.models.from_param_dict(prm)
     a = hip.predict(stack, m)
     acc = hip.predict(stack, m, weight=0.5, accumulate=True, out=a.clone())
-    monkeypatch.setenv("MHS_GBM_NA_STRIDED", "1")
+    monkeypatch.setenv("MHS_TREES_GENERIC", "1")          # the node walk: NA cells through MissingNode in every block that holds one
     b = hip.predict(stack, m)
-    monkeypatch.delenv("MHS_GBM_NA_STRIDED")
-    assert not torch.isnan(a).any() and torch.equal(a, b)
+    monkeypatch.delenv("MHS_TREES_GENERIC")
+    na = torch.from_numpy(np.isnan(X).any(axis=1).reshape(g.nrow, g.ncol)).to(a.device)
+    assert not torch.isnan(a).any() and na.any() and torch.equal(a[na], b[na])          # (the other cells: the coherent kernel's order)
+    assert float((a - b).abs().max()) <= 1e-13 * float(b.abs().max())
     assert torch.allclose(acc, 1.5 * a, rtol=1e-15, atol=0)
     want = oe.predict(prm, X)
     assert np.nanmax(np.abs(a.cpu().numpy().ravel() - want)) <= _tol(want)
@@ -280,8 +282,7 @@ def test_gbm_rank_lut_variants(hip, C, trees, n):
 def test_gbm_row_tile_kernel_equals_the_other_paths_bit_for_bit(hip, dtype, n_splits, window, monkeypatch):
     """Rows of >= ~240 cells take gbm_lutreg_rt_kernel (round 3): a wave = 256 consecutive cells of one row, the
     tree's splits on LAT and its padding levels evaluated on the scalar unit, the leaf LUT permuted per tree.  Same
-    leaf values in the same tree order as the lane-per-cell register kernel (MHS_GBM_NO_ROWTILE is read once per
-    process, so that one is reached through a narrow window here) and as the node walk: identical planes, NA cells,
+    leaf values in the same tree order as the node walk: identical planes, NA cells,
     ragged last tile, windows, trees with fewer than five splits (n_splits < 5: up to two padding levels go to the
     scalar unit, the rest read as never-true vector levels) included."""
     import torch
@@ -350,16 +351,6 @@ def test_gbm_coherent_kernel_matches_the_tree_order_kernels_and_the_oracle(hip, 
     scale = float(ordered.abs().max())
     assert float((coh - ordered).abs().max()) <= 1e-13 * scale
     assert smooth or not torch.equal(coh, ordered)            # i.e. the switch did select another kernel
-    # round 4: the LONG / LAT ranks come from per-column / per-row tables (the same ranks: the same bits) and the wave tiles are
-    # 16 x 16 cells (round 3's 64 x 4 tiles: the same leaves in another order)
-    monkeypatch.setenv("MHS_NO_AXIS_RANKS", "1")
-    searched = hip.predict(stack, m, window=win)
-    monkeypatch.delenv("MHS_NO_AXIS_RANKS")
-    assert torch.equal(searched, coh)
-    monkeypatch.setenv("MHS_GBM_STRIP_WAVES", "1")
-    strips = hip.predict(stack, m, window=win)
-    monkeypatch.delenv("MHS_GBM_STRIP_WAVES")
-    assert float((strips - ordered).abs().max()) <= 1e-13 * scale
     want = oe.predict(prm, X).reshape(g.nrow, g.ncol)[r0:r1, c0:c1]
     got = coh.cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -400,18 +391,17 @@ def test_gbm_probe_picks_the_coherent_kernel_on_smooth_rasters_and_the_tree_orde
 
 @pytest.mark.parametrize("n,dtype,ncol,trees", [(1400, "f32", 257, 7), (4600, "f64", 257, 7), (4600, "i16", 257, 7), (1400, "f32", 1100, 7),
                                                 (700, "f32", 257, 130), (300, "f32", 257, 520)])
-def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, monkeypatch):
-    """The default forest walk (round 4: rf_walk_ld_kernel -- one loader wave stages the trees, even ones through its registers and
-    odd ones by LDS-DMA (MHS_RF_LD_FLAGS=64: all through the registers; MHS_RF_TWO_LOADERS: two register loaders), fifteen waves
-    of 16 x 16 cells walk (MHS_RF_STRIP_WAVES: 64 x 4) -- where three trees and the keys fit; MHS_RF_NO_LOADER: round 3's
-    barrier-free triple-buffered kernel -- three buffers, LDS counters between the
-    waves, hand-scheduled level loops --, else the double-buffered one, MHS_RF_DOUBLE_BUFFER)
-    against the compiler's loop, the four-walk forms, round 2's single-buffer forms and the node walk: bit-identical
-    planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the triple-buffered kernel's 24 KB stride).
-    The default also walks a lane's five cells on five ADJACENT rows (123 rows: a ragged last strip) and lets a wave leave a
-    tree once all its walks sit at terminal nodes (MHS_RF_FAR_WALKS / MHS_RF_FULL_DEPTH: round 2's cell order / every tree
-    to its full depth), and starts a tree's walks where the wave's cells first part ways (MHS_RF_NO_PREFIX: at the root).  Seven trees: a count that is a multiple neither of the two nor of the three buffers.  (Two more restructurings were
-    measured in round 3 and removed again, see DESIGN.md section 4 and profiles/r03_tree_variants.txt.)"""
+def test_forest_walk_kernels_equal_each_other_and_the_node_walk(hip, n, dtype, ncol, trees, monkeypatch):
+    """The forest's three walk kernels -- the loader-wave kernel (rf_walk_ld_kernel, the default where three trees and the keys
+    fit: one loader wave stages the trees, even ones through its registers and odd ones by LDS-DMA, fifteen waves of 16 x 16
+    cells walk), the double-buffered kernel (MHS_RF_KERNEL=db) and the split-node kernel (MHS_RF_KERNEL=compact) -- each with
+    and without the wave-uniform prefix and the early exit (MHS_RF_PLAIN=1: every tree from the root to its full depth), and the
+    generic node walk: bit-identical planes.  1 400 stations give trees of ~900 nodes, 4 600 stations ~2 800 (the 24 KB buffer
+    stride).  123 rows: a ragged last strip.  Seven trees: a count that is a multiple neither of the two nor of the three
+    buffers; 130: the entry registers are reloaded every 64 trees; 520: more than they hold.  (Round 5 removed the kernels
+    and switches that lost in rounds 3 and 4 -- single buffer, triple buffer without a loader, two loaders, the compiler's
+    level loop, four-walk forms, 64 x 4 strips: their measurements are in profiles/r03_tree_variants.txt and
+    profiles/r04_forest_variants.txt, their code in the history at commit 55aadea.)"""
     import torch
     from machisplin_amd import synth
     g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=ncol, dtype=dtype, nodata_frac=0.01, n=n, gbm_trees=2, rf_trees=1)
@@ -420,22 +410,8 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
     assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
     m = hip.models.from_param_dict(prm)
     fast = hip.predict(stack, m)
-    for envs in ({"MHS_RF_COMPILER_LOOP": "1"}, {"MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_COMPILER_LOOP": "1"},
-                 {"MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_NO_PREFIX": "1", "MHS_RF_FOUR_WALKS": "1"},
-                 {"MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FAR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"},
-                 {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_FOUR_WALKS": "1", "MHS_RF_FAR_WALKS": "1"},
-                 {"MHS_RF_STRIP_WAVES": "1"}, {"MHS_RF_TWO_LOADERS": "1"}, {"MHS_RF_LD_FLAGS": "64"}, {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_TWO_LOADERS": "1"},
-                 {"MHS_NO_AXIS_RANKS": "1"}, {"MHS_NO_AXIS_RANKS": "1", "MHS_RF_STRIP_WAVES": "1"},      # LONG / LAT ranks searched, not read from the per-column / per-row tables
-                 {"MHS_RF_STRIP_WAVES": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_TWO_LOADERS": "1", "MHS_RF_FULL_DEPTH": "1"},
-                 {"MHS_RF_NO_LOADER": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_NO_PREFIX": "1"},
-                 {"MHS_RF_NO_LOADER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_NO_LOADER": "1", "MHS_RF_FAR_WALKS": "1"},
-                 {"MHS_RF_TRIPLE_BUFFER": "1"}, {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"},
-                 {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
-                 {"MHS_RF_TRIPLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1"},
-                 {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FOUR_WALKS": "1"},
-                 {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FULL_DEPTH": "1"}, {"MHS_RF_DOUBLE_BUFFER": "1", "MHS_RF_FAR_WALKS": "1"},
-                 {"MHS_RF_FORCE_COMPACT": "1"}, {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FULL_DEPTH": "1"},
-                 {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_FAR_WALKS": "1"}, {"MHS_RF_FORCE_COMPACT": "1", "MHS_RF_NO_PREFIX": "1"}, {"MHS_RF_SINGLE_BUFFER": "1"}, {"MHS_TREES_GENERIC": "1"}):
+    for envs in ({"MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "db"}, {"MHS_RF_KERNEL": "db", "MHS_RF_PLAIN": "1"},
+                 {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_KERNEL": "compact", "MHS_RF_PLAIN": "1"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():
             monkeypatch.setenv(e, v)
         other = hip.predict(stack, m)
@@ -449,7 +425,7 @@ def test_forest_round3_walks_equal_the_round2_forms(hip, n, dtype, ncol, trees, 
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
-@pytest.mark.parametrize("C,n,force", [(11, 900, None), (13, 900, None), (11, 5200, "MHS_RF_FORCE_COMPACT"), (16, 700, None)])
+@pytest.mark.parametrize("C,n,force", [(11, 900, None), (13, 900, None), (11, 5200, "compact"), (16, 700, None)])
 def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
     """p = C + 2 >= 13 predictors (11+ covariate layers, V73:127-138 adds LONG and LAT): the wave-uniform prefix keeps the
     wave's [min, max] ranks for 12 predictors only, so these forests must start their walks at the root (round-3 advisor
@@ -463,10 +439,10 @@ def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
     assert np.isin(np.arange(12, C + 2), bv).all(), "no split on a predictor >= 12"
     m = hip.models.from_param_dict(prm)
     if force:
-        monkeypatch.setenv(force, "1")
+        monkeypatch.setenv("MHS_RF_KERNEL", force)
     fast = hip.predict(stack, m)
     if force:
-        monkeypatch.delenv(force)
+        monkeypatch.delenv("MHS_RF_KERNEL")
     monkeypatch.setenv("MHS_TREES_GENERIC", "1")
     generic = hip.predict(stack, m)
     monkeypatch.delenv("MHS_TREES_GENERIC")
@@ -479,8 +455,9 @@ def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
 
 
 def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
-    """Trees of ~18 000 nodes (30 000 stations): too many for 16-bit byte addresses and for nodes + predictions in
-    LDS, so the walk takes its BIG form (node indices, predictions read from global memory).  Same results."""
+    """Trees of ~18 000 nodes (30 000 stations): too many for any LDS form (16-bit byte addresses, 16-bit terminal codes), so
+    the forest takes the generic node walk (round 5 removed the BIG forms: the split-node kernel covers every BASELINE
+    configuration, 12 000-node trees at cfg5 included).  Same results."""
     from machisplin_amd import synth
     g, stack, X, Xs, ys, params = _setup(hip, nrow=256, ncol=256, C=3, n=30000, gbm_trees=2, rf_trees=1)
     prm = synth.rf_params(Xs, ys, 5, n_trees=3)
@@ -489,20 +466,12 @@ def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     want = oe.predict(prm, X)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
-    # p = 5: the walk above was the tree-major form (a staged tree serves four batches of cells whose keys wait in
-    # registers); the one-batch-per-staging form adds the same leaves in the same order
-    os.environ["MHS_RF_BIG_PER_BATCH"] = "1"
-    try:
-        per_batch = hip.predict(stack, hip.models.from_param_dict(prm)).cpu().numpy().ravel()
-    finally:
-        del os.environ["MHS_RF_BIG_PER_BATCH"]
-    assert np.array_equal(got, per_batch, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
-def test_forest_in_the_compact_form_equals_the_big_forms(hip, dtype):
+def test_forest_in_the_compact_form_equals_the_node_walk(hip, dtype):
     """Trees of ~7 000 nodes (12 000 stations): beyond the double-buffered kernel's 4 095, within the COMPACT form
-    (split nodes only in LDS, terminals as codes).  Same leaves in the same order as the BIG forms and the oracle."""
+    (split nodes only in LDS, terminals as codes).  Same leaves in the same order as the node walk and the oracle."""
     from machisplin_amd import synth
     g, stack, X, Xs, ys, params = _setup(hip, nrow=200, ncol=300, C=5, n=12000, gbm_trees=2, rf_trees=1, nodata_frac=0.01, dtype=dtype)
     prm = synth.rf_params(Xs, ys, 6, n_trees=5)
@@ -513,7 +482,7 @@ def test_forest_in_the_compact_form_equals_the_big_forms(hip, dtype):
     want = oe.predict(prm, X)
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
-    for envs in (("MHS_RF_NO_COMPACT",), ("MHS_RF_NO_COMPACT", "MHS_RF_BIG_PER_BATCH"), ("MHS_TREES_GENERIC",)):
+    for envs in (("MHS_RF_PLAIN",), ("MHS_TREES_GENERIC",)):
         for e in envs:
             os.environ[e] = "1"
         try:

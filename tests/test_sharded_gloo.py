@@ -80,9 +80,11 @@ def _free_port():
 
 def test_row_bands_and_packing():
     band, bands = sharded.row_bands(37, 2)
-    assert band == 20 and bands == [(0, 20), (20, 37)]          # cuts at multiples of 4 rows (whole gbm tiles per band)
-    # rank 0 also carries the fit: it can be given fewer rows, or none
-    assert sharded.row_bands(100, 4, rank0_share=0.1) == (32, [(0, 8), (8, 40), (40, 72), (72, 100)])
+    assert band == 32 and bands == [(0, 32), (32, 37)]          # cuts at multiples of 16 rows (whole 16 x 16 gbm tiles per band)
+    # rank 0 also carries the fit: it can be given fewer rows, or none -- but never a cut inside a tile (round-4 advisor finding)
+    assert sharded.row_bands(100, 4, rank0_share=0.1) == (32, [(0, 16), (16, 48), (48, 80), (80, 100)])
+    for nrow, world, share in ((100, 4, 0.1), (333, 4, 0.12), (1000, 8, 0.03), (64, 3, None), (10000, 8, 0.04)):
+        assert all(a % sharded.BAND_ALIGN == 0 for a, b in sharded.row_bands(nrow, world, rank0_share=share)[1] if b > a)
     assert sharded.row_bands(10000, 8)[1][1] == (1264, 2528) and sharded.row_bands(10000, 8, rank0_share=0.04)[1][0] == (0, 400)
     assert sharded.row_bands(10, 3, rank0_share=0.0) == (5, [(0, 0), (0, 5), (5, 10)])
     assert sharded.row_bands(10, 1, rank0_share=0.3) == (10, [(0, 10)])

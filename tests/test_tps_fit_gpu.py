@@ -110,23 +110,26 @@ def test_large_fit_uses_streaming_panel_path(hip):
     assert _rel(fixed.c, got.c) < 1e-8
 
 
-@pytest.mark.parametrize("n", [300, 813, 1500])
-def test_delayed_update_scheme_equals_the_eager_one(hip, n, monkeypatch):
-    """Large trailing matrices take the DELAYED update scheme of the band reduction (groups of 8 panels, one MFMA
-    rank-128 update per group, the symmetric products corrected on the fly); MHS_DELAY_T lowers its threshold so
-    that small fits exercise it: every group position, the group update's ragged edge tiles, the switch to the eager
-    scheme.  Same lambda, same coefficients (to rounding) as the eager scheme and as the oracle."""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n", [4300, 6100])
+def test_legacy_eight_column_route_equals_the_default_route(hip, n, monkeypatch):
+    """The 8-column band route (MHS_FIT_LEGACY_BAND=1) is what a fit falls back to when a 32-column panel breaks down, and
+    what fits beyond 32 768 stations take.  At these sizes its first panels run the DELAYED update scheme (trailing matrices
+    taller than 4 000 rows: groups of 8 panels, one MFMA rank-128 update per group, the symmetric products corrected on the
+    fly), then the switch to the eager scheme; n = 6 100 also starts with panels taller than the register-resident kernel.
+    On the default route these sizes have panels taller than 4 096 rows (a second batch of split-K partial sums in the
+    32-column reduction; round-4 advisor finding: only the benchmarks reached them).  Same lambda, GCV and coefficients to
+    rounding, and both equal to the oracle's."""
     xy, y = synth_stations(n, 300 + n)
-    eager = hip.Tps(xy, y)
-    monkeypatch.setenv("MHS_DELAY_T", "40")
-    delayed = hip.Tps(xy, y)
-    monkeypatch.delenv("MHS_DELAY_T")
-    assert abs(delayed.lambda_ - eager.lambda_) < 1e-8 * eager.lambda_
-    assert abs(delayed.gcv - eager.gcv) < 1e-9 * eager.gcv
-    ref = otps.fit(xy, y, lam=delayed.lambda_)
-    assert _rel(delayed.c, ref["c"]) < 1e-8 and _rel(delayed.d, ref["d"]) < 1e-8
-    want = otps.fit(xy, y)
-    assert abs(delayed.lambda_ - want["lambda"]) < 1e-8 * want["lambda"]
+    fast = hip.Tps(xy, y)
+    monkeypatch.setenv("MHS_FIT_LEGACY_BAND", "1")
+    legacy = hip.Tps(xy, y)
+    monkeypatch.delenv("MHS_FIT_LEGACY_BAND")
+    assert abs(legacy.lambda_ - fast.lambda_) < 1e-8 * fast.lambda_
+    assert abs(legacy.gcv - fast.gcv) < 1e-9 * fast.gcv
+    assert _rel(legacy.c, fast.c) < 1e-8 and _rel(legacy.d, fast.d) < 1e-8
+    ref = otps.fit(xy, y, lam=fast.lambda_)
+    assert _rel(fast.c, ref["c"]) < 1e-7 and _rel(fast.d, ref["d"]) < 1e-7
 
 
 @pytest.mark.parametrize("n", [12, 131, 250])

@@ -6,4 +6,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf -o f
 F=$(find /tmp/pf -name "*kernel_stats.csv" | head -1)
 head -6 "$F" | cut -c1-60,100-200
 cd $GRAFT_REPO_ROOT
-MHS_FIT_TIMING=1 timeout 300 python tools/fit_speed.py 2>&1 | tail -6
+MHS_TIMING=1 timeout 300 python tools/fit_speed.py 2>&1 | tail -6

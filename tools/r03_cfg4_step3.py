@@ -1,5 +1,5 @@
 """Round 3: phases of Step 3 + 4 (reference-tiled spline surface) of ONE cfg4 user tile (5 025 x 5 025 cells, ~1 260 stations,
-4 x 4 Step-3 tiles), first layer and cached layers: MHS_SURFACE_TIMING prints tile fits + evaluation / mosaic + feather."""
+4 x 4 Step-3 tiles), first layer and cached layers: MHS_TIMING prints tile fits + evaluation / mosaic + feather."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
@@ -15,7 +15,7 @@ tg = tiles["geom"][0]
 sel = tiles["dat"][0]
 res = synth.tps_residual(uv[sel], 3)
 cov1 = np.ones(len(sel))
-os.environ["MHS_SURFACE_TIMING"] = "1"
+os.environ["MHS_TIMING"] = "1"
 with reduction_cache():
     for k in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -82,5 +82,5 @@ for nb, pageable, one in runs:
     same = np.array_equal(np.nan_to_num(out), np.nan_to_num(ref))
     print(f"host ABI, bands {nb or 'auto (8 % | <= 50 M cells ... | 8 %)':>4}: {best:.1f} ms  (+{best - dt:.1f} over resident)  bitwise equal: {same}", flush=True)
 os.environ.pop("MHS_HOST_BANDS", None)
-os.environ["MHS_HOST_TIMING"] = "1"
+os.environ["MHS_TIMING"] = "1"
 _lib.check(_lib.lib().mhs_ensemble_predict(hs, ws, len(models), 1.0, C.byref(gs), C.byref(st), 0, side, 0, side, out.ctypes.data))

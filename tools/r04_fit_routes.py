@@ -1,5 +1,5 @@
 """Round 4: the GCV fit on the 32-column route (tps_band32.hip) against the 8-column route it replaces (MHS_FIT_LEGACY_BAND=1
-in a child process), lambda and coefficients compared, phases printed (MHS_FIT_TIMING=1).
+in a child process), lambda and coefficients compared, phases printed (MHS_TIMING=1).
     python tools/r04_fit_routes.py [sizes...]"""
 import os
 import subprocess
@@ -24,11 +24,11 @@ def run(sizes, tag):
         best = 1e30
         for rep in range(4):
             if rep == 3:
-                os.environ["MHS_FIT_TIMING"] = "1"
+                os.environ["MHS_TIMING"] = "1"
             t0 = time.perf_counter()
             t = m.Tps(xy, y)
             dt = time.perf_counter() - t0
-            os.environ.pop("MHS_FIT_TIMING", None)
+            os.environ.pop("MHS_TIMING", None)
             if rep < 3:
                 best = min(best, dt)
         mm = n - 3

@@ -1,4 +1,4 @@
-"""Phases of a small GCV fit (the reference-tiled mode's 130-250 stations per tile):  MHS_FIT_TIMING=1 python tools/small_fit_speed.py"""
+"""Phases of a small GCV fit (the reference-tiled mode's 130-250 stations per tile):  MHS_TIMING=1 python tools/small_fit_speed.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
