@@ -1175,11 +1175,13 @@ def main():
             fit_ms = min(fit_ms, (time.perf_counter() - t1) * 1e3)
         # for the record (outside the timed region): the same residual surface the way the REFERENCE computes it at
         # this size -- ceil(n/1500)^2 overlapping tiles with their own fits, mean mosaic, seam feathering (V73:656-895)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        mhs.tps_residual_surface(wl.geom, knots, resid, cov1_at_stations=wl.ops.X[:, 0], tile_edge=1500)
-        torch.cuda.synchronize()
-        tiled_ms = (time.perf_counter() - t1) * 1e3
+        tiled_ms = 1e30
+        for _ in range(2):       # the first call grows the library's arenas (round-4 verdict: one cold call was reported)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            mhs.tps_residual_surface(wl.geom, knots, resid, cov1_at_stations=wl.ops.X[:, 0], tile_edge=1500)
+            torch.cuda.synchronize()
+            tiled_ms = min(tiled_ms, (time.perf_counter() - t1) * 1e3)
         nRx, nCx = mhs.tiles.step3_tile_windows(wl.geom, 1500)[:2]
         info = {"nRx": int(nRx), "nCx": int(nCx)}
         # for the record (outside the timed region): the spline of the last step evaluated by the direct sum
