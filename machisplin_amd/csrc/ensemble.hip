@@ -1858,42 +1858,40 @@ __global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restric
     }
 }
 
-// RING form (round 5): the loader stages, per block of cells, only the SUBTREE the block's cells can reach, and many trees at once.
+// SUBTREE form (round 5): the loader stages, per block of cells, only the SUBTREE the block's cells can reach, several trees to a buffer.
 // Round 4's loader-wave kernel copies every tree whole into one of three buffers -- 12 MB per block of 3 840 cells, 196 GB per
-// 1e8 cells past the L2 (PMC) -- and is bound by ONE load round trip per tree and buffer (0.75 us per tree with two in flight:
+// 1e8 cells past the L2 (PMC) -- and is bound by one load round trip per tree and buffer (0.75 us per tree with two in flight:
 // the loader alone takes 38 of the kernel's 44 ms on 8 000 x 8 000 cells).  But a block's cells are neighbours: with the block's
 // [min, max] rank of every predictor (the waves' ranges, reduced through LDS) the loader descends every tree from its root while
 // the split falls the same way for the whole block -- lane = tree, the walkers' own prefix one level up -- and needs only the
-// subtree below that node.  The loader numbers nodes in PRE-ORDER (mhs_rf_load), so the subtree is the contiguous record range
-// [entry, entry + size): on the 8d planes 3.7 KB per tree instead of 24 (tools/r04_rf_slice_sim.py with 80 x 48-cell blocks), and
-// a third of the trees need nothing at all.  The ranges are copied in 1 KB chunks into a RING of such chunks (no fixed
-// buffers: ~15 trees resident instead of 3, 16 chunk loads in flight per round trip); a tree's records keep their order, the
-// loader adds the tree's displacement (ring address - address within the tree) to the two 16-bit child addresses of every
-// record on the way, and the walkers add it to their entry address and take it off before they fetch the prediction: the
-// level loop is unchanged.  Ring positions are fixed before the first tree (a scan over the trees' chunk counts; a tree never
-// wraps around the ring's end), together with the number of trees the walkers must have LEFT before a tree may be written
-// (the trees whose chunks it overwrites): the loader polls the walkers' progress words (one per wave, plain stores) against
-// that number, the walkers poll the loader's "trees staged" word -- both normally satisfied by the cached value.
+// subtree below that node.  mhs_rf_load numbers nodes in PRE-ORDER, so that subtree is the contiguous record range
+// [entry, entry + size): on the 8d planes 3.7 KB per tree instead of 24 (tools/r04_rf_slice_sim.py with 80 x 48-cell blocks),
+// and a fifth of the trees need nothing at all.  The range goes, in 1 KB chunks, to the SAME offsets of the tree's buffer
+// (tree t: buffer t % 3) it has in a whole copy -- so every record's child addresses stay valid and the chunks travel by
+// LDS-DMA (global_load_lds, no registers, dozens in flight) -- and trees whose ranges do not overlap share a buffer: the
+// loader keeps, per buffer and chunk, the last tree that used it (lane = chunk) and waits, before it overwrites a chunk,
+// for every walker to have LEFT that tree (the walkers' progress words, one per wave, plain stores); the walkers wait for
+// the loader's "trees staged" word -- both normally satisfied by the cached value.  A round of the loader: the next trees'
+// chunks up to ~40 in flight, one s_waitcnt vmcnt(0), one store of the new count.  With whole trees (no prefix, rough
+// rasters) this degenerates into round 4's schedule.
 // Same nodes visited, same additions in the same order: identical planes (test_forest_walk_kernels_equal_each_other_...).
-template <int LOG2R, bool K64>
-__global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restrict__ gnodes,
-                                                            const double *__restrict__ glval,
-                                                            const int *__restrict__ tree_off,
-                                                            const int *__restrict__ depth,
-                                                            const void *__restrict__ sorted,
-                                                            const int *__restrict__ sorted_off, int n_trees,
-                                                            int p, StackDev s, PredGeom g,
-                                                            double weight, int accumulate,
-                                                            double *__restrict__ out, const int *__restrict__ dmin, int tiles, int flags,
-                                                            const int *__restrict__ axis_rank, int axis_ncol, int ring) {
-    constexpr int R = rf_walks(LOG2R), WALKERS = 15;                // (the loader keeps 16 chunk loads in flight per round)
+template <int LOG2R, bool K64, int STRIDE>
+__global__ __launch_bounds__(1024) void rf_walk_sub_kernel(const uint2 *__restrict__ gnodes,
+                                                           const double *__restrict__ glval,
+                                                           const int *__restrict__ tree_off,
+                                                           const int *__restrict__ depth,
+                                                           const void *__restrict__ sorted,
+                                                           const int *__restrict__ sorted_off, int n_trees,
+                                                           int p, StackDev s, PredGeom g,
+                                                           double weight, int accumulate,
+                                                           double *__restrict__ out, const int *__restrict__ dmin, int tiles, int flags,
+                                                           const int *__restrict__ axis_rank, int axis_ncol) {
+    constexpr int R = rf_walks(LOG2R), WALKERS = 15;
+    constexpr unsigned TREE_BYTES = 3u * STRIDE;
+    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES + 2048u && 2 * STRIDE <= 65535 && STRIDE % 1024 == 0, "buffer bases inside the 16-bit immediate offsets");
+    constexpr unsigned CNT = TREE_BYTES, STG = CNT, PROG = CNT + 4u;   // 16 words: trees staged; the walker waves' progress
+    constexpr unsigned RANGES = (unsigned)RF_COARSE_BYTES;           // 15 waves x 12 predictors x (min, max), behind the rank search's coarse table
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: the ring (ring x 1 KB; before the first tree: the rank search's coarse table and the waves' rank ranges), the tree
-    // table (8 bytes per tree: displacement; chunks | first chunk << 8 | trees to wait for << 16), 16 words of counters
-    // (trees staged; the walker waves' progress), the lanes' rank keys
-    const unsigned RING_BYTES = (unsigned)ring << 10;
-    const unsigned TAB = RING_BYTES, CNT = TAB + (((unsigned)n_trees * 8u + 15u) & ~15u), STG = CNT, PROG = CNT + 4u;
-    const unsigned RANGES = (unsigned)RF_COARSE_BYTES;             // 15 waves x 12 predictors x (min, max)
     float *coarse = (float *)smem;
     const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
     const unsigned lane_base = CNT + 64u + threadIdx.x * stride * 4u;
@@ -1964,6 +1962,7 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
         for (int v = 0; v < RF_PREFIX_MAX_P; ++v) { if (lane == 2 * v) val = mn[v]; if (lane == 2 * v + 1) val = mx[v]; }
         *(int *)(smem + RANGES + (unsigned)(wave * 2 * RF_PREFIX_MAX_P + lane) * 4u) = val;
     }
+    if (threadIdx.x < 16) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = 0u;
     __syncthreads();
     // lane = tree descent from node `nd` while the split falls the same way for every rank in [lo, hi] of its predictor; `end` follows
     // (pre-order: the left subtree of a node k is [k + 1, right), the right one [right, end))
@@ -1987,12 +1986,11 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             }
         }
     };
-    const unsigned POSV = RANGES + 2048u;                          // scratch inside the (still unused) ring: the trees' virtual ring positions
-    unsigned entry[RF_ENTRY_BATCHES];
+    unsigned entry[RF_ENTRY_BATCHES];                              // walkers: the wave's entry nodes; loader: the block's chunk ranges
 #pragma unroll
     for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
     if (loader) {
-        // ---- the block's ranges, the block's subtrees, their places in the ring ------------------------------------
+        // ---- the block's ranges and subtrees: entry[b], lane l = tree 64 b + l: chunks | first chunk << 8 ---------------
         int bmn[RF_PREFIX_MAX_P], bmx[RF_PREFIX_MAX_P];
 #pragma unroll
         for (int v = 0; v < RF_PREFIX_MAX_P; ++v) {
@@ -2005,62 +2003,20 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
             bmn[v] = __builtin_amdgcn_readfirstlane(a); bmx[v] = __builtin_amdgcn_readfirstlane(b);
         }
-        unsigned wbase = 0u;                                       // virtual ring position (chunks) of the next tree
-#pragma unroll 1
-        for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-            if (b * 64 >= n_trees) break;
-            const int t = b * 64 + lane;
-            const int tl = min(t, n_trees - 1);
-            unsigned nd = 0u, end = (unsigned)(tree_off[tl + 1] - tree_off[tl]), plen = 0u, term = 0u;
-            if (prefix) descend(bmn, bmx, t, nd, end, plen, term);
-            const unsigned q0 = (nd * 8u) >> 10;
-            const unsigned nq = (term || t >= n_trees) ? 0u : ((end * 8u + 1023u) >> 10) - q0;
-            // exclusive scan of the chunk counts; a tree that would run over the ring's end starts at the next lap instead
-            unsigned pos = nq;
 #pragma unroll
-            for (int q = 1; q < 64; q <<= 1) { const unsigned up = (unsigned)__shfl_up((int)pos, q); if (lane >= q) pos += up; }
-            pos = wbase + pos - nq;
-            for (;;) {
-                const bool straddles = nq > 0u && (pos % (unsigned)ring) + nq > (unsigned)ring;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(straddles);
-                if (!mask) break;
-                const int first = __builtin_ctzll(mask);
-                const unsigned fpos = (unsigned)__builtin_amdgcn_readlane((int)pos, first);
-                const unsigned pad = (unsigned)ring - fpos % (unsigned)ring;
-                if (lane >= first) pos += pad;
-            }
-            wbase = (unsigned)__builtin_amdgcn_readlane((int)(pos + nq), 63);
-            if (t < n_trees) {
-                *(unsigned *)(smem + POSV + (unsigned)t * 4u) = pos;
-                *(int *)(smem + TAB + (unsigned)t * 8u) = (int)((pos % (unsigned)ring) << 10) - (int)(q0 << 10);      // the tree's displacement
-                *(unsigned *)(smem + TAB + (unsigned)t * 8u + 4u) = nq | (q0 << 8);
-            }
-        }
-#pragma unroll 1
         for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-            if (b * 64 >= n_trees) break;
-            const int t = b * 64 + lane;
-            if (t < n_trees) {
-                const unsigned pos = *(const unsigned *)(smem + POSV + (unsigned)t * 4u);
-                const unsigned w1 = *(const unsigned *)(smem + TAB + (unsigned)t * 8u + 4u);
-                const unsigned nq = w1 & 0xFFu;
-                // trees v < t with pos_v < pos + nq - ring lie under the chunks tree t overwrites: the walkers must have left them
-                unsigned need = 0u;
-                if (nq > 0u && pos + nq > (unsigned)ring) {
-                    const unsigned x = pos + nq - (unsigned)ring;
-                    int lo = 0, hi = t;                                                              // first v in [0, t) with pos_v >= x
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (*(const unsigned *)(smem + POSV + (unsigned)mid * 4u) < x) lo = mid + 1; else hi = mid;
-                    }
-                    need = (unsigned)lo;
-                }
-                *(unsigned *)(smem + TAB + (unsigned)t * 8u + 4u) = w1 | (need << 16);
+            if (b * 64 < n_trees) {
+                const int t = b * 64 + lane;
+                const int tl = min(t, n_trees - 1);
+                unsigned nd = 0u, end = (unsigned)(tree_off[tl + 1] - tree_off[tl]), plen = 0u, term = 0u;
+                if (prefix) descend(bmn, bmx, t, nd, end, plen, term);
+                const unsigned q0 = (nd * 8u) >> 10;
+                const unsigned nq = (term || t >= n_trees) ? 0u : ((end * 8u + 1023u) >> 10) - q0;
+                entry[b] = nq | (q0 << 8);
             }
         }
-        if (lane < 16) *(unsigned *)(smem + CNT + (unsigned)lane * 4u) = 0u;
     } else if (prefix) {
-        // ---- the wave's own prefix: where its cells first part ways (rf_prefix_entries' descent) ---------------------
+        // ---- the wave's own prefix: where its cells first part ways ------------------------------------------------------
 #pragma unroll
         for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
             if (b * 64 < n_trees) {
@@ -2070,27 +2026,15 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             }
         }
     }
-    __syncthreads();                                               // the tree table is complete, the ring is free
+    __syncthreads();                                               // the ranges have been read: the buffers are free
     if (loader) {
-        // ---- staging: up to G chunks per round trip, trees in order --------------------------------------------------
+        // ---- staging ----------------------------------------------------------------------------------------------------
         const unsigned lane16 = (unsigned)lane * 16u;
-        uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-        unsigned la0, la1, la2, la3, la4, la5, la6, la7, la8, la9, la10, la11, la12, la13, la14, la15;      // LDS byte address of the chunk; ~0u: slot unused
-        unsigned dd0, dd1, dd2, dd3, dd4, dd5, dd6, dd7, dd8, dd9, dd10, dd11, dd12, dd13, dd14, dd15;      // the tree's displacement in both halves
-        int head = 0, chunk = 0;                                   // next tree, next chunk of it
+        unsigned last0 = 0u, last1 = 0u, last2 = 0u;               // lane c: 1 + the last tree that used chunk c of buffer 0 / 1 / 2
         unsigned prog = 0u;                                        // trees every walker has left (cached)
-        int w0v = 0, offv = 0;                                     // lane = tree: the current 64 trees' table words and first records
-        unsigned w1v = 0u;
-        int loaded_batch = -1;
-        auto fetch_batch = [&]() {
-            if ((head >> 6) != loaded_batch && head < n_trees) {
-                loaded_batch = head >> 6;
-                const int tl = min(loaded_batch * 64 + lane, n_trees - 1);
-                w0v = *(const int *)(smem + TAB + (unsigned)tl * 8u);
-                w1v = *(const unsigned *)(smem + TAB + (unsigned)tl * 8u + 4u);
-                offv = tree_off[tl];
-            }
-        };
+        unsigned cur = 0u;                                         // the current 64 trees' chunk ranges, lane = tree
+        int offv = 0;                                              // ... and first records
+        int inflight = 0;
         auto poll = [&]() {                                        // the slowest walker's progress
             unsigned v = 0xffffffffu;
             if (lane < WALKERS) v = *(volatile const unsigned *)(smem + PROG + (unsigned)lane * 4u);
@@ -2098,53 +2042,50 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             for (int q = 32; q > 0; q >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, q));
             prog = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
         };
-        const char *gdummy = (const char *)gnodes + lane16;
-        bool blocked = false;
-#define MHS_RING_PICK(I) { \
-            la##I = 0xffffffffu; dd##I = 0u; \
-            const char *src = gdummy; \
-            for (;;) { \
-                if (blocked || head >= n_trees) break; \
-                fetch_batch(); \
-                const unsigned w1 = (unsigned)__builtin_amdgcn_readlane((int)w1v, head & 63); \
-                const unsigned nq = w1 & 0xFFu; \
-                if (nq == 0u) { ++head; continue; } \
-                if (chunk == 0) { \
-                    const unsigned need = w1 >> 16; \
-                    if (prog < need) poll(); \
-                    if (prog < need) { blocked = true; break; } \
-                } \
-                const int dl = __builtin_amdgcn_readlane(w0v, head & 63); \
-                const unsigned q0 = (w1 >> 8) & 0xFFu; \
-                const int o = __builtin_amdgcn_readlane(offv, head & 63); \
-                src = (const char *)(gnodes + o) + (size_t)((q0 + (unsigned)chunk) << 10) + lane16; \
-                la##I = (unsigned)((int)((q0 + (unsigned)chunk) << 10) + dl) + lane16; \
-                dd##I = ((unsigned)dl & 0xFFFFu) * 0x10001u; \
-                if (++chunk == (int)nq) { chunk = 0; ++head; } \
-                break; \
-            } \
-            r##I = *(const uint4 *)src; }
-#define MHS_RING_STORE(I) if (la##I != 0xffffffffu) { \
-            uint4 v = r##I; \
-            v.y = ((v.y + dd##I) & 0xFFFFu) | ((v.y + (dd##I & 0xFFFF0000u)) & 0xFFFF0000u); \
-            v.w = ((v.w + dd##I) & 0xFFFFu) | ((v.w + (dd##I & 0xFFFF0000u)) & 0xFFFF0000u); \
-            *(uint4 *)(smem + la##I) = v; }
-#define MHS_RING_ALL(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
-        while (head < n_trees) {
-            blocked = false;
-            MHS_RING_ALL(MHS_RING_PICK)
-            if (la0 == 0xffffffffu) {                               // nothing could be placed: the walkers are behind (or only empty trees were left)
-                if (head < n_trees) __builtin_amdgcn_s_sleep(4);
-            } else {
-                MHS_RING_ALL(MHS_RING_STORE)
+        auto publish = [&](int done) {                             // every chunk issued so far has landed: trees 0 .. done - 1 are whole
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile unsigned *)(smem + STG) = (unsigned)done;
+            inflight = 0;
+        };
+        auto stage = [&](auto slot_tag, const int u) {
+            constexpr int SLOT = decltype(slot_tag)::value;
+            if ((u & 63) == 0) {
+#pragma unroll
+                for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((u >> 6) == b) cur = entry[b];
+                offv = tree_off[min(u + lane, n_trees - 1)];
+                asm volatile("" : "+v"(cur), "+v"(offv));
             }
-            // trees 0 .. head - 1 are whole (a tree in progress is `head` itself); the LDS unit executes this wave's stores in order
-            if (lane == 0) *(volatile unsigned *)(smem + STG) = (unsigned)head;
+            const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)cur, u & 63);
+            const int nq = (int)(w & 0xFFu), q0 = (int)(w >> 8);
+            if (nq == 0) return;
+            unsigned &last = SLOT == 0 ? last0 : SLOT == 1 ? last1 : last2;
+            const bool mine = lane >= q0 && lane < q0 + nq;
+            unsigned need = mine ? last : 0u;
+#pragma unroll
+            for (int q = 32; q > 0; q >>= 1) need = max(need, (unsigned)__shfl_xor((int)need, q));
+            need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+            if (prog < need) {
+                poll();
+                if (prog < need) {
+                    if (inflight) publish(u);                      // the walkers may be waiting for what is in flight
+                    while (prog < need) { __builtin_amdgcn_s_sleep(2); poll(); }
+                }
+            }
+            const char *src = (const char *)(gnodes + __builtin_amdgcn_readlane(offv, u & 63)) + ((size_t)q0 << 10) + lane16;
+            unsigned dst = (unsigned)(SLOT * STRIDE) + ((unsigned)q0 << 10);
+            if (!(flags & 2)) for (int i = 0; i < nq; ++i) { glds16(src, dst); src += 1024; dst += 1024u; }
+            if (mine) last = (unsigned)u + 1u;
+            inflight += nq;
+            if (inflight >= 40) publish(u + 1);
+        };
+        for (int u = 0; u < n_trees; u += 3) {
+            stage(std::integral_constant<int, 0>{}, u);
+            if (u + 1 < n_trees) stage(std::integral_constant<int, 1>{}, u + 1);
+            if (u + 2 < n_trees) stage(std::integral_constant<int, 2>{}, u + 2);
+            // a short forest tail / trees without chunks: keep the count moving (cheap when nothing is in flight)
+            if (inflight >= 16 || (u % 24) == 21) publish(min(u + 3, n_trees));
         }
-        if (lane == 0) *(volatile unsigned *)(smem + STG) = (unsigned)n_trees;
-#undef MHS_RING_ALL
-#undef MHS_RING_STORE
-#undef MHS_RING_PICK
+        publish(n_trees);
         return;
     }
     // ---- the walkers ------------------------------------------------------------------------------------------------
@@ -2156,12 +2097,12 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
 #pragma unroll
         for (int k = 0; k < PD; ++k) pend[k][c] = 0.0;
     }
-    unsigned staged = 0u;                                          // cached: trees 0 .. staged - 1 are in the ring
-    int ocur = 0, dlcur = 0;                                       // lane l: first record and ring displacement of tree 64 b + l
+    unsigned staged = 0u;                                          // cached: trees 0 .. staged - 1 are in their buffers
+    int ocur = 0;                                                  // lane l: first record of tree 64 b + l
     unsigned wcur = 0u;                                            // lane l: its walk -- entry node's byte address | c0 << 19 | cnt << 25 | walks << 31
     double tpcur = 0.0;                                            // lane l: the prediction of its tree's entry node where the wave does not walk the tree
-    auto step = [&](auto pidx_tag, const int t) {
-        constexpr int PIDX = decltype(pidx_tag)::value;
+    auto step = [&](auto slot_tag, auto pidx_tag, const int t) {
+        constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
         if ((t & 63) == 0) {
             // the next 64 trees' scalars, lane = tree (one vector load each), and the walk's loop counts formed on the vector unit
             unsigned ecur = 0u;
@@ -2169,21 +2110,22 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
             const int tl = min(t + lane, n_trees - 1);
             ocur = tree_off[tl];
-            dlcur = *(const int *)(smem + TAB + (unsigned)tl * 8u);
             const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
             const int plen = (int)((ecur >> 16) & 0x7FFFu);
-            const int levels = (ecur >> 31) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
+            const int levels = ((ecur >> 31) || (flags & 4)) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
             const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63
             wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
+            // a tree the wave does not walk (its cells share the entry node) has ONE prediction for all of them: fetched here
             tpcur = levels > 0 ? 0.0 : glval[ocur + (int)(ecur & 0xFFFFu)];
-            asm volatile("" : "+v"(ocur), "+v"(wcur), "+v"(tpcur), "+v"(dlcur));
+            asm volatile("" : "+v"(ocur), "+v"(wcur), "+v"(tpcur));
         }
         const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)wcur, t & 63);
         const int o = __builtin_amdgcn_readlane(ocur, t & 63);
-        const int dl = __builtin_amdgcn_readlane(dlcur, t & 63);
         unsigned node[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) node[c] = wk & 0x7FFF8u;
         if (wk >> 31) {
-            if (staged <= (unsigned)t)                              // tree t is in the ring?
+            if (staged <= (unsigned)t)                              // tree t is in its buffer?
                 for (;;) {
                     unsigned v;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(STG) : "memory");
@@ -2191,14 +2133,12 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
                     if (staged > (unsigned)t) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-#pragma unroll
-            for (int c = 0; c < R; ++c) node[c] = (unsigned)((int)(wk & 0x7FFF8u) + dl);
             int c0 = (int)((wk >> 19) & 63u), cnt = (int)((wk >> 25) & 63u);
             if constexpr (R == 4) {
                 asm volatile(
 #include "rf_walk_loop4xo.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(0)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
                       "v115", "v116", "v117", "v118", "v120");
             } else {
@@ -2207,14 +2147,14 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
 #include "rf_walk_loop5xo.inc"
                     : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[R - 1]), [cnt] "+s"(cnt),
                       [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(0)
+                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
                     : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
             }
         }
         // this wave has left tree t (or never entered it): its progress word, lane 0 (every lane is active here)
         asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(PROG + 4u * (unsigned)wave), "v"((unsigned)t + 1u) : "memory");
-        const char *lv = (const char *)(glval + o) - dl;                 // node[] are ring addresses of 8-byte records: less the displacement, of the doubles
+        const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
 #pragma unroll
         for (int c = 0; c < R; ++c) acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];      // tree t - (PD - 1)'s; still in tree order
         if (wk >> 31) {
@@ -2226,14 +2166,14 @@ __global__ __launch_bounds__(1024) void rf_walk_ring_kernel(const uint2 *__restr
             for (int c = 0; c < R; ++c) pend[PIDX][c] = tv;
         }
     };
-    static_assert(PD == 6, "the tree loop is unrolled by PD");
+    static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
     for (int t = 0; t < n_trees; t += 6) {
-        step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, t + 2);
-        if (t + 3 < n_trees) step(std::integral_constant<int, 3>{}, t + 3);
-        if (t + 4 < n_trees) step(std::integral_constant<int, 4>{}, t + 4);
-        if (t + 5 < n_trees) step(std::integral_constant<int, 5>{}, t + 5);
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4);
+        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5);
     }
     // trees n - (PD - 1) .. n - 1 are still pending (slots never written hold 0.0)
     for (int k = n_trees - (PD - 1); k < n_trees; ++k) {
@@ -2950,11 +2890,11 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
 // MHS_RF_KERNEL = ld | db | compact pins one of the three forest walk kernels where it applies (the equality tests and the
 // benchmarks' comparisons); unset: the loader-wave kernel, else the double-buffered one, else the split-node one, else the
 // generic node walk.  MHS_RF_PLAIN=1: no wave-uniform prefix and every tree to its full depth (the walk as round 2 had it).
-enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT };      // (auto: the ring kernel first)
+enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT, RF_PICK_SUB };
 static int rf_pick() {
     const char *e = getenv("MHS_RF_KERNEL");
     if (!e) return RF_PICK_AUTO;
-    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : RF_PICK_AUTO;
+    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : !strcmp(e, "sub") ? RF_PICK_SUB : RF_PICK_AUTO;
 }
 static bool rf_plain() { return getenv("MHS_RF_PLAIN") != nullptr; }
 
@@ -2969,22 +2909,6 @@ static int rf_walk_db_log2r(const mhs_model *m) {
     for (int l2 = 3; l2 >= 1; --l2)
         if ((m->p * rf_walks(l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
     return -1;
-}
-
-// ring kernel: LDS = ring (1 KB chunks) + 8 bytes per tree + counters + the lanes' keys; the ring must hold the largest tree
-static size_t rf_walk_ring_lds(const mhs_model *m, int log2r, int ring) {
-    return (size_t)ring * 1024 + (((size_t)m->n_trees * 8 + 15) & ~(size_t)15) + 64 + (size_t)1024 * (((size_t)m->p * rf_walks(log2r)) | 1) * 4;
-}
-static bool rf_walk_ring_config(const mhs_model *m, int *log2r, int *ring) {
-    if (m->rf_max_depth > 63 || m->n_trees > 1024) return false;      // level counts travel in 6 bits each; the tree table lives in LDS
-    const int need = (int)(((size_t)m->rf_max_nodes * 8 + 1023) / 1024);      // chunks of the largest tree
-    // five walks per lane where a ring of twice the largest tree (at least 32 KB) still fits beside their keys, else four
-    for (int l2 = 3; l2 >= 2; --l2) {
-        if ((m->p * rf_walks(l2) * 4) > 255) continue;
-        for (int rg = 64; rg >= 32; rg -= 8)
-            if (rg >= need && (l2 == 2 || rg >= std::min(64, 2 * need)) && rf_walk_ring_lds(m, l2, rg) <= LDS_MAX) { *log2r = l2; *ring = rg; return true; }
-    }
-    return false;
 }
 
 // loader-wave kernel (three node buffers): buffer stride (bytes, a template parameter) and walks per lane; false = does not apply
@@ -3091,11 +3015,12 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
     const int key64 = s.dtype == MHS_F64, pick = rf_pick();
     *launched = false;
     (void)total;
-    int rg_l2 = 0, rg_ring = 0;
-    if (pick != RF_PICK_DB && pick != RF_PICK_LD && rf_walk_ring_config(m, &rg_l2, &rg_ring)) {      // subtree ring, one loader wave, 15 walker waves
+    int sb_l2 = 0, sb_stride = 0;
+    if (pick == RF_PICK_SUB && rf_walk_ld_config(m, &sb_l2, &sb_stride) && m->n_trees <= 64 * RF_ENTRY_BATCHES) {
+        // block-level subtrees in three shared buffers, one loader wave, 15 walker waves (same LDS budget as the loader-wave kernel)
         TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, rg_l2, RF_SMALL, key64, &tt)) return rc;
-        const int R = rf_walks(rg_l2);
+        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, sb_l2, RF_SMALL, key64, &tt)) return rc;
+        const int R = rf_walks(sb_l2);
         const int tiles = rf_strips(g, R);
         unsigned blocks;
         if (tiles) {
@@ -3103,15 +3028,20 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
             blocks = (unsigned)(((tiles_x + 4) / 5) * ((tiles_y + 2) / 3));                      // 5 x 3 wave tiles per block
         } else blocks = (unsigned)((rf_lane_count(g, R, 0) + 64 * 15 - 1) / (64 * 15));
         const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
-        const size_t tbytes = rf_walk_ring_lds(m, rg_l2, rg_ring);
-        auto tk = rg_l2 == 3 ? (key64 ? rf_walk_ring_kernel<3, true> : rf_walk_ring_kernel<3, false>)
-                             : (key64 ? rf_walk_ring_kernel<2, true> : rf_walk_ring_kernel<2, false>);
-        MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
-        hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles,
-                           (int)(tiles && dmin), tt.axis_rank, tt.axis_ncol, rg_ring);
-        *launched = true;
-        return MHS_OK;
+        const size_t tbytes = (size_t)3 * sb_stride + 64 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
+#define MHS_SB(L2, ST) (key64 ? rf_walk_sub_kernel<L2, true, ST> : rf_walk_sub_kernel<L2, false, ST>)
+        auto tk = sb_stride == 16384 ? (sb_l2 == 3 ? MHS_SB(3, 16384) : MHS_SB(2, 16384))
+                : sb_stride == 24576 ? (sb_l2 == 3 ? MHS_SB(3, 24576) : MHS_SB(2, 24576))
+                                     : MHS_SB(2, 25600);
+#undef MHS_SB
+        if (tbytes <= LDS_MAX) {
+            MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
+            hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
+                               m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles,
+                               (int)(tiles && dmin) | (getenv("MHS_RF_DIAG") ? atoi(getenv("MHS_RF_DIAG")) & ~1 : 0), tt.axis_rank, tt.axis_ncol);
+            *launched = true;
+            return MHS_OK;
+        }
     }
     int ld_l2 = 0, ld_stride = 0;
     if (pick != RF_PICK_DB && rf_walk_ld_config(m, &ld_l2, &ld_stride)) {      // three node buffers, one loader wave, 15 walker waves

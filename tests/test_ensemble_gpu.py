@@ -410,7 +410,7 @@ def test_forest_walk_kernels_equal_each_other_and_the_node_walk(hip, n, dtype, n
     assert (nodes <= 2048) == (n < 2000) and nodes <= 3072
     m = hip.models.from_param_dict(prm)
     fast = hip.predict(stack, m)
-    for envs in ({"MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "ld"}, {"MHS_RF_KERNEL": "ld", "MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "db"}, {"MHS_RF_KERNEL": "db", "MHS_RF_PLAIN": "1"},
+    for envs in ({"MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "sub"}, {"MHS_RF_KERNEL": "sub", "MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "db"}, {"MHS_RF_KERNEL": "db", "MHS_RF_PLAIN": "1"},
                  {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_KERNEL": "compact", "MHS_RF_PLAIN": "1"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():
             monkeypatch.setenv(e, v)
