@@ -55,6 +55,23 @@ def pmc_derived():
             continue
     return {}
 
+def forest_traffic(n_nodes, cells, layers):
+    """The forest's traffic past the L2 as the PMC passes measured it (FETCH_SIZE doubled + WRITE_SIZE, per cell, on cfg3's own
+    10 000 x 10 000 8d planes) against the algorithmic bytes (the covariate planes once, the plane written once, the forest once),
+    for the default kernel and for the subtree-staging kernel (MHS_RF_KERNEL=sub) -- round-4 verdict item 8: a first-class field."""
+    alg = 4.0 * layers + 8.0 + 8.0 * n_nodes / cells
+    out = {"algorithmic_bytes_per_cell": alg, "what": "float32 covariate planes read once + float64 plane written once + 8-byte node records once"}
+    for key, name in (("default_kernel", "r05_8d_members_pmc_derived.json"), ("subtree_kernel", "r05_8d_rfsub_members_pmc_derived.json")):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            k = next(k for k in d if isinstance(d[k], dict) and "rf_" in k)
+            b = d[k]["hbm_bytes_per_cell_fetch_x2_plus_write"]
+            out[key] = {"kernel": k, "measured_bytes_per_cell": b, "ratio_to_algorithmic": b / alg, "source": "profiles/" + name}
+        except (OSError, ValueError, StopIteration, KeyError):
+            out[key] = None
+    return out
+
+
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the north-star target is quoted on
     "cfg3": dict(stations=5000, side=10000, layers=3, gbm_trees=10000, rf_trees=500, ensemble=True,
@@ -1311,6 +1328,8 @@ def main():
             "tps_solve_flop_model": "4/3 (n-3)^3: Householder reduction of Q2'KQ2 to band form (GCV path), whole mhs_tps_fit call",
             "reference_tiled_tps_ms": tiled_ms, "reference_tiled_tps_tiles": [info.get("nRx"), info.get("nCx")],
             "tps_eval_check": eval_check,
+            "forest_traffic": (forest_traffic(int(next(p["tree_offsets"][-1] for p in wl.params if p["kind"] == "rf")), 1e8, cfg["layers"])
+                               if any(p["kind"] == "rf" for p in wl.params) else None),
             "f64_boundary": f64_boundary, "raster_sensitivity": raster_sensitivity, "model_check": model_check, "projected": projected,
             "tiled_mode_same_run": tiled_mode,
             "lambda": wl.last.get("lambda"), "rsq_model": wl.last["rsq_model"], "rsq_final": wl.last["rsq_final"],
