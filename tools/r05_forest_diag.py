@@ -25,6 +25,8 @@ def timed(env):
         return best * 1e3
     finally:
         for k in env: del os.environ[k]
-for label, env in (("sub", {}), ("sub, tv by readlane", {"MHS_RF_DIAG": "8"}), ("sub, no walks", {"MHS_RF_DIAG": "4"}), ("sub, no DMA no walks", {"MHS_RF_DIAG": "6"}),
-                   ("sub plain", {"MHS_RF_PLAIN": "1"}), ("ld", {"MHS_RF_KERNEL": "ld"})):
-    print(f"{label:24s} {timed(env):7.2f} ms on {side}^2", flush=True)
+SUB = {"MHS_RF_KERNEL": "sub"}
+for label, env in (("sub", dict(SUB)), ("sub, no level loops (wrong planes)", dict(SUB, MHS_RF_DIAG="4")),
+                   ("sub, no level loops, no staging (wrong planes)", dict(SUB, MHS_RF_DIAG="6")), ("sub plain (whole trees)", dict(SUB, MHS_RF_PLAIN="1")),
+                   ("ld (default)", {}), ("ld plain", {"MHS_RF_PLAIN": "1"})):
+    print(f"{label:48s} {timed(env):7.2f} ms on {side}^2", flush=True)

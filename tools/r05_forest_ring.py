@@ -39,7 +39,7 @@ for name, pl in variants:
     stack = m.RasterStack(g, pl, nodata)
     t_ring, p_ring = timed(stack, {})
     line = f"{name:18s} ld   {t_ring:7.1f} ms/1e8"
-    for label, env in (("sub", {"MHS_RF_KERNEL": "sub"}), ("db", {"MHS_RF_KERNEL": "db"}), ("ring plain", {"MHS_RF_PLAIN": "1"})):
+    for label, env in (("sub", {"MHS_RF_KERNEL": "sub"}), ("db", {"MHS_RF_KERNEL": "db"}), ("ld plain", {"MHS_RF_PLAIN": "1"})):
         t, pln = timed(stack, env)
         line += f" | {label} {t:7.1f} equal={bool(torch.equal(torch.nan_to_num(pln), torch.nan_to_num(p_ring)))}"
     print(line, flush=True)
