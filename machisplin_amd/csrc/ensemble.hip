@@ -2073,7 +2073,7 @@ __global__ __launch_bounds__(1024) void rf_walk_sub_kernel(const uint2 *__restri
             }
             const char *src = (const char *)(gnodes + __builtin_amdgcn_readlane(offv, u & 63)) + ((size_t)q0 << 10) + lane16;
             unsigned dst = (unsigned)(SLOT * STRIDE) + ((unsigned)q0 << 10);
-            if (!(flags & 2)) for (int i = 0; i < nq; ++i) { glds16(src, dst); src += 1024; dst += 1024u; }
+            for (int i = 0; i < nq; ++i) { glds16(src, dst); src += 1024; dst += 1024u; }
             if (mine) last = (unsigned)u + 1u;
             inflight += nq;
             if (inflight >= 40) publish(u + 1);
@@ -2112,7 +2112,7 @@ __global__ __launch_bounds__(1024) void rf_walk_sub_kernel(const uint2 *__restri
             ocur = tree_off[tl];
             const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
             const int plen = (int)((ecur >> 16) & 0x7FFFu);
-            const int levels = ((ecur >> 31) || (flags & 4)) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
+            const int levels = (ecur >> 31) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
             const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63
             wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
             // a tree the wave does not walk (its cells share the entry node) has ONE prediction for all of them: fetched here
@@ -3038,7 +3038,7 @@ static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom 
             MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
             hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
                                m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles,
-                               (int)(tiles && dmin) | (getenv("MHS_RF_DIAG") ? atoi(getenv("MHS_RF_DIAG")) & ~1 : 0), tt.axis_rank, tt.axis_ncol);
+                               (int)(tiles && dmin), tt.axis_rank, tt.axis_ncol);
             *launched = true;
             return MHS_OK;
         }

@@ -59,6 +59,5 @@ if [ "$PART" = all ] || [ "$PART" = fit ]; then
 fi
 if [ "$PART" = all ] || [ "$PART" = misc ]; then
   timeout 900 python tools/r05_forest_ring.py 8000 2>&1 | grep -v "^/opt" > $O/forest_kernels.txt; cat $O/forest_kernels.txt
-  timeout 600 python tools/r05_forest_diag.py 2>&1 | grep -v "^/opt" > $O/forest_sub_ablation.txt; cat $O/forest_sub_ablation.txt
   timeout 900 python tools/r03_host_abi.py 10000 0 1 2>&1 | grep -v "^/opt" > $O/host_abi.txt; cat $O/host_abi.txt
 fi
