@@ -1749,6 +1749,7 @@ struct ReductionEntry {
     double *Ared = nullptr, *Tall = nullptr, *aux = nullptr;   // device
     std::vector<double> ab;                                    // host: m x (BW + 1), or m x 33 on the 32-column route
     bool b32 = false;                                          // reduced by tps_band32.hip (round 4)
+    bool broke = false;                                        // NEGATIVE entry (no buffers): the 32-column route broke down on this station set
     size_t bytes = 0;                                          // device bytes held (the cache's budget counts them)
     uint64_t stamp = 0;                                        // last use (least recently used entries are evicted first)
     ~ReductionEntry() {
@@ -1975,7 +1976,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     const bool small_route = !fixed && m <= TRI_SMALL_CUT && m >= 3;
     // band route: cacheable while every panel is a register-resident one (band_qt_kernel mirrors that kernel's update of g)
     // (the register back-transform holds BT_THREADS * BT_RPT rows: a cached refit past that would read buffers it never wrote)
-    const bool band_cacheable = !fixed && !small_route && !use_b32 && npanels > 0 && m - BW <= PANEL_THREADS * PANEL_RPT && m <= BT_THREADS * BT_RPT;
+    auto cacheable_band = [&](bool b32) { return !fixed && !small_route && !b32 && npanels > 0 && m - BW <= PANEL_THREADS * PANEL_RPT && m <= BT_THREADS * BT_RPT; };
+    bool band_cacheable = cacheable_band(use_b32);
     std::shared_ptr<ReductionEntry> hit_sp;
     uint64_t rkey = 0;
     bool rcache_on = false;
@@ -1985,8 +1987,17 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         if (rcache_on) {
             rkey = fnv1a(sw.data(), sizeof(double) * sw.size(), fnv1a(uv.data(), sizeof(double) * uv.size(), 1469598103934665603ull ^ (uint64_t)n));
             auto range = g_rcache.map.equal_range(rkey);
+            // an earlier layer's 32-column reduction broke down on these stations (round-4 advisor finding: every further layer
+            // repeated the failing reduction, the matrix rebuild and an uncached legacy reduction): straight to the 8-column route
+            if (use_b32)
+                for (auto it = range.first; it != range.second; ++it)
+                    if (it->second->broke && it->second->n == n && it->second->uv == uv && it->second->sw == sw) {
+                        use_b32 = false;
+                        band_cacheable = cacheable_band(false);
+                        break;
+                    }
             for (auto it = range.first; it != range.second && !hit_sp; ++it)
-                if (it->second->n == n && it->second->band == band_cacheable && it->second->b32 == use_b32 && it->second->uv == uv && it->second->sw == sw) {
+                if (!it->second->broke && it->second->n == n && it->second->band == band_cacheable && it->second->b32 == use_b32 && it->second->uv == uv && it->second->sw == sw) {
                     hit_sp = it->second;
                     hit_sp->stamp = ++g_rcache.clock;
                 }
@@ -2173,6 +2184,12 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
         } else {
             // a panel was numerically rank deficient: the matrix is rebuilt and the 8-column Householder route takes the fit
             use_b32 = false;
+            band_cacheable = cacheable_band(false);      // the legacy reduction of this fit is kept for the other layers (if it fits) ...
+            if (rcache_on) {                              // ... and they are told not to try the 32-column route again
+                auto e = std::make_shared<ReductionEntry>();
+                e->n = n; e->m = m; e->uv = uv; e->sw = sw; e->broke = true; e->bytes = 0;
+                rcache_insert(rkey, e);
+            }
             if (int rc = build_A()) return rc;
             lap("32-column route handed the fit back: matrix rebuilt");
         }

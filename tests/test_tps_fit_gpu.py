@@ -158,14 +158,17 @@ def test_reduction_cache_refits_are_bit_identical(hip, n):
     assert np.array_equal(again.c, full[2].c)
 
 
-@pytest.mark.parametrize("n", [700, 2211, 4100])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [700, 2211, 4100, 5200])
 def test_reduction_cache_band_route_refits_are_bit_identical(hip, n):
     """The same for fits beyond the small route (round 3): the band reduction of Q2'KQ2 -- reduced matrix with its
     reflectors, the panels' T factors and (tau, G) records, the band, the projected rows -- is kept, and another response
     layer on the same stations (V73:203: machisplin.mltps loops over the layers of ONE station table) sends only its
     right-hand side through band_qt_kernel, which repeats every panel's update of g exactly: lambda, GCV, effective
     degrees of freedom, c and d equal the full fit's bit for bit.  n = 700: one to two waves per panel; 2 211: the 1-4
-    wave forms and the 8-wave form; 4 100: the delayed scheme's first panels as well."""
+    wave forms and the 8-wave form; 4 100: the delayed scheme's first panels as well.  (Since round 4 these sizes take the
+    32-column route and its band32_qt replay; 5 200: panels taller than 4 096 rows -- a second batch of split-K partial sums,
+    several chunks per row block -- which only the benchmarks reached before: round-4 advisor finding.)"""
     import time
     from machisplin_amd import tps
     rng = np.random.default_rng(n)
@@ -183,3 +186,36 @@ def test_reduction_cache_band_route_refits_are_bit_identical(hip, n):
         assert np.array_equal(a.c, b.c) and np.array_equal(a.d, b.d)
     assert np.array_equal(fixed.c, hip.Tps(xy, ys[1], lambda_=1e-3).c)
     print("n = %d: first fit (builds the entry) %.1f ms, later layers %.1f ms each" % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3 / 3))
+
+
+@pytest.mark.timeout(600)
+def test_breakdown_of_the_32_column_route_falls_back_and_is_remembered(hip, monkeypatch, capfd):
+    """Stations in near-coincident pairs (1e-9 of the range apart: distinct cells for the replicate collapse, identical rows
+    for the Gram matrix) make a panel of the 32-column Cholesky-QR numerically rank deficient: the fit must hand itself back to
+    the 8-column Householder route -- same lambda and coefficients as MHS_FIT_LEGACY_BAND=1 gives, bit for bit (it IS that
+    route, on a rebuilt matrix) -- and, inside a reduction-cache scope, remember the verdict: the other response layers go
+    straight to the 8-column route (round-4 advisor finding: they repeated the failing reduction), with the fresh fits' bits."""
+    from machisplin_amd import tps
+    rng = np.random.default_rng(77)
+    base = rng.uniform(0, 1, (330, 2))
+    xy = np.vstack([base, base + 1e-9 * rng.standard_normal(base.shape)])
+    ys = [np.sin(6 * xy[:, 0]) * np.cos(5 * xy[:, 1]) + 0.1 * rng.standard_normal(len(xy)) + k * xy[:, 1] for k in range(2)]
+    monkeypatch.setenv("MHS_TIMING", "1")
+    capfd.readouterr()
+    got = hip.Tps(xy, ys[0])
+    err = capfd.readouterr().err
+    assert "handed the fit back" in err, "the station set did not break the 32-column route: the test exercises nothing"
+    with tps.reduction_cache():
+        first = hip.Tps(xy, ys[0])
+        capfd.readouterr()
+        second = hip.Tps(xy, ys[1])
+        err2 = capfd.readouterr().err
+    assert "handed the fit back" not in err2 and "32-column" not in err2      # no second attempt
+    monkeypatch.delenv("MHS_TIMING")
+    monkeypatch.setenv("MHS_FIT_LEGACY_BAND", "1")
+    legacy = [hip.Tps(xy, y) for y in ys]
+    monkeypatch.delenv("MHS_FIT_LEGACY_BAND")
+    for a, b in ((got, legacy[0]), (first, legacy[0]), (second, legacy[1])):
+        assert a.lambda_ == b.lambda_ and np.array_equal(a.c, b.c) and np.array_equal(a.d, b.d)
+    ref = otps.fit(xy, ys[0], lam=got.lambda_)
+    assert _rel(got.d, ref["d"]) < 1e-6
