@@ -398,6 +398,10 @@ typedef struct mhs_multi_stack mhs_multi_stack;
 MHS_API int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share,
                                    mhs_multi_stack **out);
 MHS_API int mhs_multi_stack_free(mhs_multi_stack *ms);
+/* host only: the bands mhs_multi_stack_create cuts (r0 / r1: n_slots entries).  Every cut is a multiple of 16 rows; chunks of
+ * `band` rows, slot 0's rows parked `lead` rows into its chunk, tile the grid (the in-place all-gather's layout).          */
+MHS_API int mhs_plan_row_bands(int64_t nrow, int n_slots, double slot0_share, int64_t *r0, int64_t *r1, int64_t *band,
+                               int64_t *lead);
 MHS_API int mhs_multi_stack_bands(const mhs_multi_stack *ms, int *n_slots, int64_t *r0 /* 16 */, int64_t *r1 /* 16 */);
 
 typedef struct mhs_mltps_info {

@@ -100,7 +100,8 @@ void rccl_prepare() {
     const int n = slot_count();
     if (g_rccl.tried && g_rccl.n == n) return;
     g_rccl.tried = true; g_rccl.usable = false; g_rccl.n = n;
-    if (n < 2) { g_rccl.why = "one slot"; return; }
+    // (one slot: the all-gather of one rank is a copy onto itself -- still taken through RCCL, so that the binding, the
+    // communicator and the call are exercised on a one-GPU box too)
     if (!slots_distinct()) { g_rccl.why = "slots share a physical device (RCCL needs one device per rank): peer copies instead"; return; }
     if (getenv("MHS_MULTI_NO_RCCL")) { g_rccl.why = "MHS_MULTI_NO_RCCL is set: peer copies instead"; return; }
     if (!g_rccl.h) {
@@ -339,6 +340,16 @@ int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, doub
 }
 
 int mhs_multi_stack_free(mhs_multi_stack *ms) { return free_stack(ms); }
+
+// host only (no GPU needed): the row bands mhs_multi_stack_create cuts for n slots
+int mhs_plan_row_bands(int64_t nrow, int n_slots, double slot0_share, int64_t *r0, int64_t *r1, int64_t *band, int64_t *lead) {
+    MHS_REQUIRE(nrow > 0 && n_slots >= 1 && n_slots <= MAX_SLOTS && r0 && r1, "bad arguments");
+    const BandPlan p = plan_bands(nrow, n_slots, slot0_share);
+    for (int k = 0; k < n_slots; ++k) { r0[k] = p.r0[(size_t)k]; r1[k] = p.r1[(size_t)k]; }
+    if (band) *band = p.band;
+    if (lead) *lead = p.lead;
+    return MHS_OK;
+}
 
 int mhs_multi_stack_bands(const mhs_multi_stack *ms, int *n_slots, int64_t *r0, int64_t *r1) {
     MHS_REQUIRE(ms && n_slots, "NULL argument");

@@ -43,6 +43,16 @@ def device_slots():
     return [int(ids[k]) for k in range(n.value)]
 
 
+def plan_row_bands(nrow: int, n_slots: int, slot0_share: float | None = None):
+    """The row bands mhs_multi_stack_create cuts (host only, no GPU): ([(r0, r1)] per slot, band, lead)."""
+    r0 = np.zeros(n_slots, dtype=np.int64)
+    r1 = np.zeros(n_slots, dtype=np.int64)
+    band, lead = C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().mhs_plan_row_bands(int(nrow), int(n_slots), float("nan") if slot0_share is None else float(slot0_share),
+                                              r0.ctypes.data, r1.ctypes.data, C.byref(band), C.byref(lead)))
+    return [(int(a), int(b)) for a, b in zip(r0, r1)], band.value, lead.value
+
+
 def _host_stack(planes, nodata):
     planes = np.ascontiguousarray(planes)
     if planes.ndim != 3 or planes.dtype not in _DT:
