@@ -1095,6 +1095,19 @@ def main_in_library(args):
         one = wl.last["final"].cpu().numpy()
         line["equals_one_device_plane"] = bool(np.array_equal(ms.download(), one, equal_nan=True))
         ms.free()
+        # what the R shim's ONE call costs with PCIe inside it (mhs_mltps_grid_multi: host planes in, host plane out): the band
+        # of every slot travels in sub-bands under its own first kernels; never `value`
+        hc = []
+        got = np.empty((g.nrow, g.ncol))          # the caller's plane, reused: a fresh 800 MB numpy array per call costs ~30 ms to unmap
+        for rep in range(4):
+            got.fill(0.0)
+            t0 = time.perf_counter()
+            _, hinfo = multi.mltps_grid_multi(g, host, wl.stack.nodata, wl.models, wl.weights, wl.wt_total, wl.X, wl.resp,
+                                              tile_edge=tile_edge, slot0_share=None if share != share else share, out=got)
+            hc.append((time.perf_counter() - t0) * 1e3)
+        driver["host_call"] = {"ms": min(hc), "calls_ms": hc, "copies_issued_ms": hinfo["upload_ms"], "download_ms": hinfo["download_ms"],
+                               "step_ms": hinfo["step_ms"], "planes": "%d x %s up, 1 x float64 down" % (cfg["layers"], host.dtype),
+                               "equals_one_device_plane": bool(np.array_equal(got, one, equal_nan=True))}
     line["in_library"] = driver
     print(json.dumps(line), flush=True)
     if dist is not None:

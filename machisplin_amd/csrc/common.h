@@ -157,6 +157,9 @@ namespace mhs {
 // ensemble.hip: the handle's twin on device slot `slot` (built on first use; owned by the handle)
 int model_on_slot(const mhs_model *m, int slot, const mhs_model **out);
 // ensemble.hip: pred.elev on grid rows [b0, b1) from a device buffer holding only those rows of every plane
+int members_rows_dev(const mhs_model *const *models, const double *weights, int n_models, int accumulate, int scale, double wt_total,
+                     const mhs_grid *g, const void *buf, int64_t buf_r0, int64_t buf_r1, int n_layers, int dtype, int64_t ld,
+                     double nodata, int64_t b0, int64_t b1, double *out_dev, int64_t ld_out, hipStream_t st);
 int ensemble_band_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
                       const void *band_data, int n_layers, int dtype, int64_t ld, double nodata, int64_t b0, int64_t b1,
                       double *out_dev, int64_t ld_out, hipStream_t st);

@@ -3265,15 +3265,18 @@ static int make_geom(const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int6
     return MHS_OK;
 }
 
-// pred.elev on rows [b0, b1) of the grid from a device buffer that holds ONLY those rows of every covariate plane (plane k
-// at band_data + k * (b1 - b0) * ld elements): the device copy is described with the PARENT grid's affine, so cell centres --
-// and with them every member's value -- are those of the one-piece evaluation (multi.hip: one row band per device).
-int ensemble_band_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
-                      const void *band_data, int n_layers, int dtype, int64_t ld, double nodata, int64_t b0, int64_t b1,
-                      double *out_dev, int64_t ld_out, hipStream_t st) {
-    MHS_REQUIRE(models && weights && n_models >= 1 && g && band_data && out_dev, "bad ensemble arguments");
+// Members k of `models` on rows [b0, b1) of the grid from a device buffer that holds rows [buf_r0, buf_r1) of every covariate
+// plane (plane k at buf + k * (buf_r1 - buf_r0) * ld elements): the device copy is described with the PARENT grid's affine,
+// so cell centres -- and with them every member's value -- are those of the one-piece evaluation (multi.hip: one row band
+// per device, evaluated in sub-bands while the rest of the band still travels).  `accumulate`: add to out_dev instead of
+// starting it; `scale`: divide by wt_total afterwards (the last members of a cell).  out_dev = row b0's first cell.
+int members_rows_dev(const mhs_model *const *models, const double *weights, int n_models, int accumulate, int scale, double wt_total,
+                     const mhs_grid *g, const void *buf, int64_t buf_r0, int64_t buf_r1, int n_layers, int dtype, int64_t ld,
+                     double nodata, int64_t b0, int64_t b1, double *out_dev, int64_t ld_out, hipStream_t st) {
+    MHS_REQUIRE(models && weights && n_models >= 0 && g && buf && out_dev, "bad ensemble arguments");
     MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
     MHS_REQUIRE(dtype == MHS_F64 || dtype == MHS_F32 || dtype == MHS_I16, "bad stack dtype");
+    MHS_REQUIRE(buf_r0 <= b0 && b0 <= b1 && b1 <= buf_r1, "rows outside the buffer");
     for (int k = 0; k < n_models; ++k)
         MHS_REQUIRE(models[k] && n_layers == models[k]->p - 2, "stack has the wrong number of layers for a model");
     if (b1 == b0) return MHS_OK;
@@ -3281,15 +3284,26 @@ int ensemble_band_dev(const mhs_model *const *models, const double *weights, int
     PredGeom pg;
     if (int rc = make_geom(g, b0, b1, 0, g->ncol, ld_out, &pg)) return rc;
     StackDev sd;
-    sd.data = (const char *)band_data - (size_t)b0 * ld * esz; sd.C = n_layers; sd.dtype = dtype;
-    sd.plane_stride = (b1 - b0) * ld; sd.ld = ld; sd.nodata = nodata;
+    sd.data = (const char *)buf - (size_t)buf_r0 * ld * esz; sd.C = n_layers; sd.dtype = dtype;
+    sd.plane_stride = (buf_r1 - buf_r0) * ld; sd.ld = ld; sd.nodata = nodata;
     sd.has_nodata = !std::isnan(nodata); sd.all_from_planes = 0;
-    if (int rc = launch_members(models, weights, n_models, sd, pg, 0, out_dev, st, g)) return rc;
-    const int64_t total = (b1 - b0) * g->ncol;
-    hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out_dev, (int)(b1 - b0),
-                       (int)g->ncol, ld_out, wt_total);
-    MHS_HIP(hipGetLastError());
+    if (n_models > 0) if (int rc = launch_members(models, weights, n_models, sd, pg, accumulate, out_dev, st, g)) return rc;
+    if (scale) {
+        const int64_t total = (b1 - b0) * g->ncol;
+        hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out_dev, (int)(b1 - b0),
+                           (int)g->ncol, ld_out, wt_total);
+        MHS_HIP(hipGetLastError());
+    }
     return MHS_OK;
+}
+
+// pred.elev on rows [b0, b1) from a buffer that holds exactly those rows
+int ensemble_band_dev(const mhs_model *const *models, const double *weights, int n_models, double wt_total, const mhs_grid *g,
+                      const void *band_data, int n_layers, int dtype, int64_t ld, double nodata, int64_t b0, int64_t b1,
+                      double *out_dev, int64_t ld_out, hipStream_t st) {
+    MHS_REQUIRE(n_models >= 1, "bad ensemble arguments");
+    return members_rows_dev(models, weights, n_models, 0, 1, wt_total, g, band_data, b0, b1, n_layers, dtype, ld, nodata, b0, b1, out_dev,
+                            ld_out, st);
 }
 
 // The handle's twin on another device slot, built on first use from the remembered loader call.

@@ -50,6 +50,8 @@ double now_ms() {
 struct MultiSlot {
     hipStream_t s = nullptr;                 // the band work of this slot (non-blocking)
     hipEvent_t e0 = nullptr, e1 = nullptr;   // timing of the band kernels
+    hipStream_t u = nullptr;                 // host -> device copies of a band that is still travelling (mhs_mltps_grid_multi)
+    hipEvent_t up[4] = {}, dn[4] = {};       // ... one per sub-band up, one per finished sub-band down
 };
 MultiSlot g_ms[MAX_SLOTS];
 std::mutex g_ms_mu;
@@ -61,6 +63,9 @@ int multi_slot(int slot, MultiSlot **out) {   // call with the thread bound to `
         MHS_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
         MHS_HIP(hipEventCreate(&m.e0));
         MHS_HIP(hipEventCreate(&m.e1));
+        MHS_HIP(hipStreamCreateWithFlags(&m.u, hipStreamNonBlocking));
+        for (hipEvent_t &e : m.up) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : m.dn) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     *out = &m;
     return MHS_OK;
@@ -250,6 +255,13 @@ struct mhs_multi_stack {
     int used_tps = 0;             // which plane holds the last step's final: 1 = tot, 0 = ens
     bool gathered = false;
     bool have_result = false;
+    // mhs_mltps_grid_multi: the caller's planes have NOT been uploaded yet -- the next step brings each band in sub-bands
+    // under its own first member kernels
+    const mhs_stack *pending = nullptr;
+    double *pending_out = nullptr;   // ... and, for the global Step 3, sends every finished sub-band down to this plane
+    bool downloaded = false;
+    double upload_ms = 0;         // how long the slowest slot's helper thread spent in the copies up
+    double download_ms = 0;       // what was left of the copies down when the slowest slot's last sub-band was final
 };
 
 namespace {
@@ -260,6 +272,10 @@ size_t elem_size(int dtype) { return dtype == MHS_F64 ? 8 : dtype == MHS_F32 ? 4
 struct Balance { int n = 0; int64_t nrow = 0, ncol = 0, stations = 0; double share = NAN; };
 Balance g_balance;
 std::mutex g_balance_mu;
+
+// mhs_mltps_grid_multi's device buffers, kept between calls of the same shape (no hipMalloc / hipFree of gigabytes per layer)
+mhs_multi_stack *g_host_ms = nullptr;
+std::mutex g_host_mu;
 
 int free_stack(mhs_multi_stack *ms) {
     if (!ms) return MHS_OK;
@@ -279,6 +295,11 @@ int free_stack(mhs_multi_stack *ms) {
 }  // namespace
 
 void mhs::multi_reset() {
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        if (g_host_ms) { bool alive = true; for (int k = 0; k < g_host_ms->n; ++k) alive = alive && ctx_slot(k).ready; if (alive) free_stack(g_host_ms); else delete g_host_ms; }
+        g_host_ms = nullptr;
+    }
     rccl_reset();
     std::lock_guard<std::mutex> lk(g_ms_mu);
     for (int k = 0; k < MAX_SLOTS; ++k) {
@@ -288,6 +309,9 @@ void mhs::multi_reset() {
             SlotBind bind(k);
             (void)hipStreamSynchronize(m.s); (void)hipStreamDestroy(m.s);
             (void)hipEventDestroy(m.e0); (void)hipEventDestroy(m.e1);
+            if (m.u) { (void)hipStreamSynchronize(m.u); (void)hipStreamDestroy(m.u); }
+            for (hipEvent_t e : m.up) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : m.dn) if (e) (void)hipEventDestroy(e);
         }
         m = MultiSlot();
     }
@@ -295,7 +319,7 @@ void mhs::multi_reset() {
 
 extern "C" {
 
-int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share, mhs_multi_stack **out) {
+static int stack_build(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share, bool upload, mhs_multi_stack **out) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(g && covars_host && covars_host->data && out, "NULL argument");
     MHS_REQUIRE(g->nrow > 0 && g->ncol > 0 && g->xres > 0 && g->yres > 0, "bad grid geometry");
@@ -321,6 +345,7 @@ int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, doub
             MHS_HIP(hipMalloc((void **)&b.cov, plane * (size_t)ms->C));
             MHS_HIP(hipMalloc((void **)&b.ens, sizeof(double) * (size_t)nb * (size_t)g->ncol));
             MHS_HIP(hipMalloc((void **)&b.tot, sizeof(double) * (size_t)nb * (size_t)g->ncol));
+            if (!upload) return MHS_OK;
             for (int k = 0; k < ms->C; ++k) {
                 const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)b.r0 * covars_host->ld) * esz;
                 if (covars_host->ld == g->ncol)
@@ -337,6 +362,10 @@ int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, doub
     if (rc) { free_stack(ms); return rc; }
     *out = ms;
     return MHS_OK;
+}
+
+int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share, mhs_multi_stack **out) {
+    return stack_build(g, covars_host, slot0_share, true, out);
 }
 
 int mhs_multi_stack_free(mhs_multi_stack *ms) { return free_stack(ms); }
@@ -380,6 +409,48 @@ std::vector<int> assign_tiles(const std::vector<double> &cost, int n) {
     return owner;
 }
 
+// rows [r0, r1) in four sub-bands of 4, 16, 40, 40 % (copies up: the short ones first) or 40, 40, 16, 4 % (copies down: the
+// short ones last), cut at whole 16-row tiles of the grid
+void sub_bands(int64_t r0, int64_t r1, bool down, int64_t cut[5]) {
+    const int pct[4] = {4, 16, 40, 40};
+    const int64_t nb = r1 - r0;
+    cut[0] = r0;
+    for (int q = 0, a = 0; q < 4; ++q) {
+        a += pct[down ? 3 - q : q];
+        cut[q + 1] = q == 3 ? r1 : std::min(r1, std::max(cut[q], (r0 + nb * a / 100 + BAND_ROWS_ALIGN / 2) / BAND_ROWS_ALIGN * BAND_ROWS_ALIGN));
+    }
+}
+
+// the helper thread that sits in a slot's copies from pageable memory while the slot's own thread launches kernels
+struct Uploader {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int issued = 0, rc = MHS_OK;
+    std::string err;
+    template <typename F>
+    void start(int slot, F issue) {
+        th = std::thread([this, slot, issue] {
+            SlotBind bind(slot);
+            for (int q = 0; q < 4; ++q) {
+                const int r = issue(q);
+                std::lock_guard<std::mutex> lk(mu);
+                if (r) { rc = r; err = mhs_last_error(); issued = 4; } else issued = q + 1;
+                cv.notify_all();
+                if (r) break;
+            }
+        });
+    }
+    int wait(int q) {                          // sub-band q's copies are in the stream and its event is recorded
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return issued > q; });
+        if (rc) set_error("%s", err.c_str());
+        return rc;
+    }
+    void join() { if (th.joinable()) th.join(); }
+    ~Uploader() { join(); }
+};
+
 struct StepShared {
     // Step 2 at the stations / Step 3's fit, produced by slot 0
     std::vector<double> resid;
@@ -397,7 +468,7 @@ struct StepShared {
     std::vector<double> f_actual;
     int used_tps = 0;
     double rsq_final = NAN;
-    double fit_ms = 0, band_ms[MAX_SLOTS] = {}, tiles_ms[MAX_SLOTS] = {};
+    double fit_ms = 0, band_ms[MAX_SLOTS] = {}, tiles_ms[MAX_SLOTS] = {}, upload_ms[MAX_SLOTS] = {}, download_ms[MAX_SLOTS] = {};
 };
 
 }  // namespace
@@ -466,39 +537,93 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         // this slot's twins of the fitted members
         for (int k = 0; k < n_models; ++k) TEAM_DO(team, model_on_slot(models[k], slot, &mods[(size_t)slot * n_models + k]));
         const mhs_model *const *my = &mods[(size_t)slot * n_models];
+        // ---- slot 0: res.FINAL at the stations (V73:477-620) and, for the global Step 3, the fit (V73:751)
+        auto fit = [&]() -> int {
+            S.resid.resize((size_t)n);
+            if (int rc2 = mhs_residual_points(my, weights, n_models, wt_total, X, resp, n, S.resid.data())) return rc2;
+            // R's sum() and mean() accumulate in long double (V73:912-917 run in R): so do these
+            long double msum = 0.0L, ss = 0.0L, rs = 0.0L;
+            for (int64_t i = 0; i < n; ++i) msum += resp[i];
+            const double mean = (double)(msum / (long double)n);
+            for (int64_t i = 0; i < n; ++i) { ss += (long double)((resp[i] - mean) * (resp[i] - mean)); rs += (long double)(S.resid[(size_t)i] * S.resid[(size_t)i]); }
+            S.tss = (double)ss; S.rsq_model = 1.0 - (double)rs / (double)ss;
+            if (tiled) return MHS_OK;
+            const double t0 = now_ms();
+            mhs_tps *t = nullptr;
+            if (int rc2 = mhs_tps_fit(knots, S.resid.data(), n, lambda, gcv_mode, &t)) return rc2;
+            S.fit_ms = now_ms() - t0;
+            tps[0] = t;
+            if (int rc2 = mhs_tps_size(t, &S.nk)) return rc2;
+            S.c.resize((size_t)S.nk); S.knots_uv.resize((size_t)S.nk * 2);
+            return mhs_tps_get(t, S.c.data(), S.d, S.knots_uv.data(), &S.lambda, S.center, S.scale, nullptr, nullptr);
+        };
         // ---- Step 2 on the band (V73:447-619): enqueued, not waited for
-        if (nb > 0 && !team.failed()) {
+        // Host planes (ms->pending): the band still lies in the caller's memory.  It travels in sub-bands of 4, 16, 40, 40 % of
+        // its rows (cut at whole 16-row tiles), issued by a helper thread -- a copy from pageable memory blocks its caller until
+        // staged --; every member but the last runs on a sub-band as soon as it has arrived: the exposed upload is the 4 %.
+        // Slot 0 fits the spline EARLY, behind the two short sub-bands only; with the coefficients there before the last member
+        // starts, that member runs on sub-bands of 40, 40, 16, 4 % and each finished sub-band --
+        // scaled, final.TPS added -- goes down to the caller's plane under the next one (`piped`): the exposed download is the
+        // 4 %.  The plane that travels is pred.elev + final.TPS; should Step 5 keep pred.elev alone (V73:917-930) it is sent
+        // afterwards.  Same cells, same members in the same order, same sums: same bits as the one-piece evaluation.
+        const bool piped = ms->pending && ms->pending_out && !tiled;
+        const int banded = n_models > 1 ? n_models - 1 : 1;
+        Uploader up;
+        if (ms->pending && nb > 0 && !team.failed()) {
+            const mhs_stack *h = ms->pending;
+            const size_t esz = elem_size(ms->dtype), plane = (size_t)nb * (size_t)ms->ld * esz;
+            int64_t cut[5];
+            sub_bands(b.r0, b.r1, false, cut);
+            const double t0 = now_ms();
+            up.start(slot, [=, &S](int q) -> int {
+                const int64_t nq = cut[q + 1] - cut[q];
+                for (int k = 0; k < ms->C && nq > 0; ++k) {
+                    const char *src = (const char *)h->data + ((size_t)k * h->plane_stride + (size_t)cut[q] * h->ld) * esz;
+                    char *dst = b.cov + plane * k + (size_t)(cut[q] - b.r0) * (size_t)ms->ld * esz;
+                    if (h->ld == g.ncol)
+                        MHS_HIP(hipMemcpyAsync(dst, src, (size_t)nq * (size_t)ms->ld * esz, hipMemcpyHostToDevice, M->u));
+                    else
+                        MHS_HIP(hipMemcpy2DAsync(dst, (size_t)ms->ld * esz, src, (size_t)h->ld * esz, (size_t)g.ncol * esz, (size_t)nq,
+                                                 hipMemcpyHostToDevice, M->u));
+                }
+                MHS_HIP(hipEventRecord(M->up[q], M->u));
+                if (q == 3) S.upload_ms[slot] = now_ms() - t0;
+                return MHS_OK;
+            });
             auto launch = [&]() -> int {
                 MHS_HIP(hipEventRecord(M->e0, M->s));
-                if (int rc2 = ensemble_band_dev(my, weights, n_models, wt_total, &g, b.cov, ms->C, ms->dtype, ms->ld, ms->nodata, b.r0, b.r1,
-                                                b.ens, g.ncol, M->s)) return rc2;
-                MHS_HIP(hipEventRecord(M->e1, M->s));
+                for (int q = 0; q < 4; ++q) {
+                    // the fit goes in once the two short sub-bands are queued: the device has their kernels to run in the
+                    // fit's thin stages, and nothing after them that could hold the fit up
+                    if (q == 2 && slot == 0) if (int rc2 = fit()) return rc2;
+                    if (int rc2 = up.wait(q)) return rc2;
+                    MHS_HIP(hipStreamWaitEvent(M->s, M->up[q], 0));
+                    if (int rc2 = members_rows_dev(my, weights, banded, 0, 0, wt_total, &g, b.cov, b.r0, b.r1, ms->C, ms->dtype, ms->ld, ms->nodata,
+                                                   cut[q], cut[q + 1], b.ens + (size_t)(cut[q] - b.r0) * (size_t)g.ncol, g.ncol, M->s)) return rc2;
+                }
+                if (!piped) {
+                    if (int rc2 = members_rows_dev(my + banded, weights + banded, n_models - banded, 1, 1, wt_total, &g, b.cov, b.r0, b.r1,
+                                                   ms->C, ms->dtype, ms->ld, ms->nodata, b.r0, b.r1, b.ens, g.ncol, M->s)) return rc2;
+                    MHS_HIP(hipEventRecord(M->e1, M->s));
+                }
                 return MHS_OK;
             };
             TEAM_DO(team, launch());
-        }
-        // ---- slot 0: res.FINAL at the stations (V73:477-620) and, for the global Step 3, the fit (V73:751)
-        if (slot == 0 && !team.failed()) {
-            auto fit = [&]() -> int {
-                S.resid.resize((size_t)n);
-                if (int rc2 = mhs_residual_points(my, weights, n_models, wt_total, X, resp, n, S.resid.data())) return rc2;
-                // R's sum() and mean() accumulate in long double (V73:912-917 run in R): so do these
-                long double msum = 0.0L, ss = 0.0L, rs = 0.0L;
-                for (int64_t i = 0; i < n; ++i) msum += resp[i];
-                const double mean = (double)(msum / (long double)n);
-                for (int64_t i = 0; i < n; ++i) { ss += (long double)((resp[i] - mean) * (resp[i] - mean)); rs += (long double)(S.resid[(size_t)i] * S.resid[(size_t)i]); }
-                S.tss = (double)ss; S.rsq_model = 1.0 - (double)rs / (double)ss;
-                if (tiled) return MHS_OK;
-                const double t0 = now_ms();
-                mhs_tps *t = nullptr;
-                if (int rc2 = mhs_tps_fit(knots, S.resid.data(), n, lambda, gcv_mode, &t)) return rc2;
-                S.fit_ms = now_ms() - t0;
-                tps[0] = t;
-                if (int rc2 = mhs_tps_size(t, &S.nk)) return rc2;
-                S.c.resize((size_t)S.nk); S.knots_uv.resize((size_t)S.nk * 2);
-                return mhs_tps_get(t, S.c.data(), S.d, S.knots_uv.data(), &S.lambda, S.center, S.scale, nullptr, nullptr);
-            };
-            TEAM_DO(team, fit());
+            up.join();
+            // the caller's planes may be released once the entry point returns: no copy may still be reading them
+            if (team.failed()) (void)hipStreamSynchronize(M->u);
+        } else {
+            if (nb > 0 && !team.failed()) {
+                auto launch = [&]() -> int {
+                    MHS_HIP(hipEventRecord(M->e0, M->s));
+                    if (int rc2 = ensemble_band_dev(my, weights, n_models, wt_total, &g, b.cov, ms->C, ms->dtype, ms->ld, ms->nodata, b.r0, b.r1,
+                                                    b.ens, g.ncol, M->s)) return rc2;
+                    MHS_HIP(hipEventRecord(M->e1, M->s));
+                    return MHS_OK;
+                };
+                TEAM_DO(team, launch());
+            }
+            if (slot == 0) TEAM_DO(team, fit());
         }
         team.bar.wait();                                               // residuals (and the global fit) are there
         if (!tiled) {
@@ -507,6 +632,36 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                 TEAM_DO(team, mhs_tps_from_coef(S.knots_uv.data(), S.c.data(), S.d, S.nk, S.lambda, S.center, S.scale, &tps[(size_t)slot]));
             if (nb > 0)
                 TEAM_DO(team, tps_predict_rows_dev(tps[(size_t)slot], &g, 0, g.nrow, 0, g.ncol, b.r0, b.r1, b.tot, g.ncol, M->s));
+            if (piped && nb > 0) {
+                auto down = [&]() -> int {
+                    int64_t cut[5];
+                    sub_bands(b.r0, b.r1, true, cut);
+                    for (int q = 0; q < 4; ++q) {
+                        const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
+                        if (cut[q + 1] > cut[q]) {
+                            if (int rc2 = members_rows_dev(my + banded, weights + banded, n_models - banded, 1, 1, wt_total, &g, b.cov, b.r0, b.r1, ms->C,
+                                                           ms->dtype, ms->ld, ms->nodata, cut[q], cut[q + 1], b.ens + off, g.ncol, M->s)) return rc2;
+                            if (int rc2 = mhs_scale_add_dev(b.ens + off, 1.0, b.tot + off, b.tot + off, (cut[q + 1] - cut[q]) * g.ncol, M->s)) return rc2;
+                        }
+                        MHS_HIP(hipEventRecord(M->dn[q], M->s));
+                    }
+                    MHS_HIP(hipEventRecord(M->e1, M->s));
+                    const double t0 = now_ms();
+                    for (int q = 0; q < 4; ++q) {
+                        if (cut[q + 1] == cut[q]) continue;
+                        const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
+                        MHS_HIP(hipStreamWaitEvent(M->u, M->dn[q], 0));
+                        if (q == 3) S.download_ms[slot] = -now_ms();      // what is left once the last sub-band is final
+                        MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol + off, b.tot + off,
+                                               sizeof(double) * (size_t)(cut[q + 1] - cut[q]) * (size_t)g.ncol, hipMemcpyDeviceToHost, M->u));
+                    }
+                    MHS_HIP(hipStreamSynchronize(M->u));
+                    S.download_ms[slot] = S.download_ms[slot] < 0 ? S.download_ms[slot] + now_ms() : now_ms() - t0;
+                    return MHS_OK;
+                };
+                const int rcd = team.failed() ? MHS_OK : down();
+                if (rcd) { (void)hipStreamSynchronize(M->u); team.fail(rcd); }
+            }
         } else {
             // ---- Step 3 the way the reference computes it above 1500 px (V73:636-747): this slot's tiles, then every tile
             // from its owner (peer copies), mosaic + feather on the whole grid, this slot's rows of it
@@ -550,7 +705,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         // ---- Step 5 on the band (V73:906-917): sum, the stations' cells
         if (nb > 0 && !team.failed()) {
             auto step5 = [&]() -> int {
-                if (int rc2 = mhs_scale_add_dev(b.ens, 1.0, b.tot, b.tot, nb * g.ncol, M->s)) return rc2;
+                if (!piped) if (int rc2 = mhs_scale_add_dev(b.ens, 1.0, b.tot, b.tot, nb * g.ncol, M->s)) return rc2;
                 std::vector<int64_t> rr, cc, idx;
                 for (int64_t i = 0; i < n; ++i)
                     if (rows[(size_t)i] >= b.r0 && rows[(size_t)i] < b.r1 && cols[(size_t)i] >= 0) {
@@ -571,6 +726,14 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             S.used_tps = S.rsq_final > S.rsq_model ? 1 : 0;
         }
         team.bar.wait();
+        if (piped && nb > 0 && !team.failed() && !S.used_tps) {
+            auto resend = [&]() -> int {
+                MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol, b.ens, sizeof(double) * (size_t)nb * (size_t)g.ncol,
+                                       hipMemcpyDeviceToHost, M->s));
+                return MHS_OK;
+            };
+            TEAM_DO(team, resend());
+        }
         // ---- the one collective: stitch the final plane on every device.  (Every thread reads failed() right after the
         // barrier above and nothing runs in between, so all of them take the same branch -- a collective must not be entered
         // by some ranks only.)
@@ -617,6 +780,12 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         team.bar.wait();                                               // pushes have landed everywhere
         if (tps[(size_t)slot]) { (void)mhs_tps_free(tps[(size_t)slot]); tps[(size_t)slot] = nullptr; }
     });
+    if (ms->pending) {
+        ms->downloaded = !rc && ms->pending_out && !tiled;
+        ms->pending = nullptr; ms->pending_out = nullptr;
+        ms->upload_ms = ms->download_ms = 0;
+        for (int k = 0; k < N; ++k) { ms->upload_ms = std::max(ms->upload_ms, S.upload_ms[k]); ms->download_ms = std::max(ms->download_ms, S.download_ms[k]); }
+    }
     if (rc) return rc;
     ms->used_tps = S.used_tps;
     ms->gathered = gather != 0;
@@ -697,15 +866,35 @@ int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, 
         std::lock_guard<std::mutex> lk(g_balance_mu);
         if (g_balance.n == slot_count() && g_balance.nrow == g->nrow && g_balance.ncol == g->ncol && g_balance.stations == n) share = g_balance.share;
     }
-    mhs_multi_stack *ms = nullptr;
+    // validated by stack_build below when the buffers are (re)built; a cached stack needs the same checks
+    MHS_REQUIRE(covars_host->data && g->nrow > 0 && g->ncol > 0, "bad arguments");
+    MHS_REQUIRE(covars_host->dtype == MHS_F64 || covars_host->dtype == MHS_F32 || covars_host->dtype == MHS_I16, "bad stack dtype");
+    MHS_REQUIRE(covars_host->ld >= g->ncol && covars_host->plane_stride >= covars_host->ld * g->nrow, "stack strides smaller than the grid");
+    std::lock_guard<std::mutex> lk(g_host_mu);
     const double t0 = now_ms();
-    if (int rc = mhs_multi_stack_create(g, covars_host, share, &ms)) return rc;
+    const BandPlan want = plan_bands(g->nrow, slot_count(), share);
+    mhs_multi_stack *ms = g_host_ms;
+    if (ms && !(ms->n == slot_count() && ms->g.nrow == g->nrow && ms->g.ncol == g->ncol && ms->C == covars_host->n_layers &&
+                ms->dtype == covars_host->dtype && ms->plan.r0 == want.r0 && ms->plan.r1 == want.r1)) {
+        free_stack(ms);
+        ms = g_host_ms = nullptr;
+    }
+    if (!ms) {
+        if (int rc = stack_build(g, covars_host, share, false, &ms)) return rc;
+        g_host_ms = ms;
+    }
+    ms->g = *g; ms->nodata = covars_host->nodata; ms->have_result = false;
+    ms->pending = covars_host;                       // the step brings each band up under its own first kernels ...
+    ms->pending_out = final_host;                    // ... and sends it down under its last ones
+    ms->downloaded = false;
     const double t1 = now_ms();
     int rc = mhs_mltps_grid_multi_dev(models, weights, n_models, wt_total, ms, X, resp, n, tile_edge, lambda, gcv_mode, 0, info);
+    ms->pending = nullptr; ms->pending_out = nullptr;
     const double t2 = now_ms();
-    if (!rc) rc = mhs_multi_final_download(ms, final_host);
-    if (info && !rc) { info->upload_ms = t1 - t0; info->download_ms = now_ms() - t2; }
-    (void)mhs_multi_stack_free(ms);
+    if (!rc && !ms->downloaded) rc = mhs_multi_final_download(ms, final_host);      // reference-tiled Step 3: in one piece
+    // upload_ms: buffers (first call of a shape) + the time the slowest slot's helper spent in its copies, most of it under that
+    // slot's kernels; download_ms: the copies down that were NOT under kernels
+    if (info && !rc) { info->upload_ms = (t1 - t0) + ms->upload_ms; info->download_ms = ms->downloaded ? ms->download_ms : now_ms() - t2; }
     return rc;
 }
 

@@ -148,15 +148,18 @@ class MultiStack:
 
 
 def mltps_grid_multi(geom: Geometry, planes, nodata, models, weights, wt_total, X, resp, tile_edge: int | None = None, lambda_=None,
-                     gcv_mode: str = "fields", slot0_share: float | None = None):
+                     gcv_mode: str = "fields", slot0_share: float | None = None, out: np.ndarray | None = None):
     """Host planes in, host plane out, one library call (mhs_mltps_grid_multi -- what the R shim binds).  Returns
-    (final plane, info)."""
+    (final plane, info).  `out`: a C-contiguous float64 (nrow, ncol) array to write the plane into (default: a new one)."""
     planes, st = _host_stack(planes, nodata)
     X = np.asfortranarray(np.asarray(X, dtype=np.float64))
     resp = np.ascontiguousarray(resp, dtype=np.float64)
     hs, ws = _members(models, weights)
     g = geom.c_struct()
-    out = np.empty((geom.nrow, geom.ncol))
+    if out is None:
+        out = np.empty((geom.nrow, geom.ncol))
+    elif out.shape != (geom.nrow, geom.ncol) or out.dtype != np.float64 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float64 (nrow, ncol) array")
     info = _lib.MltpsInfo()
     mode = {"fields": _lib.GCV_FIELDS, "converged": _lib.GCV_CONVERGED}[gcv_mode]
     _lib.check(_lib.lib().mhs_mltps_grid_multi(hs, ws, len(models), float(wt_total), C.byref(g), C.byref(st), X.ctypes.data,
