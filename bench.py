@@ -294,14 +294,14 @@ class Workload:
                 by = band_cells * (4.0 * self.cfg["layers"] + 16.0)
                 full = float(self.rf_level_sum())
                 prm = next(p for p in self.params if p["kind"] == "rf")
-                big = int(np.diff(prm["tree_offsets"]).max()) > 4095      # launch_model's choice (ensemble.hip, case K_RF)
+                big = int(np.diff(prm["tree_offsets"]).max()) > 4095      # launch_forest's choice (forest.hip)
                 pm = pmc.get("rf", {}) if not big else {}
                 # a wave leaves a tree when all its walks sit at terminal nodes: the levels really walked come from the
                 # SQ_INSTS_LDS pass on the same rasters (two LDS instructions per walk and level), scaled to this forest's depth
                 walked_share = pm["levels_walked_per_cell"] / pm["levels_full_depth_per_cell"] if "levels_walked_per_cell" in pm else 1.0
                 levels = full * min(1.0, walked_share)
                 cyc = band_cells * levels / 64.0 * 4.0
-                tb = not big and int(np.diff(prm["tree_offsets"]).max()) * 8 <= 25600      # rf_walk_tb_config (ensemble.hip)
+                tb = not big and int(np.diff(prm["tree_offsets"]).max()) * 8 <= 25600      # rf_walk_ld_config (forest.hip)
                 rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_ld_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
                              "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
                              "work": "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "

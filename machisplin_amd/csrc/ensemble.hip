@@ -22,140 +22,9 @@
 #include "common.h"
 #include "devmath.h"
 
-enum { K_LM = 0, K_NNET = 1, K_EARTH = 2, K_SVR = 3, K_GBM = 4, K_RF = 5 };
+#include "ensemble_int.h"
 
 namespace mhs {
-
-constexpr int PMAX = 12;  // predictors supported by the register-resident kernels
-
-struct PredGeom {
-    double xmin, ymax, xres, yres;
-    int64_t r0, c0;  // window origin in the grid
-    int nr, nc;      // window size
-    int64_t ld_out;
-};
-
-struct StackDev {
-    const void *data;
-    int C;            // planes
-    int dtype;
-    int64_t plane_stride, ld;
-    double nodata;
-    int has_nodata;
-    int all_from_planes;  // points mode: every predictor (LONG, LAT too) comes from a plane
-};
-
-// 16-byte node record shared by gbm and randomForest walks
-struct __attribute__((aligned(16))) Node {
-    double val;              // split value, or the prediction at a terminal
-    short var;               // 0-based predictor, -1 = terminal
-    unsigned short left, right, missing;  // tree-local child indices
-};
-
-struct TreeChunk { int first_tree, n_trees, node_begin, node_count; };
-
-}  // namespace mhs
-
-struct mhs_model {
-    int kind = -1;
-    int p = 0;
-    // lm / nnet / earth / svr parameters (device)
-    double *dpar = nullptr;
-    int *ipar = nullptr;
-    int n0 = 0, n1 = 0, n2 = 0;   // nnet: size ; earth: nterms, nfactors ; svr: SVs kept, row stride, SVs with alpha > 0
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;  // nnet: y_scale,y_shift ; svr: b, sigma, y_center, y_scale, max|alpha|
-    // trees
-    mhs::Node *nodes = nullptr;
-    int *tree_off = nullptr;       // n_trees + 1 node offsets
-    mhs::TreeChunk *chunks = nullptr;
-    int n_trees = 0, n_chunks = 0, max_chunk_nodes = 0;
-    int64_t n_nodes = 0;
-    double init_f = 0;
-    bool lds_ok = true;
-    double *split_scratch = nullptr;     // device, partial tree sums of the few-cells path (launch_trees)
-    // gbm predicate-LUT fast path (trees with <= 6 splits): see gbm_lut_kernel
-    int lut_S = 0;                       // splits per tree after padding (0 = path unavailable)
-    double *lut = nullptr;               // device, n_trees_padded << lut_S leaf values
-    int *lut_meta = nullptr;             // device, 12 dwords per tree: c[6] (float bits), key offset[6]
-    void *lut_sorted = nullptr;          // device, sorted distinct key-space thresholds, predictor after predictor
-                                         // (float keys for float32 / int16 planes, double keys for float64 planes)
-    int *lut_sorted_off = nullptr;       // device, p + 1 offsets into lut_sorted
-    int *axis_rank = nullptr;            // device, the LONG rank of every grid column, then the LAT rank of every grid row (publish_axis_ranks)
-    int axis_ncol = 0;
-    double *lut_rt = nullptr;            // device, the same leaf values with every tree's levels ordered uniform-first
-    int *lut_rt_meta = nullptr;          // device, LUT_RT_DW dwords per tree (gbm_lutreg_rt_kernel)
-    unsigned *lut_cls = nullptr;         // device, 5 class words per tree (rank threshold << 3 | predictor; gbm_coherent_kernel)
-    int *gbm_probe = nullptr;            // device, GBC_PROBE_SLOTS x 8 ints: per launch, what the probe blocks summed
-    std::atomic<unsigned> gbm_probe_next{0};
-    // NA cells of a window, compacted for the MissingNode walk (round 4): 4 buffers in turn, {count, overflow, cell indices ...}
-    unsigned *na_list[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t na_cap[4] = {0, 0, 0, 0};
-    hipEvent_t na_done[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded behind the last kernel that reads the buffer
-    hipStream_t na_stream[4] = {nullptr, nullptr, nullptr, nullptr}; // ... on this stream
-    std::atomic<unsigned> na_next{0};
-    std::vector<double> lut_host;        // host copy of lut (the row-tile tables are permutations of it)
-    std::vector<int> lut_var;            // host, n_trees x lut_S (-1 = padding)
-    std::vector<double> lut_thr;         // host, n_trees x lut_S split values
-    int n_trees_padded = 0;
-    mhs_grid meta_grid = {0, 0, 0, 0, 0, 0};  // geometry lut_meta / rf_nodes were built for
-    int meta_C = -1;
-    int meta_key64 = -1;                 // key type lut_meta / rf_nodes were built for (1 = double keys)
-    // The geometry-dependent tables above are IMMUTABLE once built: a rebuild (another grid, another plane type)
-    // allocates fresh buffers and retires the old ones until mhs_model_free, so kernels already enqueued on any
-    // stream keep reading what they were launched with; `mu` serialises rebuilds from several host threads.
-    std::vector<void *> retired;
-    std::mutex mu;
-    // randomForest level-synchronous walk (rf_walk_kernel): available when every split node has
-    // rightDaughter == leftDaughter + 1 (how randomForest numbers its nodes)
-    bool rf_fast = false;
-    unsigned long long *rf_nodes = nullptr;  // device, 8-byte records {(rank << 8) | key offset; left | right << 16}
-    double *rf_lval = nullptr;               // device, node prediction by node id
-    int *rf_depth = nullptr;                 // device, levels to descend per tree
-    int *rf_dmin = nullptr;                  // device, depth of every tree's shallowest terminal node
-    std::vector<double> rf_thr;              // host, split value per node
-    std::vector<unsigned short> rf_left, rf_right, rf_var;  // host, per node (var 0xFFFF = terminal; a terminal's children are itself)
-    int rf_max_nodes = 0;
-    int rf_max_depth = 0;                    // deepest tree (rf_walk_ld_kernel packs a tree's level counts in 6 bits each)
-    int rf_log2r = -1;                       // walks per lane rf_nodes were built for
-    int rf_form = 0;                         // ... and in which form: RF_SMALL (16-bit byte addresses, predictions in LDS),
-                                             // RF_BIG (node indices, predictions in global memory), RF_COMPACT (split nodes only)
-    std::vector<int> rf_off;                 // host, n_trees + 1 node offsets
-    int *rf_coff = nullptr;                  // device, n_trees + 1 record offsets of the COMPACT form
-    int rf_cmax = 0;                         // COMPACT: most records in a tree (its split nodes + 1)
-    int rf_compact_ok = 0;                   // every tree's leaf codes fit 16 bits (8 * splits + nodes <= 65535)
-    // Several device slots (mhs_init_devices): the buffers above live on ONE device.  The handle remembers the loader
-    // call that built it (with copies of its flat arrays) and the multi-device drivers build a replica per slot on
-    // first use (model_on_slot); replicas are owned by the handle and freed with it.
-    int slot = 0, device = -1;               // where the buffers above live
-    std::function<int(mhs_model **)> reload;
-    mhs_model *replica[mhs::MAX_SLOTS] = {};
-};
-
-namespace mhs {
-
-__device__ __forceinline__ double load_plane(const StackDev &s, int k, int64_t row, int64_t col) {
-    const int64_t idx = (int64_t)k * s.plane_stride + row * s.ld + col;
-    double v;
-    if (s.dtype == MHS_F64) v = ((const double *)s.data)[idx];
-    else if (s.dtype == MHS_F32) v = (double)((const float *)s.data)[idx];
-    else v = (double)((const short *)s.data)[idx];
-    if (s.has_nodata && v == s.nodata) v = NAN;
-    return v;
-}
-
-// predictor k of the cell at window position (row, col): rast_stack layer order
-__device__ __forceinline__ double predictor(const StackDev &s, const PredGeom &g, int k, int row, int col) {
-    const int64_t ar = g.r0 + row, ac = g.c0 + col;
-    if (k < s.C || s.all_from_planes) return load_plane(s, k, ar, ac);
-    if (k == s.C) return g.xmin + ((double)ac + 0.5) * g.xres;  // LONG (V73:131-133)
-    return g.ymax - ((double)ar + 0.5) * g.yres;                // LAT  (V73:128-130)
-}
-
-__device__ __forceinline__ void emit(double *out, int64_t idx, double pred, double weight, int accumulate) {
-    double v = pred * weight;
-    if (accumulate) v = out[idx] + v;
-    out[idx] = v;
-}
 
 // ------------------------------------------------------------------------- lm --
 __global__ __launch_bounds__(256) void lm_kernel(const double *__restrict__ coef, int p, StackDev s,
@@ -675,12 +544,6 @@ __global__ __launch_bounds__(256) void gbm_na_list_kernel(const Node *__restrict
 //     256-byte LDS row for S = 5, conflict-free).
 // Cells with an NA covariate are skipped here and walked through their MissingNode
 // children by tree_kernel<GBM, .., NA_ONLY> afterwards (gbm_pred's NA routing).
-constexpr int LUT_R = 4;            // cells per lane
-constexpr int LUT_CHUNK = 64;       // trees per LDS chunk
-constexpr int LUT_META_DW = 12;     // dwords of meta per tree: c[6] (float), key offset[6]
-constexpr int LUT_COARSE = 4096;    // floats of the coarse rank table (aliases the LUT chunk buffer)
-
-typedef float float2v __attribute__((ext_vector_type(2)));
 
 // bit[c] = clamp(c_q - rank[c], 0, 1) for the lane's 4 cells (k holds -rank); HI selects which
 // dword of the SGPR pair {c_q, c_q+1} is broadcast to both halves of the packed add
@@ -697,64 +560,6 @@ __device__ __forceinline__ void pred_bits(float2v &b01, float2v &b23, const floa
             : "=&v"(b01), "=&v"(b23) : "v"(k01), "v"(k23), "s"(cpair));
 }
 
-// rank[c] = #{sorted distinct tkeys of predictor j that are <= key[c]} for the lane's LUT_R cells: a
-// binary search of a coarse table (every stride-th tkey, staged in LDS by the whole block) and a
-// short fine search in global memory.  Must be called by every thread of the block.
-// KT = float: planes whose values are exactly float-representable (float32 / int16); KT = double: float64 planes
-// (what terra holds in RAM and the R shim hands over, V73:468-606) -- the search is 1 % of a tree kernel, so doing
-// it in double costs nothing and the ranks that come out are the same small integers either way.
-template <int LUT_R, int NT, typename KT>
-__device__ __forceinline__ void lut_ranks_t(const int j, const KT *__restrict__ sorted,
-                                            const int *__restrict__ sorted_off, KT *coarse,
-                                            const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
-                                            const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
-    constexpr int COARSE_N = LUT_COARSE * (int)sizeof(float) / (int)sizeof(KT);   // the scratch is LUT_COARSE floats
-    const int o = sorted_off[j], n = sorted_off[j + 1] - o;
-    const KT *T = sorted + o;
-    const int stride = (n + COARSE_N - 1) / COARSE_N;
-    const int nc = stride ? (n + stride - 1) / stride : 0;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nc; e += (NT ? NT : (int)blockDim.x)) coarse[e] = T[(int64_t)e * stride];
-    __syncthreads();
-    KT k[LUT_R];
-    int lo[LUT_R], cnt[LUT_R];
-#pragma unroll
-    for (int c = 0; c < LUT_R; ++c) {
-        if (j < s.C) { const double xv = load_plane(s, j, g.r0 + row[c], g.c0 + col[c]); na[c] |= isnan(xv); k[c] = (KT)xv; }
-        else if (j == s.C) k[c] = (KT)(g.c0 + col[c]);
-        else k[c] = -(KT)(g.r0 + row[c]);
-        lo[c] = 0; cnt[c] = 0;
-    }
-    int top = 1;
-    while (top < nc) top <<= 1;
-    for (int st = top; st > 0; st >>= 1) {      // lo = #{coarse <= k}
-#pragma unroll
-        for (int c = 0; c < LUT_R; ++c) {
-            const int mid = lo[c] + st;
-            if (mid <= nc && coarse[mid - 1] <= k[c]) lo[c] = mid;
-        }
-    }
-    int ftop = 1;
-    while (ftop < stride) ftop <<= 1;
-    for (int st = ftop >> 1; st > 0; st >>= 1) {  // cnt = #{T in (base, base + stride) <= k}, base = (lo-1) stride
-#pragma unroll
-        for (int c = 0; c < LUT_R; ++c) {
-            const int base = (lo[c] - 1) * stride;
-            const int mid = cnt[c] + st;
-            if (lo[c] > 0 && mid < stride && base + mid < n && T[base + mid] <= k[c]) cnt[c] = mid;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < LUT_R; ++c) rank[c] = (float)(lo[c] > 0 ? (lo[c] - 1) * stride + 1 + cnt[c] : 0);
-}
-template <int LUT_R, int NT>
-__device__ __forceinline__ void lut_ranks(const int j, const void *__restrict__ sorted, const int key64,
-                                          const int *__restrict__ sorted_off, float *coarse,
-                                          const StackDev &s, const PredGeom &g, const int (&row)[LUT_R],
-                                          const int (&col)[LUT_R], bool (&na)[LUT_R], float (&rank)[LUT_R]) {
-    if (key64) lut_ranks_t<LUT_R, NT, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, rank);
-    else lut_ranks_t<LUT_R, NT, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, rank);
-}
 
 template <int S>
 __global__ __launch_bounds__(256) void gbm_lut_kernel(const double *__restrict__ lut,
@@ -1313,1063 +1118,6 @@ static size_t gbc_lds_bytes() {
     return 2 * ((size_t)LUT_CHUNK << 5) * sizeof(double) + 2 * 384 * sizeof(unsigned) + GBC_WAVES * 8 * sizeof(int2);
 }
 
-// ------------------------------------------------- randomForest: level-synchronous walk --
-// One tree at a time lives in LDS (from byte 0) as 8-byte node records plus the node predictions.
-// Terminals point at themselves, so every lane descends a fixed, wave-uniform number of levels (the
-// tree's depth) with no divergent control flow.  As in gbm_lut_kernel the cell's predictors are
-// first replaced by their RANK among the forest's sorted distinct key-space thresholds of that
-// predictor ("x <= split" <=> key < tkey_j <=> rank <= j), which makes a level three VALU
-// instructions around its two dependent LDS reads:
-//   node = {(j << 8) | (var * 4R),  left byte address | right byte address << 16}
-//   key address  = lane base + BYTE_0(node.x)             (v_add_u32 with an SDWA byte select)
-//   go right     = (rank << 8) > node.x                   (the var byte cannot flip the compare)
-//   next address = right ? WORD_1(node.y) : WORD_0(node.y)  (v_cndmask_b32 with SDWA word selects)
-// Keys are parked in LDS as [lane][var][cell slot] with an odd lane stride (conflict-free when the
-// lanes of a wave read the same predictor).  R independent walks per lane keep the two dependent
-// LDS reads of a level in flight.
-constexpr int RF_COARSE_BYTES = LUT_COARSE * (int)sizeof(float);
-constexpr unsigned RF_LEAF_WORD = 0xffffff00u;     // RF_SMALL: word 0 of a terminal node's record (rf_walk_loop5x.inc tests for it)
-// LDS accesses by 32-bit byte address (the walk's node addresses come out of LDS data, so no pointer
-// arithmetic may be attached to them); the kernel's dynamic LDS starts at address 0 (no static LDS)
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2v lds_u2(unsigned a) { return *(__attribute__((address_space(3))) const uint2v *)(uintptr_t)a; }
-__device__ __forceinline__ unsigned lds_u32(unsigned a) { return *(__attribute__((address_space(3))) const unsigned *)(uintptr_t)a; }
-__device__ __forceinline__ double lds_f64(unsigned a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
-
-// walks per lane for the "log2r" code the forest tables are built with: 1 -> 2, 2 -> 4, 3 -> 5 (the double-buffered
-// kernel only: five walks' keys still fit beside two tree buffers when the trees are small)
-__host__ __device__ constexpr int rf_walks(int code) { return code >= 3 ? code + 2 : (1 << code); }   // 1 2 4 | 5 6 7 8
-
-
-// A lane's R cells in the forest walk kernels.  STRIPS (grids): the same column of R adjacent rows -- the rows are cut
-// into strips of R, a lane index runs along a strip and on into the next one -- so that a wave's 64 R cells are
-// neighbours, end in neighbouring leaves, and the wave can leave a tree at its cells' deepest leaf instead of the tree's.
-// Otherwise (few rows, e.g. the stations' point list): cell i0 + c * ceil(total / R).
-template <int R>
-__device__ __forceinline__ void rf_lane_cells(const PredGeom &g, int64_t i0, int strips, int (&row)[R], int (&col)[R], bool (&live)[R]) {
-    const int64_t total = (int64_t)g.nr * g.nc;
-    const int64_t part = (total + R - 1) / R;
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        if (strips) {
-            const int64_t sr = i0 / g.nc;
-            col[c] = (int)(i0 - sr * g.nc);
-            const int64_t r = sr * R + c;
-            live[c] = r < g.nr;
-            row[c] = (int)(live[c] ? r : g.nr - 1);
-        } else {
-            int64_t i = i0 + c * part;
-            live[c] = i0 < part && i < total;
-            if (i >= total) i = total - 1;
-            row[c] = (int)(i / g.nc); col[c] = (int)(i - (int64_t)row[c] * g.nc);
-        }
-    }
-}
-static int64_t rf_lane_count(const PredGeom &g, int R, int strips) {      // lanes a launch needs
-    const int64_t total = (int64_t)g.nr * g.nc;
-    return strips ? (((int64_t)g.nr + R - 1) / R) * g.nc : (total + R - 1) / R;
-}
-static int rf_strips(const PredGeom &g, int R) { return g.nr >= 4 * R; }
-
-// WAVE-UNIFORM PREFIX of the forest walks (round 3; grids).  With LANE = TREE (64 trees at a time, node records read from
-// global memory) every tree is descended for as long as the split threshold lies outside the wave's [min, max] rank of
-// the split's predictor (the ranks are the keys already parked in LDS).  entry[b], lane l = tree 64 b + l: entry node in
-// the low 16 bits, levels descended in bits 16..30, bit 31 = the entry node is terminal.
-constexpr int RF_ENTRY_BATCHES = 16;                                // batches of 64 trees held in registers
-constexpr int RF_PREFIX_MAX_P = 12;                                 // the wave's [min, max] ranks are held for this many predictors;
-                                                                    // forests with more walk from the root (prefix off)
-template <int R>
-__device__ __forceinline__ void rf_prefix_entries(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
-                                                  const int *__restrict__ tree_off, int n_trees, int p, const char *smem,
-                                                  unsigned lane_base, const bool (&na)[R]) {
-    const int lane = threadIdx.x & 63;
-    int mn[RF_PREFIX_MAX_P], mx[RF_PREFIX_MAX_P];                  // callers guarantee p <= RF_PREFIX_MAX_P
-#pragma unroll
-    for (int v = 0; v < 12; ++v) {
-        mn[v] = 0x7fffffff; mx[v] = -1;
-        if (v < p) {
-            int a = 0x7fffffff, b = -1;
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                if (!na[c]) {
-                    const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
-                    a = min(a, rk); b = max(b, rk);
-                }
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-            mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-        if (b * 64 < n_trees) {
-            const int t = b * 64 + lane;
-            bool walking = t < n_trees;
-            const int o = tree_off[min(t, n_trees - 1)];
-            unsigned nd = 0u, plen = 0u, term = 0u;
-            while (__builtin_amdgcn_ballot_w64(walking)) {
-                if (walking) {
-                    const uint2 rec = gnodes[o + (int)nd];
-                    if (rec.x == RF_LEAF_WORD) { term = 1u; walking = false; }
-                    else {
-                        const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
-                        int lo = mn[0], hi = mx[0];
-#pragma unroll
-                        for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
-                        if (lo > j) { nd = (rec.y >> 16) >> 3; ++plen; }            // every cell's rank > j: right
-                        else if (hi <= j) { nd = (rec.y & 0xFFFFu) >> 3; ++plen; }   // every cell's rank <= j: left
-                        else walking = false;
-                    }
-                }
-            }
-            entry[b] = nd | (plen << 16) | (term << 31);
-        }
-    }
-}
-
-// Double-buffered form for trees of up to 4095 nodes (two buffers stay within the 16-bit child addresses): the
-// next tree travels global -> registers -> the other LDS buffer WHILE this one is walked, the node predictions are
-// read from global memory one tree behind (issued after a walk, added after the next one, in tree order), and a
-// tree costs one barrier.  In the single-buffer form a third of the kernel was staging: every wave idle while
-// 48 KB are copied between two barriers, 500 times per block.
-template <int LOG2R, bool K64>
-__global__ __launch_bounds__(1024) void rf_walk_db_kernel(const uint2 *__restrict__ gnodes,
-                                                          const double *__restrict__ glval,
-                                                          const int *__restrict__ tree_off,
-                                                          const int *__restrict__ depth,
-                                                          const void *__restrict__ sorted, int key64,
-                                                          const int *__restrict__ sorted_off, int n_trees,
-                                                          int max_nodes, int p, StackDev s, PredGeom g,
-                                                          double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
-    constexpr int R = rf_walks(LOG2R);
-    constexpr int PF = 4;                                          // node records per thread in flight (max_nodes <= 4095)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned buf_bytes = (unsigned)max_nodes * 8u;           // one tree's nodes; the two buffers sit at 0 and buf_bytes
-    const unsigned tree_bytes = max(2u * buf_bytes, (unsigned)RF_COARSE_BYTES);
-    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
-    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
-    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int row[R], col[R];
-    bool na[R], live[R];
-    double acc[R], pending[R];
-    unsigned node[R];
-    rf_lane_cells<R>(g, i0, strips, row, col, live);
-#pragma unroll
-    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    // The wave's 64 R cells are neighbours: near the root of a tree they all go the same way.  Where that stops -- at a
-    // terminal node, then the whole wave shares the tree's prediction, or at the first split that separates the wave's cells
-    // -- is where the cell walks of the tree loop below START (rf_prefix_entries).  The cells end at the same nodes as
-    // from the root: identical planes.
-    constexpr int EB = RF_ENTRY_BATCHES;
-    unsigned entry[EB];
-#pragma unroll
-    for (int b = 0; b < EB; ++b) entry[b] = 0u;
-    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * EB) rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
-    __syncthreads();                                               // coarse table no longer needed: buffer 0 may be written
-    {
-        const int o = tree_off[0], cnt = tree_off[1] - o;
-        for (int e = threadIdx.x; e < cnt; e += 1024) ((uint2 *)smem)[e] = gnodes[o + e];
-    }
-    __syncthreads();
-    // tree t's scalars (offsets, depth) are fetched one iteration ahead: an s_load at the top of every tree
-    // would stall all 16 waves for its latency, 500 times
-    int o = tree_off[0], o1 = tree_off[1], o2 = n_trees > 1 ? tree_off[2] : o1, o3 = n_trees > 2 ? tree_off[3] : o2;
-    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
-    int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
-    unsigned ecur = 0u;
-    // The node records travel global -> registers -> LDS one tree AND one iteration ahead: tree t + 2 is requested at the top
-    // of iteration t and parked at the top of iteration t + 1 (its buffer, tree t's, is free after the barrier that ends
-    // iteration t), so the request has a whole iteration to arrive even when the walks are short (most of a forest's trees
-    // end, for a wave of neighbouring cells, at or near the entry node).
-    uint2 pn[PF];
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-        const int e = threadIdx.x + q * 1024;
-        if (n_trees > 1 && e < o2 - o1) pn[q] = gnodes[o1 + e];
-    }
-    for (int t = 0; t < n_trees; ++t) {
-        if ((t & 63) == 0) {
-            ecur = 0u;
-#pragma unroll
-            for (int b = 0; b < EB; ++b) if ((t >> 6) == b) ecur = entry[b];
-        }
-        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
-        const unsigned boff = (t & 1) ? buf_bytes : 0u, noff = (t & 1) ? 0u : buf_bytes;
-        const int cnt1 = t + 1 < n_trees ? o2 - o1 : 0, cnt2 = t + 2 < n_trees ? o3 - o2 : 0;
-        const int o4 = t + 4 <= n_trees ? tree_off[t + 4] : o3;        // consumed two iterations from now
-        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
-        const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
-        {   // park tree t + 1 in the other buffer, child addresses moved there; then request tree t + 2
-            const unsigned reloc = noff * 0x10001u;
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = threadIdx.x + q * 1024;
-                if (e < cnt1) { uint2 nd = pn[q]; nd.y += reloc; *(uint2 *)(smem + noff + (unsigned)e * 8u) = nd; }
-            }
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = threadIdx.x + q * 1024;
-                if (e < cnt2) pn[q] = gnodes[o2 + e];
-            }
-        }
-        // the walks start at the wave's entry node of this tree and descend what is left of the tree's depth
-        const int plen = (int)((ent >> 16) & 0x7FFFu);
-        const int lev = (ent >> 31) ? 0 : levels - plen, shal = max(shallow - plen, 0);
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = boff + ((ent & 0xFFFFu) << 3);
-        if constexpr (R == 5) {
-            // five walks: the level loop by hand (tools/gen_rf_walk_asm.py) -- the walks rotated so that the two wait states an
-            // SDWA select needs after v_cmp's write of VCC are the previous walk's next node read and the next walk's key wait
-            // lev - 1 of them with a next level: the first min(shallowest leaf, lev - 1) untested, the others leave the
-            // loop when every walk of the wave has reached a terminal node; then the last level
-            int c0 = min(shal, lev - 1), cnt = lev - 1 - c0;
-            if (lev > 0)
-                asm volatile(
-#include "rf_walk_loop5x.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[4]), [cnt] "+s"(cnt),
-                      [c0] "+s"(c0)
-                    : [lb] "v"(lane_base)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
-        } else if constexpr (R == 4) {
-            int c0 = min(shal, lev - 1), cnt = lev - 1 - c0;
-            if (lev > 0)
-                asm volatile(
-#include "rf_walk_loop4x.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
-                    : [lb] "v"(lane_base)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118", "v120");
-        } else
-        for (int l = 0; l < lev; ++l) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const uint2v nd = lds_u2(node[c]);
-                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(node[c]) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-            }
-        }
-        // the previous tree's predictions have arrived by now; this tree's are requested
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = glval[o + (int)((node[c] - boff) >> 3)];
-        }
-        __syncthreads();                                           // every wave has left tree t; tree t + 1 is parked
-        o = o1; o1 = o2; o2 = o3; o3 = o4;
-        levels = levels1; levels1 = levels2;
-        shallow = shallow1; shallow1 = shallow2;
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
-        if (live[c])
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
-// TRIPLE-buffered form (round 3): the double-buffered kernel above still meets at one s_barrier per tree, and the 16 waves
-// of a block do not finish a tree together (their random node reads conflict differently): measured, a quarter of that
-// kernel was waves waiting at the barrier for the slowest one while the LDS pipe -- the bound of the walk -- ran dry.
-// Here there is NO barrier in the tree loop.  Three node buffers at a compile-time STRIDE (the walk's ds_read_b64 carries
-// the buffer in its immediate offset, so the records hold buffer-relative child addresses and need no relocation; the
-// tree loop is unrolled by three); a wave that has walked tree t (buffer t % 3) parks its share of tree t + 2 in buffer
-// (t + 2) % 3 -- which held tree t - 1 -- and goes on to tree t + 1, which was parked during tree t - 1.  Two monotonic
-// LDS counters per buffer order this: walked[b] (+1 per wave and tree walked in b) guards the overwrite, staged[b] (+1
-// per wave and tree parked in b) guards the walk.  The LDS unit executes a wave's operations in order, so "parked,
-// then ds_add" and "last node read, then ds_add" need no fence; the polls are ds_read + s_waitcnt, normally satisfied at
-// the first read.  A wave may run up to a whole tree ahead of the slowest one.
-__device__ __forceinline__ void lds_wait_ge(unsigned addr, unsigned target) {
-    for (;;) {
-        unsigned v;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-__device__ __forceinline__ void lds_signal(unsigned addr) {      // the wave's first lane adds 1
-    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory");
-    else asm volatile("" ::: "memory");
-}
-
-// LOADER-WAVE form (round 4).  Round 3's ablation of the kernel above: of 64.6 ms (8 000 x 8 000 cells, 500 trees) the walks are 23
-// and the "bare tree loop" 25 -- every one of the 16 waves spends ~260 instructions per tree on its share of the staging (eight
-// address computations, PF predicated global loads, PF predicated LDS stores, two counter polls).  Here NL waves of the block
-// (the last ones) do nothing but stage, tree u being loader u % NL's; the other 16 - NL waves (x 64 lanes x R cells) only walk.
-// A loader's REGISTERS are the fourth buffer: it requests its next tree (STRIDE bytes = PF x 16 bytes per lane, all in flight,
-// straight-line code) as soon as it has written the previous one to LDS, and the records wait in registers until every walker
-// has left the buffer's previous tree.  A walker's step: four readlanes (prefix entry, first record, depth, shallowest leaf --
-// the scalars of 64 trees come in one vector load each), a poll that is skipped while the buffer's cached counter says the tree
-// is parked (the three staged counters come in one ds_read_b128), the hand-scheduled level loop, one ds_add, R prediction
-// loads that are consumed FIVE trees later.  Same buffers, counters, records and order of additions as rf_walk_tb_kernel:
-// identical planes.  The records' array carries STRIDE bytes of padding behind the last tree for the loaders' over-read.
-// Measured on the way (profiles/r04_forest_variants.txt): staging by LDS-DMA (global_load_lds_dwordx4, M0 reaches all 160 KB, data
-// visible at the issuer's vmcnt(0): tools/micro/lds_dma_range.hip) runs at the DMA path's own cadence, 1.5 us per 24.8 KB tree
-// whatever is in flight and even from L2 -- no faster than one register loader (1.35 us, bound by one load round trip per tree).
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {      // 64 lanes x 16 bytes global -> LDS at lds_dst + 16 lane
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// (round 4's timing experiments -- walks, staging or synchronisation switched off, two loaders, no LDS-DMA -- are in
-// profiles/r04_forest_variants.txt and in the history at commit 55aadea; round 5 removed their switches)
-enum { RF_LD_PREFIX = 1 };
-
-template <int LOG2R, bool K64, int STRIDE>
-__global__ __launch_bounds__(1024) void rf_walk_ld_kernel(const uint2 *__restrict__ gnodes,
-                                                          const double *__restrict__ glval,
-                                                          const int *__restrict__ tree_off,
-                                                          const int *__restrict__ depth,
-                                                          const void *__restrict__ sorted,
-                                                          const int *__restrict__ sorted_off, int n_trees,
-                                                          int p, StackDev s, PredGeom g,
-                                                          double weight, int accumulate,
-                                                          double *__restrict__ out, const int *__restrict__ dmin, int strips, int flags,
-                                                          const int *__restrict__ axis_rank, int axis_ncol) {
-    constexpr int R = rf_walks(LOG2R), NL = 1, WALKERS = 16 - NL;
-    constexpr unsigned TREE_BYTES = 3u * STRIDE;
-    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES && 2 * STRIDE <= 65535, "buffer bases inside the 16-bit immediate offsets");
-    constexpr unsigned CNT = TREE_BYTES;                           // staged[3] at CNT, walked[3] at CNT + 16
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *coarse = (float *)smem;                                 // rank search scratch (before the first tree)
-    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
-    const unsigned lane_base = TREE_BYTES + 32u + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const bool loader = threadIdx.x >= 64 * WALKERS;               // wave-uniform
-    // the loaders' lanes shadow the block's first waves (they take part in the cooperative rank search and emit nothing)
-    const int64_t i0 = (int64_t)blockIdx.x * (64 * WALKERS) + (loader ? threadIdx.x - 64 * WALKERS : threadIdx.x);
-    int row[R], col[R];
-    bool na[R], live[R];
-    if (strips == 2) {
-        // COMPACT wave tiles: 16 columns x 4 R rows (lane = column + 16 x row group, a lane's R walks on adjacent rows) instead of
-        // 64 columns x R rows -- on smooth rasters the wave's predictor ranges are narrower, its prefix longer and its deepest
-        // leaf nearer (CPU study tools/r04_rf_slice_sim.py: 3.6 -> 1.8 levels walked per wave and tree on the 8d planes)
-        const int wave = (int)(threadIdx.x >> 6), lane_ = (int)(threadIdx.x & 63u);
-        const int64_t tile = (int64_t)blockIdx.x * WALKERS + (loader ? wave - WALKERS : wave);
-        const int tiles_x = (g.nc + 15) / 16;
-        const int64_t ty = tile / tiles_x;
-        const int tx = (int)(tile - ty * tiles_x);
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            const int64_t r = ty * (4 * R) + (lane_ >> 4) * R + c;
-            const int cc = tx * 16 + (lane_ & 15);
-            live[c] = r < g.nr && cc < g.nc;
-            row[c] = (int)min(r, (int64_t)g.nr - 1); col[c] = min(cc, g.nc - 1);
-        }
-    } else
-    rf_lane_cells<R>(g, i0, strips, row, col, live);
-#pragma unroll
-    for (int c = 0; c < R; ++c) na[c] = false;
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if (axis_rank && j >= s.C && !s.all_from_planes) {          // LONG / LAT: the rank is a function of the column / the row (publish_axis_ranks)
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                r[c] = (float)(j == s.C ? axis_rank[g.c0 + col[c]] : axis_rank[(int64_t)axis_ncol + g.r0 + row[c]]);
-        } else if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    unsigned entry[RF_ENTRY_BATCHES];
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    // (measured and not kept, profiles/r04_forest_variants.txt: the chains of eight batches interleaved -- finished chains re-read,
-    // 6.1 -> 8.5 ms of 48 on 8 000 x 8 000 cells --; the upper levels descended once per block with the block's ranges and each
-    // wave continuing from there: 6.7 ms.  The prefix is bound by the gather rate of its lane = tree record loads.)
-    if (!loader && (flags & RF_LD_PREFIX) && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES)
-        rf_prefix_entries<R>(entry, gnodes, tree_off, n_trees, p, smem, lane_base, na);
-    __syncthreads();                                               // coarse table no longer needed
-    if (threadIdx.x < 8) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = 0u;
-    __syncthreads();
-    if (loader) {
-        constexpr int PF = (STRIDE + 1023) / 1024;                  // 16-byte pieces per lane and tree
-        static_assert(PF <= 25, "one named register quad per piece below");
-        const unsigned lane16 = (threadIdx.x & 63u) * 16u;
-        // named quads, not an array: hipcc keeps a 25 x 16-byte array in scratch memory; always PF pieces, straight-line: under
-        // `piece < pieces of this tree` it waits vmcnt(0) between the loads
-        uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, r19, r20, r21, r22, r23, r24;
-        const char *src = nullptr;
-#define MHS_RF_ALL(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) \
-                      F(21) F(22) F(23) F(24)
-#define MHS_RF_LOAD(Q) if constexpr (Q < PF) r##Q = *(const uint4 *)(src + (size_t)Q * 1024u);
-#define MHS_RF_STORE(Q) if constexpr (Q < PF) *(uint4 *)(smem + slot * (unsigned)STRIDE + (unsigned)Q * 1024u + lane16) = r##Q;
-#define MHS_RF_REQUEST(U) { \
-            src = (const char *)(gnodes + tree_off[(U)]) + lane16; \
-            MHS_RF_ALL(MHS_RF_LOAD) }
-        {
-            // ONE loader, TWO trees in flight: even trees through the registers (requested while their buffer is still being
-            // walked), odd trees by LDS-DMA (no registers, issued once the buffer is free; the data is in LDS at vmcnt(0)).
-            // Either path alone is one round trip per tree (1.2 - 1.5 us); alternating, a pair costs about one.
-            MHS_RF_REQUEST(0)
-            for (int u = 0; u < n_trees; u += 2) {
-                unsigned slot = (unsigned)u % 3u;
-                if (u >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)(u / 3));
-                MHS_RF_ALL(MHS_RF_STORE)
-                lds_signal(CNT + 4u * slot);
-                if (u + 2 < n_trees) MHS_RF_REQUEST(u + 2)
-                if (u + 1 < n_trees) {
-                    slot = (unsigned)(u + 1) % 3u;
-                    if (u + 1 >= 3) lds_wait_ge(CNT + 16u + 4u * slot, (unsigned)WALKERS * (unsigned)((u + 1) / 3));
-                    {
-                        const char *dsrc = (const char *)(gnodes + tree_off[u + 1]) + lane16;
-#pragma unroll
-                        for (int q = 0; q < PF; ++q)
-                            glds16(dsrc + (size_t)q * 1024u, (unsigned)__builtin_amdgcn_readfirstlane((int)(slot * (unsigned)STRIDE + (unsigned)q * 1024u)));
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    lds_signal(CNT + 4u * slot);
-                }
-            }
-            return;
-        }
-#undef MHS_RF_REQUEST
-#undef MHS_RF_STORE
-#undef MHS_RF_LOAD
-#undef MHS_RF_ALL
-        return;
-    }
-    constexpr int PD = 6;                                          // a tree's predictions are added PD - 1 trees after their request
-    double acc[R], pend[PD][R];                                    // pend[t % PD]: predictions of tree t
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) pend[k][c] = 0.0;
-    }
-    unsigned staged[3] = {0u, 0u, 0u};                             // cached counters: buffer b has held staged[b] trees so far
-    int ocur = 0;                                                  // lane l: first record of tree 64 b + l
-    unsigned wcur = 0u;                                            // lane l: its walk -- entry node's byte address | c0 << 19 | cnt << 25 | walks << 31
-    double tpcur = 0.0;                                            // lane l: the prediction of its tree's entry node where the wave does not walk the tree
-    const int lane = threadIdx.x & 63;
-    auto step = [&](auto slot_tag, auto pidx_tag, const int t, const unsigned k3) {      // k3 = t / 3
-        constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
-        if ((t & 63) == 0) {
-            // The next 64 trees' scalars, lane = tree: one vector load each instead of three scalar loads (and their waits) per
-            // tree, and the walk's loop counts (levels without / with the exit test) formed here on the vector unit, 64 trees per
-            // instruction, instead of a dozen scalar instructions per tree on the CU's one scalar unit (the PMC pass counts
-            // 0.8 scalar per vector instruction in this kernel)
-            unsigned ecur = 0u;
-#pragma unroll
-            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
-            const int tl = min(t + lane, n_trees - 1);
-            ocur = tree_off[tl];
-            const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
-            const int plen = (int)((ecur >> 16) & 0x7FFFu);
-            const int levels = (ecur >> 31) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
-            const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63: depth of a tree of <= 3 200 nodes
-            wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
-            // a tree the wave does not walk (its cells share the entry node: two thirds of the trees on smooth rasters) has ONE
-            // prediction for all of them: fetched here, lane = tree, instead of by four 64-lane loads of one address in its step
-            tpcur = levels > 0 ? 0.0 : glval[ocur + (int)(ecur & 0xFFFFu)];
-            // the loads are awaited HERE: left pending, hipcc puts s_waitcnt vmcnt(0) in front of every step's readlanes (it
-            // cannot count the loads issued since around the loop) and every step then waits for the previous steps'
-            // prediction loads as well
-            asm volatile("" : "+v"(ocur), "+v"(wcur), "+v"(tpcur));
-        }
-        const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)wcur, t & 63);
-        const int o = __builtin_amdgcn_readlane(ocur, t & 63);
-        // tree t is parked?  (also asked by a wave that skips the tree: its ds_add below must not come before the loader has
-        // counted every wave out of tree t - 3, which is what "tree t is parked" implies)
-        if (staged[SLOT] <= k3)
-            for (;;) {
-                uint4v cv;                                                   // staged[0..2] and the zero word behind them
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(CNT) : "memory");
-                staged[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.x);
-                staged[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.y);
-                staged[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)cv.z);
-                if (staged[SLOT] > k3) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        unsigned node[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = wk & 0x7FFF8u;
-        int c0 = (int)((wk >> 19) & 63u), cnt = (int)((wk >> 25) & 63u);
-        if constexpr (R == 4) {
-            if (wk >> 31)
-                asm volatile(
-#include "rf_walk_loop4xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118", "v120");
-        } else {
-            static_assert(R == 4 || R == 5, "hand loops exist for four and five walks");
-            if (wk >> 31)
-                asm volatile(
-#include "rf_walk_loop5xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[R - 1]), [cnt] "+s"(cnt),
-                      [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
-        }
-        // this wave has left tree t: lane 0 adds 1 (every lane is active here: no branch around the ds_add)
-        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(CNT + 16u + 4u * SLOT), "v"(1u) : "memory");
-        const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
-#pragma unroll
-        for (int c = 0; c < R; ++c) acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];      // tree t - (PD - 1)'s; still in tree order
-        if (wk >> 31) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) pend[PIDX][c] = *(const double *)(lv + node[c]);
-        } else {
-            const double tv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tpcur), t & 63), __builtin_amdgcn_readlane(__double2loint(tpcur), t & 63));
-#pragma unroll
-            for (int c = 0; c < R; ++c) pend[PIDX][c] = tv;
-        }
-    };
-    static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
-    unsigned k3 = 0u;
-    for (int t = 0; t < n_trees; t += 6, k3 += 2u) {
-        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t, k3);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1, k3);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2, k3);
-        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3, k3 + 1u);
-        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4, k3 + 1u);
-        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5, k3 + 1u);
-    }
-    // trees n - (PD - 1) .. n - 1 are still pending (slots never written hold 0.0)
-    for (int k = n_trees - (PD - 1); k < n_trees; ++k) {
-        const int q = ((k % PD) + PD) % PD;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            double v = pend[0][c];
-#pragma unroll
-            for (int z = 1; z < PD; ++z) if (q == z) v = pend[z][c];
-            acc[c] = acc[c] + v;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        if (live[c])
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
-// SUBTREE form (round 5): the loader stages, per block of cells, only the SUBTREE the block's cells can reach, several trees to a buffer.
-// Round 4's loader-wave kernel copies every tree whole into one of three buffers -- 12 MB per block of 3 840 cells, 196 GB per
-// 1e8 cells past the L2 (PMC) -- and is bound by one load round trip per tree and buffer (0.75 us per tree with two in flight:
-// the loader alone takes 38 of the kernel's 44 ms on 8 000 x 8 000 cells).  But a block's cells are neighbours: with the block's
-// [min, max] rank of every predictor (the waves' ranges, reduced through LDS) the loader descends every tree from its root while
-// the split falls the same way for the whole block -- lane = tree, the walkers' own prefix one level up -- and needs only the
-// subtree below that node.  mhs_rf_load numbers nodes in PRE-ORDER, so that subtree is the contiguous record range
-// [entry, entry + size): on the 8d planes 3.7 KB per tree instead of 24 (tools/r04_rf_slice_sim.py with 80 x 48-cell blocks),
-// and a fifth of the trees need nothing at all.  The range goes, in 1 KB chunks, to the SAME offsets of the tree's buffer
-// (tree t: buffer t % 3) it has in a whole copy -- so every record's child addresses stay valid and the chunks travel by
-// LDS-DMA (global_load_lds, no registers, dozens in flight) -- and trees whose ranges do not overlap share a buffer: the
-// loader keeps, per buffer and chunk, the last tree that used it (lane = chunk) and waits, before it overwrites a chunk,
-// for every walker to have LEFT that tree (the walkers' progress words, one per wave, plain stores); the walkers wait for
-// the loader's "trees staged" word -- both normally satisfied by the cached value.  A round of the loader: the next trees'
-// chunks up to ~40 in flight, one s_waitcnt vmcnt(0), one store of the new count.  With whole trees (no prefix, rough
-// rasters) this degenerates into round 4's schedule.
-// Same nodes visited, same additions in the same order: identical planes (test_forest_walk_kernels_equal_each_other_...).
-template <int LOG2R, bool K64, int STRIDE>
-__global__ __launch_bounds__(1024) void rf_walk_sub_kernel(const uint2 *__restrict__ gnodes,
-                                                           const double *__restrict__ glval,
-                                                           const int *__restrict__ tree_off,
-                                                           const int *__restrict__ depth,
-                                                           const void *__restrict__ sorted,
-                                                           const int *__restrict__ sorted_off, int n_trees,
-                                                           int p, StackDev s, PredGeom g,
-                                                           double weight, int accumulate,
-                                                           double *__restrict__ out, const int *__restrict__ dmin, int tiles, int flags,
-                                                           const int *__restrict__ axis_rank, int axis_ncol) {
-    constexpr int R = rf_walks(LOG2R), WALKERS = 15;
-    constexpr unsigned TREE_BYTES = 3u * STRIDE;
-    static_assert(TREE_BYTES >= (unsigned)RF_COARSE_BYTES + 2048u && 2 * STRIDE <= 65535 && STRIDE % 1024 == 0, "buffer bases inside the 16-bit immediate offsets");
-    constexpr unsigned CNT = TREE_BYTES, STG = CNT, PROG = CNT + 4u;   // 16 words: trees staged; the walker waves' progress
-    constexpr unsigned RANGES = (unsigned)RF_COARSE_BYTES;           // 15 waves x 12 predictors x (min, max), behind the rank search's coarse table
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *coarse = (float *)smem;
-    const unsigned stride = (unsigned)(p * R) | 1u;                // dwords of keys per lane
-    const unsigned lane_base = CNT + 64u + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const bool loader = threadIdx.x >= 64 * WALKERS;               // wave-uniform
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int cw = loader ? wave - WALKERS : wave;                 // the loader's lanes shadow wave 0 (cooperative rank search; they emit nothing)
-    int row[R], col[R];
-    bool na[R], live[R];
-    if (tiles) {
-        // wave tiles of 16 columns x 4 R rows (lane = column + 16 x row group, a lane's R walks on adjacent rows); a block's 15
-        // tiles are 5 x 3 neighbours -- 80 x 12 R cells, the compact footprint that keeps the BLOCK's rank ranges narrow
-        const int tiles_x = (g.nc + 15) / 16, bx_n = (tiles_x + 4) / 5;
-        const int by = (int)(blockIdx.x / (unsigned)bx_n), bx = (int)(blockIdx.x - (unsigned)by * (unsigned)bx_n);
-        const int tx = bx * 5 + cw % 5;
-        const int64_t ty = (int64_t)by * 3 + cw / 5;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            const int64_t r = ty * (4 * R) + (lane >> 4) * R + c;
-            const int cc = tx * 16 + (lane & 15);
-            live[c] = r < g.nr && cc < g.nc;
-            row[c] = (int)min(r, (int64_t)g.nr - 1); col[c] = min(cc, g.nc - 1);
-        }
-    } else {
-        const int64_t i0 = (int64_t)blockIdx.x * (64 * WALKERS) + (loader ? threadIdx.x - 64 * WALKERS : threadIdx.x);
-        rf_lane_cells<R>(g, i0, 0, row, col, live);
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) na[c] = false;
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if (axis_rank && j >= s.C && !s.all_from_planes) {          // LONG / LAT: the rank is a function of the column / the row (publish_axis_ranks)
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                r[c] = (float)(j == s.C ? axis_rank[g.c0 + col[c]] : axis_rank[(int64_t)axis_ncol + g.r0 + row[c]]);
-        } else if constexpr (K64) lut_ranks_t<R, 1024, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 1024, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    const bool prefix = (flags & RF_LD_PREFIX) && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES;
-    // the wave's [min, max] rank of every predictor over its cells that are not NA (wave-uniform: scalar registers)
-    int mn[RF_PREFIX_MAX_P], mx[RF_PREFIX_MAX_P];
-#pragma unroll
-    for (int v = 0; v < RF_PREFIX_MAX_P; ++v) {
-        mn[v] = 0x7fffffff; mx[v] = -1;
-        if (prefix && v < p) {
-            int a = 0x7fffffff, b = -1;
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                if (!na[c]) {
-                    const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
-                    a = min(a, rk); b = max(b, rk);
-                }
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-            mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
-            // an NA cell's walk is thrown away, but it must stay INSIDE the staged subtree: it takes the wave's smallest rank
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                if (na[c] && mx[v] >= 0) *(unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) = (unsigned)mn[v] << 8;
-        }
-    }
-    __syncthreads();                                               // the coarse table is no longer needed: the ranges go behind it
-    if (!loader && lane < 2 * RF_PREFIX_MAX_P) {
-        int val = 0;
-#pragma unroll
-        for (int v = 0; v < RF_PREFIX_MAX_P; ++v) { if (lane == 2 * v) val = mn[v]; if (lane == 2 * v + 1) val = mx[v]; }
-        *(int *)(smem + RANGES + (unsigned)(wave * 2 * RF_PREFIX_MAX_P + lane) * 4u) = val;
-    }
-    if (threadIdx.x < 16) *(unsigned *)(smem + CNT + threadIdx.x * 4u) = 0u;
-    __syncthreads();
-    // lane = tree descent from node `nd` while the split falls the same way for every rank in [lo, hi] of its predictor; `end` follows
-    // (pre-order: the left subtree of a node k is [k + 1, right), the right one [right, end))
-    auto descend = [&](const int (&lo_)[RF_PREFIX_MAX_P], const int (&hi_)[RF_PREFIX_MAX_P], int t, unsigned &nd, unsigned &end, unsigned &plen,
-                       unsigned &term) {
-        bool walking = t < n_trees;
-        const int o = tree_off[min(t, n_trees - 1)];
-        while (__builtin_amdgcn_ballot_w64(walking)) {
-            if (walking) {
-                const uint2 rec = gnodes[o + (int)nd];
-                if (rec.x == RF_LEAF_WORD) { term = 1u; walking = false; }
-                else {
-                    const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
-                    int lo = lo_[0], hi = hi_[0];
-#pragma unroll
-                    for (int q = 1; q < RF_PREFIX_MAX_P; ++q) if (q < p && v == q) { lo = lo_[q]; hi = hi_[q]; }
-                    if (lo > j) { nd = (rec.y >> 16) >> 3; ++plen; }                                   // every rank > j: right
-                    else if (hi <= j) { end = (rec.y >> 16) >> 3; nd = (rec.y & 0xFFFFu) >> 3; ++plen; }  // every rank <= j: left
-                    else walking = false;
-                }
-            }
-        }
-    };
-    unsigned entry[RF_ENTRY_BATCHES];                              // walkers: the wave's entry nodes; loader: the block's chunk ranges
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (loader) {
-        // ---- the block's ranges and subtrees: entry[b], lane l = tree 64 b + l: chunks | first chunk << 8 ---------------
-        int bmn[RF_PREFIX_MAX_P], bmx[RF_PREFIX_MAX_P];
-#pragma unroll
-        for (int v = 0; v < RF_PREFIX_MAX_P; ++v) {
-            int a = 0x7fffffff, b = -1;
-            if (prefix && v < p && lane < WALKERS) {
-                a = *(const int *)(smem + RANGES + (unsigned)(lane * 2 * RF_PREFIX_MAX_P + 2 * v) * 4u);
-                b = *(const int *)(smem + RANGES + (unsigned)(lane * 2 * RF_PREFIX_MAX_P + 2 * v + 1) * 4u);
-            }
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-            bmn[v] = __builtin_amdgcn_readfirstlane(a); bmx[v] = __builtin_amdgcn_readfirstlane(b);
-        }
-#pragma unroll
-        for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-            if (b * 64 < n_trees) {
-                const int t = b * 64 + lane;
-                const int tl = min(t, n_trees - 1);
-                unsigned nd = 0u, end = (unsigned)(tree_off[tl + 1] - tree_off[tl]), plen = 0u, term = 0u;
-                if (prefix) descend(bmn, bmx, t, nd, end, plen, term);
-                const unsigned q0 = (nd * 8u) >> 10;
-                const unsigned nq = (term || t >= n_trees) ? 0u : ((end * 8u + 1023u) >> 10) - q0;
-                entry[b] = nq | (q0 << 8);
-            }
-        }
-    } else if (prefix) {
-        // ---- the wave's own prefix: where its cells first part ways ------------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-            if (b * 64 < n_trees) {
-                unsigned nd = 0u, end = 0u, plen = 0u, term = 0u;
-                descend(mn, mx, b * 64 + lane, nd, end, plen, term);
-                entry[b] = nd | (plen << 16) | (term << 31);
-            }
-        }
-    }
-    __syncthreads();                                               // the ranges have been read: the buffers are free
-    if (loader) {
-        // ---- staging ----------------------------------------------------------------------------------------------------
-        const unsigned lane16 = (unsigned)lane * 16u;
-        unsigned last0 = 0u, last1 = 0u, last2 = 0u;               // lane c: 1 + the last tree that used chunk c of buffer 0 / 1 / 2
-        unsigned prog = 0u;                                        // trees every walker has left (cached)
-        unsigned cur = 0u;                                         // the current 64 trees' chunk ranges, lane = tree
-        int offv = 0;                                              // ... and first records
-        int inflight = 0;
-        auto poll = [&]() {                                        // the slowest walker's progress
-            unsigned v = 0xffffffffu;
-            if (lane < WALKERS) v = *(volatile const unsigned *)(smem + PROG + (unsigned)lane * 4u);
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, q));
-            prog = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-        };
-        auto publish = [&](int done) {                             // every chunk issued so far has landed: trees 0 .. done - 1 are whole
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) *(volatile unsigned *)(smem + STG) = (unsigned)done;
-            inflight = 0;
-        };
-        auto stage = [&](auto slot_tag, const int u) {
-            constexpr int SLOT = decltype(slot_tag)::value;
-            if ((u & 63) == 0) {
-#pragma unroll
-                for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((u >> 6) == b) cur = entry[b];
-                offv = tree_off[min(u + lane, n_trees - 1)];
-                asm volatile("" : "+v"(cur), "+v"(offv));
-            }
-            const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)cur, u & 63);
-            const int nq = (int)(w & 0xFFu), q0 = (int)(w >> 8);
-            if (nq == 0) return;
-            unsigned &last = SLOT == 0 ? last0 : SLOT == 1 ? last1 : last2;
-            const bool mine = lane >= q0 && lane < q0 + nq;
-            unsigned need = mine ? last : 0u;
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) need = max(need, (unsigned)__shfl_xor((int)need, q));
-            need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
-            if (prog < need) {
-                poll();
-                if (prog < need) {
-                    if (inflight) publish(u);                      // the walkers may be waiting for what is in flight
-                    while (prog < need) { __builtin_amdgcn_s_sleep(2); poll(); }
-                }
-            }
-            const char *src = (const char *)(gnodes + __builtin_amdgcn_readlane(offv, u & 63)) + ((size_t)q0 << 10) + lane16;
-            unsigned dst = (unsigned)(SLOT * STRIDE) + ((unsigned)q0 << 10);
-            for (int i = 0; i < nq; ++i) { glds16(src, dst); src += 1024; dst += 1024u; }
-            if (mine) last = (unsigned)u + 1u;
-            inflight += nq;
-            if (inflight >= 40) publish(u + 1);
-        };
-        for (int u = 0; u < n_trees; u += 3) {
-            stage(std::integral_constant<int, 0>{}, u);
-            if (u + 1 < n_trees) stage(std::integral_constant<int, 1>{}, u + 1);
-            if (u + 2 < n_trees) stage(std::integral_constant<int, 2>{}, u + 2);
-            // a short forest tail / trees without chunks: keep the count moving (cheap when nothing is in flight)
-            if (inflight >= 16 || (u % 24) == 21) publish(min(u + 3, n_trees));
-        }
-        publish(n_trees);
-        return;
-    }
-    // ---- the walkers ------------------------------------------------------------------------------------------------
-    constexpr int PD = 6;                                          // a tree's predictions are added PD - 1 trees after their request
-    double acc[R], pend[PD][R];                                    // pend[t % PD]: predictions of tree t
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) pend[k][c] = 0.0;
-    }
-    unsigned staged = 0u;                                          // cached: trees 0 .. staged - 1 are in their buffers
-    int ocur = 0;                                                  // lane l: first record of tree 64 b + l
-    unsigned wcur = 0u;                                            // lane l: its walk -- entry node's byte address | c0 << 19 | cnt << 25 | walks << 31
-    double tpcur = 0.0;                                            // lane l: the prediction of its tree's entry node where the wave does not walk the tree
-    auto step = [&](auto slot_tag, auto pidx_tag, const int t) {
-        constexpr int SLOT = decltype(slot_tag)::value, PIDX = decltype(pidx_tag)::value;
-        if ((t & 63) == 0) {
-            // the next 64 trees' scalars, lane = tree (one vector load each), and the walk's loop counts formed on the vector unit
-            unsigned ecur = 0u;
-#pragma unroll
-            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
-            const int tl = min(t + lane, n_trees - 1);
-            ocur = tree_off[tl];
-            const int dcur = depth[tl], mcur = dmin ? dmin[tl] : dcur;
-            const int plen = (int)((ecur >> 16) & 0x7FFFu);
-            const int levels = (ecur >> 31) ? 0 : dcur - plen, shallow = max(mcur - plen, 0);
-            const int c0 = min(shallow, levels - 1), cnt = levels - 1 - c0;              // levels <= 63
-            wcur = ((ecur & 0xFFFFu) << 3) | (levels > 0 ? ((unsigned)c0 << 19) | ((unsigned)cnt << 25) | 0x80000000u : 0u);
-            // a tree the wave does not walk (its cells share the entry node) has ONE prediction for all of them: fetched here
-            tpcur = levels > 0 ? 0.0 : glval[ocur + (int)(ecur & 0xFFFFu)];
-            asm volatile("" : "+v"(ocur), "+v"(wcur), "+v"(tpcur));
-        }
-        const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)wcur, t & 63);
-        const int o = __builtin_amdgcn_readlane(ocur, t & 63);
-        unsigned node[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = wk & 0x7FFF8u;
-        if (wk >> 31) {
-            if (staged <= (unsigned)t)                              // tree t is in its buffer?
-                for (;;) {
-                    unsigned v;
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(STG) : "memory");
-                    staged = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-                    if (staged > (unsigned)t) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            int c0 = (int)((wk >> 19) & 63u), cnt = (int)((wk >> 25) & 63u);
-            if constexpr (R == 4) {
-                asm volatile(
-#include "rf_walk_loop4xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [cnt] "+s"(cnt), [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113",
-                      "v115", "v116", "v117", "v118", "v120");
-            } else {
-                static_assert(R == 4 || R == 5, "hand loops exist for four and five walks");
-                asm volatile(
-#include "rf_walk_loop5xo.inc"
-                    : [n0] "+v"(node[0]), [n1] "+v"(node[1]), [n2] "+v"(node[2]), [n3] "+v"(node[3]), [n4] "+v"(node[R - 1]), [cnt] "+s"(cnt),
-                      [c0] "+s"(c0)
-                    : [lb] "v"(lane_base), [off] "n"(SLOT * STRIDE)
-                    : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120");
-            }
-        }
-        // this wave has left tree t (or never entered it): its progress word, lane 0 (every lane is active here)
-        asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(PROG + 4u * (unsigned)wave), "v"((unsigned)t + 1u) : "memory");
-        const char *lv = (const char *)(glval + o);                      // node[] are byte addresses of 8-byte records = of the doubles
-#pragma unroll
-        for (int c = 0; c < R; ++c) acc[c] = acc[c] + pend[(PIDX + 1) % PD][c];      // tree t - (PD - 1)'s; still in tree order
-        if (wk >> 31) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) pend[PIDX][c] = *(const double *)(lv + node[c]);
-        } else {
-            const double tv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tpcur), t & 63), __builtin_amdgcn_readlane(__double2loint(tpcur), t & 63));
-#pragma unroll
-            for (int c = 0; c < R; ++c) pend[PIDX][c] = tv;
-        }
-    };
-    static_assert(PD == 6, "the tree loop is unrolled by the least common multiple of the 3 buffers and PD");
-    for (int t = 0; t < n_trees; t += 6) {
-        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
-        if (t + 1 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t + 2);
-        if (t + 3 < n_trees) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, t + 3);
-        if (t + 4 < n_trees) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, t + 4);
-        if (t + 5 < n_trees) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, t + 5);
-    }
-    // trees n - (PD - 1) .. n - 1 are still pending (slots never written hold 0.0)
-    for (int k = n_trees - (PD - 1); k < n_trees; ++k) {
-        const int q = ((k % PD) + PD) % PD;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            double v = pend[0][c];
-#pragma unroll
-            for (int z = 1; z < PD; ++z) if (q == z) v = pend[z][c];
-            acc[c] = acc[c] + v;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        if (live[c])
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
-// rf_prefix_entries for the COMPACT records (split nodes only; a state is a split record's byte address or D + the index of a
-// terminal node, D = 8 x the tree's splits): entry state in the low 16 bits, levels descended above them.
-template <int R>
-__device__ __forceinline__ void rf_prefix_entries_compact(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
-                                                          const int *__restrict__ coff, int n_trees, int p, const char *smem,
-                                                          unsigned lane_base, const bool (&na)[R]) {
-    const int lane = threadIdx.x & 63;
-    int mn[12], mx[12];
-#pragma unroll
-    for (int v = 0; v < 12; ++v) {
-        mn[v] = 0x7fffffff; mx[v] = -1;
-        if (v < p) {
-            int a = 0x7fffffff, b = -1;
-#pragma unroll
-            for (int c = 0; c < R; ++c)
-                if (!na[c]) {
-                    const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
-                    a = min(a, rk); b = max(b, rk);
-                }
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-            mn[v] = __builtin_amdgcn_readfirstlane(a); mx[v] = __builtin_amdgcn_readfirstlane(b);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) {
-        if (b * 64 < n_trees) {
-            const int t = min(b * 64 + lane, n_trees - 1);
-            const int cb = coff[t];
-            const unsigned D = (unsigned)(coff[t + 1] - cb - 1) * 8u;
-            unsigned state = 0u, plen = 0u;
-            bool walking = b * 64 + lane < n_trees && state < D;
-            while (__builtin_amdgcn_ballot_w64(walking)) {
-                if (walking) {
-                    const uint2 rec = gnodes[cb + (int)(state >> 3)];
-                    const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
-                    int lo = mn[0], hi = mx[0];
-#pragma unroll
-                    for (int q = 1; q < 12; ++q) if (q < p && v == q) { lo = mn[q]; hi = mx[q]; }
-                    if (lo > j) { state = rec.y >> 16; ++plen; }
-                    else if (hi <= j) { state = rec.y & 0xFFFFu; ++plen; }
-                    else walking = false;
-                    if (state >= D) walking = false;
-                }
-            }
-            entry[b] = state | (plen << 16);
-        }
-    }
-}
-
-// COMPACT form for trees beyond the double-buffered kernel's 4 095 nodes (a 20 000-station forest: ~12 000 nodes per
-// tree).  Half of a tree's nodes are terminals, which the walk never needs to READ -- it only has to remember which one
-// it reached.  LDS holds the records of the split nodes alone plus one all-zero record at byte address D = 8 * splits
-// (build_rf_nodes_t, RF_COMPACT): ~49 KB instead of 97 KB for such a tree, which leaves room for the keys of
-// 4 cells x 960 lanes (15 waves; the BIG form fits 2 x 1024 or 4 x 512 -- half the walks in flight, and this loop
-// is bound by the latency of its two dependent LDS reads).  A lane's state is the byte address of a split node's
-// record or, once it has reached a terminal, D + that node's index:
-//       rec = LDS[min(state, D)];  child = key > rec.rank ? rec.right : rec.left;  state = max(child, state)
-// (children follow their parent in randomForest's numbering and every terminal code is >= D, so max() leaves a split
-// node's state to its child and a terminal's state alone: the all-zero record's children are 0).  The next tree's
-// records travel global -> registers during the walk (PF x 8 bytes per thread) and registers -> LDS between two
-// barriers after it, so staging costs the block one LDS write pass per tree instead of a round trip to L2.
-template <int PF, bool K64>
-__global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
-                                                               const int *__restrict__ tree_off, const int *__restrict__ coff,
-                                                               const int *__restrict__ depth, const void *__restrict__ sorted,
-                                                               const int *__restrict__ sorted_off, int n_trees, int cmax, int p,
-                                                               StackDev s, PredGeom g, double weight, int accumulate,
-                                                               double *__restrict__ out, const int *__restrict__ dmin, int strips, int prefix) {
-    constexpr int R = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned nt = blockDim.x;
-    const unsigned tree_bytes = max((unsigned)cmax * 8u, (unsigned)RF_COARSE_BYTES);
-    float *coarse = (float *)smem;
-    const unsigned stride = (unsigned)(p * R) | 1u;
-    const unsigned lane_base = tree_bytes + threadIdx.x * stride * 4u;
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const int64_t i0 = (int64_t)blockIdx.x * nt + threadIdx.x;
-    int row[R], col[R];
-    bool na[R], live[R];
-    double acc[R], pending[R];
-    unsigned node[R];
-    rf_lane_cells<R>(g, i0, strips, row, col, live);
-#pragma unroll
-    for (int c = 0; c < R; ++c) { na[c] = false; acc[c] = 0.0; pending[c] = 0.0; }
-    for (int j = 0; j < p; ++j) {
-        float r[R];
-        if constexpr (K64) lut_ranks_t<R, 0, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
-        else lut_ranks_t<R, 0, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
-#pragma unroll
-        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
-    }
-    unsigned entry[RF_ENTRY_BATCHES];                              // where each tree's walks start for this wave
-#pragma unroll
-    for (int b = 0; b < RF_ENTRY_BATCHES; ++b) entry[b] = 0u;
-    if (prefix && p <= RF_PREFIX_MAX_P && n_trees <= 64 * RF_ENTRY_BATCHES) rf_prefix_entries_compact<R>(entry, gnodes, coff, n_trees, p, smem, lane_base, na);
-    unsigned ecur = 0u;
-    __syncthreads();                                               // coarse table no longer needed
-    {
-        const int o = coff[0], cnt = coff[1] - o;
-        for (int e = threadIdx.x; e < cnt; e += (int)nt) ((uint2 *)smem)[e] = gnodes[o + e];
-    }
-    __syncthreads();
-    // scalars of the trees ahead are fetched early, as in rf_walk_db_kernel
-    int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
-    int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
-    int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
-    int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
-    for (int t = 0; t < n_trees; ++t) {
-        const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
-        const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
-        const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
-        const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
-        const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
-        const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
-        uint2 pn[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = (int)threadIdx.x + q * (int)nt;
-            if (e < cnt1) pn[q] = gnodes[c1 + e];
-        }
-        if ((t & 63) == 0) {
-            ecur = 0u;
-#pragma unroll
-            for (int b = 0; b < RF_ENTRY_BATCHES; ++b) if ((t >> 6) == b) ecur = entry[b];
-        }
-        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
-        const int plen = (int)(ent >> 16);
-        const int lev = (ent & 0xFFFFu) >= D ? 0 : levels - plen, shal = min(max(shallow - plen, 0), lev);
-#pragma unroll
-        for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
-        auto level = [&]() {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const uint2v nd = lds_u2(min(node[c], D));
-                const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
-                unsigned child;
-                asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                    : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
-                node[c] = max(child, node[c]);
-            }
-        };
-        // no state is terminal above the tree's shallowest leaf; from there on the wave leaves the tree as soon as every
-        // state of every lane is a terminal code (>= D)
-        for (int l = 0; l < shal; ++l) level();
-        for (int l = shal; l < lev; ++l) {
-            const unsigned lowest = min(min(node[0], node[1]), min(node[2], node[3]));
-            if (!__builtin_amdgcn_ballot_w64(lowest < D)) break;
-            level();
-        }
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            acc[c] = acc[c] + pending[c];
-            pending[c] = glval[o + (int)(node[c] - D)];
-        }
-        __syncthreads();                                           // every wave has left this tree
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = (int)threadIdx.x + q * (int)nt;
-            if (e < cnt1) *(uint2 *)(smem + (unsigned)e * 8u) = pn[q];
-        }
-        __syncthreads();
-        o = o1; o1 = o2;
-        c0 = c1; c1 = c2; c2 = c3;
-        levels = levels1; levels1 = levels2;
-        shallow = shallow1; shallow1 = shallow2;
-    }
-#pragma unroll
-    for (int c = 0; c < R; ++c) {
-        acc[c] = acc[c] + pending[c];
-        if (live[c])
-            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
-    }
-}
-
 // predict.gbm(model, newdata, n.trees = step, 2 step, ...) at a table of points: what machisplin.gbm.step evaluates on
 // every fold's hold-out rows after every gbm.more (V73:1843, 1919) -- here in one walk over the trees, the running sum
 // written out every `step` trees (same additions in the same order as a model cut at that tree count)
@@ -2425,19 +1173,8 @@ __global__ __launch_bounds__(256) void scale_window_kernel(double *__restrict__ 
 }
 
 // ------------------------------------------------------------------ host side --
-template <typename T>
-static int to_device(const T *h, size_t n, T **d) {
-    MHS_HIP(hipMalloc((void **)d, sizeof(T) * (n ? n : 1)));
-    if (n) MHS_HIP(hipMemcpy(*d, h, sizeof(T) * n, hipMemcpyHostToDevice));
-    return MHS_OK;
-}
 
-constexpr int TREE_R = 2;
-constexpr size_t LDS_LIMIT = 150 * 1024;     // of the 160 KiB per CU
-constexpr size_t LDS_MAX = 160 * 1024;       // all of it (one block per CU)
-constexpr int GBM_CHUNK_NODES = 1024;        // 16 KiB of node records per chunk
-
-static int finish_trees(mhs_model *m, const std::vector<Node> &nodes, const std::vector<int> &off) {
+int finish_trees(mhs_model *m, const std::vector<Node> &nodes, const std::vector<int> &off) {
     const int nt = m->n_trees;
     const size_t xs_bytes = (size_t)m->p * TREE_R * 256 * sizeof(double);
     int biggest = 0;
@@ -2466,7 +1203,7 @@ static int finish_trees(mhs_model *m, const std::vector<Node> &nodes, const std:
     return to_device(chunks.data(), chunks.size(), &m->chunks);
 }
 
-static int check_common(int p, mhs_model **out) {
+int check_common(int p, mhs_model **out) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(out != nullptr, "out is NULL");
     MHS_REQUIRE(p >= 2 && p <= 64, "p (covariates + LONG + LAT) out of range");
@@ -2555,103 +1292,6 @@ static int launch_trees(const mhs_model *m, const StackDev &s, const PredGeom &g
                            m->n_chunks, m->n_trees, m->init_f, m->p, s, g, w, acc, out, (const unsigned *)nullptr);
     }
     return MHS_OK;
-}
-
-static float ceil_to_float(double thr) {  // smallest float >= thr
-    float f = (float)thr;
-    if ((double)f < thr) f = nextafterf(f, INFINITY);
-    return f;
-}
-static float floor_to_float(double thr) {  // largest float <= thr
-    float f = (float)thr;
-    if ((double)f > thr) f = nextafterf(f, -INFINITY);
-    return f;
-}
-
-// Key-space threshold of a split for this grid:  x < thr (gbm, LE = false)  or  x <= thr (randomForest, LE = true)
-// <=>  key < tkey  EXACTLY, with key = the plane value as KT (float for float32 / int16 planes, which hold nothing
-// but float-representable values; double for float64 planes), the column index for LONG, minus the row index for
-// LAT (thresholds converted with the same double formula the kernels use for the cell centres).
-template <typename KT, bool LE>
-static KT split_tkey(int v, int C, double thr, const mhs_grid &grid) {
-    KT tk;
-    if (v < C) {
-        if constexpr (sizeof(KT) == 4) tk = LE ? nextafterf(floor_to_float(thr), INFINITY) : ceil_to_float(thr);
-        else tk = LE ? nextafter(thr, (double)INFINITY) : thr;
-    } else if (v == C) {  // LONG: columns whose centre is < (<=) thr form a prefix [0, c*)
-        int64_t lo = 0, hi = grid.ncol;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            const double x = grid.xmin + ((double)mid + 0.5) * grid.xres;
-            if (LE ? x <= thr : x < thr) lo = mid + 1; else hi = mid;
-        }
-        tk = (KT)lo;
-    } else {              // LAT: rows whose centre is < (<=) thr form a suffix [r*, nrow)
-        int64_t lo = 0, hi = grid.nrow;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            const double y = grid.ymax - ((double)mid + 0.5) * grid.yres;
-            if (LE ? y <= thr : y < thr) hi = mid; else lo = mid + 1;
-        }
-        tk = (KT)0.5 - (KT)lo;
-    }
-    if (tk != tk) tk = (KT)INFINITY;   // a NaN split value never sends a cell left or right by "<"
-    return tk;
-}
-
-static bool same_meta(const mhs_model *m, const mhs_grid &grid, int C, int key64) {
-    const mhs_grid &o = m->meta_grid;
-    return m->meta_C == C && m->meta_key64 == key64 && o.xmin == grid.xmin && o.ymax == grid.ymax && o.xres == grid.xres &&
-           o.yres == grid.yres && o.nrow == grid.nrow && o.ncol == grid.ncol;
-}
-
-enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomForest node records (build_rf_nodes_t)
-
-// what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
-struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
-                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; const int *axis_rank = nullptr; int axis_ncol = 0; };
-
-// fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
-template <typename T>
-static int publish(mhs_model *m, const std::vector<T> &h, T **slot) {
-    T *d = nullptr;
-    if (int rc = to_device(h.data(), h.size(), &d)) return rc;
-    if (*slot) m->retired.push_back((void *)*slot);
-    *slot = d;
-    return MHS_OK;
-}
-
-// sorted distinct key-space thresholds per predictor, flattened; returns the per-predictor lists for the rank lookup
-template <typename KT>
-static void sort_unique(std::vector<std::vector<KT>> &sorted, std::vector<int> &off, std::vector<KT> &flat) {
-    off.assign(sorted.size() + 1, 0);
-    for (size_t v = 0; v < sorted.size(); ++v) {
-        std::vector<KT> &sv = sorted[v];
-        std::sort(sv.begin(), sv.end());
-        sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
-        off[v + 1] = off[v] + (int)sv.size();
-        flat.insert(flat.end(), sv.begin(), sv.end());
-    }
-    if (flat.empty()) flat.push_back((KT)0);
-}
-
-// Round 4: the ranks of the two coordinate predictors by table.  LONG's key is the grid column and LAT's minus the grid row
-// (lut_ranks_t), so rank = #{thresholds <= key} is a function of the column / of the row alone: one table entry per grid
-// column, then one per grid row, instead of a coarse-table staging, two barriers and ~18 search steps per cell and predictor
-// (two of cfg3's five predictors; the rank keys are 9 % of the forest kernel and 20 % of the coherent gbm kernel).
-template <typename KT>
-static int publish_axis_ranks(mhs_model *m, const std::vector<std::vector<KT>> &sorted, int C, const mhs_grid &grid) {
-    if (m->p != C + 2 || grid.ncol <= 0 || grid.nrow <= 0 || (int64_t)grid.ncol + grid.nrow > (1 << 26)) {
-        if (m->axis_rank) m->retired.push_back((void *)m->axis_rank);
-        m->axis_rank = nullptr; m->axis_ncol = 0;
-        return MHS_OK;
-    }
-    std::vector<int> ar((size_t)grid.ncol + (size_t)grid.nrow);
-    const std::vector<KT> &sl = sorted[(size_t)C], &st = sorted[(size_t)C + 1];
-    for (int64_t c = 0; c < grid.ncol; ++c) ar[(size_t)c] = (int)(std::upper_bound(sl.begin(), sl.end(), (KT)c) - sl.begin());
-    for (int64_t r = 0; r < grid.nrow; ++r) ar[(size_t)grid.ncol + (size_t)r] = (int)(std::upper_bound(st.begin(), st.end(), -(KT)r) - st.begin());
-    m->axis_ncol = (int)grid.ncol;
-    return publish(m, ar, &m->axis_rank);
 }
 
 // key-space thresholds of every split for this grid, the sorted distinct thresholds of each
@@ -2887,237 +1527,6 @@ static int launch_gbm_lut(const mhs_model *m, const StackDev &s, const PredGeom 
 }
 
 
-// MHS_RF_KERNEL = ld | db | compact pins one of the three forest walk kernels where it applies (the equality tests and the
-// benchmarks' comparisons); unset: the loader-wave kernel, else the double-buffered one, else the split-node one, else the
-// generic node walk.  MHS_RF_PLAIN=1: no wave-uniform prefix and every tree to its full depth (the walk as round 2 had it).
-enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT, RF_PICK_SUB };
-static int rf_pick() {
-    const char *e = getenv("MHS_RF_KERNEL");
-    if (!e) return RF_PICK_AUTO;
-    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : !strcmp(e, "sub") ? RF_PICK_SUB : RF_PICK_AUTO;
-}
-static bool rf_plain() { return getenv("MHS_RF_PLAIN") != nullptr; }
-
-// the double-buffered kernel: two node buffers within 16-bit byte addresses, predictions in global memory.  The predictor's
-// key offset is one byte.
-static size_t rf_walk_db_lds(const mhs_model *m, int log2r) {
-    const size_t tree_bytes = std::max((size_t)m->rf_max_nodes * 16, (size_t)RF_COARSE_BYTES);
-    return tree_bytes + (size_t)1024 * (((size_t)m->p * rf_walks(log2r)) | 1) * 4;
-}
-static int rf_walk_db_log2r(const mhs_model *m) {
-    if (m->rf_max_nodes > 4095) return -1;
-    for (int l2 = 3; l2 >= 1; --l2)
-        if ((m->p * rf_walks(l2) * 4) <= 255 && rf_walk_db_lds(m, l2) <= LDS_LIMIT) return l2;
-    return -1;
-}
-
-// loader-wave kernel (three node buffers): buffer stride (bytes, a template parameter) and walks per lane; false = does not apply
-static bool rf_walk_ld_config(const mhs_model *m, int *log2r, int *stride) {
-    if (m->rf_max_depth > 63) return false;                       // a tree's level counts travel in 6 bits each
-    for (int st : {16384, 24576, 25600}) {
-        if ((size_t)m->rf_max_nodes * 8 > (size_t)st) continue;
-        for (int l2 = st != 25600 ? 3 : 2; l2 >= 2; --l2)      // the widest stride is instantiated for four walks only
-            if ((m->p * rf_walks(l2) * 4) <= 255 &&
-                (size_t)3 * st + 32 + (size_t)1024 * (((size_t)m->p * rf_walks(l2)) | 1) * 4 <= LDS_MAX) {
-                *log2r = l2; *stride = st;
-                return true;
-            }
-    }
-    return false;
-}
-
-// key-space node records of the forest for this grid (see rf_walk_db_kernel); cached per geometry and key type
-template <typename KT>
-static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r, int form) {
-    const bool big = form == RF_BIG;
-    const size_t nn = m->rf_thr.size();
-    std::vector<KT> tkey(nn, (KT)0);
-    std::vector<std::vector<KT>> sorted((size_t)m->p);
-    for (size_t k = 0; k < nn; ++k) {
-        const unsigned v = m->rf_var[k];
-        if (v == 0xFFFFu) continue;
-        const KT tk = split_tkey<KT, true>((int)v, C, m->rf_thr[k], grid);
-        tkey[k] = tk;
-        sorted[(size_t)v].push_back(tk);
-    }
-    std::vector<int> off;
-    std::vector<KT> flat;
-    sort_unique(sorted, off, flat);
-    for (int v = 0; v < m->p; ++v)
-        if (sorted[(size_t)v].size() >= ((size_t)1 << 24)) { set_error("randomForest: too many distinct split values"); return MHS_ERR_INVALID; }
-    if (int rc = publish_axis_ranks(m, sorted, C, grid)) return rc;
-    std::vector<unsigned long long> rec((nn ? nn : 1) + 3200, 0ull);     // + 25 600 bytes: rf_walk_ld_kernel's loaders read whole strides
-    const unsigned R = (unsigned)rf_walks(log2r);
-    if (form == RF_COMPACT) {
-        // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
-        // A child field holds the LDS byte address of a split child's record or, for a terminal child, D + its node
-        // index: the walk reads record min(state, D), picks the child field and keeps max(child, state) -- a split
-        // node's children come after it and every terminal code is >= D, so a terminal state stays what it is.
-        rec.clear();
-        std::vector<int> coff(1, 0), newid;
-        for (int t = 0; t < m->n_trees; ++t) {
-            const int o = m->rf_off[(size_t)t], cnt = m->rf_off[(size_t)t + 1] - o;
-            newid.assign((size_t)cnt, 0);
-            unsigned splits = 0;
-            for (int k = 0; k < cnt; ++k) if (m->rf_var[(size_t)(o + k)] != 0xFFFFu) newid[(size_t)k] = (int)splits++;
-            const unsigned D = 8u * splits;
-            auto code = [&](unsigned k) { return m->rf_var[(size_t)o + k] != 0xFFFFu ? 8u * (unsigned)newid[k] : D + k; };
-            for (int k = 0; k < cnt; ++k) {
-                const unsigned v = m->rf_var[(size_t)(o + k)];
-                if (v == 0xFFFFu) continue;
-                const std::vector<KT> &sv = sorted[(size_t)v];
-                const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[(size_t)(o + k)]) - sv.begin());
-                const unsigned left = m->rf_left[(size_t)(o + k)], right = m->rf_right[(size_t)(o + k)];
-                const unsigned children = code(left) | (code(right) << 16);
-                rec.push_back(((unsigned long long)children << 32) | ((j << 8) | (v * R * 4u)));
-            }
-            rec.push_back(0ull);
-            coff.push_back((int)rec.size());
-        }
-        if (int rc = publish(m, coff, &m->rf_coff)) return rc;
-    } else
-    for (size_t k = 0; k < nn; ++k) {
-        const unsigned v = m->rf_var[k];
-        const unsigned left = m->rf_left[k], right = m->rf_right[k];   // node indices within the tree (terminal: its own index)
-        const unsigned unit = big ? 1u : 8u;   // children as node indices or as LDS byte addresses
-        unsigned node0 = 0, children;
-        if (v == 0xFFFFu) {
-            children = (left * unit) | ((left * unit) << 16);
-            if (!big) node0 = RF_LEAF_WORD;      // above every key: the compare is false, both children are the node itself
-        } else {
-            const std::vector<KT> &sv = sorted[(size_t)v];
-            const unsigned j = (unsigned)(std::lower_bound(sv.begin(), sv.end(), tkey[k]) - sv.begin());
-            node0 = (j << 8) | (v * R * 4u);
-            children = (left * unit) | ((right * unit) << 16);
-        }
-        rec[k] = ((unsigned long long)children << 32) | node0;
-    }
-    if (int rc = publish(m, flat, (KT **)&m->lut_sorted)) return rc;
-    if (int rc = publish(m, off, &m->lut_sorted_off)) return rc;
-    return publish(m, rec, &m->rf_nodes);
-}
-
-static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, int form, int key64, TreeTables *tt) {
-    std::lock_guard<std::mutex> lk(m->mu);
-    if (!(m->rf_nodes && m->rf_log2r == log2r && m->rf_form == form && same_meta(m, grid, C, key64))) {
-        if (int rc = key64 ? build_rf_nodes_t<double>(m, grid, C, log2r, form) : build_rf_nodes_t<float>(m, grid, C, log2r, form)) return rc;
-        m->meta_grid = grid; m->meta_C = C; m->meta_key64 = key64;
-        m->rf_log2r = log2r; m->rf_form = form;
-    }
-    *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes, form == RF_COMPACT ? m->rf_coff : nullptr, nullptr, nullptr, nullptr,
-                     m->axis_rank, m->axis_ncol};
-    return MHS_OK;
-}
-
-// the loader-wave kernel where it applies (or is asked for), else the double-buffered one; *launched = false when neither does
-static int launch_rf_walk(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
-                          double w, int acc, double *out, hipStream_t st, int64_t total, bool *launched) {
-    const int key64 = s.dtype == MHS_F64, pick = rf_pick();
-    *launched = false;
-    (void)total;
-    int sb_l2 = 0, sb_stride = 0;
-    if (pick == RF_PICK_SUB && rf_walk_ld_config(m, &sb_l2, &sb_stride) && m->n_trees <= 64 * RF_ENTRY_BATCHES) {
-        // block-level subtrees in three shared buffers, one loader wave, 15 walker waves (same LDS budget as the loader-wave kernel)
-        TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, sb_l2, RF_SMALL, key64, &tt)) return rc;
-        const int R = rf_walks(sb_l2);
-        const int tiles = rf_strips(g, R);
-        unsigned blocks;
-        if (tiles) {
-            const int64_t tiles_x = (g.nc + 15) / 16, tiles_y = (g.nr + 4 * R - 1) / (4 * R);
-            blocks = (unsigned)(((tiles_x + 4) / 5) * ((tiles_y + 2) / 3));                      // 5 x 3 wave tiles per block
-        } else blocks = (unsigned)((rf_lane_count(g, R, 0) + 64 * 15 - 1) / (64 * 15));
-        const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
-        const size_t tbytes = (size_t)3 * sb_stride + 64 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-#define MHS_SB(L2, ST) (key64 ? rf_walk_sub_kernel<L2, true, ST> : rf_walk_sub_kernel<L2, false, ST>)
-        auto tk = sb_stride == 16384 ? (sb_l2 == 3 ? MHS_SB(3, 16384) : MHS_SB(2, 16384))
-                : sb_stride == 24576 ? (sb_l2 == 3 ? MHS_SB(3, 24576) : MHS_SB(2, 24576))
-                                     : MHS_SB(2, 25600);
-#undef MHS_SB
-        if (tbytes <= LDS_MAX) {
-            MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
-            hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                               m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, tiles,
-                               (int)(tiles && dmin), tt.axis_rank, tt.axis_ncol);
-            *launched = true;
-            return MHS_OK;
-        }
-    }
-    int ld_l2 = 0, ld_stride = 0;
-    if (pick != RF_PICK_DB && rf_walk_ld_config(m, &ld_l2, &ld_stride)) {      // three node buffers, one loader wave, 15 walker waves
-        TreeTables tt;
-        if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, ld_l2, RF_SMALL, key64, &tt)) return rc;
-        const int R = rf_walks(ld_l2);
-        const int strips = rf_strips(g, R);
-        const int64_t per_block = 64 * 15;
-        unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + per_block - 1) / per_block);
-        if (strips) blocks = (unsigned)((((int64_t)(g.nc + 15) / 16) * ((g.nr + 4 * R - 1) / (4 * R)) + 15 - 1) / 15);   // 16 x 4R-cell wave tiles
-        const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
-        const size_t tbytes = (size_t)3 * ld_stride + 32 + (size_t)1024 * (((size_t)m->p * R) | 1) * 4;
-#define MHS_LD(L2, ST) (key64 ? rf_walk_ld_kernel<L2, true, ST> : rf_walk_ld_kernel<L2, false, ST>)
-        auto tk = ld_stride == 16384 ? (ld_l2 == 3 ? MHS_LD(3, 16384) : MHS_LD(2, 16384))
-                : ld_stride == 24576 ? (ld_l2 == 3 ? MHS_LD(3, 24576) : MHS_LD(2, 24576))
-                                     : MHS_LD(2, 25600);
-#undef MHS_LD
-        MHS_HIP(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbytes));
-        hipLaunchKernelGGL(tk, dim3(blocks), dim3(1024), tbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                           m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->p, s, g, w, acc, out, dmin, strips ? 2 : 0,
-                           (int)(strips && dmin), tt.axis_rank, tt.axis_ncol);
-        *launched = true;
-        return MHS_OK;
-    }
-    const int log2r = rf_walk_db_log2r(m);
-    if (log2r < 0) return MHS_OK;
-    TreeTables tt;
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, log2r, RF_SMALL, key64, &tt)) return rc;
-    const int R = rf_walks(log2r);
-    const size_t dbytes = rf_walk_db_lds(m, log2r);
-    // grids: a lane's walks on R adjacent rows and the early exit per wave
-    const int strips = rf_strips(g, R);
-    const unsigned blocks = (unsigned)((rf_lane_count(g, R, strips) + 1023) / 1024);
-    const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
-    auto dk = log2r == 3 ? (key64 ? rf_walk_db_kernel<3, true> : rf_walk_db_kernel<3, false>)
-            : log2r == 2 ? (key64 ? rf_walk_db_kernel<2, true> : rf_walk_db_kernel<2, false>)
-                         : (key64 ? rf_walk_db_kernel<1, true> : rf_walk_db_kernel<1, false>);
-    MHS_HIP(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbytes));
-    hipLaunchKernelGGL(dk, dim3(blocks), dim3(1024), dbytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off,
-                       m->rf_depth, tt.sorted, key64, tt.sorted_off, m->n_trees, m->rf_max_nodes, m->p, s, g, w, acc, out, dmin, strips,
-                       strips && dmin);
-    *launched = true;
-    return MHS_OK;
-}
-
-// rf_walk_compact_kernel: the most threads (whole waves, at least 8) whose keys fit beside one tree's split records,
-// 0 = the form does not apply (terminal codes beyond 16 bits, too many predictors, no room)
-static int rf_compact_threads(const mhs_model *m) {
-    if (!m->rf_compact_ok || m->p * 16 > 255) return 0;
-    const size_t tree_bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES);
-    if (tree_bytes >= LDS_MAX) return 0;
-    const size_t per_lane = (((size_t)m->p * 4) | 1) * 4;
-    int nt = (int)std::min<size_t>(1024, (LDS_MAX - tree_bytes) / per_lane) / 64 * 64;
-    if (nt < 512 || (size_t)nt * 8 < (size_t)m->rf_cmax) return 0;     // PF <= 8 records per thread
-    return nt;
-}
-
-static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
-                             double w, int acc, double *out, hipStream_t st, int64_t total, int nt) {
-    const int key64 = s.dtype == MHS_F64;
-    TreeTables tt;
-    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_COMPACT, key64, &tt)) return rc;
-    const size_t bytes = std::max((size_t)m->rf_cmax * 8, (size_t)RF_COARSE_BYTES) + (size_t)nt * (((size_t)m->p * 4) | 1) * 4;
-    const int strips = rf_strips(g, 4);
-    const unsigned blocks = (unsigned)((rf_lane_count(g, 4, strips) + nt - 1) / nt);
-    const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
-    const bool pf4 = (size_t)nt * 4 >= (size_t)m->rf_cmax;
-    auto k = pf4 ? (key64 ? rf_walk_compact_kernel<4, true> : rf_walk_compact_kernel<4, false>)
-                 : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
-    MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
-                       m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips,
-                       strips && dmin);
-    return MHS_OK;
-}
-
 static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g, double weight,
                         int accumulate, double *out, hipStream_t st, const mhs_grid *grid = nullptr) {
     const int64_t total = (int64_t)g.nr * g.nc;
@@ -3150,21 +1559,12 @@ static int launch_model(const mhs_model *m, const StackDev &s, const PredGeom &g
                 if (int rc = launch_gbm_lut(m, s, g, *grid, weight, accumulate, out, st, total)) return rc;
             } else if (int rc = launch_trees<true, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
             break;
-        case K_RF:
-            if (grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC")) {
-                const int pick = rf_pick();
-                bool launched = false;
-                if (pick != RF_PICK_COMPACT)
-                    if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, &launched)) return rc;
-                if (launched) break;
-                const int nt = rf_compact_threads(m);      // trees beyond 4 095 nodes: split nodes only in LDS
-                if (nt > 0) {
-                    if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
-                    break;
-                }
-            }
-            if (int rc = launch_trees<false, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
+        case K_RF: {
+            bool launched = false;
+            if (int rc = launch_forest(m, s, g, grid, weight, accumulate, out, st, total, &launched)) return rc;
+            if (!launched) if (int rc = launch_trees<false, false>(m, s, g, weight, accumulate, out, st, total)) return rc;
             break;
+        }
         default:
             set_error("predict: unknown model kind %d", m->kind);
             return MHS_ERR_INVALID;
@@ -3545,134 +1945,6 @@ int mhs_gbm_load(double init_f, int64_t n_trees, const int64_t *tree_offsets, co
                  l = std::vector<int32_t>(left, left + nn), r = std::vector<int32_t>(right, right + nn),
                  ms = std::vector<int32_t>(missing, missing + nn), p](mhs_model **o) {
         return mhs_gbm_load(init_f, n_trees, to.data(), sv.data(), sl.data(), l.data(), r.data(), ms.data(), p, o);
-    };
-    *out = m;
-    return MHS_OK;
-}
-
-int mhs_rf_load(int64_t n_trees, const int64_t *tree_offsets, const int32_t *left, const int32_t *right,
-                const int32_t *status, const int32_t *best_var, const double *split,
-                const double *node_pred, int p, mhs_model **out) {
-    if (int rc = check_common(p, out)) return rc;
-    MHS_REQUIRE(tree_offsets && left && right && status && best_var && split && node_pred, "NULL rf array");
-    MHS_REQUIRE(n_trees >= 1 && n_trees < (1LL << 30) && tree_offsets[0] == 0, "bad tree offsets");
-    const int64_t nn = tree_offsets[n_trees];
-    MHS_REQUIRE(nn < (1LL << 31), "too many nodes");
-    std::vector<Node> nodes((size_t)nn);
-    std::vector<int> off((size_t)n_trees + 1);
-    for (int64_t t = 0; t <= n_trees; ++t) off[t] = (int)tree_offsets[t];
-    for (int64_t t = 0; t < n_trees; ++t) {
-        const int64_t o = tree_offsets[t], cnt = tree_offsets[t + 1] - o;
-        MHS_REQUIRE(cnt >= 1 && cnt <= 65535, "a randomForest tree must have 1..65535 nodes");
-        for (int64_t k = 0; k < cnt; ++k) {
-            Node &nd = nodes[(size_t)(o + k)];
-            if (status[o + k] == -1) {
-                nd.val = node_pred[o + k]; nd.var = -1; nd.left = nd.right = nd.missing = 0;
-            } else {
-                MHS_REQUIRE(best_var[o + k] >= 1 && best_var[o + k] <= p, "rf bestvar out of range");
-                MHS_REQUIRE(left[o + k] >= 1 && left[o + k] <= cnt && right[o + k] >= 1 && right[o + k] <= cnt,
-                            "rf daughter index out of range");
-                nd.val = split[o + k]; nd.var = (short)(best_var[o + k] - 1);
-                nd.left = (unsigned short)(left[o + k] - 1); nd.right = (unsigned short)(right[o + k] - 1);
-                nd.missing = 0;
-            }
-        }
-    }
-    // Nodes renumbered in PRE-ORDER (round 5): a subtree is then a contiguous range of node ids [k, k + size(k)), which is what
-    // lets the forest kernel stage, per block of cells, only the subtree its cells can reach (rf_walk_ring_kernel).  The tree is
-    // the same tree -- same splits, same leaves, same predictions; randomForest's own numbering (breadth-first, right daughter =
-    // left daughter + 1) is not needed by any kernel.  A malformed tree (a node reached twice or never, a cycle) keeps its
-    // numbering and takes the generic walk.
-    bool paired = true;
-    {
-        std::vector<Node> ordered(nodes.size());
-        std::vector<int> newid, stack;
-        for (int64_t t = 0; t < n_trees && paired; ++t) {
-            const int o = off[t], cnt = off[t + 1] - off[t];
-            newid.assign((size_t)cnt, -1);
-            stack.assign(1, 0);
-            int next = 0;
-            while (!stack.empty() && paired) {
-                const int k = stack.back();
-                stack.pop_back();
-                if (k < 0 || k >= cnt || newid[(size_t)k] >= 0) { paired = false; break; }
-                newid[(size_t)k] = next++;
-                const Node &nd = nodes[(size_t)(o + k)];
-                if (nd.var >= 0) { stack.push_back(nd.right); stack.push_back(nd.left); }      // left first: left child = parent + 1
-            }
-            if (next != cnt) paired = false;
-            for (int k = 0; k < cnt && paired; ++k) {
-                Node nd = nodes[(size_t)(o + k)];
-                if (nd.var >= 0) { nd.left = (unsigned short)newid[nd.left]; nd.right = (unsigned short)newid[nd.right]; }
-                ordered[(size_t)(o + newid[(size_t)k])] = nd;
-            }
-        }
-        if (paired) nodes.swap(ordered);
-    }
-    mhs_model *m = new mhs_model();
-    m->kind = K_RF; m->p = p; m->n_trees = (int)n_trees;
-    if (int rc = finish_trees(m, nodes, off)) { mhs_model_free(m); return rc; }
-    if (paired) {
-        m->rf_thr.resize(nodes.size());
-        m->rf_left.resize(nodes.size());
-        m->rf_right.resize(nodes.size());
-        m->rf_var.resize(nodes.size());
-        std::vector<double> lval(nodes.size());
-        std::vector<int> depth((size_t)n_trees, 0), shallow((size_t)n_trees, 0), lev;
-        int max_nodes = 0;
-        for (int64_t t = 0; t < n_trees && paired; ++t) {
-            const int o = off[t], cnt = off[t + 1] - off[t];
-            if (cnt > 65535) { paired = false; break; }   // node indices within a tree are 16-bit in the walk kernels
-            max_nodes = std::max(max_nodes, cnt);
-            m->rf_off.push_back(o);
-            lev.assign((size_t)cnt, -1);
-            lev[0] = 0;
-            int dmax = 0, dlow = 1 << 30;
-            for (int k = 0; k < cnt; ++k) {  // randomForest numbers children after their parent
-                const Node &nd = nodes[(size_t)(o + k)];
-                if (lev[k] < 0) { paired = false; break; }  // unreachable or out-of-order node
-                m->rf_thr[(size_t)(o + k)] = nd.val;
-                lval[(size_t)(o + k)] = nd.var < 0 ? nd.val : 0.0;
-                if (nd.var >= 0) {
-                    if (nd.left != k + 1 || nd.right <= nd.left || nd.right >= cnt) { paired = false; break; }      // pre-order
-                    m->rf_left[(size_t)(o + k)] = nd.left;
-                    m->rf_right[(size_t)(o + k)] = nd.right;
-                    m->rf_var[(size_t)(o + k)] = (unsigned short)nd.var;
-                    lev[nd.left] = lev[nd.right] = lev[k] + 1;
-                    dmax = std::max(dmax, lev[k] + 1);
-                } else {
-                    m->rf_left[(size_t)(o + k)] = m->rf_right[(size_t)(o + k)] = (unsigned short)k;  // self loop
-                    m->rf_var[(size_t)(o + k)] = 0xFFFFu;
-                    dlow = std::min(dlow, lev[k]);
-                }
-            }
-            depth[(size_t)t] = dmax;
-            m->rf_max_depth = std::max(m->rf_max_depth, dmax);
-            shallow[(size_t)t] = std::min(dlow, dmax);
-        }
-        if (paired) {
-            m->rf_off.push_back((int)nodes.size());
-            m->rf_compact_ok = 1;
-            for (int64_t t = 0; t < n_trees; ++t) {
-                int splits = 0;
-                for (int k = m->rf_off[(size_t)t]; k < m->rf_off[(size_t)t + 1]; ++k) splits += m->rf_var[(size_t)k] != 0xFFFFu;
-                m->rf_cmax = std::max(m->rf_cmax, splits + 1);
-                if (8 * splits + (m->rf_off[(size_t)t + 1] - m->rf_off[(size_t)t]) > 65535) m->rf_compact_ok = 0;
-            }
-            m->rf_fast = true;
-            m->rf_max_nodes = max_nodes;
-            int rc = to_device(lval.data(), lval.size(), &m->rf_lval);
-            if (!rc) rc = to_device(depth.data(), depth.size(), &m->rf_depth);
-            if (!rc) rc = to_device(shallow.data(), shallow.size(), &m->rf_dmin);
-            if (rc) { mhs_model_free(m); return rc; }
-        }
-    }
-    m->slot = current_slot(); m->device = ctx().device;
-    m->reload = [n_trees, to = std::vector<int64_t>(tree_offsets, tree_offsets + n_trees + 1), l = std::vector<int32_t>(left, left + nn),
-                 r = std::vector<int32_t>(right, right + nn), st = std::vector<int32_t>(status, status + nn),
-                 bv = std::vector<int32_t>(best_var, best_var + nn), sp = std::vector<double>(split, split + nn),
-                 np_ = std::vector<double>(node_pred, node_pred + nn), p](mhs_model **o) {
-        return mhs_rf_load(n_trees, to.data(), l.data(), r.data(), st.data(), bv.data(), sp.data(), np_.data(), p, o);
     };
     *out = m;
     return MHS_OK;
