@@ -52,8 +52,10 @@ struct Context {
     double *exp_tab = nullptr;   // device, 4096 entries 2^(j/4096) (svr_kernel)
     double *points_arena = nullptr;       // grow-only device scratch of mhs_residual_points
     size_t points_arena_cap = 0;          // in doubles
-    char *mosaic_arena = nullptr;         // grow-only device scratch of mhs_mosaic_feather_dev (sums, counts, seam boxes)
-    size_t mosaic_arena_cap = 0;          // in bytes
+    // grow-only device scratch of mhs_mosaic_feather_dev (sums, counts, seam boxes), one per mosaic lane: lane 0 = the calling
+    // thread's own mosaics (Step 3 + 4 inside a tile), lane 1 = the merging helper threads of multi.hip, which run beside them
+    char *mosaic_arena[2] = {nullptr, nullptr};
+    size_t mosaic_arena_cap[2] = {0, 0};  // in bytes
     double *surface_arena = nullptr;      // grow-only device scratch of mhs_tps_surface (the tiles' keep windows)
     size_t surface_arena_cap = 0;         // in doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -95,7 +97,9 @@ struct SlotBind {                     // RAII: bind for a scope, restore the pre
 std::mutex &pipe_mutex();             // one pipelined host-pointer call at a time (per slot)
 int host_pipe(size_t arena_bytes);    // streams / events on first use; grows the arena (grow-only) to at least arena_bytes
 std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences (per slot)
-std::mutex &mosaic_mutex();           // one user of the slot's mosaic arena at a time
+std::mutex &mosaic_mutex();           // one user of the slot's mosaic arena (of the calling thread's lane) at a time
+int mosaic_lane();                    // the calling thread's mosaic lane (0 unless set)
+void set_mosaic_lane(int lane);
 Context &ctx();                       // the current slot's context
 Context &ctx_slot(int slot);
 int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)

@@ -904,12 +904,25 @@ int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, 
 namespace {
 
 struct UnitSlot {                 // what one slot keeps while its units run
-    int tile = -1;                // the tile whose covariates are resident
-    char *cov = nullptr;
-    size_t cov_cap = 0;
+    std::vector<char *> cov;      // tile t's covariate rows x cols, uploaded when the slot's first unit of the tile starts
     double *ens = nullptr, *tps = nullptr;      // scratch planes of the largest tile
     std::vector<double *> merge_in;             // a layer's tile planes on the merging slot
     double *merged = nullptr;
+};
+
+// which response layers have all their tiles final (the merging slots wait on it)
+struct LayerBoard {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int64_t> done;
+    bool stop = false;
+    void finished(int l) { std::lock_guard<std::mutex> lk(mu); ++done[(size_t)l]; cv.notify_all(); }
+    void abort() { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+    bool wait(int l, int64_t n_tiles) {       // false: the call failed somewhere
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || done[(size_t)l] >= n_tiles; });
+        return !stop;
+    }
 };
 
 }  // namespace
@@ -942,12 +955,15 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
     std::vector<double *> plane((size_t)n_units, nullptr);          // unit u's final plane, on its owner's device
     std::vector<double> rsq_model((size_t)n_units, NAN), rsq_final((size_t)n_units, NAN), unit_ms((size_t)n_units, 0.0);
     std::vector<UnitSlot> us((size_t)N);
+    LayerBoard board;
+    board.done.assign((size_t)n_layers, 0);
     Team team(N);
     const int rc = team.run([&](int slot) {
         UnitSlot &L = us[(size_t)slot];
         MultiSlot *M = nullptr;
         TEAM_DO(team, multi_slot(slot, &M));
         auto alloc = [&]() -> int {
+            L.cov.assign((size_t)n_tiles, nullptr);
             MHS_HIP(hipMalloc((void **)&L.ens, sizeof(double) * (size_t)max_cells));
             if (tps) MHS_HIP(hipMalloc((void **)&L.tps, sizeof(double) * (size_t)max_cells));
             return MHS_OK;
@@ -956,6 +972,46 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         // a tile's response layers share its stations: the Step-3 tiles' reductions are built by the first layer this slot
         // runs on the tile and reused by the others (bit-identical fits); nothing outlives the call
         TEAM_DO(team, mhs_tps_reduction_cache(1));
+        // ---- machisplin.tiles.merge (V73:1392-1548) of layer l on slot l mod N, by a helper thread of that slot: as soon as
+        // the layer's last tile is final anywhere its tiles come over xGMI, are mosaicked and feathered on the slot's second
+        // stream and go down to the caller's plane -- under the units of the following layers (the copy to pageable memory
+        // blocks its thread, which is why it has its own)
+        std::thread merger;
+        {
+            bool any = false;
+            for (int l = slot; l < n_layers; l += N) any = any || merged_host[l] != nullptr;
+            if (any && !team.failed()) merger = std::thread([&, slot] {
+                SlotBind bind(slot);
+                set_mosaic_lane(1);              // its own scratch: the units' Step-3 / Step-4 mosaics do not wait for a merge
+                for (int l = slot; l < n_layers; l += N) {
+                    if (!merged_host[l]) continue;
+                    if (!board.wait(l, n_tiles)) return;
+                    auto merge = [&]() -> int {
+                        if (L.merge_in.empty()) {
+                            L.merge_in.assign((size_t)n_tiles, nullptr);
+                            for (int64_t t = 0; t < n_tiles; ++t)
+                                MHS_HIP(hipMalloc((void **)&L.merge_in[(size_t)t], sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]))));
+                            MHS_HIP(hipMalloc((void **)&L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol));
+                        }
+                        std::vector<const double *> ptrs((size_t)n_tiles);
+                        for (int64_t t = 0; t < n_tiles; ++t) {
+                            const int64_t u = (int64_t)l * n_tiles + t;
+                            const int owner = (int)(u % N);
+                            const size_t bytes = sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]));
+                            if (owner == slot) { ptrs[(size_t)t] = plane[(size_t)u]; continue; }
+                            MHS_HIP(hipMemcpyPeerAsync(L.merge_in[(size_t)t], ctx_slot(slot).device, plane[(size_t)u], ctx_slot(owner).device, bytes, M->u));
+                            ptrs[(size_t)t] = L.merge_in[(size_t)t];
+                        }
+                        if (int rc2 = mhs_mosaic_feather_dev(g, out_nrow, out_ncol, win.data(), ptrs.data(), 1, L.merged, g->ncol, nullptr, M->u)) return rc2;
+                        MHS_HIP(hipMemcpyAsync(merged_host[l], L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol, hipMemcpyDeviceToHost, M->u));
+                        MHS_HIP(hipStreamSynchronize(M->u));
+                        return MHS_OK;
+                    };
+                    const int rcm = merge();
+                    if (rcm) { team.fail(rcm); board.abort(); (void)hipStreamSynchronize(M->u); return; }
+                }
+            });
+        }
         // ---- this slot's units, layer-major (u = layer * n_tiles + tile, slot u mod N: sharded.unit_owner)
         for (int64_t u = slot; u < n_units && !team.failed(); u += N) {
             const int64_t t = u % n_tiles;
@@ -966,19 +1022,13 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                 const double t0 = now_ms();
                 // terra::crop(rast, e.ext[[t]]): the tile's geometry and its rows x cols of every plane (V73:1207)
                 mhs_grid gt = {g->xmin + (double)w[2] * g->xres, g->ymax - (double)w[0] * g->yres, g->xres, g->yres, nr, nc};
-                if (L.tile != (int)t) {
-                    const size_t need = (size_t)nr * (size_t)nc * esz * (size_t)C;
-                    if (need > L.cov_cap) {
-                        if (L.cov) { MHS_HIP(hipStreamSynchronize(M->s)); MHS_HIP(hipFree(L.cov)); L.cov = nullptr; L.cov_cap = 0; }
-                        MHS_HIP(hipMalloc((void **)&L.cov, need));
-                        L.cov_cap = need;
-                    }
+                if (!L.cov[(size_t)t]) {       // 288 GB of HBM: every tile this slot works on stays resident, uploaded once
+                    MHS_HIP(hipMalloc((void **)&L.cov[(size_t)t], (size_t)nr * (size_t)nc * esz * (size_t)C));
                     for (int k = 0; k < C; ++k) {
                         const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)w[0] * covars_host->ld + (size_t)w[2]) * esz;
-                        MHS_HIP(hipMemcpy2DAsync(L.cov + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
+                        MHS_HIP(hipMemcpy2DAsync(L.cov[(size_t)t] + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
                                                  (size_t)nc * esz, (size_t)nr, hipMemcpyHostToDevice, M->s));
                     }
-                    L.tile = (int)t;
                 }
                 std::vector<const mhs_model *> my((size_t)U.n_models);
                 int p0 = 0;
@@ -990,7 +1040,7 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                 }
                 MHS_HIP(hipMalloc((void **)&plane[(size_t)u], sizeof(double) * (size_t)nr * (size_t)nc));
                 // Step 2 (V73:447-620)
-                if (int rc2 = ensemble_band_dev(my.data(), U.weights, U.n_models, U.wt_total, &gt, L.cov, C, covars_host->dtype, nc,
+                if (int rc2 = ensemble_band_dev(my.data(), U.weights, U.n_models, U.wt_total, &gt, L.cov[(size_t)t], C, covars_host->dtype, nc,
                                                 covars_host->nodata, 0, nr, L.ens, nc, M->s)) return rc2;
                 std::vector<double> res((size_t)U.n);
                 if (int rc2 = mhs_residual_points(my.data(), U.weights, U.n_models, U.wt_total, U.X, U.resp, U.n, res.data())) return rc2;
@@ -1021,40 +1071,17 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                 return MHS_OK;
             };
             TEAM_DO(team, run());
+            if (team.failed()) board.abort(); else board.finished((int)(u / n_tiles));
         }
+        if (team.failed()) board.abort();
         if (ctx().ready) (void)mhs_tps_reduction_cache(0);
-        team.bar.wait();                                               // every unit's plane is final on its owner
-        // ---- machisplin.tiles.merge (V73:1392-1548) of layer l on slot l mod N: its tiles come over xGMI
-        for (int l = slot; l < n_layers && !team.failed(); l += N) {
-            if (!merged_host[l]) continue;
-            auto merge = [&]() -> int {
-                if (L.merge_in.empty()) {
-                    L.merge_in.assign((size_t)n_tiles, nullptr);
-                    for (int64_t t = 0; t < n_tiles; ++t)
-                        MHS_HIP(hipMalloc((void **)&L.merge_in[(size_t)t], sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]))));
-                    MHS_HIP(hipMalloc((void **)&L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol));
-                }
-                std::vector<const double *> ptrs((size_t)n_tiles);
-                for (int64_t t = 0; t < n_tiles; ++t) {
-                    const int64_t u = (int64_t)l * n_tiles + t;
-                    const int owner = (int)(u % N);
-                    const size_t bytes = sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]));
-                    if (owner == slot) { ptrs[(size_t)t] = plane[(size_t)u]; continue; }
-                    MHS_HIP(hipMemcpyPeerAsync(L.merge_in[(size_t)t], ctx_slot(slot).device, plane[(size_t)u], ctx_slot(owner).device, bytes, M->s));
-                    ptrs[(size_t)t] = L.merge_in[(size_t)t];
-                }
-                if (int rc2 = mhs_mosaic_feather_dev(g, out_nrow, out_ncol, win.data(), ptrs.data(), 1, L.merged, g->ncol, nullptr, M->s)) return rc2;
-                MHS_HIP(hipMemcpyAsync(merged_host[l], L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol, hipMemcpyDeviceToHost, M->s));
-                MHS_HIP(hipStreamSynchronize(M->s));
-                return MHS_OK;
-            };
-            TEAM_DO(team, merge());
-        }
+        if (merger.joinable()) merger.join();
         team.bar.wait();                                               // nobody reads a unit plane any more
         if (M) (void)hipStreamSynchronize(M->s);
         for (int64_t u = slot; u < n_units; u += N) if (plane[(size_t)u]) (void)hipFree(plane[(size_t)u]);
         for (double *q : L.merge_in) if (q) (void)hipFree(q);
-        for (void *q : {(void *)L.cov, (void *)L.ens, (void *)L.tps, (void *)L.merged}) if (q) (void)hipFree(q);
+        for (char *q : L.cov) if (q) (void)hipFree(q);
+        for (void *q : {(void *)L.ens, (void *)L.tps, (void *)L.merged}) if (q) (void)hipFree(q);
     });
     if (rc) return rc;
     if (rsq) for (int64_t u = 0; u < n_units; ++u) { rsq[2 * u] = rsq_model[(size_t)u]; rsq[2 * u + 1] = rsq_final[(size_t)u]; }

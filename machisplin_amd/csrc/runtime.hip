@@ -31,7 +31,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 namespace {
 struct Slots {
     Context c[MAX_SLOTS];
-    std::mutex pipe_mu[MAX_SLOTS], mask_mu[MAX_SLOTS], mosaic_mu[MAX_SLOTS];
+    std::mutex pipe_mu[MAX_SLOTS], mask_mu[MAX_SLOTS], mosaic_mu[MAX_SLOTS][2];
     int count = 0;                        // slots 0 .. count - 1 are ready
 };
 Slots &slots() { static Slots s; return s; }
@@ -52,7 +52,10 @@ int bind_slot(int slot) {
 }
 
 std::mutex &mask_mutex() { return slots().mask_mu[t_slot]; }
-std::mutex &mosaic_mutex() { return slots().mosaic_mu[t_slot]; }
+thread_local int t_mosaic_lane = 0;
+int mosaic_lane() { return t_mosaic_lane; }
+void set_mosaic_lane(int lane) { t_mosaic_lane = lane ? 1 : 0; }
+std::mutex &mosaic_mutex() { return slots().mosaic_mu[t_slot][t_mosaic_lane]; }
 
 namespace {
 struct BlockPool {
@@ -272,7 +275,8 @@ static void shutdown_slot(int slot) {
     pool_clear();                         // (handles that outlive the shutdown release into an empty pool: ignored)
     if (c.log_tab) (void)hipFree(c.log_tab);
     if (c.surface_arena) (void)hipFree(c.surface_arena);
-    if (c.mosaic_arena) (void)hipFree(c.mosaic_arena);
+    for (char *&q : c.mosaic_arena) { if (q) (void)hipFree(q); q = nullptr; }
+    c.mosaic_arena_cap[0] = c.mosaic_arena_cap[1] = 0;
     if (c.points_arena) (void)hipFree(c.points_arena);
     if (c.exp_tab) (void)hipFree(c.exp_tab);
     if (c.upload) { (void)hipStreamSynchronize(c.upload); (void)hipStreamDestroy(c.upload); }

@@ -300,12 +300,13 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
         Context &c = ctx();
         const size_t ns_max = (size_t)seam_list(nRx, nCx).size();
         const size_t need = (size_t)cells * 18 + 16 * (ns_max + 1) + 64;
-        if (need > c.mosaic_arena_cap) {
-            if (c.mosaic_arena) { (void)hipStreamSynchronize(s); (void)hipFree(c.mosaic_arena); c.mosaic_arena = nullptr; c.mosaic_arena_cap = 0; }
-            MHS_HIP(hipMalloc((void **)&c.mosaic_arena, need));
-            c.mosaic_arena_cap = need;
+        const int lane = mosaic_lane();
+        if (need > c.mosaic_arena_cap[lane]) {
+            if (c.mosaic_arena[lane]) { (void)hipStreamSynchronize(s); (void)hipFree(c.mosaic_arena[lane]); c.mosaic_arena[lane] = nullptr; c.mosaic_arena_cap[lane] = 0; }
+            MHS_HIP(hipMalloc((void **)&c.mosaic_arena[lane], need));
+            c.mosaic_arena_cap[lane] = need;
         }
-        char *a = c.mosaic_arena;
+        char *a = c.mosaic_arena[lane];
         bsum.p = (double *)a; a += sizeof(double) * (size_t)cells;
         ssum.p = (double *)a; a += sizeof(double) * (size_t)cells;
         box.p = (int *)a; a += 16 * (ns_max + 1);

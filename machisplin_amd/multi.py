@@ -171,11 +171,13 @@ def mltps_grid_multi(geom: Geometry, planes, nodata, models, weights, wt_total, 
 
 
 def tiles_units_multi(geom: Geometry, planes, nodata, out_ncol: int, out_nrow: int, feather_d: float, units, n_layers: int,
-                      tps: bool = True, tile_edge: int | None = 1500, lambda_=None, gcv_mode: str = "fields", merge_layers=None):
+                      tps: bool = True, tile_edge: int | None = 1500, lambda_=None, gcv_mode: str = "fields", merge_layers=None,
+                      out=None):
     """machisplin.tiles.create -> mltps per (tile, layer) -> machisplin.tiles.merge over the device slots
     (mhs_tiles_units_multi).  `units[l][t]` = dict(models, weights, wt_total, X, resp) of tile t (row-major from the
     south-west) and layer l.  Returns (list of merged planes per layer -- None where `merge_layers` skips one --, rsq array
-    (n_layers, n_tiles, 2), info dict)."""
+    (n_layers, n_tiles, 2), info dict).  `out`: a list of n_layers C-contiguous float64 (nrow, ncol) arrays (None where
+    skipped) to write the merged planes into instead of new ones."""
     planes, st = _host_stack(planes, nodata)
     n_tiles = out_ncol * out_nrow
     keep = []                                   # numpy arrays and ctypes arrays the call reads
@@ -191,7 +193,13 @@ def tiles_units_multi(geom: Geometry, planes, nodata, out_ncol: int, out_nrow: i
             a.models, a.weights, a.n_models = C.cast(hs, C.POINTER(C.c_void_p)), C.cast(ws, C.POINTER(C.c_double)), len(u["models"])
             a.wt_total, a.X, a.resp, a.n = float(u["wt_total"]), X.ctypes.data, y.ctypes.data, X.shape[0]
     want = list(range(n_layers)) if merge_layers is None else list(merge_layers)
-    outs = [np.empty((geom.nrow, geom.ncol)) if l in want else None for l in range(n_layers)]
+    if out is None:
+        outs = [np.empty((geom.nrow, geom.ncol)) if l in want else None for l in range(n_layers)]
+    else:
+        outs = [out[l] if l in want else None for l in range(n_layers)]
+        for o in outs:
+            if o is not None and (o.shape != (geom.nrow, geom.ncol) or o.dtype != np.float64 or not o.flags.c_contiguous):
+                raise ValueError("out planes must be C-contiguous float64 (nrow, ncol) arrays")
     ptrs = (C.c_void_p * n_layers)(*[None if o is None else o.ctypes.data for o in outs])
     rsq = np.full((n_layers, n_tiles, 2), np.nan)
     info = _lib.UnitsInfo()
