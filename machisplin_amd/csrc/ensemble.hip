@@ -2005,7 +2005,7 @@ int mhs_ensemble_predict_dev(const mhs_model *const *models, const double *weigh
 // pays the partly filled last round of every member kernel once per band (measured: 3 bands +20 ms on a 497 ms pass).  Only
 // two things have to be banded: the FIRST member launch, so that it can start on the rows that have arrived while the rest
 // of the covariates still travels (bands of 4, 16, 40, 40 % of the rows: the exposed upload is the 4 %), and the LAST one, so
-// that finished rows travel back under the rows still being computed (40, 40, 16, 4 %: the exposed download is the 4 %).
+// that finished rows travel back under the rows still being computed (48, 30, 14, 6, 2 %: the exposed download is the 2 %; round 5: both band plans grow no faster than the copies outrun the kernels, see below).
 // Everything between them runs once over the whole window.  Per cell the members are still accumulated in the caller's
 // order, so the plane equals the one-piece evaluation bit for bit.  The window lives in the persistent arena.
 // Error returns of the host-pointer pipelines: copies between the caller's pageable buffers and the arena may still be in flight on
@@ -2034,14 +2034,26 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
     PipeDrain drain(c);
     char *in = c.pipe_arena;
     double *outp = (double *)(c.pipe_arena + in_bytes);
-    const int pct[4] = {4, 16, 40, 40};
-    int64_t up[5], down[5];
+    // Upload bands: band b + 1 must have arrived when band b's kernels end, and the copies (0.43 ms per % of cfg3's three
+    // float64 planes) are only ~2.2 x faster than the members that run on them (gbm + forest: 0.93 ms per %): with 4, 16, 40,
+    // 40 % the device waited 3 ms for the 16 % and 2 ms for the first 40 %.  Float64 planes therefore go in five bands that
+    // grow by at most that factor (3, 6, 13, 28, 50 %); float32 / int16 planes (half / a quarter of the bytes) keep four.
+    const bool wide = covars->dtype == MHS_F64;
+    const int NU = wide ? 5 : 4;
+    const int pct_up5[5] = {3, 6, 13, 28, 50}, pct_up4[4] = {4, 16, 40, 40};
+    // ... and the last member (ksvm: 1.1 ms per %) runs ~2.3 x slower than its rows travel down (0.48 ms per %): the same rule mirrored
+    constexpr int ND = 5;
+    const int pct_down[ND] = {48, 30, 14, 6, 2};
+    int64_t up[6], down[ND + 1];
     up[0] = down[0] = r0;
-    for (int b = 0, a = 0, d = 0; b < 4; ++b) {
-        a += pct[b]; d += pct[3 - b];
-        // cut at multiples of BAND_ALIGN grid rows (gbm_coherent_kernel's tiles are anchored to the grid: a band sees whole tiles)
-        up[b + 1] = b == 3 ? r1 : std::min(r1, std::max(r0, (r0 + nr * a / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
-        down[b + 1] = b == 3 ? r1 : std::min(r1, std::max(r0, (r0 + nr * d / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
+    // cut at multiples of BAND_ALIGN grid rows (gbm_coherent_kernel's tiles are anchored to the grid: a band sees whole tiles)
+    for (int b = 0, a = 0; b < NU; ++b) {
+        a += wide ? pct_up5[b] : pct_up4[b];
+        up[b + 1] = b == NU - 1 ? r1 : std::min(r1, std::max(up[b], (r0 + nr * a / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
+    }
+    for (int b = 0, d = 0; b < ND; ++b) {
+        d += pct_down[b];
+        down[b + 1] = b == ND - 1 ? r1 : std::min(r1, std::max(down[b], (r0 + nr * d / 100 + BAND_ALIGN / 2) / BAND_ALIGN * BAND_ALIGN));
     }
     StackDev sd;
     sd.data = in - (size_t)r0 * covars->ld * esz; sd.C = covars->n_layers; sd.dtype = covars->dtype;
@@ -2064,14 +2076,14 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
         return launch_members(models + k0, weights + k0, k1 - k0, sd, pg, acc, outp + (size_t)(b0 - r0) * nc, c.pipe_comp, g);
     };
     if (int rc = upload(0)) return rc;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NU; ++b) {
         MHS_HIP(hipStreamWaitEvent(c.pipe_comp, c.pipe_in[b], 0));
         if (up[b + 1] > up[b]) if (int rc = members(0, first_end, up[b], up[b + 1], 0)) return rc;
-        if (b + 1 < 4) if (int rc = upload(b + 1)) return rc;
+        if (b + 1 < NU) if (int rc = upload(b + 1)) return rc;
     }
     const double t_up = now_ms();
     if (last_start > first_end) if (int rc = members(first_end, last_start, r0, r1, 1)) return rc;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < ND; ++b) {
         if (down[b + 1] > down[b]) {
             if (int rc = members(last_start, n_models, down[b], down[b + 1], 1)) return rc;
             hipLaunchKernelGGL(scale_window_kernel, dim3((unsigned)(((down[b + 1] - down[b]) * nc + 255) / 256)), dim3(256), 0, c.pipe_comp,
@@ -2080,7 +2092,7 @@ static int host_window_pipeline(const mhs_model *const *models, const double *we
         }
         MHS_HIP(hipEventRecord(c.pipe_done[b], c.pipe_comp));
     }
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < ND; ++b) {
         if (down[b + 1] == down[b]) continue;
         MHS_HIP(hipStreamWaitEvent(c.pipe_d2h, c.pipe_done[b], 0));
         MHS_HIP(hipMemcpyAsync(out_host + (size_t)(down[b] - r0) * nc, outp + (size_t)(down[b] - r0) * nc,

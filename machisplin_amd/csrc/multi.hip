@@ -51,7 +51,7 @@ struct MultiSlot {
     hipStream_t s = nullptr;                 // the band work of this slot (non-blocking)
     hipEvent_t e0 = nullptr, e1 = nullptr;   // timing of the band kernels
     hipStream_t u = nullptr;                 // host -> device copies of a band that is still travelling (mhs_mltps_grid_multi)
-    hipEvent_t up[4] = {}, dn[4] = {};       // ... one per sub-band up, one per finished sub-band down
+    hipEvent_t up[5] = {}, dn[5] = {};       // ... one per sub-band up, one per finished sub-band down
 };
 MultiSlot g_ms[MAX_SLOTS];
 std::mutex g_ms_mu;
@@ -409,16 +409,21 @@ std::vector<int> assign_tiles(const std::vector<double> &cost, int n) {
     return owner;
 }
 
-// rows [r0, r1) in four sub-bands of 4, 16, 40, 40 % (copies up: the short ones first) or 40, 40, 16, 4 % (copies down: the
-// short ones last), cut at whole 16-row tiles of the grid
-void sub_bands(int64_t r0, int64_t r1, bool down, int64_t cut[5]) {
-    const int pct[4] = {4, 16, 40, 40};
+// rows [r0, r1) in sub-bands, cut at whole 16-row tiles of the grid; returns how many.  Copies up: the short ones first -- 4,
+// 16, 40, 40 %, or for float64 planes (twice the bytes per row: the copies are then only ~2 x faster than the kernels that
+// wait for them, see host_window_pipeline in ensemble.hip) 3, 6, 13, 28, 50 %.  Copies down: the short ones last, 48, 30, 14, 6, 2 %.
+enum { BANDS_UP = 0, BANDS_UP_F64 = 1, BANDS_DOWN = 2 };
+constexpr int MAX_SUB = 5;
+int sub_bands(int64_t r0, int64_t r1, int mode, int64_t cut[MAX_SUB + 1]) {
+    static const int pct[3][MAX_SUB] = {{4, 16, 40, 40, 0}, {3, 6, 13, 28, 50}, {48, 30, 14, 6, 2}};
+    const int nq = mode == BANDS_UP ? 4 : 5;
     const int64_t nb = r1 - r0;
     cut[0] = r0;
-    for (int q = 0, a = 0; q < 4; ++q) {
-        a += pct[down ? 3 - q : q];
-        cut[q + 1] = q == 3 ? r1 : std::min(r1, std::max(cut[q], (r0 + nb * a / 100 + BAND_ROWS_ALIGN / 2) / BAND_ROWS_ALIGN * BAND_ROWS_ALIGN));
+    for (int q = 0, a = 0; q < nq; ++q) {
+        a += pct[mode][q];
+        cut[q + 1] = q == nq - 1 ? r1 : std::min(r1, std::max(cut[q], (r0 + nb * a / 100 + BAND_ROWS_ALIGN / 2) / BAND_ROWS_ALIGN * BAND_ROWS_ALIGN));
     }
+    return nq;
 }
 
 // the helper thread that sits in a slot's copies from pageable memory while the slot's own thread launches kernels
@@ -429,13 +434,13 @@ struct Uploader {
     int issued = 0, rc = MHS_OK;
     std::string err;
     template <typename F>
-    void start(int slot, F issue) {
-        th = std::thread([this, slot, issue] {
+    void start(int slot, int nq, F issue) {
+        th = std::thread([this, slot, nq, issue] {
             SlotBind bind(slot);
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < nq; ++q) {
                 const int r = issue(q);
                 std::lock_guard<std::mutex> lk(mu);
-                if (r) { rc = r; err = mhs_last_error(); issued = 4; } else issued = q + 1;
+                if (r) { rc = r; err = mhs_last_error(); issued = nq; } else issued = q + 1;
                 cv.notify_all();
                 if (r) break;
             }
@@ -558,13 +563,13 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             return mhs_tps_get(t, S.c.data(), S.d, S.knots_uv.data(), &S.lambda, S.center, S.scale, nullptr, nullptr);
         };
         // ---- Step 2 on the band (V73:447-619): enqueued, not waited for
-        // Host planes (ms->pending): the band still lies in the caller's memory.  It travels in sub-bands of 4, 16, 40, 40 % of
+        // Host planes (ms->pending): the band still lies in the caller's memory.  It travels in sub-bands of 4, 16, 40, 40 % (float64 planes: 3, 6, 13, 28, 50 %) of
         // its rows (cut at whole 16-row tiles), issued by a helper thread -- a copy from pageable memory blocks its caller until
         // staged --; every member but the last runs on a sub-band as soon as it has arrived: the exposed upload is the 4 %.
         // Slot 0 fits the spline EARLY, behind the two short sub-bands only; with the coefficients there before the last member
-        // starts, that member runs on sub-bands of 40, 40, 16, 4 % and each finished sub-band --
+        // starts, that member runs on sub-bands of 48, 30, 14, 6, 2 % and each finished sub-band --
         // scaled, final.TPS added -- goes down to the caller's plane under the next one (`piped`): the exposed download is the
-        // 4 %.  The plane that travels is pred.elev + final.TPS; should Step 5 keep pred.elev alone (V73:917-930) it is sent
+        // 2 %.  The plane that travels is pred.elev + final.TPS; should Step 5 keep pred.elev alone (V73:917-930) it is sent
         // afterwards.  Same cells, same members in the same order, same sums: same bits as the one-piece evaluation.
         const bool piped = ms->pending && ms->pending_out && !tiled;
         const int banded = n_models > 1 ? n_models - 1 : 1;
@@ -572,27 +577,27 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         if (ms->pending && nb > 0 && !team.failed()) {
             const mhs_stack *h = ms->pending;
             const size_t esz = elem_size(ms->dtype), plane = (size_t)nb * (size_t)ms->ld * esz;
-            int64_t cut[5];
-            sub_bands(b.r0, b.r1, false, cut);
+            int64_t cut[MAX_SUB + 1];
+            const int nq = sub_bands(b.r0, b.r1, ms->dtype == MHS_F64 ? BANDS_UP_F64 : BANDS_UP, cut);
             const double t0 = now_ms();
-            up.start(slot, [=, &S](int q) -> int {
-                const int64_t nq = cut[q + 1] - cut[q];
-                for (int k = 0; k < ms->C && nq > 0; ++k) {
+            up.start(slot, nq, [=, &S](int q) -> int {
+                const int64_t rows_q = cut[q + 1] - cut[q];
+                for (int k = 0; k < ms->C && rows_q > 0; ++k) {
                     const char *src = (const char *)h->data + ((size_t)k * h->plane_stride + (size_t)cut[q] * h->ld) * esz;
                     char *dst = b.cov + plane * k + (size_t)(cut[q] - b.r0) * (size_t)ms->ld * esz;
                     if (h->ld == g.ncol)
-                        MHS_HIP(hipMemcpyAsync(dst, src, (size_t)nq * (size_t)ms->ld * esz, hipMemcpyHostToDevice, M->u));
+                        MHS_HIP(hipMemcpyAsync(dst, src, (size_t)rows_q * (size_t)ms->ld * esz, hipMemcpyHostToDevice, M->u));
                     else
-                        MHS_HIP(hipMemcpy2DAsync(dst, (size_t)ms->ld * esz, src, (size_t)h->ld * esz, (size_t)g.ncol * esz, (size_t)nq,
+                        MHS_HIP(hipMemcpy2DAsync(dst, (size_t)ms->ld * esz, src, (size_t)h->ld * esz, (size_t)g.ncol * esz, (size_t)rows_q,
                                                  hipMemcpyHostToDevice, M->u));
                 }
                 MHS_HIP(hipEventRecord(M->up[q], M->u));
-                if (q == 3) S.upload_ms[slot] = now_ms() - t0;
+                if (q == nq - 1) S.upload_ms[slot] = now_ms() - t0;
                 return MHS_OK;
             });
             auto launch = [&]() -> int {
                 MHS_HIP(hipEventRecord(M->e0, M->s));
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < nq; ++q) {
                     // the fit goes in once the two short sub-bands are queued: the device has their kernels to run in the
                     // fit's thin stages, and nothing after them that could hold the fit up
                     if (q == 2 && slot == 0) if (int rc2 = fit()) return rc2;
@@ -634,9 +639,9 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                 TEAM_DO(team, tps_predict_rows_dev(tps[(size_t)slot], &g, 0, g.nrow, 0, g.ncol, b.r0, b.r1, b.tot, g.ncol, M->s));
             if (piped && nb > 0) {
                 auto down = [&]() -> int {
-                    int64_t cut[5];
-                    sub_bands(b.r0, b.r1, true, cut);
-                    for (int q = 0; q < 4; ++q) {
+                    int64_t cut[MAX_SUB + 1];
+                    const int nd = sub_bands(b.r0, b.r1, BANDS_DOWN, cut);
+                    for (int q = 0; q < nd; ++q) {
                         const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
                         if (cut[q + 1] > cut[q]) {
                             if (int rc2 = members_rows_dev(my + banded, weights + banded, n_models - banded, 1, 1, wt_total, &g, b.cov, b.r0, b.r1, ms->C,
@@ -647,11 +652,11 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                     }
                     MHS_HIP(hipEventRecord(M->e1, M->s));
                     const double t0 = now_ms();
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < nd; ++q) {
                         if (cut[q + 1] == cut[q]) continue;
                         const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
                         MHS_HIP(hipStreamWaitEvent(M->u, M->dn[q], 0));
-                        if (q == 3) S.download_ms[slot] = -now_ms();      // what is left once the last sub-band is final
+                        if (q == nd - 1) S.download_ms[slot] = -now_ms();      // what is left once the last sub-band is final
                         MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol + off, b.tot + off,
                                                sizeof(double) * (size_t)(cut[q + 1] - cut[q]) * (size_t)g.ncol, hipMemcpyDeviceToHost, M->u));
                     }
