@@ -119,6 +119,48 @@ def test_float64_and_int16_planes_and_nodata_across_slots(hip, slots4):
             assert np.isnan(got).sum() > 0
 
 
+@pytest.mark.timeout(600)
+def test_host_plane_pipeline_edge_cases(hip):
+    """mhs_mltps_grid_multi's pipeline (sub-bands up under the first members, finished sub-bands down under the last one): ONE
+    member (it is first and last at once), a band shorter than a 16-row tile (empty sub-bands), the caller's plane reused, the
+    device buffers of another shape discarded and rebuilt, and a failing call that must not leave copies in flight or the
+    library unusable."""
+    import torch
+    from machisplin_amd import multi, _lib
+    multi.init_devices(3, [0, 0, 0])
+    g, planes, nodata, xy, X, resp, models, weights, wt_total = _workload(hip, seed=23, nrow=97, ncol=130, n=300)
+    stack = hip.RasterStack(g, planes, nodata)
+    host = planes.cpu().numpy()
+    out = np.full((97, 130), -1.0)
+    for members in ([5], [0, 5], list(range(len(models)))):          # ksvm alone; gbm + ksvm; all six (synth order b g n m r v)
+        mods, wts = [models[k] for k in members], [weights[k] for k in members]
+        ref = hip.mltps_predict(stack, xy, resp, mods, wts, wt_total, tile_edge=None)
+        got, info = multi.mltps_grid_multi(g, host, nodata, mods, wts, wt_total, X, resp, out=out)
+        assert got is out and np.array_equal(out, ref["final"].cpu().numpy(), equal_nan=True), members
+        assert sum(b - a for a, b in info["bands"]) == 97 and info["n_slots"] == 3
+    # another shape in between: the cached buffers are rebuilt, then rebuilt again
+    g2, planes2, nodata2, xy2, X2, resp2, models2, weights2, wt2 = _workload(hip, seed=29, nrow=64, ncol=48, n=120)
+    ref2 = hip.mltps_predict(hip.RasterStack(g2, planes2, nodata2), xy2, resp2, models2, weights2, wt2, tile_edge=None)
+    got2, _ = multi.mltps_grid_multi(g2, planes2.cpu().numpy(), nodata2, models2, weights2, wt2, X2, resp2)
+    assert np.array_equal(got2, ref2["final"].cpu().numpy(), equal_nan=True)
+    ref = hip.mltps_predict(stack, xy, resp, models, weights, wt_total, tile_edge=None)
+    got, _ = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp)
+    assert np.array_equal(got, ref["final"].cpu().numpy(), equal_nan=True)
+    # a member with the wrong predictor count fails the call before anything is enqueued ...
+    with pytest.raises(_lib.MhsError):
+        multi.mltps_grid_multi(g, host, nodata, [hip.models.Gam(np.ones(9))], [1.0], 1.0, X, resp)
+    # ... a fit that cannot be done (all stations on one point) fails it on slot 0 while the other slots' copies are in flight
+    Xbad = X.copy()
+    Xbad[:, -2:] = X[0, -2:]
+    with pytest.raises(_lib.MhsError):
+        multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, Xbad, resp)
+    got, _ = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp)
+    assert np.array_equal(got, ref["final"].cpu().numpy(), equal_nan=True)
+    with pytest.raises(ValueError):
+        multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp, out=np.zeros((97, 131)))
+    multi.init_devices(1, [0])
+
+
 # ---------------------------------------------------------------- machisplin.tiles.* units (BASELINE config 4) --
 T_NROW, T_NCOL, T_N, T_LAYERS = 300, 380, 900, 3
 
@@ -167,6 +209,11 @@ def test_tile_layer_units_over_slots_equal_the_python_chain(hip):
     # a layer whose merge is skipped stays untouched; smooth members only (tps = False) return pred.elev
     outs, rsq, _ = multi.tiles_units_multi(g, host, nodata, 2, 2, 24, units, T_LAYERS, tps=False, tile_edge=100, merge_layers=[1])
     assert outs[0] is None and outs[2] is None and np.isnan(rsq[:, :, 1]).all()
+    # the caller's planes, reused: layers 0 and 2 are written, layer 1's plane is left alone
+    mine = [np.full((T_NROW, T_NCOL), -7.0) for _ in range(T_LAYERS)]
+    outs, _, _ = multi.tiles_units_multi(g, host, nodata, 2, 2, 24, units, T_LAYERS, tile_edge=100, merge_layers=[0, 2], out=mine)
+    assert outs[0] is mine[0] and outs[1] is None and (mine[1] == -7.0).all()
+    assert np.array_equal(mine[0], want[0], equal_nan=True) and np.array_equal(mine[2], want[2], equal_nan=True)
     multi.init_devices(1, [0])
 
 
