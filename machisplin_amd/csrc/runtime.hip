@@ -331,6 +331,21 @@ int mhs_init_devices(int n_devices, const int *device_ids) {
         }
         S.count = k + 1;
     }
+    // Peer access between every pair of distinct devices: the tile planes of multi.hip (hipMemcpyPeerAsync) then travel over
+    // xGMI directly instead of through host memory.  A pair the hardware cannot connect keeps the staged copies; nothing
+    // here is an error.
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = 0; b < n_devices; ++b) {
+            const int da = S.c[a].device, db = S.c[b].device;
+            bool seen = da == db;
+            for (int q = 0; q < b && !seen; ++q) seen = S.c[q].device == db;      // each peer once per owner
+            for (int q = 0; q < a && !seen; ++q) seen = S.c[q].device == da;
+            if (seen) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            if (hipSetDevice(da) == hipSuccess) (void)hipDeviceEnablePeerAccess(db, 0);      // "already enabled" is fine
+            (void)hipGetLastError();
+        }
     // streams (CU-masked ones among them) are destroyed while the HIP runtime is still whole, whatever the host forgets:
     // handlers run in reverse order of registration, so this one runs before the runtime's own
     static bool registered = false;
