@@ -47,7 +47,7 @@ class Model:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and _lib._lib is not None:
+        if h is not None and _lib is not None and _lib._lib is not None:      # (module globals are gone at interpreter exit)
             _lib._lib.mhs_model_free(h)
             self._h = None
 
