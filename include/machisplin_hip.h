@@ -438,9 +438,14 @@ MHS_API int mhs_multi_final_download(const mhs_multi_stack *ms, double *final_ho
 /* ... or its device pointers on one slot: the slot's rows (band_dev, ld = ncol) and, after gather, the whole grid */
 MHS_API int mhs_multi_final_dev(const mhs_multi_stack *ms, int slot, double **band_dev, int64_t *r0, int64_t *r1,
                                 double **full_dev);
-/* Host planes in, host plane out, ONE call: what the R shim binds in place of V73:447-930 for a layer (upload of the
- * bands, the steps above, download).  slot0_share NaN = automatic (equal bands, then what the last call of the same
- * shape measured).                                                                                                   */
+/* Host planes in, host plane out, ONE call: what the R shim binds in place of V73:447-930 for a layer.  The copies are
+ * inside the call and pipelined with it: every slot's band comes up in sub-bands under its first members, finished
+ * sub-bands of the sum go down under its last one (the plane equals the resident call's bit for bit).  The device buffers
+ * are kept for the next call of the same shape (released by mhs_shutdown / a call of another shape); calls from several
+ * host threads are served one after the other.  covars_host and final_host may be pageable memory and must stay valid
+ * until the call returns (also when it fails: no copy is left in flight).  slot0_share NaN = automatic (equal bands,
+ * then what the last call of the same shape measured).  info->upload_ms: time the slowest slot's copy thread spent in
+ * its copies up (most of it under kernels); info->download_ms: what was left of the copies down after the last kernel. */
 MHS_API int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, int n_models, double wt_total,
                                  const mhs_grid *g, const mhs_stack *covars_host, const double *X, const double *resp,
                                  int64_t n, int64_t tile_edge, double lambda, int gcv_mode, double slot0_share,
@@ -467,7 +472,9 @@ typedef struct mhs_units_info {
  * unit u = layer * n_tiles + tile (tiles row-major from the south-west) runs on slot u mod N with no exchange; layer l is
  * merged on slot l mod N (its tiles arrive over xGMI) and lands in merged_host[l] (nrow x ncol; a NULL entry skips the
  * layer's merge).  units[u] as above; tps = 0 returns pred.elev alone (V73:934-953); rsq (may be NULL) receives
- * rsq.model, rsq.final per unit.                                                                                     */
+ * rsq.model, rsq.final per unit.  A tile's crop of the covariate planes is uploaded once per slot that works on it and
+ * stays resident for the call; a layer is merged and written to merged_host[l] as soon as its last tile is final, by a
+ * helper thread of its slot, while the following layers' units run.                                                   */
 MHS_API int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_host, int64_t out_ncol, int64_t out_nrow,
                                   double feather_d, int n_layers, const mhs_unit *units, int tps, int64_t tile_edge,
                                   double lambda, int gcv_mode, double *const *merged_host, double *rsq,
