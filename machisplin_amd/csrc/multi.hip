@@ -52,6 +52,7 @@ struct MultiSlot {
     hipEvent_t e0 = nullptr, e1 = nullptr;   // timing of the band kernels
     hipStream_t u = nullptr;                 // host -> device copies of a band that is still travelling (mhs_mltps_grid_multi)
     hipEvent_t up[5] = {}, dn[5] = {};       // ... one per sub-band up, one per finished sub-band down
+    hipStream_t h = nullptr;                 // mhs_tiles_units_multi: the tiles' covariate crops, uploaded ahead of their first unit
 };
 MultiSlot g_ms[MAX_SLOTS];
 std::mutex g_ms_mu;
@@ -64,6 +65,7 @@ int multi_slot(int slot, MultiSlot **out) {   // call with the thread bound to `
         MHS_HIP(hipEventCreate(&m.e0));
         MHS_HIP(hipEventCreate(&m.e1));
         MHS_HIP(hipStreamCreateWithFlags(&m.u, hipStreamNonBlocking));
+        MHS_HIP(hipStreamCreateWithFlags(&m.h, hipStreamNonBlocking));
         for (hipEvent_t &e : m.up) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (hipEvent_t &e : m.dn) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -310,6 +312,7 @@ void mhs::multi_reset() {
             (void)hipStreamSynchronize(m.s); (void)hipStreamDestroy(m.s);
             (void)hipEventDestroy(m.e0); (void)hipEventDestroy(m.e1);
             if (m.u) { (void)hipStreamSynchronize(m.u); (void)hipStreamDestroy(m.u); }
+            if (m.h) { (void)hipStreamSynchronize(m.h); (void)hipStreamDestroy(m.h); }
             for (hipEvent_t e : m.up) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : m.dn) if (e) (void)hipEventDestroy(e);
         }
@@ -977,6 +980,30 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         // a tile's response layers share its stations: the Step-3 tiles' reductions are built by the first layer this slot
         // runs on the tile and reused by the others (bit-identical fits); nothing outlives the call
         TEAM_DO(team, mhs_tps_reduction_cache(1));
+        // ---- terra::crop of every tile this slot works on (V73:1207), uploaded by a helper thread in the order of first use, ahead
+        // of the units: only the first tile's copy is waited for with nothing to run (288 GB of HBM: every crop stays resident)
+        std::vector<int64_t> order;
+        std::vector<int> pos((size_t)n_tiles, -1);
+        for (int64_t u = slot; u < n_units; u += N)
+            if (pos[(size_t)(u % n_tiles)] < 0) { pos[(size_t)(u % n_tiles)] = (int)order.size(); order.push_back(u % n_tiles); }
+        std::vector<hipEvent_t> tev(order.size(), nullptr);
+        Uploader pre;
+        if (!order.empty() && !team.failed())
+            pre.start(slot, (int)order.size(), [&](int q) -> int {
+                const int64_t t = order[(size_t)q];
+                const int64_t *w = &win[(size_t)t * 4];
+                const int64_t nr = w[1] - w[0], nc = w[3] - w[2];
+                MHS_HIP(hipMalloc((void **)&L.cov[(size_t)t], (size_t)nr * (size_t)nc * esz * (size_t)C));
+                for (int k = 0; k < C; ++k) {
+                    const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)w[0] * covars_host->ld + (size_t)w[2]) * esz;
+                    MHS_HIP(hipMemcpy2DAsync(L.cov[(size_t)t] + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
+                                             (size_t)nc * esz, (size_t)nr, hipMemcpyHostToDevice, M->h));
+                }
+                MHS_HIP(hipEventCreateWithFlags(&tev[(size_t)q], hipEventDisableTiming));
+                MHS_HIP(hipEventRecord(tev[(size_t)q], M->h));
+                return MHS_OK;
+            });
+        std::vector<char> ready((size_t)n_tiles, 0);
         // ---- machisplin.tiles.merge (V73:1392-1548) of layer l on slot l mod N, by a helper thread of that slot: as soon as
         // the layer's last tile is final anywhere its tiles come over xGMI, are mosaicked and feathered on the slot's second
         // stream and go down to the caller's plane -- under the units of the following layers (the copy to pageable memory
@@ -1027,13 +1054,10 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                 const double t0 = now_ms();
                 // terra::crop(rast, e.ext[[t]]): the tile's geometry and its rows x cols of every plane (V73:1207)
                 mhs_grid gt = {g->xmin + (double)w[2] * g->xres, g->ymax - (double)w[0] * g->yres, g->xres, g->yres, nr, nc};
-                if (!L.cov[(size_t)t]) {       // 288 GB of HBM: every tile this slot works on stays resident, uploaded once
-                    MHS_HIP(hipMalloc((void **)&L.cov[(size_t)t], (size_t)nr * (size_t)nc * esz * (size_t)C));
-                    for (int k = 0; k < C; ++k) {
-                        const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)w[0] * covars_host->ld + (size_t)w[2]) * esz;
-                        MHS_HIP(hipMemcpy2DAsync(L.cov[(size_t)t] + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
-                                                 (size_t)nc * esz, (size_t)nr, hipMemcpyHostToDevice, M->s));
-                    }
+                if (!ready[(size_t)t]) {       // the tile's crop is (being) uploaded by the helper: this stream waits for it once
+                    if (int rc2 = pre.wait(pos[(size_t)t])) return rc2;
+                    MHS_HIP(hipStreamWaitEvent(M->s, tev[(size_t)pos[(size_t)t]], 0));
+                    ready[(size_t)t] = 1;
                 }
                 std::vector<const mhs_model *> my((size_t)U.n_models);
                 int p0 = 0;
@@ -1080,6 +1104,9 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         }
         if (team.failed()) board.abort();
         if (ctx().ready) (void)mhs_tps_reduction_cache(0);
+        pre.join();
+        if (M && M->h) (void)hipStreamSynchronize(M->h);       // the caller's planes are not read after the call, whatever happened
+        for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
         if (merger.joinable()) merger.join();
         team.bar.wait();                                               // nobody reads a unit plane any more
         if (M) (void)hipStreamSynchronize(M->s);
