@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
@@ -64,8 +65,13 @@ int multi_slot(int slot, MultiSlot **out) {   // call with the thread bound to `
         MHS_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
         MHS_HIP(hipEventCreate(&m.e0));
         MHS_HIP(hipEventCreate(&m.e1));
-        MHS_HIP(hipStreamCreateWithFlags(&m.u, hipStreamNonBlocking));
-        MHS_HIP(hipStreamCreateWithFlags(&m.h, hipStreamNonBlocking));
+        // the copy streams at the LOWEST priority: streams of one priority share a few hardware queues, and a 32 MB copy chunk at the
+        // head of a queue holds up every small kernel behind it -- measured on cfg4: the merged layers' copies down (on a stream of
+        // the default priority) cost the units beside them as much time as the copies took
+        int prio_lo = 0, prio_hi = 0;
+        MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MHS_HIP(hipStreamCreateWithPriority(&m.u, hipStreamNonBlocking, prio_lo));
+        MHS_HIP(hipStreamCreateWithPriority(&m.h, hipStreamNonBlocking, prio_lo));
         for (hipEvent_t &e : m.up) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (hipEvent_t &e : m.dn) MHS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -278,6 +284,107 @@ std::mutex g_balance_mu;
 // mhs_mltps_grid_multi's device buffers, kept between calls of the same shape (no hipMalloc / hipFree of gigabytes per layer)
 mhs_multi_stack *g_host_ms = nullptr;
 std::mutex g_host_mu;
+// mhs_tiles_units_multi's device memory, one grow-only arena per slot kept between calls: hipMalloc / hipFree cost ~35 ms per
+// GB here, and a cfg4 call needs 14 GB (crops, scratch, 48 unit planes, merge buffers) -- 0.4 s of a 0.84 s call went there
+struct UnitsArena { char *base = nullptr; size_t cap = 0; };
+UnitsArena g_units_arena[MAX_SLOTS];
+
+// Device -> pageable host memory through the library's own pinned ring (per slot, kept between calls): the runtime's path for a
+// pageable destination is ONE thread copying out of its staging buffer (16-20 GB/s here) and, measured on cfg4, slows the
+// kernels beside it by a quarter.  Here a chunk travels by DMA into a pinned buffer, and SINK_THREADS host threads copy finished
+// chunks to their place, several at a time.
+constexpr int RING_BUFS = 8, SINK_THREADS = 3;
+constexpr size_t RING_CHUNK = (size_t)8 << 20;
+struct PinnedRing { char *buf[RING_BUFS] = {}; hipEvent_t ev[RING_BUFS] = {}; bool ok = false; };
+PinnedRing g_ring[MAX_SLOTS];
+
+int ring_prepare(int slot) {                     // call with the thread bound to `slot`
+    PinnedRing &R = g_ring[slot];
+    if (R.ok) return MHS_OK;
+    for (int b = 0; b < RING_BUFS; ++b) {
+        if (!R.buf[b]) MHS_HIP(hipHostMalloc((void **)&R.buf[b], RING_CHUNK, hipHostMallocDefault));
+        if (!R.ev[b]) MHS_HIP(hipEventCreateWithFlags(&R.ev[b], hipEventDisableTiming));
+    }
+    R.ok = true;
+    return MHS_OK;
+}
+
+class HostSink {
+  public:
+    HostSink(int slot, hipStream_t st) : slot_(slot), st_(st), R_(g_ring[slot]) {
+        for (int b = 0; b < RING_BUFS; ++b) free_[b] = true;
+        for (int w = 0; w < SINK_THREADS; ++w) th_.emplace_back([this] { work(); });
+    }
+    ~HostSink() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    // bytes from device memory (src, on this slot's device) to dst; returns when every byte is in place
+    int download(void *dst, const void *src, size_t bytes) {
+        size_t off = 0;
+        for (int c = 0; off < bytes; ++c) {
+            const size_t sz = std::min(RING_CHUNK, bytes - off);
+            int b = -1;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { for (int q = 0; q < RING_BUFS; ++q) if (free_[q]) { b = q; return true; } return false; });
+                free_[b] = false;
+            }
+            hipError_t e = hipMemcpyAsync(R_.buf[b], (const char *)src + off, sz, hipMemcpyDeviceToHost, st_);
+            if (e == hipSuccess) e = hipEventRecord(R_.ev[b], st_);
+            if (e != hipSuccess) {
+                set_error("HostSink: %s", hipGetErrorString(e));
+                std::lock_guard<std::mutex> lk(mu_);
+                free_[b] = true; rc_ = MHS_ERR_HIP;
+                break;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                jobs_.push_back(Job{b, (char *)dst + off, sz});
+                ++pending_;
+            }
+            cv_.notify_all();
+            off += sz;
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return pending_ == 0; });
+        return rc_;
+    }
+
+  private:
+    struct Job { int b; char *dst; size_t sz; };
+    void work() {
+        SlotBind bind(slot_);
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;
+                j = jobs_.front(); jobs_.pop_front();
+            }
+            const hipError_t e = hipEventSynchronize(R_.ev[j.b]);
+            if (e == hipSuccess) memcpy(j.dst, R_.buf[j.b], j.sz);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (e != hipSuccess) rc_ = MHS_ERR_HIP;
+                free_[j.b] = true; --pending_;
+            }
+            cv_.notify_all();
+        }
+    }
+    int slot_;
+    hipStream_t st_;
+    PinnedRing &R_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Job> jobs_;
+    bool free_[RING_BUFS];
+    int pending_ = 0, rc_ = MHS_OK;
+    bool stop_ = false;
+};
 
 int free_stack(mhs_multi_stack *ms) {
     if (!ms) return MHS_OK;
@@ -301,6 +408,18 @@ void mhs::multi_reset() {
         std::lock_guard<std::mutex> lk(g_host_mu);
         if (g_host_ms) { bool alive = true; for (int k = 0; k < g_host_ms->n; ++k) alive = alive && ctx_slot(k).ready; if (alive) free_stack(g_host_ms); else delete g_host_ms; }
         g_host_ms = nullptr;
+        for (int k = 0; k < MAX_SLOTS; ++k) {
+            if (g_units_arena[k].base && ctx_slot(k).ready) { SlotBind bind(k); (void)hipFree(g_units_arena[k].base); }
+            g_units_arena[k] = UnitsArena();
+            if (ctx_slot(k).ready) {
+                SlotBind bind(k);
+                for (int b = 0; b < RING_BUFS; ++b) {
+                    if (g_ring[k].buf[b]) (void)hipHostFree(g_ring[k].buf[b]);
+                    if (g_ring[k].ev[b]) (void)hipEventDestroy(g_ring[k].ev[b]);
+                }
+            }
+            g_ring[k] = PinnedRing();
+        }
     }
     rccl_reset();
     std::lock_guard<std::mutex> lk(g_ms_mu);
@@ -911,7 +1030,7 @@ int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, 
 // ------------------------------------------------------------------------------- (tile, layer) units --
 namespace {
 
-struct UnitSlot {                 // what one slot keeps while its units run
+struct UnitSlot {                 // what one slot uses while its units run (all of it carved out of the slot's UnitsArena)
     std::vector<char *> cov;      // tile t's covariate rows x cols, uploaded when the slot's first unit of the tile starts
     double *ens = nullptr, *tps = nullptr;      // scratch planes of the largest tile
     std::vector<double *> merge_in;             // a layer's tile planes on the merging slot
@@ -959,6 +1078,7 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         MHS_REQUIRE(U.models && U.weights && U.n_models >= 1 && U.n_models <= 8 && U.X && U.resp && U.n > 3, "bad unit");
         MHS_REQUIRE(U.wt_total != 0.0 && !std::isnan(U.wt_total), "a unit's wt_total must be non-zero");
     }
+    std::lock_guard<std::mutex> arena_lk(g_host_mu);                // the slots' arenas serve one call at a time
     const double t_start = now_ms();
     std::vector<double *> plane((size_t)n_units, nullptr);          // unit u's final plane, on its owner's device
     std::vector<double> rsq_model((size_t)n_units, NAN), rsq_final((size_t)n_units, NAN), unit_ms((size_t)n_units, 0.0);
@@ -971,9 +1091,39 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         MultiSlot *M = nullptr;
         TEAM_DO(team, multi_slot(slot, &M));
         auto alloc = [&]() -> int {
+            // everything this slot needs, carved out of its arena: the crops of its tiles, two scratch planes, its units' final
+            // planes and -- if it merges a layer -- every tile's plane once more and the merged grid
+            auto cells_of = [&](int64_t t) { return (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2])); };
+            auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+            std::vector<char> mine((size_t)n_tiles, 0);
+            size_t need = 2 * up(sizeof(double) * (size_t)max_cells);
+            for (int64_t u = slot; u < n_units; u += N) { mine[(size_t)(u % n_tiles)] = 1; need += up(sizeof(double) * cells_of(u % n_tiles)); }
+            for (int64_t t = 0; t < n_tiles; ++t) if (mine[(size_t)t]) need += up(cells_of(t) * esz * (size_t)C);
+            bool merges = false;
+            for (int l = slot; l < n_layers; l += N) merges = merges || merged_host[l] != nullptr;
+            if (merges) {
+                for (int64_t t = 0; t < n_tiles; ++t) need += up(sizeof(double) * cells_of(t));
+                need += up(sizeof(double) * (size_t)g->nrow * (size_t)g->ncol);
+            }
+            UnitsArena &A = g_units_arena[slot];
+            if (need > A.cap) {
+                if (A.base) { MHS_HIP(hipDeviceSynchronize()); MHS_HIP(hipFree(A.base)); A.base = nullptr; A.cap = 0; }
+                MHS_HIP(hipMalloc((void **)&A.base, need));
+                A.cap = need;
+            }
+            char *q = A.base;
+            auto take = [&](size_t bytes) { char *r = q; q += up(bytes); return r; };
+            L.ens = (double *)take(sizeof(double) * (size_t)max_cells);
+            L.tps = (double *)take(sizeof(double) * (size_t)max_cells);
             L.cov.assign((size_t)n_tiles, nullptr);
-            MHS_HIP(hipMalloc((void **)&L.ens, sizeof(double) * (size_t)max_cells));
-            if (tps) MHS_HIP(hipMalloc((void **)&L.tps, sizeof(double) * (size_t)max_cells));
+            for (int64_t t = 0; t < n_tiles; ++t) if (mine[(size_t)t]) L.cov[(size_t)t] = take(cells_of(t) * esz * (size_t)C);
+            for (int64_t u = slot; u < n_units; u += N)        // (read by other slots' mergers only after the unit is reported finished)
+                plane[(size_t)u] = (double *)take(sizeof(double) * cells_of(u % n_tiles));
+            if (merges) {
+                L.merge_in.assign((size_t)n_tiles, nullptr);
+                for (int64_t t = 0; t < n_tiles; ++t) L.merge_in[(size_t)t] = (double *)take(sizeof(double) * cells_of(t));
+                L.merged = (double *)take(sizeof(double) * (size_t)g->nrow * (size_t)g->ncol);
+            }
             return MHS_OK;
         };
         TEAM_DO(team, alloc());
@@ -993,7 +1143,6 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                 const int64_t t = order[(size_t)q];
                 const int64_t *w = &win[(size_t)t * 4];
                 const int64_t nr = w[1] - w[0], nc = w[3] - w[2];
-                MHS_HIP(hipMalloc((void **)&L.cov[(size_t)t], (size_t)nr * (size_t)nc * esz * (size_t)C));
                 for (int k = 0; k < C; ++k) {
                     const char *src = (const char *)covars_host->data + ((size_t)k * covars_host->plane_stride + (size_t)w[0] * covars_host->ld + (size_t)w[2]) * esz;
                     MHS_HIP(hipMemcpy2DAsync(L.cov[(size_t)t] + (size_t)k * (size_t)nr * (size_t)nc * esz, (size_t)nc * esz, src, (size_t)covars_host->ld * esz,
@@ -1015,16 +1164,12 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
             if (any && !team.failed()) merger = std::thread([&, slot] {
                 SlotBind bind(slot);
                 set_mosaic_lane(1);              // its own scratch: the units' Step-3 / Step-4 mosaics do not wait for a merge
+                if (const int rcr = ring_prepare(slot)) { team.fail(rcr); board.abort(); return; }
+                HostSink sink(slot, M->u);
                 for (int l = slot; l < n_layers; l += N) {
                     if (!merged_host[l]) continue;
                     if (!board.wait(l, n_tiles)) return;
                     auto merge = [&]() -> int {
-                        if (L.merge_in.empty()) {
-                            L.merge_in.assign((size_t)n_tiles, nullptr);
-                            for (int64_t t = 0; t < n_tiles; ++t)
-                                MHS_HIP(hipMalloc((void **)&L.merge_in[(size_t)t], sizeof(double) * (size_t)((win[4 * t + 1] - win[4 * t]) * (win[4 * t + 3] - win[4 * t + 2]))));
-                            MHS_HIP(hipMalloc((void **)&L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol));
-                        }
                         std::vector<const double *> ptrs((size_t)n_tiles);
                         for (int64_t t = 0; t < n_tiles; ++t) {
                             const int64_t u = (int64_t)l * n_tiles + t;
@@ -1035,9 +1180,7 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                             ptrs[(size_t)t] = L.merge_in[(size_t)t];
                         }
                         if (int rc2 = mhs_mosaic_feather_dev(g, out_nrow, out_ncol, win.data(), ptrs.data(), 1, L.merged, g->ncol, nullptr, M->u)) return rc2;
-                        MHS_HIP(hipMemcpyAsync(merged_host[l], L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol, hipMemcpyDeviceToHost, M->u));
-                        MHS_HIP(hipStreamSynchronize(M->u));
-                        return MHS_OK;
+                        return sink.download(merged_host[l], L.merged, sizeof(double) * (size_t)g->nrow * (size_t)g->ncol);
                     };
                     const int rcm = merge();
                     if (rcm) { team.fail(rcm); board.abort(); (void)hipStreamSynchronize(M->u); return; }
@@ -1067,7 +1210,6 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
                     MHS_REQUIRE(p0 == p, "a unit's model does not match the stack (layers + 2 predictors)");
                     if (int rc2 = model_on_slot(U.models[k], slot, &my[(size_t)k])) return rc2;
                 }
-                MHS_HIP(hipMalloc((void **)&plane[(size_t)u], sizeof(double) * (size_t)nr * (size_t)nc));
                 // Step 2 (V73:447-620)
                 if (int rc2 = ensemble_band_dev(my.data(), U.weights, U.n_models, U.wt_total, &gt, L.cov[(size_t)t], C, covars_host->dtype, nc,
                                                 covars_host->nodata, 0, nr, L.ens, nc, M->s)) return rc2;
@@ -1110,10 +1252,6 @@ extern "C" int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_
         if (merger.joinable()) merger.join();
         team.bar.wait();                                               // nobody reads a unit plane any more
         if (M) (void)hipStreamSynchronize(M->s);
-        for (int64_t u = slot; u < n_units; u += N) if (plane[(size_t)u]) (void)hipFree(plane[(size_t)u]);
-        for (double *q : L.merge_in) if (q) (void)hipFree(q);
-        for (char *q : L.cov) if (q) (void)hipFree(q);
-        for (void *q : {(void *)L.ens, (void *)L.tps, (void *)L.merged}) if (q) (void)hipFree(q);
     });
     if (rc) return rc;
     if (rsq) for (int64_t u = 0; u < n_units; ++u) { rsq[2 * u] = rsq_model[(size_t)u]; rsq[2 * u + 1] = rsq_final[(size_t)u]; }

@@ -120,8 +120,12 @@ std::mutex &pipe_mutex() { return slots().pipe_mu[t_slot]; }
 int host_pipe(size_t arena_bytes) {
     Context &c = ctx();
     if (!c.pipe_h2d) {
-        MHS_HIP(hipStreamCreateWithFlags(&c.pipe_h2d, hipStreamNonBlocking));
-        MHS_HIP(hipStreamCreateWithFlags(&c.pipe_d2h, hipStreamNonBlocking));
+        // copy streams at the lowest priority: they then do not share a hardware queue with a kernel stream, where a large copy
+        // chunk would hold up every kernel queued behind it (multi.hip measured that on cfg4)
+        int prio_lo = 0, prio_hi = 0;
+        MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MHS_HIP(hipStreamCreateWithPriority(&c.pipe_h2d, hipStreamNonBlocking, prio_lo));
+        MHS_HIP(hipStreamCreateWithPriority(&c.pipe_d2h, hipStreamNonBlocking, prio_lo));
         MHS_HIP(hipStreamCreateWithFlags(&c.pipe_comp, hipStreamNonBlocking));
         for (int i = 0; i < 8; ++i) {
             MHS_HIP(hipEventCreateWithFlags(&c.pipe_in[i], hipEventDisableTiming));
