@@ -474,7 +474,9 @@ typedef struct mhs_units_info {
  * layer's merge).  units[u] as above; tps = 0 returns pred.elev alone (V73:934-953); rsq (may be NULL) receives
  * rsq.model, rsq.final per unit.  A tile's crop of the covariate planes is uploaded once per slot that works on it and
  * stays resident for the call; a layer is merged and written to merged_host[l] as soon as its last tile is final, by a
- * helper thread of its slot, while the following layers' units run.                                                   */
+ * helper thread of its slot, while the following layers' units run.  Every slot keeps ONE device arena (crops, scratch, unit
+ * planes, merge buffers: 14 GB for 4 x 12 units on a 10 000 x 10 000 grid) and a 64 MB pinned ring between calls; both are
+ * released by mhs_shutdown.  Calls from several host threads are served one after the other.                             */
 MHS_API int mhs_tiles_units_multi(const mhs_grid *g, const mhs_stack *covars_host, int64_t out_ncol, int64_t out_nrow,
                                   double feather_d, int n_layers, const mhs_unit *units, int tps, int64_t tile_edge,
                                   double lambda, int gcv_mode, double *const *merged_host, double *rsq,
