@@ -98,6 +98,7 @@ std::mutex &pipe_mutex();             // one pipelined host-pointer call at a ti
 int host_pipe(size_t arena_bytes);    // streams / events on first use; grows the arena (grow-only) to at least arena_bytes
 std::mutex &mask_mutex();             // guards the fields above and the event pair's record / wait sequences (per slot)
 std::mutex &mosaic_mutex();           // one user of the slot's mosaic arena (of the calling thread's lane) at a time
+int cpu_budget();                     // CPUs this process may keep busy (hardware threads capped by the cgroup quota; tps_gcv_host.hip)
 int mosaic_lane();                    // the calling thread's mosaic lane (0 unless set)
 void set_mosaic_lane(int lane);
 Context &ctx();                       // the current slot's context

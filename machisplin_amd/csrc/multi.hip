@@ -293,7 +293,7 @@ UnitsArena g_units_arena[MAX_SLOTS];
 // pageable destination is ONE thread copying out of its staging buffer (16-20 GB/s here) and, measured on cfg4, slows the
 // kernels beside it by a quarter.  Here a chunk travels by DMA into a pinned buffer, and SINK_THREADS host threads copy finished
 // chunks to their place, several at a time.
-constexpr int RING_BUFS = 8, SINK_THREADS = 3;
+constexpr int RING_BUFS = 8, SINK_THREADS = 3;      // (fewer threads where the host has few cores per slot)
 constexpr size_t RING_CHUNK = (size_t)8 << 20;
 struct PinnedRing { char *buf[RING_BUFS] = {}; hipEvent_t ev[RING_BUFS] = {}; bool ok = false; };
 PinnedRing g_ring[MAX_SLOTS];
@@ -313,7 +313,8 @@ class HostSink {
   public:
     HostSink(int slot, hipStream_t st) : slot_(slot), st_(st), R_(g_ring[slot]) {
         for (int b = 0; b < RING_BUFS; ++b) free_[b] = true;
-        for (int w = 0; w < SINK_THREADS; ++w) th_.emplace_back([this] { work(); });
+        const int nth = std::min(SINK_THREADS, std::max(1, cpu_budget() / (4 * std::max(1, slot_count()))));
+        for (int w = 0; w < nth; ++w) th_.emplace_back([this] { work(); });
     }
     ~HostSink() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }

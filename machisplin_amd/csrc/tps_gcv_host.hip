@@ -458,6 +458,7 @@ private:
     std::atomic<uint64_t> ticket_{0};
     std::atomic<int> done_{0};
 };
+}  // namespace
 // CPUs this process may keep busy: the hardware threads, capped by the cgroup CPU quota (cpu.max of cgroup v2,
 // cfs_quota_us / cfs_period_us of v1).  Spinning workers beyond the quota get the whole cgroup throttled --
 // including the thread that feeds the GPU.
@@ -480,6 +481,7 @@ int cpu_budget() {
     if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
     return n;
 }
+namespace {
 int auto_threads() {
     if (const char *e = getenv("MHS_GCV_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
     return std::min(64, cpu_budget());
