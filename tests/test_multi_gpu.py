@@ -161,6 +161,34 @@ def test_host_plane_pipeline_edge_cases(hip):
     multi.init_devices(1, [0])
 
 
+@pytest.mark.timeout(600)
+def test_host_plane_calls_from_several_host_threads(hip):
+    """The host-plane calls keep device buffers between calls; several host threads calling at once are served one after the
+    other (ctypes releases the GIL inside the call) and every one gets the one-device plane."""
+    import threading
+    from machisplin_amd import multi
+    multi.init_devices(2, [0, 0])
+    g, planes, nodata, xy, X, resp, models, weights, wt_total = _workload(hip, seed=31, nrow=160, ncol=200, n=300)
+    ref = hip.mltps_predict(hip.RasterStack(g, planes, nodata), xy, resp, models, weights, wt_total, tile_edge=None)["final"].cpu().numpy()
+    host = planes.cpu().numpy()
+    got, errs = [None] * 4, []
+    def call(i):
+        try:
+            for _ in range(2):
+                got[i], _ = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp)
+        except Exception as e:          # noqa: BLE001 -- reported below
+            errs.append(e)
+    ths = [threading.Thread(target=call, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(got[i], ref, equal_nan=True), i
+    multi.init_devices(1, [0])
+
+
 # ---------------------------------------------------------------- machisplin.tiles.* units (BASELINE config 4) --
 T_NROW, T_NCOL, T_N, T_LAYERS = 300, 380, 900, 3
 
