@@ -970,6 +970,18 @@ class TileWorkload:
                 "host": host, "unit_s": t_unit, "gpu_over_cpu": t_unit * n_units * 1e3 / ms_per_step}
 
 
+def emit_line(obj):
+    """The ONE JSON line, as the last thing on stdout: C libraries loaded into the process (RCCL prints a version banner through
+    C stdio when its first communicator is made) are flushed first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001 -- a platform without fflush in the global namespace loses nothing
+        pass
+    sys.stdout.flush()
+    print(json.dumps(obj), flush=True)
+
+
 def main_in_library(args):
     """`--in-library`: the same step driven by ONE host process over N device slots (csrc/multi.hip).  Launched plainly
     (`python bench.py --gpus N --in-library`) or under torch.distributed.run as the driver launches bench.py -- then rank 0
@@ -1111,7 +1123,7 @@ def main_in_library(args):
                                "step_ms": hinfo["step_ms"], "planes": "%d x %s up, 1 x float64 down" % (cfg["layers"], host.dtype),
                                "equals_one_device_plane": bool(np.array_equal(got, one, equal_nan=True))}
     line["in_library"] = driver
-    print(json.dumps(line), flush=True)
+    emit_line(line)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -1194,7 +1206,7 @@ def main():
                 res["roofline"].setdefault("traffic", None)
             if not args.no_cpu_baseline and world == 1:
                 res["cpu_baseline"] = wl.cpu_baseline(res["ms_per_step"])
-            print(json.dumps(res), flush=True)
+            emit_line(res)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -1396,7 +1408,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
             ff = next((r["launch_ms"] for r in table if r["kernel"].startswith("tps_ff")), None)
             res["cpu_baseline"] = wl.cpu_baseline(res["ms_per_step"], eval_check["direct_sum_ms"] if eval_check else None, ff)
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
