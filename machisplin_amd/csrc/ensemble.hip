@@ -973,20 +973,34 @@ __global__ __launch_bounds__(1024) void gbm_coherent_kernel(const double *__rest
         for (int q = 0; q < S; ++q) w[q] = cw[q];
 #pragma unroll
         for (int q = 0; q < S; ++q) mm[q] = srange[wave * 8 + (int)(w[q] & 7u)];
-        unsigned known = 0u, nstr = 0u;
-        unsigned cl[S], vl[S];     // the straddling levels in level order: c as a float's bits; 4 * predictor | bit position << 8
-#pragma unroll
-        for (int q = 0; q < S; ++q) { cl[q] = 0u; vl[q] = 0u; }
+        // (round 5: the straddling levels are first collected as a 5-bit mask and their (c, predictor, bit position) lists are
+        // filled from it only in lanes that have any -- one at a time, most significant bit = first level -- instead of 25
+        // predicated moves per lane and chunk: the classification is the whole price of a tree without a straddling split)
+        unsigned known = 0u, smask = 0u;
 #pragma unroll
         for (int q = 0; q < S; ++q) {
             const int c = (int)(w[q] >> 3);
             const bool all1 = mm[q].y < c, all0 = mm[q].x >= c;
             if (all1) known |= 16u >> q;
-            if (!(all1 || all0)) {
-                const unsigned cb = __float_as_uint((float)c), vb = ((w[q] & 7u) << 2) | ((unsigned)(S - 1 - q) << 8);
+            if (!(all1 || all0)) smask |= 16u >> q;
+        }
+        const unsigned nstr = (unsigned)__popc(smask);
+        unsigned cl[S], vl[S];     // the straddling levels in level order: c as a float's bits; 4 * predictor | bit position << 8
 #pragma unroll
-                for (int l = 0; l < S; ++l) if (nstr == (unsigned)l) { cl[l] = cb; vl[l] = vb; }
-                ++nstr;
+        for (int q = 0; q < S; ++q) { cl[q] = 0u; vl[q] = 0u; }
+        {
+            unsigned sm = smask;
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                if (sm) {                                              // (nested: level l + 1 is looked at only behind level l)
+                    const int pos = 31 - __clz((int)sm);               // bit position of the level in the leaf index; level q = 4 - pos
+                    unsigned wq = w[S - 1];
+#pragma unroll
+                    for (int k = 0; k < S - 1; ++k) if (pos == S - 1 - k) wq = w[k];
+                    cl[l] = __float_as_uint((float)(int)(wq >> 3));
+                    vl[l] = ((wq & 7u) << 2) | ((unsigned)pos << 8);
+                    sm &= ~(1u << pos);
+                } else break;
             }
         }
         if (PROBE) {
