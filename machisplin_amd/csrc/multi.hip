@@ -694,7 +694,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         // scaled, final.TPS added -- goes down to the caller's plane under the next one (`piped`): the exposed download is the
         // 2 %.  The plane that travels is pred.elev + final.TPS; should Step 5 keep pred.elev alone (V73:917-930) it is sent
         // afterwards.  Same cells, same members in the same order, same sums: same bits as the one-piece evaluation.
-        const bool piped = ms->pending && ms->pending_out && !tiled;
+        const bool piped = ms->pending && ms->pending_out;
         const int banded = n_models > 1 ? n_models - 1 : 1;
         Uploader up;
         if (ms->pending && nb > 0 && !team.failed()) {
@@ -754,6 +754,33 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             if (slot == 0) TEAM_DO(team, fit());
         }
         team.bar.wait();                                               // residuals (and the global fit) are there
+        // the last member sub-band by sub-band, each scaled, final.TPS (b.tot) added and sent down under the next (host planes)
+        auto down = [&]() -> int {
+            int64_t cut[MAX_SUB + 1];
+            const int nd = sub_bands(b.r0, b.r1, BANDS_DOWN, cut);
+            for (int q = 0; q < nd; ++q) {
+                const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
+                if (cut[q + 1] > cut[q]) {
+                    if (int rc2 = members_rows_dev(my + banded, weights + banded, n_models - banded, 1, 1, wt_total, &g, b.cov, b.r0, b.r1, ms->C,
+                                                   ms->dtype, ms->ld, ms->nodata, cut[q], cut[q + 1], b.ens + off, g.ncol, M->s)) return rc2;
+                    if (int rc2 = mhs_scale_add_dev(b.ens + off, 1.0, b.tot + off, b.tot + off, (cut[q + 1] - cut[q]) * g.ncol, M->s)) return rc2;
+                }
+                MHS_HIP(hipEventRecord(M->dn[q], M->s));
+            }
+            MHS_HIP(hipEventRecord(M->e1, M->s));
+            const double t0 = now_ms();
+            for (int q = 0; q < nd; ++q) {
+                if (cut[q + 1] == cut[q]) continue;
+                const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
+                MHS_HIP(hipStreamWaitEvent(M->u, M->dn[q], 0));
+                if (q == nd - 1) S.download_ms[slot] = -now_ms();      // what is left once the last sub-band is final
+                MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol + off, b.tot + off,
+                                       sizeof(double) * (size_t)(cut[q + 1] - cut[q]) * (size_t)g.ncol, hipMemcpyDeviceToHost, M->u));
+            }
+            MHS_HIP(hipStreamSynchronize(M->u));
+            S.download_ms[slot] = S.download_ms[slot] < 0 ? S.download_ms[slot] + now_ms() : now_ms() - t0;
+            return MHS_OK;
+        };
         if (!tiled) {
             // ---- Step 3, global: every slot evaluates ITS rows with the whole grid's plan (V73:753)
             if (slot != 0 && nb > 0)
@@ -761,32 +788,6 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             if (nb > 0)
                 TEAM_DO(team, tps_predict_rows_dev(tps[(size_t)slot], &g, 0, g.nrow, 0, g.ncol, b.r0, b.r1, b.tot, g.ncol, M->s));
             if (piped && nb > 0) {
-                auto down = [&]() -> int {
-                    int64_t cut[MAX_SUB + 1];
-                    const int nd = sub_bands(b.r0, b.r1, BANDS_DOWN, cut);
-                    for (int q = 0; q < nd; ++q) {
-                        const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
-                        if (cut[q + 1] > cut[q]) {
-                            if (int rc2 = members_rows_dev(my + banded, weights + banded, n_models - banded, 1, 1, wt_total, &g, b.cov, b.r0, b.r1, ms->C,
-                                                           ms->dtype, ms->ld, ms->nodata, cut[q], cut[q + 1], b.ens + off, g.ncol, M->s)) return rc2;
-                            if (int rc2 = mhs_scale_add_dev(b.ens + off, 1.0, b.tot + off, b.tot + off, (cut[q + 1] - cut[q]) * g.ncol, M->s)) return rc2;
-                        }
-                        MHS_HIP(hipEventRecord(M->dn[q], M->s));
-                    }
-                    MHS_HIP(hipEventRecord(M->e1, M->s));
-                    const double t0 = now_ms();
-                    for (int q = 0; q < nd; ++q) {
-                        if (cut[q + 1] == cut[q]) continue;
-                        const size_t off = (size_t)(cut[q] - b.r0) * (size_t)g.ncol;
-                        MHS_HIP(hipStreamWaitEvent(M->u, M->dn[q], 0));
-                        if (q == nd - 1) S.download_ms[slot] = -now_ms();      // what is left once the last sub-band is final
-                        MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol + off, b.tot + off,
-                                               sizeof(double) * (size_t)(cut[q + 1] - cut[q]) * (size_t)g.ncol, hipMemcpyDeviceToHost, M->u));
-                    }
-                    MHS_HIP(hipStreamSynchronize(M->u));
-                    S.download_ms[slot] = S.download_ms[slot] < 0 ? S.download_ms[slot] + now_ms() : now_ms() - t0;
-                    return MHS_OK;
-                };
                 const int rcd = team.failed() ? MHS_OK : down();
                 if (rcd) { (void)hipStreamSynchronize(M->u); team.fail(rcd); }
             }
@@ -829,6 +830,10 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                 return MHS_OK;
             };
             TEAM_DO(team, bring());
+            if (piped && nb > 0) {
+                const int rcd = team.failed() ? MHS_OK : down();
+                if (rcd) { (void)hipStreamSynchronize(M->u); team.fail(rcd); }
+            }
         }
         // ---- Step 5 on the band (V73:906-917): sum, the stations' cells
         if (nb > 0 && !team.failed()) {
@@ -909,7 +914,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         if (tps[(size_t)slot]) { (void)mhs_tps_free(tps[(size_t)slot]); tps[(size_t)slot] = nullptr; }
     });
     if (ms->pending) {
-        ms->downloaded = !rc && ms->pending_out && !tiled;
+        ms->downloaded = !rc && ms->pending_out;
         ms->pending = nullptr; ms->pending_out = nullptr;
         ms->upload_ms = ms->download_ms = 0;
         for (int k = 0; k < N; ++k) { ms->upload_ms = std::max(ms->upload_ms, S.upload_ms[k]); ms->download_ms = std::max(ms->download_ms, S.download_ms[k]); }
@@ -1019,7 +1024,7 @@ int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, 
     int rc = mhs_mltps_grid_multi_dev(models, weights, n_models, wt_total, ms, X, resp, n, tile_edge, lambda, gcv_mode, 0, info);
     ms->pending = nullptr; ms->pending_out = nullptr;
     const double t2 = now_ms();
-    if (!rc && !ms->downloaded) rc = mhs_multi_final_download(ms, final_host);      // reference-tiled Step 3: in one piece
+    if (!rc && !ms->downloaded) rc = mhs_multi_final_download(ms, final_host);
     // upload_ms: buffers (first call of a shape) + the time the slowest slot's helper spent in its copies, most of it under that
     // slot's kernels; download_ms: the copies down that were NOT under kernels
     if (info && !rc) { info->upload_ms = (t1 - t0) + ms->upload_ms; info->download_ms = ms->downloaded ? ms->download_ms : now_ms() - t2; }
