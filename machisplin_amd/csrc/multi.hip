@@ -689,7 +689,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         // Host planes (ms->pending): the band still lies in the caller's memory.  It travels in sub-bands of 4, 16, 40, 40 % (float64 planes: 3, 6, 13, 28, 50 %) of
         // its rows (cut at whole 16-row tiles), issued by a helper thread -- a copy from pageable memory blocks its caller until
         // staged --; every member but the last runs on a sub-band as soon as it has arrived: the exposed upload is the 4 %.
-        // Slot 0 fits the spline EARLY, behind the two short sub-bands only; with the coefficients there before the last member
+        // Slot 0 fits the spline beside its first members (a thread of its own); with the coefficients there before the last member
         // starts, that member runs on sub-bands of 48, 30, 14, 6, 2 % and each finished sub-band --
         // scaled, final.TPS added -- goes down to the caller's plane under the next one (`piped`): the exposed download is the
         // 2 %.  The plane that travels is pred.elev + final.TPS; should Step 5 keep pred.elev alone (V73:917-930) it is sent
@@ -718,12 +718,21 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                 if (q == nq - 1) S.upload_ms[slot] = now_ms() - t0;
                 return MHS_OK;
             });
+            // slot 0's fit runs on a thread of its own beside this one (which goes on launching sub-bands as they arrive): the fit
+            // call blocks its caller for its whole length, and with it inline the device ran out of queued kernels behind the
+            // short sub-bands (float64 planes: +15 ms on cfg3)
+            std::thread fitter;
+            int fit_rc = MHS_OK;
+            std::string fit_err;
+            if (slot == 0)
+                fitter = std::thread([&] {
+                    SlotBind bind(slot);
+                    fit_rc = fit();
+                    if (fit_rc) fit_err = mhs_last_error();
+                });
             auto launch = [&]() -> int {
                 MHS_HIP(hipEventRecord(M->e0, M->s));
                 for (int q = 0; q < nq; ++q) {
-                    // the fit goes in once the two short sub-bands are queued: the device has their kernels to run in the
-                    // fit's thin stages, and nothing after them that could hold the fit up
-                    if (q == 2 && slot == 0) if (int rc2 = fit()) return rc2;
                     if (int rc2 = up.wait(q)) return rc2;
                     MHS_HIP(hipStreamWaitEvent(M->s, M->up[q], 0));
                     if (int rc2 = members_rows_dev(my, weights, banded, 0, 0, wt_total, &g, b.cov, b.r0, b.r1, ms->C, ms->dtype, ms->ld, ms->nodata,
@@ -737,6 +746,10 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                 return MHS_OK;
             };
             TEAM_DO(team, launch());
+            if (fitter.joinable()) {
+                fitter.join();
+                if (fit_rc) { set_error("%s", fit_err.c_str()); team.fail(fit_rc); }
+            }
             up.join();
             // the caller's planes may be released once the entry point returns: no copy may still be reading them
             if (team.failed()) (void)hipStreamSynchronize(M->u);
