@@ -438,6 +438,10 @@ MHS_API int mhs_multi_final_download(const mhs_multi_stack *ms, double *final_ho
 /* ... or its device pointers on one slot: the slot's rows (band_dev, ld = ncol) and, after gather, the whole grid */
 MHS_API int mhs_multi_final_dev(const mhs_multi_stack *ms, int slot, double **band_dev, int64_t *r0, int64_t *r1,
                                 double **full_dev);
+/* Releases what the two host-plane calls (mhs_mltps_grid_multi, mhs_tiles_units_multi) keep between calls -- device band
+ * buffers, unit arenas, pinned rings -- without touching the slots; the next call builds them again.  (mhs_shutdown and
+ * mhs_init_devices with other devices do the same.)                                                                      */
+MHS_API int mhs_multi_trim(void);
 /* Host planes in, host plane out, ONE call: what the R shim binds in place of V73:447-930 for a layer.  The copies are
  * inside the call and pipelined with it: every slot's band comes up in sub-bands under its first members, finished
  * sub-bands of the sum go down under its last one (the plane equals the resident call's bit for bit).  The device buffers

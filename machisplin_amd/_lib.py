@@ -149,6 +149,7 @@ SIGNATURES = {
     "mhs_multi_stack_create": (C.c_int, [C.POINTER(Grid), C.POINTER(Stack), C.c_double, C.POINTER(_vp)]),
     "mhs_multi_stack_free": (C.c_int, [_vp]),
     "mhs_plan_row_bands": (C.c_int, [_i64, C.c_int, C.c_double, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mhs_multi_trim": (C.c_int, []),
     "mhs_multi_stack_bands": (C.c_int, [_vp, C.POINTER(C.c_int), _vp, _vp]),
     "mhs_mltps_grid_multi_dev": (C.c_int, [C.POINTER(_vp), _dp, C.c_int, C.c_double, _vp, _vp, _vp, _i64, _i64, C.c_double,
                                            C.c_int, C.c_int, C.POINTER(MltpsInfo)]),

@@ -404,24 +404,36 @@ int free_stack(mhs_multi_stack *ms) {
 
 }  // namespace
 
-void mhs::multi_reset() {
-    {
-        std::lock_guard<std::mutex> lk(g_host_mu);
-        if (g_host_ms) { bool alive = true; for (int k = 0; k < g_host_ms->n; ++k) alive = alive && ctx_slot(k).ready; if (alive) free_stack(g_host_ms); else delete g_host_ms; }
-        g_host_ms = nullptr;
-        for (int k = 0; k < MAX_SLOTS; ++k) {
-            if (g_units_arena[k].base && ctx_slot(k).ready) { SlotBind bind(k); (void)hipFree(g_units_arena[k].base); }
-            g_units_arena[k] = UnitsArena();
-            if (ctx_slot(k).ready) {
-                SlotBind bind(k);
-                for (int b = 0; b < RING_BUFS; ++b) {
-                    if (g_ring[k].buf[b]) (void)hipHostFree(g_ring[k].buf[b]);
-                    if (g_ring[k].ev[b]) (void)hipEventDestroy(g_ring[k].ev[b]);
-                }
+// what the host-plane calls keep between calls: the band buffers of mhs_mltps_grid_multi, the unit arenas and pinned rings of
+// mhs_tiles_units_multi
+static void trim_caches() {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (g_host_ms) { bool alive = true; for (int k = 0; k < g_host_ms->n; ++k) alive = alive && ctx_slot(k).ready; if (alive) free_stack(g_host_ms); else delete g_host_ms; }
+    g_host_ms = nullptr;
+    const int home = current_slot();
+    for (int k = 0; k < MAX_SLOTS; ++k) {
+        if (ctx_slot(k).ready) {
+            (void)bind_slot(k);
+            if (g_units_arena[k].base) { (void)hipDeviceSynchronize(); (void)hipFree(g_units_arena[k].base); }
+            for (int b = 0; b < RING_BUFS; ++b) {
+                if (g_ring[k].buf[b]) (void)hipHostFree(g_ring[k].buf[b]);
+                if (g_ring[k].ev[b]) (void)hipEventDestroy(g_ring[k].ev[b]);
             }
-            g_ring[k] = PinnedRing();
         }
+        g_units_arena[k] = UnitsArena();
+        g_ring[k] = PinnedRing();
     }
+    (void)bind_slot(home);
+}
+
+extern "C" int mhs_multi_trim(void) {
+    if (int rc = require_ready()) return rc;
+    trim_caches();
+    return MHS_OK;
+}
+
+void mhs::multi_reset() {
+    trim_caches();
     rccl_reset();
     std::lock_guard<std::mutex> lk(g_ms_mu);
     for (int k = 0; k < MAX_SLOTS; ++k) {

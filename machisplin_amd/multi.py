@@ -43,6 +43,11 @@ def device_slots():
     return [int(ids[k]) for k in range(n.value)]
 
 
+def trim():
+    """mhs_multi_trim: release the device buffers, arenas and pinned rings the host-plane calls keep between calls."""
+    _lib.check(_lib.lib().mhs_multi_trim())
+
+
 def plan_row_bands(nrow: int, n_slots: int, slot0_share: float | None = None):
     """The row bands mhs_multi_stack_create cuts (host only, no GPU): ([(r0, r1)] per slot, band, lead)."""
     r0 = np.zeros(n_slots, dtype=np.int64)

@@ -156,6 +156,9 @@ def test_host_plane_pipeline_edge_cases(hip):
         multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, Xbad, resp)
     got, _ = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp)
     assert np.array_equal(got, ref["final"].cpu().numpy(), equal_nan=True)
+    multi.trim()                                     # the kept buffers released: the next call builds them again
+    got, _ = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp)
+    assert np.array_equal(got, ref["final"].cpu().numpy(), equal_nan=True)
     with pytest.raises(ValueError):
         multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp, out=np.zeros((97, 131)))
     multi.init_devices(1, [0])
