@@ -15,6 +15,9 @@ mhs_init_devices <- function(n.gpus, ids = NULL) {
   .Call("mhsr_init_devices", as.integer(n.gpus), if (is.null(ids)) NULL else as.integer(ids))
 }
 
+# The two calls below keep their device buffers between calls (a layer loop reuses them); a long session gets the memory back with
+mhs_multi_trim <- function() invisible(.Call("mhsr_multi_trim"))
+
 # ---- machisplin.mltps Steps 2-5 of ONE response layer over all GPUs (replaces V73:447-930 behind `if (hip)`) -------------
 # handles / OptX.mfit.wt / OptX.mfit.wt.tot: the fitted members as .mhs_step2_member collects them (mods.run order, rounded
 # kept weights, unrounded total -- V73:337-392); dat: dat_tps[[i]] (resp, covariates, LONG, LAT -- V73:145-154).

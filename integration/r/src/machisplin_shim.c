@@ -254,6 +254,12 @@ SEXP mhsr_init_devices(SEXP n, SEXP ids) {
     return Rf_ScalarInteger(slots);
 }
 
+/* mhs_multi_trim: give back the device buffers, arenas and pinned rings the two host-plane calls keep between calls */
+SEXP mhsr_multi_trim(void) {
+    chk(mhs_multi_trim());
+    return R_NilValue;
+}
+
 static const mhs_model **model_handles(SEXP models, int *n) {
     *n = Rf_length(models);
     const mhs_model **h = (const mhs_model **)R_alloc((size_t)(*n > 0 ? *n : 1), sizeof(*h));

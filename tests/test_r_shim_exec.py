@@ -234,6 +234,10 @@ def test_shim_planes_equal_the_direct_c_abi_calls_bit_for_bit(R, hip):
                          R.int([1]), R.int([64]), R.num([R.NA]), R.int([0])))
     assert np.array_equal(R.values(R.values(ru[0])[0]).reshape(g.nrow, g.ncol), outs[0], equal_nan=True)
     assert np.array_equal(R.values(ru[1]).T.reshape(1, 4, 2), rsq)
+    R.call("mhsr_multi_trim")                        # multi_gpu.R: mhs_multi_trim -- the kept buffers go, the next call builds them again
+    out2 = R.values(R.call("mhsr_mltps_grid_multi", R.list(hs), R.num(weights), R.num([wt_total]), R.geom(g), R.mat(values), R.mat(X), R.num(resp),
+                           R.int([0]), R.num([R.NA]), R.int([0]), R.num([R.NA])))
+    assert np.array_equal(R.values(out2[0]).reshape(g.nrow, g.ncol), final, equal_nan=True)
     multi.init_devices(1, [0])
 
     # what R's garbage collector does with unreachable handles: finalizers run, pointers are cleared
