@@ -111,6 +111,15 @@ MHS_API int mhs_timer_stop(void *stream, double *elapsed_ms);
  * GCV search run on the host.                                                   */
 MHS_API int mhs_tps_fit(const double *xy, const double *y, int64_t N, double lambda,
                 int gcv_mode, mhs_tps **out);
+/* `count` independent fits in one call -- what the reference's tiled Step 3 is (V73:690-738: one fields::Tps per tile on
+ * the 130-250 stations of its fit box), and what a caller with several response layers has.  Fit k reads N[k] rows:
+ * xy[k] is N[k] x 2 column-major, y[k] N[k] residuals.  Every fit with 8..256 distinct locations is done by ONE kernel
+ * launch, one workgroup per fit (Gram matrix, null-space projection, tridiagonalisation in registers, the GCV search of
+ * mhs_tps_fit with its independent evaluations side by side, solve, back-transform: csrc/tps_batch.hip); larger ones
+ * take mhs_tps_fit's route one after the other.  out[k] = NULL and status[k] != MHS_OK for a fit that failed
+ * (collinear stations, ...); the call itself fails only on bad arguments or a HIP error.  status may be NULL. */
+MHS_API int mhs_tps_fit_many(const double *const *xy, const double *const *y, const int64_t *N, int64_t count,
+                             double lambda, int gcv_mode, mhs_tps **out, int *status);
 /* Several response layers on one station table (the layer loop of machisplin.mltps, V73:176-957: BIO 1..12 on the same
  * stations; V73:154 keeps the same rows for every layer): B = Q2'KQ2 and its reduction depend on the coordinates only,
  * yet every fields::Tps call reduces it again.  Between mhs_tps_reduction_cache(1) and mhs_tps_reduction_cache(0),

@@ -11,7 +11,8 @@ from ._lib import MhsError, init
 from .raster import Geometry, RasterStack
 from . import models
 from .models import predict, ensemble_predict
-from .tps import Tps, interpolate, eval_mode, EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD
+from . import tps
+from .tps import Tps, fit_many, interpolate, eval_mode, EVAL_AUTO, EVAL_DIRECT, EVAL_FAR_FIELD
 from . import tiles, mltps, cv
 from .mltps import mltps as mltps_layers, mltps_predict, tps_residual_surface
 

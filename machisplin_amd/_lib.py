@@ -82,6 +82,7 @@ SIGNATURES = {
     "mhs_timer_start": (C.c_int, [_vp]),
     "mhs_timer_stop": (C.c_int, [_vp, _dp]),
     "mhs_tps_fit": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "mhs_tps_fit_many": (C.c_int, [_vp, _vp, _vp, _i64, C.c_double, C.c_int, _vp, _vp]),
     "mhs_host_gcv_tridiag": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_double, C.c_double, C.c_int,
                                        _dp, _dp, _dp, _vp]),
     "mhs_host_gcv_band": (C.c_int, [_vp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, C.c_double, C.c_int,

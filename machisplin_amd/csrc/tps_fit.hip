@@ -1834,6 +1834,42 @@ static void collapse_replicates(const double *xy, const double *y, int64_t N, st
     for (int64_t i = 0; i < N; ++i) { const double r = y[i] - ym_out[gid[i]]; pure_ss += r * r; }
 }
 
+int tps_prepare(const double *xy, const double *y, int64_t N, TpsPrep &P) {
+    for (int64_t i = 0; i < N; ++i)
+        if (!std::isfinite(xy[i]) || !std::isfinite(xy[N + i]) || !std::isfinite(y[i])) {
+            set_error("mhs_tps_fit: non-finite input at row %lld (drop NA rows first, V73:706)", (long long)i);
+            return MHS_ERR_INVALID;
+        }
+    P.N = N;
+    collapse_replicates(xy, y, N, P.xm, P.ym, P.w, P.pure_ss);
+    const int64_t n = P.n = (int64_t)P.ym.size();
+    if (n <= 3) { set_error("mhs_tps_fit: need more than 3 distinct locations"); return MHS_ERR_NUMERIC; }
+
+    // range scaling (fields scale.type = "range")
+    P.uv.resize(2 * n); P.sw.resize(n);
+    for (int d = 0; d < 2; ++d) {
+        double lo = P.xm[d * n], hi = P.xm[d * n];
+        for (int64_t i = 0; i < n; ++i) { lo = std::min(lo, P.xm[d * n + i]); hi = std::max(hi, P.xm[d * n + i]); }
+        P.center[d] = lo; P.scale[d] = hi - lo;
+        if (!(P.scale[d] > 0)) { set_error("mhs_tps_fit: degenerate station coordinates (zero range)"); return MHS_ERR_NUMERIC; }
+        for (int64_t i = 0; i < n; ++i) P.uv[d * n + i] = (P.xm[d * n + i] - P.center[d]) / P.scale[d];
+    }
+    for (int64_t i = 0; i < n; ++i) P.sw[i] = sqrt(P.w[i]);
+
+    // QR of T~ = W^1/2 [1 u v]
+    std::vector<double> T(3 * n);
+    for (int64_t i = 0; i < n; ++i) { T[i] = P.sw[i]; T[n + i] = P.sw[i] * P.uv[i]; T[2 * n + i] = P.sw[i] * P.uv[n + i]; }
+    qr_n3(T, n, P.hv, P.htau, P.R);
+    if (fabs(P.R[8]) < 1e-10 * fabs(P.R[0]) || fabs(P.R[4]) < 1e-10 * fabs(P.R[0])) {
+        set_error("mhs_tps_fit: collinear station coordinates");
+        return MHS_ERR_NUMERIC;
+    }
+    P.wv.resize(n);  // Q' y~
+    for (int64_t i = 0; i < n; ++i) P.wv[i] = P.sw[i] * P.ym[i];
+    for (int k = 0; k < 3; ++k) apply_reflector(P.hv[k], P.htau[k], P.wv.data(), n);
+    return MHS_OK;
+}
+
 }  // namespace mhs
 
 using namespace mhs;
@@ -1858,43 +1894,14 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     MHS_REQUIRE(N > 3 && N < (1LL << 30), "need more than 3 observations");
     MHS_REQUIRE(std::isnan(lambda) || lambda >= 0, "lambda must be >= 0 or NaN");
     MHS_REQUIRE(gcv_mode == MHS_GCV_FIELDS || gcv_mode == MHS_GCV_CONVERGED, "bad gcv_mode");
-    for (int64_t i = 0; i < N; ++i)
-        if (!std::isfinite(xy[i]) || !std::isfinite(xy[N + i]) || !std::isfinite(y[i])) {
-            set_error("mhs_tps_fit: non-finite input at row %lld (drop NA rows first, V73:706)", (long long)i);
-            return MHS_ERR_INVALID;
-        }
-
-    std::vector<double> xm, ym, w;
-    double pure_ss = 0.0;
-    collapse_replicates(xy, y, N, xm, ym, w, pure_ss);
-    const int64_t n = (int64_t)ym.size();
-    if (n <= 3) { set_error("mhs_tps_fit: need more than 3 distinct locations"); return MHS_ERR_NUMERIC; }
+    TpsPrep prep;
+    if (int rc = tps_prepare(xy, y, N, prep)) return rc;
+    const int64_t n = prep.n;
     const int m = (int)(n - 3);
-
-    // range scaling (fields scale.type = "range")
-    double center[2], scale[2];
-    std::vector<double> uv(2 * n), sw(n);
-    for (int d = 0; d < 2; ++d) {
-        double lo = xm[d * n], hi = xm[d * n];
-        for (int64_t i = 0; i < n; ++i) { lo = std::min(lo, xm[d * n + i]); hi = std::max(hi, xm[d * n + i]); }
-        center[d] = lo; scale[d] = hi - lo;
-        if (!(scale[d] > 0)) { set_error("mhs_tps_fit: degenerate station coordinates (zero range)"); return MHS_ERR_NUMERIC; }
-        for (int64_t i = 0; i < n; ++i) uv[d * n + i] = (xm[d * n + i] - center[d]) / scale[d];
-    }
-    for (int64_t i = 0; i < n; ++i) sw[i] = sqrt(w[i]);
-
-    // QR of T~ = W^1/2 [1 u v]
-    std::vector<double> T(3 * n), hv[3];
-    double htau[3], R[9];
-    for (int64_t i = 0; i < n; ++i) { T[i] = sw[i]; T[n + i] = sw[i] * uv[i]; T[2 * n + i] = sw[i] * uv[n + i]; }
-    qr_n3(T, n, hv, htau, R);
-    if (fabs(R[8]) < 1e-10 * fabs(R[0]) || fabs(R[4]) < 1e-10 * fabs(R[0])) {
-        set_error("mhs_tps_fit: collinear station coordinates");
-        return MHS_ERR_NUMERIC;
-    }
-    std::vector<double> wv(n);  // Q' y~
-    for (int64_t i = 0; i < n; ++i) wv[i] = sw[i] * ym[i];
-    for (int k = 0; k < 3; ++k) apply_reflector(hv[k], htau[k], wv.data(), n);
+    const double pure_ss = prep.pure_ss;
+    const double *center = prep.center, *scale = prep.scale, *htau = prep.htau, *R = prep.R;
+    const std::vector<double> &uv = prep.uv, &sw = prep.sw, &wv = prep.wv;
+    const std::vector<double> *hv = prep.hv;
 
     // mhs_fit_reserve_cus active: the fit stays on the compute units the ensemble's masked member leaves free
     // (the GCV route only: the Cholesky route takes its two streams from the lane itself)
@@ -2365,8 +2372,8 @@ int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, doubl
     mhs_tps *t = new mhs_tps();
     t->n = n;
     t->lambda = lam; t->eff_df = eff_df; t->gcv = gcv;
-    memcpy(t->center, center, sizeof(center));
-    memcpy(t->scale, scale, sizeof(scale));
+    memcpy(t->center, center, sizeof(t->center));
+    memcpy(t->scale, scale, sizeof(t->scale));
     memcpy(t->d, dd, sizeof(dd));
     t->c.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) t->c[i] = sw[i] * ct[i];

@@ -46,6 +46,22 @@ GcvPool *gcv_pool_lease(int threads);
 void gcv_pool_release(GcvPool *p);
 
 void qr_n3(std::vector<double> &T, int64_t n, std::vector<double> v[3], double tau[3], double R[9]);
+
+// The O(N) host part every fit starts with (fields' Krig.replicates + scale.type = "range" + QR of W^1/2 [1 u v]):
+// unique locations in first-appearance order with their means and counts, range-scaled coordinates, the three
+// reflectors of the polynomial block and the rotated data Q'(W^1/2 ym).  Shared by mhs_tps_fit (tps_fit.hip) and the
+// batched small fits (tps_batch.hip).  Returns MHS_OK or an error code with the message set.
+struct TpsPrep {
+    int64_t N = 0, n = 0;               // observations, distinct locations
+    double pure_ss = 0.0;
+    double center[2] = {0, 0}, scale[2] = {1, 1};
+    std::vector<double> xm, ym, w;      // unique coordinates (n x 2 column-major), means, counts
+    std::vector<double> uv, sw;         // scaled coordinates (n x 2 column-major), sqrt(counts)
+    std::vector<double> hv[3];          // reflectors of the QR of W^1/2 [1 u v]
+    double htau[3] = {0, 0, 0}, R[9] = {0};
+    std::vector<double> wv;             // Q' W^1/2 ym
+};
+int tps_prepare(const double *xy, const double *y, int64_t N, TpsPrep &P);
 void apply_reflector(const std::vector<double> &v, double tau, double *x, int64_t n);
 
 }  // namespace mhs

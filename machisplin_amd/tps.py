@@ -98,6 +98,44 @@ class Tps:
             self._h = None
 
 
+def fit_many(xs, Ys, lambda_: float | None = None, gcv_mode: str = "fields"):
+    """``[fields::Tps(x, Y) for x, Y in zip(xs, Ys)]`` in ONE library call (mhs_tps_fit_many): every fit with 8..256
+    distinct locations -- the tiles of the reference's Step 3, V73:690-738 -- is done by a single kernel launch, one
+    workgroup per fit.  Returns a list of :class:`Tps` (None where a fit failed, e.g. collinear stations)."""
+    lib = _lib.lib()
+    k = len(xs)
+    if len(Ys) != k:
+        raise ValueError("xs and Ys have different lengths")
+    xcm, ycm = [], []
+    for x, Y in zip(xs, Ys):
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("every x must be an N x 2 matrix of (LONG, LAT)")
+        y = np.ascontiguousarray(np.asarray(Y, dtype=np.float64).reshape(-1))
+        if y.shape[0] != x.shape[0]:
+            raise ValueError("x and Y have different numbers of rows")
+        xcm.append(np.asfortranarray(x)); ycm.append(y)
+    _lib.init()
+    px = (C.c_void_p * k)(*[a.ctypes.data for a in xcm])
+    py = (C.c_void_p * k)(*[a.ctypes.data for a in ycm])
+    ns = (C.c_int64 * k)(*[a.shape[0] for a in xcm])
+    out = (C.c_void_p * k)()
+    st = (C.c_int * k)()
+    mode = {"fields": _lib.GCV_FIELDS, "converged": _lib.GCV_CONVERGED}[gcv_mode]
+    lam = math.nan if lambda_ is None else float(lambda_)
+    _lib.check(lib.mhs_tps_fit_many(px, py, ns, k, lam, mode, out, st))
+    fits = []
+    for i in range(k):
+        if not out[i]:
+            fits.append(None)
+            continue
+        t = Tps.__new__(Tps)
+        t._h = C.c_void_p(out[i])
+        t._pull()
+        fits.append(t)
+    return fits
+
+
 def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None):
     """terra::interpolate(geometry-only raster, tps): evaluate the spline at EVERY cell
     centre of ``geom`` (or of the window (r0, r1, c0, c1)); no NA mask (V73:726,753).
