@@ -10,6 +10,7 @@ namespace mhs {
 
 constexpr int SB_NMAX = 256;        // distinct stations one workgroup can hold (the matrix lives in its registers)
 constexpr int SB_NMIN = 8;
+constexpr int BATCH_LANE = 9;        // the batch's own lane (stream + arena), beside lane 0 and the tile lanes 1..8 of tps_surface.hip
 
 // one spline of a batch as the kernel reads it (device array)
 struct SmallJob {
@@ -44,9 +45,25 @@ struct SmallBatch {
 
 // append one prepared fit; perm may be NULL (knots written in natural order).  Returns the job index.
 int small_batch_add(SmallBatch &B, const TpsPrep &P, double lambda, int gcv_mode, const int *perm);
-// upload and launch on `s`; the buffers come from `arena` (grown if needed: synchronises the device, first calls only)
-int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s);
+// upload and launch on `s`; the buffers come from the lane's arena (grown if needed: synchronises the device, first calls
+// only), with `extra_bytes` more behind them for the caller (*extra_dev)
+int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s, size_t extra_bytes = 0, char **extra_dev = nullptr);
 // after the stream has been synchronised: copy results (and optionally coefficients) back
 int small_batch_results(const SmallBatch &B, hipStream_t s, std::vector<SmallResult> &res, std::vector<double> *c);
+
+
+// Batched grid evaluation of the batch's splines (tps_eval.hip): one window per spline -- a tile's keep window on its
+// fit raster (terra::interpolate(terra::rast(rb), tps), V73:726) -- all windows in one nodes launch + one cells launch,
+// reading the knot records and the polynomial part where the fit kernel left them on the device.
+struct EvalBatch;
+EvalBatch *eval_batch_create();
+void eval_batch_destroy(EvalBatch *B);
+// plan window [r0, r1) x [c0, c1) of `grid` for a spline with these (scaled) knots; perm[i] = position of knot i in the
+// evaluation's knot order (what SmallJob::perm_off points at); res_index / knot_off: the spline's job in the fit batch
+int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                   int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, int res_index, int64_t knot_off,
+                   std::vector<int> &perm);
+size_t eval_batch_device_bytes(const EvalBatch *B);
+int eval_batch_launch(EvalBatch *B, char *dev, const Knot *knots_base, const SmallResult *res_base, hipStream_t s);
 
 }  // namespace mhs

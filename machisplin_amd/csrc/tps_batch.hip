@@ -41,6 +41,7 @@ constexpr int SB_EV = 256;           // GCV evaluations in flight (their pivots 
 constexpr int SB_TREE_DEPTH = 8;     // golden-section levels per round: 2^8 - 1 = 255 evaluations
 
 struct SbShared {
+    double mx[16][SB_THREADS];        // n > 224 only: the matrix's first 32 columns (16 elements per thread; the registers hold 56, not 72)
     double u[SB_NMAX], v[SB_NMAX], sw[SB_NMAX];
     double vs[2][SB_NMAX];            // the step's Householder vector (double-buffered: the next owner writes while others still update)
     double ps[SB_NMAX];               // p = tau A v
@@ -110,17 +111,53 @@ __device__ __forceinline__ double sb_rcp(double x) {
     return r;
 }
 
+// x of the lane whose number differs in one bit: quad permutes (DPP) for bits 0 and 1, ds_swizzle's bit mode for bits 2-4
+template <int CTRL>
+__device__ __forceinline__ double sb_dpp(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int XOR>
+__device__ __forceinline__ double sb_swz(double x) {
+    constexpr int PAT = (XOR << 10) | 0x1f;     // bit mode: and_mask 0x1f, or_mask 0, xor_mask XOR
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), PAT);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), PAT);
+    return __hiloint2double(hi, lo);
+}
+// Sixteen values per lane summed over the 32 lanes of each half-wave, by halving: at every stage a lane hands half of
+// its partial sums to its partner and keeps the other half, so 8 + 4 + 2 + 1 + 1 values cross lanes instead of 16 x 5.
+// Result: the total of value (lane & 15), in every lane.
+__device__ __forceinline__ double sb_colsum16(const double (&x)[16], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    double s1[8], s2[4], s3[2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s1[t] = (b0 ? x[2 * t + 1] : x[2 * t]) + sb_dpp<0xB1>(b0 ? x[2 * t] : x[2 * t + 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s2[t] = (b1 ? s1[2 * t + 1] : s1[2 * t]) + sb_dpp<0x4E>(b1 ? s1[2 * t] : s1[2 * t + 1]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) s3[t] = (b2 ? s2[2 * t + 1] : s2[2 * t]) + sb_swz<4>(b2 ? s2[2 * t] : s2[2 * t + 1]);
+    const double s4 = (b3 ? s3[1] : s3[0]) + sb_swz<8>(b3 ? s3[0] : s3[1]);
+    return s4 + sb_swz<16>(s4);
+}
+
 #define SB_IDX(i, j) ((i) * ((i) + 1) + (j))      // row block i (32 rows), column block j (16 columns), j <= 2 i + 1
+// At NS = 8 (225..256 stations) the 72 doubles per thread leave the compiler no room and it parks a part of the matrix in
+// scratch memory, ~100 round trips per step; the two column blocks that die first (columns 0..31: 16 elements per thread)
+// live in LDS instead, thread-contiguous (no bank conflicts), and cost LDS bandwidth only during the first 64 steps.
+#define SB_INLDS(j) (NS == 8 && (j) < 2)
+#define SB_MLD(i, j) (SB_INLDS(j) ? S.mx[(i) * 2 + (j)][tid] : M[SB_IDX(i, j)])
+#define SB_MST(i, j, val) do { if (SB_INLDS(j)) S.mx[(i) * 2 + (j)][tid] = (val); else M[SB_IDX(i, j)] = (val); } while (0)
 
 // element (row block si, column block sj) of this thread, blocks given at run time (block-uniform)
 template <int NS>
-__device__ __forceinline__ double sb_get(const double (&M)[NS * (NS + 1)], int si, int sj) {
+__device__ __forceinline__ double sb_get(const double (&M)[NS * (NS + 1)], const SbShared &S, int tid, int si, int sj) {
     double x = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j <= 2 * i + 1; ++j)
-            if (i == si && j == sj) x = M[SB_IDX(i, j)];
+            if (i == si && j == sj) x = SB_MLD(i, j);
     return x;
 }
 
@@ -246,7 +283,7 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
             const double dx = S.u[r] - uc, dy = S.v[r] - vc;
             const double d2 = fma(dy, dy, dx * dx);
             const double k = S.sw[r] * (0.5 / (8.0 * M_PI)) * sc * r2logr2(d2, S.tab);
-            M[SB_IDX(i, j)] = (r < n && c < n) ? k : 0.0;
+            SB_MST(i, j, (r < n && c < n) ? k : 0.0);
         }
     }
     if (tid == 0) S.stamp[1] = wall_clock64();
@@ -265,7 +302,10 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
     // ---- three projection steps (given reflectors), then the tridiagonalisation of the trailing m x m block
 #ifdef SB_PHASE_TRACE
     unsigned long long tr_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tr_last = wall_clock64();
-#define SB_TR(k) do { const unsigned long long now_ = wall_clock64(); tr_acc[k] += now_ - tr_last; tr_last = now_; } while (0)
+#ifndef SB_TRACE_STEP
+#define SB_TRACE_STEP kk
+#endif
+#define SB_TR(k) do { const unsigned long long now_ = wall_clock64(); if (kk == (SB_TRACE_STEP)) tr_acc[k] += now_ - tr_last; tr_last = now_; } while (0)
 #else
 #define SB_TR(k) do {} while (0)
 #endif
@@ -273,7 +313,7 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
         const int buf = kk & 1;
         const bool proj = kk < 3;
         const int dl = proj ? 0 : kk + 1;          // rows / columns below dl are dead (final) for this step
-        const int jlo = dl >> 4;                   // 16-column blocks below jlo are dead as a whole
+        const int glo = dl >> 6;                   // groups of four 16-column blocks below glo are dead as a whole
         const int ilo = dl >> 5;                   // 32-row blocks below ilo
         if (proj) {
             SB_THREAD_IDS();
@@ -291,7 +331,7 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
                 x[i] = 0.0;
 #pragma unroll
                 for (int j = 0; j <= 2 * i + 1; ++j)
-                    if (j == jk) x[i] = M[SB_IDX(i, j)];
+                    if (j == jk) x[i] = SB_MLD(i, j);
             }
             double ssl = 0.0, al = 0.0, dk = 0.0;
 #pragma unroll
@@ -325,24 +365,33 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
         const double tau = S.sc[buf];
         {   // p = A v: row sums (over b) and column sums (over a)
             SB_THREAD_IDS();
-            double vr[NS], prow[NS];
+            double vr[NS], prow[NS], pc[16];
 #pragma unroll
             for (int i = 0; i < NS; ++i) { vr[i] = S.vs[buf][a + 32 * i]; prow[i] = 0.0; }
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                if (j >= jlo) {
-                    const double vc = S.vs[buf][b + 16 * j];
-                    double pc = 0.0;
+            for (int j = 0; j < 16; ++j) pc[j] = 0.0;
 #pragma unroll
-                    for (int i = j >> 1; i < NS; ++i) {
-                        const double e = M[SB_IDX(i, j)];
-                        prow[i] = fma(e, vc, prow[i]);
-                        if (j <= 2 * i - 1) pc = fma(e, vr[i], pc);      // strictly lower block: stands for its mirror image too
+            for (int g = 0; g < (NC + 3) / 4; ++g) {
+                if (g >= glo) {         // a group of four column blocks (64 columns): dead ones inside it multiply zeros
+                    double vc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vc[q] = 4 * g + q < NC ? S.vs[buf][b + 16 * (4 * g + q)] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 4 * g + q;
+                        if (j < NC) {
+#pragma unroll
+                            for (int i = j >> 1; i < NS; ++i) {
+                                const double e = SB_MLD(i, j);
+                                prow[i] = fma(e, vc[q], prow[i]);
+                                if (j <= 2 * i - 1) pc[j] = fma(e, vr[i], pc[j]);      // strictly lower block: stands for its mirror image too
+                            }
+                        }
                     }
-                    pc = half_sum_upper_row(pc);
-                    if ((lane & 31) == 31) S.pcs[b + 16 * j] = pc;
                 }
             }
+            const double ptot = sb_colsum16(pc, lane);
+            if ((lane & 16) == 0) S.pcs[b + 16 * (lane & 15)] = ptot;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 if (i >= ilo) {
@@ -390,16 +439,27 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
                 wr[i] = S.ps[a + 32 * i] - alpha * vr[i];
             }
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                if (j >= jlo) {
-                    const double vc = S.vs[buf][b + 16 * j];
-                    const double wc = S.ps[b + 16 * j] - alpha * vc;
+            for (int g = 0; g < (NC + 3) / 4; ++g) {
+                if (g >= glo) {
+                    double vc[4], wc[4];
 #pragma unroll
-                    for (int i = j >> 1; i < NS; ++i) {
-                        double e = M[SB_IDX(i, j)];
-                        e = fma(-vr[i], wc, e);
-                        e = fma(-wr[i], vc, e);
-                        M[SB_IDX(i, j)] = e;
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 4 * g + q;
+                        vc[q] = j < NC ? S.vs[buf][b + 16 * j] : 0.0;
+                        wc[q] = j < NC ? S.ps[b + 16 * j] - alpha * vc[q] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 4 * g + q;
+                        if (j < NC) {
+#pragma unroll
+                            for (int i = j >> 1; i < NS; ++i) {
+                                double e = SB_MLD(i, j);
+                                e = fma(-vr[i], wc[q], e);
+                                e = fma(-wr[i], vc[q], e);
+                                SB_MST(i, j, e);
+                            }
+                        }
                     }
                 }
             }
@@ -414,12 +474,12 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
     {   // the last 2 x 2 block of the tridiagonal, and the three projected rows
         SB_THREAD_IDS();
         const int r = n - 1, c = n - 2;
-        if (a == (c & 31) && b == (c & 15)) S.ta[c] = sb_get<NS>(M, c >> 5, c >> 4);
-        if (a == (r & 31) && b == (c & 15)) S.tb[c] = sb_get<NS>(M, r >> 5, c >> 4);
-        if (a == (r & 31) && b == (r & 15)) S.ta[r] = sb_get<NS>(M, r >> 5, r >> 4);
+        if (a == (c & 31) && b == (c & 15)) S.ta[c] = sb_get<NS>(M, S, tid, c >> 5, c >> 4);
+        if (a == (r & 31) && b == (c & 15)) S.tb[c] = sb_get<NS>(M, S, tid, r >> 5, c >> 4);
+        if (a == (r & 31) && b == (r & 15)) S.ta[r] = sb_get<NS>(M, S, tid, r >> 5, r >> 4);
         if (b < 3) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) S.at[b][a + 32 * i] = M[SB_IDX(i, 0)];
+            for (int i = 0; i < NS; ++i) S.at[b][a + 32 * i] = SB_MLD(i, 0);
         }
     }
     __syncthreads();
@@ -750,9 +810,9 @@ int small_batch_add(SmallBatch &B, const TpsPrep &P, double lambda, int gcv_mode
     return B.count++;
 }
 
-int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s) {
-    if (B.count == 0) return MHS_OK;
-    const int nblk = std::min(B.count, std::max(1, ctx().n_cu));
+int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s, size_t extra_bytes, char **extra_dev) {
+    if (B.count == 0 && extra_bytes == 0) return MHS_OK;
+    const int nblk = std::max(1, std::min(B.count, std::max(1, ctx().n_cu)));
     const int ldv = (B.nmax + 31) & ~31;
     const size_t per_block = (size_t)ldv * ldv + (size_t)2 * ldv * SB_EV;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -764,6 +824,7 @@ int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s) {
     const size_t o_k = off; off = up(off + sizeof(Knot) * (size_t)B.knot_total);
     const size_t o_res = off; off = up(off + sizeof(SmallResult) * (size_t)B.count);
     const size_t o_scr = off; off = up(off + sizeof(double) * per_block * (size_t)nblk);
+    const size_t o_extra = off; off = up(off + extra_bytes);
     if (off > L.arena_cap) {
         if (L.arena) { (void)hipDeviceSynchronize(); (void)hipFree(L.arena); L.arena = nullptr; L.arena_cap = 0; }
         const size_t cap = off + off / 4;
@@ -778,6 +839,8 @@ int small_batch_launch(SmallBatch &B, FitLane &L, hipStream_t s) {
     B.knots_dev = (Knot *)(base + o_k);
     B.res_dev = (SmallResult *)(base + o_res);
     double *scratch = (double *)(base + o_scr);
+    if (extra_dev) *extra_dev = base + o_extra;
+    if (B.count == 0) return MHS_OK;
     MHS_HIP(hipMemcpyAsync(B.jobs_dev, B.jobs.data(), sizeof(SmallJob) * B.jobs.size(), hipMemcpyHostToDevice, s));
     MHS_HIP(hipMemcpyAsync(B.in_dev, B.in.data(), sizeof(double) * B.in.size(), hipMemcpyHostToDevice, s));
     if (!B.perm.empty()) MHS_HIP(hipMemcpyAsync(B.perm_dev, B.perm.data(), sizeof(int) * B.perm.size(), hipMemcpyHostToDevice, s));
@@ -805,7 +868,6 @@ int small_batch_results(const SmallBatch &B, hipStream_t s, std::vector<SmallRes
 
 using namespace mhs;
 
-constexpr int BATCH_LANE = 9;       // the batch's own lane (stream + arena), beside lane 0 and the tile lanes 1..8 of tps_surface.hip
 
 extern "C" int mhs_tps_fit_many(const double *const *xy, const double *const *y, const int64_t *N, int64_t count,
                                 double lambda, int gcv_mode, mhs_tps **out, int *status) {

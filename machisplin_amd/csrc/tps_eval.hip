@@ -30,6 +30,7 @@
 #include <vector>
 #include "common.h"
 #include "devmath.h"
+#include "tps_batch.h"
 
 namespace mhs {
 
@@ -64,16 +65,13 @@ __device__ __forceinline__ void tps_accumulate(const Knot *__restrict__ knots, c
     }
 }
 
-__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
-    const Knot *__restrict__ knots, int n, const double2 *__restrict__ gtab, EvalGeom g,
-    double *__restrict__ out) {
-    __shared__ double2 tab[LOG_TAB_N];
-    stage_log_table(tab, gtab);
-
+// one block of the direct sum: 64 columns x 16 rows of the window, block (bx, by); tab is the staged table
+__device__ __forceinline__ void eval_direct_block(const Knot *__restrict__ knots, int n, const double2 *tab, const EvalGeom &g,
+                                                  double *__restrict__ out, int bx, int by) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int row0 = blockIdx.y * EVAL_TILE_ROWS + wave * EVAL_ROWS;
+    const int col = bx * 64 + lane;
+    const int row0 = by * EVAL_TILE_ROWS + wave * EVAL_ROWS;
     if (row0 >= g.nr) return;
 
     // cell centre -> scaled coordinates, same operation order as the host/oracle
@@ -95,6 +93,14 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
             if (row0 + k < g.nr)
                 out[(int64_t)(row0 + k) * g.ld + col] = g.d0 + g.d1 * u + g.d2 * v[k] + acc[k];
     }
+}
+
+__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_eval_grid_kernel(
+    const Knot *__restrict__ knots, int n, const double2 *__restrict__ gtab, EvalGeom g,
+    double *__restrict__ out) {
+    __shared__ double2 tab[LOG_TAB_N];
+    stage_log_table(tab, gtab);
+    eval_direct_block(knots, n, tab, g, out, blockIdx.x, blockIdx.y);
 }
 
 __global__ __launch_bounds__(256) void tps_eval_points_kernel(
@@ -132,15 +138,12 @@ struct FarGeom {
 };
 
 // far-field sum (plus the affine part) at the 16 x 16 nodes of every tile; one wave per tile,
-// lane = (node column a, group of 4 node rows)
-__global__ __launch_bounds__(256) void tps_ff_nodes_kernel(const Knot *__restrict__ knots, int n,
-                                                           const int *__restrict__ bin_start,
-                                                           const double2 *__restrict__ gtab, EvalGeom g,
-                                                           FarGeom f, double *__restrict__ nodes) {
-    __shared__ double2 tab[LOG_TAB_N];
-    stage_log_table(tab, gtab);
+// lane = (node column a, group of 4 node rows); blk = index of the block of four tiles
+__device__ __forceinline__ void ff_nodes_block(const Knot *__restrict__ knots, int n, const int *__restrict__ bin_start,
+                                               const double2 *tab, const EvalGeom &g, const FarGeom &f,
+                                               double *__restrict__ nodes, int blk) {
     const int lane = threadIdx.x & 63;
-    const int tile = f.ty_lo * f.ntx + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = f.ty_lo * f.ntx + blk * 4 + (threadIdx.x >> 6);
     if (tile >= f.ty_hi * f.ntx) return;
     const int tyi = tile / f.ntx, txi = tile - tyi * f.ntx;
     const int a = lane & 15, bg = lane >> 4;
@@ -169,20 +172,32 @@ __global__ __launch_bounds__(256) void tps_ff_nodes_kernel(const Knot *__restric
         nodes[(int64_t)tile * FF_NODES + (bg * EVAL_ROWS + k) * FF_N + a] = g.d0 + g.d1 * u + g.d2 * v[k] + acc[k];
 }
 
-// cells: interpolated far field + direct near field.  A block covers 64 columns x 16 rows of one
-// tile (tile widths are multiples of 64, heights of 16); lane = column, 4 rows per lane.
-__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
-    const Knot *__restrict__ knots, const int *__restrict__ bin_start, const double2 *__restrict__ gtab,
-    EvalGeom g, FarGeom f, const double *__restrict__ nodes, const double *__restrict__ lx,
-    const double *__restrict__ ly, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void tps_ff_nodes_kernel(const Knot *__restrict__ knots, int n,
+                                                           const int *__restrict__ bin_start,
+                                                           const double2 *__restrict__ gtab, EvalGeom g,
+                                                           FarGeom f, double *__restrict__ nodes) {
     __shared__ double2 tab[LOG_TAB_N];
-    __shared__ double sF[FF_NODES];
-    __shared__ double sG[FF_N][64];
+    stage_log_table(tab, gtab);
+    ff_nodes_block(knots, n, bin_start, tab, g, f, nodes, blockIdx.x);
+}
+
+// cells: interpolated far field + direct near field.  A block covers 64 columns x 16 rows of one
+// tile (tile widths are multiples of 64, heights of 16); lane = column, 4 rows per lane.  Block (bx, by) of the window.
+struct FfCellsShared {
+    double2 tab[LOG_TAB_N];
+    double sF[FF_NODES];
+    double sG[FF_N][64];
+};
+__device__ __forceinline__ void ff_cells_block(const Knot *__restrict__ knots, const int *__restrict__ bin_start,
+                                               const double2 *__restrict__ gtab, const EvalGeom &g, const FarGeom &f,
+                                               const double *__restrict__ nodes, const double *__restrict__ lx,
+                                               const double *__restrict__ ly, double *__restrict__ out, FfCellsShared &sh,
+                                               int bx, int by_in) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cchunks = f.tx / 64, rchunks = f.ty / EVAL_TILE_ROWS;
-    const int txi = blockIdx.x / cchunks, cc = blockIdx.x - txi * cchunks;
-    const int by = blockIdx.y + f.ty_lo * rchunks;
+    const int txi = bx / cchunks, cc = bx - txi * cchunks;
+    const int by = by_in + f.ty_lo * rchunks;
     const int tyi = by / rchunks, rc = by - tyi * rchunks;
     const int tile = tyi * f.ntx + txi;
     const int lcol = cc * 64 + lane;                                  // column within the tile
@@ -191,8 +206,8 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
     const int row0 = tyi * f.ty + lrow0;
     if (tyi * f.ty + rc * EVAL_TILE_ROWS >= f.row_hi || tyi * f.ty + (rc + 1) * EVAL_TILE_ROWS <= f.row_lo ||
         txi * f.tx + cc * 64 >= g.nc) return;   // whole block outside
-    for (int i = threadIdx.x; i < LOG_TAB_N; i += 64 * EVAL_WAVES) tab[i] = gtab[i];
-    sF[threadIdx.x] = nodes[(int64_t)tile * FF_NODES + threadIdx.x];
+    for (int i = threadIdx.x; i < LOG_TAB_N; i += 64 * EVAL_WAVES) sh.tab[i] = gtab[i];
+    sh.sF[threadIdx.x] = nodes[(int64_t)tile * FF_NODES + threadIdx.x];
     __syncthreads();
     {   // G[b][i] = sum_a F[b][a] Lx[i][a] for the block's 64 columns; this wave: b = 4 wave .. 4 wave + 3
         double lxr[FF_N];
@@ -203,8 +218,8 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
             const int b = wave * EVAL_ROWS + k;
             double s = 0.0;
 #pragma unroll
-            for (int a = 0; a < FF_N; ++a) s = fma(sF[b * FF_N + a], lxr[a], s);
-            sG[b][lane] = s;
+            for (int a = 0; a < FF_N; ++a) s = fma(sh.sF[b * FF_N + a], lxr[a], s);
+            sh.sG[b][lane] = s;
         }
     }
     __syncthreads();
@@ -218,19 +233,67 @@ __global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
         const double *lyr = ly + (int64_t)(lrow0 + k) * FF_N;           // wave-uniform row of Ly
         double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < FF_N; ++b) s = fma(lyr[b], sG[b][lane], s);
+        for (int b = 0; b < FF_N; ++b) s = fma(lyr[b], sh.sG[b][lane], s);
         acc[k] = s;
     }
     const int nbx = f.ntx + 2 * FF_PAD;
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
         const int *brow = bin_start + (int64_t)(tyi + FF_PAD - 1 + r) * nbx + (txi + FF_PAD - 1);
-        tps_accumulate(knots, brow[0], brow[3], u, v, acc, tab);
+        tps_accumulate(knots, brow[0], brow[3], u, v, acc, sh.tab);
     }
     if (col < g.nc) {
 #pragma unroll
         for (int k = 0; k < EVAL_ROWS; ++k)
             if (row0 + k >= f.row_lo && row0 + k < f.row_hi) out[(int64_t)(row0 + k - f.row_lo) * g.ld + col] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_ff_cells_kernel(
+    const Knot *__restrict__ knots, const int *__restrict__ bin_start, const double2 *__restrict__ gtab,
+    EvalGeom g, FarGeom f, const double *__restrict__ nodes, const double *__restrict__ lx,
+    const double *__restrict__ ly, double *__restrict__ out) {
+    __shared__ FfCellsShared sh;
+    ff_cells_block(knots, bin_start, gtab, g, f, nodes, lx, ly, out, sh, blockIdx.x, blockIdx.y);
+}
+
+// ---- the same three kernels over MANY windows in one launch each (a tiled Step 3: one window per tile spline, the
+// splines' coefficients written on the device by tps_batch.hip).  blockIdx.y = window, blockIdx.x = block within it
+// (the grid is as wide as the largest window needs; the others' surplus blocks leave at once).
+struct EvalWindow {
+    EvalGeom g;                 // d0..d2 are read from d3 on the device
+    FarGeom f;
+    const Knot *knots;          // far: in bin order; direct: any order
+    const int *bin_start;
+    double *nodes;
+    const double *lx, *ly;
+    double *out;
+    const double *d3;
+    int n, far;
+    int node_blocks;            // far: blocks of four tiles
+    int cgx, cgy;               // blocks of 64 columns x 16 rows
+};
+__global__ __launch_bounds__(256) void tps_batch_nodes_kernel(const EvalWindow *__restrict__ W, const double2 *__restrict__ gtab) {
+    __shared__ double2 tab[LOG_TAB_N];
+    const EvalWindow &D = W[blockIdx.y];
+    if (!D.far || (int)blockIdx.x >= D.node_blocks) return;
+    stage_log_table(tab, gtab);
+    EvalGeom g = D.g;
+    g.d0 = D.d3[0]; g.d1 = D.d3[1]; g.d2 = D.d3[2];
+    ff_nodes_block(D.knots, D.n, D.bin_start, tab, g, D.f, D.nodes, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * EVAL_WAVES) void tps_batch_cells_kernel(const EvalWindow *__restrict__ W, const double2 *__restrict__ gtab) {
+    __shared__ FfCellsShared sh;
+    const EvalWindow &D = W[blockIdx.y];
+    if ((int)blockIdx.x >= D.cgx * D.cgy) return;
+    const int by = blockIdx.x / D.cgx, bx = blockIdx.x - by * D.cgx;
+    if (D.far) {
+        ff_cells_block(D.knots, D.bin_start, gtab, D.g, D.f, D.nodes, D.lx, D.ly, D.out, sh, bx, by);
+    } else {
+        stage_log_table(sh.tab, gtab);
+        EvalGeom g = D.g;
+        g.d0 = D.d3[0]; g.d1 = D.d3[1]; g.d2 = D.d3[2];
+        eval_direct_block(D.knots, D.n, sh.tab, g, D.out, bx, by);
     }
 }
 
@@ -294,17 +357,18 @@ static void cheb_matrix(int cells, bool flip, const double (&t)[FF_N], std::vect
     }
 }
 
-// Choose tile sizes for the far-field-interpolated path and (re)build its plan.  *use = false when the
-// direct sum is expected to be at least as cheap (few knots, small windows).
-static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1, int64_t c1, FarGeom *f, bool *use) {
+// Host side of the far-field plan, from the knots' coordinates alone (coefficients play no part): tile sizes, and the
+// counting sort of the knots by bin.  Shared by the per-handle plan below and the batched evaluation of a tiled Step 3.
+// far_plan_choose: *use = false when the direct sum is expected to be at least as cheap (few knots, small windows).
+static void far_plan_choose(const double *knots_uv, int64_t N, const EvalGeom &e, FarGeom *f, bool *use,
+                            std::vector<double> &kc, std::vector<double> &kr) {
     *use = false;
-    const int64_t N = t->n;
-    if (g_eval_mode == 1 || e.nc < 64 || e.nr < 16 || N < 32) return MHS_OK;
+    if (g_eval_mode == 1 || e.nc < 64 || e.nr < 16 || N < 32) return;
     // knots in window cell coordinates
-    std::vector<double> kc((size_t)N), kr((size_t)N);
+    kc.resize((size_t)N); kr.resize((size_t)N);
     int64_t inside = 0;
     for (int64_t j = 0; j < N; ++j) {
-        const double x = t->knots_uv[j] * e.sx + e.cx, y = t->knots_uv[N + j] * e.sy + e.cy;
+        const double x = knots_uv[j] * e.sx + e.cx, y = knots_uv[N + j] * e.sy + e.cy;
         kc[j] = (x - e.xmin) / e.xres - (double)e.c0;
         kr[j] = (e.ymax - y) / e.yres - (double)e.r0;
         if (kc[j] >= 0 && kc[j] < e.nc && kr[j] >= 0 && kr[j] < e.nr) ++inside;
@@ -322,51 +386,75 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
         const double cost = ntx * nty * FF_NODES * (double)N / cells + 9.0 * rho * tx * ty + 4.0;
         if (cost < best) { best = cost; btx = tx; bty = ty; }
     }
-    if (btx == 0) return MHS_OK;
-    if (g_eval_mode != 2 && best > 0.5 * (double)N) return MHS_OK;
+    if (btx == 0) return;
+    if (g_eval_mode != 2 && best > 0.5 * (double)N) return;
     const double tile_aspect = ((double)btx * e.xres / e.sx) / ((double)bty * e.yres / e.sy);
-    if (tile_aspect > 1.25 || tile_aspect < 0.8) return MHS_OK;            // cannot make square tiles: direct
-    mhs_tps::FarPlan &P = t->far;
+    if (tile_aspect > 1.25 || tile_aspect < 0.8) return;                   // cannot make square tiles: direct
     f->tx = btx; f->ty = bty;
     f->ntx = (int)((e.nc + btx - 1) / btx); f->nty = (int)((e.nr + bty - 1) / bty);
     for (int a = 0; a < FF_N; ++a) f->t[a] = cos((2 * a + 1) * M_PI / (2.0 * FF_N));
+    f->row_lo = 0; f->row_hi = e.nr; f->ty_lo = 0; f->ty_hi = f->nty;
     *use = true;
-    const bool same = P.sorted_dev && P.xmin == e.xmin && P.ymax == e.ymax && P.xres == e.xres && P.yres == e.yres &&
-                      P.r0 == e.r0 && P.r1 == r1 && P.c0 == e.c0 && P.c1 == c1 && P.tx == btx && P.ty == bty;
-    if (same) return MHS_OK;
-    // The plan's device buffers are about to be rewritten (blocking copies on the null stream): kernels of the previous
-    // evaluation, enqueued on a caller's non-blocking stream, may still be reading them.
-    if (P.in_flight) { MHS_HIP(hipStreamSynchronize(P.last_stream)); P.in_flight = false; }
-    // counting sort of the knots by bin; bins beyond FF_PAD tiles outside the window collapse onto the rim
-    const int nbx = f->ntx + 2 * FF_PAD, nby = f->nty + 2 * FF_PAD;
-    std::vector<int> bin((size_t)N), start((size_t)nbx * nby + 1, 0);
+}
+// counting sort of the knots by bin; bins beyond FF_PAD tiles outside the window collapse onto the rim.
+// start: (nty + 4) * (ntx + 4) + 1 offsets; order[p] = index of the knot at sorted position p.
+static void far_plan_sort(int64_t N, const EvalGeom &e, const FarGeom &f, const std::vector<double> &kc,
+                          const std::vector<double> &kr, std::vector<int> &start, std::vector<int> &order,
+                          int64_t *node_pairs, int64_t *cell_pairs) {
+    const int btx = f.tx, bty = f.ty;
+    const int nbx = f.ntx + 2 * FF_PAD, nby = f.nty + 2 * FF_PAD;
+    std::vector<int> bin((size_t)N);
+    start.assign((size_t)nbx * nby + 1, 0);
     for (int64_t j = 0; j < N; ++j) {
         double bx = floor(kc[j] / btx), by = floor(kr[j] / bty);
-        bx = std::min(std::max(bx, (double)-FF_PAD), (double)(f->ntx + FF_PAD - 1));
-        by = std::min(std::max(by, (double)-FF_PAD), (double)(f->nty + FF_PAD - 1));
+        bx = std::min(std::max(bx, (double)-FF_PAD), (double)(f.ntx + FF_PAD - 1));
+        by = std::min(std::max(by, (double)-FF_PAD), (double)(f.nty + FF_PAD - 1));
         bin[j] = ((int)by + FF_PAD) * nbx + ((int)bx + FF_PAD);
         ++start[(size_t)bin[j] + 1];
     }
     for (size_t b = 0; b + 1 < start.size(); ++b) start[b + 1] += start[b];
     std::vector<int> fill(start.begin(), start.end() - 1);
-    std::vector<Knot> sorted((size_t)N);
-    const double kk = 0.5 / (8.0 * M_PI);
-    for (int64_t j = 0; j < N; ++j) {
-        Knot &k = sorted[(size_t)fill[(size_t)bin[j]]++];
-        k.u = t->knots_uv[j]; k.v = t->knots_uv[N + j]; k.cw = t->c[j] * kk; k.pad = 0.0;
-    }
-    P.node_pairs = P.cell_pairs = 0;
-    for (int tyi = 0; tyi < f->nty; ++tyi)
-        for (int txi = 0; txi < f->ntx; ++txi) {
+    order.resize((size_t)N);
+    for (int64_t j = 0; j < N; ++j) order[(size_t)fill[(size_t)bin[j]]++] = (int)j;
+    int64_t np = 0, cp = 0;
+    for (int tyi = 0; tyi < f.nty; ++tyi)
+        for (int txi = 0; txi < f.ntx; ++txi) {
             int64_t near = 0;
             for (int r = 0; r < 3; ++r) {
                 const size_t b = (size_t)(tyi + FF_PAD - 1 + r) * nbx + (size_t)(txi + FF_PAD - 1);
                 near += start[b + 3] - start[b];
             }
             const int64_t tc = std::min<int64_t>(btx, e.nc - (int64_t)txi * btx) * std::min<int64_t>(bty, e.nr - (int64_t)tyi * bty);
-            P.node_pairs += (int64_t)FF_NODES * (N - near);
-            P.cell_pairs += tc * near;
+            np += (int64_t)FF_NODES * (N - near);
+            cp += tc * near;
         }
+    if (node_pairs) *node_pairs = np;
+    if (cell_pairs) *cell_pairs = cp;
+}
+
+// Choose tile sizes for the far-field-interpolated path and (re)build the handle's plan.
+static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1, int64_t c1, FarGeom *f, bool *use) {
+    const int64_t N = t->n;
+    std::vector<double> kc, kr;
+    far_plan_choose(t->knots_uv.data(), N, e, f, use, kc, kr);
+    if (!*use) return MHS_OK;
+    const int btx = f->tx, bty = f->ty;
+    mhs_tps::FarPlan &P = t->far;
+    const bool same = P.sorted_dev && P.xmin == e.xmin && P.ymax == e.ymax && P.xres == e.xres && P.yres == e.yres &&
+                      P.r0 == e.r0 && P.r1 == r1 && P.c0 == e.c0 && P.c1 == c1 && P.tx == btx && P.ty == bty;
+    if (same) return MHS_OK;
+    // The plan's device buffers are about to be rewritten (blocking copies on the null stream): kernels of the previous
+    // evaluation, enqueued on a caller's non-blocking stream, may still be reading them.
+    if (P.in_flight) { MHS_HIP(hipStreamSynchronize(P.last_stream)); P.in_flight = false; }
+    std::vector<int> start, order;
+    far_plan_sort(N, e, *f, kc, kr, start, order, &P.node_pairs, &P.cell_pairs);
+    std::vector<Knot> sorted((size_t)N);
+    const double kk = 0.5 / (8.0 * M_PI);
+    for (int64_t p = 0; p < N; ++p) {
+        const int j = order[(size_t)p];
+        Knot &k = sorted[(size_t)p];
+        k.u = t->knots_uv[j]; k.v = t->knots_uv[N + j]; k.cw = t->c[j] * kk; k.pad = 0.0;
+    }
     std::vector<double> lx, ly;
     cheb_matrix(btx, false, f->t, lx);
     cheb_matrix(bty, true, f->t, ly);
@@ -381,6 +469,124 @@ static int plan_far(mhs_tps *t, const mhs_grid *g, const EvalGeom &e, int64_t r1
     if (int rc = h2d_sync(P.ly_dev, ly.data(), sizeof(double) * ly.size())) return rc;
     P.xmin = e.xmin; P.ymax = e.ymax; P.xres = e.xres; P.yres = e.yres;
     P.r0 = e.r0; P.r1 = r1; P.c0 = e.c0; P.c1 = c1; P.tx = btx; P.ty = bty; P.ntx = f->ntx; P.nty = f->nty;
+    return MHS_OK;
+}
+
+// ---- host side of the batched evaluation (declared in tps_batch.h)
+struct EvalBatch {
+    struct Item {
+        EvalWindow w;               // pointers filled at launch
+        int64_t knot_off = 0;       // the spline's knot records in the fit batch's output
+        int res_index = 0;          // its SmallResult
+        size_t bins_off = 0, nodes_off = 0;     // in ints / doubles
+        int lxy = -1;               // index into mats
+    };
+    struct Mats { int tx, ty; std::vector<double> lx, ly; size_t lx_off = 0, ly_off = 0; };
+    std::vector<Item> items;
+    std::vector<int> bins;          // all windows' bin offsets
+    std::vector<Mats> mats;         // interpolation matrices, one pair per distinct tile size
+    size_t nodes_total = 0;
+    unsigned max_node_blocks = 0, max_cell_blocks = 0;
+};
+EvalBatch *eval_batch_create() { return new EvalBatch(); }
+void eval_batch_destroy(EvalBatch *B) { delete B; }
+
+int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                   int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, int res_index, int64_t knot_off,
+                   std::vector<int> &perm) {
+    MHS_REQUIRE(r1 - r0 < (1LL << 30) && c1 - c0 < (1LL << 30) && r1 > r0 && c1 > c0, "window too large or empty");
+    EvalBatch::Item it;
+    memset(&it.w, 0, sizeof(it.w));
+    EvalGeom &e = it.w.g;
+    e.xmin = grid->xmin; e.ymax = grid->ymax; e.xres = grid->xres; e.yres = grid->yres;
+    e.cx = center[0]; e.cy = center[1]; e.sx = scale[0]; e.sy = scale[1];
+    e.d0 = e.d1 = e.d2 = 0.0;
+    e.r0 = r0; e.c0 = c0; e.nr = (int)(r1 - r0); e.nc = (int)(c1 - c0); e.ld = ld;
+    it.w.out = out_dev; it.w.n = n;
+    it.knot_off = knot_off; it.res_index = res_index;
+    bool far = false;
+    std::vector<double> kc, kr;
+    far_plan_choose(knots_uv, n, e, &it.w.f, &far, kc, kr);
+    perm.resize((size_t)n);
+    if (far) {
+        std::vector<int> start, order;
+        far_plan_sort(n, e, it.w.f, kc, kr, start, order, nullptr, nullptr);
+        for (int p = 0; p < n; ++p) perm[(size_t)order[(size_t)p]] = p;
+        it.bins_off = B->bins.size();
+        B->bins.insert(B->bins.end(), start.begin(), start.end());
+        it.nodes_off = B->nodes_total;
+        B->nodes_total += (size_t)it.w.f.ntx * it.w.f.nty * FF_NODES;
+        for (size_t q = 0; q < B->mats.size(); ++q)
+            if (B->mats[q].tx == it.w.f.tx && B->mats[q].ty == it.w.f.ty) it.lxy = (int)q;
+        if (it.lxy < 0) {
+            EvalBatch::Mats m;
+            m.tx = it.w.f.tx; m.ty = it.w.f.ty;
+            cheb_matrix(m.tx, false, it.w.f.t, m.lx);
+            cheb_matrix(m.ty, true, it.w.f.t, m.ly);
+            it.lxy = (int)B->mats.size();
+            B->mats.push_back(std::move(m));
+        }
+        it.w.far = 1;
+        it.w.node_blocks = (it.w.f.ntx * it.w.f.nty + 3) / 4;
+        it.w.cgx = it.w.f.ntx * (it.w.f.tx / 64);
+        it.w.cgy = it.w.f.nty * (it.w.f.ty / EVAL_TILE_ROWS);
+    } else {
+        for (int p = 0; p < n; ++p) perm[(size_t)p] = p;
+        it.w.far = 0; it.w.node_blocks = 0;
+        it.w.cgx = (e.nc + 63) / 64;
+        it.w.cgy = (e.nr + EVAL_TILE_ROWS - 1) / EVAL_TILE_ROWS;
+    }
+    B->max_node_blocks = std::max(B->max_node_blocks, (unsigned)it.w.node_blocks);
+    B->max_cell_blocks = std::max(B->max_cell_blocks, (unsigned)(it.w.cgx * it.w.cgy));
+    B->items.push_back(it);
+    return MHS_OK;
+}
+
+static size_t eb_up(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t eval_batch_device_bytes(const EvalBatch *B) {
+    size_t off = 0;
+    off = eb_up(off + sizeof(EvalWindow) * B->items.size());
+    off = eb_up(off + sizeof(int) * B->bins.size());
+    for (const EvalBatch::Mats &m : B->mats) off = eb_up(off + sizeof(double) * (m.lx.size() + m.ly.size()));
+    off = eb_up(off + sizeof(double) * B->nodes_total);
+    return off;
+}
+
+int eval_batch_launch(EvalBatch *B, char *dev, const Knot *knots_base, const SmallResult *res_base, hipStream_t s) {
+    if (B->items.empty()) return MHS_OK;
+    size_t off = 0;
+    EvalWindow *wdev = (EvalWindow *)(dev + off); off = eb_up(off + sizeof(EvalWindow) * B->items.size());
+    int *bins_dev = (int *)(dev + off); off = eb_up(off + sizeof(int) * B->bins.size());
+    std::vector<double *> lxd, lyd;
+    for (EvalBatch::Mats &m : B->mats) {
+        double *p = (double *)(dev + off);
+        off = eb_up(off + sizeof(double) * (m.lx.size() + m.ly.size()));
+        lxd.push_back(p); lyd.push_back(p + m.lx.size());
+        MHS_HIP(hipMemcpyAsync(p, m.lx.data(), sizeof(double) * m.lx.size(), hipMemcpyHostToDevice, s));
+        MHS_HIP(hipMemcpyAsync(p + m.lx.size(), m.ly.data(), sizeof(double) * m.ly.size(), hipMemcpyHostToDevice, s));
+    }
+    double *nodes_dev = (double *)(dev + off);
+    std::vector<EvalWindow> w(B->items.size());
+    for (size_t k = 0; k < B->items.size(); ++k) {
+        const EvalBatch::Item &it = B->items[k];
+        w[k] = it.w;
+        w[k].knots = knots_base + it.knot_off;
+        w[k].d3 = res_base[it.res_index].d;
+        if (it.w.far) {
+            w[k].bin_start = bins_dev + it.bins_off;
+            w[k].nodes = nodes_dev + it.nodes_off;
+            w[k].lx = lxd[(size_t)it.lxy]; w[k].ly = lyd[(size_t)it.lxy];
+        }
+    }
+    MHS_HIP(hipMemcpyAsync(wdev, w.data(), sizeof(EvalWindow) * w.size(), hipMemcpyHostToDevice, s));
+    if (!B->bins.empty()) MHS_HIP(hipMemcpyAsync(bins_dev, B->bins.data(), sizeof(int) * B->bins.size(), hipMemcpyHostToDevice, s));
+    MHS_HIP(hipStreamSynchronize(s));      // w is a host temporary (pageable copies are staged, but keep it simple and safe)
+    const unsigned nt = (unsigned)B->items.size();
+    MHS_REQUIRE(nt <= 65535u, "too many windows for one launch");
+    if (B->max_node_blocks > 0)
+        hipLaunchKernelGGL(tps_batch_nodes_kernel, dim3(B->max_node_blocks, nt), dim3(256), 0, s, wdev, ctx().log_tab);
+    hipLaunchKernelGGL(tps_batch_cells_kernel, dim3(B->max_cell_blocks, nt), dim3(64 * EVAL_WAVES), 0, s, wdev, ctx().log_tab);
+    MHS_HIP(hipGetLastError());
     return MHS_OK;
 }
 

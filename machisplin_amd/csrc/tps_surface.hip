@@ -13,94 +13,160 @@
 #include <thread>
 #include <vector>
 #include "common.h"
+#include "tps_batch.h"
 
 using namespace mhs;
 
 constexpr int64_t TILE_LANES = 8;   // tiles fitted side by side (mhs_tps_surface)
 
-// Fit and evaluate a set of Step-3 tiles side by side: job k = tile tile_ids[k] (or tile k), its keep-window plane
-// (rows x cols of the window, contiguous) written to out_ptrs[k].  Returns after every lane has finished.
+// Fit and evaluate a set of Step-3 tiles: job k = tile tile_ids[k] (or tile k), its keep-window plane (rows x cols of
+// the window, contiguous) written to out_ptrs[k].  Returns after everything has finished.
+//
+// Round 6: every tile with 8..256 distinct stations -- all of them at the reference's tile size (105-250
+// per tile) -- goes through ONE fit launch (tps_batch.hip: a workgroup per spline) and ONE pair of evaluation launches
+// (tps_eval.hip: a window per spline, knots and polynomial part read where the fit left them): three kernels and two
+// copies for the whole set, where rounds 1-5 drove a chain of ~10 launches and 4 host round trips per tile from eight
+// host threads (41 ms for cfg3's 49 tiles; the launches were the time).  Tiles the batch cannot hold (more than 256
+// stations: tile_edge far above the reference's 1500) still take that route, on the lanes, beside the batch.
+// MHS_TILES_BATCH=0 sends every tile down the lanes (the parity tests compare the two).
 static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, int64_t n, const double *cov1_at_stations,
                      const std::vector<int64_t> &fit, const std::vector<int64_t> &keep, const std::vector<int64_t> &rows,
                      const std::vector<int64_t> &cols, double lambda, int gcv_mode, const int64_t *tile_ids, int64_t njobs,
                      double *const *out_ptrs) {
     if (njobs <= 0) return MHS_OK;
-    // The tiles' fits are chains of small, latency-bound kernels: several of them run side by side, each on
-    // its own lane (two streams + work arena) driven by its own host thread.
-    const int64_t want_lanes = TILE_LANES;
-    const int nlanes = (int)std::min<int64_t>(njobs, want_lanes);
-    std::vector<FitLane *> lanes((size_t)nlanes);
-    for (int l = 0; l < nlanes; ++l)
-        if (int rc = fit_lane(1 + l, &lanes[(size_t)l])) return rc;
-    std::vector<mhs_tps *> handles((size_t)njobs, nullptr);
-    std::atomic<int64_t> next{0};
-    std::atomic<int> first_rc{MHS_OK};
-    std::mutex err_mu;
-    std::string err_msg;
-    const int slot = current_slot();
-    auto worker = [&](int lane_id) {
-        FitLane &L = *lanes[(size_t)lane_id];
-        SlotBind bind(slot);                // the slot and HIP's current device are per host thread
-        // mhs_fit_reserve_cus active: the tiles' evaluations stay, like their fits, on the reserved compute units
-        const hipStream_t ls = (ctx().reserved_cus > 0 && L.ms) ? L.ms : L.s;
-        std::vector<double> sx, sy, sr, txy;
-        for (;;) {
-            const int64_t job = next.fetch_add(1);
-            if (job >= njobs || first_rc.load() != MHS_OK) break;
-            const int64_t h = tile_ids ? tile_ids[job] : job;
-            double *dst = out_ptrs[job];
-            const int64_t *f = &fit[(size_t)h * 4], *k = &keep[(size_t)h * 4];
-            const int64_t kr = k[1] - k[0], kc = k[3] - k[2];
-            sx.clear(); sy.clear(); sr.clear();
-            for (int64_t i = 0; i < n; ++i) {  // terra::extract(rb[[1]], Full.cords) + complete.cases (V73:701-706)
-                if (rows[i] < f[0] || rows[i] >= f[1] || cols[i] < f[2] || cols[i] >= f[3]) continue;
-                if (cov1_at_stations && std::isnan(cov1_at_stations[i])) continue;
-                if (std::isnan(resid[i])) continue;
-                sx.push_back(xy[i]); sy.push_back(xy[n + i]); sr.push_back(resid[i]);
+    const char *benv = getenv("MHS_TILES_BATCH");
+    const bool use_batch = !(benv && benv[0] == '0');
+    // ---- the tiles' stations (terra::extract(rb[[1]], Full.cords) + complete.cases, V73:701-706)
+    struct Job { int64_t h; std::vector<double> txy, sr; int64_t m = 0; int route = 0; /* 0 zeros, 1 batch, 2 lane */ int bjob = -1; };
+    std::vector<Job> jobs((size_t)njobs);
+    FitLane *Lb = nullptr;
+    if (int rc = fit_lane(BATCH_LANE, &Lb)) return rc;
+    const hipStream_t sb = Lb->s;
+    SmallBatch B;
+    EvalBatch *EB = eval_batch_create();
+    struct EbGuard { EvalBatch *p; ~EbGuard() { eval_batch_destroy(p); } } eb_guard{EB};
+    std::vector<TpsPrep> preps((size_t)njobs);
+    std::vector<int64_t> lane_jobs;
+    std::vector<double> sx, sy;
+    std::vector<int> perm;
+    for (int64_t job = 0; job < njobs; ++job) {
+        Job &J = jobs[(size_t)job];
+        J.h = tile_ids ? tile_ids[job] : job;
+        const int64_t *f = &fit[(size_t)J.h * 4], *k = &keep[(size_t)J.h * 4];
+        const int64_t kr = k[1] - k[0], kc = k[3] - k[2];
+        sx.clear(); sy.clear(); J.sr.clear();
+        for (int64_t i = 0; i < n; ++i) {
+            if (rows[i] < f[0] || rows[i] >= f[1] || cols[i] < f[2] || cols[i] >= f[3]) continue;
+            if (cov1_at_stations && std::isnan(cov1_at_stations[i])) continue;
+            if (std::isnan(resid[i])) continue;
+            sx.push_back(xy[i]); sy.push_back(xy[n + i]); J.sr.push_back(resid[i]);
+        }
+        J.m = (int64_t)J.sr.size();
+        if (J.m < 10) {  // V73:710-721: the tile is all zeros
+            J.route = 0;
+            MHS_HIP(hipMemsetAsync(out_ptrs[job], 0, sizeof(double) * (size_t)(kr * kc), sb));
+            continue;
+        }
+        J.txy.resize((size_t)2 * J.m);
+        for (int64_t i = 0; i < J.m; ++i) { J.txy[(size_t)i] = sx[(size_t)i]; J.txy[(size_t)(J.m + i)] = sy[(size_t)i]; }
+        J.route = 2;
+        if (use_batch && J.m <= 4 * SB_NMAX) {      // (replicates can only shrink the count)
+            TpsPrep &P = preps[(size_t)job];
+            if (int rc = tps_prepare(J.txy.data(), J.sr.data(), J.m, P)) return rc;
+            if (P.n >= SB_NMIN && P.n <= SB_NMAX) {
+                // terra::interpolate(terra::rast(rb), tps): cell centres of the FIT raster (V73:726), the keep window of it
+                mhs_grid gf = *g;
+                gf.xmin = g->xmin + (double)f[2] * g->xres;
+                gf.ymax = g->ymax - (double)f[0] * g->yres;
+                gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
+                if (int rc = eval_batch_add(EB, P.uv.data(), (int)P.n, P.center, P.scale, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2],
+                                            k[3] - f[2], out_ptrs[job], kc, B.count, B.knot_total, perm)) return rc;
+                J.bjob = small_batch_add(B, P, lambda, gcv_mode, perm.data());
+                J.route = 1;
             }
-            const int64_t m = (int64_t)sr.size();
-            int rc = MHS_OK;
-            if (m < 10) {  // V73:710-721: the tile is all zeros
-                if (hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(kr * kc), ls) != hipSuccess) rc = MHS_ERR_HIP;
-            } else {
-                txy.resize((size_t)2 * m);
-                for (int64_t i = 0; i < m; ++i) { txy[i] = sx[i]; txy[m + i] = sy[i]; }
+        }
+        if (J.route == 2) lane_jobs.push_back(job);
+    }
+    // ---- the batch: fit launch, then the two evaluation launches behind it on the same stream
+    char *extra = nullptr;
+    if (int rc = small_batch_launch(B, *Lb, sb, eval_batch_device_bytes(EB), &extra)) return rc;
+    if (B.count > 0)
+        if (int rc = eval_batch_launch(EB, extra, B.knots_dev, B.res_dev, sb)) return rc;
+    // ---- the other tiles: chains of small, latency-bound kernels, several side by side, each on its own lane (two streams +
+    // work arena) driven by its own host thread
+    int rc = MHS_OK;
+    std::string err_msg;
+    std::vector<mhs_tps *> handles(lane_jobs.size(), nullptr);
+    std::vector<FitLane *> lanes;
+    if (!lane_jobs.empty()) {
+        const int nlanes = (int)std::min<int64_t>((int64_t)lane_jobs.size(), TILE_LANES);
+        lanes.resize((size_t)nlanes);
+        for (int l = 0; l < nlanes; ++l)
+            if (int rc2 = fit_lane(1 + l, &lanes[(size_t)l])) return rc2;
+        std::atomic<int64_t> next{0};
+        std::atomic<int> first_rc{MHS_OK};
+        std::mutex err_mu;
+        const int slot = current_slot();
+        auto worker = [&](int lane_id) {
+            FitLane &L = *lanes[(size_t)lane_id];
+            SlotBind bind(slot);                // the slot and HIP's current device are per host thread
+            // mhs_fit_reserve_cus active: the tiles' evaluations stay, like their fits, on the reserved compute units
+            const hipStream_t ls = (ctx().reserved_cus > 0 && L.ms) ? L.ms : L.s;
+            for (;;) {
+                const int64_t q = next.fetch_add(1);
+                if (q >= (int64_t)lane_jobs.size() || first_rc.load() != MHS_OK) break;
+                const int64_t job = lane_jobs[(size_t)q];
+                Job &J = jobs[(size_t)job];
+                const int64_t *f = &fit[(size_t)J.h * 4], *k = &keep[(size_t)J.h * 4];
+                const int64_t kc = k[3] - k[2];
                 mhs_tps *t = nullptr;
-                rc = tps_fit_lane(L, txy.data(), sr.data(), m, lambda, gcv_mode, m < 1500 ? 2 : 0, &t);
-                if (!rc) {
-                    handles[(size_t)job] = t;   // freed after the last tile: hipFree synchronises the device
-                    // terra::interpolate(terra::rast(rb), tps): cell centres of the FIT raster (V73:726)
+                int rc2 = tps_fit_lane(L, J.txy.data(), J.sr.data(), J.m, lambda, gcv_mode, J.m < 1500 ? 2 : 0, &t);
+                if (!rc2) {
+                    handles[(size_t)q] = t;   // freed after the last tile: hipFree synchronises the device
                     mhs_grid gf = *g;
                     gf.xmin = g->xmin + (double)f[2] * g->xres;
                     gf.ymax = g->ymax - (double)f[0] * g->yres;
                     gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
-                    rc = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], dst, kc, ls);
+                    rc2 = mhs_tps_predict_grid_dev(t, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2], k[3] - f[2], out_ptrs[job], kc, ls);
+                }
+                if (rc2) {
+                    int expected = MHS_OK;
+                    if (first_rc.compare_exchange_strong(expected, rc2)) {
+                        std::lock_guard<std::mutex> lk(err_mu);
+                        err_msg = mhs_last_error();   // thread-local in the worker: carry it to the caller
+                    }
+                    break;
                 }
             }
-            if (rc) {
-                int expected = MHS_OK;
-                if (first_rc.compare_exchange_strong(expected, rc)) {
-                    std::lock_guard<std::mutex> lk(err_mu);
-                    err_msg = mhs_last_error();   // thread-local in the worker: carry it to the caller
-                }
-                break;
-            }
+        };
+        {
+            std::vector<std::thread> threads;
+            for (int l = 1; l < nlanes; ++l) threads.emplace_back(worker, l);
+            worker(0);
+            for (std::thread &th : threads) th.join();
         }
-    };
-    {
-        std::vector<std::thread> threads;
-        for (int l = 1; l < nlanes; ++l) threads.emplace_back(worker, l);
-        worker(0);
-        for (std::thread &th : threads) th.join();
+        rc = first_rc.load();
+        for (FitLane *L : lanes) {
+            if (hipStreamSynchronize(L->s) != hipSuccess && !rc) rc = MHS_ERR_HIP;
+            if (L->ms && hipStreamSynchronize(L->ms) != hipSuccess && !rc) rc = MHS_ERR_HIP;
+        }
     }
-    int rc = first_rc.load();
-    for (FitLane *L : lanes) {
-        if (hipStreamSynchronize(L->s) != hipSuccess && !rc) rc = MHS_ERR_HIP;
-        if (L->ms && hipStreamSynchronize(L->ms) != hipSuccess && !rc) rc = MHS_ERR_HIP;
-    }
+    // ---- the batch's verdicts
+    std::vector<SmallResult> res;
+    if (int rc2 = small_batch_results(B, sb, res, nullptr)) { if (!rc) rc = rc2; }
+    else if (hipStreamSynchronize(sb) != hipSuccess) { if (!rc) rc = MHS_ERR_HIP; }
     for (mhs_tps *t : handles) tps_free_quiet(t);      // every lane is idle: no wait, the blocks go back to the pool
-    if (rc && !err_msg.empty()) set_error("%s", err_msg.c_str());
-    return rc;
+    if (rc) { if (!err_msg.empty()) set_error("%s", err_msg.c_str()); return rc; }
+    for (const SmallResult &r : res)
+        if (r.status != 0.0) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }
+    if (getenv("MHS_TIMING") && !res.empty()) {
+        double t[8] = {0};
+        for (const SmallResult &r : res) for (int q = 0; q < 8; ++q) t[q] += r.t_us[q] / (double)res.size();
+        fprintf(stderr, "[run_tiles] %d tiles batched, %d on the lanes; mean us per batched fit: gram %.1f projection %.1f tridiagonalisation %.1f "
+                "eigenvalues %.1f bracket+grid %.1f golden section %.1f solve+back-transform %.1f\n", (int)res.size(), (int)lane_jobs.size(),
+                t[6], t[0], t[1], t[2], t[3], t[4], t[5]);
+    }
+    return MHS_OK;
 }
 
 extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const double *resid, int64_t n,

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib, tiles
 from .models import ensemble_predict
 from .raster import Geometry, RasterStack
-from .tps import Tps, interpolate
+from .tps import Tps, fit_many, interpolate
 
 
 def station_predictors(stack: RasterStack, xy):
@@ -98,17 +98,27 @@ def tps_residual_surface(geom: Geometry, knots_xy, resid, cov1_at_stations=None,
     ok = rows >= 0
     if cov1_at_stations is not None:
         ok &= ~np.isnan(np.asarray(cov1_at_stations, dtype=np.float64))
+    # the tiles' stations first, then every tile's fields::Tps in ONE library call (mhs_tps_fit_many: a workgroup per
+    # spline -- the arithmetic mhs_tps_surface itself uses for its tiles), then the evaluations
+    sels = []
+    for h in range(nRx * nCx):
+        fr0, fr1, fc0, fc1 = (int(v) for v in fit_win[h])
+        sels.append(np.flatnonzero(ok & (rows >= fr0) & (rows < fr1) & (cols >= fc0) & (cols < fc1)))
+    todo = [h for h in range(nRx * nCx) if sels[h].size >= 10]
+    fits = dict(zip(todo, fit_many([knots_xy[sels[h]] for h in todo], [resid[sels[h]] for h in todo],
+                                   lambda_=lambda_, gcv_mode=gcv_mode)))
     bufs = []
     for h in range(nRx * nCx):
         fr0, fr1, fc0, fc1 = (int(v) for v in fit_win[h])
         kr0, kr1, kc0, kc1 = (int(v) for v in keep_win[h])
-        sel = np.flatnonzero(ok & (rows >= fr0) & (rows < fr1) & (cols >= fc0) & (cols < fc1))
-        if sel.size < 10:  # V73:710-721: the tile is all zeros
+        if h not in fits:  # V73:710-721: the tile is all zeros
             bufs.append(torch.zeros((kr1 - kr0, kc1 - kc0), dtype=torch.float64, device=dev))
             if info is not None:
-                info["tile_n"].append(int(sel.size)); info["lambda"].append(float("nan"))
+                info["tile_n"].append(int(sels[h].size)); info["lambda"].append(float("nan"))
             continue
-        fit = Tps(knots_xy[sel], resid[sel], lambda_=lambda_, gcv_mode=gcv_mode)
+        fit = fits[h]
+        if fit is None:
+            raise _lib.MhsError(_lib.ERR_NUMERIC, f"the spline of tile {h} could not be fitted")
         gf = geom.window(fr0, fr1, fc0, fc1)  # terra::rast(rb): geometry of the fit raster
         bufs.append(interpolate(gf, fit, window=(kr0 - fr0, kr1 - fr0, kc0 - fc0, kc1 - fc0)))
         if info is not None:

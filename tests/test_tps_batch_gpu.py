@@ -84,3 +84,46 @@ def test_batch_many_more_fits_than_compute_units(hip):
         assert fits[k].lambda_ == alone.lambda_ and np.array_equal(fits[k].c, alone.c) and np.array_equal(fits[k].d, alone.d)
     want = otps.fit(*sets[300])
     assert abs(fits[300].lambda_ - want["lambda"]) / want["lambda"] < 1e-8
+
+
+def test_tiled_surface_batched_route_equals_lane_route(hip, monkeypatch):
+    """mhs_tps_surface's tiles through the batch (one fit launch + one pair of evaluation launches) against the same
+    tiles fitted and evaluated one by one on the lanes (MHS_TILES_BATCH=0, the route of rounds 1-5): the spline of every
+    tile agrees to 1e-10, hence the mosaicked, feathered surface."""
+    from machisplin_amd import synth
+    g = synth.grid(700, 900)
+    xy, rows, cols, uv = synth.stations(g, 1800, 5)
+    resid = synth.tps_residual(uv, 5)
+    cov1 = np.ones(1800)
+    cov1[::41] = np.nan
+    got = hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=300).cpu().numpy()
+    monkeypatch.setenv("MHS_TILES_BATCH", "0")
+    want = hip.tps_residual_surface(g, xy, resid, cov1_at_stations=cov1, tile_edge=300).cpu().numpy()
+    monkeypatch.delenv("MHS_TILES_BATCH")
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    # fixed lambda takes the same two routes
+    got = hip.tps_residual_surface(g, xy, resid, tile_edge=300, lambda_=2e-3).cpu().numpy()
+    monkeypatch.setenv("MHS_TILES_BATCH", "0")
+    want = hip.tps_residual_surface(g, xy, resid, tile_edge=300, lambda_=2e-3).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
+def test_tiled_surface_mixes_batch_and_lanes(hip):
+    """A tile edge far above the reference's: some tiles hold more than 256 stations (lanes), the sparse corner ones
+    fewer (batch); the one-call surface equals the Python composition of the same steps bit for bit."""
+    from machisplin_amd import synth
+    g = synth.grid(600, 800)
+    rng = np.random.default_rng(3)
+    # dense in the west, sparse in the east
+    cells_w = rng.choice(600 * 400, size=1500, replace=False)
+    cells_e = rng.choice(600 * 400, size=150, replace=False)
+    rows = np.concatenate([cells_w // 400, cells_e // 400]); cols = np.concatenate([cells_w % 400, 400 + cells_e % 400])
+    xy = np.column_stack([g.x_from_col(cols), g.y_from_row(rows)])
+    u = (xy - xy.min(0)) / (xy.max(0) - xy.min(0))
+    resid = np.sin(6 * u[:, 0]) * np.cos(5 * u[:, 1]) + 0.1 * rng.standard_normal(xy.shape[0])
+    info = {}
+    want = hip.tps_residual_surface(g, xy, resid, tile_edge=400, info=info).cpu().numpy()
+    assert max(info["tile_n"]) > 256 and min(n for n in info["tile_n"] if n >= 10) <= 256
+    got = hip.tps_residual_surface(g, xy, resid, tile_edge=400).cpu().numpy()
+    assert np.array_equal(got, want)
