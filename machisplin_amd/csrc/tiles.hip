@@ -87,80 +87,129 @@ static int check_grid(const mhs_grid *g) {
 }
 
 // ------------------------------------------------------------------- kernels --
-// base / strip accumulation planes: double sum + uint8 count
-__global__ __launch_bounds__(256) void accum_tile_kernel(const double *__restrict__ tile, int64_t tld,
-                                                         Win w, double *__restrict__ sum,
-                                                         unsigned char *__restrict__ cnt, int64_t ncol) {
+// bounding box (rows/cols, grid indices) of the cells of window w where A + B is not NA -- every seam in one launch
+// (blockIdx.y = seam; seams whose tiles do not overlap have an empty window)
+struct TileDesc { Win w; const double *p; int64_t ld; };
+struct SeamDesc { int a, b; Win w; };
+__global__ __launch_bounds__(256) void bbox_all_kernel(const TileDesc *__restrict__ T, const SeamDesc *__restrict__ S,
+                                                       int *__restrict__ box /* per seam: rmin,rmax,cmin,cmax */) {
+    const SeamDesc sd = S[blockIdx.y];
+    const Win w = sd.w;
     const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int64_t r = i / nc, c = i - r * nc;
-    const double v = tile[r * tld + c];
-    if (!isnan(v)) {
-        const int64_t o = (w.r0 + r) * ncol + (w.c0 + c);
-        sum[o] = sum[o] + v;
-        cnt[o] = (unsigned char)(cnt[o] + 1);
+    if (total <= 0) return;
+    const TileDesc ta = T[sd.a], tb = T[sd.b];
+    int rmin = INT32_MAX, rmax = -1, cmin = INT32_MAX, cmax = -1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = w.r0 + i / nc, c = w.c0 + i % nc;
+        const double a = ta.p[(r - ta.w.r0) * ta.ld + (c - ta.w.c0)];
+        const double b = tb.p[(r - tb.w.r0) * tb.ld + (c - tb.w.c0)];
+        if (!isnan(a + b)) { rmin = min(rmin, (int)r); rmax = max(rmax, (int)r); cmin = min(cmin, (int)c); cmax = max(cmax, (int)c); }
+    }
+    if (rmax >= 0) {
+        int *bx = box + 4 * (int64_t)blockIdx.y;
+        atomicMin(&bx[0], rmin); atomicMax(&bx[1], rmax);
+        atomicMin(&bx[2], cmin); atomicMax(&bx[3], cmax);
     }
 }
 
-// bounding box (rows/cols, grid indices) of the cells of window w where A + B is not NA
-__global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ A, Win wa, int64_t lda,
-                                                   const double *__restrict__ B, Win wb, int64_t ldb,
-                                                   Win w, int *__restrict__ box /* rmin,rmax,cmin,cmax */) {
-    const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int64_t r = w.r0 + i / nc, c = w.c0 + i % nc;
-    const double a = A[(r - wa.r0) * lda + (c - wa.c0)];
-    const double b = B[(r - wb.r0) * ldb + (c - wb.c0)];
-    if (!isnan(a + b)) {
-        atomicMin(&box[0], (int)r); atomicMax(&box[1], (int)r);
-        atomicMin(&box[2], (int)c); atomicMax(&box[3], (int)c);
+// Step 4 in ONE pass over the output (round 6).  Rounds 1-5 scattered: two sum planes and two count planes zeroed,
+// every tile and every strip added into them by a launch of its own (49 + 84 launches and 2 x 18 bytes per cell of
+// scratch traffic at cfg3), a last pass composing the result -- 8.8 ms for 1e8 cells, the largest term of the tiled
+// Step 3 + 4 once the tiles' fits went into one launch.  Here a block owns a 32 x 128 patch of the output, finds the
+// few tiles and strips that touch it (bitmaps in LDS), and every cell gathers: the tiles that cover it in the
+// reference's order (the sprc is built by prepending: last tile first), then the strips in collection order, the
+// same additions in the same order as the scattered form -- bit-identical planes, 16 bytes per cell of traffic.
+struct StripDesc { int a, b, axis_y, pad; Win w; double origin, res, cmin, delta; };
+constexpr int MOSAIC_PR = 32, MOSAIC_PC = 128;
+constexpr int MOSAIC_MAXWORDS = 1024;      // up to 32 768 tiles / strips per call
+__global__ __launch_bounds__(256) void mosaic_fused_kernel(const TileDesc *__restrict__ T, int n_tiles,
+                                                           const StripDesc *__restrict__ S, int n_strips, int64_t nrow,
+                                                           int64_t ncol, double *__restrict__ out, int64_t ld) {
+    __shared__ unsigned tmap[MOSAIC_MAXWORDS], smap[MOSAIC_MAXWORDS];
+    const int tw = (n_tiles + 31) >> 5, sw = (n_strips + 31) >> 5;
+    for (int i = threadIdx.x; i < tw; i += 256) tmap[i] = 0u;
+    for (int i = threadIdx.x; i < sw; i += 256) smap[i] = 0u;
+    __syncthreads();
+    const int64_t pr0 = (int64_t)blockIdx.y * MOSAIC_PR, pc0 = (int64_t)blockIdx.x * MOSAIC_PC;
+    const int64_t pr1 = min(pr0 + MOSAIC_PR, nrow), pc1 = min(pc0 + MOSAIC_PC, ncol);
+    for (int h = threadIdx.x; h < n_tiles; h += 256) {
+        const Win w = T[h].w;
+        if (w.r0 < pr1 && w.r1 > pr0 && w.c0 < pc1 && w.c1 > pc0) atomicOr(&tmap[h >> 5], 1u << (h & 31));
     }
-}
-
-// one seam strip: feath = B * t + A * (1 - t), t = (coord - cmin) / delta   (V73:787-798)
-__global__ __launch_bounds__(256) void strip_kernel(const double *__restrict__ A, Win wa, int64_t lda,
-                                                    const double *__restrict__ B, Win wb, int64_t ldb,
-                                                    Win w, int axis_y, double origin, double res,
-                                                    double cmin, double delta, double *__restrict__ sum,
-                                                    unsigned char *__restrict__ cnt, int64_t ncol) {
-    const int64_t nc = w.c1 - w.c0, total = (w.r1 - w.r0) * nc;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int64_t lr = i / nc, lc = i - lr * nc;
-    const int64_t r = w.r0 + lr, c = w.c0 + lc;
-    const bool ina = r >= wa.r0 && r < wa.r1 && c >= wa.c0 && c < wa.c1;
-    const bool inb = r >= wb.r0 && r < wb.r1 && c >= wb.c0 && c < wb.c1;
-    const double a = ina ? A[(r - wa.r0) * lda + (c - wa.c0)] : NAN;   // extend(): NA outside
-    const double b = inb ? B[(r - wb.r0) * ldb + (c - wb.c0)] : NAN;
-    // strip raster's own cell centres: xmin_s + (col + 0.5) xres  /  ymax_s - (row + 0.5) yres
-    const double coord = axis_y ? origin - ((double)lr + 0.5) * res : origin + ((double)lc + 0.5) * res;
-    const double stD2 = (coord - cmin) / delta;
-    const double stD1 = 1.0 - (coord - cmin) / delta;
-    const double v = b * stD2 + a * stD1;
-    if (!isnan(v)) {
-        const int64_t o = r * ncol + c;
-        sum[o] = sum[o] + v;
-        cnt[o] = (unsigned char)(cnt[o] + 1);
+    for (int q = threadIdx.x; q < n_strips; q += 256) {
+        const Win w = S[q].w;
+        if (w.r0 < pr1 && w.r1 > pr0 && w.c0 < pc1 && w.c1 > pc0) atomicOr(&smap[q >> 5], 1u << (q & 31));
     }
-}
-
-// final.TPS = first non-NA of (mean of strips, mean of tiles)   (V73:887-889, 1528-1540)
-__global__ __launch_bounds__(256) void compose_kernel(const double *__restrict__ ssum,
-                                                      const unsigned char *__restrict__ scnt,
-                                                      const double *__restrict__ bsum,
-                                                      const unsigned char *__restrict__ bcnt,
-                                                      int64_t nrow, int64_t ncol, double *__restrict__ out,
-                                                      int64_t ld) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nrow * ncol) return;
-    const int64_t r = i / ncol, c = i - r * ncol;
-    double v;
-    if (scnt[i] > 0) v = ssum[i] / (double)scnt[i];
-    else if (bcnt[i] > 0) v = bsum[i] / (double)bcnt[i];
-    else v = NAN;
-    out[r * ld + c] = v;
+    __syncthreads();
+    const int64_t c = pc0 + (threadIdx.x & (MOSAIC_PC - 1));
+    const int64_t rbase = pr0 + (threadIdx.x / MOSAIC_PC) * (MOSAIC_PR / (256 / MOSAIC_PC));
+    constexpr int RPT = MOSAIC_PR / (256 / MOSAIC_PC);      // rows per thread
+    double bsum[RPT], ssum[RPT];
+    int bcnt[RPT], scnt[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { bsum[k] = 0.0; ssum[k] = 0.0; bcnt[k] = 0; scnt[k] = 0; }
+    // mean mosaic of the tiles: last tile first
+    for (int wi = tw - 1; wi >= 0; --wi) {
+        unsigned bits = tmap[wi];
+        while (bits) {
+            const int bit = 31 - __clz(bits);
+            bits &= ~(1u << bit);
+            const TileDesc t = T[wi * 32 + bit];
+            if (c >= t.w.c0 && c < t.w.c1) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const int64_t r = rbase + k;
+                    if (r >= t.w.r0 && r < t.w.r1) {
+                        const double v = t.p[(r - t.w.r0) * t.ld + (c - t.w.c0)];
+                        if (!isnan(v)) { bsum[k] = bsum[k] + v; ++bcnt[k]; }
+                    }
+                }
+            }
+        }
+    }
+    // seam strips in collection order: feath = B * t + A * (1 - t), t = (coord - cmin) / delta   (V73:787-798)
+    for (int wi = 0; wi < sw; ++wi) {
+        unsigned bits = smap[wi];
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= ~(1u << bit);
+            const StripDesc sd = S[wi * 32 + bit];
+            if (c >= sd.w.c0 && c < sd.w.c1) {
+                const TileDesc ta = T[sd.a], tb = T[sd.b];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const int64_t r = rbase + k;
+                    if (r >= sd.w.r0 && r < sd.w.r1) {
+                        const int64_t lr = r - sd.w.r0, lc = c - sd.w.c0;
+                        const bool ina = r >= ta.w.r0 && r < ta.w.r1 && c >= ta.w.c0 && c < ta.w.c1;
+                        const bool inb = r >= tb.w.r0 && r < tb.w.r1 && c >= tb.w.c0 && c < tb.w.c1;
+                        const double a = ina ? ta.p[(r - ta.w.r0) * ta.ld + (c - ta.w.c0)] : NAN;   // extend(): NA outside
+                        const double b = inb ? tb.p[(r - tb.w.r0) * tb.ld + (c - tb.w.c0)] : NAN;
+                        // strip raster's own cell centres: xmin_s + (col + 0.5) xres  /  ymax_s - (row + 0.5) yres
+                        const double coord = sd.axis_y ? sd.origin - ((double)lr + 0.5) * sd.res : sd.origin + ((double)lc + 0.5) * sd.res;
+                        const double stD2 = (coord - sd.cmin) / sd.delta;
+                        const double stD1 = 1.0 - (coord - sd.cmin) / sd.delta;
+                        const double v = b * stD2 + a * stD1;
+                        if (!isnan(v)) { ssum[k] = ssum[k] + v; ++scnt[k]; }
+                    }
+                }
+            }
+        }
+    }
+    // final.TPS = first non-NA of (mean of strips, mean of tiles)   (V73:887-889, 1528-1540)
+    if (c < ncol) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t r = rbase + k;
+            if (r < nrow) {
+                double v;
+                if (scnt[k] > 0) v = ssum[k] / (double)scnt[k];
+                else if (bcnt[k] > 0) v = bsum[k] / (double)bcnt[k];
+                else v = NAN;
+                out[r * ld + c] = v;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ plane, int64_t ld,
@@ -272,77 +321,79 @@ int mhs_tiles_create_windows(const mhs_grid *g, int64_t out_ncol, int64_t out_nr
     return MHS_OK;
 }
 
-int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
-                           const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
-                           int64_t *seam_win_out, void *stream) {
+}  // extern "C"
+
+// finite_tiles: the caller vouches that no tile holds an NA (thin-plate-spline planes: mhs_tps_surface) -- every seam's
+// A + B is then non-NA on the whole overlap and the bounding-box pass (a kernel, a copy back and a host wait) is skipped
+int mhs::mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
+                             const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
+                             int64_t *seam_win_out, void *stream, bool finite_tiles) {
     if (int rc = require_ready()) return rc;
     if (int rc = check_grid(g)) return rc;
     MHS_REQUIRE(nRx >= 1 && nCx >= 1 && tile_win && tile_dev && out_dev && ld >= g->ncol, "bad arguments");
     hipStream_t s = pick_stream(stream);
-    const int64_t n = nRx * nCx, cells = g->nrow * g->ncol;
+    const int64_t n = nRx * nCx;
+    MHS_REQUIRE(n <= 32 * MOSAIC_MAXWORDS, "too many tiles");
     std::vector<Win> tw((size_t)n);
+    std::vector<TileDesc> td((size_t)n);
     for (int64_t h = 0; h < n; ++h) {
         tw[h] = Win{tile_win[4 * h], tile_win[4 * h + 1], tile_win[4 * h + 2], tile_win[4 * h + 3]};
         MHS_REQUIRE(0 <= tw[h].r0 && tw[h].r0 < tw[h].r1 && tw[h].r1 <= g->nrow && 0 <= tw[h].c0 &&
                     tw[h].c0 < tw[h].c1 && tw[h].c1 <= g->ncol && tile_dev[h], "bad tile window");
+        td[h] = TileDesc{tw[h], tile_dev[h], tw[h].c1 - tw[h].c0};
     }
-    // 18 bytes per cell of scratch (two sums, two counts) + the seams' boxes, from a grow-only arena: a hipMalloc /
-    // hipFree pair of 1.8 GB per call cost 40-60 ms per merged layer at 10 000^2 cells (and the free synchronises the
-    // device).  One call at a time uses it; the call ends with a stream synchronisation.
+    std::vector<Seam> seams = n > 1 ? seam_list(nRx, nCx) : std::vector<Seam>();
+    const size_t ns = seams.size();
+    MHS_REQUIRE((int64_t)ns <= 32 * MOSAIC_MAXWORDS, "too many seams");
+    // descriptors and the seams' boxes live in a small grow-only arena of the slot (one call at a time uses it; the
+    // call ends with a stream synchronisation)
     std::lock_guard<std::mutex> arena_lock(mosaic_mutex());
-    struct Span { double *p; };
-    struct SpanB { unsigned char *p; };
-    struct SpanI { int *p; };
-    Span bsum, ssum;
-    SpanB bcnt, scnt;
-    SpanI box;
+    TileDesc *td_dev; SeamDesc *sd_dev; StripDesc *st_dev; int *box_dev;
     {
         Context &c = ctx();
-        const size_t ns_max = (size_t)seam_list(nRx, nCx).size();
-        const size_t need = (size_t)cells * 18 + 16 * (ns_max + 1) + 64;
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_td = 0, o_sd = up(o_td + sizeof(TileDesc) * (size_t)n), o_st = up(o_sd + sizeof(SeamDesc) * (ns + 1)),
+                     o_box = up(o_st + sizeof(StripDesc) * (ns + 1)), need = up(o_box + 16 * (ns + 1));
         const int lane = mosaic_lane();
         if (need > c.mosaic_arena_cap[lane]) {
             if (c.mosaic_arena[lane]) { (void)hipStreamSynchronize(s); (void)hipFree(c.mosaic_arena[lane]); c.mosaic_arena[lane] = nullptr; c.mosaic_arena_cap[lane] = 0; }
-            MHS_HIP(hipMalloc((void **)&c.mosaic_arena[lane], need));
-            c.mosaic_arena_cap[lane] = need;
+            MHS_HIP(hipMalloc((void **)&c.mosaic_arena[lane], need * 2));
+            c.mosaic_arena_cap[lane] = need * 2;
         }
         char *a = c.mosaic_arena[lane];
-        bsum.p = (double *)a; a += sizeof(double) * (size_t)cells;
-        ssum.p = (double *)a; a += sizeof(double) * (size_t)cells;
-        box.p = (int *)a; a += 16 * (ns_max + 1);
-        bcnt.p = (unsigned char *)a; a += (size_t)cells;
-        scnt.p = (unsigned char *)a;
+        td_dev = (TileDesc *)(a + o_td); sd_dev = (SeamDesc *)(a + o_sd); st_dev = (StripDesc *)(a + o_st); box_dev = (int *)(a + o_box);
     }
-    MHS_HIP(hipMemsetAsync(bsum.p, 0, sizeof(double) * cells, s));
-    MHS_HIP(hipMemsetAsync(ssum.p, 0, sizeof(double) * cells, s));
-    MHS_HIP(hipMemsetAsync(bcnt.p, 0, (size_t)cells, s));
-    MHS_HIP(hipMemsetAsync(scnt.p, 0, (size_t)cells, s));
-    // mean mosaic of the tiles; the sprc is built by prepending, so it runs last tile -> first
-    for (int64_t h = n - 1; h >= 0; --h) {
-        const int64_t tot = (tw[h].r1 - tw[h].r0) * (tw[h].c1 - tw[h].c0);
-        hipLaunchKernelGGL(accum_tile_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[h],
-                           tw[h].c1 - tw[h].c0, tw[h], bsum.p, bcnt.p, g->ncol);
-    }
-    MHS_HIP(hipGetLastError());
-    std::vector<Seam> seams = seam_list(nRx, nCx);
-    const size_t ns = seams.size();
-    if (n > 1 && ns > 0) {
+    MHS_HIP(hipMemcpyAsync(td_dev, td.data(), sizeof(TileDesc) * (size_t)n, hipMemcpyHostToDevice, s));
+    std::vector<StripDesc> strips;
+    if (ns > 0) {
         std::vector<int> hbox(4 * ns);
         std::vector<Win> inter(ns);
         std::vector<char> has(ns, 0);
-        for (size_t k = 0; k < ns; ++k) { hbox[4 * k] = INT32_MAX; hbox[4 * k + 1] = -1; hbox[4 * k + 2] = INT32_MAX; hbox[4 * k + 3] = -1; }
-        MHS_HIP(hipMemcpyAsync(box.p, hbox.data(), sizeof(int) * 4 * ns, hipMemcpyHostToDevice, s));
+        std::vector<SeamDesc> sd(ns);
+        int64_t max_tot = 0;
         for (size_t k = 0; k < ns; ++k) {
             const Win &wa = tw[seams[k].a], &wb = tw[seams[k].b];
-            if (!intersect(wa, wb, &inter[k])) continue;
-            has[k] = 1;
-            const int64_t tot = (inter[k].r1 - inter[k].r0) * (inter[k].c1 - inter[k].c0);
-            hipLaunchKernelGGL(bbox_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[seams[k].a], wa, wa.c1 - wa.c0,
-                               tile_dev[seams[k].b], wb, wb.c1 - wb.c0, inter[k], box.p + 4 * k);
+            has[k] = intersect(wa, wb, &inter[k]) ? 1 : 0;
+            sd[k] = SeamDesc{(int)seams[k].a, (int)seams[k].b, has[k] ? inter[k] : Win{0, 0, 0, 0}};
+            if (has[k]) max_tot = std::max(max_tot, (inter[k].r1 - inter[k].r0) * (inter[k].c1 - inter[k].c0));
         }
-        MHS_HIP(hipGetLastError());
-        MHS_HIP(hipMemcpyAsync(hbox.data(), box.p, sizeof(int) * 4 * ns, hipMemcpyDeviceToHost, s));
-        MHS_HIP(hipStreamSynchronize(s));
+        if (finite_tiles) {
+            for (size_t k = 0; k < ns; ++k) {
+                if (has[k]) { hbox[4 * k] = (int)inter[k].r0; hbox[4 * k + 1] = (int)inter[k].r1 - 1; hbox[4 * k + 2] = (int)inter[k].c0; hbox[4 * k + 3] = (int)inter[k].c1 - 1; }
+                else { hbox[4 * k] = INT32_MAX; hbox[4 * k + 1] = -1; hbox[4 * k + 2] = INT32_MAX; hbox[4 * k + 3] = -1; }
+            }
+        } else {
+            for (size_t k = 0; k < ns; ++k) { hbox[4 * k] = INT32_MAX; hbox[4 * k + 1] = -1; hbox[4 * k + 2] = INT32_MAX; hbox[4 * k + 3] = -1; }
+            MHS_HIP(hipMemcpyAsync(box_dev, hbox.data(), sizeof(int) * 4 * ns, hipMemcpyHostToDevice, s));
+            MHS_HIP(hipMemcpyAsync(sd_dev, sd.data(), sizeof(SeamDesc) * ns, hipMemcpyHostToDevice, s));
+            if (max_tot > 0) {
+                const unsigned gx = (unsigned)std::min<int64_t>((max_tot + 255) / 256, 1024);
+                hipLaunchKernelGGL(bbox_all_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, s, td_dev, sd_dev, box_dev);
+                MHS_HIP(hipGetLastError());
+            }
+            MHS_HIP(hipMemcpyAsync(hbox.data(), box_dev, sizeof(int) * 4 * ns, hipMemcpyDeviceToHost, s));
+            MHS_HIP(hipStreamSynchronize(s));
+        }
         // strips enter the mean in collection order: creation order for Step 4 (the stack is built by
         // prepending and the sprc prepends again), reversed for tiles.merge (c() appends, sprc prepends).
         // With exactly two tiles there is one seam and terra::merge takes it as is.
@@ -368,21 +419,25 @@ int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const in
             }
             const double cmin = std::min(cfirst, clast), cmax = std::max(cfirst, clast);
             const double delta = cmax - cmin;  // 0 for a one-cell-wide strip: 0/0 = NA, as in R
-            const Win &wa = tw[seams[k].a], &wb = tw[seams[k].b];
-            const int64_t tot = (w.r1 - w.r0) * (w.c1 - w.c0);
-            hipLaunchKernelGGL(strip_kernel, dim3(nblk(tot)), dim3(256), 0, s, tile_dev[seams[k].a], wa, wa.c1 - wa.c0,
-                               tile_dev[seams[k].b], wb, wb.c1 - wb.c0, w, seams[k].axis_y, origin, res, cmin, delta,
-                               ssum.p, scnt.p, g->ncol);
+            strips.push_back(StripDesc{(int)seams[k].a, (int)seams[k].b, seams[k].axis_y, 0, w, origin, res, cmin, delta});
         }
-        MHS_HIP(hipGetLastError());
+        if (!strips.empty()) MHS_HIP(hipMemcpyAsync(st_dev, strips.data(), sizeof(StripDesc) * strips.size(), hipMemcpyHostToDevice, s));
     }
-    hipLaunchKernelGGL(compose_kernel, dim3(nblk(cells)), dim3(256), 0, s, ssum.p, scnt.p, bsum.p, bcnt.p,
-                       g->nrow, g->ncol, out_dev, ld);
+    dim3 grid((unsigned)((g->ncol + MOSAIC_PC - 1) / MOSAIC_PC), (unsigned)((g->nrow + MOSAIC_PR - 1) / MOSAIC_PR));
+    MHS_REQUIRE(grid.y <= 65535u, "too many rows for one launch");
+    hipLaunchKernelGGL(mosaic_fused_kernel, grid, dim3(256), 0, s, td_dev, (int)n, st_dev, (int)strips.size(), g->nrow, g->ncol, out_dev, ld);
     MHS_HIP(hipGetLastError());
-    MHS_HIP(hipStreamSynchronize(s));  // the arena is free for the next call on return
+    MHS_HIP(hipStreamSynchronize(s));  // the arena (and the host vectors the copies read) are free for the next call on return
     return MHS_OK;
 }
 
+extern "C" int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
+                                      const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
+                                      int64_t *seam_win_out, void *stream) {
+    return mosaic_feather_impl(g, nRx, nCx, tile_win, tile_dev, merge_mode, out_dev, ld, seam_win_out, stream, false);
+}
+
+extern "C" {
 int mhs_mosaic_feather(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
                        const double *const *tile_host, int merge_mode, double *out_host) {
     if (int rc = require_ready()) return rc;

@@ -230,7 +230,7 @@ extern "C" int mhs_tps_surface_dev(const mhs_grid *g, const double *xy, const do
     int rc = run_tiles(g, xy, resid, n, cov1_at_stations, fit, keep, rows, cols, lambda, gcv_mode, nullptr, nt, outs.data());
     lap("tile fits + evaluation");
     if (rc) return rc;
-    rc = mhs_mosaic_feather_dev(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s);
+    rc = mosaic_feather_impl(g, nRx, nCx, keep.data(), ptrs.data(), 0, out_dev, ld, nullptr, s, true);      // spline planes: no NA
     if (timing) { (void)hipStreamSynchronize(s); lap("mosaic + feather"); }
     return rc;
 }
