@@ -982,7 +982,7 @@ def emit_line(obj):
     print(json.dumps(obj), flush=True)
 
 
-def main_in_library(args):
+def main_in_library(args, require_distinct=False):
     """`--in-library`: the same step driven by ONE host process over N device slots (csrc/multi.hip).  Launched plainly
     (`python bench.py --gpus N --in-library`) or under torch.distributed.run as the driver launches bench.py -- then rank 0
     drives all N devices and the other ranks only stand at the barriers (they never touch a GPU)."""
@@ -1003,6 +1003,11 @@ def main_in_library(args):
     from machisplin_amd import multi, synth
     N = args.gpus
     ndev = torch.cuda.device_count()
+    if require_distinct and ndev < N:
+        sys.stderr.write("bench.py: --gpus %d without a launcher drives %d devices from one process, but this host has %d; "
+                         "refusing to report an N-GPU line from fewer devices (use --in-library for the aliased-slot plumbing run)\n"
+                         % (N, N, ndev))
+        sys.exit(3)
     ids = [k % max(ndev, 1) for k in range(N)]
     torch.cuda.set_device(0)
     multi.init_devices(N, ids)
@@ -1010,7 +1015,7 @@ def main_in_library(args):
     line = {"metric": "grid Mcells/s (ensemble+TPS predict) + TPS-solve GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
     driver = {"host": "one process, one host thread per device slot (mhs_init_devices)", "device_ids": ids,
-              "slots_share_devices": len(set(ids)) < N}
+              "n_physical_gpus": len(set(ids)), "slots_share_devices": len(set(ids)) < N}
     if cfg.get("tiled"):
         # BASELINE configs[3]: machisplin.tiles.create -> mltps per (tile, layer) -> machisplin.tiles.merge in ONE library call,
         # host planes in, host planes out (what the R shim hands over): PCIe is inside the call
@@ -1091,6 +1096,16 @@ def main_in_library(args):
                      "roofline": None, "cpu_baseline": None})
     else:
         driver.update({k: last[k] for k in ("bands", "band_ms", "tiles_ms", "fit_ms", "step_ms", "collective", "suggested_slot0_share")})
+        driver["collective_ranks"] = N
+        try:
+            driver["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            driver["rccl_version"] = None
+        if N > 1 and len(set(ids)) == N and last["collective"] != "rccl-all-gather":
+            # N distinct devices must stitch the plane with the ONE RCCL all-gather the north star names: a silent fall-back to
+            # peer copies would measure another collective
+            sys.stderr.write("bench.py: %d distinct devices but the step's collective was '%s', not the RCCL all-gather\n" % (N, last["collective"]))
+            sys.exit(4)
         line.update({"lambda": last["lambda"], "rsq_model": last["rsq_model"], "rsq_final": last["rsq_final"]})
         # the dominant kernel's roofline: the slots launch the kernels of the one-device step on their bands; the member-by-member
         # HIP-event table is taken from that step on slot 0's device over the whole grid (outside the timed region)
@@ -1132,6 +1147,11 @@ def main():
     args = parse()
     if args.in_library:
         return main_in_library(args)
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # `python bench.py --gpus N` with no launcher: the N devices are driven from THIS process through the library's own
+        # multi-device path (mhs_init_devices: the path the single-threaded R host takes, one RCCL all-gather over xGMI) --
+        # never a one-GPU line under an N-GPU flag.  N distinct devices are required; anything else exits non-zero.
+        return main_in_library(args, require_distinct=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1150,7 +1170,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (args.gpus, world))
+        sys.exit(2)
 
     cfg = WORKLOADS[args.workload]
     wl = TileWorkload(cfg, mhs, torch, dist, rank, world) if cfg.get("tiled") else Workload(cfg, mhs, torch, dist, rank, world, args.tps_mode)

@@ -403,7 +403,12 @@ MHS_API int mhs_device_slots(int *n_slots, int *device_ids /* may be NULL; room 
 
 /* covariate planes cut into row bands, band k resident on slot k (cuts at multiples of 16 rows) */
 typedef struct mhs_multi_stack mhs_multi_stack;
-/* slot0_share: the share of the rows slot 0 takes -- it also carries the spline fit; NaN = equal bands */
+/* slot0_share: the share of the rows slot 0 takes -- it also carries the spline fit; NaN = equal bands.
+ * THREADING: the calls on a resident stack (mhs_multi_stack_create / _free, mhs_mltps_grid_multi_dev,
+ * mhs_multi_final_download) share the slots' streams, events and host-thread team: issue them from ONE host thread at a
+ * time (R's single main thread does; the two host-plane calls mhs_mltps_grid_multi / mhs_tiles_units_multi serialise
+ * themselves).  A stack belongs to the devices its slots were bound to when it was created: after another
+ * mhs_init_devices it is refused (MHS_ERR_INVALID) and mhs_multi_stack_free only drops the handle. */
 MHS_API int mhs_multi_stack_create(const mhs_grid *g, const mhs_stack *covars_host, double slot0_share,
                                    mhs_multi_stack **out);
 MHS_API int mhs_multi_stack_free(mhs_multi_stack *ms);

@@ -258,6 +258,7 @@ struct mhs_multi_stack {
     int64_t ld = 0;               // elements per stored row (= ncol)
     double nodata = NAN;
     int n = 0;
+    int dev[MAX_SLOTS] = {};      // the physical device every band's buffers live on (slot k's device when the stack was built)
     BandPlan plan;
     MultiBand b[MAX_SLOTS];
     int used_tps = 0;             // which plane holds the last step's final: 1 = tot, 0 = ens
@@ -387,8 +388,17 @@ class HostSink {
     bool stop_ = false;
 };
 
+// the stack's bands still sit on the devices its slots are bound to (round-5 advisor finding: mhs_init_devices with the same
+// count but other ids would send slot k's kernels after another device's pointers)
+bool stack_current(const mhs_multi_stack *ms) {
+    if (ms->n != slot_count()) return false;
+    for (int k = 0; k < ms->n; ++k) if (!ctx_slot(k).ready || ctx_slot(k).device != ms->dev[k]) return false;
+    return true;
+}
+
 int free_stack(mhs_multi_stack *ms) {
     if (!ms) return MHS_OK;
+    if (!stack_current(ms)) { delete ms; return MHS_OK; }      // its devices were re-initialised: their memory went with them
     const int home = current_slot();
     for (int k = 0; k < ms->n; ++k) {
         (void)bind_slot(k);
@@ -465,6 +475,7 @@ static int stack_build(const mhs_grid *g, const mhs_stack *covars_host, double s
     mhs_multi_stack *ms = new mhs_multi_stack();
     ms->g = *g; ms->C = covars_host->n_layers; ms->dtype = covars_host->dtype; ms->ld = g->ncol; ms->nodata = covars_host->nodata;
     ms->n = n;
+    for (int k = 0; k < n; ++k) ms->dev[k] = ctx_slot(k).device;
     ms->plan = plan_bands(g->nrow, n, slot0_share);
     const size_t esz = elem_size(ms->dtype);
     Team team(n);
@@ -621,7 +632,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
                              double lambda, int gcv_mode, int gather, mhs_mltps_info *info) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(models && weights && n_models >= 1 && n_models <= 8 && ms && X && resp && n > 3, "bad arguments");
-    MHS_REQUIRE(ms->n == slot_count(), "the stack was built for another set of device slots");
+    MHS_REQUIRE(stack_current(ms), "the stack was built for another set of device slots");
     MHS_REQUIRE(wt_total != 0.0 && !std::isnan(wt_total), "wt_total must be non-zero");
     const int N = ms->n;
     const mhs_grid g = ms->g;
@@ -884,7 +895,11 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             S.used_tps = S.rsq_final > S.rsq_model ? 1 : 0;
         }
         team.bar.wait();
-        if (piped && nb > 0 && !team.failed() && !S.used_tps) {
+        // ---- read here, right behind the barrier and before anything that can fail: every thread takes the same branch at
+        // the collective below (a collective must not be entered by some ranks only; round-5 advisor finding: the re-send
+        // in between can call team.fail())
+        const bool go = !team.failed();
+        if (piped && nb > 0 && go && !S.used_tps) {
             auto resend = [&]() -> int {
                 MHS_HIP(hipMemcpyAsync(ms->pending_out + (size_t)b.r0 * (size_t)g.ncol, b.ens, sizeof(double) * (size_t)nb * (size_t)g.ncol,
                                        hipMemcpyDeviceToHost, M->s));
@@ -892,10 +907,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             };
             TEAM_DO(team, resend());
         }
-        // ---- the one collective: stitch the final plane on every device.  (Every thread reads failed() right after the
-        // barrier above and nothing runs in between, so all of them take the same branch -- a collective must not be entered
-        // by some ranks only.)
-        const bool go = !team.failed();
+        // ---- the one collective: stitch the final plane on every device
         if (gather && go) {
             auto stitch = [&]() -> int {
                 const int64_t band = ms->plan.band;
@@ -960,7 +972,12 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             const double s0 = 1.0 / N - S.fit_ms * (N - 1) / ((double)N * cells_ms);
             suggested = std::min(std::max(s0, 0.0), 1.0 / N);
             std::lock_guard<std::mutex> lk(g_balance_mu);
-            g_balance = Balance{N, g.nrow, g.ncol, n, suggested};
+            // hysteresis (round-5 advisor finding): the suggestion moves with the jitter of fit_ms / band_ms, and a plan that
+            // moves slot 0's band by one 16-row unit makes mhs_mltps_grid_multi free and rebuild gigabytes of cached
+            // device buffers -- the remembered share only follows a change of more than 5 % of a band
+            const bool same_shape = g_balance.n == N && g_balance.nrow == g.nrow && g_balance.ncol == g.ncol && g_balance.stations == n;
+            if (!same_shape || !(fabs(suggested - g_balance.share) <= 0.05 / (double)N))
+                g_balance = Balance{N, g.nrow, g.ncol, n, suggested};
         }
     }
     if (info) {
@@ -981,6 +998,7 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
 int mhs_multi_final_download(const mhs_multi_stack *ms, double *final_host) {
     if (int rc = require_ready()) return rc;
     MHS_REQUIRE(ms && final_host && ms->have_result, "no result to download");
+    MHS_REQUIRE(stack_current(ms), "the stack was built for another set of device slots");
     Team team(ms->n);
     return team.run([&](int slot) {
         const MultiBand &b = ms->b[slot];
@@ -1032,7 +1050,7 @@ int mhs_mltps_grid_multi(const mhs_model *const *models, const double *weights, 
     const double t0 = now_ms();
     const BandPlan want = plan_bands(g->nrow, slot_count(), share);
     mhs_multi_stack *ms = g_host_ms;
-    if (ms && !(ms->n == slot_count() && ms->g.nrow == g->nrow && ms->g.ncol == g->ncol && ms->C == covars_host->n_layers &&
+    if (ms && !(stack_current(ms) && ms->g.nrow == g->nrow && ms->g.ncol == g->ncol && ms->C == covars_host->n_layers &&
                 ms->dtype == covars_host->dtype && ms->plan.r0 == want.r0 && ms->plan.r1 == want.r1)) {
         free_stack(ms);
         ms = g_host_ms = nullptr;

@@ -145,9 +145,13 @@ class MultiStack:
         return out
 
     def free(self):
-        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+        # also __del__: at interpreter shutdown the module global may already be None, and after the library's atexit
+        # shutdown the handle's device memory is gone with its device -- nothing to free then
+        if getattr(self, "_h", None) is None:
+            return
+        if _lib is not None and getattr(_lib, "_lib", None) is not None and getattr(_lib, "_inited_device", None) is not None:
             _lib._lib.mhs_multi_stack_free(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = free
 
