@@ -1095,7 +1095,8 @@ def main_in_library(args, require_distinct=False):
         line.update({"rsq_model_mean": float(np.nanmean(rsq[:, :, 0])), "rsq_final_mean": float(np.nanmean(rsq[:, :, 1])),
                      "roofline": None, "cpu_baseline": None})
     else:
-        driver.update({k: last[k] for k in ("bands", "band_ms", "tiles_ms", "fit_ms", "step_ms", "collective", "suggested_slot0_share")})
+        driver.update({k: last[k] for k in ("bands", "band_ms", "tiles_ms", "tiles_owned", "tiles_pulled_bytes", "fit_ms", "step_ms", "collective",
+                                             "suggested_slot0_share")})
         driver["collective_ranks"] = N
         try:
             driver["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -1341,8 +1342,8 @@ def main():
             # Reference-tiled Step 3 (V73:656-747) has NO serial fit: every rank predicts its band and fits + evaluates its
             # share of the tiles (LPT-dealt on stations x cells), ONE all-gather moves bands and tile planes, every rank mosaics.
             # Model: step(N) = max(ens / N, tiles(N)) + gather(N) + mosaic + Step 5, with
-            #   tiles(N)  = the stand-alone time of all tiles x the heaviest rank's cost share, but never less than one wave of
-            #               8 tiles side by side (8 / n_tiles of the stand-alone time: the library fits 8 tiles at once);
+            #   tiles(N)  = the stand-alone time of all tiles x the heaviest rank's cost share (round 6: a rank's tiles are ONE fit
+            #               launch + one pair of evaluation launches, a workgroup per spline -- no 8-at-a-time floor any more);
             #   gather(N) = one rank's chunk (its band + its tile planes, 8 B per cell) over one 153 GB/s xGMI link per peer;
             #   mosaic + Step 5 measured here, stand-alone.
             from machisplin_amd import sharded
@@ -1359,8 +1360,8 @@ def main():
             tiles_alone = max(tiled_ms - mosaic_ms, 1e-3)
             tiles_in_step = float(np.mean(tm["tps_tiles_ms"][-max(1, len(tm["tps_tiles_ms"]) // 2):])) if tm.get("tps_tiles_ms") else None
             tail1 = max(0.0, step1 - max(ens, tiles_in_step or 0.0))      # mosaic, the band sums, Step 5 as this run had them
-            projected = {"model": "step(N) = max(ens / N, tiles(N)) + gather(N) + tail; tiles(N) = stand-alone tile time x max(heaviest rank's LPT cost share, "
-                                  "8 / n_tiles); gather(N) = (band + tile planes of one rank) x 8 B over one 153 GB/s xGMI link per peer; tail = this run's step "
+            projected = {"model": "step(N) = max(ens / N, tiles(N)) + gather(N) + tail; tiles(N) = stand-alone tile time x the heaviest rank's LPT cost share; "
+                                  "gather(N) = (band + tile planes of one rank) x 8 B over one 153 GB/s xGMI link per peer; tail = this run's step "
                                   "minus max(ens, tiles in the step) = mosaic + feathering + band sums + Step 5.  No serial fit in this mode.",
                          "ensemble_ms_n1": ens, "tiles_ms_alone": tiles_alone, "tiles_ms_in_step_n1": tiles_in_step, "mosaic_ms": mosaic_ms,
                          "tail_ms": tail1, "step_ms_n1": step1, "n_tiles": len(costs)}
@@ -1368,7 +1369,7 @@ def main():
             for N in (2, 4, 8):
                 owner = sharded.assign_tiles(costs, N)
                 load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(N)]
-                share = max(max(load) / sum(costs), min(1.0, 8.0 / len(costs)))
+                share = max(load) / sum(costs)
                 tiles_n = tiles_alone * share
                 gather = (wl.cells + tile_cells) * 8.0 / N / 153e9 * 1e3
                 step = max(ens / N, tiles_n) + gather + tail1
@@ -1378,17 +1379,18 @@ def main():
             ens = sum(r["launch_ms"] for r in table if not r["kernel"].startswith("tps_"))
             spl = sum(r["launch_ms"] for r in table if r["kernel"].startswith("tps_"))
             step1 = dt / args.steps * 1e3
-            projected = {"model": "rank 0: band x + the serial fit; ranks 1..N-1: band (ens - x) / (N - 1) then its all-gather share "
-                                  "(band bytes over one 153 GB/s xGMI link per peer); x = max(0, (ens - (N - 1) fit) / N); every rank then "
-                                  "evaluates the whole-grid spline and Step 5 (~3 ms); fit unconfined (no CU reservation at N > 1)",
+            projected = {"model": "rank 0: band x + the serial fit; ranks 1..N-1: band (ens - x) / (N - 1); x = max(0, (ens - (N - 1) fit) / N); then every "
+                                  "rank evaluates the spline on ITS rows (spline / N; round 6 -- the whole grid on every rank before), sums, and ONE "
+                                  "all-gather stitches the selected plane (a band's bytes from each peer over its own 153 GB/s xGMI link), plus Step 5 "
+                                  "and the small all-reduce (~3 ms); fit unconfined (no CU reservation at N > 1)",
                          "ensemble_ms_n1": ens, "fit_ms": fit_ms, "spline_eval_ms": spl, "step_ms_n1": step1}
             for N in (2, 4, 8):
                 x = max(0.0, (ens - (N - 1) * fit_ms) / N)
                 others = (ens - x) / (N - 1)
                 band_bytes = wl.cells * 8.0 * (others / ens)
                 gather = band_bytes / 153e9 * 1e3
-                step = max(x + fit_ms, others + gather) + spl + 3.0
-                projected["n%d" % N] = {"rank0_band_ms": x, "other_band_ms": others, "gather_ms": gather, "step_ms": step,
+                step = max(x + fit_ms, others) + spl / N + gather + 3.0
+                projected["n%d" % N] = {"rank0_band_ms": x, "other_band_ms": others, "spline_band_ms": spl / N, "gather_ms": gather, "step_ms": step,
                                         "mcells_per_s": wl.cells / step / 1e3, "speedup_over_n1": step1 / step}
         m = wl.ops.X.shape[0] - 3
         if cfg["ensemble"] and wl.cfg["stations"] >= 2000:

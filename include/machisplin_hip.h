@@ -181,6 +181,11 @@ MHS_API int mhs_tps_eval_plan(const mhs_tps *t, int *tile_cols, int *tile_rows, 
                       int64_t *cell_pairs);
 MHS_API int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1,
                              int64_t c0, int64_t c1, double *out_dev, int64_t ld, void *stream);
+/* Rows [b0, b1) of the window [r0, r1) x [c0, c1), evaluated with the WINDOW's own plan (far-field tile size and origin, path
+ * decision): out_dev holds row b0 first.  What a device that owns a row band of the grid calls: every cell gets exactly the
+ * arithmetic of the one-piece evaluation, so the bands of N devices stitch to the one-device plane bit for bit. */
+MHS_API int mhs_tps_predict_rows_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                                     int64_t b0, int64_t b1, double *out_dev, int64_t ld, void *stream);
 /* predict(tps, xy): arbitrary points, xy n x 2 column-major (Step-5 station check) */
 MHS_API int mhs_tps_predict_points(const mhs_tps *t, const double *xy, int64_t n, double *out_host);
 
@@ -434,12 +439,17 @@ typedef struct mhs_mltps_info {
     double step_ms;                    /* wall time of the whole call */
     double upload_ms, download_ms;     /* mhs_mltps_grid_multi only: host <-> device */
     double suggested_slot0_share;      /* the slot0_share that would have balanced THIS step (NaN if undetermined) */
+    int64_t tiles_pulled_bytes[16];    /* reference-tiled Step 3: bytes of tile planes every slot pulled from its peers (the tiles that
+                                        * reach its rows and are owned elsewhere) */
+    int32_t tiles_owned[16];           /* ... and the tiles it fitted and evaluated itself (a tile goes to the slot whose band holds
+                                        * most of its keep window) */
 } mhs_mltps_info;
 
 /* machisplin.mltps Steps 2-5 for one response layer (V73:442-930) over the device slots: ensemble on every band;
  * res.FINAL at the stations and the fields::Tps fit on slot 0 (tile_edge <= 0 or one tile: the global fit of V73:748-753;
- * otherwise the reference's tiles dealt over the slots by cost, V73:636-747); every slot evaluates the spline on its rows
- * with the WHOLE grid's evaluation plan, sums, reads its stations' cells; rsq.final > rsq.model selects the sum (V73:925).
+ * otherwise the reference's tiles, V73:636-747, each fitted and evaluated by the slot whose band holds most of it; a slot pulls
+ * the tiles that reach its rows from their owners and mosaics + feathers its rows only); global fit: every slot evaluates the
+ * spline on its rows with the WHOLE grid's evaluation plan; then sums, reads its stations' cells; rsq.final > rsq.model selects the sum (V73:925).
  * X is the n x p station table dat_tps (column-major: covariates, LONG, LAT -- cell-centre coordinates), complete cases
  * only (V73:154).  gather != 0: ONE all-gather (RCCL over xGMI) stitches the final plane on every device
  * (mhs_multi_final_dev).  The N-slot planes equal the one-slot planes bit for bit.                                   */

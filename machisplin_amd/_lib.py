@@ -50,7 +50,8 @@ class MltpsInfo(C.Structure):
                 ("tiles_rows", C.c_int64), ("tiles_cols", C.c_int64), ("used_tps", C.c_int32), ("n_slots", C.c_int32),
                 ("collective", C.c_int32), ("reserved_", C.c_int32), ("band_r0", C.c_int64 * 16), ("band_r1", C.c_int64 * 16),
                 ("band_ms", C.c_double * 16), ("tiles_ms", C.c_double * 16), ("fit_ms", C.c_double), ("step_ms", C.c_double),
-                ("upload_ms", C.c_double), ("download_ms", C.c_double), ("suggested_slot0_share", C.c_double)]
+                ("upload_ms", C.c_double), ("download_ms", C.c_double), ("suggested_slot0_share", C.c_double),
+                ("tiles_pulled_bytes", C.c_int64 * 16), ("tiles_owned", C.c_int32 * 16)]
 
 
 class Unit(C.Structure):
@@ -96,6 +97,7 @@ SIGNATURES = {
     "mhs_tps_free": (C.c_int, [_vp]),
     "mhs_tps_predict_grid": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp]),
     "mhs_tps_predict_grid_dev": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "mhs_tps_predict_rows_dev": (C.c_int, [_vp, C.POINTER(Grid), _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "mhs_tps_predict_points": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mhs_tps_eval_mode": (C.c_int, [C.c_int]),
     "mhs_tps_eval_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),

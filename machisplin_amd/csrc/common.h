@@ -115,9 +115,12 @@ void *pool_alloc(size_t bytes);
 void pool_release(void *p);
 void pool_clear();
 int require_ready();
-// tiles.hip: mhs_mosaic_feather_dev; finite_tiles = no tile holds an NA (spline planes): the seams' bounding-box pass is skipped
+// tiles.hip: mhs_mosaic_feather_dev; finite_tiles = no tile holds an NA (spline planes): the seams' bounding-box pass is skipped;
+// [row_lo, row_hi) (row_hi < 0: the whole grid): the rows to produce, out_dev holding row row_lo first -- a device's row band;
+// tiles that do not reach those rows may be NULL
 int mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win, const double *const *tile_dev,
-                        int merge_mode, double *out_dev, int64_t ld, int64_t *seam_win_out, void *stream, bool finite_tiles);
+                        int merge_mode, double *out_dev, int64_t ld, int64_t *seam_win_out, void *stream, bool finite_tiles,
+                        int64_t row_lo = 0, int64_t row_hi = -1);
 void reduction_cache_clear();           // tps_fit.hip: drop every cached reduction of the current slot (mhs_shutdown)
 void multi_reset();                     // multi.hip: drop the multi-device drivers' per-slot state (mhs_shutdown, mhs_init_devices)
 // Blocking host -> device copy that does NOT go through the NULL stream: a plain hipMemcpy synchronises with every

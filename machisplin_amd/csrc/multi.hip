@@ -247,7 +247,6 @@ struct MultiBand {
     double *ens = nullptr;        // pred.elev on the band (rows x ncol)
     double *tot = nullptr;        // pred.elev + final.TPS on the band
     double *full = nullptr;       // gather target: n * band rows x ncol (the grid starts `lead` rows in)
-    double *tps_full = nullptr;   // reference-tiled Step 3: final.TPS on the whole grid (mosaic + feather)
     double *tiles = nullptr;      // ... and every tile's keep window
     size_t tiles_cap = 0;
 };
@@ -404,7 +403,7 @@ int free_stack(mhs_multi_stack *ms) {
         (void)bind_slot(k);
         MultiBand &b = ms->b[k];
         if (g_ms[k].s) (void)hipStreamSynchronize(g_ms[k].s);
-        for (void *q : {(void *)b.cov, (void *)b.ens, (void *)b.tot, (void *)b.full, (void *)b.tps_full, (void *)b.tiles})
+        for (void *q : {(void *)b.cov, (void *)b.ens, (void *)b.tot, (void *)b.full, (void *)b.tiles})
             if (q) (void)hipFree(q);
     }
     (void)bind_slot(home);
@@ -540,21 +539,6 @@ int mhs_multi_stack_bands(const mhs_multi_stack *ms, int *n_slots, int64_t *r0, 
 
 namespace {
 
-// Longest-processing-time deal of the Step-3 tiles (sharded.assign_tiles): heaviest first onto the least loaded slot
-std::vector<int> assign_tiles(const std::vector<double> &cost, int n) {
-    std::vector<int> order(cost.size()), owner(cost.size(), 0);
-    for (size_t h = 0; h < cost.size(); ++h) order[h] = (int)h;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
-    std::vector<double> load((size_t)n, 0.0);
-    for (int h : order) {
-        int best = 0;
-        for (int k = 1; k < n; ++k) if (load[(size_t)k] < load[(size_t)best]) best = k;
-        owner[(size_t)h] = best;
-        load[(size_t)best] += cost[(size_t)h];
-    }
-    return owner;
-}
-
 // rows [r0, r1) in sub-bands, cut at whole 16-row tiles of the grid; returns how many.  Copies up: the short ones first -- 4,
 // 16, 40, 40 %, or for float64 planes (twice the bytes per row: the copies are then only ~2 x faster than the kernels that
 // wait for them, see host_window_pipeline in ensemble.hip) 3, 6, 13, 28, 50 %.  Copies down: the short ones last, 48, 30, 14, 6, 2 %.
@@ -614,7 +598,12 @@ struct StepShared {
     int64_t nRx = 1, nCx = 1;
     std::vector<int64_t> fit_win, keep_win;
     std::vector<int> owner;
-    std::vector<size_t> tile_off;             // offset of tile h in every slot's tile area (doubles)
+    std::vector<size_t> tile_cells;           // cells of tile h's keep window, rounded up to 32
+    // what every slot holds of the tiles: the ones it owns (fits + evaluates) and the ones that reach its rows (pulled from
+    // their owners) -- offsets into its own tile area, -1 for the others; bytes pulled from peers
+    std::vector<int64_t> slot_off[MAX_SLOTS];
+    size_t slot_need[MAX_SLOTS] = {};
+    int64_t pulled_bytes[MAX_SLOTS] = {};
     // Step 5
     std::vector<double> f_actual;
     int used_tps = 0;
@@ -659,21 +648,27 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
     if (tiled) {
         S.fit_win.resize((size_t)nt * 4); S.keep_win.resize((size_t)nt * 4);
         if (int rc = mhs_step3_tile_windows(&g, tile_edge, 0.2, 0.025, &S.nRx, &S.nCx, S.fit_win.data(), S.keep_win.data(), nt)) return rc;
-        std::vector<double> cost((size_t)nt);
-        S.tile_off.resize((size_t)nt + 1);
-        size_t off = 0;
+        // Ownership follows the rows (round 6): a tile is fitted and evaluated by the slot whose band holds most of its keep
+        // window -- that slot needs the plane anyway -- and a slot pulls from its peers only the tiles that reach ITS rows,
+        // then mosaics and feathers only those rows, straight into its band.  (Rounds 1-5 dealt the tiles by cost, pulled
+        // EVERY tile to EVERY slot and mosaicked the whole grid N times: 0.8 GB per slot over the fabric at cfg3 and N x
+        // redundant Step-4 work.)  Bands with no rows own nothing.
+        S.tile_cells.resize((size_t)nt);
+        S.owner.assign((size_t)nt, 0);
+        for (int k = 0; k < N; ++k) S.slot_off[k].assign((size_t)nt, -1);
         for (int64_t h = 0; h < nt; ++h) {
-            const int64_t *f = &S.fit_win[(size_t)h * 4], *kw = &S.keep_win[(size_t)h * 4];
-            int64_t cnt = 0;
-            for (int64_t i = 0; i < n; ++i)
-                if (rows[(size_t)i] >= f[0] && rows[(size_t)i] < f[1] && cols[(size_t)i] >= f[2] && cols[(size_t)i] < f[3] && !std::isnan(X[i])) ++cnt;
-            const double cells = (double)((kw[1] - kw[0]) * (kw[3] - kw[2]));
-            cost[(size_t)h] = (double)cnt * cells + (double)cnt * (double)cnt * (double)cnt;
-            S.tile_off[(size_t)h] = off;
-            off += ((size_t)cells + 31) & ~(size_t)31;
+            const int64_t *kw = &S.keep_win[(size_t)h * 4];
+            S.tile_cells[(size_t)h] = ((size_t)((kw[1] - kw[0]) * (kw[3] - kw[2])) + 31) & ~(size_t)31;
+            int64_t best_rows = -1;
+            for (int k = 0; k < N; ++k) {
+                const int64_t ov = std::min(kw[1], ms->b[k].r1) - std::max(kw[0], ms->b[k].r0);
+                if (ov > best_rows) { best_rows = ov; S.owner[(size_t)h] = k; }
+            }
+            for (int k = 0; k < N; ++k) {
+                const bool reaches = ms->b[k].r1 > ms->b[k].r0 && kw[0] < ms->b[k].r1 && kw[1] > ms->b[k].r0;
+                if (reaches || S.owner[(size_t)h] == k) { S.slot_off[k][(size_t)h] = (int64_t)S.slot_need[k]; S.slot_need[k] += S.tile_cells[(size_t)h]; }
+            }
         }
-        S.tile_off[(size_t)nt] = off;
-        S.owner = assign_tiles(cost, N);
     }
     if (gather) rccl_prepare();
     const bool use_rccl = gather && g_rccl.usable;
@@ -832,16 +827,15 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             // from its owner (peer copies), mosaic + feather on the whole grid, this slot's rows of it
             const double t0 = now_ms();
             auto my_tiles = [&]() -> int {
-                if (b.tiles_cap < S.tile_off[(size_t)nt]) {
+                if (b.tiles_cap < S.slot_need[slot]) {
                     if (b.tiles) { MHS_HIP(hipStreamSynchronize(M->s)); MHS_HIP(hipFree(b.tiles)); b.tiles = nullptr; b.tiles_cap = 0; }
-                    MHS_HIP(hipMalloc((void **)&b.tiles, sizeof(double) * S.tile_off[(size_t)nt]));
-                    b.tiles_cap = S.tile_off[(size_t)nt];
+                    MHS_HIP(hipMalloc((void **)&b.tiles, sizeof(double) * S.slot_need[slot]));
+                    b.tiles_cap = S.slot_need[slot];
                 }
-                if (!b.tps_full) MHS_HIP(hipMalloc((void **)&b.tps_full, sizeof(double) * (size_t)g.nrow * (size_t)g.ncol));
                 std::vector<int64_t> ids;
                 std::vector<double *> outs;
                 for (int64_t h = 0; h < nt; ++h)
-                    if (S.owner[(size_t)h] == slot) { ids.push_back(h); outs.push_back(b.tiles + S.tile_off[(size_t)h]); }
+                    if (S.owner[(size_t)h] == slot) { ids.push_back(h); outs.push_back(b.tiles + S.slot_off[slot][(size_t)h]); }
                 if (ids.empty()) return MHS_OK;
                 return mhs_tps_tiles_dev(&g, knots, S.resid.data(), n, X /* covariate 1 at the stations */, tile_edge, lambda, gcv_mode,
                                          ids.data(), (int64_t)ids.size(), outs.data());
@@ -850,20 +844,21 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
             S.tiles_ms[slot] = now_ms() - t0;
             team.bar.wait();                                           // every tile is final on its owner
             auto bring = [&]() -> int {
-                std::vector<const double *> ptrs((size_t)nt);
+                if (nb == 0) return MHS_OK;
+                std::vector<const double *> ptrs((size_t)nt, nullptr);
                 for (int64_t h = 0; h < nt; ++h) {
+                    const int64_t *kw = &S.keep_win[(size_t)h * 4];
+                    if (!(kw[0] < b.r1 && kw[1] > b.r0)) continue;     // does not reach this slot's rows
                     const int o = S.owner[(size_t)h];
-                    ptrs[(size_t)h] = b.tiles + S.tile_off[(size_t)h];
+                    ptrs[(size_t)h] = b.tiles + S.slot_off[slot][(size_t)h];
                     if (o == slot) continue;
-                    const size_t bytes = sizeof(double) * (S.tile_off[(size_t)h + 1] - S.tile_off[(size_t)h]);
-                    MHS_HIP(hipMemcpyPeerAsync(b.tiles + S.tile_off[(size_t)h], ctx_slot(slot).device, ms->b[o].tiles + S.tile_off[(size_t)h],
-                                               ctx_slot(o).device, bytes, M->s));
+                    const size_t bytes = sizeof(double) * S.tile_cells[(size_t)h];
+                    MHS_HIP(hipMemcpyPeerAsync(b.tiles + S.slot_off[slot][(size_t)h], ctx_slot(slot).device,
+                                               ms->b[o].tiles + S.slot_off[o][(size_t)h], ctx_slot(o).device, bytes, M->s));
+                    S.pulled_bytes[slot] += (int64_t)bytes;
                 }
-                if (int rc2 = mhs_mosaic_feather_dev(&g, S.nRx, S.nCx, S.keep_win.data(), ptrs.data(), 0, b.tps_full, g.ncol, nullptr, M->s)) return rc2;
-                if (nb > 0)
-                    MHS_HIP(hipMemcpyAsync(b.tot, b.tps_full + (size_t)b.r0 * (size_t)g.ncol, sizeof(double) * (size_t)nb * (size_t)g.ncol,
-                                           hipMemcpyDeviceToDevice, M->s));
-                return MHS_OK;
+                // Step 4 on this slot's rows only, into its band (the tiles are spline planes: no NA)
+                return mosaic_feather_impl(&g, S.nRx, S.nCx, S.keep_win.data(), ptrs.data(), 0, b.tot, g.ncol, nullptr, M->s, true, b.r0, b.r1);
             };
             TEAM_DO(team, bring());
             if (piped && nb > 0) {
@@ -989,6 +984,9 @@ int mhs_mltps_grid_multi_dev(const mhs_model *const *models, const double *weigh
         info->fit_ms = S.fit_ms; info->step_ms = step_ms; info->suggested_slot0_share = suggested;
         for (int k = 0; k < N; ++k) {
             info->band_r0[k] = ms->b[k].r0; info->band_r1[k] = ms->b[k].r1; info->band_ms[k] = S.band_ms[k]; info->tiles_ms[k] = S.tiles_ms[k];
+            info->tiles_pulled_bytes[k] = S.pulled_bytes[k];
+            info->tiles_owned[k] = 0;
+            for (size_t h = 0; h < S.owner.size(); ++h) if (S.owner[h] == k) ++info->tiles_owned[k];
         }
     }
     return MHS_OK;

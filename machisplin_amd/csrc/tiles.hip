@@ -122,16 +122,17 @@ __global__ __launch_bounds__(256) void bbox_all_kernel(const TileDesc *__restric
 struct StripDesc { int a, b, axis_y, pad; Win w; double origin, res, cmin, delta; };
 constexpr int MOSAIC_PR = 32, MOSAIC_PC = 128;
 constexpr int MOSAIC_MAXWORDS = 1024;      // up to 32 768 tiles / strips per call
+// Rows [row_lo, row_hi) of the output only (a device's row band); out points at row row_lo.
 __global__ __launch_bounds__(256) void mosaic_fused_kernel(const TileDesc *__restrict__ T, int n_tiles,
-                                                           const StripDesc *__restrict__ S, int n_strips, int64_t nrow,
-                                                           int64_t ncol, double *__restrict__ out, int64_t ld) {
+                                                           const StripDesc *__restrict__ S, int n_strips, int64_t row_lo,
+                                                           int64_t row_hi, int64_t ncol, double *__restrict__ out, int64_t ld) {
     __shared__ unsigned tmap[MOSAIC_MAXWORDS], smap[MOSAIC_MAXWORDS];
     const int tw = (n_tiles + 31) >> 5, sw = (n_strips + 31) >> 5;
     for (int i = threadIdx.x; i < tw; i += 256) tmap[i] = 0u;
     for (int i = threadIdx.x; i < sw; i += 256) smap[i] = 0u;
     __syncthreads();
-    const int64_t pr0 = (int64_t)blockIdx.y * MOSAIC_PR, pc0 = (int64_t)blockIdx.x * MOSAIC_PC;
-    const int64_t pr1 = min(pr0 + MOSAIC_PR, nrow), pc1 = min(pc0 + MOSAIC_PC, ncol);
+    const int64_t pr0 = row_lo + (int64_t)blockIdx.y * MOSAIC_PR, pc0 = (int64_t)blockIdx.x * MOSAIC_PC;
+    const int64_t pr1 = min(pr0 + MOSAIC_PR, row_hi), pc1 = min(pc0 + MOSAIC_PC, ncol);
     for (int h = threadIdx.x; h < n_tiles; h += 256) {
         const Win w = T[h].w;
         if (w.r0 < pr1 && w.r1 > pr0 && w.c0 < pc1 && w.c1 > pc0) atomicOr(&tmap[h >> 5], 1u << (h & 31));
@@ -201,12 +202,12 @@ __global__ __launch_bounds__(256) void mosaic_fused_kernel(const TileDesc *__res
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int64_t r = rbase + k;
-            if (r < nrow) {
+            if (r < row_hi) {
                 double v;
                 if (scnt[k] > 0) v = ssum[k] / (double)scnt[k];
                 else if (bcnt[k] > 0) v = bsum[k] / (double)bcnt[k];
                 else v = NAN;
-                out[r * ld + c] = v;
+                out[(r - row_lo) * ld + c] = v;
             }
         }
     }
@@ -325,12 +326,17 @@ int mhs_tiles_create_windows(const mhs_grid *g, int64_t out_ncol, int64_t out_nr
 
 // finite_tiles: the caller vouches that no tile holds an NA (thin-plate-spline planes: mhs_tps_surface) -- every seam's
 // A + B is then non-NA on the whole overlap and the bounding-box pass (a kernel, a copy back and a host wait) is skipped
+// [row_lo, row_hi): the rows to produce (out_dev holds row row_lo first); tiles that do not reach them may be NULL
 int mhs::mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
                              const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
-                             int64_t *seam_win_out, void *stream, bool finite_tiles) {
+                             int64_t *seam_win_out, void *stream, bool finite_tiles, int64_t row_lo, int64_t row_hi) {
     if (int rc = require_ready()) return rc;
     if (int rc = check_grid(g)) return rc;
     MHS_REQUIRE(nRx >= 1 && nCx >= 1 && tile_win && tile_dev && out_dev && ld >= g->ncol, "bad arguments");
+    if (row_hi < 0) row_hi = g->nrow;
+    MHS_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= g->nrow, "bad row band");
+    MHS_REQUIRE(finite_tiles || (row_lo == 0 && row_hi == g->nrow), "a row band needs tiles without NA");
+    if (row_lo == row_hi) return MHS_OK;
     hipStream_t s = pick_stream(stream);
     const int64_t n = nRx * nCx;
     MHS_REQUIRE(n <= 32 * MOSAIC_MAXWORDS, "too many tiles");
@@ -339,7 +345,8 @@ int mhs::mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const 
     for (int64_t h = 0; h < n; ++h) {
         tw[h] = Win{tile_win[4 * h], tile_win[4 * h + 1], tile_win[4 * h + 2], tile_win[4 * h + 3]};
         MHS_REQUIRE(0 <= tw[h].r0 && tw[h].r0 < tw[h].r1 && tw[h].r1 <= g->nrow && 0 <= tw[h].c0 &&
-                    tw[h].c0 < tw[h].c1 && tw[h].c1 <= g->ncol && tile_dev[h], "bad tile window");
+                    tw[h].c0 < tw[h].c1 && tw[h].c1 <= g->ncol, "bad tile window");
+        MHS_REQUIRE(tile_dev[h] || tw[h].r1 <= row_lo || tw[h].r0 >= row_hi, "a tile that reaches the requested rows is NULL");
         td[h] = TileDesc{tw[h], tile_dev[h], tw[h].c1 - tw[h].c0};
     }
     std::vector<Seam> seams = n > 1 ? seam_list(nRx, nCx) : std::vector<Seam>();
@@ -423,9 +430,9 @@ int mhs::mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const 
         }
         if (!strips.empty()) MHS_HIP(hipMemcpyAsync(st_dev, strips.data(), sizeof(StripDesc) * strips.size(), hipMemcpyHostToDevice, s));
     }
-    dim3 grid((unsigned)((g->ncol + MOSAIC_PC - 1) / MOSAIC_PC), (unsigned)((g->nrow + MOSAIC_PR - 1) / MOSAIC_PR));
+    dim3 grid((unsigned)((g->ncol + MOSAIC_PC - 1) / MOSAIC_PC), (unsigned)((row_hi - row_lo + MOSAIC_PR - 1) / MOSAIC_PR));
     MHS_REQUIRE(grid.y <= 65535u, "too many rows for one launch");
-    hipLaunchKernelGGL(mosaic_fused_kernel, grid, dim3(256), 0, s, td_dev, (int)n, st_dev, (int)strips.size(), g->nrow, g->ncol, out_dev, ld);
+    hipLaunchKernelGGL(mosaic_fused_kernel, grid, dim3(256), 0, s, td_dev, (int)n, st_dev, (int)strips.size(), row_lo, row_hi, g->ncol, out_dev, ld);
     MHS_HIP(hipGetLastError());
     MHS_HIP(hipStreamSynchronize(s));  // the arena (and the host vectors the copies read) are free for the next call on return
     return MHS_OK;
@@ -434,7 +441,7 @@ int mhs::mosaic_feather_impl(const mhs_grid *g, int64_t nRx, int64_t nCx, const 
 extern "C" int mhs_mosaic_feather_dev(const mhs_grid *g, int64_t nRx, int64_t nCx, const int64_t *tile_win,
                                       const double *const *tile_dev, int merge_mode, double *out_dev, int64_t ld,
                                       int64_t *seam_win_out, void *stream) {
-    return mosaic_feather_impl(g, nRx, nCx, tile_win, tile_dev, merge_mode, out_dev, ld, seam_win_out, stream, false);
+    return mosaic_feather_impl(g, nRx, nCx, tile_win, tile_dev, merge_mode, out_dev, ld, seam_win_out, stream, false, 0, -1);
 }
 
 extern "C" {

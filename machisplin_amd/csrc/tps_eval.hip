@@ -675,6 +675,11 @@ int mhs_tps_predict_grid_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, in
     return tps_predict_rows_dev(t, g, r0, r1, c0, c1, r0, r1, out_dev, ld, stream);
 }
 
+int mhs_tps_predict_rows_dev(const mhs_tps *t, const mhs_grid *g, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                             int64_t b0, int64_t b1, double *out_dev, int64_t ld, void *stream) {
+    return tps_predict_rows_dev(t, g, r0, r1, c0, c1, b0, b1, out_dev, ld, stream);
+}
+
 }  // extern "C"
 
 // Rows [b0, b1) of the window [r0, r1) x [c0, c1), evaluated with the WINDOW's plan (far-field tile size, tile origin,

@@ -81,7 +81,8 @@ def _info_dict(info: _lib.MltpsInfo):
             "bands": [(info.band_r0[k], info.band_r1[k]) for k in range(n)],
             "band_ms": [info.band_ms[k] for k in range(n)], "tiles_ms": [info.tiles_ms[k] for k in range(n)],
             "fit_ms": info.fit_ms, "step_ms": info.step_ms, "upload_ms": info.upload_ms, "download_ms": info.download_ms,
-            "suggested_slot0_share": info.suggested_slot0_share}
+            "suggested_slot0_share": info.suggested_slot0_share,
+            "tiles_pulled_bytes": [info.tiles_pulled_bytes[k] for k in range(n)], "tiles_owned": [info.tiles_owned[k] for k in range(n)]}
 
 
 class MultiStack:

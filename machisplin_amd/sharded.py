@@ -126,9 +126,9 @@ class ShardedMltps:
         # other band is `band` rows high, so the gathered chunks ARE the grid, in place, from row `self.lead` on.
         self.lead = self.band - (self.bands[0][1] - self.bands[0][0]) if world > 1 else 0
         kw = {"dtype": torch.float64, "device": ops.device}
-        self.full = torch.zeros((self.band * world, ncol), **kw)      # all-gather target
-        self.pred = torch.zeros((self.band, ncol), **kw) if world > 1 else self.full   # this rank's chunk
-        self.total = torch.zeros((nrow, ncol), **kw)                  # final.TPS, then pred.elev + final.TPS
+        self.full = torch.zeros((self.band * world, ncol), **kw) if world > 1 else None   # all-gather target
+        self.pred = torch.zeros((self.band, ncol), **kw)              # this rank's chunk: pred.elev
+        self.tot = torch.zeros((self.band, ncol), **kw)               # ... final.TPS, then pred.elev + final.TPS
         self.torch = torch
         self.fit_reserve_cus = int(os.environ.get("MHS_FIT_RESERVE_CUS", 0))
         self.reservation_calibration = None
@@ -192,10 +192,6 @@ class ShardedMltps:
                 ops.ensemble_band(self.r0, self.r1, self.pred[off:off + nb])
             knots, resid, resp, rows, cols = ops.station_residuals()
             n = knots.shape[0]
-            # the one all-gather: the ensemble bands, issued now so that it runs behind rank 0's fit
-            work = None
-            if self.world > 1:
-                work = self.dist.all_gather_into_tensor(self.full, self.pred, async_op=True)
             msg = torch.zeros(tps_msg_len(n), dtype=torch.float64, device=ops.device)
             if self.rank == 0:
                 packed0 = np.ascontiguousarray(ops.tps_fit(knots, resid))
@@ -206,18 +202,33 @@ class ShardedMltps:
         if self.world > 1:
             self.dist.broadcast(msg, src=0)
         packed = msg.cpu().numpy()
-        # Step 3 on the whole grid on every rank, straight into the plane that becomes the sum (while the gather runs)
-        ops.tps_band(packed, 0, self.nrow, self.total)
-        if work is not None:
-            work.wait()
-        pred_full = self.full[self.lead:self.lead + self.nrow]
-        ops.add(pred_full, self.total, self.total)       # Step 5's sum, in place
-        # Step 5 (V73:910-930) on every rank: extract at the stations, R^2, select
-        f_actual = ops.gather(self.total, rows, cols)
+        # Step 3 + the sum on THIS rank's rows only (round 6; rounds 1-5 evaluated the whole grid on every rank, a term that
+        # did not shrink with N): the band is evaluated with the whole grid's plan (ops.tps_band: mhs_tps_predict_rows_dev),
+        # so the stitched plane is the one-rank plane bit for bit -- the flow of the library's own driver (csrc/multi.hip).
+        rows, cols = np.asarray(rows), np.asarray(cols)
+        band_pred, band_tot = self.pred[off:off + nb], self.tot[off:off + nb]
+        f_actual = np.zeros(n)
+        if nb > 0:
+            ops.tps_band(packed, self.r0, self.r1, band_tot)
+            ops.add(band_pred, band_tot, band_tot)           # Step 5's sum, in place
+            mine = (rows >= self.r0) & (rows < self.r1)
+            if mine.any():
+                f_actual[mine] = ops.gather(band_tot, rows[mine] - self.r0, cols[mine])
+        if self.world > 1:                                   # every station's cell lives on exactly one rank
+            t = torch.from_numpy(f_actual).to(ops.device)
+            self.dist.all_reduce(t)
+            f_actual = t.cpu().numpy()
+        f_actual[(rows < 0) | (cols < 0)] = np.nan
+        # Step 5 (V73:910-930): R^2 at the stations, select
         tss = float(np.sum((resp - resp.mean()) ** 2))
         rsq_model = 1.0 - float(np.sum(resid ** 2)) / tss
         rsq_final = 1.0 - float(np.sum((resp - f_actual) ** 2)) / tss
-        final = self.total if rsq_final > rsq_model else pred_full   # V73:925-930
+        src = self.tot if rsq_final > rsq_model else self.pred          # V73:925-930
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.full, src)            # the ONE collective: the output plane, stitched in place
+            final = self.full[self.lead:self.lead + self.nrow]
+        else:
+            final = src[:self.nrow]
         return {"final": final, "rsq_model": rsq_model, "rsq_final": rsq_final, "lambda": unpack_tps(packed)["lambda"]}
 
 
@@ -435,7 +446,8 @@ class HipOps:
         d = unpack_tps(packed)
         fit = Tps.from_coef(d["knots"], d["c"], d["d"], d["lambda"], d["center"], d["scale"])
         g = self.stack.geom
-        self._timed("tps_eval_ms", lambda: interpolate(g, fit, window=(r0, r1, 0, g.ncol), out=out))
+        # rows [r0, r1) with the WHOLE grid's plan: the bands of several ranks stitch to the one-rank plane bit for bit
+        self._timed("tps_eval_ms", lambda: interpolate(g, fit, rows=(r0, r1), out=out))
         self.last_eval_plan = fit.eval_plan()
 
     # ---- reference-tiled Step 3 (TiledTpsShardedMltps) --------------------------------------------------------------

@@ -136,26 +136,30 @@ def fit_many(xs, Ys, lambda_: float | None = None, gcv_mode: str = "fields"):
     return fits
 
 
-def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None):
+def interpolate(geom: Geometry, model: Tps, window=None, out=None, stream=None, rows=None):
     """terra::interpolate(geometry-only raster, tps): evaluate the spline at EVERY cell
     centre of ``geom`` (or of the window (r0, r1, c0, c1)); no NA mask (V73:726,753).
 
     Returns a float64 torch tensor on the GPU, shape (r1-r0, c1-c0), row-major from the
     north-west cell.  ``out`` may be a pre-allocated 2-D device tensor (row stride = ld).
+    ``rows=(b0, b1)``: only those rows of the window, evaluated with the WINDOW's plan (a device's row band: the bands
+    of several devices stitch to the one-piece plane bit for bit); ``out`` then has b1 - b0 rows.
     """
     import torch
     r0, r1, c0, c1 = window if window is not None else (0, geom.nrow, 0, geom.ncol)
+    b0, b1 = rows if rows is not None else (r0, r1)
     dev = torch.device("cuda", _lib.init())
     if out is None:
-        out = torch.empty((r1 - r0, c1 - c0), dtype=torch.float64, device=dev)
+        out = torch.empty((b1 - b0, c1 - c0), dtype=torch.float64, device=dev)
     if out.dtype != torch.float64 or not out.is_cuda or out.dim() != 2 or out.stride(1) != 1:
         raise ValueError("out must be a 2-D float64 device tensor with unit column stride")
-    if tuple(out.shape) != (r1 - r0, c1 - c0):
+    if tuple(out.shape) != (b1 - b0, c1 - c0):
         raise ValueError("out has the wrong shape for the window")
     g = geom.c_struct()
     s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(_lib.lib().mhs_tps_predict_grid_dev(model._h, C.byref(g), r0, r1, c0, c1,
-                                                   out.data_ptr(), out.stride(0), s))
+    if b1 > b0:
+        _lib.check(_lib.lib().mhs_tps_predict_rows_dev(model._h, C.byref(g), r0, r1, c0, c1, b0, b1,
+                                                       out.data_ptr(), out.stride(0), s))
     return out
 
 
