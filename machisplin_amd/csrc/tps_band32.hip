@@ -732,21 +732,59 @@ __global__ __launch_bounds__(256) void b32_symm_kernel(double *__restrict__ A, i
     const double *a0p = Ab + (ok00 ? rp0 : 0), *a1p = Ab + (ok10 ? rp1 : 0);
     // four k-steps per trip, their sixteen global loads issued before the first MFMA (the compiler declines to unroll this
     // loop by itself: with two loads in flight per wave the kernel streamed at 2.7 TB/s)
+    // Round 6: the trailing matrix is kept in its LOWER triangle only (b32_rankk_kernel updates the tiles on and below the
+    // diagonal: half the bytes and half the MFMA work of the update, the largest kernel of a large fit).  An entry above the
+    // diagonal is read from its mirror image, A22[r][c] = A22[c][r] at Ab + c + r * ld: for a fixed row that is a
+    // contiguous run along c, so over the four k-steps of a trip every 128-byte line a lane touches is used in full.
+    const int r00 = ok00 ? rp0 : 0, r01 = ok01 ? rp0 + 1 : 0, r10 = ok10 ? rp1 : 0, r11 = ok11 ? rp1 + 1 : 0;
     for (int j = jbeg; j < jend; j += 16) {
         double2 a0[4], a1[4];
         double b0[4], b1[4];
+        if (j + 16 <= I0) {      // every column of the trip lies left of the block's rows: the stored triangle
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int jc = j + 4 * u + l4;
-            const int col = min(jc, t - 1);
-            a0[u] = *(const double2 *)(a0p + (int64_t)col * ld);
-            a1[u] = *(const double2 *)(a1p + (int64_t)col * ld);
-            const double *vrow = Vr + (int64_t)min(jc, t + 59) * NB + l15;      // rows t .. t + 63 of Vr are zero
-            b0[u] = vrow[0]; b1[u] = vrow[16];
+            for (int u = 0; u < 4; ++u) {
+                const int jc = j + 4 * u + l4;
+                const int col = min(jc, t - 1);
+                a0[u] = *(const double2 *)(a0p + (int64_t)col * ld);
+                a1[u] = *(const double2 *)(a1p + (int64_t)col * ld);
+                const double *vrow = Vr + (int64_t)min(jc, t + 59) * NB + l15;      // rows t .. t + 63 of Vr are zero
+                b0[u] = vrow[0]; b1[u] = vrow[16];
+            }
+        } else if (j >= I0 + 64) {      // every column of the trip lies right of the block's rows: the mirror image, whole.
+            // Along a mirrored row the columns are contiguous, so a lane takes them in PAIRS (16-byte loads): k-steps 2 q and
+            // 2 q + 1 of the trip stand for columns j + 8 q + 2 l4 and + 1 -- the sum over a trip's 16 columns does not care
+            // in which order they come, as long as A22's and V's operands agree.
+            const int tcl = (t - 2) & ~1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int jc = j + 8 * q + 2 * l4;
+                const int col = jc < t ? jc : tcl;      // (jc = t - 1: its partner, column t, is finite memory of the same row and meets a zero row of V)
+                const double2 m00 = *(const double2 *)(Ab + (int64_t)r00 * ld + col), m01 = *(const double2 *)(Ab + (int64_t)r01 * ld + col);
+                const double2 m10 = *(const double2 *)(Ab + (int64_t)r10 * ld + col), m11 = *(const double2 *)(Ab + (int64_t)r11 * ld + col);
+                const bool lv0 = jc < jend, lv1 = jc + 1 < jend;
+                a0[2 * q].x = lv0 ? m00.x : 0.0; a0[2 * q].y = lv0 ? m01.x : 0.0; a1[2 * q].x = lv0 ? m10.x : 0.0; a1[2 * q].y = lv0 ? m11.x : 0.0;
+                a0[2 * q + 1].x = lv1 ? m00.y : 0.0; a0[2 * q + 1].y = lv1 ? m01.y : 0.0; a1[2 * q + 1].x = lv1 ? m10.y : 0.0; a1[2 * q + 1].y = lv1 ? m11.y : 0.0;
+                const double *vrow = Vr + (int64_t)min(jc, t + 58) * NB + l15;
+                b0[2 * q] = vrow[0]; b1[2 * q] = vrow[16];
+                b0[2 * q + 1] = vrow[NB]; b1[2 * q + 1] = vrow[NB + 16];
+            }
+        } else {                 // the trips across the diagonal: entry by entry, the mirror image where the column is the larger index
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jc = j + 4 * u + l4;
+                const int col = min(jc, t - 1);
+                a0[u].x = col <= r00 ? Ab[(int64_t)col * ld + r00] : Ab[(int64_t)r00 * ld + col];
+                a0[u].y = col <= r01 ? Ab[(int64_t)col * ld + r01] : Ab[(int64_t)r01 * ld + col];
+                a1[u].x = col <= r10 ? Ab[(int64_t)col * ld + r10] : Ab[(int64_t)r10 * ld + col];
+                a1[u].y = col <= r11 ? Ab[(int64_t)col * ld + r11] : Ab[(int64_t)r11 * ld + col];
+                const double *vrow = Vr + (int64_t)min(jc, t + 59) * NB + l15;
+                b0[u] = vrow[0]; b1[u] = vrow[16];
+            }
         }
+        const bool mirrored = j >= I0 + 64;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool live = j + 4 * u < jend;
+            const bool live = mirrored || j + 4 * u < jend;
             const double x0 = ok00 && live ? a0[u].x : 0.0, x1 = ok01 && live ? a0[u].y : 0.0;
             const double x2 = ok10 && live ? a1[u].x : 0.0, x3 = ok11 && live ? a1[u].y : 0.0;
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0[u], acc[0][0], 0, 0, 0);
@@ -973,8 +1011,9 @@ __global__ __launch_bounds__(256) void b32_wfin_kernel(int t, int cpb, const dou
     }
 }
 
-// K5: A22 -= V W' + W V' = Z Zs' with Z = [V | W] (t x 64, column-major, stride vs) and Zs = [W | V], on 128 x 128 tiles of
-// the whole t x t block (full symmetric storage).  The tile loop is tps_fit.hip's band_rankk_kernel with K = 64: 4 waves
+// K5: A22 -= V W' + W V' = Z Zs' with Z = [V | W] (t x 64, column-major, stride vs) and Zs = [W | V], on the 128 x 128 tiles
+// on and below the diagonal of the t x t block (round 6: the upper triangle is never read again -- the symmetric product
+// takes it from its mirror image -- so it is not updated either).  The tile loop is tps_fit.hip's band_rankk_kernel with K = 64: 4 waves
 // x 64 x 64, K streamed through two LDS buffers in chunks of 16, the C tile preloaded into the accumulators with a negated
 // operand.  col0_only: the first block column only (look-ahead: the next panel lives in its first 32 columns).
 constexpr int RK_T = 128, RK_KC = 16, RK_S = RK_T + 16, RK_K = 2 * NB;
@@ -982,7 +1021,11 @@ __global__ __launch_bounds__(256, 2) void b32_rankk_kernel(double *__restrict__ 
                                                            const double *__restrict__ Z, int64_t vs, int nt) {
     __shared__ __attribute__((aligned(16))) double sI[2][RK_KC * RK_S];
     __shared__ __attribute__((aligned(16))) double sJ[2][RK_KC * RK_S];
-    const int bi = blockIdx.x % nt, bj = blockIdx.x / nt;
+    // tiles on and below the diagonal only, column by column (round 6: b32_symm_kernel reads the upper triangle from its
+    // mirror image): block index -> (bi >= bj)
+    int bj = 0, rem = blockIdx.x;
+    while (rem >= nt - bj) { rem -= nt - bj; ++bj; }
+    const int bi = bj + rem;
     const int lmin = NB;      // columns 0 .. 31 belong to b32_strip_kernel (and, by now, to the next panel's kernels)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
@@ -1838,7 +1881,7 @@ int band32_reduce(FitLane &L, hipStream_t s, hipStream_t s2, double *A, int64_t 
             hipEvent_t ev_w = pool[2 * p], ev_rest = pool[2 * p + 1];
             MHS_HIP(hipEventRecord(ev_w, s));
             MHS_HIP(hipStreamWaitEvent(s2, ev_w, 0));
-            hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt * nt), dim3(256), 0, s2, A, ld, r0, t, Zc, vs, nt);
+            hipLaunchKernelGGL(b32_rankk_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s2, A, ld, r0, t, Zc, vs, nt);
             MHS_HIP(hipEventRecord(ev_rest, s2));
             pending_rest = ev_rest;
         }
