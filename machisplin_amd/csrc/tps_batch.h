@@ -63,6 +63,12 @@ void eval_batch_destroy(EvalBatch *B);
 int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
                    int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, int res_index, int64_t knot_off,
                    std::vector<int> &perm);
+// the same in two halves: the plan is pure (any host thread), the commit appends to the batch (one thread, in job order)
+struct EvalPlanHandle;
+EvalPlanHandle *eval_batch_plan(const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                                int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, std::vector<int> &perm, int *rc_out);
+void eval_batch_commit(EvalBatch *B, EvalPlanHandle *h, int res_index, int64_t knot_off);
+void eval_plan_drop(EvalPlanHandle *h);
 size_t eval_batch_device_bytes(const EvalBatch *B);
 int eval_batch_launch(EvalBatch *B, char *dev, const Knot *knots_base, const SmallResult *res_base, hipStream_t s);
 

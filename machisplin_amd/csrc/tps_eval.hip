@@ -483,6 +483,7 @@ struct EvalBatch {
     };
     struct Mats { int tx, ty; std::vector<double> lx, ly; size_t lx_off = 0, ly_off = 0; };
     std::vector<Item> items;
+    std::vector<EvalWindow> wh;     // the descriptors as uploaded (kept until the batch is destroyed: the copy is asynchronous)
     std::vector<int> bins;          // all windows' bin offsets
     std::vector<Mats> mats;         // interpolation matrices, one pair per distinct tile size
     size_t nodes_total = 0;
@@ -491,11 +492,12 @@ struct EvalBatch {
 EvalBatch *eval_batch_create() { return new EvalBatch(); }
 void eval_batch_destroy(EvalBatch *B) { delete B; }
 
-int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
-                   int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, int res_index, int64_t knot_off,
-                   std::vector<int> &perm) {
+// the planning half of eval_batch_add: pure (no shared state), so the tiles of a surface are planned by several host threads
+struct EvalPlan { EvalBatch::Item it; std::vector<int> start; bool far = false; };
+static int eval_plan_one(const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                         int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, EvalPlan &P, std::vector<int> &perm) {
     MHS_REQUIRE(r1 - r0 < (1LL << 30) && c1 - c0 < (1LL << 30) && r1 > r0 && c1 > c0, "window too large or empty");
-    EvalBatch::Item it;
+    EvalBatch::Item &it = P.it;
     memset(&it.w, 0, sizeof(it.w));
     EvalGeom &e = it.w.g;
     e.xmin = grid->xmin; e.ymax = grid->ymax; e.xres = grid->xres; e.yres = grid->yres;
@@ -503,29 +505,13 @@ int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *ce
     e.d0 = e.d1 = e.d2 = 0.0;
     e.r0 = r0; e.c0 = c0; e.nr = (int)(r1 - r0); e.nc = (int)(c1 - c0); e.ld = ld;
     it.w.out = out_dev; it.w.n = n;
-    it.knot_off = knot_off; it.res_index = res_index;
-    bool far = false;
     std::vector<double> kc, kr;
-    far_plan_choose(knots_uv, n, e, &it.w.f, &far, kc, kr);
+    far_plan_choose(knots_uv, n, e, &it.w.f, &P.far, kc, kr);
     perm.resize((size_t)n);
-    if (far) {
-        std::vector<int> start, order;
-        far_plan_sort(n, e, it.w.f, kc, kr, start, order, nullptr, nullptr);
+    if (P.far) {
+        std::vector<int> order;
+        far_plan_sort(n, e, it.w.f, kc, kr, P.start, order, nullptr, nullptr);
         for (int p = 0; p < n; ++p) perm[(size_t)order[(size_t)p]] = p;
-        it.bins_off = B->bins.size();
-        B->bins.insert(B->bins.end(), start.begin(), start.end());
-        it.nodes_off = B->nodes_total;
-        B->nodes_total += (size_t)it.w.f.ntx * it.w.f.nty * FF_NODES;
-        for (size_t q = 0; q < B->mats.size(); ++q)
-            if (B->mats[q].tx == it.w.f.tx && B->mats[q].ty == it.w.f.ty) it.lxy = (int)q;
-        if (it.lxy < 0) {
-            EvalBatch::Mats m;
-            m.tx = it.w.f.tx; m.ty = it.w.f.ty;
-            cheb_matrix(m.tx, false, it.w.f.t, m.lx);
-            cheb_matrix(m.ty, true, it.w.f.t, m.ly);
-            it.lxy = (int)B->mats.size();
-            B->mats.push_back(std::move(m));
-        }
         it.w.far = 1;
         it.w.node_blocks = (it.w.f.ntx * it.w.f.nty + 3) / 4;
         it.w.cgx = it.w.f.ntx * (it.w.f.tx / 64);
@@ -536,11 +522,55 @@ int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *ce
         it.w.cgx = (e.nc + 63) / 64;
         it.w.cgy = (e.nr + EVAL_TILE_ROWS - 1) / EVAL_TILE_ROWS;
     }
+    return MHS_OK;
+}
+static void eval_plan_commit(EvalBatch *B, EvalPlan &P, int res_index, int64_t knot_off) {
+    EvalBatch::Item &it = P.it;
+    it.knot_off = knot_off; it.res_index = res_index;
+    if (P.far) {
+        it.bins_off = B->bins.size();
+        B->bins.insert(B->bins.end(), P.start.begin(), P.start.end());
+        it.nodes_off = B->nodes_total;
+        B->nodes_total += (size_t)it.w.f.ntx * it.w.f.nty * FF_NODES;
+        it.lxy = -1;
+        for (size_t q = 0; q < B->mats.size(); ++q)
+            if (B->mats[q].tx == it.w.f.tx && B->mats[q].ty == it.w.f.ty) it.lxy = (int)q;
+        if (it.lxy < 0) {
+            EvalBatch::Mats m;
+            m.tx = it.w.f.tx; m.ty = it.w.f.ty;
+            cheb_matrix(m.tx, false, it.w.f.t, m.lx);
+            cheb_matrix(m.ty, true, it.w.f.t, m.ly);
+            it.lxy = (int)B->mats.size();
+            B->mats.push_back(std::move(m));
+        }
+    }
     B->max_node_blocks = std::max(B->max_node_blocks, (unsigned)it.w.node_blocks);
     B->max_cell_blocks = std::max(B->max_cell_blocks, (unsigned)(it.w.cgx * it.w.cgy));
     B->items.push_back(it);
+}
+int eval_batch_add(EvalBatch *B, const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                   int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, int res_index, int64_t knot_off,
+                   std::vector<int> &perm) {
+    EvalPlan P;
+    if (int rc = eval_plan_one(knots_uv, n, center, scale, grid, r0, r1, c0, c1, out_dev, ld, P, perm)) return rc;
+    eval_plan_commit(B, P, res_index, knot_off);
     return MHS_OK;
 }
+// two halves for callers that plan many windows side by side: plan (any thread), then commit (one thread, in job order)
+EvalPlanHandle *eval_batch_plan(const double *knots_uv, int n, const double *center, const double *scale, const mhs_grid *grid,
+                                int64_t r0, int64_t r1, int64_t c0, int64_t c1, double *out_dev, int64_t ld, std::vector<int> &perm, int *rc_out) {
+    EvalPlan *P = new EvalPlan();
+    const int rc = eval_plan_one(knots_uv, n, center, scale, grid, r0, r1, c0, c1, out_dev, ld, *P, perm);
+    if (rc_out) *rc_out = rc;
+    if (rc) { delete P; return nullptr; }
+    return reinterpret_cast<EvalPlanHandle *>(P);
+}
+void eval_batch_commit(EvalBatch *B, EvalPlanHandle *h, int res_index, int64_t knot_off) {
+    EvalPlan *P = reinterpret_cast<EvalPlan *>(h);
+    eval_plan_commit(B, *P, res_index, knot_off);
+    delete P;
+}
+void eval_plan_drop(EvalPlanHandle *h) { delete reinterpret_cast<EvalPlan *>(h); }
 
 static size_t eb_up(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t eval_batch_device_bytes(const EvalBatch *B) {
@@ -566,7 +596,8 @@ int eval_batch_launch(EvalBatch *B, char *dev, const Knot *knots_base, const Sma
         MHS_HIP(hipMemcpyAsync(p + m.lx.size(), m.ly.data(), sizeof(double) * m.ly.size(), hipMemcpyHostToDevice, s));
     }
     double *nodes_dev = (double *)(dev + off);
-    std::vector<EvalWindow> w(B->items.size());
+    std::vector<EvalWindow> &w = B->wh;
+    w.resize(B->items.size());
     for (size_t k = 0; k < B->items.size(); ++k) {
         const EvalBatch::Item &it = B->items[k];
         w[k] = it.w;
@@ -580,7 +611,6 @@ int eval_batch_launch(EvalBatch *B, char *dev, const Knot *knots_base, const Sma
     }
     MHS_HIP(hipMemcpyAsync(wdev, w.data(), sizeof(EvalWindow) * w.size(), hipMemcpyHostToDevice, s));
     if (!B->bins.empty()) MHS_HIP(hipMemcpyAsync(bins_dev, B->bins.data(), sizeof(int) * B->bins.size(), hipMemcpyHostToDevice, s));
-    MHS_HIP(hipStreamSynchronize(s));      // w is a host temporary (pageable copies are staged, but keep it simple and safe)
     const unsigned nt = (unsigned)B->items.size();
     MHS_REQUIRE(nt <= 65535u, "too many windows for one launch");
     if (B->max_node_blocks > 0)

@@ -34,10 +34,26 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
                      const std::vector<int64_t> &cols, double lambda, int gcv_mode, const int64_t *tile_ids, int64_t njobs,
                      double *const *out_ptrs) {
     if (njobs <= 0) return MHS_OK;
+    const bool timing = getenv("MHS_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[run_tiles] %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const char *benv = getenv("MHS_TILES_BATCH");
     const bool use_batch = !(benv && benv[0] == '0');
     // ---- the tiles' stations (terra::extract(rb[[1]], Full.cords) + complete.cases, V73:701-706)
-    struct Job { int64_t h; std::vector<double> txy, sr; int64_t m = 0; int route = 0; /* 0 zeros, 1 batch, 2 lane */ int bjob = -1; };
+    struct Job {
+        int64_t h = 0, m = 0;
+        std::vector<double> txy, sr;
+        int route = 0;      // 0 zeros, 1 batch, 2 lane
+        int bjob = -1, rc = MHS_OK;
+        std::string err;
+        EvalPlanHandle *plan = nullptr;
+        std::vector<int> perm;
+    };
     std::vector<Job> jobs((size_t)njobs);
     FitLane *Lb = nullptr;
     if (int rc = fit_lane(BATCH_LANE, &Lb)) return rc;
@@ -47,14 +63,15 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     struct EbGuard { EvalBatch *p; ~EbGuard() { eval_batch_destroy(p); } } eb_guard{EB};
     std::vector<TpsPrep> preps((size_t)njobs);
     std::vector<int64_t> lane_jobs;
-    std::vector<double> sx, sy;
-    std::vector<int> perm;
-    for (int64_t job = 0; job < njobs; ++job) {
+    // Everything the host does per tile before the launches -- its stations (an O(n) scan), Krig's replicate collapse, the
+    // QR of [1 u v], the evaluation plan's counting sort -- is independent of the other tiles: a few host threads share
+    // the tiles (2.1 ms on one thread for cfg3's 49 tiles, as long as the kernels they feed).
+    auto prepare_one = [&](int64_t job) {
         Job &J = jobs[(size_t)job];
         J.h = tile_ids ? tile_ids[job] : job;
         const int64_t *f = &fit[(size_t)J.h * 4], *k = &keep[(size_t)J.h * 4];
-        const int64_t kr = k[1] - k[0], kc = k[3] - k[2];
-        sx.clear(); sy.clear(); J.sr.clear();
+        const int64_t kc = k[3] - k[2];
+        std::vector<double> sx, sy;
         for (int64_t i = 0; i < n; ++i) {
             if (rows[i] < f[0] || rows[i] >= f[1] || cols[i] < f[2] || cols[i] >= f[3]) continue;
             if (cov1_at_stations && std::isnan(cov1_at_stations[i])) continue;
@@ -62,36 +79,58 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
             sx.push_back(xy[i]); sy.push_back(xy[n + i]); J.sr.push_back(resid[i]);
         }
         J.m = (int64_t)J.sr.size();
-        if (J.m < 10) {  // V73:710-721: the tile is all zeros
-            J.route = 0;
-            MHS_HIP(hipMemsetAsync(out_ptrs[job], 0, sizeof(double) * (size_t)(kr * kc), sb));
-            continue;
-        }
+        if (J.m < 10) { J.route = 0; return; }      // V73:710-721: the tile is all zeros
         J.txy.resize((size_t)2 * J.m);
         for (int64_t i = 0; i < J.m; ++i) { J.txy[(size_t)i] = sx[(size_t)i]; J.txy[(size_t)(J.m + i)] = sy[(size_t)i]; }
         J.route = 2;
         if (use_batch && J.m <= 4 * SB_NMAX) {      // (replicates can only shrink the count)
             TpsPrep &P = preps[(size_t)job];
-            if (int rc = tps_prepare(J.txy.data(), J.sr.data(), J.m, P)) return rc;
+            J.rc = tps_prepare(J.txy.data(), J.sr.data(), J.m, P);
+            if (J.rc) { J.err = mhs_last_error(); return; }
             if (P.n >= SB_NMIN && P.n <= SB_NMAX) {
                 // terra::interpolate(terra::rast(rb), tps): cell centres of the FIT raster (V73:726), the keep window of it
                 mhs_grid gf = *g;
                 gf.xmin = g->xmin + (double)f[2] * g->xres;
                 gf.ymax = g->ymax - (double)f[0] * g->yres;
                 gf.nrow = f[1] - f[0]; gf.ncol = f[3] - f[2];
-                if (int rc = eval_batch_add(EB, P.uv.data(), (int)P.n, P.center, P.scale, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2],
-                                            k[3] - f[2], out_ptrs[job], kc, B.count, B.knot_total, perm)) return rc;
-                J.bjob = small_batch_add(B, P, lambda, gcv_mode, perm.data());
+                J.plan = eval_batch_plan(P.uv.data(), (int)P.n, P.center, P.scale, &gf, k[0] - f[0], k[1] - f[0], k[2] - f[2],
+                                         k[3] - f[2], out_ptrs[job], kc, J.perm, &J.rc);
+                if (J.rc) { J.err = mhs_last_error(); return; }
                 J.route = 1;
             }
         }
-        if (J.route == 2) lane_jobs.push_back(job);
+    };
+    {
+        const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(njobs / 8, 6), cpu_budget()));
+        std::atomic<int64_t> next{0};
+        auto work = [&]() { for (;;) { const int64_t job = next.fetch_add(1); if (job >= njobs) break; prepare_one(job); } };
+        std::vector<std::thread> threads;
+        for (int q = 1; q < nthreads; ++q) threads.emplace_back(work);
+        work();
+        for (std::thread &th : threads) th.join();
     }
+    for (int64_t job = 0; job < njobs; ++job) {      // in job order: errors, the zero tiles, the batch's entries
+        Job &J = jobs[(size_t)job];
+        if (J.rc) {
+            for (Job &Q : jobs) if (Q.plan) { eval_plan_drop(Q.plan); Q.plan = nullptr; }
+            set_error("%s", J.err.c_str());
+            return J.rc;
+        }
+        const int64_t *k = &keep[(size_t)J.h * 4];
+        if (J.route == 0) MHS_HIP(hipMemsetAsync(out_ptrs[job], 0, sizeof(double) * (size_t)((k[1] - k[0]) * (k[3] - k[2])), sb));
+        else if (J.route == 1) {
+            eval_batch_commit(EB, J.plan, B.count, B.knot_total);
+            J.plan = nullptr;
+            J.bjob = small_batch_add(B, preps[(size_t)job], lambda, gcv_mode, J.perm.data());
+        } else lane_jobs.push_back(job);
+    }
+    lap("stations, preparation, plans (host)");
     // ---- the batch: fit launch, then the two evaluation launches behind it on the same stream
     char *extra = nullptr;
     if (int rc = small_batch_launch(B, *Lb, sb, eval_batch_device_bytes(EB), &extra)) return rc;
     if (B.count > 0)
         if (int rc = eval_batch_launch(EB, extra, B.knots_dev, B.res_dev, sb)) return rc;
+    lap("uploads + launches");
     // ---- the other tiles: chains of small, latency-bound kernels, several side by side, each on its own lane (two streams +
     // work arena) driven by its own host thread
     int rc = MHS_OK;
@@ -156,6 +195,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     if (int rc2 = small_batch_results(B, sb, res, nullptr)) { if (!rc) rc = rc2; }
     else if (hipStreamSynchronize(sb) != hipSuccess) { if (!rc) rc = MHS_ERR_HIP; }
     for (mhs_tps *t : handles) tps_free_quiet(t);      // every lane is idle: no wait, the blocks go back to the pool
+    lap("wait for the kernels (+ lanes)");
     if (rc) { if (!err_msg.empty()) set_error("%s", err_msg.c_str()); return rc; }
     for (const SmallResult &r : res)
         if (r.status != 0.0) { set_error("mhs_tps_fit: GCV search failed"); return MHS_ERR_NUMERIC; }

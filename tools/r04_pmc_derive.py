@@ -48,5 +48,8 @@ for k, d in S.items():
         r["levels_walked_per_cell"] = (v["SQ_INSTS_LDS"] - staging) * 64.0 / cells / 2.0
         r["levels_full_depth_per_cell"] = units["rf"]
     out[k] = r
+sys.path.insert(0, ROOT)
+import bench      # the counters are quoted only for the build of the member kernels they were taken on
+out["member_kernel_source_hash"] = bench.member_kernel_source_hash()
 json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_members_pmc_derived.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
