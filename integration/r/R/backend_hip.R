@@ -70,6 +70,13 @@ mhs_Tps <- function(x, Y, lambda = NA_real_) {
   structure(list(handle = .Call("mhsr_tps_fit", as.matrix(x), as.numeric(unlist(Y)), lambda, 0L)),
             class = "machisplin_tps")
 }
+# lapply(seq_along(xs), function(k) fields::Tps(xs[[k]], Ys[[k]])) in ONE library call: the tiles of V73:690-738 (or the
+# response layers of one station table); every fit with 8..256 distinct locations is one workgroup of one kernel launch.
+# Returns a list of "machisplin_tps" objects, NULL where a fit failed (the loop of V73:707-738 skips such a tile's spline).
+mhs_Tps_many <- function(xs, Ys, lambda = NA_real_) {
+  hs <- .Call("mhsr_tps_fit_many", lapply(xs, as.matrix), lapply(Ys, function(y) as.numeric(unlist(y))), lambda, 0L)
+  lapply(hs, function(h) if (is.null(h)) NULL else structure(list(handle = h), class = "machisplin_tps"))
+}
 predict.machisplin_tps <- function(object, x, ...) .Call("mhsr_tps_predict_points", object$handle, as.matrix(x))
 mhs_interpolate <- function(r, object) {
   v <- .Call("mhsr_tps_predict_grid", object$handle, .mhs_geom(r), c(0L, nrow(r), 0L, ncol(r)))

@@ -40,6 +40,34 @@ SEXP mhsr_tps_fit(SEXP xy, SEXP y, SEXP lambda, SEXP mode) {
     return wrap(t, tps_finalizer);
 }
 
+/* lapply(seq_along(xs), function(k) fields::Tps(xs[[k]], ys[[k]])) in ONE library call (the tiles of V73:690-738, or the
+ * response layers of one station table): xs a list of n_k x 2 numeric matrices, ys a list of numeric vectors.  Every fit with
+ * 8..256 distinct locations is done by one kernel launch, a workgroup per fit (mhs_tps_fit_many).  Returns a list of external
+ * pointers, NULL where a fit failed (collinear stations, ...). */
+SEXP mhsr_tps_fit_many(SEXP xs, SEXP ys, SEXP lambda, SEXP mode) {
+    const R_xlen_t k = Rf_xlength(xs);
+    double lam = Rf_asReal(lambda);
+    const double **px = (const double **)R_alloc((size_t)(k ? k : 1), sizeof(double *));
+    const double **py = (const double **)R_alloc((size_t)(k ? k : 1), sizeof(double *));
+    int64_t *n = (int64_t *)R_alloc((size_t)(k ? k : 1), sizeof(int64_t));
+    mhs_tps **h = (mhs_tps **)R_alloc((size_t)(k ? k : 1), sizeof(mhs_tps *));
+    int *st = (int *)R_alloc((size_t)(k ? k : 1), sizeof(int));
+    if (Rf_xlength(ys) != k) Rf_error("mhsr_tps_fit_many: xs and ys have different lengths");
+    for (R_xlen_t i = 0; i < k; ++i) {
+        SEXP x = VECTOR_ELT(xs, i), y = VECTOR_ELT(ys, i);
+        if (Rf_xlength(x) != 2 * Rf_xlength(y)) Rf_error("mhsr_tps_fit_many: element %d: x must be an n x 2 matrix beside n values", (int)i + 1);
+        px[i] = REAL(x); py[i] = REAL(y); n[i] = (int64_t)Rf_xlength(y); h[i] = NULL;
+    }
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, k));
+    int rc = mhs_tps_fit_many(px, py, n, (int64_t)k, ISNA(lam) ? R_NaN : lam, Rf_asInteger(mode), h, st);
+    /* every handle gets its owner BEFORE an error can unwind: nothing leaks */
+    for (R_xlen_t i = 0; i < k; ++i)
+        if (h[i]) SET_VECTOR_ELT(out, i, wrap(h[i], tps_finalizer));
+    UNPROTECT(1);
+    chk(rc);
+    return out;
+}
+
 /* predict(tps, xy): the spline at arbitrary points -- what terra::interpolate feeds an S3 predict method
  * block by block; xy is an n x 2 numeric matrix */
 SEXP mhsr_tps_predict_points(SEXP tps, SEXP xy) {

@@ -187,6 +187,14 @@ def test_shim_planes_equal_the_direct_c_abi_calls_bit_for_bit(R, hip):
     assert np.array_equal(got.reshape(g.nrow, g.ncol), hip.interpolate(g, fit).cpu().numpy())
     pts = R.values(R.call("mhsr_tps_predict_points", t, R.mat(xy[:50])))
     assert np.array_equal(pts, fit.predict(xy[:50]))
+    # several fits in one call (the tiles of V73:690-738): a list of external pointers, NULL where a fit failed
+    sets = [(xy[:120], resid[:120]), (xy[100:330], resid[100:330]), (np.column_stack([np.linspace(0, 1, 20)] * 2), np.ones(20))]
+    many = R.values(R.call("mhsr_tps_fit_many", R.list([R.mat(a) for a, _ in sets]), R.list([R.num(b) for _, b in sets]), R.num([R.NA]), R.int([0])))
+    want = hip.tps.fit_many([a for a, _ in sets], [b for _, b in sets])
+    assert want[2] is None and R.lib.rstub_type(many[2]) != EXTPTRSXP          # collinear stations: NULL in the list
+    for k in (0, 1):
+        assert R.lib.rstub_type(many[k]) == EXTPTRSXP
+        assert np.array_equal(R.values(R.call("mhsr_tps_predict_points", many[k], R.mat(xy[:50]))), want[k].predict(xy[:50]))
 
     # the six loaders + the Step-2 raster loop (V73:447-619) and the station predictions
     hs = _load_members(R, params)
