@@ -48,6 +48,7 @@ struct Context {
     int device = -1;
     hipStream_t stream = nullptr;         // = lanes[0]->s: the stream of the blocking host entry points
     std::vector<FitLane *> lanes;         // lanes[0] is created by mhs_init, the others on demand (fit_lane)
+    FitLane *batch = nullptr;             // the batched small fits' own lane: ONE plain stream + arena, no CU-masked streams (batch_lane)
     double2 *log_tab = nullptr;  // device, LOG_TAB_N entries
     double *exp_tab = nullptr;   // device, 4096 entries 2^(j/4096) (svr_kernel)
     double *points_arena = nullptr;       // grow-only device scratch of mhs_residual_points
@@ -104,6 +105,11 @@ void set_mosaic_lane(int lane);
 Context &ctx();                       // the current slot's context
 Context &ctx_slot(int slot);
 int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from one thread at a time)
+// The batch's lane (tps_batch.hip, the tiled Step 3): a single non-blocking stream and a grow-only arena.  NOT one of `lanes`:
+// those carry up to three CU-masked streams each, and a process that holds a few dozen masked streams sees every later kernel on
+// its other streams run ~1.8 x slower (measured in round 6: the hardware queues are shared and a queue keeps a mask) -- the
+// tiled Step 3 must not create nine lanes to use one stream.
+int batch_lane(FitLane **out);
 // mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                  int gcv_threads, mhs_tps **out);

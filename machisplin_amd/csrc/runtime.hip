@@ -183,6 +183,22 @@ int fit_lane(int i, FitLane **out) {
     return MHS_OK;
 }
 
+int batch_lane(FitLane **out) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(mask_mutex());
+    if (!c.batch) {
+        int prio_lo = 0, prio_hi = 0;
+        MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        FitLane *L = new FitLane();
+        const hipError_t e = getenv("MHS_BATCH_STREAM_HIGH") ? hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi)
+                                                             : hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete L; return hip_fail(e, "batch_lane: stream creation", __FILE__, __LINE__); }
+        c.batch = L;
+    }
+    *out = c.batch;
+    return MHS_OK;
+}
+
 int h2d_sync(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return MHS_OK;
     hipStream_t up = ctx().upload;
@@ -295,6 +311,12 @@ static void shutdown_slot(int slot) {
     if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); }
     if (c.mask_ev0) (void)hipEventDestroy(c.mask_ev0);
     if (c.mask_ev1) (void)hipEventDestroy(c.mask_ev1);
+    if (c.batch) {
+        (void)hipStreamSynchronize(c.batch->s);
+        if (c.batch->arena) (void)hipFree(c.batch->arena);
+        (void)hipStreamDestroy(c.batch->s);
+        delete c.batch;
+    }
     for (FitLane *L : c.lanes) {
         (void)hipStreamSynchronize(L->s); (void)hipStreamSynchronize(L->s2);
         for (hipEvent_t e : L->pool) (void)hipEventDestroy(e);
@@ -387,6 +409,20 @@ int mhs_fit_reserve_cus(int n_cus, int *previous) {
     MHS_REQUIRE(n_cus >= 0 && n_cus <= c.n_cu / 2 && n_cus % 8 == 0, "n_cus must be a multiple of 8 between 0 and half of the device's compute units");
     std::lock_guard<std::mutex> lk(mask_mutex());
     if (previous) *previous = c.reserved_cus;
+    // Lifting the reservation gives the CU-masked streams back as well (round 6).  Rounds 2-5 kept them for the next time; but
+    // while they exist -- the masked member's stream and every lane's pair confined to the reserved units -- a one-call tiled
+    // Step 3 (mhs_tps_surface_dev: fits + evaluations on the library's own streams) leaves EVERY later kernel of the process,
+    // on any stream, ~1.8 x slower until the streams are destroyed (tools/r06_masked_streams_probe.py,
+    // profiles/r06_masked_streams_probe.txt: ksvm 115 -> 205 ms per 1e8 cells; neither the allocation, nor the mosaic, nor
+    // stream priorities, nor a second stream reproduce it alone; mechanism inside the runtime not identified).  Creating three
+    // masked streams again at the next reservation costs ~0.3 ms.  MHS_RESERVE_KEEP=1 restores the old behaviour.
+    if (n_cus == 0 && !getenv("MHS_RESERVE_KEEP")) {
+        if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); c.masked_stream = nullptr; }
+        for (FitLane *L : c.lanes)
+            if (L->ms) { (void)hipStreamSynchronize(L->ms); (void)hipStreamSynchronize(L->ms2); (void)hipStreamDestroy(L->ms); (void)hipStreamDestroy(L->ms2); L->ms = L->ms2 = nullptr; }
+        c.reserved_cus = c.masked_cus = 0;
+        return MHS_OK;
+    }
     if (n_cus == 0 || n_cus == c.masked_cus) { c.reserved_cus = n_cus; return MHS_OK; }   // the stream is kept for the next time
     if (c.masked_stream) { (void)hipStreamSynchronize(c.masked_stream); (void)hipStreamDestroy(c.masked_stream); c.masked_stream = nullptr; }
     c.reserved_cus = c.masked_cus = 0;

@@ -10,7 +10,6 @@ namespace mhs {
 
 constexpr int SB_NMAX = 256;        // distinct stations one workgroup can hold (the matrix lives in its registers)
 constexpr int SB_NMIN = 8;
-constexpr int BATCH_LANE = 9;        // the batch's own lane (stream + arena), beside lane 0 and the tile lanes 1..8 of tps_surface.hip
 
 // one spline of a batch as the kernel reads it (device array)
 struct SmallJob {

@@ -325,23 +325,28 @@ __device__ __forceinline__ void sb_reduce(const SmallJob *__restrict__ Jp, const
             if (kk == 3 && lane == 0) S.stamp[2] = wall_clock64();
             const int bk = kk & 15, jk = kk >> 4, half = bk & 1, r1 = kk + 1;
             const bool mine = (lane >> 5) == half;
+            // column kk of this thread's blocks: a jump on the (block-uniform) column block instead of a select per element
             double x[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                x[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j <= 2 * i + 1; ++j)
-                    if (j == jk) x[i] = SB_MLD(i, j);
+            for (int i = 0; i < NS; ++i) x[i] = 0.0;
+#define SB_XCASE(J) case J: if constexpr ((J) < NC) { _Pragma("unroll") for (int i = (J) >> 1; i < NS; ++i) x[i] = SB_MLD(i, J); } break;
+            switch (jk) {
+                SB_XCASE(0) SB_XCASE(1) SB_XCASE(2) SB_XCASE(3) SB_XCASE(4) SB_XCASE(5) SB_XCASE(6) SB_XCASE(7)
+                SB_XCASE(8) SB_XCASE(9) SB_XCASE(10) SB_XCASE(11) SB_XCASE(12) SB_XCASE(13) SB_XCASE(14) SB_XCASE(15)
+                default: break;
             }
-            double ssl = 0.0, al = 0.0, dk = 0.0;
+#undef SB_XCASE
+            // alpha = A[kk + 1][kk] and the diagonal entry A[kk][kk] sit in ONE known lane each: a readlane, not a reduction
+            double ssl = 0.0, xa = 0.0, xd = 0.0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int r = a + 32 * i;
                 if (mine && r > r1) ssl += x[i] * x[i];
-                if (mine && r == r1) al = x[i];
-                if (mine && r == kk) dk = x[i];
+                if (i == (r1 >> 5)) xa = x[i];
+                if (i == (kk >> 5)) xd = x[i];
             }
-            const double ss = half_total(ssl, half), alpha = half_total(al, half), dkk = half_total(dk, half);
+            const double ss = half_total(ssl, half);
+            const double alpha = lane_value(xa, 32 * half + (r1 & 31)), dkk = lane_value(xd, 32 * half + (kk & 31));
             double beta = alpha, tk = 0.0, scal = 0.0;
             if (ss != 0.0) {
                 beta = -copysign(sqrt(alpha * alpha + ss), alpha);
@@ -882,7 +887,7 @@ extern "C" int mhs_tps_fit_many(const double *const *xy, const double *const *y,
     }
     if (count == 0) return MHS_OK;
     FitLane *Lb = nullptr, *L0 = nullptr;
-    if (int rc = fit_lane(BATCH_LANE, &Lb)) return rc;
+    if (int rc = batch_lane(&Lb)) return rc;
     if (int rc = fit_lane(0, &L0)) return rc;
     SmallBatch B;
     std::vector<TpsPrep> preps((size_t)count);

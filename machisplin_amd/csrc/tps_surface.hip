@@ -56,7 +56,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
     };
     std::vector<Job> jobs((size_t)njobs);
     FitLane *Lb = nullptr;
-    if (int rc = fit_lane(BATCH_LANE, &Lb)) return rc;
+    if (int rc = batch_lane(&Lb)) return rc;
     const hipStream_t sb = Lb->s;
     SmallBatch B;
     EvalBatch *EB = eval_batch_create();

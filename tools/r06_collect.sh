@@ -21,10 +21,13 @@ if [ "$PART" = all ] || [ "$PART" = gputest ]; then
 fi
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
   timeout 900 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench_cfg3_n1.err; tail -c 300 $O/bench_cfg3_n1.json; echo
-  # the same command under rocprofv3: the line's HIP-event launch times and the profiler's averages from ONE run on ONE box
-  ( cd /tmp && rm -rf /tmp/kst && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o cfg3 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/tmp/kst.log )
-  find /tmp/kst -name "*kernel_stats.csv" -exec cp {} $O/cfg3_rocprofv3_kernel_stats.csv \;
-  python tools/r06_launch_vs_rocprof.py $O/bench_under_rocprof.json $O/cfg3_rocprofv3_kernel_stats.csv > $O/cfg3_launch_vs_rocprof.json; cat $O/cfg3_launch_vs_rocprof.json
+  # the timed steps alone under rocprofv3 (the line's extra records -- float64 boundary, raster sensitivity -- launch the same
+  # kernels on other windows and would blur the per-kernel statistics): the line's HIP-event launch times and the profiler's
+  # durations of the full-grid dispatches from ONE run on ONE box
+  ( cd /tmp && rm -rf /tmp/kst && MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_SENSITIVITY=1 MHS_BENCH_SKIP_FITTED=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o cfg3 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/tmp/kst.log )
+  find /tmp/kst -name "*kernel_stats.csv" -exec cp {} $O/cfg3_steps_only_rocprofv3_kernel_stats.csv \;
+  find /tmp/kst -name "*kernel_trace.csv" -exec cp {} /tmp/cfg3_kernel_trace.csv \;
+  python tools/r06_launch_vs_rocprof.py $O/bench_under_rocprof.json $O/cfg3_steps_only_rocprofv3_kernel_stats.csv /tmp/cfg3_kernel_trace.csv > $O/cfg3_launch_vs_rocprof.json; cat $O/cfg3_launch_vs_rocprof.json
   summ $O/bench_cfg3_n1.json $O/bench_under_rocprof.json
 fi
 if [ "$PART" = all ] || [ "$PART" = benchmore ]; then
@@ -63,4 +66,14 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then      # the batched fit kernel: i
     find /tmp/pmcb -name "*counter_collection.csv" -exec cp {} $O/batch_fit_pmc_$tag.csv \;
   done
   python tools/r06_batch_pmc_summary.py $O > $O/batch_fit_pmc_summary.json; cat $O/batch_fit_pmc_summary.json
+fi
+if [ "$PART" = all ] || [ "$PART" = fitpmc ]; then      # MFMA counters of the large GCV fits (separate passes, --pmc only + --kernel-trace)
+  for n in 20000 5000; do
+    for set in "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES"; do
+      tag=$(echo $set | tr ' ' '_')
+      ( cd /tmp && rm -rf /tmp/pmcf && timeout 900 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcf -o f -- python $GRAFT_REPO_ROOT/tools/fit_prof.py $n gcv 1 > /tmp/pmcf.log 2>&1 )
+      find /tmp/pmcf -name "*counter_collection.csv" -exec cp {} /tmp/fit_pmc_${n}_$tag.csv \;
+    done
+    python tools/r06_fit_pmc_summary.py $n /tmp/fit_pmc_${n}_*.csv > $O/fit_gcv_n${n}_mfma_pmc.json; cat $O/fit_gcv_n${n}_mfma_pmc.json
+  done
 fi
