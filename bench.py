@@ -1382,12 +1382,14 @@ def main():
             step1 = dt / args.steps * 1e3
             costs = [float(c) for c in run.layout["cost"]]
             tiles_view = [run._tile_view(run.full, run.owner[h] * run.chunk, h) for h in range(len(run.keep))]
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run.ops.tps_mosaic(run.layout["nRx"], run.layout["nCx"], run.keep, tiles_view, run.total)
-            torch.cuda.synchronize()
-            mosaic_ms = (time.perf_counter() - t1) * 1e3
-            tiles_alone = max(tiled_ms - mosaic_ms, 1e-3)
+            mosaic_ms = 1e30
+            for _ in range(3):      # best of three: the first call of this path loads its kernels
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run.ops.tps_mosaic(run.layout["nRx"], run.layout["nCx"], run.keep, tiles_view, run.total)
+                torch.cuda.synchronize()
+                mosaic_ms = min(mosaic_ms, (time.perf_counter() - t1) * 1e3)
+            tiles_alone = max(tiled_ms - mosaic_ms, 0.5 * tiled_ms)      # (the stand-alone mosaic also looks for the seams' boxes: never more than half)
             tiles_in_step = float(np.mean(tm["tps_tiles_ms"][-max(1, len(tm["tps_tiles_ms"]) // 2):])) if tm.get("tps_tiles_ms") else None
             tail1 = max(0.0, step1 - max(ens, tiles_in_step or 0.0))      # mosaic, the band sums, Step 5 as this run had them
             projected = {"model": "step(N) = max(ens / N, tiles(N)) + gather(N) + tail; tiles(N) = stand-alone tile time x the heaviest rank's LPT cost share; "
