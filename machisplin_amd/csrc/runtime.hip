@@ -190,8 +190,7 @@ int batch_lane(FitLane **out) {
         int prio_lo = 0, prio_hi = 0;
         MHS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         FitLane *L = new FitLane();
-        const hipError_t e = getenv("MHS_BATCH_STREAM_HIGH") ? hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi)
-                                                             : hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking);
+        const hipError_t e = hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, prio_hi);
         if (e != hipSuccess) { delete L; return hip_fail(e, "batch_lane: stream creation", __FILE__, __LINE__); }
         c.batch = L;
     }
