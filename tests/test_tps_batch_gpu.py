@@ -127,3 +127,56 @@ def test_tiled_surface_mixes_batch_and_lanes(hip):
     assert max(info["tile_n"]) > 256 and min(n for n in info["tile_n"] if n >= 10) <= 256
     got = hip.tps_residual_surface(g, xy, resid, tile_edge=400).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_batch_edge_cases_match_oracle(hip):
+    """The edges of the batch kernel's range and of the search: 8 stations (the smallest it takes), 256 (the largest), more
+    observations than a workgroup holds collapsing to fewer distinct locations, an exactly linear residual (c = 0: the
+    criterion's minimum sits at the upper end of the grid), a constant one, strongly anisotropic coordinates."""
+    rng = np.random.default_rng(17)
+    sets = {}
+    xy, y = synth_stations(8, 801); sets["n8"] = (xy, y)
+    xy, y = synth_stations(256, 802); sets["n256"] = (xy, y)
+    xy, y = synth_stations(230, 803)
+    dup = rng.integers(0, 230, 90)
+    sets["collapse_320_to_230"] = (np.vstack([xy, xy[dup]]), np.concatenate([y, y[dup] + 0.05 * rng.standard_normal(90)]))
+    xy, _ = synth_stations(120, 804); sets["linear"] = (xy, 2.0 + 0.5 * xy[:, 0] - 0.25 * xy[:, 1])
+    xy, _ = synth_stations(60, 805); sets["constant"] = (xy, np.full(60, 3.25))
+    xy, y = synth_stations(150, 806); xy = xy.copy(); xy[:, 1] = -6.0 + 1e-3 * (xy[:, 1] + 6.0); sets["anisotropic"] = (xy, y)
+    names = list(sets)
+    fits = hip.tps.fit_many([sets[k][0] for k in names], [sets[k][1] for k in names])
+    for k, got in zip(names, fits):
+        a, b = sets[k]
+        assert got is not None, k
+        want = otps.fit(a, b)
+        assert got.n == want["knots"].shape[0], k
+        if k in ("linear", "constant"):
+            # c = 0 whatever lambda is: the surface is the plane (G4 KAT); lambda sits at the grid's end in both
+            assert np.abs(got.c).max() < 1e-8 * max(1.0, np.abs(b).max()), k
+            assert np.abs(got.predict(a) - b).max() < 1e-8 * max(1.0, np.abs(b).max()), k
+            continue
+        assert abs(got.lambda_ - want["lambda"]) / want["lambda"] < 1e-8, (k, got.lambda_, want["lambda"])
+        ref = otps.fit(a, b, lam=got.lambda_)
+        assert _rel(got.c, ref["c"]) < 1e-7 and _rel(got.d, ref["d"]) < 1e-7, k
+        assert abs(got.eff_df - want["eff_df"]) < 1e-5 * want["eff_df"], k
+
+
+def test_tiled_surface_zero_tiles_and_replicated_stations(hip):
+    """A surface whose eastern tiles hold fewer than 10 stations (zero tiles, V73:710-721) and whose western ones hold
+    replicated stations: the one-call route (batch) equals the tile-by-tile composition bit for bit, and the oracle's flow."""
+    from machisplin_amd import synth
+    from oracle import tiles as ot
+    g = synth.grid(500, 900)
+    rng = np.random.default_rng(23)
+    cells = rng.choice(500 * 400, size=700, replace=False)
+    rows, cols = cells // 400, cells % 400
+    xy = np.column_stack([g.x_from_col(cols), g.y_from_row(rows)])
+    xy = np.vstack([xy, xy[:40], [[g.x_from_col(np.array([880]))[0], g.y_from_row(np.array([20]))[0]]] * 3])      # replicates; 3 stations far east
+    u = (xy - xy.min(0)) / (xy.max(0) - xy.min(0))
+    resid = np.sin(6 * u[:, 0]) * np.cos(5 * u[:, 1]) + 0.1 * rng.standard_normal(xy.shape[0])
+    info = {}
+    want = hip.tps_residual_surface(g, xy, resid, tile_edge=250, info=info).cpu().numpy()
+    assert min(info["tile_n"]) < 10 < max(info["tile_n"])
+    got = hip.tps_residual_surface(g, xy, resid, tile_edge=250).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.all(got[:, 700:][np.isfinite(got[:, 700:])] == 0.0) or np.abs(got[:, 750:]).max() < 1e-12      # the zero tiles
