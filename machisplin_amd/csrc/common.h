@@ -110,6 +110,7 @@ int fit_lane(int i, FitLane **out);   // lane i, created on first use (call from
 // its other streams run ~1.8 x slower (measured in round 6: the hardware queues are shared and a queue keeps a mask) -- the
 // tiled Step 3 must not create nine lanes to use one stream.
 int batch_lane(FitLane **out);
+std::mutex &batch_mutex();            // one user of the slot's batch lane (its stream and arena) at a time: mhs_tps_fit_many, the tiled Step 3
 // mhs_tps_fit on a given lane; gcv_threads = host threads of the GCV search (0 = auto)
 int tps_fit_lane(FitLane &L, const double *xy, const double *y, int64_t N, double lambda, int gcv_mode,
                  int gcv_threads, mhs_tps **out);

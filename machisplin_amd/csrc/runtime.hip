@@ -31,7 +31,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 namespace {
 struct Slots {
     Context c[MAX_SLOTS];
-    std::mutex pipe_mu[MAX_SLOTS], mask_mu[MAX_SLOTS], mosaic_mu[MAX_SLOTS][2];
+    std::mutex pipe_mu[MAX_SLOTS], mask_mu[MAX_SLOTS], mosaic_mu[MAX_SLOTS][2], batch_mu[MAX_SLOTS];
     int count = 0;                        // slots 0 .. count - 1 are ready
 };
 Slots &slots() { static Slots s; return s; }
@@ -56,6 +56,7 @@ thread_local int t_mosaic_lane = 0;
 int mosaic_lane() { return t_mosaic_lane; }
 void set_mosaic_lane(int lane) { t_mosaic_lane = lane ? 1 : 0; }
 std::mutex &mosaic_mutex() { return slots().mosaic_mu[t_slot][t_mosaic_lane]; }
+std::mutex &batch_mutex() { return slots().batch_mu[t_slot]; }
 
 namespace {
 struct BlockPool {

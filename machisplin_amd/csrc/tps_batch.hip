@@ -886,6 +886,7 @@ extern "C" int mhs_tps_fit_many(const double *const *xy, const double *const *y,
         if (status) status[k] = MHS_OK;
     }
     if (count == 0) return MHS_OK;
+    std::lock_guard<std::mutex> batch_lock(batch_mutex());
     FitLane *Lb = nullptr, *L0 = nullptr;
     if (int rc = batch_lane(&Lb)) return rc;
     if (int rc = fit_lane(0, &L0)) return rc;

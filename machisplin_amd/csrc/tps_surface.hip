@@ -55,6 +55,7 @@ static int run_tiles(const mhs_grid *g, const double *xy, const double *resid, i
         std::vector<int> perm;
     };
     std::vector<Job> jobs((size_t)njobs);
+    std::lock_guard<std::mutex> batch_lock(batch_mutex());
     FitLane *Lb = nullptr;
     if (int rc = batch_lane(&Lb)) return rc;
     const hipStream_t sb = Lb->s;
