@@ -24,7 +24,9 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
   # the timed steps alone under rocprofv3 (the line's extra records -- float64 boundary, raster sensitivity -- launch the same
   # kernels on other windows and would blur the per-kernel statistics): the line's HIP-event launch times and the profiler's
   # durations of the full-grid dispatches from ONE run on ONE box
-  ( cd /tmp && rm -rf /tmp/kst && MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_SENSITIVITY=1 MHS_BENCH_SKIP_FITTED=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o cfg3 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/tmp/kst.log )
+  # (MHS_RESERVE_KEEP=1: under the profiler, creating and destroying the CU-masked streams in every step -- what lifting the
+  # reservation does since this round -- made every kernel of the run 3 x slower; the streams are kept for this run only)
+  ( cd /tmp && rm -rf /tmp/kst && MHS_RESERVE_KEEP=1 MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_SENSITIVITY=1 MHS_BENCH_SKIP_FITTED=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o cfg3 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/tmp/kst.log )
   find /tmp/kst -name "*kernel_stats.csv" -exec cp {} $O/cfg3_steps_only_rocprofv3_kernel_stats.csv \;
   find /tmp/kst -name "*kernel_trace.csv" -exec cp {} /tmp/cfg3_kernel_trace.csv \;
   python tools/r06_launch_vs_rocprof.py $O/bench_under_rocprof.json $O/cfg3_steps_only_rocprofv3_kernel_stats.csv /tmp/cfg3_kernel_trace.csv > $O/cfg3_launch_vs_rocprof.json; cat $O/cfg3_launch_vs_rocprof.json

@@ -9,7 +9,7 @@ trace = {}
 if len(sys.argv) > 3:
     for r in csv.DictReader(open(sys.argv[3])):
         trace.setdefault(r["Kernel_Name"], []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
-out = {"source": "one run of `MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_SENSITIVITY=1 MHS_BENCH_SKIP_FITTED=1 rocprofv3 --kernel-trace --stats -- python bench.py "
+out = {"source": "one run of `MHS_RESERVE_KEEP=1 MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_SENSITIVITY=1 MHS_BENCH_SKIP_FITTED=1 rocprofv3 --kernel-trace --stats -- python bench.py "
                  "--steps 5 --warmup 1 --no-cpu-baseline` on one box: the timed steps (+ warm-up and the reservation calibration's steps) only",
        "ms_per_step": line.get("ms_per_step"), "value": line.get("value"), "kernels": []}
 for row in line.get("kernels", []):
