@@ -310,3 +310,24 @@ def test_cfg4_one_unit_full_size(hip):
         ref = cbind.tps_eval_grid(m, gf.xmin, gf.ymax, gf.xres, gf.yres, ro - fw[h][0], ro - fw[h][0] + 1, ic0 - fw[h][2], ic1 - fw[h][2], threads=8)
         got = hand["final_tps"][ro, ic0:ic1].cpu().numpy()
         assert np.abs(got - ref.ravel()).max() < 1e-9 * np.abs(ref).max(), ro
+
+
+def test_cfg3_reference_tiled_step3_batch_equals_lanes_on_1e8_cells(hip, monkeypatch):
+    """BASELINE config 3 with Step 3 the way the reference computes it at this size (7 x 7 tiles of 131-224 stations,
+    V73:656-897), full grid: the one-launch batch (round 6) against the tile-by-tile lane route of rounds 1-5 -- every tile's
+    spline agrees to 1e-10, hence the mosaicked and feathered surface; and the surface interpolates the smooth residual."""
+    import torch
+    from machisplin_amd import synth
+    g = synth.grid(10000, 10000)
+    xy, rows, cols, uv = synth.stations(g, 5000, synth.BASE_SEED + 3)
+    resid = synth.tps_residual(uv, synth.BASE_SEED + 3)
+    got = hip.tps_residual_surface(g, xy, resid, tile_edge=1500)
+    monkeypatch.setenv("MHS_TILES_BATCH", "0")
+    want = hip.tps_residual_surface(g, xy, resid, tile_edge=1500)
+    monkeypatch.delenv("MHS_TILES_BATCH")
+    assert bool(torch.isfinite(got).all())
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-10 * scale
+    # at the stations the smoothing spline stays within the noise of the residual (sd 0.1) of its data
+    at = got[torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy()
+    assert np.sqrt(np.mean((at - resid) ** 2)) < 0.15

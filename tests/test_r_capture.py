@@ -60,6 +60,11 @@ def test_hip_matches_fields(hip, name):
     fg = hip.Tps(z["xy"], z["y"])
     lam_r = _csv(f"{name}_gcv_scalars.csv")[0]
     assert abs(fg.lambda_ - lam_r) < 1e-6 * lam_r
+    # the batched route (round 6: one workgroup per spline; what the tiles of the reference's Step 3 take) against the same capture
+    fm = hip.tps.fit_many([z["xy"]], [z["y"]])[0]
+    assert abs(fm.lambda_ - lam_r) < 1e-6 * lam_r
+    fm_fixed = hip.tps.fit_many([z["xy"]], [z["y"]], lambda_=float(z["lam"]))[0]
+    assert np.abs(fm_fixed.c - _csv(f"{name}_fixed_c.csv")).max() < 1e-8 * np.abs(fm_fixed.c).max()
     for mode, fit in (("fixed", hip.Tps(z["xy"], z["y"], lambda_=float(z["lam"]))), ("gcv", hip.Tps(z["xy"], z["y"], lambda_=lam_r))):
         tag = f"{name}_{mode}"
         assert np.abs(fit.c - _csv(tag + "_c.csv")).max() < 1e-8 * np.abs(fit.c).max()
