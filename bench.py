@@ -581,12 +581,12 @@ class Workload:
         return torch.stack(allv).cpu().numpy()
 
     def model_check(self, allv, fit_ms, step_ms):
-        """Predicted step = max over ranks of (band [+ rank 0's fit]) + gather + whole-grid spline + Step 5, against
-        the observed step."""
+        """Predicted step = max over ranks of (band [+ rank 0's fit]) + the spline on the rank's own rows + the one all-gather of
+        the output plane + Step 5 (round 6's flow), against the observed step."""
         gather_bytes = self.run.band * self.geom.ncol * 8 * (self.world - 1)
         gather_ms = gather_bytes / 153e9 * 1e3 / max(1, min(7, self.world - 1))   # direct mesh: one xGMI link per peer
         pred0 = allv[0, 0] + fit_ms
-        pred = max(pred0, float(allv[1:, 0].max()) + gather_ms) + float(allv[:, 1].max()) + 3.0
+        pred = max(pred0, float(allv[1:, 0].max())) + float(allv[:, 1].max()) + gather_ms + 3.0
         return {"band_ms_per_rank": allv[:, 0].tolist(), "rows_per_rank": allv[:, 4].astype(int).tolist(),
                 "tps_eval_ms_per_rank": allv[:, 1].tolist(), "fit_ms_in_step_rank0": float(allv[0, 2]),
                 "fit_ms_standalone": fit_ms, "rank0_share": self.rank0_share,
@@ -1190,6 +1190,10 @@ def main():
     import torch.distributed as dist
     import machisplin_amd as mhs
 
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants GPU %d but this node shows %d device(s); one rank per GPU is the contract\n"
+                         % (rank, local, torch.cuda.device_count()))
+        sys.exit(3)
     torch.cuda.set_device(local)
     mhs.init(local)
     if world > 1:
