@@ -1773,6 +1773,8 @@ int mhs_model_free(mhs_model *m) {
     if (m->rf_depth) (void)hipFree(m->rf_depth);
     if (m->rf_dmin) (void)hipFree(m->rf_dmin);
     if (m->rf_coff) (void)hipFree(m->rf_coff);
+    if (m->rf_csub) (void)hipFree(m->rf_csub);
+    if (m->rf_clval) (void)hipFree(m->rf_clval);
     for (void *q : m->retired) (void)hipFree(q);
     delete m;
     return MHS_OK;

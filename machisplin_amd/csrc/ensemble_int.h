@@ -111,6 +111,9 @@ struct mhs_model {
     std::vector<int> rf_off;                 // host, n_trees + 1 node offsets
     int *rf_coff = nullptr;                  // device, n_trees + 1 record offsets of the COMPACT form
     int rf_cmax = 0;                         // COMPACT: most records in a tree (its split nodes + 1)
+    int *rf_csub = nullptr;                  // device, per COMPACT record: {split nodes in the subtree below it (itself included),
+                                             // first terminal of that subtree (terminals numbered in node order within the tree)}
+    double *rf_clval = nullptr;              // device, COMPACT: the terminals' predictions, tree after tree in that numbering
     int rf_compact_ok = 0;                   // every tree's leaf codes fit 16 bits (8 * splits + nodes <= 65535)
     // Several device slots (mhs_init_devices): the buffers above live on ONE device.  The handle remembers the loader
     // call that built it (with copies of its flat arrays) and the multi-device drivers build a replica per slot on
@@ -279,7 +282,8 @@ enum { RF_SMALL = 0, RF_BIG = 1, RF_COMPACT = 2 };   // forms of the randomFores
 
 // what a tree kernel launch reads of the geometry-dependent tables (a snapshot taken under the model's mutex)
 struct TreeTables { const void *sorted; const int *sorted_off; const int *lut_meta; const unsigned long long *rf_nodes; const int *rf_coff;
-                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; const int *axis_rank = nullptr; int axis_ncol = 0; };
+                    const double *lut_rt; const int *lut_rt_meta; const unsigned *lut_cls; const int *axis_rank = nullptr; int axis_ncol = 0;
+                    const int *rf_csub = nullptr; const double *rf_clval = nullptr; };
 
 // fresh device copy of a host table; the buffer it replaces is retired, not freed (kernels in flight may read it)
 template <typename T>

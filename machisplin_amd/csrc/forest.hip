@@ -1,6 +1,7 @@
 // randomForest on a grid window: the level-synchronous walk kernels (trees in LDS as key-space node records, a lane's
 // cells walking them in lock step) and the loader that numbers a forest's nodes for them -- predict.randomForest inside
 // terra::predict(rast_stack, mod.rf) of machisplin.mltps Step 2 (V73:447-619).  LDS-latency bound: see DESIGN.md section 4.
+#include <type_traits>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -892,8 +893,8 @@ __global__ __launch_bounds__(1024) void rf_walk_sub_kernel(const uint2 *__restri
     }
 }
 
-// rf_prefix_entries for the COMPACT records (split nodes only; a state is a split record's byte address or D + the index of a
-// terminal node, D = 8 x the tree's splits): entry state in the low 16 bits, levels descended above them.
+// rf_prefix_entries for the COMPACT records (split nodes only; a state is a split record's byte address or D + the number of a
+// terminal node among the tree's terminals, D = 8 x the tree's splits): entry state in the low 16 bits, levels descended above them.
 template <int R>
 __device__ __forceinline__ void rf_prefix_entries_compact(unsigned (&entry)[RF_ENTRY_BATCHES], const uint2 *__restrict__ gnodes,
                                                           const int *__restrict__ coff, int n_trees, int p, const char *smem,
@@ -948,7 +949,7 @@ __device__ __forceinline__ void rf_prefix_entries_compact(unsigned (&entry)[RF_E
 // (build_rf_nodes_t, RF_COMPACT): ~49 KB instead of 97 KB for such a tree, which leaves room for the keys of
 // 4 cells x 960 lanes (15 waves; the BIG form fits 2 x 1024 or 4 x 512 -- half the walks in flight, and this loop
 // is bound by the latency of its two dependent LDS reads).  A lane's state is the byte address of a split node's
-// record or, once it has reached a terminal, D + that node's index:
+// record or, once it has reached a terminal, D + that node's number among the tree's terminals:
 //       rec = LDS[min(state, D)];  child = key > rec.rank ? rec.right : rec.left;  state = max(child, state)
 // (children follow their parent in randomForest's numbering and every terminal code is >= D, so max() leaves a split
 // node's state to its child and a terminal's state alone: the all-zero record's children are 0).  The next tree's
@@ -996,14 +997,15 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
     }
     __syncthreads();
     // scalars of the trees ahead are fetched early, as in rf_walk_db_kernel
-    int o = tree_off[0], o1 = n_trees > 1 ? tree_off[1] : 0;
+    // o: the tree's first terminal in glval (the terminals' predictions, tree after tree: tree_off[t] - (coff[t] - t))
     int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
+    int o = tree_off[0] - c0, o1 = n_trees > 1 ? tree_off[1] - c1 + 1 : 0;
     int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
     int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
     for (int t = 0; t < n_trees; ++t) {
         const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
         const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
-        const int o2 = t + 2 < n_trees ? tree_off[t + 2] : 0;
+        const int o2 = t + 2 < n_trees ? tree_off[t + 2] - c2 + (t + 2) : 0;
         const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
         const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
         const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
@@ -1070,14 +1072,479 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
 }
 
 
+// BLOCK-SUBTREE form of the compact walk (round 6): the trees of a 20 000-station forest (~6 000 split records, 48 KB each)
+// no longer travel whole.  rf_walk_compact_kernel copies every tree into LDS for every block of 3 840 cells -- 2.5 TB past the
+// L2 per 4e8 cells and two barriers per tree, with every wave waiting for the block's deepest walk -- yet a block's cells are
+// neighbours and reach a sliver of each tree.  Here a block is 80 x 48 cells (TW x TH wave tiles of 16 x 16, a lane's 4 walks
+// on adjacent rows) and, after the rank keys are parked:
+//   1. BLOCK PREFIX, lane = tree: waves 0..7 descend 64 trees each from the root (records from global memory) for as long as
+//      the split falls the same way for the block's whole [min, max] rank of its predictor.  Where that ends is the block's
+//      entry into the tree: a terminal (every cell of the block gets that leaf: nothing to stage, nothing to walk) or a split
+//      record a, whose subtree is the n = csub[a] consecutive records [a, a + n) (nodes are numbered in pre-order).
+//   2. WAVE PREFIX: every wave goes on from the block's entries with its own, narrower ranges (as rf_prefix_entries_compact
+//      does from the root) -- its walks start there.
+//   3. The trees are taken in order, as many at a time as their subtrees (n + 1 records each: an all-zero record follows)
+//      fit in the LDS region beside the keys (64-aligned groups, lane = tree: one prefix sum places them).  The waves copy the
+//      subtrees in (64 records a turn, turns dealt round robin), meet at a barrier, and every wave walks the batch's trees
+//      by itself, in tree order -- no barrier, no waiting for another wave's deepest leaf -- until the next batch.
+// A staged subtree keeps its records as they are: child fields are byte addresses relative to the TREE, so a walk reads
+//       rec = LDS[min(state, Dz) + delta],   Dz = a + 8 n (the zero record),  delta = 8 * slot - a
+// and otherwise steps as the compact kernel does (state = max(child, state); terminal codes are >= D >= Dz).  A tree too rough
+// for its block (or MHS_RF_PLAIN) is a batch of its own, whole.  Same leaf for every cell, predictions added in tree order:
+// the planes are those of every other forest kernel, bit for bit (test_forest_walk_kernels_equal_each_other).
+constexpr int RF_CBS_BATCHES = 8;                                   // x 64 trees, held lane = tree in registers
+#ifdef RF_CBS_STATS
+__device__ unsigned long long g_cbs_stats[16];
+#define CBS_ADD(i, v) atomicAdd(&g_cbs_stats[i], (unsigned long long)(v))
+#define CBS_CLOCK() __builtin_readcyclecounter()
+#else
+#define CBS_ADD(i, v) ((void)0)
+#define CBS_CLOCK() 0ull
+#endif
+template <bool K64>
+__global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restrict__ gnodes, const double *__restrict__ glval,
+                                                           const int *__restrict__ tree_off, const int *__restrict__ coff,
+                                                           const int *__restrict__ csub, const int *__restrict__ depth,
+                                                           const void *__restrict__ sorted, const int *__restrict__ sorted_off,
+                                                           int n_trees, unsigned region_bytes, int p, StackDev s, PredGeom g,
+                                                           double weight, int accumulate, double *__restrict__ out,
+                                                           const int *__restrict__ dmin, const int *__restrict__ axis_rank,
+                                                           int axis_ncol, int tw, int th, int prefix, unsigned rough_slots) {
+    constexpr int R = 4, NB = RF_CBS_BATCHES, P = RF_PREFIX_MAX_P, PF = 8;
+    constexpr unsigned RANGES = 0u, TAB = 2048u;                    // 16 waves x 12 x (min, max); then {entry, records, first terminal} per tree
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *coarse = (float *)smem;
+    const int nw = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const unsigned stride = (unsigned)(p * R) | 1u;
+    const unsigned lane_base = region_bytes + threadIdx.x * stride * 4u;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    int row[R], col[R];
+    bool na[R], live[R];
+    [[maybe_unused]] const unsigned long long st_t0 = CBS_CLOCK();
+    [[maybe_unused]] unsigned long long st_stage = 0, st_walk = 0, st_levels = 0, st_term = 0;
+    {
+        const int tiles_x = (g.nc + 15) / 16, bx_n = (tiles_x + tw - 1) / tw;
+        const int by = (int)(blockIdx.x / (unsigned)bx_n), bx = (int)(blockIdx.x - (unsigned)by * (unsigned)bx_n);
+        const int tx = bx * tw + wave % tw;
+        const int64_t ty = (int64_t)by * th + wave / tw;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int64_t r = ty * (4 * R) + (lane >> 4) * R + c;
+            const int cc = tx * 16 + (lane & 15);
+            live[c] = r < g.nr && cc < g.nc;
+            row[c] = (int)min(r, (int64_t)g.nr - 1); col[c] = min(cc, g.nc - 1);
+            na[c] = false;
+        }
+    }
+    for (int j = 0; j < p; ++j) {
+        float r[R];
+        if (axis_rank && j >= s.C && !s.all_from_planes) {          // LONG / LAT: a function of the column / the row (publish_axis_ranks)
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+                r[c] = (float)(j == s.C ? axis_rank[g.c0 + col[c]] : axis_rank[(int64_t)axis_ncol + g.r0 + row[c]]);
+        } else if constexpr (K64) lut_ranks_t<R, 0, double>(j, (const double *)sorted, sorted_off, (double *)coarse, s, g, row, col, na, r);
+        else lut_ranks_t<R, 0, float>(j, (const float *)sorted, sorted_off, coarse, s, g, row, col, na, r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) *(unsigned *)(smem + lane_base + (unsigned)(j * R + c) * 4u) = (unsigned)r[c] << 8;
+    }
+    __syncthreads();                                               // the coarse table is no longer needed
+    // the wave's [min, max] rank of every predictor over its cells that are not NA -> LDS (lane 2v: min, 2v + 1: max)
+    {
+        int mine = lane & 1 ? -1 : 0x7fffffff;
+#pragma unroll
+        for (int v = 0; v < P; ++v) {
+            if (v < p) {
+                int a = 0x7fffffff, b = -1;
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+                    if (!na[c]) {
+                        const int rk = (int)(*(const unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) >> 8);
+                        a = min(a, rk); b = max(b, rk);
+                    }
+#pragma unroll
+                for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
+                // an NA cell's walk is thrown away, but it must stay inside the staged subtree: it takes the wave's smallest rank
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+                    if (na[c] && b >= 0) *(unsigned *)(smem + lane_base + (unsigned)(v * R + c) * 4u) = (unsigned)a << 8;
+                if (lane == 2 * v) mine = a;
+                if (lane == 2 * v + 1) mine = b;
+            }
+        }
+        if (lane < 2 * P) *(int *)(smem + RANGES + (unsigned)(wave * 2 * P + lane) * 4u) = mine;
+    }
+    __syncthreads();
+    // ranges of waves [w0, w1) merged, wave-uniform
+    auto ranges = [&](int w0, int w1, int (&lo_)[P], int (&hi_)[P]) {
+#pragma unroll
+        for (int v = 0; v < P; ++v) {
+            int a = 0x7fffffff, b = -1;
+            if (v < p && prefix && w0 + lane < w1) {
+                a = *(const int *)(smem + RANGES + (unsigned)((w0 + lane) * 2 * P + 2 * v) * 4u);
+                b = *(const int *)(smem + RANGES + (unsigned)((w0 + lane) * 2 * P + 2 * v + 1) * 4u);
+            }
+#pragma unroll
+            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
+            lo_[v] = __builtin_amdgcn_readfirstlane(a); hi_[v] = __builtin_amdgcn_readfirstlane(b);
+        }
+    };
+    // lane = tree: descend from `state` while the split falls the same way for every rank in [lo, hi] of its predictor
+    auto descend = [&](const int (&lo_)[P], const int (&hi_)[P], bool walking, int cb, unsigned D, unsigned &state, unsigned &plen) {
+        walking = walking && state < D;
+        while (__builtin_amdgcn_ballot_w64(walking)) {
+            if (walking) {
+                const uint2 rec = gnodes[cb + (int)(state >> 3)];
+                const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
+                int lo = lo_[0], hi = hi_[0];
+#pragma unroll
+                for (int q = 1; q < P; ++q) if (q < p && v == q) { lo = lo_[q]; hi = hi_[q]; }
+                if (lo > j) { state = rec.y >> 16; ++plen; }
+                else if (hi <= j) { state = rec.y & 0xFFFFu; ++plen; }
+                else walking = false;
+                if (state >= D) walking = false;
+            }
+        }
+    };
+    const int nbatch = (n_trees + 63) >> 6;
+    [[maybe_unused]] const unsigned long long st_t1 = CBS_CLOCK();
+    {   // 1. the block's entries
+        int lo_[P], hi_[P];
+        ranges(0, nw, lo_, hi_);
+        for (int b = wave; b < nbatch; b += nw) {
+            const int t = b * 64 + lane, tl = min(t, n_trees - 1);
+            const int cb = coff[tl];
+            const unsigned D = (unsigned)(coff[tl + 1] - cb - 1) * 8u;
+            unsigned state = 0u, plen = 0u;
+            if (prefix) descend(lo_, hi_, t < n_trees, cb, D, state, plen);
+            // the subtree below the entry: n split records from `state` on and n + 1 terminals from lf on; a terminal entry: itself
+            const int2 sub = (t < n_trees && state < D) ? *(const int2 *)(csub + 2 * (cb + (int)(state >> 3))) : make_int2(0, (int)(state - D));
+            if (t < n_trees) *(uint4 *)(smem + TAB + (unsigned)t * 16u) = make_uint4(state | (plen << 16), (unsigned)sub.x, (unsigned)sub.y, 0u);
+        }
+    }
+    __syncthreads();
+    [[maybe_unused]] const unsigned long long st_t2 = CBS_CLOCK();
+    unsigned entry[NB], bent[NB], bsz[NB];                          // bent: the block's entry | its first terminal << 16
+    {   // 2. the wave's entries
+        int lo_[P], hi_[P];
+        ranges(wave, wave + 1, lo_, hi_);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            entry[b] = 0u; bent[b] = 0u; bsz[b] = 0u;
+            if (b * 64 < n_trees) {
+                const int t = b * 64 + lane, tl = min(t, n_trees - 1);
+                const uint4 e = *(const uint4 *)(smem + TAB + (unsigned)tl * 16u);
+                const int cb = coff[tl];
+                const unsigned D = (unsigned)(coff[tl + 1] - cb - 1) * 8u;
+                unsigned state = e.x & 0xFFFFu, plen = e.x >> 16;
+                bent[b] = state | (e.z << 16); bsz[b] = e.y;
+                if (prefix) descend(lo_, hi_, t < n_trees, cb, D, state, plen);
+                entry[b] = state | (plen << 16);
+#ifdef RF_CBS_STATS
+                {   // the subtree below the WAVE's entry
+                    unsigned long long sl = t < n_trees ? (state < D ? 2ull * (unsigned)csub[2 * (cb + (int)(state >> 3))] + 2ull : 1ull) : 0ull;
+                    unsigned long long big = sl > 400, s64 = sl > 64, sbig = big ? sl : 0;
+                    for (int q = 32; q > 0; q >>= 1) { sl += __shfl_xor(sl, q); big += __shfl_xor(big, q); s64 += __shfl_xor(s64, q); sbig += __shfl_xor(sbig, q); }
+                    if (lane == 0) { CBS_ADD(14, sl - sbig); CBS_ADD(15, big); }
+                }
+#endif
+            }
+        }
+    }
+    [[maybe_unused]] const unsigned long long st_t3 = CBS_CLOCK();
+#ifdef RF_CBS_STATS
+    if (wave == 0) {
+        unsigned long long sl = 0, nz = 0, pb = 0, pw = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) if (b * 64 + lane < n_trees) { sl += bsz[b] ? 2 * bsz[b] + 2 : 1; nz += bsz[b] == 0; pw += entry[b] >> 16; }
+        for (int q = 32; q > 0; q >>= 1) { sl += __shfl_xor(sl, q); nz += __shfl_xor(nz, q); pw += __shfl_xor(pw, q); }
+        if (lane == 0) { CBS_ADD(0, 1); CBS_ADD(1, sl); CBS_ADD(3, nz); CBS_ADD(7, pw); }
+        (void)pb;
+    }
+#endif
+    // slots (8-byte words) the region holds -- and no more than the waves fetch in one turn (256 16-byte units each, less the
+    // ragged ends of 64 trees' ranges)
+    const unsigned cap = min(region_bytes >> 3, 512u * (unsigned)nw - 256u);
+    double acc[R], pending[R];
+    unsigned node[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) { acc[c] = 0.0; pending[c] = 0.0; }
+    // A ROUGH block -- its subtrees average more than rough_slots LDS slots a tree: noisy rasters, MHS_RF_PLAIN -- gains nothing
+    // from batches of one or two trees and takes rf_walk_compact_kernel's loop instead: whole trees, the next one travelling
+    // through registers while this one is walked (same region, same keys, the waves' entries as computed above).
+    unsigned tot = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) if (b * 64 + lane < n_trees) tot += bsz[b] ? 2u * bsz[b] + 4u : 2u;
+#pragma unroll
+    for (int q = 32; q > 0; q >>= 1) tot += (unsigned)__shfl_xor((int)tot, q);
+    if (__builtin_amdgcn_readfirstlane((int)tot) > rough_slots * (unsigned)n_trees) {
+        const unsigned nt = blockDim.x;
+        __syncthreads();                                           // the prefixes' tables are no longer needed
+        {
+            const int o = coff[0], cnt = coff[1] - o;
+            for (int e = threadIdx.x; e < cnt; e += (int)nt) ((uint2 *)smem)[e] = gnodes[o + e];
+        }
+        __syncthreads();
+        int c0 = coff[0], c1 = coff[1], c2 = n_trees > 1 ? coff[2] : c1;
+        int o = tree_off[0] - c0, o1 = n_trees > 1 ? tree_off[1] - c1 + 1 : 0;
+        int levels = depth[0], levels1 = n_trees > 1 ? depth[1] : 0;
+        int shallow = dmin ? dmin[0] : levels, shallow1 = n_trees > 1 ? (dmin ? dmin[1] : levels1) : 0;
+        unsigned ecur = 0u;
+        for (int t = 0; t < n_trees; ++t) {
+            const int cnt1 = t + 1 < n_trees ? c2 - c1 : 0;
+            const int c3 = t + 3 <= n_trees ? coff[t + 3] : c2;
+            const int o2 = t + 2 < n_trees ? tree_off[t + 2] - c2 + (t + 2) : 0;
+            const int levels2 = t + 2 < n_trees ? depth[t + 2] : 0;
+            const int shallow2 = t + 2 < n_trees ? (dmin ? dmin[t + 2] : levels2) : 0;
+            const unsigned D = (unsigned)(c1 - c0 - 1) * 8u;
+            uint2 pn[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = (int)threadIdx.x + q * (int)nt;
+                if (e < cnt1) pn[q] = gnodes[c1 + e];
+            }
+            if ((t & 63) == 0) {
+                ecur = 0u;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) if ((t >> 6) == b) ecur = entry[b];
+            }
+            const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, t & 63);
+            const int plen = (int)(ent >> 16);
+            const int lev = (ent & 0xFFFFu) >= D ? 0 : levels - plen, shal = min(max(shallow - plen, 0), lev);
+#pragma unroll
+            for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
+            auto level = [&]() {
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const uint2v nd = lds_u2(min(node[c], D));
+                    const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                    unsigned child;
+                    asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                        : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                    node[c] = max(child, node[c]);
+                }
+            };
+            for (int l = 0; l < shal; ++l) level();
+            for (int l = shal; l < lev; ++l) {
+                const unsigned lowest = min(min(node[0], node[1]), min(node[2], node[3]));
+                if (!__builtin_amdgcn_ballot_w64(lowest < D)) break;
+                level();
+            }
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                acc[c] = acc[c] + pending[c];
+                pending[c] = glval[o + (int)(node[c] - D)];
+            }
+            __syncthreads();                                       // every wave has left this tree
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = (int)threadIdx.x + q * (int)nt;
+                if (e < cnt1) *(uint2 *)(smem + (unsigned)e * 8u) = pn[q];
+            }
+            __syncthreads();
+            o = o1; o1 = o2;
+            c0 = c1; c1 = c2; c2 = c3;
+            levels = levels1; levels1 = levels2;
+            shallow = shallow1; shallow1 = shallow2;
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            acc[c] = acc[c] + pending[c];
+            if (live[c])
+                emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+        }
+        return;
+    }
+    // Per tree of a batch, wave-uniform: where its ranges go.  Records: global words [gr, gr + n) + one word that is stored as
+    // zeros (the zero record) -> LDS slots [sr, sr + n]; predictions: global words [gv, gv + m) -> slots [sv, sv + m).  A range sits
+    // at the parity of its global word index, so it travels in 16-byte units (ragged ends: the valid half alone).
+    struct Place { unsigned n, a, gr, gv, m, sr, sv, ur, uv; };
+    auto place = [&](unsigned n, unsigned a, unsigned base, unsigned cb, unsigned gv) {
+        Place P;
+        P.n = n; P.a = a; P.gr = cb + (a >> 3); P.gv = gv;
+        P.m = 2u * n + 4u <= cap ? (n ? n + 1u : 1u) : 0u;
+        P.sr = base + ((base ^ P.gr) & 1u);
+        P.sv = n ? P.sr + n + 1u : base;
+        P.sv += (P.sv ^ gv) & 1u;
+        P.ur = n ? ((P.gr + n + 2u) >> 1) - (P.gr >> 1) : 0u;
+        P.uv = P.m ? ((gv + P.m + 1u) >> 1) - (gv >> 1) : 0u;
+        return P;
+    };
+#pragma nounroll
+    for (int b = 0; b < nbatch; ++b) {
+        unsigned ecur = 0u, acur = 0u, ncur = 0u, fcur = 0u;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) if (q == b) { ecur = entry[q]; acur = bent[q] & 0xFFFFu; ncur = bsz[q]; fcur = bent[q] >> 16; }
+        const int tl = min(b * 64 + lane, n_trees - 1);
+        const int cbv = coff[tl];
+        const int ov = tree_off[tl] - cbv + tl + (int)fcur;        // the subtree's first terminal in glval
+        const unsigned Dv = (unsigned)(coff[tl + 1] - cbv - 1) * 8u;
+        const int levv = depth[tl], shv = dmin ? dmin[tl] : levv;
+        // LDS slots of a tree: n records, the zero record, n + 1 predictions (+ a slot before each range for its parity); a
+        // terminal entry: its prediction alone; a subtree too large for that -- a whole tree, MHS_RF_PLAIN -- leaves its
+        // predictions in global memory
+        const unsigned slots = !ncur ? 2u : 2u * ncur + 4u <= cap ? 2u * ncur + 4u : ncur + 2u;
+        const int lend = min(64, n_trees - b * 64);
+        // the batch from tree l0 on: the trees [l0, l1) whose ranges fit the region together, and where each goes
+        auto plan = [&](int l0, unsigned &basev) {
+            unsigned cum = lane >= l0 ? slots : 0u;
+#pragma unroll
+            for (int q = 1; q < 64; q <<= 1) { const unsigned up = (unsigned)__shfl_up((int)cum, q); if (lane >= q) cum += up; }
+            const unsigned long long fit = __builtin_amdgcn_ballot_w64(lane >= l0 && lane < lend && cum <= cap);
+            basev = cum - slots;
+            return l0 + max(1, (int)__builtin_popcountll(fit));
+        };
+        // this wave's share of a batch's 16-byte units (the batch's ranges end to end, 256 units a wave, 4 a lane): requested
+        // here, parked in LDS by park() -- a batch is fetched while the batch before it is walked
+        uint4 w[4];
+        unsigned waddr[4], wflag = 0u;                              // per unit: LDS byte address; bits 4q..4q+3: lo, hi valid, lo, hi zero
+        auto fetch = [&](int l0, int l1, unsigned basev) {
+            const unsigned x0 = 256u * (unsigned)wave;
+            unsigned ustart = 0u, wsrc[4] = {0u, 0u, 0u, 0u};      // the unit's index in its array; bit 31: the predictions
+            wflag = 0u;
+            for (int l = l0; l < l1; ++l) {
+                const Place P = place((unsigned)__builtin_amdgcn_readlane((int)ncur, l), (unsigned)__builtin_amdgcn_readlane((int)acur, l),
+                                      (unsigned)__builtin_amdgcn_readlane((int)basev, l), (unsigned)__builtin_amdgcn_readlane(cbv, l),
+                                      (unsigned)__builtin_amdgcn_readlane(ov, l));
+                const unsigned un = P.ur + P.uv;
+                if (ustart + un > x0 && ustart < x0 + 256u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned rel = x0 + (unsigned)(q * 64 + lane) - ustart;
+                        if (rel < un) {
+                            const bool isrec = rel < P.ur;
+                            const unsigned g0 = isrec ? P.gr : P.gv, cnt = isrec ? P.n + 1u : P.m, s0 = isrec ? P.sr : P.sv;
+                            const unsigned u = (g0 >> 1) + (isrec ? rel : rel - P.ur), w0 = 2u * u;
+                            const unsigned lo = w0 >= g0 && w0 < g0 + cnt, hi = w0 + 1u >= g0 && w0 + 1u < g0 + cnt;
+                            const unsigned zlo = isrec && w0 == P.gr + P.n, zhi = isrec && w0 + 1u == P.gr + P.n;
+                            waddr[q] = (s0 + w0 - g0) * 8u;
+                            wflag |= (lo | (hi << 1) | (zlo << 2) | (zhi << 3)) << (4 * q);
+                            wsrc[q] = u | (isrec ? 0u : 0x80000000u);
+                        }
+                    }
+                }
+                ustart += un;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                             // all requests together, nothing waits for them here
+                if ((wflag >> (4 * q)) & 3u) {
+                    const uint4 *src = wsrc[q] >> 31 ? (const uint4 *)glval : (const uint4 *)gnodes;
+                    w[q] = src[wsrc[q] & 0x7FFFFFFFu];
+                }
+        };
+        auto park = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned f = (wflag >> (4 * q)) & 15u;
+                if (f & 3u) {
+                    uint4 d = w[q];
+                    if (f & 4u) { d.x = 0u; d.y = 0u; }
+                    if (f & 8u) { d.z = 0u; d.w = 0u; }
+                    if ((f & 3u) == 3u) *(uint4 *)(smem + waddr[q]) = d;
+                    else if (f & 1u) *(uint2 *)(smem + waddr[q]) = make_uint2(d.x, d.y);
+                    else *(uint2 *)(smem + waddr[q] + 8u) = make_uint2(d.z, d.w);
+                }
+            }
+        };
+        int l0 = 0;
+        unsigned basev = 0u, basen = 0u;
+        int l1 = plan(l0, basev);
+        fetch(l0, l1, basev);                                       // the group's first batch: nothing to walk meanwhile
+        while (l0 < lend) {
+            [[maybe_unused]] const unsigned long long st_a = CBS_CLOCK();
+            __syncthreads();                                       // every wave has left the region's previous trees
+            park();
+            __syncthreads();
+            [[maybe_unused]] const unsigned long long st_b = CBS_CLOCK();
+            st_stage += st_b - st_a;
+            if (wave == 0 && lane == 0) CBS_ADD(2, 1);
+            int l2 = l1;
+            if (l1 < lend) { l2 = plan(l1, basen); fetch(l1, l2, basen); }      // the next batch travels while this one is walked
+            // (two copies of the walk: the one for batches whose predictions are all in LDS holds no global load, so nothing in it
+            // waits for the batch that is on its way)
+            auto walk = [&](int l, auto all_in_lds) {
+                const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, l);
+                const Place P = place((unsigned)__builtin_amdgcn_readlane((int)ncur, l), (unsigned)__builtin_amdgcn_readlane((int)acur, l),
+                                      (unsigned)__builtin_amdgcn_readlane((int)basev, l), (unsigned)__builtin_amdgcn_readlane(cbv, l),
+                                      (unsigned)__builtin_amdgcn_readlane(ov, l));
+                const unsigned D = (unsigned)__builtin_amdgcn_readlane((int)Dv, l);
+                const unsigned lf = (unsigned)__builtin_amdgcn_readlane((int)fcur, l);
+                const int levels = __builtin_amdgcn_readlane(levv, l), shallow = __builtin_amdgcn_readlane(shv, l);
+                const unsigned Dz = P.n ? P.a + 8u * P.n : 0u, delta = 8u * P.sr - P.a;
+                // a terminal code c = D + the terminal's number: its prediction sits at LDS word sv + (number - lf)
+                const unsigned vbase = 8u * P.sv - 8u * (D + lf);
+                const int plen = (int)(ent >> 16);
+                const int lev = (ent & 0xFFFFu) >= Dz ? 0 : levels - plen, shal = min(max(shallow - plen, 0), lev);
+#pragma unroll
+                for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
+                auto level = [&]() {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const uint2v nd = lds_u2(min(node[c], Dz) + delta);
+                        const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
+                        unsigned child;
+                        asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+                            : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                        node[c] = max(child, node[c]);
+                    }
+                };
+                st_term += lev == 0;
+                for (int q = 0; q < shal; ++q) { level(); ++st_levels; }
+                for (int q = shal; q < lev; ++q) {
+                    const unsigned lowest = min(min(node[0], node[1]), min(node[2], node[3]));
+                    if (!__builtin_amdgcn_ballot_w64(lowest < Dz)) break;
+                    level(); ++st_levels;
+                }
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    acc[c] = acc[c] + pending[c];
+                    if (decltype(all_in_lds)::value || P.m) pending[c] = lds_f64(vbase + 8u * node[c]);
+                    else pending[c] = glval[P.gv + (node[c] - D - lf)];
+                }
+            };
+            if (!__builtin_amdgcn_ballot_w64(lane >= l0 && lane < l1 && ncur && 2u * ncur + 4u > cap))
+                for (int l = l0; l < l1; ++l) walk(l, std::true_type());
+            else
+                for (int l = l0; l < l1; ++l) walk(l, std::false_type());
+            st_walk += CBS_CLOCK() - st_b;
+            l0 = l1; l1 = l2; basev = basen;
+        }
+    }
+#ifdef RF_CBS_STATS
+    if (lane == 0) {
+        CBS_ADD(4, st_levels); CBS_ADD(5, st_term); CBS_ADD(6, 1);
+        CBS_ADD(8, st_t1 - st_t0); CBS_ADD(9, st_t2 - st_t1); CBS_ADD(10, st_t3 - st_t2); CBS_ADD(11, st_stage); CBS_ADD(12, st_walk);
+        CBS_ADD(13, CBS_CLOCK() - st_t0);
+    }
+#endif
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+        acc[c] = acc[c] + pending[c];
+        if (live[c])
+            emit(out, (int64_t)row[c] * g.ld_out + col[c], na[c] ? NAN : acc[c] / (double)n_trees, weight, accumulate);
+    }
+}
+#ifdef RF_CBS_STATS
+extern "C" __attribute__((visibility("default"))) int mhs_debug_cbs_stats(unsigned long long *out16) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cbs_stats), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cbs_stats), z, sizeof(z)) != hipSuccess;
+}
+#endif
+
+
 // MHS_RF_KERNEL = ld | db | compact pins one of the three forest walk kernels where it applies (the equality tests and the
 // benchmarks' comparisons); unset: the loader-wave kernel, else the double-buffered one, else the split-node one, else the
 // generic node walk.  MHS_RF_PLAIN=1: no wave-uniform prefix and every tree to its full depth (the walk as round 2 had it).
-enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT, RF_PICK_SUB };
+enum { RF_PICK_AUTO = 0, RF_PICK_LD, RF_PICK_DB, RF_PICK_COMPACT, RF_PICK_SUB, RF_PICK_CBS };
 static int rf_pick() {
     const char *e = getenv("MHS_RF_KERNEL");
     if (!e) return RF_PICK_AUTO;
-    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : !strcmp(e, "sub") ? RF_PICK_SUB : RF_PICK_AUTO;
+    return !strcmp(e, "ld") ? RF_PICK_LD : !strcmp(e, "db") ? RF_PICK_DB : !strcmp(e, "compact") ? RF_PICK_COMPACT : !strcmp(e, "sub") ? RF_PICK_SUB
+         : !strcmp(e, "cbs") ? RF_PICK_CBS : RF_PICK_AUTO;
 }
 static bool rf_plain() { return getenv("MHS_RF_PLAIN") != nullptr; }
 
@@ -1133,18 +1600,39 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
     const unsigned R = (unsigned)rf_walks(log2r);
     if (form == RF_COMPACT) {
         // Records of the SPLIT nodes only, in node order, then one all-zero record at byte address D = 8 * splits.
-        // A child field holds the LDS byte address of a split child's record or, for a terminal child, D + its node
-        // index: the walk reads record min(state, D), picks the child field and keeps max(child, state) -- a split
-        // node's children come after it and every terminal code is >= D, so a terminal state stays what it is.
+        // A child field holds the LDS byte address of a split child's record or, for a terminal child, D + its number
+        // among the tree's terminals (node order): the walk reads record min(state, D), picks the child field and keeps
+        // max(child, state) -- a split node's children come after it and every terminal code is >= D, so a terminal state
+        // stays what it is.  clval holds the terminals' predictions in that numbering, tree after tree (tree t's first:
+        // tree_off[t] - (coff[t] - t), its nodes less its split nodes before it).
         rec.clear();
-        std::vector<int> coff(1, 0), newid;
+        // csub: per record, the split nodes in the subtree below it (itself included) and that subtree's first terminal.
+        // mhs_rf_load numbers nodes in pre-order, so the subtree of node k is the node range [k, end(k)): its split records are
+        // consecutive, and so are its terminals (rf_walk_cbs_kernel stages both ranges).
+        std::vector<int> coff(1, 0), newid, csub, before, end;
+        std::vector<double> clval;
         for (int t = 0; t < m->n_trees; ++t) {
             const int o = m->rf_off[(size_t)t], cnt = m->rf_off[(size_t)t + 1] - o;
             newid.assign((size_t)cnt, 0);
+            before.assign((size_t)cnt + 1, 0);
+            end.assign((size_t)cnt, 0);
             unsigned splits = 0;
-            for (int k = 0; k < cnt; ++k) if (m->rf_var[(size_t)(o + k)] != 0xFFFFu) newid[(size_t)k] = (int)splits++;
+            for (int k = 0; k < cnt; ++k) {
+                before[(size_t)k] = (int)splits;
+                if (m->rf_var[(size_t)(o + k)] != 0xFFFFu) newid[(size_t)k] = (int)splits++;
+                else clval.push_back(m->rf_thr[(size_t)(o + k)]);       // a terminal's rf_thr is its prediction (mhs_rf_load)
+            }
+            before[(size_t)cnt] = (int)splits;
+            for (int k = cnt - 1; k >= 0; --k)
+                end[(size_t)k] = m->rf_var[(size_t)(o + k)] == 0xFFFFu ? k + 1 : end[(size_t)m->rf_right[(size_t)(o + k)]];
+            for (int k = 0; k < cnt; ++k)
+                if (m->rf_var[(size_t)(o + k)] != 0xFFFFu) {
+                    csub.push_back(before[(size_t)end[(size_t)k]] - before[(size_t)k]);
+                    csub.push_back(k - before[(size_t)k]);
+                }
+            csub.push_back(0); csub.push_back(0);
             const unsigned D = 8u * splits;
-            auto code = [&](unsigned k) { return m->rf_var[(size_t)o + k] != 0xFFFFu ? 8u * (unsigned)newid[k] : D + k; };
+            auto code = [&](unsigned k) { return m->rf_var[(size_t)o + k] != 0xFFFFu ? 8u * (unsigned)newid[k] : D + (k - (unsigned)before[k]); };
             for (int k = 0; k < cnt; ++k) {
                 const unsigned v = m->rf_var[(size_t)(o + k)];
                 if (v == 0xFFFFu) continue;
@@ -1157,7 +1645,11 @@ static int build_rf_nodes_t(mhs_model *m, const mhs_grid &grid, int C, int log2r
             rec.push_back(0ull);
             coff.push_back((int)rec.size());
         }
+        rec.push_back(0ull); rec.push_back(0ull);                 // rf_walk_cbs_kernel reads 16-byte units: one word past a range's end
+        clval.push_back(0.0); clval.push_back(0.0);
         if (int rc = publish(m, coff, &m->rf_coff)) return rc;
+        if (int rc = publish(m, clval, &m->rf_clval)) return rc;
+        if (int rc = publish(m, csub, &m->rf_csub)) return rc;
     } else
     for (size_t k = 0; k < nn; ++k) {
         const unsigned v = m->rf_var[k];
@@ -1188,7 +1680,7 @@ static int build_rf_nodes(mhs_model *m, const mhs_grid &grid, int C, int log2r, 
         m->rf_log2r = log2r; m->rf_form = form;
     }
     *tt = TreeTables{m->lut_sorted, m->lut_sorted_off, nullptr, m->rf_nodes, form == RF_COMPACT ? m->rf_coff : nullptr, nullptr, nullptr, nullptr,
-                     m->axis_rank, m->axis_ncol};
+                     m->axis_rank, m->axis_ncol, form == RF_COMPACT ? m->rf_csub : nullptr, form == RF_COMPACT ? m->rf_clval : nullptr};
     return MHS_OK;
 }
 
@@ -1295,21 +1787,71 @@ static int launch_rf_compact(const mhs_model *m, const StackDev &s, const PredGe
     auto k = pf4 ? (key64 ? rf_walk_compact_kernel<4, true> : rf_walk_compact_kernel<4, false>)
                  : (key64 ? rf_walk_compact_kernel<8, true> : rf_walk_compact_kernel<8, false>);
     MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, m->rf_lval, m->tree_off, tt.rf_coff,
+    hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, tt.rf_clval, m->tree_off, tt.rf_coff,
                        m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, m->rf_cmax, m->p, s, g, w, acc, out, dmin, strips,
                        strips && dmin);
     return MHS_OK;
 }
 
 
+// rf_walk_cbs_kernel: threads and wave tiles (across x down) of a block, and the bytes of LDS left for subtrees beside the keys;
+// false = does not apply (the compact form's own limits, more predictors or trees than the prefixes hold, a window too low for tiles)
+static bool rf_cbs_config(const mhs_model *m, const PredGeom &g, int *nt, int *tw, int *th, unsigned *region) {
+    if (!m->rf_compact_ok || m->p * 16 > 255 || m->p > RF_PREFIX_MAX_P || m->n_trees > 64 * RF_CBS_BATCHES || !rf_strips(g, 4)) return false;
+    const size_t per_lane = (((size_t)m->p * 4) | 1) * 4;
+    const size_t need = std::max(((size_t)m->rf_cmax + 1) * 8, (size_t)RF_COARSE_BYTES);     // a whole tree's records + the parity slot
+    static const int shapes[][3] = {{1024, 4, 4}, {960, 5, 3}, {768, 4, 3}, {640, 5, 2}, {512, 4, 2}};
+    for (const auto &sh : shapes) {
+        if ((size_t)sh[0] * per_lane + need > LDS_MAX || need > ((size_t)sh[0] * 8 - 256) * 8) continue;   // ... and within one fetch turn
+        if ((size_t)sh[0] * 8 < (size_t)m->rf_cmax) continue;     // the whole-tree loop: 8 records a thread
+        *nt = sh[0]; *tw = sh[1]; *th = sh[2];
+        *region = (unsigned)((LDS_MAX - (size_t)sh[0] * per_lane) & ~(size_t)7);
+        return true;
+    }
+    return false;
+}
+
+static int launch_rf_cbs(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid &grid,
+                         double w, int acc, double *out, hipStream_t st, int nt, int tw, int th, unsigned region) {
+    const int key64 = s.dtype == MHS_F64;
+    TreeTables tt;
+    if (int rc = build_rf_nodes(const_cast<mhs_model *>(m), grid, s.C, 2, RF_COMPACT, key64, &tt)) return rc;
+    const size_t bytes = (size_t)region + (size_t)nt * (((size_t)m->p * 4) | 1) * 4;
+    const int64_t tiles_x = (g.nc + 15) / 16, tiles_y = ((int64_t)g.nr + 15) / 16;
+    const unsigned blocks = (unsigned)(((tiles_x + tw - 1) / tw) * ((tiles_y + th - 1) / th));
+    const int *dmin = rf_plain() ? nullptr : m->rf_dmin;
+    // blocks whose subtrees average more LDS slots than this take the whole-tree loop (MHS_RF_CBS_ROUGH: the measurements' knob)
+    const char *re = getenv("MHS_RF_CBS_ROUGH");
+    const unsigned rough = re ? (unsigned)atoi(re) : 3000u;
+    auto k = key64 ? rf_walk_cbs_kernel<true> : rf_walk_cbs_kernel<false>;
+    MHS_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3((unsigned)nt), bytes, st, (const uint2 *)tt.rf_nodes, tt.rf_clval, m->tree_off, tt.rf_coff,
+                       tt.rf_csub, m->rf_depth, tt.sorted, tt.sorted_off, m->n_trees, region, m->p, s, g, w, acc, out, dmin,
+                       tt.axis_rank, tt.axis_ncol, tw, th, (int)(dmin != nullptr), rough);
+    return MHS_OK;
+}
+
 int launch_forest(const mhs_model *m, const StackDev &s, const PredGeom &g, const mhs_grid *grid, double weight, int accumulate,
                   double *out, hipStream_t st, int64_t total, bool *launched) {
     *launched = false;
     if (!(grid && m->rf_fast && !s.all_from_planes && !getenv("MHS_TREES_GENERIC"))) return MHS_OK;
-    if (rf_pick() != RF_PICK_COMPACT)
+    const int pick = rf_pick();
+    int cnt = 0, ctw = 0, cth = 0;
+    unsigned cregion = 0;
+    if (pick == RF_PICK_CBS && rf_cbs_config(m, g, &cnt, &ctw, &cth, &cregion)) {      // pinned: whatever the trees' size
+        if (int rc = launch_rf_cbs(m, s, g, *grid, weight, accumulate, out, st, cnt, ctw, cth, cregion)) return rc;
+        *launched = true;
+        return MHS_OK;
+    }
+    if (pick != RF_PICK_COMPACT)
         if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, launched)) return rc;
     if (*launched) return MHS_OK;
-    const int nt = rf_compact_threads(m);      // trees beyond 4 095 nodes: split nodes only in LDS
+    if (pick != RF_PICK_COMPACT && rf_cbs_config(m, g, &cnt, &ctw, &cth, &cregion)) {   // trees beyond 4 095 nodes: the block's subtrees
+        if (int rc = launch_rf_cbs(m, s, g, *grid, weight, accumulate, out, st, cnt, ctw, cth, cregion)) return rc;
+        *launched = true;
+        return MHS_OK;
+    }
+    const int nt = rf_compact_threads(m);      // ... or whole trees, split nodes only
     if (nt > 0) {
         if (int rc = launch_rf_compact(m, s, g, *grid, weight, accumulate, out, st, total, nt)) return rc;
         *launched = true;

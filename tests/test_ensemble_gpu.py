@@ -411,7 +411,9 @@ def test_forest_walk_kernels_equal_each_other_and_the_node_walk(hip, n, dtype, n
     m = hip.models.from_param_dict(prm)
     fast = hip.predict(stack, m)
     for envs in ({"MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "sub"}, {"MHS_RF_KERNEL": "sub", "MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "db"}, {"MHS_RF_KERNEL": "db", "MHS_RF_PLAIN": "1"},
-                 {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_KERNEL": "compact", "MHS_RF_PLAIN": "1"}, {"MHS_TREES_GENERIC": "1"}):
+                 {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_KERNEL": "compact", "MHS_RF_PLAIN": "1"},
+                 {"MHS_RF_KERNEL": "cbs"}, {"MHS_RF_KERNEL": "cbs", "MHS_RF_PLAIN": "1"}, {"MHS_RF_KERNEL": "cbs", "MHS_RF_CBS_ROUGH": "0"},
+                 {"MHS_RF_KERNEL": "cbs", "MHS_RF_CBS_ROUGH": "1000000"}, {"MHS_TREES_GENERIC": "1"}):
         for e, v in envs.items():
             monkeypatch.setenv(e, v)
         other = hip.predict(stack, m)
@@ -471,7 +473,9 @@ def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_forest_in_the_compact_form_equals_the_node_walk(hip, dtype):
     """Trees of ~7 000 nodes (12 000 stations): beyond the double-buffered kernel's 4 095, within the COMPACT form
-    (split nodes only in LDS, terminals as codes).  Same leaves in the same order as the node walk and the oracle."""
+    (split nodes only in LDS, terminals as codes): by default the block-subtree kernel (rf_walk_cbs_kernel: per block of 80 x 48
+    cells only the subtrees its cells can reach are staged, several trees at a time), pinned the whole-tree kernel
+    (MHS_RF_KERNEL=compact).  Same leaves in the same order as the node walk and the oracle."""
     from machisplin_amd import synth
     g, stack, X, Xs, ys, params = _setup(hip, nrow=200, ncol=300, C=5, n=12000, gbm_trees=2, rf_trees=1, nodata_frac=0.01, dtype=dtype)
     prm = synth.rf_params(Xs, ys, 6, n_trees=5)
@@ -482,15 +486,19 @@ def test_forest_in_the_compact_form_equals_the_node_walk(hip, dtype):
     want = oe.predict(prm, X)
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
-    for envs in (("MHS_RF_PLAIN",), ("MHS_TREES_GENERIC",)):
-        for e in envs:
-            os.environ[e] = "1"
+    # MHS_RF_CBS_ROUGH: the LDS slots per tree above which a block takes whole trees -- 0: every block does, 1000000: none
+    for envs in ({"MHS_RF_PLAIN": "1"}, {"MHS_TREES_GENERIC": "1"}, {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_KERNEL": "compact", "MHS_RF_PLAIN": "1"},
+                 {"MHS_RF_CBS_ROUGH": "0"}, {"MHS_RF_CBS_ROUGH": "1000000"}, {"MHS_RF_CBS_ROUGH": "1000000", "MHS_RF_PLAIN": "1"}):
+        os.environ.update(envs)
         try:
             other = hip.predict(stack, model).cpu().numpy().ravel()
         finally:
             for e in envs:
                 del os.environ[e]
         assert np.array_equal(got, other, equal_nan=True), envs
+    # a window that starts inside a wave tile and is narrower than a block of tiles: same cells
+    win = hip.predict(stack, model, window=(37, 150, 21, 94)).cpu().numpy()
+    assert np.array_equal(win, got.reshape(200, 300)[37:150, 21:94], equal_nan=True)
 
 
 @pytest.mark.parametrize("C,dtype", [(1, "f32"), (3, "f64"), (5, "f32"), (9, "i16")])
