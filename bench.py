@@ -317,9 +317,14 @@ class Workload:
                 levels = full * min(1.0, walked_share)
                 cyc = band_cells * levels / 64.0 * 4.0
                 tb = not big and int(np.diff(prm["tree_offsets"]).max()) * 8 <= 25600      # rf_walk_ld_config (forest.hip)
-                rows.append({"kernel": "rf_walk_compact_kernel" if big else "rf_walk_ld_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
+                rows.append({"kernel": "rf_walk_cbs_kernel" if big else "rf_walk_ld_kernel" if tb else "rf_walk_db_kernel", "bound": "lds", "launch_ms": ms,
                              "achieved": cyc / ms / 1e6, "peak": LDS_CYCLE_PEAK_G, "unit": "G LDS-cycles/s",
-                             "work": "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "
+                             "frac_is_upper_reading": bool(big),
+                             "work": ("trees beyond 4 095 nodes: the block-subtree kernel (round 6) -- no PMC pass on it, so the figure prices every tree "
+                                      "at its FULL depth, which the kernel does not walk (tools/r06_forest_stats.py on a forest of this shape and the 8d "
+                                      "planes: 11 levels a tree skipped above the wave's entry, 2 - 4 walked below it): an upper reading, not a utilisation.  "
+                                      if big else "") +
+                                     "4 conflict-free LDS-array cycles per wave, tree level WALKED and walk (ds_read_b64 node + ds_read_b32 key): "
                                      "%.0f levels/cell walked (a wave of neighbouring cells starts a tree where its cells part ways and leaves it at its deepest leaf; "
                                      "share of the full depth from SQ_INSTS_LDS / 2 in %s -- measured on those rasters, not in this run) "
                                      "of %d levels/cell of full tree depth; %.0f node visits/cell on the reference's walk, %.3g visits/s" % (

@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
                                                            const int *__restrict__ dmin, const int *__restrict__ axis_rank,
                                                            int axis_ncol, int tw, int th, int prefix, unsigned rough_slots) {
     constexpr int R = 4, NB = RF_CBS_BATCHES, P = RF_PREFIX_MAX_P, PF = 8;
-    constexpr unsigned RANGES = 0u, TAB = 2048u;                    // 16 waves x 12 x (min, max); then {entry, records, first terminal} per tree
+    constexpr unsigned RANGES = 0u, TAB = 2048u;                    // 16 waves' + the block's 12 x (min, max); then {entry, records, first terminal} per tree
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *coarse = (float *)smem;
     const int nw = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -1174,32 +1174,29 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
         if (lane < 2 * P) *(int *)(smem + RANGES + (unsigned)(wave * 2 * P + lane) * 4u) = mine;
     }
     __syncthreads();
-    // ranges of waves [w0, w1) merged, wave-uniform
-    auto ranges = [&](int w0, int w1, int (&lo_)[P], int (&hi_)[P]) {
-#pragma unroll
-        for (int v = 0; v < P; ++v) {
-            int a = 0x7fffffff, b = -1;
-            if (v < p && prefix && w0 + lane < w1) {
-                a = *(const int *)(smem + RANGES + (unsigned)((w0 + lane) * 2 * P + 2 * v) * 4u);
-                b = *(const int *)(smem + RANGES + (unsigned)((w0 + lane) * 2 * P + 2 * v + 1) * 4u);
-            }
-#pragma unroll
-            for (int q = 32; q > 0; q >>= 1) { a = min(a, __shfl_xor(a, q)); b = max(b, __shfl_xor(b, q)); }
-            lo_[v] = __builtin_amdgcn_readfirstlane(a); hi_[v] = __builtin_amdgcn_readfirstlane(b);
+    // the block's ranges: the waves' merged (behind theirs in the table)
+    constexpr unsigned BRANGES = RANGES + 16u * 2u * P * 4u;
+    if (threadIdx.x < 2 * P) {
+        int val = lane & 1 ? -1 : 0x7fffffff;
+        for (int w = 0; w < nw; ++w) {
+            const int x = *(const int *)(smem + RANGES + (unsigned)(w * 2 * P + lane) * 4u);
+            val = lane & 1 ? max(val, x) : min(val, x);
         }
-    };
-    // lane = tree: descend from `state` while the split falls the same way for every rank in [lo, hi] of its predictor
-    auto descend = [&](const int (&lo_)[P], const int (&hi_)[P], bool walking, int cb, unsigned D, unsigned &state, unsigned &plen) {
+        *(int *)(smem + BRANGES + (unsigned)lane * 4u) = val;
+    }
+    __syncthreads();
+    // lane = tree: descend from `state` while the split falls the same way for every rank in [lo, hi] of its predictor -- the
+    // ranges table at LDS byte address rbase (one ds_read_b64 a level: kept in registers, the compiler indexes them through scratch)
+    auto descend = [&](unsigned rbase, bool walking, int cb, unsigned D, unsigned &state, unsigned &plen) {
         walking = walking && state < D;
         while (__builtin_amdgcn_ballot_w64(walking)) {
             if (walking) {
                 const uint2 rec = gnodes[cb + (int)(state >> 3)];
-                const int j = (int)(rec.x >> 8), v = (int)(rec.x & 0xFFu) / (4 * R);
-                int lo = lo_[0], hi = hi_[0];
-#pragma unroll
-                for (int q = 1; q < P; ++q) if (q < p && v == q) { lo = lo_[q]; hi = hi_[q]; }
-                if (lo > j) { state = rec.y >> 16; ++plen; }
-                else if (hi <= j) { state = rec.y & 0xFFFFu; ++plen; }
+                const int j = (int)(rec.x >> 8);
+                const unsigned v = (rec.x & 0xFFu) / (4 * R);
+                const int2 r = *(const int2 *)(smem + rbase + v * 8u);
+                if (r.x > j) { state = rec.y >> 16; ++plen; }
+                else if (r.y <= j) { state = rec.y & 0xFFFFu; ++plen; }
                 else walking = false;
                 if (state >= D) walking = false;
             }
@@ -1208,14 +1205,12 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
     const int nbatch = (n_trees + 63) >> 6;
     [[maybe_unused]] const unsigned long long st_t1 = CBS_CLOCK();
     {   // 1. the block's entries
-        int lo_[P], hi_[P];
-        ranges(0, nw, lo_, hi_);
         for (int b = wave; b < nbatch; b += nw) {
             const int t = b * 64 + lane, tl = min(t, n_trees - 1);
             const int cb = coff[tl];
             const unsigned D = (unsigned)(coff[tl + 1] - cb - 1) * 8u;
             unsigned state = 0u, plen = 0u;
-            if (prefix) descend(lo_, hi_, t < n_trees, cb, D, state, plen);
+            if (prefix) descend(BRANGES, t < n_trees, cb, D, state, plen);
             // the subtree below the entry: n split records from `state` on and n + 1 terminals from lf on; a terminal entry: itself
             const int2 sub = (t < n_trees && state < D) ? *(const int2 *)(csub + 2 * (cb + (int)(state >> 3))) : make_int2(0, (int)(state - D));
             if (t < n_trees) *(uint4 *)(smem + TAB + (unsigned)t * 16u) = make_uint4(state | (plen << 16), (unsigned)sub.x, (unsigned)sub.y, 0u);
@@ -1225,8 +1220,6 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
     [[maybe_unused]] const unsigned long long st_t2 = CBS_CLOCK();
     unsigned entry[NB], bent[NB], bsz[NB];                          // bent: the block's entry | its first terminal << 16
     {   // 2. the wave's entries
-        int lo_[P], hi_[P];
-        ranges(wave, wave + 1, lo_, hi_);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             entry[b] = 0u; bent[b] = 0u; bsz[b] = 0u;
@@ -1237,7 +1230,7 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
                 const unsigned D = (unsigned)(coff[tl + 1] - cb - 1) * 8u;
                 unsigned state = e.x & 0xFFFFu, plen = e.x >> 16;
                 bent[b] = state | (e.z << 16); bsz[b] = e.y;
-                if (prefix) descend(lo_, hi_, t < n_trees, cb, D, state, plen);
+                if (prefix) descend(RANGES + (unsigned)wave * 2u * P * 4u, t < n_trees, cb, D, state, plen);
                 entry[b] = state | (plen << 16);
 #ifdef RF_CBS_STATS
                 {   // the subtree below the WAVE's entry

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the evidence set for profiles/ (run on the GPU box through gpurun; results land in gpurun_out/r06_final/, copied to profiles/r06_*)
-#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc]
+#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc|fitpmc|forest|cfg5]
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06_final
 mkdir -p $O
@@ -78,4 +78,17 @@ if [ "$PART" = all ] || [ "$PART" = fitpmc ]; then      # MFMA counters of the l
     done
     python tools/r06_fit_pmc_summary.py $n /tmp/fit_pmc_${n}_*.csv > $O/fit_gcv_n${n}_mfma_pmc.json; cat $O/fit_gcv_n${n}_mfma_pmc.json
   done
+fi
+if [ "$PART" = all ] || [ "$PART" = forest ]; then      # cfg5's forest: the block-subtree kernel against the whole-tree compact kernel, and what it does per block
+  timeout 1100 python tools/r06_forest_big.py 60 20000 2>&1 | grep -v "^/opt" > $O/forest_big.txt; cat $O/forest_big.txt
+  if [ -f machisplin_amd/libmhs_cbs_stats.so ]; then      # built by hand: forest.hip with -DRF_CBS_STATS (tools/README.md)
+    MHS_LIB=machisplin_amd/libmhs_cbs_stats.so timeout 1100 python tools/r06_forest_stats.py 60 20000 2>&1 | grep -v "^/opt" > $O/forest_cbs_stats.txt; tail -5 $O/forest_cbs_stats.txt
+  fi
+  ( cd /tmp && rm -rf /tmp/kfo && MHS_BENCH_SKIP_F64=1 MHS_BENCH_SKIP_TILED=1 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kfo -o cfg5 -- python $GRAFT_REPO_ROOT/bench.py --workload cfg5 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/kfo.json 2>/tmp/kfo.log )
+  find /tmp/kfo -name "*kernel_stats.csv" -exec cp {} $O/cfg5_rocprofv3_kernel_stats.csv \;
+  head -6 $O/cfg5_rocprofv3_kernel_stats.csv | cut -c1-160
+fi
+if [ "$PART" = cfg5 ]; then
+  MHS_BENCH_SKIP_F64=1 timeout 1800 python bench.py --workload cfg5 --steps 1 --warmup 1 > $O/bench_cfg5_n1.json 2>/dev/null
+  summ $O/bench_cfg5_n1.json
 fi
