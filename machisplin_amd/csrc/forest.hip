@@ -1026,6 +1026,8 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
 #pragma unroll
         for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
         auto level = [&]() {
+            // (one walk after the other, as the compiler lays it out: issuing the four walks' reads side by side -- as the batched
+            // walk of rf_walk_cbs_kernel does -- measured 6 % SLOWER here, where 15 waves walk ~20 levels a tree and the LDS pipe is the bound)
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 const uint2v nd = lds_u2(min(node[c], D));
@@ -1306,6 +1308,8 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
 #pragma unroll
             for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
             auto level = [&]() {
+                // (one walk after the other, as the compiler lays it out: issuing the four walks' reads side by side -- as the batched
+                // walk of rf_walk_cbs_kernel does -- measured 6 % SLOWER here, where 15 waves walk ~20 levels a tree and the LDS pipe is the bound)
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
                     const uint2v nd = lds_u2(min(node[c], D));
@@ -1472,15 +1476,21 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
 #pragma unroll
                 for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
                 auto level = [&]() {
+                    // (three passes: the compiler keeps the asm statements in order and would otherwise wait for each walk's two
+                    // reads before it issues the next walk's)
+                    uint2v nd[R];
+                    unsigned k[R];
+#pragma unroll
+                    for (int c = 0; c < R; ++c) nd[c] = lds_u2(min(node[c], Dz) + delta);
+#pragma unroll
+                    for (int c = 0; c < R; ++c) k[c] = lds_u32(lane_base + (nd[c].x & 0xFFu) + c * 4);
 #pragma unroll
                     for (int c = 0; c < R; ++c) {
-                        const uint2v nd = lds_u2(min(node[c], Dz) + delta);
-                        const unsigned k = lds_u32(lane_base + (nd.x & 0xFFu) + c * 4);
                         unsigned child;
                         asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\t"
                             "s_nop 1\n\t"
                             "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-                            : "=v"(child) : "v"(k), "v"(nd.x), "v"(nd.y) : "vcc");
+                            : "=v"(child) : "v"(k[c]), "v"(nd[c].x), "v"(nd[c].y) : "vcc");
                         node[c] = max(child, node[c]);
                     }
                 };
