@@ -1353,13 +1353,13 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
         }
         return;
     }
-    // Per tree of a batch, wave-uniform: where its ranges go.  Records: global words [gr, gr + n) + one word that is stored as
+    // Per tree of a batch, lane = tree: where its ranges go.  Records: global words [gr, gr + n) + one word that is stored as
     // zeros (the zero record) -> LDS slots [sr, sr + n]; predictions: global words [gv, gv + m) -> slots [sv, sv + m).  A range sits
     // at the parity of its global word index, so it travels in 16-byte units (ragged ends: the valid half alone).
-    struct Place { unsigned n, a, gr, gv, m, sr, sv, ur, uv; };
+    struct Place { unsigned gr, m, sr, sv, ur, uv; };
     auto place = [&](unsigned n, unsigned a, unsigned base, unsigned cb, unsigned gv) {
         Place P;
-        P.n = n; P.a = a; P.gr = cb + (a >> 3); P.gv = gv;
+        P.gr = cb + (a >> 3);
         P.m = 2u * n + 4u <= cap ? (n ? n + 1u : 1u) : 0u;
         P.sr = base + ((base ^ P.gr) & 1u);
         P.sv = n ? P.sr + n + 1u : base;
@@ -1393,35 +1393,43 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
             return l0 + max(1, (int)__builtin_popcountll(fit));
         };
         // this wave's share of a batch's 16-byte units (the batch's ranges end to end, 256 units a wave, 4 a lane): requested
-        // here, parked in LDS by park() -- a batch is fetched while the batch before it is walked
+        // here, parked in LDS by park() -- a batch is fetched while the batch before it is walked.  Only the trees whose units
+        // overlap the wave's 256 are looked at (lane = tree: a prefix sum of the units).
         uint4 w[4];
         unsigned waddr[4], wflag = 0u;                              // per unit: LDS byte address; bits 4q..4q+3: lo, hi valid, lo, hi zero
         auto fetch = [&](int l0, int l1, unsigned basev) {
             const unsigned x0 = 256u * (unsigned)wave;
-            unsigned ustart = 0u, wsrc[4] = {0u, 0u, 0u, 0u};      // the unit's index in its array; bit 31: the predictions
-            wflag = 0u;
-            for (int l = l0; l < l1; ++l) {
-                const Place P = place((unsigned)__builtin_amdgcn_readlane((int)ncur, l), (unsigned)__builtin_amdgcn_readlane((int)acur, l),
-                                      (unsigned)__builtin_amdgcn_readlane((int)basev, l), (unsigned)__builtin_amdgcn_readlane(cbv, l),
-                                      (unsigned)__builtin_amdgcn_readlane(ov, l));
-                const unsigned un = P.ur + P.uv;
-                if (ustart + un > x0 && ustart < x0 + 256u) {
+            const Place V = place(ncur, acur, basev, (unsigned)cbv, (unsigned)ov);
+            const unsigned unv = lane >= l0 && lane < l1 ? V.ur + V.uv : 0u;
+            unsigned uend = unv;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned rel = x0 + (unsigned)(q * 64 + lane) - ustart;
-                        if (rel < un) {
-                            const bool isrec = rel < P.ur;
-                            const unsigned g0 = isrec ? P.gr : P.gv, cnt = isrec ? P.n + 1u : P.m, s0 = isrec ? P.sr : P.sv;
-                            const unsigned u = (g0 >> 1) + (isrec ? rel : rel - P.ur), w0 = 2u * u;
-                            const unsigned lo = w0 >= g0 && w0 < g0 + cnt, hi = w0 + 1u >= g0 && w0 + 1u < g0 + cnt;
-                            const unsigned zlo = isrec && w0 == P.gr + P.n, zhi = isrec && w0 + 1u == P.gr + P.n;
-                            waddr[q] = (s0 + w0 - g0) * 8u;
-                            wflag |= (lo | (hi << 1) | (zlo << 2) | (zhi << 3)) << (4 * q);
-                            wsrc[q] = u | (isrec ? 0u : 0x80000000u);
-                        }
+            for (int q = 1; q < 64; q <<= 1) { const unsigned up = (unsigned)__shfl_up((int)uend, q); if (lane >= q) uend += up; }
+            const unsigned long long mine = __builtin_amdgcn_ballot_w64(unv && uend > x0 && uend - unv < x0 + 256u);
+            unsigned wsrc[4] = {0u, 0u, 0u, 0u};                   // the unit's index in its array; bit 31: the predictions
+            wflag = 0u;
+            for (unsigned long long left = mine; left; left &= left - 1ull) {
+                const int l = __builtin_ctzll(left);
+                const unsigned n = (unsigned)__builtin_amdgcn_readlane((int)ncur, l);
+                const unsigned gr = (unsigned)__builtin_amdgcn_readlane((int)V.gr, l), gv = (unsigned)__builtin_amdgcn_readlane(ov, l);
+                const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)V.m, l);
+                const unsigned sr = (unsigned)__builtin_amdgcn_readlane((int)V.sr, l), sv = (unsigned)__builtin_amdgcn_readlane((int)V.sv, l);
+                const unsigned ur = (unsigned)__builtin_amdgcn_readlane((int)V.ur, l);
+                const unsigned un = (unsigned)__builtin_amdgcn_readlane((int)unv, l);
+                const unsigned ustart = (unsigned)__builtin_amdgcn_readlane((int)uend, l) - un;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned rel = x0 + (unsigned)(q * 64 + lane) - ustart;
+                    if (rel < un) {
+                        const bool isrec = rel < ur;
+                        const unsigned g0 = isrec ? gr : gv, cnt = isrec ? n + 1u : m, s0 = isrec ? sr : sv;
+                        const unsigned u = (g0 >> 1) + (isrec ? rel : rel - ur), w0 = 2u * u;
+                        const unsigned lo = w0 >= g0 && w0 < g0 + cnt, hi = w0 + 1u >= g0 && w0 + 1u < g0 + cnt;
+                        const unsigned zlo = isrec && w0 == gr + n, zhi = isrec && w0 + 1u == gr + n;
+                        waddr[q] = (s0 + w0 - g0) * 8u;
+                        wflag |= (lo | (hi << 1) | (zlo << 2) | (zhi << 3)) << (4 * q);
+                        wsrc[q] = u | (isrec ? 0u : 0x80000000u);
                     }
                 }
-                ustart += un;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)                             // all requests together, nothing waits for them here
@@ -1456,28 +1464,43 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
             [[maybe_unused]] const unsigned long long st_b = CBS_CLOCK();
             st_stage += st_b - st_a;
             if (wave == 0 && lane == 0) CBS_ADD(2, 1);
+            // the batch's trees, lane = tree: the walk's three scalars -- rec = LDS[min(state, Dz) + delta], a terminal code's
+            // prediction at LDS[vbase + 8 code] -- and, where the wave enters the tree at a terminal (every cell of the wave gets
+            // that prediction: three (wave, tree) pairs in four on cfg5's planes), the prediction itself
+            const Place V = place(ncur, acur, basev, (unsigned)cbv, (unsigned)ov);
+            const unsigned Dzv = ncur ? acur + 8u * ncur : 0u, deltav = 8u * V.sr - acur, vbasev = 8u * V.sv - 8u * (Dv + fcur);
+            const bool inb = lane >= l0 && lane < l1;
+            const bool quick = inb && V.m && (ecur & 0xFFFFu) >= Dzv;
+            double tval = 0.0;
+            if (quick) tval = lds_f64(vbasev + 8u * (ecur & 0xFFFFu));
+            const unsigned long long quickm = __builtin_amdgcn_ballot_w64(quick);
+            const unsigned long long bigm = __builtin_amdgcn_ballot_w64(inb && !V.m);
             int l2 = l1;
             if (l1 < lend) { l2 = plan(l1, basen); fetch(l1, l2, basen); }      // the next batch travels while this one is walked
             // (two copies of the walk: the one for batches whose predictions are all in LDS holds no global load, so nothing in it
             // waits for the batch that is on its way)
             auto walk = [&](int l, auto all_in_lds) {
+                if ((quickm >> l) & 1ull) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(tval);
+                    const unsigned vlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, l);
+                    const unsigned vhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), l);
+                    const double v = __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
+                    st_term += 1;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { acc[c] = acc[c] + pending[c]; pending[c] = v; }
+                    return;
+                }
                 const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ecur, l);
-                const Place P = place((unsigned)__builtin_amdgcn_readlane((int)ncur, l), (unsigned)__builtin_amdgcn_readlane((int)acur, l),
-                                      (unsigned)__builtin_amdgcn_readlane((int)basev, l), (unsigned)__builtin_amdgcn_readlane(cbv, l),
-                                      (unsigned)__builtin_amdgcn_readlane(ov, l));
-                const unsigned D = (unsigned)__builtin_amdgcn_readlane((int)Dv, l);
-                const unsigned lf = (unsigned)__builtin_amdgcn_readlane((int)fcur, l);
+                const unsigned Dz = (unsigned)__builtin_amdgcn_readlane((int)Dzv, l), delta = (unsigned)__builtin_amdgcn_readlane((int)deltav, l);
+                const unsigned vbase = (unsigned)__builtin_amdgcn_readlane((int)vbasev, l);
                 const int levels = __builtin_amdgcn_readlane(levv, l), shallow = __builtin_amdgcn_readlane(shv, l);
-                const unsigned Dz = P.n ? P.a + 8u * P.n : 0u, delta = 8u * P.sr - P.a;
-                // a terminal code c = D + the terminal's number: its prediction sits at LDS word sv + (number - lf)
-                const unsigned vbase = 8u * P.sv - 8u * (D + lf);
                 const int plen = (int)(ent >> 16);
                 const int lev = (ent & 0xFFFFu) >= Dz ? 0 : levels - plen, shal = min(max(shallow - plen, 0), lev);
 #pragma unroll
                 for (int c = 0; c < R; ++c) node[c] = ent & 0xFFFFu;
+                // the R walks' reads side by side (three passes: the compiler keeps the asm statements in order and would
+                // otherwise wait for each walk's two reads before it issues the next walk's)
                 auto level = [&]() {
-                    // (three passes: the compiler keeps the asm statements in order and would otherwise wait for each walk's two
-                    // reads before it issues the next walk's)
                     uint2v nd[R];
                     unsigned k[R];
 #pragma unroll
@@ -1501,14 +1524,19 @@ __global__ __launch_bounds__(1024) void rf_walk_cbs_kernel(const uint2 *__restri
                     if (!__builtin_amdgcn_ballot_w64(lowest < Dz)) break;
                     level(); ++st_levels;
                 }
+                const bool in_lds = decltype(all_in_lds)::value || !((bigm >> l) & 1ull);
+                // a terminal code c = D + the terminal's number: its prediction sits at LDS word sv + (number - lf)
+                // (predictions left in global memory: glval[gv + (number - lf)], number = code - D)
+                const unsigned gofs = in_lds ? 0u : (unsigned)__builtin_amdgcn_readlane(ov, l) - (unsigned)__builtin_amdgcn_readlane((int)Dv, l)
+                                                    - (unsigned)__builtin_amdgcn_readlane((int)fcur, l);
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
                     acc[c] = acc[c] + pending[c];
-                    if (decltype(all_in_lds)::value || P.m) pending[c] = lds_f64(vbase + 8u * node[c]);
-                    else pending[c] = glval[P.gv + (node[c] - D - lf)];
+                    if (in_lds) pending[c] = lds_f64(vbase + 8u * node[c]);
+                    else pending[c] = glval[gofs + node[c]];
                 }
             };
-            if (!__builtin_amdgcn_ballot_w64(lane >= l0 && lane < l1 && ncur && 2u * ncur + 4u > cap))
+            if (!bigm)
                 for (int l = l0; l < l1; ++l) walk(l, std::true_type());
             else
                 for (int l = l0; l < l1; ++l) walk(l, std::false_type());
