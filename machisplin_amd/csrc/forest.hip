@@ -1075,25 +1075,32 @@ __global__ __launch_bounds__(1024) void rf_walk_compact_kernel(const uint2 *__re
 
 
 // BLOCK-SUBTREE form of the compact walk (round 6): the trees of a 20 000-station forest (~6 000 split records, 48 KB each)
-// no longer travel whole.  rf_walk_compact_kernel copies every tree into LDS for every block of 3 840 cells -- 2.5 TB past the
-// L2 per 4e8 cells and two barriers per tree, with every wave waiting for the block's deepest walk -- yet a block's cells are
-// neighbours and reach a sliver of each tree.  Here a block is 80 x 48 cells (TW x TH wave tiles of 16 x 16, a lane's 4 walks
-// on adjacent rows) and, after the rank keys are parked:
-//   1. BLOCK PREFIX, lane = tree: waves 0..7 descend 64 trees each from the root (records from global memory) for as long as
-//      the split falls the same way for the block's whole [min, max] rank of its predictor.  Where that ends is the block's
-//      entry into the tree: a terminal (every cell of the block gets that leaf: nothing to stage, nothing to walk) or a split
-//      record a, whose subtree is the n = csub[a] consecutive records [a, a + n) (nodes are numbered in pre-order).
-//   2. WAVE PREFIX: every wave goes on from the block's entries with its own, narrower ranges (as rf_prefix_entries_compact
-//      does from the root) -- its walks start there.
-//   3. The trees are taken in order, as many at a time as their subtrees (n + 1 records each: an all-zero record follows)
-//      fit in the LDS region beside the keys (64-aligned groups, lane = tree: one prefix sum places them).  The waves copy the
-//      subtrees in (64 records a turn, turns dealt round robin), meet at a barrier, and every wave walks the batch's trees
-//      by itself, in tree order -- no barrier, no waiting for another wave's deepest leaf -- until the next batch.
+// no longer travel whole.  rf_walk_compact_kernel copies every tree into LDS for every block of 3 840 cells -- two barriers a
+// tree, every wave waiting for the block's deepest walk, and a cost that is linear in the trees whether the forest fits the L2
+// or not (tools/r06_forest_big.py: the CU's own global -> LDS path is the limit, so the bytes staged are what to cut) -- yet a
+// block's cells are neighbours and reach a sliver of each tree.  Here a block is 80 x 48 cells (TW x TH wave tiles of 16 x 16, a
+// lane's 4 walks on adjacent rows) and, after the rank keys are parked:
+//   1. BLOCK PREFIX, lane = tree: waves 0..7 descend 64 trees each from the root (records from global memory, the ranges from a
+//      table in LDS) for as long as the split falls the same way for the block's whole [min, max] rank of its predictor.  Where
+//      that ends is the block's entry into the tree: a terminal (its prediction is all the block needs) or a split record a,
+//      below which lie -- nodes are numbered in pre-order -- the n = csub[a] consecutive records [a, a + n) and the n + 1
+//      consecutive terminals from csub's second word on (the compact records number terminals in node order; rf_clval holds
+//      their predictions in that order).
+//   2. WAVE PREFIX: every wave goes on from the block's entries with its own, narrower ranges -- its walks start there.
+//   3. The trees are taken in order, as many per BATCH as their ranges fit the LDS region beside the keys (64-aligned groups,
+//      lane = tree: one prefix sum places them, another deals the batch's 16-byte units out, 256 to a wave).  A batch is
+//      requested (registers) before the batch ahead of it is walked and parked in LDS between two barriers after; every wave then
+//      walks the batch's trees by itself, in tree order -- no barrier, no waiting for another wave's deepest leaf.  A (wave, tree)
+//      pair entered at a terminal -- three in four on cfg5's planes -- costs two readlanes: the predictions of such pairs are
+//      read lane = tree, once per batch.
 // A staged subtree keeps its records as they are: child fields are byte addresses relative to the TREE, so a walk reads
 //       rec = LDS[min(state, Dz) + delta],   Dz = a + 8 n (the zero record),  delta = 8 * slot - a
-// and otherwise steps as the compact kernel does (state = max(child, state); terminal codes are >= D >= Dz).  A tree too rough
-// for its block (or MHS_RF_PLAIN) is a batch of its own, whole.  Same leaf for every cell, predictions added in tree order:
-// the planes are those of every other forest kernel, bit for bit (test_forest_walk_kernels_equal_each_other).
+// and otherwise steps as the compact kernel does (state = max(child, state); terminal codes are >= D >= Dz); a terminal code's
+// prediction is LDS[vbase + 8 code].  A subtree too large to sit in LDS with its predictions (a whole tree) leaves them in
+// global memory; a block whose subtrees average more than rough_slots LDS slots (noisy rasters; MHS_RF_PLAIN) takes the
+// compact kernel's whole-tree loop instead, inside this kernel.  Same leaf for every cell, predictions added in tree order: the
+// planes are those of every other forest kernel, bit for bit (test_forest_walk_kernels_equal_each_other_and_the_node_walk,
+// test_forest_in_the_compact_form_equals_the_node_walk).  cfg5's step: 1 137 -> 455 ms for 4e8 cells and 500 trees.
 constexpr int RF_CBS_BATCHES = 8;                                   // x 64 trees, held lane = tree in registers
 #ifdef RF_CBS_STATS
 __device__ unsigned long long g_cbs_stats[16];
