@@ -2,6 +2,8 @@
 these sizes): two independent HIP implementations of the same member must agree bit for bit,
 windows must tile the full-grid result exactly, the fitted spline must satisfy its normal
 equations, and sampled rows must match the C oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -230,6 +232,15 @@ def test_cfg5_five_covariate_ensemble_rows(hip):
         b = hip.predict(stack, mods[k], window=(r0 - 1000, r1 + 24, 0, side))
         if k == 4:
             assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b[1000:1000 + (r1 - r0)]))
+            # ... and the block-subtree kernel (the default for these trees) the bits of the whole-tree kernel and of the node walk
+            for env in ({"MHS_RF_KERNEL": "compact"}, {"MHS_TREES_GENERIC": "1"}):
+                os.environ.update(env)
+                try:
+                    c = hip.predict(stack, mods[k], window=(r0 - 1000, r1 + 24, 0, side))
+                finally:
+                    for e in env:
+                        del os.environ[e]
+                assert torch.equal(torch.isnan(b), torch.isnan(c)) and torch.equal(torch.nan_to_num(b), torch.nan_to_num(c)), env
         else:      # gbm: whole 16-row tiles (anchored to the grid; round 4: 16 x 16 cells) hold the same bits, the window's clipped edge tiles the same to rounding
             lo, hi = -r0 % 16, (r1 - r0) - r1 % 16
             assert hi - lo >= 16
