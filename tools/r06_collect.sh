@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the evidence set for profiles/ (run on the GPU box through gpurun; results land in gpurun_out/r06_final/, copied to profiles/r06_*)
-#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc|fitpmc|forest|cfg5]
+#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc|fitpmc|forest|forestpmc|cfg5]
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06_final
 mkdir -p $O
@@ -91,4 +91,10 @@ fi
 if [ "$PART" = cfg5 ]; then
   MHS_BENCH_SKIP_F64=1 timeout 1800 python bench.py --workload cfg5 --steps 1 --warmup 1 > $O/bench_cfg5_n1.json 2>/dev/null
   summ $O/bench_cfg5_n1.json
+fi
+if [ "$PART" = forestpmc ]; then      # memory-side bytes of the two big-tree forest kernels (a --pmc pass of its own)
+  ( cd /tmp && rm -rf /tmp/kfp && timeout 2000 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/kfp -o fb -- python $GRAFT_REPO_ROOT/tools/r06_forest_big.py 60 20000 > /tmp/kfp.log 2>&1 )
+  tail -3 /tmp/kfp.log
+  F=$(find /tmp/kfp -name "*counter_collection.csv" | head -1)
+  python tools/r06_forest_pmc_summary.py $F 60 400000000 > $O/forest_fetch_size.json; head -40 $O/forest_fetch_size.json
 fi
