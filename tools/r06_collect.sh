@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the evidence set for profiles/ (run on the GPU box through gpurun; results land in gpurun_out/r06_final/, copied to profiles/r06_*)
-#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc|fitpmc|forest|forestpmc|cfg5]
+#   bash tools/r06_collect.sh [all|gputest|bench|benchmore|inlib|fit|pmc|fitpmc|forest|forestpmc|memberspmc|cfg5]
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06_final
 mkdir -p $O
@@ -97,4 +97,9 @@ if [ "$PART" = forestpmc ]; then      # memory-side bytes of the two big-tree fo
   tail -3 /tmp/kfp.log
   F=$(find /tmp/kfp -name "*counter_collection.csv" | head -1)
   python tools/r06_forest_pmc_summary.py $F 60 400000000 > $O/forest_fetch_size.json; head -40 $O/forest_fetch_size.json
+fi
+if [ "$PART" = memberspmc ]; then      # PMC passes on the member kernels of THIS build (bench.py quotes counters only for the build it runs): 8d planes, 1e8 cells
+  bash tools/r04_members_pmc.sh 10000 brvs 8d > $O/members_pmc_8d.log 2>&1; tail -5 $O/members_pmc_8d.log
+  cp gpurun_out/r4/pmc_8d/summary.json profiles/r06_8d_members_pmc_summary.json; cp gpurun_out/r4/pmc_8d/units.json profiles/r06_8d_members_pmc_units.json
+  python tools/r04_pmc_derive.py r06_8d > /dev/null; cp profiles/r06_8d_members_pmc_*.json $O/; ls -la $O/r06_8d_members_pmc_*.json
 fi
