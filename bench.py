@@ -52,8 +52,8 @@ def member_kernel_source_hash():
 
 
 def pmc_derived():
-    """profiles/r04_8d_members_pmc_derived.json (tools/r04_members_pmc.sh + tools/r04_pmc_derive.py; round 3's file if this
-    round's is absent): per-unit instruction counts and pipe utilisations of the member kernels from rocprofv3 --pmc passes
+    """profiles/r06_8d_members_pmc_derived.json (tools/r06_collect.sh memberspmc = tools/r04_members_pmc.sh + tools/r04_pmc_derive.py;
+    an earlier round's file if its hash still matches): per-unit instruction counts and pipe utilisations of the member kernels from rocprofv3 --pmc passes
     of a torch-free driver over cfg3's own 10 000 x 10 000 SURVEY-8d planes.  Every figure the roofline rows take from it is
     a property of THOSE rasters and of that run, not of the timed steps; the rows say so ("pmc_source")."""
     for name in PMC_FILES:
@@ -76,8 +76,10 @@ def forest_traffic(n_nodes, cells, layers):
     for the default kernel and for the subtree-staging kernel (MHS_RF_KERNEL=sub) -- round-4 verdict item 8: a first-class field."""
     alg = 4.0 * layers + 8.0 + 8.0 * n_nodes / cells
     out = {"algorithmic_bytes_per_cell": alg, "what": "float32 covariate planes read once + float64 plane written once + 8-byte node records once"}
-    for key, name in (("default_kernel", "r05_8d_members_pmc_derived.json"), ("subtree_kernel", "r05_8d_rfsub_members_pmc_derived.json")):
+    for key, names in (("default_kernel", ("r06_8d_members_pmc_derived.json", "r05_8d_members_pmc_derived.json")),
+                       ("subtree_kernel", ("r05_8d_rfsub_members_pmc_derived.json",))):
         try:
+            name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = next(k for k in d if isinstance(d[k], dict) and "rf_" in k)
             b = d[k]["hbm_bytes_per_cell_fetch_x2_plus_write"]
