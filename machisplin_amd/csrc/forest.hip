@@ -1881,6 +1881,15 @@ int launch_forest(const mhs_model *m, const StackDev &s, const PredGeom &g, cons
         *launched = true;
         return MHS_OK;
     }
+    // trees of 3 201 .. 4 095 nodes fit neither three times in LDS (the loader-wave kernel) nor need the compact form, and used
+    // to take the double-buffered kernel: the block-subtree kernel is 1.6 x faster there on the 8d planes (124 -> 77 ms per 1e8
+    // cells and 500 trees), 1.3 x with 1 % noise, 0.9 x with 10 % (tools/r06_forest_small.py 8000 6000)
+    int ld_l2 = 0, ld_stride = 0;
+    if (pick == RF_PICK_AUTO && !rf_walk_ld_config(m, &ld_l2, &ld_stride) && rf_cbs_config(m, g, &cnt, &ctw, &cth, &cregion)) {
+        if (int rc = launch_rf_cbs(m, s, g, *grid, weight, accumulate, out, st, cnt, ctw, cth, cregion)) return rc;
+        *launched = true;
+        return MHS_OK;
+    }
     if (pick != RF_PICK_COMPACT)
         if (int rc = launch_rf_walk(m, s, g, *grid, weight, accumulate, out, st, total, launched)) return rc;
     if (*launched) return MHS_OK;

@@ -427,6 +427,32 @@ def test_forest_walk_kernels_equal_each_other_and_the_node_walk(hip, n, dtype, n
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
+def test_forest_with_trees_between_the_loader_wave_and_the_compact_forms(hip, monkeypatch):
+    """Trees of 3 201 .. 4 095 nodes (6 000 stations): three of them do not fit LDS (no loader-wave kernel), and the block-subtree
+    kernel takes them by default (round 6; the double-buffered kernel before).  Default, double-buffered, whole-tree compact and
+    the node walk: the same bits; the oracle to its tolerance."""
+    import torch
+    from machisplin_amd import synth
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=123, ncol=257, dtype="f32", nodata_frac=0.01, n=6000, gbm_trees=2, rf_trees=1)
+    prm = synth.rf_params(Xs, ys, 9, n_trees=7)
+    nodes = np.diff(prm["tree_offsets"]).max()
+    assert 3200 < nodes <= 4095
+    m = hip.models.from_param_dict(prm)
+    fast = hip.predict(stack, m)
+    for envs in ({"MHS_RF_KERNEL": "db"}, {"MHS_RF_KERNEL": "cbs"}, {"MHS_RF_KERNEL": "compact"}, {"MHS_RF_PLAIN": "1"}, {"MHS_TREES_GENERIC": "1"}):
+        for e, v in envs.items():
+            monkeypatch.setenv(e, v)
+        other = hip.predict(stack, m)
+        for e in envs:
+            monkeypatch.delenv(e)
+        assert torch.equal(torch.isnan(fast), torch.isnan(other)), envs
+        assert torch.equal(torch.nan_to_num(fast), torch.nan_to_num(other)), envs
+    want = oe.predict(prm, X)
+    got = fast.cpu().numpy().ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= _tol(want)
+
+
 @pytest.mark.parametrize("C,n,force", [(11, 900, None), (13, 900, None), (11, 5200, "compact"), (16, 700, None)])
 def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
     """p = C + 2 >= 13 predictors (11+ covariate layers, V73:127-138 adds LONG and LAT): the wave-uniform prefix keeps the

@@ -8,14 +8,17 @@ import machisplin_amd as m
 from machisplin_amd import synth
 m.init()
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
+nst = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 g = synth.grid(side, side)
 seed = synth.BASE_SEED + 3
 planes, nodata = synth.covariates(g, 3, seed, dtype="f32")
-xy, rows, cols, uv = synth.stations(g, 5000, seed)
+xy, rows, cols, uv = synth.stations(g, nst, seed)
 cov_at = planes[:, torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64).T
 X = np.column_stack([cov_at, xy])
 y = synth.response(X, uv, seed)
-mod = m.models.from_param_dict(synth.rf_params(X, y, seed))
+prm = synth.rf_params(X, y, seed)
+print("nodes per tree up to", int(np.diff(prm["tree_offsets"]).max()), flush=True)
+mod = m.models.from_param_dict(prm)
 gen = torch.Generator(device="cuda"); gen.manual_seed(7)
 variants = [("8d planes", planes)]
 for frac in (0.01, 0.1):
@@ -38,8 +41,8 @@ def timed(stack, env):
 for name, pl in variants:
     stack = m.RasterStack(g, pl, nodata)
     t_ring, p_ring = timed(stack, {})
-    line = f"{name:18s} ld   {t_ring:7.1f} ms/1e8"
-    for label, env in (("cbs", {"MHS_RF_KERNEL": "cbs"}), ("sub", {"MHS_RF_KERNEL": "sub"}), ("compact", {"MHS_RF_KERNEL": "compact"})):
+    line = f"{name:18s} default {t_ring:7.1f} ms/1e8"
+    for label, env in (("cbs", {"MHS_RF_KERNEL": "cbs"}), ("sub", {"MHS_RF_KERNEL": "sub"}), ("db", {"MHS_RF_KERNEL": "db"}), ("compact", {"MHS_RF_KERNEL": "compact"})):
         t, pln = timed(stack, env)
         line += f" | {label} {t:7.1f} equal={bool(torch.equal(torch.nan_to_num(pln), torch.nan_to_num(p_ring)))}"
     print(line, flush=True)
