@@ -496,7 +496,7 @@ def test_forest_with_trees_larger_than_the_16_bit_lds_addresses(hip):
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", ["f32", "f64", "i16"])
 def test_forest_in_the_compact_form_equals_the_node_walk(hip, dtype):
     """Trees of ~7 000 nodes (12 000 stations): beyond the double-buffered kernel's 4 095, within the COMPACT form
     (split nodes only in LDS, terminals as codes): by default the block-subtree kernel (rf_walk_cbs_kernel: per block of 80 x 48
