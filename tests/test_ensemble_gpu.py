@@ -453,6 +453,39 @@ def test_forest_with_trees_between_the_loader_wave_and_the_compact_forms(hip, mo
     assert np.nanmax(np.abs(got - want)) <= _tol(want)
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_forest_block_subtree_kernel_on_random_shapes(hip, case, monkeypatch):
+    """rf_walk_cbs_kernel pinned (MHS_RF_KERNEL=cbs) on seeded random shapes -- 1 .. 10 covariates (p = 3 .. 12), 40 .. 5 000
+    stations (trees of a few dozen to ~3 000 nodes), 1 .. 70 trees, every plane type, 0 .. 5 % NoData, grids whose sides are no
+    multiples of the 16 x 16 wave tiles, a window inside the grid, a threshold that sends every / no block through the
+    whole-tree loop -- against the node walk, bit for bit, NA cells included."""
+    import torch
+    from machisplin_amd import synth
+    rng = np.random.default_rng(1000 + case)
+    C = int(rng.integers(1, 11))
+    n = int(rng.choice([40, 150, 700, 2500, 5000]))
+    nrow, ncol = int(rng.integers(17, 140)), int(rng.integers(20, 400))
+    n = min(n, nrow * ncol // 3)
+    dtype = ["f32", "f64", "i16"][case % 3]
+    g, stack, X, Xs, ys, params = _setup(hip, nrow=nrow, ncol=ncol, C=C, dtype=dtype, nodata_frac=float(rng.choice([0.0, 0.01, 0.05])), n=n,
+                                         seed=20 + case, gbm_trees=2, rf_trees=1)
+    prm = synth.rf_params(Xs, ys, 30 + case, n_trees=int(rng.integers(1, 71)))
+    m = hip.models.from_param_dict(prm)
+    r0, c0 = int(rng.integers(0, nrow - 16)), int(rng.integers(0, ncol - 1))
+    win = (r0, int(rng.integers(r0 + 16, nrow + 1)), c0, int(rng.integers(c0 + 1, ncol + 1)))
+    monkeypatch.setenv("MHS_TREES_GENERIC", "1")
+    want_full, want_win = hip.predict(stack, m), hip.predict(stack, m, window=win)
+    monkeypatch.delenv("MHS_TREES_GENERIC")
+    monkeypatch.setenv("MHS_RF_KERNEL", "cbs")
+    for rough in (None, "0", "1000000"):
+        if rough is not None:
+            monkeypatch.setenv("MHS_RF_CBS_ROUGH", rough)
+        for want, w in ((want_full, None), (want_win, win)):
+            got = hip.predict(stack, m, window=w)
+            assert torch.equal(torch.isnan(got), torch.isnan(want)), (case, rough, w)
+            assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (case, rough, w)
+
+
 @pytest.mark.parametrize("C,n,force", [(11, 900, None), (13, 900, None), (11, 5200, "compact"), (16, 700, None)])
 def test_forest_with_more_than_twelve_predictors(hip, C, n, force, monkeypatch):
     """p = C + 2 >= 13 predictors (11+ covariate layers, V73:127-138 adds LONG and LAT): the wave-uniform prefix keeps the
