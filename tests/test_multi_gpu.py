@@ -76,6 +76,31 @@ def test_row_bands_over_slots_equal_the_single_device_chain_bit_for_bit(hip, til
 
 
 @pytest.mark.timeout(600)
+def test_block_subtree_forest_on_slot_replicas(hip):
+    """A forest whose trees (~3 700 nodes, 6 000 stations) take rf_walk_cbs_kernel: its compact records, subtree table and
+    terminal predictions are built per slot on the model's replicas.  Two slots' plane = the one-device chain's, bit for bit."""
+    import torch
+    from machisplin_amd import multi, synth
+    multi.init_devices(1, [0])
+    g, planes, nodata, xy, X, resp, models, weights, wt_total = _workload(hip, seed=13, n=6000)
+    rf = synth.rf_params(X, resp, 13, n_trees=5)
+    assert 3200 < np.diff(rf["tree_offsets"]).max() <= 4095
+    models = [hip.models.from_param_dict(rf) if isinstance(m, hip.models.RandomForest) else m for m in models]
+    stack = hip.RasterStack(g, planes, nodata)
+    ref = hip.mltps_predict(stack, xy, resp, models, weights, wt_total, tile_edge=None)
+    torch.cuda.synchronize()
+    want = ref["final"].cpu().numpy()
+    host = planes.cpu().numpy()
+    try:
+        multi.init_devices(2, [0, 0])
+        got, info = multi.mltps_grid_multi(g, host, nodata, models, weights, wt_total, X, resp, tile_edge=None, slot0_share=0.3)
+        assert info["n_slots"] == 2
+        assert np.array_equal(got, want, equal_nan=True), np.nanmax(np.abs(got - want))
+    finally:
+        multi.init_devices(1, [0])
+
+
+@pytest.mark.timeout(600)
 def test_pred_elev_is_returned_when_the_spline_does_not_help(hip, slots4):
     """V73:925-930 across bands: a response the ensemble already explains and pure-noise residuals leave rsq.final <=
     rsq.model, and every slot hands back its pred.elev rows."""
